@@ -1,0 +1,413 @@
+/* fo_oracle.c -- CPU restatement (float64, scalar, reference loop order) of the metric sweep of
+ * Frenetix-Occlusion.  TEST INFRASTRUCTURE ONLY (see fo_oracle.h).  Not used by the product path.
+ *
+ * Loop structure follows the reference: per trajectory -> per metric -> per agent prediction -> per timestep
+ * (interface.py:216-219 -> metrics/metric.py:35-100).
+ */
+#define _GNU_SOURCE
+#include "fo_oracle.h"
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ numpy helpers */
+double fo_oracle_round3(double v) { return rint(v * 1000.0) / 1000.0; } /* np.round(v,3): rint(v*10^3)/10^3 */
+
+/* ------------------------------------------------------------------ GEOS 3.11 distance (published algorithm)
+ * algorithm/Distance.cpp pointToSegment / segmentToSegment; operation/distance/DistanceOp.cpp
+ * computeContainmentDistance + computeFacetDistance.  shapely 2.0.2 (poetry.lock:1379) bundles GEOS 3.11.x. */
+static double pt_dist(double px, double py, double qx, double qy) {
+  double dx = px - qx, dy = py - qy;
+  return sqrt(dx * dx + dy * dy);
+}
+
+static double point_to_segment(double px, double py, double ax, double ay, double bx, double by) {
+  if (ax == bx && ay == by) return pt_dist(px, py, ax, ay);
+  double len2 = (bx - ax) * (bx - ax) + (by - ay) * (by - ay);
+  double r = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / len2;
+  if (r <= 0.0) return pt_dist(px, py, ax, ay);
+  if (r >= 1.0) return pt_dist(px, py, bx, by);
+  double s = ((ay - py) * (bx - ax) - (ax - px) * (by - ay)) / len2;
+  return fabs(s) * sqrt(len2);
+}
+
+static int env_intersects(double ax, double ay, double bx, double by, double cx, double cy, double dx, double dy) {
+  double minq = fmin(cx, dx), maxq = fmax(cx, dx), minp = fmin(ax, bx), maxp = fmax(ax, bx);
+  if (minp > maxq) return 0;
+  if (maxp < minq) return 0;
+  minq = fmin(cy, dy); maxq = fmax(cy, dy); minp = fmin(ay, by); maxp = fmax(ay, by);
+  if (minp > maxq) return 0;
+  if (maxp < minq) return 0;
+  return 1;
+}
+
+static double segment_to_segment(double ax, double ay, double bx, double by, double cx, double cy, double dx, double dy) {
+  if (ax == bx && ay == by) return point_to_segment(ax, ay, cx, cy, dx, dy);
+  if (cx == dx && cy == dy) return point_to_segment(dx, dy, ax, ay, bx, by);
+  int no_intersection = 0;
+  if (!env_intersects(ax, ay, bx, by, cx, cy, dx, dy)) {
+    no_intersection = 1;
+  } else {
+    double denom = (bx - ax) * (dy - cy) - (by - ay) * (dx - cx);
+    if (denom == 0.0) {
+      no_intersection = 1;
+    } else {
+      double r_num = (ay - cy) * (dx - cx) - (ax - cx) * (dy - cy);
+      double s_num = (ay - cy) * (bx - ax) - (ax - cx) * (by - ay);
+      double s = s_num / denom, r = r_num / denom;
+      if (r < 0.0 || r > 1.0 || s < 0.0 || s > 1.0) no_intersection = 1;
+    }
+  }
+  if (no_intersection) {
+    double d = point_to_segment(ax, ay, cx, cy, dx, dy);
+    d = fmin(d, point_to_segment(bx, by, cx, cy, dx, dy));
+    d = fmin(d, point_to_segment(cx, cy, ax, ay, bx, by));
+    d = fmin(d, point_to_segment(dx, dy, ax, ay, bx, by));
+    return d;
+  }
+  return 0.0;
+}
+
+/* point not EXTERIOR to a convex quad (boundary counts as inside, DistanceOp::computeInside) */
+static int point_in_or_on_quad(double px, double py, const double *q) {
+  int pos = 0, neg = 0;
+  for (int i = 0; i < 4; ++i) {
+    int j = (i + 1) & 3;
+    double cr = (q[2 * j] - q[2 * i]) * (py - q[2 * i + 1]) - (q[2 * j + 1] - q[2 * i + 1]) * (px - q[2 * i]);
+    if (cr > 0.0) pos = 1;
+    if (cr < 0.0) neg = 1;
+  }
+  return !(pos && neg);
+}
+
+double fo_oracle_quad_distance(const double *qa, const double *qb) {
+  /* containment: first vertex of one inside the other -> 0 */
+  if (point_in_or_on_quad(qa[0], qa[1], qb)) return 0.0;
+  if (point_in_or_on_quad(qb[0], qb[1], qa)) return 0.0;
+  double best = INFINITY;
+  for (int i = 0; i < 4; ++i) {
+    int i2 = (i + 1) & 3;
+    for (int j = 0; j < 4; ++j) {
+      int j2 = (j + 1) & 3;
+      double d = segment_to_segment(qa[2 * i], qa[2 * i + 1], qa[2 * i2], qa[2 * i2 + 1], qb[2 * j], qb[2 * j + 1],
+                                    qb[2 * j2], qb[2 * j2 + 1]);
+      if (d < best) best = d;
+      if (best <= 0.0) return 0.0;
+    }
+  }
+  return best;
+}
+
+void fo_oracle_rect_vertices(double cx, double cy, double yaw, double length, double width, double *q) {
+  const double lx[4] = {-0.5 * length, -0.5 * length, 0.5 * length, 0.5 * length};
+  const double ly[4] = {-0.5 * width, 0.5 * width, 0.5 * width, -0.5 * width};
+  double c = cos(yaw), s = sin(yaw);
+  for (int i = 0; i < 4; ++i) {
+    q[2 * i] = c * lx[i] - s * ly[i] + cx;
+    q[2 * i + 1] = s * lx[i] + c * ly[i] + cy;
+  }
+}
+
+/* ------------------------------------------------------------------ DCE  (metrics/dce.py:52-99)
+ * ego rectangle: rear-axle reference shifted by wb_rear_axle along heading (convert_dynamic_obstacle.py:69-78)
+ * agent rectangle: un-inflated agent.shape at pos_list[t], orientation_list[t] (convert_dynamic_obstacle.py:27-47) */
+static void dce_pair(int T, const double *x, const double *y, const double *th, const fo_vehicle_t *veh, int L,
+                     const double *pos, const double *yaw, double raw_l, double raw_w, double *dce_out,
+                     int *time_out) {
+  double dce = INFINITY;
+  int time_dce = 0;
+  for (int i = 0; i < T; ++i) {
+    if (i >= L) break; /* occupancy_at_time(i) is None  (dce.py:72,87-88) */
+    double qa[8], qb[8];
+    double cx = x[i] + veh->wb_rear_axle * cos(th[i]);
+    double cy = y[i] + veh->wb_rear_axle * sin(th[i]);
+    fo_oracle_rect_vertices(cx, cy, th[i], veh->length, veh->width, qa);
+    fo_oracle_rect_vertices(pos[2 * i], pos[2 * i + 1], yaw[i], raw_l, raw_w, qb);
+    double distance = fo_oracle_round3(fo_oracle_quad_distance(qa, qb)); /* dce.py:79 */
+    if (distance < dce) { time_dce = i; dce = distance; }                /* dce.py:82-84 */
+    if (dce == 0.0) break;                                               /* dce.py:85-86 */
+  }
+  *dce_out = dce;
+  *time_out = time_dce;
+}
+
+/* ------------------------------------------------------------------ CP  (collision_probability.py:14-126) */
+/* scipy.stats.mvn.mvnun == MVNDST (Genz).  For d = 2 MVNDNT reduces the box to BVNMVN(lower, upper, infin=(2,2), r):
+ *   BVU(l0,l1) - BVU(u0,l1) - BVU(l0,u1) + BVU(u0,u1),   BVU(h,k) = P(X>h, Y>k)
+ * and for r = 0 (diagonal covariance, the only kind the reference's phantom agents carry, agent.py:260-280)
+ * BVU(h,k) = MVNPHI(-h) * MVNPHI(-k): products of upper-tail normal probabilities.  Restated literally so that
+ * the far-tail behaviour (relative precision in the upper tails, absolute in the lower) follows the reference. */
+static double upper_tail(double z) { return 0.5 * erfc(z / M_SQRT2); } /* MVNPHI(-z) */
+
+double fo_oracle_box_prob(const double lo[2], const double hi[2], const double mu[2], double sxx, double syy) {
+  double sx = sqrt(sxx), sy = sqrt(syy);
+  double l0 = (lo[0] - mu[0]) / sx, u0 = (hi[0] - mu[0]) / sx;
+  double l1 = (lo[1] - mu[1]) / sy, u1 = (hi[1] - mu[1]) / sy;
+  double ql0 = upper_tail(l0), qu0 = upper_tail(u0), ql1 = upper_tail(l1), qu1 = upper_tail(u1);
+  return ql0 * ql1 - qu0 * ql1 - ql0 * qu1 + qu0 * qu1;
+}
+
+/* probs[T-1]; returns -2 when a covariance with non-zero off-diagonal is met (not produced by the reference's
+ * phantom agents, agent.py:260-280; general BVN is not restated). */
+static int cp_pair(int T, const double *x, const double *y, const double *th, const fo_vehicle_t *veh, int L,
+                   const double *pos, const double *yaw, const double *cov, double len_infl, double *probs) {
+  const double off0 = veh->length / 6.0, off1 = veh->width / 2.0; /* :35 */
+  for (int i = 1; i < T; ++i) {
+    double prob = 0.0;
+    if (i < L) { /* :69 */
+      /* means: agent position i-1, heading i  (Q1; :49-53) */
+      double devx = cos(yaw[i]) * len_infl / 2.0, devy = sin(yaw[i]) * len_infl / 2.0;
+      double mx[3] = {pos[2 * (i - 1)], pos[2 * (i - 1)] + devx, pos[2 * (i - 1)] - devx};
+      double my[3] = {pos[2 * (i - 1) + 1], pos[2 * (i - 1) + 1] + devy, pos[2 * (i - 1) + 1] - devy};
+      double mind = INFINITY;
+      for (int j = 0; j < 3; ++j) {
+        double ddx = mx[j] - x[i], ddy = my[j] - y[i];
+        double d = sqrt(ddx * ddx + ddy * ddy);
+        if (d < mind) mind = d;
+      }
+      if (!(mind > 5.0)) { /* :67,75 */
+        const double *c4 = cov + 4 * (i - 1);
+        double sxx = c4[0], sxy = c4[1], syx = c4[2], syy = c4[3];
+        if (sxx == 0.0 && sxy == 0.0 && syx == 0.0 && syy == 0.0) { sxx = 0.1; syy = 0.1; } /* :84-86 */
+        if (sxy != 0.0 || syx != 0.0) return -2;
+        /* three axis-aligned boxes around the REAR-AXLE point (Q2; :94-107,129-164) */
+        double r_x = veh->length / 2.0;
+        double ax = cos(th[i]), ay = sin(th[i]);
+        double ccx[3] = {x[i], x[i] + r_x * (2.0 / 3.0) * ax, x[i] - r_x * (2.0 / 3.0) * ax};
+        double ccy[3] = {y[i], y[i] + r_x * (2.0 / 3.0) * ay, y[i] - r_x * (2.0 / 3.0) * ay};
+        for (int j = 0; j < 3; ++j) {
+          for (int b = 0; b < 3; ++b) {
+            double lo[2] = {ccx[b] - off0, ccy[b] - off1}, hi[2] = {ccx[b] + off0, ccy[b] + off1};
+            double mu[2] = {mx[j], my[j]};
+            prob += fo_oracle_box_prob(lo, hi, mu, sxx, syy);
+          }
+        }
+      }
+    }
+    probs[i - 1] = prob / 3.0; /* :122 */
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ harm (harm_model.py:35-190) */
+static double obstacle_mass(int type, double size) { /* harm_model.py:158-190 */
+  switch (type) {
+    case FO_TYPE_CAR: case FO_TYPE_PRIORITY_VEHICLE: case FO_TYPE_PARKED_VEHICLE: case FO_TYPE_TAXI:
+      return -1333.5 + 526.9 * pow(size, 0.8);
+    case FO_TYPE_TRUCK: return 25000.0;
+    case FO_TYPE_BUS: return 13000.0;
+    case FO_TYPE_BICYCLE: return 90.0;
+    case FO_TYPE_PEDESTRIAN: return 75.0;
+    case FO_TYPE_TRAIN: return 118800.0;
+    case FO_TYPE_MOTORCYCLE: return 250.0;
+    default: return 0.0;
+  }
+}
+
+/* 1 protected, 0 unprotected, 2 = None (harm_model.py:15-32) */
+static int obstacle_protection(int type) {
+  switch (type) {
+    case FO_TYPE_CAR: case FO_TYPE_TRUCK: case FO_TYPE_BUS: case FO_TYPE_PRIORITY_VEHICLE:
+    case FO_TYPE_PARKED_VEHICLE: case FO_TYPE_TRAIN: case FO_TYPE_TAXI: return 1;
+    case FO_TYPE_BICYCLE: case FO_TYPE_PEDESTRIAN: case FO_TYPE_MOTORCYCLE: case FO_TYPE_UNKNOWN: return 0;
+    default: return 2;
+  }
+}
+
+static double lr4s(double velocity, double angle, const fo_harm_coeff_t *hc) { /* logistic_regression.py:11-52 */
+  const double t_a = 45.0 / 180.0 * M_PI, t_b = 3.0 * t_a;
+  double coef;
+  if (-t_a < angle && angle < t_a) coef = 0.0;
+  else if (t_a <= angle && angle < t_b) coef = hc->lr4s_side;
+  else if (-t_a >= angle && angle > -t_b) coef = hc->lr4s_side;
+  else coef = hc->lr4s_rear; /* incl. everything outside (-3pi/4, 3pi/4) on the UN-WRAPPED angle (Q5) */
+  return 1.0 / (1.0 + exp(-hc->lr4s_const - hc->lr4s_speed * velocity - coef));
+}
+
+static double lr1s(double velocity, const fo_harm_coeff_t *hc) { /* logistic_regression.py:55-75 */
+  return 1.0 / (1.0 + exp(-hc->lr1s_const - hc->lr1s_speed * velocity));
+}
+
+/* ego_harm[Lh], obst_harm[Lh], Lh = min(T-1, L) (harm_model.py:65-66) */
+static void harm_pair(int Lh, const double *x, const double *y, const double *th, const double *v,
+                      const fo_vehicle_t *veh, const double *pos, const double *yaw, const double *av, int type,
+                      double size_infl, const fo_harm_coeff_t *hc, double *ego_harm, double *obst_harm) {
+  double m_obs = obstacle_mass(type, size_infl); /* inflated footprint (Q8; :73,78) */
+  int prot = obstacle_protection(type);
+  for (int t = 0; t < Lh; ++t) {
+    double pdof = yaw[t] - th[t] + M_PI;                               /* :81 */
+    double rel = atan2(pos[2 * t + 1] - y[t], pos[2 * t] - x[t]);      /* :82-83 */
+    double ego_angle = rel - th[t];                                    /* :86 */
+    double obs_angle = M_PI + rel - yaw[t];                            /* :88 */
+    double dv = sqrt(pow(v[t], 2) + pow(av[t], 2) + 2 * v[t] * av[t] * cos(pdof)); /* :91-95 */
+    double ego_dv = m_obs / (veh->mass + m_obs) * dv;                  /* :96 */
+    double obs_dv = veh->mass / (veh->mass + m_obs) * dv;              /* :97 */
+    if (prot == 1) {
+      ego_harm[t] = lr4s(ego_dv, ego_angle, hc);
+      obst_harm[t] = lr4s(obs_dv, obs_angle, hc);
+    } else if (prot == 0) {
+      ego_harm[t] = lr1s(ego_dv, hc);
+      obst_harm[t] = 1.0 / (1.0 + exp(hc->ped_const - hc->ped_speed * obs_dv)); /* :140-146 */
+    } else {
+      ego_harm[t] = 1.0; obst_harm[t] = 1.0;                            /* :148-149 */
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ metric ordering (metric.py:125-147) */
+uint32_t fo_oracle_required_metrics(uint32_t m) {
+  if (m & FO_M_WTTC) m |= FO_M_TTC;
+  if (m & (FO_M_TTC | FO_M_TTCE | FO_M_BE)) m |= FO_M_DCE;
+  if (m & FO_M_HR) m |= FO_M_CP;
+  return m;
+}
+
+/* ------------------------------------------------------------------ one trajectory (metric.py:35-100) */
+static int eval_trajectory(int T, const double *x, const double *y, const double *th, const double *v, int A, int Ta,
+                           const double *apos, const double *ayaw, const double *av, const double *acov,
+                           const double *ashape, const double *araw, const int32_t *atype, const int32_t *alen,
+                           const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, double dt, const fo_thresholds_t *thr,
+                           uint32_t mask, double *pair_f, int32_t *pair_i, double *lists, double *cost,
+                           uint8_t *safe, double *scratch) {
+  const int Tm1 = T - 1 > 0 ? T - 1 : 0;
+  double *cp = scratch, *eh = scratch + Tm1, *oh = scratch + 2 * Tm1;
+  double c[FO_NC];
+  for (int i = 0; i < FO_NC; ++i) c[i] = 0.0;
+  c[FO_C_WTTC] = INFINITY; c[FO_C_MIN_DCE] = INFINITY; c[FO_C_MIN_TTCE] = INFINITY;
+  c[FO_C_ARGMIN_DCE] = -1; c[FO_C_ARGMIN_TTC] = -1; c[FO_C_ARGMAX_RISK] = -1;
+  int ok = 1, dce_flag = 0;
+  double min_ttc = INFINITY;
+  for (int k = 0; k < A; ++k) {
+    int L = alen[k];
+    const double *pos = apos + (size_t)k * Ta * 2, *yaw = ayaw + (size_t)k * Ta, *vv = av + (size_t)k * Ta;
+    const double *cov = acov + (size_t)k * Ta * 4;
+    double pf[FO_NPF];
+    int32_t pi[FO_NPI] = {0, 0, 0, 0};
+    for (int i = 0; i < FO_NPF; ++i) pf[i] = NAN;
+    /* --- cp (cp.py:25-42) */
+    if (mask & FO_M_CP) {
+      int rc = cp_pair(T, x, y, th, veh, L, pos, yaw, cov, ashape[2 * k], cp);
+      if (rc) return rc;
+    }
+    /* --- dce, ttc, ttce, wttc */
+    if (mask & FO_M_DCE) {
+      double dce; int tdce;
+      dce_pair(T, x, y, th, veh, L, pos, yaw, araw[2 * k], araw[2 * k + 1], &dce, &tdce);
+      pf[FO_PF_DCE] = dce; pi[FO_PI_TIME_DCE] = tdce;
+      if (dce < c[FO_C_MIN_DCE]) { c[FO_C_MIN_DCE] = dce; c[FO_C_ARGMIN_DCE] = k; }
+      if (!isnan(thr->dce) && dce < thr->dce) dce_flag = 1; /* metric.py:93-98 */
+      if (mask & FO_M_TTC) {
+        /* ttc.py:43: np.isclose(dce, 0.0) == |dce| <= 1e-8 */
+        double ttc = (fabs(dce) <= 1e-8) ? fo_oracle_round3(tdce * dt) : INFINITY;
+        pf[FO_PF_TTC] = ttc;
+        if (ttc < min_ttc) { min_ttc = ttc; c[FO_C_ARGMIN_TTC] = k; }
+      }
+      if (mask & FO_M_TTCE) {
+        double ttce = fo_oracle_round3(tdce * dt); /* ttce.py:39 */
+        pf[FO_PF_TTCE] = ttce;
+        if (ttce < c[FO_C_MIN_TTCE]) c[FO_C_MIN_TTCE] = ttce;
+      }
+    }
+    /* --- hr (hr.py:43-116) */
+    int Lh = Tm1 < L ? Tm1 : L; /* harm_model.py:66 */
+    if ((mask & FO_M_HR) && Lh > 0) {
+      harm_pair(Lh, x, y, th, v, veh, pos, yaw, vv, atype[k], ashape[2 * k] * ashape[2 * k + 1], hc, eh, oh);
+      double max_er = -INFINITY, max_or = -INFINITY, max_eh = -INFINITY, max_oh = -INFINITY, max_cp = -INFINITY;
+      int idx_or = 0, idx_cp = 0;
+      for (int t = 0; t < Lh; ++t) {
+        double er = eh[t] * cp[t], orr = oh[t] * cp[t]; /* hr.py:78-79 (Q6) */
+        if (er > max_er) max_er = er;
+        if (orr > max_or) { max_or = orr; idx_or = t; }
+        if (eh[t] > max_eh) max_eh = eh[t];
+        if (oh[t] > max_oh) max_oh = oh[t];
+        if (lists) {
+          double *l = lists + (size_t)k * FO_NL * Tm1;
+          l[FO_L_EGO_HARM * Tm1 + t] = eh[t]; l[FO_L_OBST_HARM * Tm1 + t] = oh[t];
+          l[FO_L_EGO_RISK * Tm1 + t] = er;    l[FO_L_OBST_RISK * Tm1 + t] = orr;
+        }
+      }
+      for (int t = 0; t < Tm1; ++t) if (cp[t] > max_cp) { max_cp = cp[t]; idx_cp = t; } /* np.max / np.argmax */
+      double hwc = (max_cp > 0.01) ? oh[idx_cp] : 0.0; /* hr.py:81-84 */
+      pf[FO_PF_MAX_EGO_RISK] = max_er; pf[FO_PF_MAX_OBST_RISK] = max_or; pf[FO_PF_HARM_WITH_CP] = hwc;
+      pf[FO_PF_MAX_EGO_HARM] = max_eh; pf[FO_PF_MAX_OBST_HARM] = max_oh; pf[FO_PF_MAX_CP] = max_cp;
+      pi[FO_PI_RISK_INDEX] = idx_or; pi[FO_PI_CP_ARGMAX] = idx_cp; pi[FO_PI_HR_VALID] = 1;
+      if (max_er > c[FO_C_MAX_EGO_RISK]) c[FO_C_MAX_EGO_RISK] = max_er; /* hr.py:101-106 */
+      if (max_or > c[FO_C_MAX_OBST_RISK]) { c[FO_C_MAX_OBST_RISK] = max_or; c[FO_C_ARGMAX_RISK] = k; }
+      if (max_eh > c[FO_C_MAX_EGO_HARM]) c[FO_C_MAX_EGO_HARM] = max_eh;
+      if (max_oh > c[FO_C_MAX_OBST_HARM]) c[FO_C_MAX_OBST_HARM] = max_oh;
+      if (hwc > c[FO_C_HARM_WITH_CP]) c[FO_C_HARM_WITH_CP] = hwc;
+      if (max_cp > c[FO_C_MAX_CP]) c[FO_C_MAX_CP] = max_cp;
+    }
+    if (lists && (mask & FO_M_CP)) {
+      double *l = lists + (size_t)k * FO_NL * Tm1;
+      for (int t = 0; t < Tm1; ++t) l[FO_L_CP * Tm1 + t] = cp[t];
+    }
+    if (pair_f) memcpy(pair_f + (size_t)k * FO_NPF, pf, sizeof pf);
+    if (pair_i) memcpy(pair_i + (size_t)k * FO_NPI, pi, sizeof pi);
+  }
+  c[FO_C_WTTC] = (mask & FO_M_WTTC) || (mask & FO_M_TTC) ? min_ttc : INFINITY;
+  /* thresholds (metric.py:50-98); no agents -> ({}, True) (metric.py:44-45) */
+  if (A > 0) {
+    if ((mask & FO_M_HR) && !isnan(thr->harm) && c[FO_C_HARM_WITH_CP] > thr->harm) ok = 0;
+    if ((mask & FO_M_HR) && !isnan(thr->risk) && c[FO_C_MAX_OBST_RISK] > thr->risk) ok = 0;
+    if ((mask & FO_M_HR) && !isnan(thr->cp) && c[FO_C_MAX_CP] > thr->cp) ok = 0;
+    if ((mask & FO_M_TTC) && !isnan(thr->ttc) && min_ttc < thr->ttc) ok = 0;
+    if ((mask & FO_M_DCE) && dce_flag) ok = 0;
+  }
+  c[FO_C_SAFE] = ok;
+  if (cost) memcpy(cost, c, sizeof c);
+  if (safe) *safe = (uint8_t)ok;
+  return 0;
+}
+
+int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double *theta, const double *v,
+                    const double *a, int A, int Ta, const double *apos, const double *ayaw, const double *av,
+                    const double *acov, const double *ashape, const double *araw, const int32_t *atype,
+                    const int32_t *alen, const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, double dt,
+                    const fo_thresholds_t *thr, uint32_t metric_mask, double *pair_f, int32_t *pair_i,
+                    double *lists, double *cost, uint8_t *safe, int nthreads) {
+  (void)a;
+  if (M < 0 || T < 1 || A < 0) return -1;
+  for (int k = 0; k < A; ++k) if (alen[k] < 1 || alen[k] > Ta) return -1;
+  uint32_t mask = fo_oracle_required_metrics(metric_mask);
+  const int Tm1 = T - 1;
+  if (lists) {
+    size_t n = (size_t)M * A * FO_NL * Tm1;
+    for (size_t i = 0; i < n; ++i) lists[i] = NAN;
+  }
+  int err = 0;
+#ifdef _OPENMP
+  if (nthreads > 1) omp_set_num_threads(nthreads);
+#pragma omp parallel if (nthreads > 1)
+#endif
+  {
+    double *scratch = (double *)malloc(sizeof(double) * 3 * (size_t)(Tm1 > 0 ? Tm1 : 1));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 8)
+#endif
+    for (int m = 0; m < M; ++m) {
+      int rc = eval_trajectory(T, x + (size_t)m * T, y + (size_t)m * T, theta + (size_t)m * T, v + (size_t)m * T, A,
+                               Ta, apos, ayaw, av, acov, ashape, araw, atype, alen, veh, hc, dt, thr, mask,
+                               pair_f ? pair_f + (size_t)m * A * FO_NPF : NULL,
+                               pair_i ? pair_i + (size_t)m * A * FO_NPI : NULL,
+                               lists ? lists + (size_t)m * A * FO_NL * Tm1 : NULL,
+                               cost ? cost + (size_t)m * FO_NC : NULL, safe ? safe + m : NULL, scratch);
+      if (rc) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+        err = rc;
+      }
+    }
+    free(scratch);
+  }
+  return err;
+}

@@ -1,0 +1,87 @@
+/* fo_oracle.h -- CPU restatement of the Frenetix-Occlusion per-timestep hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product path (frenetix-occlusion_amd/) never links, imports or calls it.
+ *
+ * Everything is float64 like the reference (numpy).  Citations are relative to /root/reference/.
+ *
+ * Pinning status:
+ *   CP, harm, HR, TTC, TTCE, WTTC  -- pinned against golden vectors produced by the reference's own code
+ *                                     (tests/golden/gen_golden.py).
+ *   DCE, thresholds (Metric), sensor model, spawn, pedestrian prediction -- PARITY UNPINNED: the reference
+ *                                     delegates to shapely/GEOS + commonroad, absent here; pinned only by
+ *                                     analytic known-answer tests (tests/test_oracle_kat.py).
+ */
+#ifndef FO_ORACLE_H
+#define FO_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* agent type codes (strings of commonroad ObstacleType, harm_model.py:15-32) */
+enum {
+  FO_TYPE_CAR = 0, FO_TYPE_TRUCK = 1, FO_TYPE_BUS = 2, FO_TYPE_BICYCLE = 3, FO_TYPE_PEDESTRIAN = 4,
+  FO_TYPE_PRIORITY_VEHICLE = 5, FO_TYPE_PARKED_VEHICLE = 6, FO_TYPE_TRAIN = 7, FO_TYPE_MOTORCYCLE = 8,
+  FO_TYPE_TAXI = 9, FO_TYPE_UNKNOWN = 10, FO_TYPE_STRUCTURE = 11 /* roadBoundary/pillar/... : protection None */
+};
+
+/* metric bits (metric.py:109-117) */
+enum { FO_M_DCE = 1, FO_M_CP = 2, FO_M_TTC = 4, FO_M_TTCE = 8, FO_M_WTTC = 16, FO_M_BE = 32, FO_M_HR = 64 };
+
+typedef struct { double length, width, wb_rear_axle, mass, a_max; } fo_vehicle_t;
+
+/* harm_params.json: log_reg.reduced_sym_angle_areas{const,speed,side,rear}, log_reg.ignore_angle{const,speed},
+ * pedestrian{const,speed} -- the only entries read (harm_model.py:109-155, logistic_regression.py) */
+typedef struct {
+  double lr4s_const, lr4s_speed, lr4s_side, lr4s_rear;
+  double lr1s_const, lr1s_speed;
+  double ped_const, ped_speed;
+} fo_harm_coeff_t;
+
+/* metric_thresholds (config.yaml:14-22); NaN = null = deactivated */
+typedef struct { double harm, risk, be, cp, ttc, dce; } fo_thresholds_t;
+
+/* pair scalar slots */
+enum { FO_PF_DCE = 0, FO_PF_TTC, FO_PF_TTCE, FO_PF_MAX_EGO_RISK, FO_PF_MAX_OBST_RISK, FO_PF_HARM_WITH_CP,
+       FO_PF_MAX_EGO_HARM, FO_PF_MAX_OBST_HARM, FO_PF_MAX_CP, FO_PF_BE_DECEL, FO_PF_BE_BTN, FO_PF_SPARE, FO_NPF = 12 };
+enum { FO_PI_TIME_DCE = 0, FO_PI_RISK_INDEX, FO_PI_CP_ARGMAX, FO_PI_HR_VALID, FO_NPI = 4 };
+/* per-timestep lists */
+enum { FO_L_CP = 0, FO_L_EGO_HARM, FO_L_OBST_HARM, FO_L_EGO_RISK, FO_L_OBST_RISK, FO_NL = 5 };
+/* per-trajectory cost vector */
+enum { FO_C_WTTC = 0, FO_C_MIN_DCE, FO_C_MAX_EGO_RISK, FO_C_MAX_OBST_RISK, FO_C_MAX_EGO_HARM, FO_C_MAX_OBST_HARM,
+       FO_C_MAX_CP, FO_C_HARM_WITH_CP, FO_C_MIN_TTCE, FO_C_ARGMIN_DCE, FO_C_ARGMIN_TTC, FO_C_ARGMAX_RISK,
+       FO_C_SAFE, FO_C_MAX_BTN, FO_C_RES0, FO_C_RES1, FO_NC = 16 };
+
+/* polygon(quad)-polygon(quad) distance the way GEOS 3.11 DistanceOp computes it (shapely 2.0.2
+ * Polygon.distance, called at metrics/dce.py:79).  q = 4 vertices x,y interleaved. */
+double fo_oracle_quad_distance(const double *qa, const double *qb);
+
+/* vertices of a commonroad Rectangle(length,width) at centre (cx,cy), yaw: (-l/2,-w/2),(-l/2,w/2),(l/2,w/2),(l/2,-w/2)
+ * rotated then translated (convert_dynamic_obstacle.py:41,78 + commonroad Rectangle semantics [ext]) */
+void fo_oracle_rect_vertices(double cx, double cy, double yaw, double length, double width, double *q8);
+
+double fo_oracle_round3(double v); /* np.round(v, 3) */
+
+/* P(lower <= X <= upper), X ~ N(mu, diag(sxx, syy)) -- closed form equal to scipy mvnun for diagonal cov */
+double fo_oracle_box_prob(const double lo[2], const double hi[2], const double mu[2], double sxx, double syy);
+
+/* The sweep.  Inputs: trajectories [M][T]; agent predictions [A][Ta](...) with per-agent valid length alen[k]
+ * (1..Ta).  acov = [A][Ta][4] (xx,xy,yx,yy); ashape = inflated (prediction dict 'shape'), araw = agent.shape.
+ * Outputs may be NULL: pair_f [M][A][FO_NPF], pair_i [M][A][FO_NPI], lists [M][A][FO_NL][T-1] (NaN beyond the
+ * reference's list length), cost [M][FO_NC], safe [M].  Returns 0, or a negative error code.
+ * nthreads <= 1: scalar loop; > 1: OpenMP over trajectories (used only for the timed CPU baseline). */
+int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double *theta, const double *v,
+                    const double *a, int A, int Ta, const double *apos, const double *ayaw, const double *av,
+                    const double *acov, const double *ashape, const double *araw, const int32_t *atype,
+                    const int32_t *alen, const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, double dt,
+                    const fo_thresholds_t *thr, uint32_t metric_mask, double *pair_f, int32_t *pair_i,
+                    double *lists, double *cost, uint8_t *safe, int nthreads);
+
+/* metric.py:125-147 dependency closure on the activated-metric bit mask */
+uint32_t fo_oracle_required_metrics(uint32_t mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,142 @@
+"""ctypes front-end of the CPU oracle (oracle/fo_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (frenetix-occlusion_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libfo_oracle.so")
+
+NPF, NPI, NL, NC = 12, 4, 5, 16
+PF = {"dce": 0, "ttc": 1, "ttce": 2, "max_ego_risk": 3, "max_obst_risk": 4, "max_obst_harm_with_cp": 5,
+      "max_ego_harm": 6, "max_obst_harm": 7, "max_collision_probability": 8, "be_decel": 9, "be_btn": 10}
+PI = {"time_dce": 0, "max_obst_risk_index": 1, "cp_argmax": 2, "hr_valid": 3}
+LST = {"cp": 0, "ego_harm": 1, "obst_harm": 2, "ego_risk": 3, "obst_risk": 4}
+COST = {"wttc": 0, "min_dce": 1, "max_ego_risk_all": 2, "max_obst_risk_all": 3, "max_ego_harm_all": 4,
+        "max_obst_harm_all": 5, "max_collision_probability_all": 6, "max_obst_harm_with_cp_all": 7, "min_ttce": 8,
+        "argmin_dce": 9, "argmin_ttc": 10, "argmax_risk": 11, "safe": 12, "max_btn": 13}
+METRIC_BITS = {"dce": 1, "cp": 2, "ttc": 4, "ttce": 8, "wttc": 16, "be": 32, "hr": 64}
+TYPE_CODES = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4, "priorityvehicle": 5,
+              "parkedvehicle": 6, "train": 7, "motorcycle": 8, "taxi": 9, "unknown": 10}
+
+# harm_params.json entries that the reference reads (harm_params.json:26-29,40-45,98-101)
+HARM_COEFF = dict(lr4s_const=-4.457, lr4s_speed=0.177, lr4s_side=0.244, lr4s_rear=-0.431,
+                  lr1s_const=-4.591, lr1s_speed=0.185, ped_const=3.164, ped_speed=0.288)
+
+
+class Vehicle(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("length", "width", "wb_rear_axle", "mass", "a_max")]
+
+
+class HarmCoeff(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("lr4s_const", "lr4s_speed", "lr4s_side", "lr4s_rear", "lr1s_const",
+                                          "lr1s_speed", "ped_const", "ped_speed")]
+
+
+class Thresholds(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("harm", "risk", "be", "cp", "ttc", "dce")]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("fo_oracle.c", "fo_oracle_scene.c", "fo_oracle.h")]
+    srcs = [s for s in srcs if os.path.exists(s)]
+    if (not force and os.path.exists(_LIB)
+            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libfo_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        _lib.fo_oracle_quad_distance.restype = C.c_double
+        _lib.fo_oracle_round3.restype = C.c_double
+        _lib.fo_oracle_round3.argtypes = [C.c_double]
+        _lib.fo_oracle_box_prob.restype = C.c_double
+        _lib.fo_oracle_required_metrics.restype = C.c_uint32
+        _lib.fo_oracle_required_metrics.argtypes = [C.c_uint32]
+        _lib.fo_oracle_sweep.restype = C.c_int
+    return _lib
+
+
+def _p(arr, typ=C.c_double):
+    return arr.ctypes.data_as(C.POINTER(typ)) if arr is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def metric_mask(names):
+    m = 0
+    for n in names:
+        m |= METRIC_BITS[n]
+    return m
+
+
+def thresholds(d=None):
+    d = d or {}
+    return Thresholds(*[float("nan") if d.get(k) is None else float(d[k]) for k in ("harm", "risk", "be", "cp", "ttc", "dce")])
+
+
+def quad_distance(qa, qb):
+    qa, qb = _f64(qa).reshape(8), _f64(qb).reshape(8)
+    return lib().fo_oracle_quad_distance(_p(qa), _p(qb))
+
+
+def rect_vertices(cx, cy, yaw, length, width):
+    q = np.zeros(8)
+    lib().fo_oracle_rect_vertices(C.c_double(cx), C.c_double(cy), C.c_double(yaw), C.c_double(length),
+                                  C.c_double(width), _p(q))
+    return q.reshape(4, 2)
+
+
+def box_prob(lo, hi, mu, sxx, syy):
+    lo, hi, mu = _f64(lo), _f64(hi), _f64(mu)
+    return lib().fo_oracle_box_prob(_p(lo), _p(hi), _p(mu), C.c_double(sxx), C.c_double(syy))
+
+
+def sweep(traj, agents, vehicle, dt, metrics=("hr", "ttc", "ttce", "dce", "wttc", "cp"), thr=None,
+          harm_coeff=None, want_lists=True, nthreads=1):
+    """traj: dict x,y,theta,v,a [M,T]; agents: dict pos[A,Ta,2], yaw[A,Ta], v[A,Ta], cov[A,Ta,2,2], shape[A,2],
+    raw_dims[A,2], type[A] int, len[A] int; vehicle: (length,width,wb_rear_axle,mass,a_max).
+    Returns dict of numpy arrays in the oracle's [M,A,...] layout."""
+    x, y, th, v = (_f64(traj[k]) for k in ("x", "y", "theta", "v"))
+    a = _f64(traj.get("a", np.zeros_like(x)))
+    M, T = x.shape
+    pos, yaw, av = _f64(agents["pos"]), _f64(agents["yaw"]), _f64(agents["v"])
+    A = pos.shape[0]
+    Ta = pos.shape[1] if A else 1
+    cov = _f64(agents["cov"]).reshape(A, Ta, 4) if A else np.zeros((0, 1, 4))
+    shape, raw = _f64(agents["shape"]), _f64(agents["raw_dims"])
+    typ = np.ascontiguousarray(agents["type"], dtype=np.int32)
+    ln = np.ascontiguousarray(agents["len"], dtype=np.int32)
+    veh = Vehicle(*[float(q) for q in vehicle])
+    hc = HarmCoeff(**(harm_coeff or HARM_COEFF))
+    th_s = thr if isinstance(thr, Thresholds) else thresholds(thr)
+    Tm1 = max(T - 1, 0)
+    pair_f = np.empty((M, A, NPF))
+    pair_i = np.empty((M, A, NPI), dtype=np.int32)
+    lists = np.empty((M, A, NL, Tm1)) if want_lists else None
+    cost = np.empty((M, NC))
+    safe = np.empty(M, dtype=np.uint8)
+    rc = lib().fo_oracle_sweep(
+        C.c_int(M), C.c_int(T), _p(x), _p(y), _p(th), _p(v), _p(a), C.c_int(A), C.c_int(Ta), _p(pos), _p(yaw),
+        _p(av), _p(cov), _p(shape), _p(raw), _p(typ, C.c_int32), _p(ln, C.c_int32), C.byref(veh), C.byref(hc),
+        C.c_double(dt), C.byref(th_s), C.c_uint32(metric_mask(metrics)), _p(pair_f), _p(pair_i, C.c_int32),
+        _p(lists), _p(cost), _p(safe, C.c_uint8), C.c_int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"fo_oracle_sweep failed with code {rc}")
+    return {"pair_f": pair_f, "pair_i": pair_i, "lists": lists, "cost": cost, "safe": safe}

@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the reference's OWN metric code and records inputs + outputs.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+What is executed unmodified from /root/reference/frenetix_occlusion:
+  metrics/cp.py  (CP.evaluate -> metrics/utils/collision_probability.py:14-126)
+  metrics/hr.py  (HR.evaluate -> metrics/utils/harm_model.py:35-107, logistic_regression.py:11-75)
+  metrics/ttc.py:28-49, metrics/ttce.py:28-43, metrics/wttc.py:29-44
+
+Three third-party names those files import are absent from this image and are aliased before import
+(SURVEY.md §8c).  They contain no algorithm of the hot path:
+  * commonroad.scenario.obstacle.ObstacleType  -> an Enum of the type strings (harm_model.py:15-32 keys)
+  * commonroad_dc.pycrcc.RectOBB               -> value holder with center()/r_x()/local_x_axis()
+                                                  (collision_probability.py:149-156 uses only these)
+  * scipy.stats.mvn                            -> scipy.stats._mvn (the same Fortran MVNDST wrapper; the public
+                                                  alias was dropped in scipy 1.15)
+DCE, BE, SensorModel, SpawnLocator need shapely/commonroad proper and are NOT run here; for those the
+oracle is pinned by analytic known-answer tests only ("parity unpinned").
+
+Only arrays (inputs and the reference's outputs) are written, to tests/golden/*.npz.  No reference source
+or bytecode is copied.
+"""
+import enum
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+# --------------------------------------------------------------------------- aliases for absent third-party names
+def _install_aliases():
+    class ObstacleType(enum.Enum):
+        UNKNOWN = "unknown"
+        CAR = "car"
+        TRUCK = "truck"
+        BUS = "bus"
+        BICYCLE = "bicycle"
+        PEDESTRIAN = "pedestrian"
+        PRIORITY_VEHICLE = "priorityVehicle"
+        PARKED_VEHICLE = "parkedVehicle"
+        CONSTRUCTION_ZONE = "constructionZone"
+        TRAIN = "train"
+        ROAD_BOUNDARY = "roadBoundary"
+        MOTORCYCLE = "motorcycle"
+        TAXI = "taxi"
+        BUILDING = "building"
+        PILLAR = "pillar"
+        MEDIAN_STRIP = "median_strip"
+
+    cr = types.ModuleType("commonroad")
+    cr_s = types.ModuleType("commonroad.scenario")
+    cr_o = types.ModuleType("commonroad.scenario.obstacle")
+    cr_o.ObstacleType = ObstacleType
+    cr.scenario = cr_s
+    cr_s.obstacle = cr_o
+    sys.modules.update({"commonroad": cr, "commonroad.scenario": cr_s, "commonroad.scenario.obstacle": cr_o})
+
+    class RectOBB:
+        def __init__(self, r_x, r_y, yaw, x, y):
+            self._rx, self._yaw, self._c = r_x, yaw, np.array([x, y], dtype=np.float64)
+
+        def center(self):
+            return self._c
+
+        def r_x(self):
+            return self._rx
+
+        def local_x_axis(self):
+            return np.array([np.cos(self._yaw), np.sin(self._yaw)])
+
+    dc = types.ModuleType("commonroad_dc")
+    pc = types.ModuleType("commonroad_dc.pycrcc")
+    pc.RectOBB = RectOBB
+    dc.pycrcc = pc
+    sys.modules.update({"commonroad_dc": dc, "commonroad_dc.pycrcc": pc})
+
+    import scipy.stats
+    import scipy.stats._mvn as _mvn
+    scipy.stats.mvn = _mvn
+    sys.modules["scipy.stats.mvn"] = _mvn
+
+
+# --------------------------------------------------------------------------- harness objects (duck-typed inputs)
+class Cartesian:
+    def __init__(self, x, y, theta, v, a):
+        self.x, self.y, self.theta, self.v, self.a = (np.array(q, dtype=np.float64) for q in (x, y, theta, v, a))
+
+
+class Traj:
+    def __init__(self, *args):
+        self.cartesian = Cartesian(*args)
+
+
+class VehicleParams:
+    # CommonRoad vehicle 2 (BMW 320i) as quoted in SURVEY.md §8
+    length, width, wb_rear_axle, mass, a_max = 4.508, 1.610, 1.4227, 1093.3, 11.5
+
+
+class Agent:
+    def __init__(self, agent_id, agent_type):
+        self.agent_id, self.agent_type = agent_id, agent_type
+
+
+class AgentManager:
+    def __init__(self, dt):
+        self.dt, self.phantom_agents, self.predictions = dt, [], {}
+
+    def agent_by_prediction_id(self, pid):
+        aid = int(str(pid)[:5])
+        for a in self.phantom_agents:
+            if a.agent_id == aid:
+                return a
+
+
+AGENT_TYPES = ["Car", "Truck", "Bicycle", "Pedestrian"]
+RAW_DIMS = {"Car": (4.8, 2.0), "Truck": (9.0, 2.5), "Bicycle": (2.0, 0.9), "Pedestrian": (0.3, 0.5)}
+
+
+def make_traj(rng, T, dt, x0=0.0, y0=0.0, psi0=0.0):
+    """Quintic-blend lateral offset + smoothly changing speed, in a frame rotated by psi0."""
+    v0 = rng.uniform(3, 12)
+    v1 = v0 * rng.uniform(0.3, 1.3)
+    d1 = rng.uniform(-3, 3)
+    tau = np.linspace(0, 1, T)
+    blend = 10 * tau ** 3 - 15 * tau ** 4 + 6 * tau ** 5
+    v = v0 + (v1 - v0) * blend
+    s = np.concatenate(([0.0], np.cumsum(0.5 * (v[1:] + v[:-1]) * dt)))
+    d = d1 * blend
+    c, sn = np.cos(psi0), np.sin(psi0)
+    x = x0 + c * s - sn * d
+    y = y0 + sn * s + c * d
+    theta = np.arctan2(np.gradient(y), np.gradient(x))
+    a = np.gradient(v, dt)
+    return x, y, theta, v, a
+
+
+def make_prediction(rng, kind, L, dt, near_xy, var0=0.1, vf=1.05, zero_cov=False, curved=False):
+    raw_l, raw_w = RAW_DIMS[kind]
+    fl, fw = (1.4, 2.5) if kind == "Bicycle" else (1.2, 1.3)
+    speed = {"Car": 10.0, "Truck": 10.0, "Bicycle": 5.0, "Pedestrian": 1.4}[kind] * rng.uniform(0.6, 1.2)
+    psi = rng.uniform(-np.pi, np.pi)
+    p0 = np.asarray(near_xy) + rng.uniform(-6, 6, size=2)
+    t = np.arange(L) * dt
+    if curved:
+        om = rng.uniform(-0.4, 0.4)
+        yaw = psi + om * t
+        pos = p0 + np.cumsum(np.stack((np.cos(yaw), np.sin(yaw)), -1) * speed * dt, axis=0)
+    else:
+        yaw = np.full(L, psi)
+        vx, vy = round(speed * np.cos(psi), 3), round(speed * np.sin(psi), 3)
+        pos = p0 + t[:, None] * np.array([vx, vy])
+    var = var0 * vf ** np.arange(L)
+    cov = np.array([[[q, 0.0], [0.0, q]] for q in var])
+    if zero_cov:
+        cov[: L // 2] = 0.0
+    return {"pos_list": pos, "v_list": np.full(L, speed), "orientation_list": yaw,
+            "cov_list": cov, "shape": {"length": raw_l * fl, "width": raw_w * fw}}
+
+
+def pad(arr_list, n, fill=np.nan):
+    out = np.full((len(arr_list), n), fill)
+    for i, a in enumerate(arr_list):
+        out[i, : len(a)] = a
+    return out
+
+
+def run_case(name, trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC, dce_inputs=None):
+    am = AgentManager(dt)
+    keys = []
+    for i, (kind, pred) in enumerate(zip(kinds, preds)):
+        aid = 10000 + i
+        am.phantom_agents.append(Agent(aid, kind))
+        key = int(str(aid) + "0")
+        am.predictions[key] = pred
+        keys.append(key)
+    vp = VehicleParams()
+    cp_m, hr_m = CP(vp, am), HR(vp, am)
+    M, A = len(trajs), len(keys)
+    T = len(trajs[0].cartesian.x)
+    Lmax = max(len(p["pos_list"]) for p in preds)
+    out = {
+        "dt": dt, "vehicle": np.array([vp.length, vp.width, vp.wb_rear_axle, vp.mass, vp.a_max]),
+        "traj_x": np.stack([t.cartesian.x for t in trajs]), "traj_y": np.stack([t.cartesian.y for t in trajs]),
+        "traj_theta": np.stack([t.cartesian.theta for t in trajs]), "traj_v": np.stack([t.cartesian.v for t in trajs]),
+        "traj_a": np.stack([t.cartesian.a for t in trajs]),
+        "agent_type": np.array(kinds), "agent_len": np.array([len(p["pos_list"]) for p in preds]),
+        "agent_pos": np.stack([np.pad(p["pos_list"], ((0, Lmax - len(p["pos_list"])), (0, 0))) for p in preds]),
+        "agent_yaw": pad([p["orientation_list"] for p in preds], Lmax, 0.0),
+        "agent_v": pad([p["v_list"] for p in preds], Lmax, 0.0),
+        "agent_cov": np.stack([np.pad(p["cov_list"], ((0, Lmax - len(p["cov_list"])), (0, 0), (0, 0))) for p in preds]),
+        "agent_shape": np.array([[p["shape"]["length"], p["shape"]["width"]] for p in preds]),
+        "agent_raw_dims": np.array([RAW_DIMS[k] for k in kinds]),
+    }
+    cp = np.zeros((M, A, T - 1))
+    Lh = [min(T - 1, len(p["pos_list"])) for p in preds]
+    lists = {k: np.full((M, A, T - 1), np.nan) for k in ("ego_harm", "obst_harm", "ego_risk", "obst_risk")}
+    scal = {k: np.zeros((M, A)) for k in ("max_ego_risk", "max_obst_risk", "max_obst_harm_with_cp", "max_ego_harm",
+                                          "max_obst_harm", "max_collision_probability")}
+    ridx = np.zeros((M, A), dtype=np.int64)
+    glob = {k: np.zeros(M) for k in ("max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
+                                     "max_collision_probability_all", "max_obst_harm_with_cp_all")}
+    for m, tr in enumerate(trajs):
+        res = {"cp": cp_m.evaluate(tr, {})}
+        res["hr"] = hr_m.evaluate(tr, res)
+        for j, key in enumerate(keys):
+            cp[m, j] = res["cp"][key]
+            h = res["hr"][key]
+            lists["ego_harm"][m, j, : Lh[j]] = h["ego_harm_traj"]
+            lists["obst_harm"][m, j, : Lh[j]] = h["obst_harm_traj"]
+            lists["ego_risk"][m, j, : Lh[j]] = h["ego_risk_traj"]
+            lists["obst_risk"][m, j, : Lh[j]] = h["obst_risk_traj"]
+            for k in scal:
+                scal[k][m, j] = h[k]
+            ridx[m, j] = h["max_obst_risk_index"]
+        for k in glob:
+            glob[k][m] = res["hr"][k]
+    out["ref_cp"] = cp
+    out.update({"ref_" + k: v for k, v in lists.items()})
+    out.update({"ref_" + k: v for k, v in scal.items()})
+    out["ref_max_obst_risk_index"] = ridx
+    out.update({"ref_" + k: v for k, v in glob.items()})
+
+    # TTC / TTCE / WTTC are post-processing of a DCE result dict: feed chosen (dce, time_dce) pairs.
+    if dce_inputs is not None:
+        dce_v, dce_t = dce_inputs  # [M, A]
+        ttc = np.zeros((M, A))
+        ttce = np.zeros((M, A))
+        wttc = np.zeros(M)
+        for m in range(M):
+            res = {"dce": {key: {"dce": float(dce_v[m, j]), "time_dce": int(dce_t[m, j])} for j, key in enumerate(keys)}}
+            res["ttc"] = TTC(am).evaluate(None, res)
+            res["ttce"] = TTCE(am).evaluate(None, res)
+            w = WTTC.evaluate(None, res)
+            for j, key in enumerate(keys):
+                ttc[m, j] = res["ttc"][key]
+                ttce[m, j] = res["ttce"][key]
+            wttc[m] = w
+        out.update({"in_dce": dce_v, "in_time_dce": dce_t, "ref_ttc": ttc, "ref_ttce": ttce, "ref_wttc": wttc})
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "M", M, "A", A, "T", T, "max cp", cp.max())
+
+
+def main():
+    _install_aliases()
+    sys.path.insert(0, REF)
+    from frenetix_occlusion.metrics.cp import CP
+    from frenetix_occlusion.metrics.hr import HR
+    from frenetix_occlusion.metrics.ttc import TTC
+    from frenetix_occlusion.metrics.ttce import TTCE
+    from frenetix_occlusion.metrics.wttc import WTTC
+    dt = 0.1
+
+    # case 0: the SURVEY §8c probe (straight 8 m/s ego, pedestrian crossing at x = 15)
+    T = 31
+    t = np.arange(T) * dt
+    tr = Traj(8.0 * t, np.zeros(T), np.zeros(T), np.full(T, 8.0), np.zeros(T))
+    psi = np.pi / 2
+    pos = np.array([15.0, -2.0]) + t[:, None] * np.array([round(1.4 * np.cos(psi), 3), round(1.4 * np.sin(psi), 3)])
+    var = 0.1 * 1.05 ** np.arange(T)
+    ped = {"pos_list": pos, "v_list": np.full(T, 1.4), "orientation_list": np.full(T, psi),
+           "cov_list": np.array([[[q, 0.0], [0.0, q]] for q in var]), "shape": {"length": 0.3 * 1.2, "width": 0.5 * 1.3}}
+    run_case("probe_ped_crossing", [tr], ["Pedestrian"], [ped], dt, CP, HR, TTC, TTCE, WTTC,
+             dce_inputs=(np.array([[0.0]]), np.array([[19]])))
+
+    # case 1: random batch, all four phantom types, equal lengths
+    rng = np.random.default_rng(20240131)
+    trajs = [Traj(*make_traj(rng, 31, dt, psi0=0.3)) for _ in range(24)]
+    mid = np.array([trajs[0].cartesian.x[15], trajs[0].cartesian.y[15]])
+    kinds = [AGENT_TYPES[i % 4] for i in range(8)]
+    preds = [make_prediction(rng, k, 31, dt, mid, curved=(i % 3 == 0)) for i, k in enumerate(kinds)]
+    dv = rng.choice([0.0, 0.0, 1e-9, 0.001, 0.004, 0.25, 3.217, 17.5], size=(24, 8))
+    dtm = rng.integers(0, 31, size=(24, 8))
+    run_case("random_equal_len", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC, dce_inputs=(dv, dtm))
+
+    # case 2: ragged predictions (shorter and longer than the trajectory), zero covariance blocks, headings
+    # outside (-pi, pi] so that the un-wrapped angle binning of logistic_regression.py:28-42 is exercised
+    rng = np.random.default_rng(20240132)
+    trajs = []
+    for i in range(16):
+        x, y, th, v, a = make_traj(rng, 31, dt, psi0=2.9)
+        trajs.append(Traj(x, y, th + (2 * np.pi if i % 4 == 1 else 0.0), v, a))
+    mid = np.array([trajs[0].cartesian.x[12], trajs[0].cartesian.y[12]])
+    kinds = ["Pedestrian", "Car", "Bicycle", "Truck", "Car", "Pedestrian"]
+    lens = [31, 20, 40, 5, 1, 30]
+    preds = [make_prediction(rng, k, L, dt, mid, zero_cov=(i == 1), curved=(i == 2)) for i, (k, L) in enumerate(zip(kinds, lens))]
+    preds[4]["orientation_list"] = preds[4]["orientation_list"] + 2 * np.pi
+    run_case("random_ragged", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC)
+
+    # case 3: short trajectories (T = 12) against full-length predictions
+    rng = np.random.default_rng(20240133)
+    trajs = [Traj(*make_traj(rng, 12, dt, psi0=-1.0)) for _ in range(8)]
+    mid = np.array([trajs[0].cartesian.x[6], trajs[0].cartesian.y[6]])
+    kinds = ["Car", "Pedestrian", "Bicycle"]
+    preds = [make_prediction(rng, k, 31, dt, mid) for k in kinds]
+    run_case("short_traj", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,18 @@
+"""Helpers shared by the golden-vector tests: load a fixture and turn it into sweep inputs."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TYPE_CODES = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4}
+CASES = ["probe_ped_crossing", "random_equal_len", "random_ragged", "short_traj"]
+
+
+def load_case(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    traj = {k: g["traj_" + k] for k in ("x", "y", "theta", "v", "a")}
+    agents = {"pos": g["agent_pos"], "yaw": g["agent_yaw"], "v": g["agent_v"], "cov": g["agent_cov"],
+              "shape": g["agent_shape"], "raw_dims": g["agent_raw_dims"],
+              "type": np.array([TYPE_CODES[str(t).lower()] for t in g["agent_type"]], dtype=np.int32),
+              "len": g["agent_len"].astype(np.int32)}
+    return g, traj, agents, tuple(g["vehicle"]), float(g["dt"])
