@@ -1,0 +1,60 @@
+// fo_api.hip -- context management of the C ABI (include/fo_hip.h).
+#include <hip/hip_runtime.h>
+#include <new>
+#include "fo_ctx.hpp"
+
+extern "C" void fo_scene_destroy_(fo_ctx *ctx);  // fo_scene.hip
+
+extern "C" {
+
+int fo_abi_version(void) { return FO_ABI_VERSION; }
+
+int fo_create(fo_ctx **out, int device) {
+  if (!out) return FO_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return FO_E_HIP;  // no GPU: fail loudly
+  if (hipSetDevice(device) != hipSuccess) return FO_E_HIP;
+  fo_ctx *ctx = new (std::nothrow) fo_ctx();
+  if (!ctx) return FO_E_NOMEM;
+  ctx->device = device;
+  if (hipMalloc((void **)&ctx->d_status, sizeof(int)) != hipSuccess) { delete ctx; return FO_E_NOMEM; }
+  if (hipMemset(ctx->d_status, 0, sizeof(int)) != hipSuccess) { (void)hipFree(ctx->d_status); delete ctx; return FO_E_HIP; }
+  *out = ctx;
+  return FO_OK;
+}
+
+void fo_destroy(fo_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  fo_scene_destroy_(ctx);
+  if (ctx->d_agent_tab) (void)hipFree(ctx->d_agent_tab);
+  if (ctx->d_agent_const) (void)hipFree(ctx->d_agent_const);
+  if (ctx->d_traj_tab) (void)hipFree(ctx->d_traj_tab);
+  if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  if (ctx->d_status) (void)hipFree(ctx->d_status);
+  if (ctx->ev_start) {
+    for (int i = 0; i < fo_ctx::kMaxTimed; ++i) { (void)hipEventDestroy(ctx->ev_start[i]); (void)hipEventDestroy(ctx->ev_stop[i]); }
+    delete[] ctx->ev_start;
+    delete[] ctx->ev_stop;
+  }
+  delete ctx;
+}
+
+const char *fo_last_error(const fo_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+// blocks until `stream` drained, then reports data-dependent failures recorded on the device
+int fo_sweep_check(fo_ctx *ctx, void *stream) {
+  if (!ctx) return FO_E_ARG;
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  FO_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+  int st = 0;
+  FO_HIP_TRY(ctx, hipMemcpy(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  if (st & 1)
+    return fo_fail(ctx, FO_E_UNSUPPORTED_COV,
+                   "agent covariance with non-zero off-diagonal terms: only diagonal covariances (what "
+                   "agent.py:260-280 produces) are implemented; affected collision probabilities are NaN");
+  return FO_OK;
+}
+
+}  // extern "C"

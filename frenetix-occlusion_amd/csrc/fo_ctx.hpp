@@ -1,0 +1,70 @@
+// fo_ctx.hpp -- context object behind the C ABI (include/fo_hip.h).  Internal to libfo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "fo_hip.h"
+
+struct fo_ctx {
+  int device = 0;
+  char err[512] = {0};
+
+  // ---- sweep configuration (Metric.__init__)
+  fo_vehicle_t veh{};
+  fo_harm_coeff_t hc{};
+  fo_thresholds_t thr{};
+  uint32_t mask = 0;   // after dependency closure
+  double dt = 0.1;
+  bool configured = false;
+
+  // ---- agents (prepared form, HBM)
+  int A = 0, Ta = 0;
+  double *d_agent_tab = nullptr;    // [A][Ta][NAF]
+  double *d_agent_const = nullptr;  // [A][NAC]
+  int *d_status = nullptr;          // device status word (bit 0: off-diagonal covariance met)
+  size_t cap_agent_tab = 0, cap_agent_const = 0;
+
+  // ---- trajectory tile buffer + partial reductions (HBM workspace)
+  double *d_traj_tab = nullptr;     // [T][NEF][Mp]
+  double *d_partial = nullptr;      // [n_chunks][NPS][Mp]
+  size_t cap_traj_tab = 0, cap_partial = 0;
+
+  // ---- last launch (profiling aid) + optional HIP-event timing of the sweep kernel alone
+  int last_grid = 0, last_block = 0, last_apw = 0;
+  bool timing = false;
+  static constexpr int kMaxTimed = 1024;
+  hipEvent_t *ev_start = nullptr, *ev_stop = nullptr;
+  int n_timed = 0;
+
+  // ---- scene (ray-cast / grid) state lives in fo_scene.hip
+  void *scene = nullptr;
+};
+
+inline int fo_fail(fo_ctx *ctx, int code, const char *fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define FO_HIP_TRY(ctx, expr)                                                                   \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fo_fail(ctx, FO_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// grow-only device buffer
+template <typename T>
+inline int fo_reserve(fo_ctx *ctx, T **ptr, size_t *cap, size_t need_elems) {
+  if (need_elems <= *cap) return FO_OK;
+  if (*ptr) FO_HIP_TRY(ctx, hipFree(*ptr));
+  *ptr = nullptr;
+  *cap = 0;
+  FO_HIP_TRY(ctx, hipMalloc((void **)ptr, need_elems * sizeof(T)));
+  *cap = need_elems;
+  return FO_OK;
+}

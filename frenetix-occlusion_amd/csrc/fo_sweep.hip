@@ -1,0 +1,578 @@
+// fo_sweep.hip -- the trajectory x agent criticality sweep for gfx950 (MI355X, CDNA4).
+//
+// One launch evaluates DCE -> TTC/TTCE/WTTC, CP and harm/risk for M candidate trajectories x A agent predictions
+// x T timesteps; it replaces M calls of FOInterface.trajectory_safety_assessment
+// (ref: interface.py:216-219 -> metrics/metric.py:35-100 -> metrics/{dce,ttc,ttce,wttc,cp,hr}.py).
+//
+// Mapping (wave64): lane = trajectory (64 consecutive trajectories per wave, trajectory-fastest SoA tile
+// [T][6][Mp] so that every per-timestep load/store of a wave is one contiguous 512-byte segment); the agent
+// prediction a wave works on is wave-uniform, so its samples come through the scalar cache (s_load) and live
+// in SGPRs.  The four waves of a workgroup share one trajectory tile (L1/L2 reuse) and take different agents;
+// workgroups that share a tile are placed on the same XCD (blockIdx % 8) so the tile stays in that XCD's L2.
+// No MFMA: this is branchy fp64 geometry + transcendentals, not a contraction.
+//
+// Arithmetic is float64 throughout (the reference is numpy float64; np.round(d,3) at dce.py:79 turns 1e-7
+// errors into 1e-3 jumps, see DESIGN.md "Why fp64").
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "fo_ctx.hpp"
+
+namespace {
+
+constexpr int TILE = 64;   // trajectories per wave
+constexpr int WAVES = 4;   // waves per workgroup
+constexpr int NEF = 6;     // ego fields per (t, trajectory): x, y, cos, sin, theta, v
+constexpr int NAF = 8;     // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2)
+constexpr int NAC = 8;     // per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type
+constexpr int NPS = 14;    // partial-reduction slots
+enum { PS_MIN_DCE = 0, PS_ARG_DCE, PS_MIN_TTC, PS_ARG_TTC, PS_MIN_TTCE, PS_MAX_ER, PS_MAX_OR, PS_ARG_OR, PS_MAX_EH,
+       PS_MAX_OH, PS_MAX_CP, PS_MAX_HWC, PS_DCE_FLAG, PS_MAX_BTN };
+
+__device__ __forceinline__ double fo_round3(double v) { return __builtin_rint(v * 1000.0) / 1000.0; }  // np.round(v,3)
+
+// ------------------------------------------------------------------------------------------------ prep kernels
+// trajectories [M][T] (row per trajectory) -> tile table [T][NEF][Mp], transposed through LDS so that both the
+// HBM read (along T) and the HBM write (along trajectories) are contiguous; sincos(theta) is taken once here.
+__global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int Mp, const double *__restrict__ x,
+                                                           const double *__restrict__ y,
+                                                           const double *__restrict__ th,
+                                                           const double *__restrict__ v, double *__restrict__ tab) {
+  extern __shared__ double sh[];  // [T][TILE+1]
+  const int m0 = blockIdx.x * TILE;
+  const int n = min(TILE, M - m0);
+  const int ld = TILE + 1;
+  const double *src[4] = {x, y, th, v};
+  for (int f = 0; f < 4; ++f) {
+    const double *s = src[f] + (size_t)m0 * T;
+    for (int i = threadIdx.x; i < n * T; i += blockDim.x) sh[(i % T) * ld + (i / T)] = s[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * TILE; i += blockDim.x) {
+      const int t = i / TILE, ml = i % TILE;
+      const double val = sh[t * ld + min(ml, n - 1)];  // pad lanes replicate the last trajectory of the tile
+      double *dst = tab + (size_t)t * NEF * Mp + m0 + ml;
+      if (f == 0) dst[0 * (size_t)Mp] = val;
+      else if (f == 1) dst[1 * (size_t)Mp] = val;
+      else if (f == 2) {
+        double sn, cs;
+        sincos(val, &sn, &cs);
+        dst[2 * (size_t)Mp] = cs;
+        dst[3 * (size_t)Mp] = sn;
+        dst[4 * (size_t)Mp] = val;
+      } else dst[5 * (size_t)Mp] = val;
+    }
+    __syncthreads();
+  }
+}
+
+// obstacle mass / protection class by type (ref: harm_model.py:15-32,158-190)
+__device__ double fo_obstacle_mass(int type, double size) {
+  switch (type) {
+    case FO_TYPE_CAR: case FO_TYPE_PRIORITY_VEHICLE: case FO_TYPE_PARKED_VEHICLE: case FO_TYPE_TAXI:
+      return -1333.5 + 526.9 * pow(size, 0.8);
+    case FO_TYPE_TRUCK: return 25000.0;
+    case FO_TYPE_BUS: return 13000.0;
+    case FO_TYPE_BICYCLE: return 90.0;
+    case FO_TYPE_PEDESTRIAN: return 75.0;
+    case FO_TYPE_TRAIN: return 118800.0;
+    case FO_TYPE_MOTORCYCLE: return 250.0;
+    default: return 0.0;
+  }
+}
+__device__ int fo_obstacle_protection(int type) {
+  switch (type) {
+    case FO_TYPE_CAR: case FO_TYPE_TRUCK: case FO_TYPE_BUS: case FO_TYPE_PRIORITY_VEHICLE:
+    case FO_TYPE_PARKED_VEHICLE: case FO_TYPE_TRAIN: case FO_TYPE_TAXI: return 1;
+    case FO_TYPE_BICYCLE: case FO_TYPE_PEDESTRIAN: case FO_TYPE_MOTORCYCLE: case FO_TYPE_UNKNOWN: return 0;
+    default: return 2;
+  }
+}
+
+// agent predictions -> [A][Ta][NAF] table + [A][NAC] constants (one thread per (k, t))
+__global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ pos, const double *__restrict__ yaw,
+                                      const double *__restrict__ v, const double *__restrict__ cov,
+                                      const double *__restrict__ shape, const double *__restrict__ raw,
+                                      const int32_t *__restrict__ type, const int32_t *__restrict__ len,
+                                      double ego_mass, double *__restrict__ tab, double *__restrict__ cst,
+                                      int *__restrict__ status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A * Ta) return;
+  const int k = i / Ta, t = i % Ta;
+  double sn, cs;
+  sincos(yaw[i], &sn, &cs);
+  double sxx = cov[4 * (size_t)i], sxy = cov[4 * (size_t)i + 1], syx = cov[4 * (size_t)i + 2], syy = cov[4 * (size_t)i + 3];
+  if (sxx == 0.0 && sxy == 0.0 && syx == 0.0 && syy == 0.0) { sxx = 0.1; syy = 0.1; }  // collision_probability.py:84-86
+  double isx = 1.0 / (sqrt(sxx) * M_SQRT2), isy = 1.0 / (sqrt(syy) * M_SQRT2);
+  if ((sxy != 0.0 || syx != 0.0) && t < len[k]) {  // general BVN not implemented: poison + status word
+    atomicOr(status, 1);
+    isx = NAN;
+    isy = NAN;
+  }
+  double *o = tab + (size_t)i * NAF;
+  o[0] = pos[2 * (size_t)i]; o[1] = pos[2 * (size_t)i + 1]; o[2] = cs; o[3] = sn; o[4] = yaw[i]; o[5] = v[i];
+  o[6] = isx; o[7] = isy;
+  if (t == 0) {
+    const double m_obs = fo_obstacle_mass(type[k], shape[2 * k] * shape[2 * k + 1]);  // inflated footprint (Q8)
+    double *c = cst + (size_t)k * NAC;
+    c[0] = 0.5 * raw[2 * k]; c[1] = 0.5 * raw[2 * k + 1]; c[2] = shape[2 * k] / 2.0;
+    c[3] = m_obs / (ego_mass + m_obs); c[4] = ego_mass / (ego_mass + m_obs);
+    c[5] = (double)fo_obstacle_protection(type[k]); c[6] = (double)len[k]; c[7] = (double)type[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ the sweep
+struct SweepArgs {
+  int M, Mp, T, A, Ta, n_tiles, nt8, apw;  // apw = agents per wave
+  const double *traj;    // [T][NEF][Mp]
+  const double *atab;    // [A][Ta][NAF]
+  const double *acst;    // [A][NAC]
+  double *partial;       // [n_chunks][NPS][Mp]
+  double *pair_f;        // [NPF][A][M] or null
+  int32_t *pair_i;       // [NPI][A][M] or null
+  double *lists;         // [NL][A][T-1][M] or null
+  double hlA, hwA, wb, len3, off_x, off_y;  // ego half dims, rear-axle offset, L/3, L/6, W/2
+  fo_harm_coeff_t hc;
+  double dt, thr_dce;
+  uint32_t mask;
+};
+
+__device__ __forceinline__ double fo_lr4s_coef(double ang, double side, double rear) {
+  const double t_a = 45.0 / 180.0 * M_PI, t_b = 3.0 * t_a;  // logistic_regression.py:28-29
+  if (-t_a < ang && ang < t_a) return 0.0;
+  if (t_a <= ang && ang < t_b) return side;
+  if (-t_a >= ang && ang > -t_b) return side;
+  return rear;  // un-wrapped angle: everything else is "rear" (Q5)
+}
+
+// squared distance from point (px,py) to the axis-aligned box [-hl,hl]x[-hw,hw]
+__device__ __forceinline__ double fo_pt_box2(double px, double py, double hl, double hw) {
+  const double qx = fmax(fabs(px) - hl, 0.0), qy = fmax(fabs(py) - hw, 0.0);
+  return qx * qx + qy * qy;
+}
+
+// 1-D normal box probability  P(lo <= X <= hi)  in upper-tail form  Q(lo) - Q(hi)  (MVNDST orientation)
+__device__ __forceinline__ double fo_phi_diff(double lo, double hi) { return 0.5 * (erfc(lo) - erfc(hi)); }
+
+template <bool PAIR, bool LISTS>
+__global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a) {
+  __shared__ double red[(WAVES - 1) * NPS * TILE];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware decode: blocks b and b+8 share an XCD (and its L2); keep every chunk of one tile on one XCD
+  const int r = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int tile = (j % a.nt8) * 8 + r;
+  const int chunk = j / a.nt8;
+  if (tile >= a.n_tiles) return;
+  const int m = tile * TILE + lane;
+  const bool valid = m < a.M;
+  const int T = a.T, Tm1 = a.T - 1, M = a.M, A = a.A;
+  const size_t Mp = (size_t)a.Mp;
+  const double *tj = a.traj + (size_t)tile * TILE + lane;
+  const bool do_dce = a.mask & FO_M_DCE, do_cp = a.mask & FO_M_CP, do_hr = a.mask & FO_M_HR;
+  const bool do_ttc = a.mask & FO_M_TTC, do_ttce = a.mask & FO_M_TTCE;
+
+  // reductions over this wave's agents (metric.py / hr.py "all" values)
+  double w_min_dce = INFINITY, w_min_ttc = INFINITY, w_min_ttce = INFINITY;
+  double w_max_er = 0.0, w_max_or = 0.0, w_max_eh = 0.0, w_max_oh = 0.0, w_max_cp = 0.0, w_max_hwc = 0.0;
+  double w_arg_dce = -1.0, w_arg_ttc = -1.0, w_arg_or = -1.0, w_dce_flag = 0.0;
+
+  const int k0 = (chunk * WAVES + wave) * a.apw;
+  for (int kk = 0; kk < a.apw; ++kk) {
+    const int k = k0 + kk;
+    if (k >= A) break;
+    const double *G = a.atab + (size_t)k * a.Ta * NAF;
+    const double *C = a.acst + (size_t)k * NAC;
+    const double hlB = C[0], hwB = C[1], hdev = C[2], f_ego = C[3], f_obs = C[4];
+    const int prot = (int)C[5], L = (int)C[6];
+    const int Lh = min(Tm1, L);
+
+    double dce = INFINITY;
+    int tdce = 0;
+    bool done = false;
+    double max_er = -INFINITY, max_or = -INFINITY, max_eh = -INFINITY, max_oh = -INFINITY, max_cp = -INFINITY;
+    double oh_at_cp = 0.0;
+    int idx_or = 0, idx_cp = 0;
+
+    double ex = tj[0 * Mp], ey = tj[1 * Mp], ec = tj[2 * Mp], es = tj[3 * Mp], eth = tj[4 * Mp], ev = tj[5 * Mp];
+    for (int t = 0; t < T; ++t) {
+      const int tn = min(t + 1, T - 1);
+      const double *tjn = tj + (size_t)tn * NEF * Mp;
+      const double ex1 = tjn[0 * Mp], ey1 = tjn[1 * Mp], ec1 = tjn[2 * Mp], es1 = tjn[3 * Mp], eth1 = tjn[4 * Mp],
+                   ev1 = tjn[5 * Mp];
+      const double *g = G + (size_t)min(t, L - 1) * NAF;
+      const double px = g[0], py = g[1], pc = g[2], ps = g[3], pth = g[4], pv = g[5], isx = g[6], isy = g[7];
+      const double cr = pc * ec + ps * es;  // cos(yaw - theta)
+      const double sr = ps * ec - pc * es;  // sin(yaw - theta)
+
+      // ---------------- DCE (dce.py:69-88): oriented rectangle distance, rounded to 1e-3, first minimum, stop at 0
+      if (do_dce && t < L) {
+        const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
+        const double dx = px - ccx, dy = py - ccy;
+        // agent centre / half axes in the ego frame
+        const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;
+        const double ux = hlB * cr, uy = hlB * sr, wx = -hwB * sr, wy = hwB * cr;
+        // ego centre / half axes in the agent frame
+        const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);
+        const double vx = a.hlA * cr, vy = -a.hlA * sr, zx = a.hwA * sr, zy = a.hwA * cr;
+        const bool sep = (fabs(ax) > a.hlA + fabs(ux) + fabs(wx)) || (fabs(ay) > a.hwA + fabs(uy) + fabs(wy)) ||
+                         (fabs(bx) > hlB + fabs(vx) + fabs(zx)) || (fabs(by) > hwB + fabs(vy) + fabs(zy));
+        double d2 = 0.0;
+        if (sep) {
+          d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, a.hlA, a.hwA);
+          d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, a.hlA, a.hwA));
+          d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, a.hlA, a.hwA));
+          d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, a.hlA, a.hwA));
+          d2 = fmin(d2, fo_pt_box2(bx + vx + zx, by + vy + zy, hlB, hwB));
+          d2 = fmin(d2, fo_pt_box2(bx + vx - zx, by + vy - zy, hlB, hwB));
+          d2 = fmin(d2, fo_pt_box2(bx - vx + zx, by - vy + zy, hlB, hwB));
+          d2 = fmin(d2, fo_pt_box2(bx - vx - zx, by - vy - zy, hlB, hwB));
+        }
+        const double dist = fo_round3(sqrt(d2));
+        if (!done && dist < dce) { dce = dist; tdce = t; }
+        if (dce == 0.0) done = true;
+      }
+
+      if (t < Tm1 && (do_cp || do_hr)) {
+        // ---------------- CP (collision_probability.py:69-122): ego sample t+1, agent mean/cov t, agent yaw t+1 (Q1)
+        double cp = 0.0;
+        if (t + 1 < L) {
+          const double pc1 = g[NAF + 2], ps1 = g[NAF + 3];
+          const double devx = pc1 * hdev, devy = ps1 * hdev;
+          const double rx = ex1 - px, ry = ey1 - py;  // ego(t+1) - mean
+          const double d0 = rx * rx + ry * ry;
+          const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
+          const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
+          if (!(sqrt(fmin(d0, fmin(dp, dm))) > 5.0)) {  // :67,75
+            const double bxs = a.len3 * ec1, bys = a.len3 * es1;  // box centre step (L/3 along heading), rear-axle based (Q2)
+            double acc = 0.0;
+#pragma unroll
+            for (int jm = -1; jm <= 1; ++jm) {    // three means
+              const double qx = rx - jm * devx, qy = ry - jm * devy;  // ego - mean_j
+#pragma unroll
+              for (int b = -1; b <= 1; ++b) {     // three boxes
+                const double cx = qx + b * bxs, cy = qy + b * bys;
+                const double fx = fo_phi_diff((cx - a.off_x) * isx, (cx + a.off_x) * isx);
+                const double fy = fo_phi_diff((cy - a.off_y) * isy, (cy + a.off_y) * isy);
+                acc += fx * fy;
+              }
+            }
+            cp = acc / 3.0;  // :122
+          }
+        }
+        // ---------------- harm (harm_model.py:80-107) + risk (hr.py:78-79), same index on both sides
+        double eh = NAN, oh = NAN, er = NAN, orr = NAN;
+        if (do_hr && t < Lh) {
+          const double rel = atan2(py - ey, px - ex);
+          const double ego_ang = rel - eth;
+          const double obs_ang = M_PI + rel - pth;
+          const double dv = sqrt(fmax(ev * ev + pv * pv - 2.0 * ev * pv * cr, 0.0));  // cos(pdof) = -cos(yaw-theta)
+          const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
+          if (prot == 1) {
+            eh = 1.0 / (1.0 + exp(-a.hc.lr4s_const - a.hc.lr4s_speed * ego_dv -
+                                  fo_lr4s_coef(ego_ang, a.hc.lr4s_side, a.hc.lr4s_rear)));
+            oh = 1.0 / (1.0 + exp(-a.hc.lr4s_const - a.hc.lr4s_speed * obs_dv -
+                                  fo_lr4s_coef(obs_ang, a.hc.lr4s_side, a.hc.lr4s_rear)));
+          } else if (prot == 0) {
+            eh = 1.0 / (1.0 + exp(-a.hc.lr1s_const - a.hc.lr1s_speed * ego_dv));
+            oh = 1.0 / (1.0 + exp(a.hc.ped_const - a.hc.ped_speed * obs_dv));
+          } else {
+            eh = 1.0;
+            oh = 1.0;
+          }
+          er = eh * cp;
+          orr = oh * cp;
+          max_er = fmax(max_er, er);
+          if (orr > max_or) { max_or = orr; idx_or = t; }
+          max_eh = fmax(max_eh, eh);
+          max_oh = fmax(max_oh, oh);
+        }
+        if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
+        if (LISTS && valid) {
+          double *l = a.lists + ((size_t)k * Tm1 + t) * M + m;
+          const size_t ls = (size_t)A * Tm1 * M;
+          __builtin_nontemporal_store(cp, l + FO_L_CP * ls);
+          __builtin_nontemporal_store(eh, l + FO_L_EGO_HARM * ls);
+          __builtin_nontemporal_store(oh, l + FO_L_OBST_HARM * ls);
+          __builtin_nontemporal_store(er, l + FO_L_EGO_RISK * ls);
+          __builtin_nontemporal_store(orr, l + FO_L_OBST_RISK * ls);
+        }
+      }
+      ex = ex1; ey = ey1; ec = ec1; es = es1; eth = eth1; ev = ev1;
+    }
+
+    // ---------------- per-pair scalars
+    const double ttc = (fabs(dce) <= 1e-8) ? fo_round3((double)tdce * a.dt) : INFINITY;  // ttc.py:43-46
+    const double ttce = fo_round3((double)tdce * a.dt);                                   // ttce.py:39
+    const bool hr_valid = do_hr && Lh > 0;
+    const double hwc = (max_cp > 0.01) ? oh_at_cp : 0.0;                                   // hr.py:81-84
+    if (PAIR && valid) {
+      const size_t ps_ = (size_t)A * M;
+      double *pf = a.pair_f + (size_t)k * M + m;
+      pf[FO_PF_DCE * ps_] = do_dce ? dce : NAN;
+      pf[FO_PF_TTC * ps_] = do_ttc ? ttc : NAN;
+      pf[FO_PF_TTCE * ps_] = do_ttce ? ttce : NAN;
+      pf[FO_PF_MAX_EGO_RISK * ps_] = hr_valid ? max_er : NAN;
+      pf[FO_PF_MAX_OBST_RISK * ps_] = hr_valid ? max_or : NAN;
+      pf[FO_PF_HARM_WITH_CP * ps_] = hr_valid ? hwc : NAN;
+      pf[FO_PF_MAX_EGO_HARM * ps_] = hr_valid ? max_eh : NAN;
+      pf[FO_PF_MAX_OBST_HARM * ps_] = hr_valid ? max_oh : NAN;
+      pf[FO_PF_MAX_CP * ps_] = hr_valid ? max_cp : NAN;
+      pf[FO_PF_BE_DECEL * ps_] = NAN;
+      pf[FO_PF_BE_BTN * ps_] = NAN;
+      pf[FO_PF_SPARE * ps_] = NAN;
+      int32_t *pi = a.pair_i + (size_t)k * M + m;
+      pi[FO_PI_TIME_DCE * ps_] = do_dce ? tdce : 0;
+      pi[FO_PI_RISK_INDEX * ps_] = hr_valid ? idx_or : 0;
+      pi[FO_PI_CP_ARGMAX * ps_] = hr_valid ? idx_cp : 0;
+      pi[FO_PI_HR_VALID * ps_] = hr_valid ? 1 : 0;
+    }
+    // ---------------- fold into the wave's running "all agents" values (first-wins on ties = ascending k)
+    if (do_dce) {
+      if (dce < w_min_dce) { w_min_dce = dce; w_arg_dce = (double)k; }
+      if (dce < a.thr_dce) w_dce_flag = 1.0;  // thr NaN -> never
+      if (do_ttc && ttc < w_min_ttc) { w_min_ttc = ttc; w_arg_ttc = (double)k; }
+      if (do_ttce) w_min_ttce = fmin(w_min_ttce, ttce);
+    }
+    if (hr_valid) {
+      w_max_er = fmax(w_max_er, max_er);
+      if (max_or > w_max_or) { w_max_or = max_or; w_arg_or = (double)k; }
+      w_max_eh = fmax(w_max_eh, max_eh);
+      w_max_oh = fmax(w_max_oh, max_oh);
+      w_max_cp = fmax(w_max_cp, max_cp);
+      w_max_hwc = fmax(w_max_hwc, hwc);
+    }
+  }
+
+  // ---------------- combine the four waves (ascending agent order) and write one partial per (chunk, trajectory)
+  if (wave > 0) {
+    double *rp = red + (size_t)(wave - 1) * NPS * TILE + lane;
+    rp[PS_MIN_DCE * TILE] = w_min_dce; rp[PS_ARG_DCE * TILE] = w_arg_dce; rp[PS_MIN_TTC * TILE] = w_min_ttc;
+    rp[PS_ARG_TTC * TILE] = w_arg_ttc; rp[PS_MIN_TTCE * TILE] = w_min_ttce; rp[PS_MAX_ER * TILE] = w_max_er;
+    rp[PS_MAX_OR * TILE] = w_max_or; rp[PS_ARG_OR * TILE] = w_arg_or; rp[PS_MAX_EH * TILE] = w_max_eh;
+    rp[PS_MAX_OH * TILE] = w_max_oh; rp[PS_MAX_CP * TILE] = w_max_cp; rp[PS_MAX_HWC * TILE] = w_max_hwc;
+    rp[PS_DCE_FLAG * TILE] = w_dce_flag; rp[PS_MAX_BTN * TILE] = 0.0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 0; w < WAVES - 1; ++w) {
+      const double *rp = red + (size_t)w * NPS * TILE + lane;
+      if (rp[PS_MIN_DCE * TILE] < w_min_dce) { w_min_dce = rp[PS_MIN_DCE * TILE]; w_arg_dce = rp[PS_ARG_DCE * TILE]; }
+      if (rp[PS_MIN_TTC * TILE] < w_min_ttc) { w_min_ttc = rp[PS_MIN_TTC * TILE]; w_arg_ttc = rp[PS_ARG_TTC * TILE]; }
+      w_min_ttce = fmin(w_min_ttce, rp[PS_MIN_TTCE * TILE]);
+      w_max_er = fmax(w_max_er, rp[PS_MAX_ER * TILE]);
+      if (rp[PS_MAX_OR * TILE] > w_max_or) { w_max_or = rp[PS_MAX_OR * TILE]; w_arg_or = rp[PS_ARG_OR * TILE]; }
+      w_max_eh = fmax(w_max_eh, rp[PS_MAX_EH * TILE]);
+      w_max_oh = fmax(w_max_oh, rp[PS_MAX_OH * TILE]);
+      w_max_cp = fmax(w_max_cp, rp[PS_MAX_CP * TILE]);
+      w_max_hwc = fmax(w_max_hwc, rp[PS_MAX_HWC * TILE]);
+      w_dce_flag = fmax(w_dce_flag, rp[PS_DCE_FLAG * TILE]);
+    }
+    double *pp = a.partial + (size_t)chunk * NPS * Mp + (size_t)tile * TILE + lane;
+    pp[PS_MIN_DCE * Mp] = w_min_dce; pp[PS_ARG_DCE * Mp] = w_arg_dce; pp[PS_MIN_TTC * Mp] = w_min_ttc;
+    pp[PS_ARG_TTC * Mp] = w_arg_ttc; pp[PS_MIN_TTCE * Mp] = w_min_ttce; pp[PS_MAX_ER * Mp] = w_max_er;
+    pp[PS_MAX_OR * Mp] = w_max_or; pp[PS_ARG_OR * Mp] = w_arg_or; pp[PS_MAX_EH * Mp] = w_max_eh;
+    pp[PS_MAX_OH * Mp] = w_max_oh; pp[PS_MAX_CP * Mp] = w_max_cp; pp[PS_MAX_HWC * Mp] = w_max_hwc;
+    pp[PS_DCE_FLAG * Mp] = w_dce_flag; pp[PS_MAX_BTN * Mp] = 0.0;
+  }
+}
+
+// fold the per-chunk partials into the cost vector + safety flag (metric.py:50-100, hr.py:101-114, wttc.py:32-42)
+__global__ void fo_reduce_kernel(int M, int Mp, int A, int n_chunks, const double *__restrict__ partial,
+                                 fo_thresholds_t thr, uint32_t mask, double *__restrict__ cost,
+                                 uint8_t *__restrict__ safe) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double min_dce = INFINITY, arg_dce = -1, min_ttc = INFINITY, arg_ttc = -1, min_ttce = INFINITY;
+  double max_er = 0, max_or = 0, arg_or = -1, max_eh = 0, max_oh = 0, max_cp = 0, max_hwc = 0, flag = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const double *p = partial + (size_t)c * NPS * Mp + m;
+    if (p[PS_MIN_DCE * (size_t)Mp] < min_dce) { min_dce = p[PS_MIN_DCE * (size_t)Mp]; arg_dce = p[PS_ARG_DCE * (size_t)Mp]; }
+    if (p[PS_MIN_TTC * (size_t)Mp] < min_ttc) { min_ttc = p[PS_MIN_TTC * (size_t)Mp]; arg_ttc = p[PS_ARG_TTC * (size_t)Mp]; }
+    min_ttce = fmin(min_ttce, p[PS_MIN_TTCE * (size_t)Mp]);
+    max_er = fmax(max_er, p[PS_MAX_ER * (size_t)Mp]);
+    if (p[PS_MAX_OR * (size_t)Mp] > max_or) { max_or = p[PS_MAX_OR * (size_t)Mp]; arg_or = p[PS_ARG_OR * (size_t)Mp]; }
+    max_eh = fmax(max_eh, p[PS_MAX_EH * (size_t)Mp]);
+    max_oh = fmax(max_oh, p[PS_MAX_OH * (size_t)Mp]);
+    max_cp = fmax(max_cp, p[PS_MAX_CP * (size_t)Mp]);
+    max_hwc = fmax(max_hwc, p[PS_MAX_HWC * (size_t)Mp]);
+    flag = fmax(flag, p[PS_DCE_FLAG * (size_t)Mp]);
+  }
+  bool ok = true;
+  if (A > 0) {  // no agents -> ({}, True)  (metric.py:44-45)
+    if ((mask & FO_M_HR) && max_hwc > thr.harm) ok = false;  // NaN thresholds compare false = disabled
+    if ((mask & FO_M_HR) && max_or > thr.risk) ok = false;
+    if ((mask & FO_M_HR) && max_cp > thr.cp) ok = false;
+    if ((mask & FO_M_TTC) && min_ttc < thr.ttc) ok = false;
+    if ((mask & FO_M_DCE) && flag > 0.0) ok = false;
+  }
+  double *c = cost + (size_t)m * FO_NC;
+  c[FO_C_WTTC] = min_ttc; c[FO_C_MIN_DCE] = min_dce; c[FO_C_MAX_EGO_RISK] = max_er; c[FO_C_MAX_OBST_RISK] = max_or;
+  c[FO_C_MAX_EGO_HARM] = max_eh; c[FO_C_MAX_OBST_HARM] = max_oh; c[FO_C_MAX_CP] = max_cp;
+  c[FO_C_HARM_WITH_CP] = max_hwc; c[FO_C_MIN_TTCE] = min_ttce; c[FO_C_ARGMIN_DCE] = arg_dce;
+  c[FO_C_ARGMIN_TTC] = arg_ttc; c[FO_C_ARGMAX_RISK] = arg_or; c[FO_C_SAFE] = ok ? 1.0 : 0.0; c[FO_C_MAX_BTN] = 0.0;
+  c[FO_C_RES0] = 0.0; c[FO_C_RES1] = 0.0;
+  safe[m] = ok ? 1 : 0;
+}
+
+uint32_t required_metrics(uint32_t m) {  // metric.py:125-147
+  if (m & FO_M_WTTC) m |= FO_M_TTC;
+  if (m & (FO_M_TTC | FO_M_TTCE | FO_M_BE)) m |= FO_M_DCE;
+  if (m & FO_M_HR) m |= FO_M_CP;
+  return m;
+}
+
+inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+// agents per wave: enough workgroups to fill 256 CUs several times over, but no more partial rows than needed
+int pick_apw(int n_tiles, int A) {
+  int apw = 8;
+  while (apw > 1 && (long)n_tiles * ((A + WAVES * apw - 1) / (WAVES * apw)) < 2048) apw >>= 1;
+  return apw;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fo_sweep_configure(fo_ctx *ctx, const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, const fo_thresholds_t *thr,
+                       uint32_t metric_mask, double dt) {
+  if (!ctx || !veh || !hc || !thr) return fo_fail(ctx, FO_E_ARG, "fo_sweep_configure: null argument");
+  if (!(veh->length > 0) || !(veh->width > 0) || !(dt > 0)) return fo_fail(ctx, FO_E_ARG, "fo_sweep_configure: bad vehicle/dt");
+  if (metric_mask & FO_M_BE) return fo_fail(ctx, FO_E_ARG, "fo_sweep_configure: metric 'be' is not implemented in this build");
+  ctx->veh = *veh; ctx->hc = *hc; ctx->thr = *thr; ctx->dt = dt;
+  ctx->mask = required_metrics(metric_mask);
+  ctx->configured = true;
+  return FO_OK;
+}
+
+int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
+  if (!ctx || max_M < 0 || max_T < 1 || max_A < 0 || max_Ta < 0) return fo_fail(ctx, FO_E_ARG, "fo_sweep_reserve: bad sizes");
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int Mp = round_up(max_M > 0 ? max_M : 1, TILE);
+  int rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)max_T * NEF * Mp))) return rc;
+  // worst case number of chunks: one agent per wave
+  const size_t chunks = (size_t)(max_A + WAVES - 1) / WAVES + 1;
+  if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, chunks * NPS * Mp))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) * NAF))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(max_A > 0 ? max_A : 1) * NAC))) return rc;
+  return FO_OK;
+}
+
+int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const double *d_yaw, const double *d_v,
+                        const double *d_cov, const double *d_shape, const double *d_raw_dims, const int32_t *d_type,
+                        const int32_t *d_len, void *stream) {
+  if (!ctx) return FO_E_ARG;
+  if (!ctx->configured) return fo_fail(ctx, FO_E_STATE, "fo_sweep_set_agents: call fo_sweep_configure first");
+  if (A < 0 || (A > 0 && (Ta < 1 || !d_pos || !d_yaw || !d_v || !d_cov || !d_shape || !d_raw_dims || !d_type || !d_len)))
+    return fo_fail(ctx, FO_E_ARG, "fo_sweep_set_agents: bad arguments (A=%d Ta=%d)", A, Ta);
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(A > 0 ? A : 1) * Ta * NAF))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(A > 0 ? A : 1) * NAC))) return rc;
+  ctx->A = A;
+  ctx->Ta = Ta;
+  FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), s));
+  if (A > 0) {
+    const int n = A * Ta;
+    hipLaunchKernelGGL(fo_prep_agents_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, Ta, d_pos, d_yaw, d_v, d_cov,
+                       d_shape, d_raw_dims, d_type, d_len, ctx->veh.mass, ctx->d_agent_tab, ctx->d_agent_const,
+                       ctx->d_status);
+    FO_HIP_TRY(ctx, hipGetLastError());
+  }
+  return FO_OK;
+}
+
+int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
+                 const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
+                 int32_t *d_pair_i, double *d_lists, void *stream) {
+  (void)d_a;
+  if (!ctx) return FO_E_ARG;
+  if (!ctx->configured) return fo_fail(ctx, FO_E_STATE, "fo_sweep_run: call fo_sweep_configure first");
+  if (M < 0 || T < 1 || (M > 0 && (!d_x || !d_y || !d_theta || !d_v || !d_cost || !d_safe)))
+    return fo_fail(ctx, FO_E_ARG, "fo_sweep_run: bad arguments (M=%d T=%d)", M, T);
+  if ((d_pair_f == nullptr) != (d_pair_i == nullptr)) return fo_fail(ctx, FO_E_ARG, "fo_sweep_run: pair_f and pair_i go together");
+  if (d_lists && !d_pair_f) return fo_fail(ctx, FO_E_ARG, "fo_sweep_run: lists output requires the pair outputs");
+  if (M == 0) return FO_OK;
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int A = ctx->A, Ta = ctx->Ta;
+  if (d_lists && A > 0 && T > 1 && !(ctx->mask & (FO_M_CP | FO_M_HR)))  // nothing will write them: all-ones = NaN
+    FO_HIP_TRY(ctx, hipMemsetAsync(d_lists, 0xFF, sizeof(double) * FO_NL * (size_t)A * (T - 1) * M, s));
+  const int Mp = round_up(M, TILE);
+  const int n_tiles = Mp / TILE;
+  const int apw = pick_apw(n_tiles, A);
+  const int n_chunks = A > 0 ? (A + WAVES * apw - 1) / (WAVES * apw) : 0;
+  int rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)T * NEF * Mp))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)(n_chunks + 1) * NPS * Mp))) return rc;
+
+  if (A > 0) {
+    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles), dim3(256), (size_t)T * (TILE + 1) * sizeof(double), s, M, T,
+                       Mp, d_x, d_y, d_theta, d_v, ctx->d_traj_tab);
+    FO_HIP_TRY(ctx, hipGetLastError());
+    SweepArgs a{};
+    a.M = M; a.Mp = Mp; a.T = T; a.A = A; a.Ta = Ta; a.n_tiles = n_tiles; a.nt8 = (n_tiles + 7) / 8; a.apw = apw;
+    a.traj = ctx->d_traj_tab; a.atab = ctx->d_agent_tab; a.acst = ctx->d_agent_const; a.partial = ctx->d_partial;
+    a.pair_f = d_pair_f; a.pair_i = d_pair_i; a.lists = d_lists;
+    a.hlA = 0.5 * ctx->veh.length; a.hwA = 0.5 * ctx->veh.width; a.wb = ctx->veh.wb_rear_axle;
+    a.len3 = ctx->veh.length / 2.0 * (2.0 / 3.0);  // r_x * (2/3)  (collision_probability.py:160-161)
+    a.off_x = ctx->veh.length / 6.0; a.off_y = ctx->veh.width / 2.0;
+    a.hc = ctx->hc; a.dt = ctx->dt; a.thr_dce = ctx->thr.dce; a.mask = ctx->mask;
+    const int grid = a.nt8 * 8 * n_chunks;
+    ctx->last_grid = grid; ctx->last_block = TILE * WAVES; ctx->last_apw = apw;
+    const bool timed = ctx->timing && ctx->n_timed < fo_ctx::kMaxTimed;
+    if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[ctx->n_timed], s));
+    if (d_lists) hipLaunchKernelGGL((fo_sweep_kernel<true, true>), dim3(grid), dim3(TILE * WAVES), 0, s, a);
+    else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_kernel<true, false>), dim3(grid), dim3(TILE * WAVES), 0, s, a);
+    else hipLaunchKernelGGL((fo_sweep_kernel<false, false>), dim3(grid), dim3(TILE * WAVES), 0, s, a);
+    FO_HIP_TRY(ctx, hipGetLastError());
+    if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop[ctx->n_timed++], s));
+  }
+  hipLaunchKernelGGL(fo_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, Mp, A, n_chunks, ctx->d_partial,
+                     ctx->thr, ctx->mask, d_cost, d_safe);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  return FO_OK;
+}
+
+int fo_sweep_timing(fo_ctx *ctx, int enable) {
+  if (!ctx) return FO_E_ARG;
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (enable && !ctx->ev_start) {
+    ctx->ev_start = new hipEvent_t[fo_ctx::kMaxTimed];
+    ctx->ev_stop = new hipEvent_t[fo_ctx::kMaxTimed];
+    for (int i = 0; i < fo_ctx::kMaxTimed; ++i) {
+      FO_HIP_TRY(ctx, hipEventCreate(&ctx->ev_start[i]));
+      FO_HIP_TRY(ctx, hipEventCreate(&ctx->ev_stop[i]));
+    }
+  }
+  ctx->timing = enable != 0;
+  ctx->n_timed = 0;
+  return FO_OK;
+}
+
+int fo_sweep_timing_read(fo_ctx *ctx, double *total_ms, int *launches) {
+  if (!ctx || !total_ms || !launches) return FO_E_ARG;
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  double sum = 0.0;
+  for (int i = 0; i < ctx->n_timed; ++i) {
+    float ms = 0.f;
+    FO_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop[i]));
+    FO_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = ctx->n_timed;
+  ctx->n_timed = 0;
+  return FO_OK;
+}
+
+int fo_sweep_last_launch(const fo_ctx *ctx, int *grid, int *block, int *agents_per_wave) {
+  if (!ctx) return FO_E_ARG;
+  if (grid) *grid = ctx->last_grid;
+  if (block) *block = ctx->last_block;
+  if (agents_per_wave) *agents_per_wave = ctx->last_apw;
+  return FO_OK;
+}
+
+}  // extern "C"

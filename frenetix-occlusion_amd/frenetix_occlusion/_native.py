@@ -1,0 +1,140 @@
+"""ctypes binding of libfo_hip.so (C ABI: include/fo_hip.h).
+
+The HIP library is the product path.  There is NO CPU fallback: if the library is missing, fails to load, or no
+GPU is visible, every entry point raises.  PyTorch is used only as the owner of device memory and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfo_hip.so")
+
+FO_OK, FO_E_ARG, FO_E_UNSUPPORTED_COV, FO_E_HIP, FO_E_NOMEM, FO_E_STATE = 0, -1, -2, -3, -4, -5
+NPF, NPI, NL, NC = 12, 4, 5, 16
+
+PF = {"dce": 0, "ttc": 1, "ttce": 2, "max_ego_risk": 3, "max_obst_risk": 4, "max_obst_harm_with_cp": 5,
+      "max_ego_harm": 6, "max_obst_harm": 7, "max_collision_probability": 8, "be_decel": 9, "be_btn": 10}
+PI = {"time_dce": 0, "max_obst_risk_index": 1, "cp_argmax": 2, "hr_valid": 3}
+LST = {"cp": 0, "ego_harm": 1, "obst_harm": 2, "ego_risk": 3, "obst_risk": 4}
+COST = {"wttc": 0, "min_dce": 1, "max_ego_risk_all": 2, "max_obst_risk_all": 3, "max_ego_harm_all": 4,
+        "max_obst_harm_all": 5, "max_collision_probability_all": 6, "max_obst_harm_with_cp_all": 7, "min_ttce": 8,
+        "argmin_dce": 9, "argmin_ttc": 10, "argmax_risk": 11, "safe": 12, "max_btn": 13}
+METRIC_BITS = {"dce": 1, "cp": 2, "ttc": 4, "ttce": 8, "wttc": 16, "be": 32, "hr": 64}
+TYPE_CODES = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4, "priorityvehicle": 5,
+              "parkedvehicle": 6, "train": 7, "motorcycle": 8, "taxi": 9, "unknown": 10}
+
+# every symbol include/fo_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "fo_abi_version", "fo_create", "fo_destroy", "fo_last_error",
+    "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
+    "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read",
+]
+
+
+class Vehicle(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("length", "width", "wb_rear_axle", "mass", "a_max")]
+
+
+class HarmCoeff(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("lr4s_const", "lr4s_speed", "lr4s_side", "lr4s_rear", "lr1s_const",
+                                          "lr1s_speed", "ped_const", "ped_speed")]
+
+
+class Thresholds(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("harm", "risk", "be", "cp", "ttc", "dce")]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfo_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libfo_hip.so or raise (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
+    lib.fo_abi_version.restype = C.c_int
+    lib.fo_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.fo_destroy.argtypes = [vp]
+    lib.fo_destroy.restype = None
+    lib.fo_last_error.argtypes = [vp]
+    lib.fo_last_error.restype = C.c_char_p
+    lib.fo_sweep_configure.argtypes = [vp, C.POINTER(Vehicle), C.POINTER(HarmCoeff), C.POINTER(Thresholds),
+                                       C.c_uint32, C.c_double]
+    lib.fo_sweep_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.fo_sweep_set_agents.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, vp]
+    lib.fo_sweep_run.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, vp]
+    lib.fo_sweep_check.argtypes = [vp, vp]
+    lib.fo_sweep_timing.argtypes = [vp, C.c_int]
+    lib.fo_sweep_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.fo_sweep_last_launch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("fo_destroy", "fo_last_error"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def metric_mask(names):
+    m = 0
+    for n in names:
+        if n not in METRIC_BITS:
+            raise ValueError(f"unknown metric '{n}'")
+        m |= METRIC_BITS[n]
+    return m
+
+
+def make_thresholds(d=None):
+    d = d or {}
+    return Thresholds(*[float("nan") if d.get(k) is None else float(d[k])
+                        for k in ("harm", "risk", "be", "cp", "ttc", "dce")])
+
+
+class Context:
+    """Owns one fo_ctx (one ego vehicle on one GPU)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        rc = self._lib.fo_create(C.byref(self._h), int(device))
+        if rc != FO_OK:
+            raise NativeError(rc, "fo_create failed (is a gfx950 GPU visible? there is no CPU fallback)")
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.fo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != FO_OK:
+            raise NativeError(rc, self._lib.fo_last_error(self._h).decode())
+
+    def call(self, name, *args):
+        self._check(getattr(self._lib, name)(self._h, *args))
+
+    def timing(self, enable=True):
+        self.call("fo_sweep_timing", 1 if enable else 0)
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_int()
+        self._check(self._lib.fo_sweep_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_launch(self):
+        g, b, a = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.fo_sweep_last_launch(self._h, C.byref(g), C.byref(b), C.byref(a)))
+        return {"grid": g.value, "block": b.value, "agents_per_wave": a.value}

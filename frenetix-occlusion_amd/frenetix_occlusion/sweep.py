@@ -1,0 +1,106 @@
+"""Batched trajectory x agent criticality sweep on the GPU (host side).
+
+Mirrors what M calls of the reference's ``Metric.evaluate_metrics`` compute (metrics/metric.py:35-100), but for the
+whole candidate batch in one launch of the HIP kernel behind ``fo_sweep_run`` (include/fo_hip.h).
+PyTorch only owns the device buffers and the stream; all arithmetic happens in libfo_hip.so.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+# entries of harm_params.json that the reference reads (config/harm_params.json:26-29,40-45,98-101)
+DEFAULT_HARM_COEFF = dict(lr4s_const=-4.457, lr4s_speed=0.177, lr4s_side=0.244, lr4s_rear=-0.431,
+                          lr1s_const=-4.591, lr1s_speed=0.185, ped_const=3.164, ped_speed=0.288)
+DEFAULT_METRICS = ("hr", "ttc", "ttce", "dce", "wttc", "cp")  # config/config.yaml:6-12
+
+
+@dataclass
+class SweepResult:
+    cost: torch.Tensor                    # [M, 16] float64
+    safe: torch.Tensor                    # [M] uint8
+    pair_f: Optional[torch.Tensor] = None  # [12, A, M] float64
+    pair_i: Optional[torch.Tensor] = None  # [4, A, M] int32
+    lists: Optional[torch.Tensor] = None   # [5, A, T-1, M] float64
+
+
+def _vehicle_tuple(vp):
+    if isinstance(vp, (tuple, list, np.ndarray)):
+        return tuple(float(q) for q in vp)
+    return tuple(float(getattr(vp, k)) for k in ("length", "width", "wb_rear_axle", "mass", "a_max"))
+
+
+class MetricSweep:
+    def __init__(self, vehicle_params, dt, metrics=DEFAULT_METRICS, thresholds=None, harm_coeff=None, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("MetricSweep needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
+        self.ctx = N.Context(self.device.index)
+        self.dt = float(dt)
+        self.metrics = tuple(metrics)
+        self.A = 0
+        self.Ta = 0
+        self._agent_tensors = None
+        self.configure(vehicle_params, thresholds, harm_coeff)
+
+    def configure(self, vehicle_params, thresholds=None, harm_coeff=None, metrics=None):
+        if metrics is not None:
+            self.metrics = tuple(metrics)
+        self.vehicle = _vehicle_tuple(vehicle_params)
+        veh = N.Vehicle(*self.vehicle)
+        hc = N.HarmCoeff(**(harm_coeff or DEFAULT_HARM_COEFF))
+        thr = thresholds if isinstance(thresholds, N.Thresholds) else N.make_thresholds(thresholds)
+        self.ctx.call("fo_sweep_configure", veh, hc, thr, N.metric_mask(self.metrics), self.dt)
+
+    def reserve(self, M, T, A, Ta):
+        self.ctx.call("fo_sweep_reserve", int(M), int(T), int(A), int(Ta))
+
+    def _dev(self, t, dtype=torch.float64):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.ascontiguousarray(t))
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def set_agents(self, pos, yaw, v, cov, shape, raw_dims, type, len, check=True):
+        """pos [A,Ta,2], yaw/v [A,Ta], cov [A,Ta,2,2], shape/raw_dims [A,2], type/len [A] (numpy or torch)."""
+        pos, yaw, v, cov = self._dev(pos), self._dev(yaw), self._dev(v), self._dev(cov)
+        shape, raw = self._dev(shape), self._dev(raw_dims)
+        typ, ln = self._dev(type, torch.int32), self._dev(len, torch.int32)
+        A = int(pos.shape[0])
+        Ta = int(pos.shape[1]) if A else 0
+        if A:
+            assert pos.shape == (A, Ta, 2) and yaw.shape == (A, Ta) and v.shape == (A, Ta)
+            assert cov.numel() == A * Ta * 4 and shape.shape == (A, 2) and raw.shape == (A, 2)
+        self._agent_tensors = (pos, yaw, v, cov, shape, raw, typ, ln)  # keep alive until the stream has consumed them
+        p = lambda t: t.data_ptr() if t.numel() else None
+        self.ctx.call("fo_sweep_set_agents", A, Ta, p(pos), p(yaw), p(v), p(cov), p(shape), p(raw), p(typ), p(ln),
+                      self._stream())
+        self.A, self.Ta = A, Ta
+        if check:
+            self.ctx.call("fo_sweep_check", self._stream())
+
+    def run(self, x, y, theta, v, a=None, mode="reduced", out: Optional[SweepResult] = None) -> SweepResult:
+        """x,y,theta,v[,a]: [M,T].  mode: 'reduced' (cost+safe), 'pair' (+ per-pair scalars), 'full' (+ lists)."""
+        x, y, theta, v = self._dev(x), self._dev(y), self._dev(theta), self._dev(v)
+        a = self._dev(a) if a is not None else None
+        M, T = int(x.shape[0]), int(x.shape[1])
+        A = self.A
+        if out is None:
+            out = SweepResult(cost=torch.empty((M, N.NC), dtype=torch.float64, device=self.device),
+                              safe=torch.empty((M,), dtype=torch.uint8, device=self.device))
+            if mode in ("pair", "full"):
+                out.pair_f = torch.empty((N.NPF, A, M), dtype=torch.float64, device=self.device)
+                out.pair_i = torch.empty((N.NPI, A, M), dtype=torch.int32, device=self.device)
+            if mode == "full":
+                out.lists = torch.empty((N.NL, A, max(T - 1, 0), M), dtype=torch.float64, device=self.device)
+        p = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
+        self._last_inputs = (x, y, theta, v, a)
+        self.ctx.call("fo_sweep_run", M, T, p(x), p(y), p(theta), p(v), p(a), p(out.cost), p(out.safe),
+                      p(out.pair_f), p(out.pair_i), p(out.lists), self._stream())
+        return out

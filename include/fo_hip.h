@@ -1,0 +1,111 @@
+/* fo_hip.h -- C ABI of the MI355X (gfx950) implementation of the Frenetix-Occlusion per-timestep hot path.
+ *
+ * Shared library: frenetix-occlusion_amd/lib/libfo_hip.so  (built by __graft_entry__.build()).
+ * All pointers named d_* are DEVICE pointers (HBM), caller-owned, and must stay valid until the work queued on
+ * `stream` (a hipStream_t passed as void*; NULL = the default stream) has completed.  No torch types, no C++
+ * types, no exceptions cross this boundary: every entry point returns 0 or a negative FO_E_* code and
+ * fo_last_error(ctx) gives the message.  One context per ego vehicle per GPU; a context is not re-entrant
+ * (same ownership model as one FOInterface instance, /root/reference/frenetix_occlusion/interface.py:85-90).
+ *
+ * Citations "ref:" are relative to /root/reference/frenetix_occlusion/.
+ *
+ * Array layouts (float64 unless noted):
+ *   trajectories  x,y,theta,v,a : [M][T]   row = one candidate trajectory (trajectory.cartesian.*, ref: interface.py:216)
+ *   agent predictions           : pos [A][Ta][2], yaw [A][Ta], v [A][Ta], cov [A][Ta][4] (xx,xy,yx,yy),
+ *                                 shape [A][2] = prediction['shape'] (inflated length,width; ref: agent.py:404-409,523-524),
+ *                                 raw_dims [A][2] = agent.shape (ref: agent.py:216), type int32 [A] (FO_TYPE_*),
+ *                                 len int32 [A] = number of valid samples of that prediction (1..Ta)
+ *   outputs, trajectory index fastest (lane = trajectory):
+ *     cost   [M][FO_NC]                 per-trajectory cost vector (the unit all-gathered across GPUs)
+ *     safe   uint8 [M]                  safety_assessment of metric.py:50-100
+ *     pair_f [FO_NPF][A][M]             per (trajectory, agent) scalars
+ *     pair_i int32 [FO_NPI][A][M]
+ *     lists  [FO_NL][A][T-1][M]         per-timestep lists of hr.py:87-98 (NaN past the reference's list length)
+ */
+#ifndef FO_HIP_H
+#define FO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FO_ABI_VERSION 1
+
+enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
+
+/* commonroad ObstacleType strings -> codes (ref: metrics/utils/harm_model.py:15-32) */
+enum {
+  FO_TYPE_CAR = 0, FO_TYPE_TRUCK = 1, FO_TYPE_BUS = 2, FO_TYPE_BICYCLE = 3, FO_TYPE_PEDESTRIAN = 4,
+  FO_TYPE_PRIORITY_VEHICLE = 5, FO_TYPE_PARKED_VEHICLE = 6, FO_TYPE_TRAIN = 7, FO_TYPE_MOTORCYCLE = 8,
+  FO_TYPE_TAXI = 9, FO_TYPE_UNKNOWN = 10, FO_TYPE_STRUCTURE = 11
+};
+
+/* activated_metrics bits (ref: metrics/metric.py:109-117; dependency closure :125-147 is applied inside) */
+enum { FO_M_DCE = 1, FO_M_CP = 2, FO_M_TTC = 4, FO_M_TTCE = 8, FO_M_WTTC = 16, FO_M_BE = 32, FO_M_HR = 64 };
+
+/* vehicle_params attributes the path reads (ref: convert_dynamic_obstacle.py:60,78; collision_probability.py:35;
+ * harm_model.py:96-97; be.py:56) */
+typedef struct { double length, width, wb_rear_axle, mass, a_max; } fo_vehicle_t;
+
+/* coefficients read from config/harm_params.json (ref: harm_params.json:26-29,40-45,98-101) */
+typedef struct {
+  double lr4s_const, lr4s_speed, lr4s_side, lr4s_rear;
+  double lr1s_const, lr1s_speed;
+  double ped_const, ped_speed;
+} fo_harm_coeff_t;
+
+/* metrics.metric_thresholds of the YAML (ref: config/config.yaml:14-22); NaN = null = check disabled */
+typedef struct { double harm, risk, be, cp, ttc, dce; } fo_thresholds_t;
+
+enum { FO_PF_DCE = 0, FO_PF_TTC, FO_PF_TTCE, FO_PF_MAX_EGO_RISK, FO_PF_MAX_OBST_RISK, FO_PF_HARM_WITH_CP,
+       FO_PF_MAX_EGO_HARM, FO_PF_MAX_OBST_HARM, FO_PF_MAX_CP, FO_PF_BE_DECEL, FO_PF_BE_BTN, FO_PF_SPARE, FO_NPF = 12 };
+enum { FO_PI_TIME_DCE = 0, FO_PI_RISK_INDEX, FO_PI_CP_ARGMAX, FO_PI_HR_VALID, FO_NPI = 4 };
+enum { FO_L_CP = 0, FO_L_EGO_HARM, FO_L_OBST_HARM, FO_L_EGO_RISK, FO_L_OBST_RISK, FO_NL = 5 };
+enum { FO_C_WTTC = 0, FO_C_MIN_DCE, FO_C_MAX_EGO_RISK, FO_C_MAX_OBST_RISK, FO_C_MAX_EGO_HARM, FO_C_MAX_OBST_HARM,
+       FO_C_MAX_CP, FO_C_HARM_WITH_CP, FO_C_MIN_TTCE, FO_C_ARGMIN_DCE, FO_C_ARGMIN_TTC, FO_C_ARGMAX_RISK,
+       FO_C_SAFE, FO_C_MAX_BTN, FO_C_RES0, FO_C_RES1, FO_NC = 16 };
+
+typedef struct fo_ctx fo_ctx;
+
+/* ---- context -------------------------------------------------------------------------------------------- */
+int fo_create(fo_ctx **out, int device);            /* replaces: FOInterface.__init__ native state (interface.py:69-131) */
+void fo_destroy(fo_ctx *ctx);
+const char *fo_last_error(const fo_ctx *ctx);       /* replaces: Python exceptions (SURVEY 8b "error conventions") */
+int fo_abi_version(void);
+
+/* ---- metric sweep: replaces M calls of FOInterface.trajectory_safety_assessment (interface.py:216-219 ->
+ *      metrics/metric.py:35-100 -> dce.py, ttc.py, ttce.py, wttc.py, cp.py, hr.py) ------------------------ */
+int fo_sweep_configure(fo_ctx *ctx, const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, const fo_thresholds_t *thr,
+                       uint32_t metric_mask, double dt);        /* Metric.__init__ (metric.py:22-33), HR._load_param */
+
+/* pre-size the context's HBM workspace so that fo_sweep_run never allocates (needed before hipGraph capture) */
+int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta);
+
+/* replaces: agent_manager.predictions (agent.py:179-183) as read by every metric */
+int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const double *d_yaw, const double *d_v,
+                        const double *d_cov, const double *d_shape, const double *d_raw_dims, const int32_t *d_type,
+                        const int32_t *d_len, void *stream);
+
+/* d_pair_f / d_pair_i / d_lists may be NULL (reduced output mode); d_cost and d_safe are required.
+ * d_a may be NULL unless FO_M_BE is active. */
+int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
+                 const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
+                 int32_t *d_pair_i, double *d_lists, void *stream);
+
+/* Blocks until `stream` has drained, then returns FO_E_UNSUPPORTED_COV if the last fo_sweep_set_agents met a
+ * covariance with non-zero off-diagonal terms (those agents' collision probabilities are NaN), else FO_OK.
+ * Replaces: the exception scipy's mvnun would raise / the silent wrong answer.  Not capturable in a hipGraph. */
+int fo_sweep_check(fo_ctx *ctx, void *stream);
+
+/* HIP-event timing of the sweep kernel alone (events recorded on the launch stream around that one kernel):
+ * enable, run K times (K <= 1024), then read the summed duration.  fo_sweep_timing_read synchronises. */
+int fo_sweep_timing(fo_ctx *ctx, int enable);
+int fo_sweep_timing_read(fo_ctx *ctx, double *total_ms, int *launches);
+
+/* launch geometry of the last sweep launch (for profiling scripts) */
+int fo_sweep_last_launch(const fo_ctx *ctx, int *grid, int *block, int *agents_per_wave);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/fo_hip.h
+declares; the host layer refuses to run without a GPU (no silent fallback)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "fo_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fo_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as g
+    g.build()
+    from frenetix_occlusion import _native
+    return _native
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = native.load()
+    declared = _declared()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/fo_hip.h but not exported"
+    assert sorted(native.EXPORTS) == declared
+    assert lib.fo_abi_version() == 1
+
+
+def test_enums_match_header(native):
+    txt = open(os.path.join(ROOT, "include", "fo_hip.h")).read()
+    assert f"FO_NPF = {native.NPF}" in txt and f"FO_NPI = {native.NPI}" in txt
+    assert f"FO_NL = {native.NL}" in txt and f"FO_NC = {native.NC}" in txt
+
+
+def test_no_gpu_means_loud_failure(native):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.NativeError):
+        native.Context(0)
+    from frenetix_occlusion.sweep import MetricSweep
+    with pytest.raises(RuntimeError):
+        MetricSweep((4.5, 1.6, 1.4, 1000.0, 11.5), 0.1)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "frenetix-occlusion_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(d, f)).read()
+                assert "fo_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
