@@ -4,10 +4,13 @@
 #include "fo_ctx.hpp"
 
 extern "C" void fo_scene_destroy_(fo_ctx *ctx);  // fo_scene.hip
+extern "C" int fo_sweep_init_(fo_ctx *ctx);      // fo_sweep.hip
 
 extern "C" {
 
 int fo_abi_version(void) { return FO_ABI_VERSION; }
+
+void fo_destroy(fo_ctx *ctx);
 
 int fo_create(fo_ctx **out, int device) {
   if (!out) return FO_E_ARG;
@@ -20,6 +23,7 @@ int fo_create(fo_ctx **out, int device) {
   ctx->device = device;
   if (hipMalloc((void **)&ctx->d_status, sizeof(int)) != hipSuccess) { delete ctx; return FO_E_NOMEM; }
   if (hipMemset(ctx->d_status, 0, sizeof(int)) != hipSuccess) { (void)hipFree(ctx->d_status); delete ctx; return FO_E_HIP; }
+  if (fo_sweep_init_(ctx) != FO_OK) { fo_destroy(ctx); return FO_E_HIP; }
   *out = ctx;
   return FO_OK;
 }
@@ -33,6 +37,7 @@ void fo_destroy(fo_ctx *ctx) {
   if (ctx->d_traj_tab) (void)hipFree(ctx->d_traj_tab);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
+  if (ctx->d_erf_tab) (void)hipFree(ctx->d_erf_tab);
   if (ctx->ev_start) {
     for (int i = 0; i < fo_ctx::kMaxTimed; ++i) { (void)hipEventDestroy(ctx->ev_start[i]); (void)hipEventDestroy(ctx->ev_stop[i]); }
     delete[] ctx->ev_start;

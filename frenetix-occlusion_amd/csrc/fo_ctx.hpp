@@ -22,6 +22,7 @@ struct fo_ctx {
   int A = 0, Ta = 0;
   double *d_agent_tab = nullptr;    // [A][Ta][NAF]
   double *d_agent_const = nullptr;  // [A][NAC]
+  void *d_erf_tab = nullptr;        // erf lookup table (fo_sweep.hip)
   int *d_status = nullptr;          // device status word (bit 0: off-diagonal covariance met)
   size_t cap_agent_tab = 0, cap_agent_const = 0;
 

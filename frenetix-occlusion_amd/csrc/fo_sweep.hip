@@ -15,6 +15,7 @@
 // errors into 1e-3 jumps, see DESIGN.md "Why fp64").
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cstdlib>
 #include "fo_ctx.hpp"
 
 namespace {
@@ -27,6 +28,34 @@ constexpr int NAC = 8;     // per-agent constants: hl_raw, hw_raw, half_len_infl
 constexpr int NPS = 14;    // partial-reduction slots
 enum { PS_MIN_DCE = 0, PS_ARG_DCE, PS_MIN_TTC, PS_ARG_TTC, PS_MIN_TTCE, PS_MAX_ER, PS_MAX_OR, PS_ARG_OR, PS_MAX_EH,
        PS_MAX_OH, PS_MAX_CP, PS_MAX_HWC, PS_DCE_FLAG, PS_MAX_BTN };
+
+// erf by table + 5th-order Taylor step.  Nodes x0 = i/128, i = 0..768 (|u| < 6; erf(6) == 1 in float64); each entry
+// holds erf(x0) and g(x0) = 2/sqrt(pi) exp(-x0^2).  |delta| <= 1/256, remainder f^(6)/720 * delta^6 < 3e-16:
+// the same absolute accuracy as libm erf/erfc for the box probabilities, at ~25 VALU ops + one 16-byte LDS gather
+// instead of ~300 for the branchy ocml erfc (which dominated the first version of this kernel, profiles/r01_a_*).
+constexpr int ERF_N = 769;
+constexpr double ERF_SCALE = 128.0;
+
+__global__ void fo_erf_table_kernel(double2 *tab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ERF_N) return;
+  const double x0 = (double)i / ERF_SCALE;
+  tab[i] = make_double2(erf(x0), 1.1283791670955125738961589031 * exp(-x0 * x0));
+}
+
+__device__ __forceinline__ double fo_erf_lds(const double2 *__restrict__ tab, double u) {
+  const double au = fmin(fabs(u), 6.0);
+  const double fi = __builtin_rint(au * ERF_SCALE);
+  const double x0 = fi * (1.0 / ERF_SCALE);
+  const double d = au - x0;
+  const double2 e = tab[(int)fi];
+  const double q = x0 * x0;
+  const double a2 = (2.0 * q - 1.0) * (1.0 / 3.0);
+  const double a3 = -x0 * (2.0 * q - 3.0) * (1.0 / 6.0);
+  const double a4 = (4.0 * q * q - 12.0 * q + 3.0) * (1.0 / 30.0);
+  const double p = 1.0 + d * (-x0 + d * (a2 + d * (a3 + d * a4)));
+  return copysign(e.x + e.y * d * p, u);
+}
 
 __device__ __forceinline__ double fo_round3(double v) { return __builtin_rint(v * 1000.0) / 1000.0; }  // np.round(v,3)
 
@@ -125,6 +154,7 @@ struct SweepArgs {
   const double *traj;    // [T][NEF][Mp]
   const double *atab;    // [A][Ta][NAF]
   const double *acst;    // [A][NAC]
+  const double2 *erf_tab;  // [ERF_N]
   double *partial;       // [n_chunks][NPS][Mp]
   double *pair_f;        // [NPF][A][M] or null
   int32_t *pair_i;       // [NPI][A][M] or null
@@ -133,6 +163,7 @@ struct SweepArgs {
   fo_harm_coeff_t hc;
   double dt, thr_dce;
   uint32_t mask;
+  uint32_t ablate;  // debug only (env FO_SWEEP_ABLATE): 1 skip DCE, 2 skip CP box sums, 4 skip harm -- wrong results, timing aid
 };
 
 __device__ __forceinline__ double fo_lr4s_coef(double ang, double side, double rear) {
@@ -149,12 +180,17 @@ __device__ __forceinline__ double fo_pt_box2(double px, double py, double hl, do
   return qx * qx + qy * qy;
 }
 
-// 1-D normal box probability  P(lo <= X <= hi)  in upper-tail form  Q(lo) - Q(hi)  (MVNDST orientation)
-__device__ __forceinline__ double fo_phi_diff(double lo, double hi) { return 0.5 * (erfc(lo) - erfc(hi)); }
+// 1-D normal box probability  P(lo <= X <= hi)  with arguments already divided by sigma*sqrt(2)
+__device__ __forceinline__ double fo_phi_diff(const double2 *__restrict__ tab, double lo, double hi) {
+  return 0.5 * (fo_erf_lds(tab, hi) - fo_erf_lds(tab, lo));
+}
 
 template <bool PAIR, bool LISTS>
 __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a) {
   __shared__ double red[(WAVES - 1) * NPS * TILE];
+  __shared__ double2 erf_tab[ERF_N];
+  for (int i = threadIdx.x; i < ERF_N; i += TILE * WAVES) erf_tab[i] = a.erf_tab[i];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-aware decode: blocks b and b+8 share an XCD (and its L2); keep every chunk of one tile on one XCD
@@ -204,7 +240,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
       const double sr = ps * ec - pc * es;  // sin(yaw - theta)
 
       // ---------------- DCE (dce.py:69-88): oriented rectangle distance, rounded to 1e-3, first minimum, stop at 0
-      if (do_dce && t < L) {
+      if (do_dce && t < L && !(a.ablate & 1)) {
         const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
         const double dx = px - ccx, dy = py - ccy;
         // agent centre / half axes in the ego frame
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
           const double d0 = rx * rx + ry * ry;
           const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
           const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
-          if (!(sqrt(fmin(d0, fmin(dp, dm))) > 5.0)) {  // :67,75
+          if (!(sqrt(fmin(d0, fmin(dp, dm))) > 5.0) && !(a.ablate & 2)) {  // :67,75
             const double bxs = a.len3 * ec1, bys = a.len3 * es1;  // box centre step (L/3 along heading), rear-axle based (Q2)
             double acc = 0.0;
 #pragma unroll
@@ -250,8 +286,8 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
 #pragma unroll
               for (int b = -1; b <= 1; ++b) {     // three boxes
                 const double cx = qx + b * bxs, cy = qy + b * bys;
-                const double fx = fo_phi_diff((cx - a.off_x) * isx, (cx + a.off_x) * isx);
-                const double fy = fo_phi_diff((cy - a.off_y) * isy, (cy + a.off_y) * isy);
+                const double fx = fo_phi_diff(erf_tab, (cx - a.off_x) * isx, (cx + a.off_x) * isx);
+                const double fy = fo_phi_diff(erf_tab, (cy - a.off_y) * isy, (cy + a.off_y) * isy);
                 acc += fx * fy;
               }
             }
@@ -260,13 +296,13 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
         }
         // ---------------- harm (harm_model.py:80-107) + risk (hr.py:78-79), same index on both sides
         double eh = NAN, oh = NAN, er = NAN, orr = NAN;
-        if (do_hr && t < Lh) {
-          const double rel = atan2(py - ey, px - ex);
-          const double ego_ang = rel - eth;
-          const double obs_ang = M_PI + rel - pth;
+        if (do_hr && t < Lh && !(a.ablate & 4)) {
           const double dv = sqrt(fmax(ev * ev + pv * pv - 2.0 * ev * pv * cr, 0.0));  // cos(pdof) = -cos(yaw-theta)
           const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
           if (prot == 1) {
+            const double rel = atan2(py - ey, px - ex);  // the impact angles only enter the LR4S model
+            const double ego_ang = rel - eth;
+            const double obs_ang = M_PI + rel - pth;
             eh = 1.0 / (1.0 + exp(-a.hc.lr4s_const - a.hc.lr4s_speed * ego_dv -
                                   fo_lr4s_coef(ego_ang, a.hc.lr4s_side, a.hc.lr4s_rear)));
             oh = 1.0 / (1.0 + exp(-a.hc.lr4s_const - a.hc.lr4s_speed * obs_dv -
@@ -433,6 +469,15 @@ int pick_apw(int n_tiles, int A) {
 
 extern "C" {
 
+// called from fo_create (fo_api.hip)
+int fo_sweep_init_(fo_ctx *ctx) {
+  FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_erf_tab, sizeof(double2) * ERF_N));
+  hipLaunchKernelGGL(fo_erf_table_kernel, dim3((ERF_N + 255) / 256), dim3(256), 0, 0, (double2 *)ctx->d_erf_tab);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  FO_HIP_TRY(ctx, hipDeviceSynchronize());
+  return FO_OK;
+}
+
 int fo_sweep_configure(fo_ctx *ctx, const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, const fo_thresholds_t *thr,
                        uint32_t metric_mask, double dt) {
   if (!ctx || !veh || !hc || !thr) return fo_fail(ctx, FO_E_ARG, "fo_sweep_configure: null argument");
@@ -513,12 +558,17 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     FO_HIP_TRY(ctx, hipGetLastError());
     SweepArgs a{};
     a.M = M; a.Mp = Mp; a.T = T; a.A = A; a.Ta = Ta; a.n_tiles = n_tiles; a.nt8 = (n_tiles + 7) / 8; a.apw = apw;
+    a.erf_tab = (const double2 *)ctx->d_erf_tab;
     a.traj = ctx->d_traj_tab; a.atab = ctx->d_agent_tab; a.acst = ctx->d_agent_const; a.partial = ctx->d_partial;
     a.pair_f = d_pair_f; a.pair_i = d_pair_i; a.lists = d_lists;
     a.hlA = 0.5 * ctx->veh.length; a.hwA = 0.5 * ctx->veh.width; a.wb = ctx->veh.wb_rear_axle;
     a.len3 = ctx->veh.length / 2.0 * (2.0 / 3.0);  // r_x * (2/3)  (collision_probability.py:160-161)
     a.off_x = ctx->veh.length / 6.0; a.off_y = ctx->veh.width / 2.0;
     a.hc = ctx->hc; a.dt = ctx->dt; a.thr_dce = ctx->thr.dce; a.mask = ctx->mask;
+    {
+      const char *ab = getenv("FO_SWEEP_ABLATE");
+      a.ablate = ab ? (uint32_t)atoi(ab) : 0u;
+    }
     const int grid = a.nt8 * 8 * n_chunks;
     ctx->last_grid = grid; ctx->last_block = TILE * WAVES; ctx->last_apw = apw;
     const bool timed = ctx->timing && ctx->n_timed < fo_ctx::kMaxTimed;

@@ -379,10 +379,6 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
   for (int k = 0; k < A; ++k) if (alen[k] < 1 || alen[k] > Ta) return -1;
   uint32_t mask = fo_oracle_required_metrics(metric_mask);
   const int Tm1 = T - 1;
-  if (lists) {
-    size_t n = (size_t)M * A * FO_NL * Tm1;
-    for (size_t i = 0; i < n; ++i) lists[i] = NAN;
-  }
   int err = 0;
 #ifdef _OPENMP
   if (nthreads > 1) omp_set_num_threads(nthreads);
@@ -394,6 +390,10 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
 #pragma omp for schedule(dynamic, 8)
 #endif
     for (int m = 0; m < M; ++m) {
+      if (lists) {
+        double *lm = lists + (size_t)m * A * FO_NL * Tm1;
+        for (size_t i = 0; i < (size_t)A * FO_NL * Tm1; ++i) lm[i] = NAN;
+      }
       int rc = eval_trajectory(T, x + (size_t)m * T, y + (size_t)m * T, theta + (size_t)m * T, v + (size_t)m * T, A,
                                Ta, apos, ayaw, av, acov, ashape, araw, atype, alen, veh, hc, dt, thr, mask,
                                pair_f ? pair_f + (size_t)m * A * FO_NPF : NULL,

@@ -109,7 +109,7 @@ def box_prob(lo, hi, mu, sxx, syy):
 
 
 def sweep(traj, agents, vehicle, dt, metrics=("hr", "ttc", "ttce", "dce", "wttc", "cp"), thr=None,
-          harm_coeff=None, want_lists=True, nthreads=1):
+          harm_coeff=None, want_lists=True, nthreads=1, out=None):
     """traj: dict x,y,theta,v,a [M,T]; agents: dict pos[A,Ta,2], yaw[A,Ta], v[A,Ta], cov[A,Ta,2,2], shape[A,2],
     raw_dims[A,2], type[A] int, len[A] int; vehicle: (length,width,wb_rear_axle,mass,a_max).
     Returns dict of numpy arrays in the oracle's [M,A,...] layout."""
@@ -127,11 +127,15 @@ def sweep(traj, agents, vehicle, dt, metrics=("hr", "ttc", "ttce", "dce", "wttc"
     hc = HarmCoeff(**(harm_coeff or HARM_COEFF))
     th_s = thr if isinstance(thr, Thresholds) else thresholds(thr)
     Tm1 = max(T - 1, 0)
-    pair_f = np.empty((M, A, NPF))
-    pair_i = np.empty((M, A, NPI), dtype=np.int32)
-    lists = np.empty((M, A, NL, Tm1)) if want_lists else None
-    cost = np.empty((M, NC))
-    safe = np.empty(M, dtype=np.uint8)
+    if out is not None:  # reuse (already page-faulted) buffers of a previous call with the same shapes
+        pair_f, pair_i, lists, cost, safe = out["pair_f"], out["pair_i"], out["lists"], out["cost"], out["safe"]
+        assert pair_f.shape == (M, A, NPF) and cost.shape == (M, NC)
+    else:
+        pair_f = np.empty((M, A, NPF))
+        pair_i = np.empty((M, A, NPI), dtype=np.int32)
+        lists = np.empty((M, A, NL, Tm1)) if want_lists else None
+        cost = np.empty((M, NC))
+        safe = np.empty(M, dtype=np.uint8)
     rc = lib().fo_oracle_sweep(
         C.c_int(M), C.c_int(T), _p(x), _p(y), _p(th), _p(v), _p(a), C.c_int(A), C.c_int(Ta), _p(pos), _p(yaw),
         _p(av), _p(cov), _p(shape), _p(raw), _p(typ, C.c_int32), _p(ln, C.c_int32), C.byref(veh), C.byref(hc),

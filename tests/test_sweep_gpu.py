@@ -119,12 +119,13 @@ def test_hip_matches_reference_golden_outputs(torch_cuda, name):
 def test_hip_matches_oracle_on_synthetic_batches(torch_cuda, oracle, M, A, cfg):
     from frenetix_occlusion import synthetic as S
     traj, agents = S.make_batch(M, A, config_id=cfg)
-    thr = {"harm": 0.1, "risk": 0.05, "ttc": 1.0, "dce": 0.3, "cp": 0.5}
+    thr = {"harm": 0.3, "risk": 0.2, "ttc": 1.0, "dce": 0.05, "cp": 0.8}
     ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, nthreads=8)
     got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr)
     worst = _compare(oracle, ref, got)
     assert worst < NORTH_STAR_ATOL
-    assert 0 < ref["safe"].mean() < 1 or M < 10  # both verdicts occur
+    if M >= 300:
+        assert 0 < ref["safe"].mean() < 1  # both verdicts occur
 
 
 def test_output_modes_agree(torch_cuda):
