@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--A", type=int, default=256)
     ap.add_argument("--T", type=int, default=31)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", default="sampler", choices=["sampler", "random"],
+                    help="row order of the synthetic trajectories (synthetic.make_trajectories)")
     args = ap.parse_args()
 
     import numpy as np
@@ -88,7 +90,7 @@ def main():
     torch.cuda.set_device(dev)
 
     M, A, T = args.M, args.A, args.T
-    traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3 + 1000 * rank)   # config 3; one shard per rank
+    traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3 + 1000 * rank, order=args.order)   # config 3; one shard per rank
     agents = S.make_agents(A, T, 0.1, seed=20240131 + 3)                      # replicated
     sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, device=local_rank)
     sw.reserve(M, T, A, T)
@@ -140,7 +142,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: synthetic 10k trajectories x 256 phantom predictions, T=31 "
                                    "(metric sweep; per-rank shard when n_gpus>1)",
-                       "M_per_gpu": M, "A": A, "T": T, "output_mode": args.mode,
+                       "M_per_gpu": M, "A": A, "T": T, "output_mode": args.mode, "traj_order": args.order,
                        "metrics": ["hr", "ttc", "ttce", "dce", "wttc", "cp"], "parallelism": f"traj-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "fo_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -38,6 +38,8 @@ void fo_destroy(fo_ctx *ctx) {
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->d_erf_tab) (void)hipFree(ctx->d_erf_tab);
+  if (ctx->d_exp_tab) (void)hipFree(ctx->d_exp_tab);
+  if (ctx->d_agent_int) (void)hipFree(ctx->d_agent_int);
   if (ctx->ev_start) {
     for (int i = 0; i < fo_ctx::kMaxTimed; ++i) { (void)hipEventDestroy(ctx->ev_start[i]); (void)hipEventDestroy(ctx->ev_stop[i]); }
     delete[] ctx->ev_start;

@@ -23,6 +23,9 @@ struct fo_ctx {
   double *d_agent_tab = nullptr;    // [A][Ta][NAF]
   double *d_agent_const = nullptr;  // [A][NAC]
   void *d_erf_tab = nullptr;        // erf lookup table (fo_sweep.hip)
+  void *d_exp_tab = nullptr;        // 2^(j/64) table
+  int32_t *d_agent_int = nullptr;   // [A][2] protection class, valid length
+  size_t cap_agent_int = 0;
   int *d_status = nullptr;          // device status word (bit 0: off-diagonal covariance met)
   size_t cap_agent_tab = 0, cap_agent_const = 0;
 

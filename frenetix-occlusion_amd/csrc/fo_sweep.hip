@@ -43,6 +43,10 @@ __global__ void fo_erf_table_kernel(double2 *tab) {
   tab[i] = make_double2(erf(x0), 1.1283791670955125738961589031 * exp(-x0 * x0));
 }
 
+__global__ void fo_exp_table_kernel(double *tab) {
+  if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x / 64.0);
+}
+
 __device__ __forceinline__ double fo_erf_lds(const double2 *__restrict__ tab, double u) {
   const double au = fmin(fabs(u), 6.0);
   const double fi = __builtin_rint(au * ERF_SCALE);
@@ -60,9 +64,11 @@ __device__ __forceinline__ double fo_erf_lds(const double2 *__restrict__ tab, do
 __device__ __forceinline__ double fo_round3(double v) { return __builtin_rint(v * 1000.0) / 1000.0; }  // np.round(v,3)
 
 // ------------------------------------------------------------------------------------------------ prep kernels
-// trajectories [M][T] (row per trajectory) -> tile table [T][NEF][Mp], transposed through LDS so that both the
+// trajectories [M][T] (row per trajectory) -> tile table [tile][T][NEF][64], transposed through LDS so that both the
 // HBM read (along T) and the HBM write (along trajectories) are contiguous; sincos(theta) is taken once here.
-__global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int Mp, const double *__restrict__ x,
+// Within a tile every (t, field) row is 512 contiguous bytes = one wave-wide load, and field / timestep strides
+// are compile-time constants (immediate offsets in the sweep's loads).
+__global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int /*Mp*/, const double *__restrict__ x,
                                                            const double *__restrict__ y,
                                                            const double *__restrict__ th,
                                                            const double *__restrict__ v, double *__restrict__ tab) {
@@ -78,16 +84,16 @@ __global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int Mp,
     for (int i = threadIdx.x; i < T * TILE; i += blockDim.x) {
       const int t = i / TILE, ml = i % TILE;
       const double val = sh[t * ld + min(ml, n - 1)];  // pad lanes replicate the last trajectory of the tile
-      double *dst = tab + (size_t)t * NEF * Mp + m0 + ml;
-      if (f == 0) dst[0 * (size_t)Mp] = val;
-      else if (f == 1) dst[1 * (size_t)Mp] = val;
+      double *dst = tab + ((size_t)blockIdx.x * T + t) * NEF * TILE + ml;
+      if (f == 0) dst[0 * TILE] = val;
+      else if (f == 1) dst[1 * TILE] = val;
       else if (f == 2) {
         double sn, cs;
         sincos(val, &sn, &cs);
-        dst[2 * (size_t)Mp] = cs;
-        dst[3 * (size_t)Mp] = sn;
-        dst[4 * (size_t)Mp] = val;
-      } else dst[5 * (size_t)Mp] = val;
+        dst[2 * TILE] = cs;
+        dst[3 * TILE] = sn;
+        dst[4 * TILE] = val;
+      } else dst[5 * TILE] = val;
     }
     __syncthreads();
   }
@@ -122,7 +128,7 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
                                       const double *__restrict__ shape, const double *__restrict__ raw,
                                       const int32_t *__restrict__ type, const int32_t *__restrict__ len,
                                       double ego_mass, double *__restrict__ tab, double *__restrict__ cst,
-                                      int *__restrict__ status) {
+                                      int32_t *__restrict__ aint, int *__restrict__ status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A * Ta) return;
   const int k = i / Ta, t = i % Ta;
@@ -145,16 +151,20 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
     c[0] = 0.5 * raw[2 * k]; c[1] = 0.5 * raw[2 * k + 1]; c[2] = shape[2 * k] / 2.0;
     c[3] = m_obs / (ego_mass + m_obs); c[4] = ego_mass / (ego_mass + m_obs);
     c[5] = (double)fo_obstacle_protection(type[k]); c[6] = (double)len[k]; c[7] = (double)type[k];
+    aint[2 * k] = fo_obstacle_protection(type[k]);
+    aint[2 * k + 1] = len[k];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ the sweep
 struct SweepArgs {
   int M, Mp, T, A, Ta, n_tiles, nt8, apw;  // apw = agents per wave
-  const double *traj;    // [T][NEF][Mp]
+  const double *traj;    // [n_tiles][T][NEF][64]
   const double *atab;    // [A][Ta][NAF]
   const double *acst;    // [A][NAC]
   const double2 *erf_tab;  // [ERF_N]
+  const double *exp_tab;   // [64]  2^(j/64)
+  const int32_t *aint;     // [A][2] protection class, valid length
   double *partial;       // [n_chunks][NPS][Mp]
   double *pair_f;        // [NPF][A][M] or null
   int32_t *pair_i;       // [NPI][A][M] or null
@@ -186,7 +196,7 @@ __device__ __forceinline__ double fo_phi_diff(const double2 *__restrict__ tab, d
 }
 
 template <bool PAIR, bool LISTS>
-__global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a) {
+__global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const SweepArgs a) {
   __shared__ double red[(WAVES - 1) * NPS * TILE];
   __shared__ double2 erf_tab[ERF_N];
   for (int i = threadIdx.x; i < ERF_N; i += TILE * WAVES) erf_tab[i] = a.erf_tab[i];
@@ -201,8 +211,8 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
   const int m = tile * TILE + lane;
   const bool valid = m < a.M;
   const int T = a.T, Tm1 = a.T - 1, M = a.M, A = a.A;
-  const size_t Mp = (size_t)a.Mp;
-  const double *tj = a.traj + (size_t)tile * TILE + lane;
+  const size_t Mp = TILE;  // field stride inside a tile
+  const double *tj = a.traj + (size_t)tile * T * NEF * TILE + lane;
   const bool do_dce = a.mask & FO_M_DCE, do_cp = a.mask & FO_M_CP, do_hr = a.mask & FO_M_HR;
   const bool do_ttc = a.mask & FO_M_TTC, do_ttce = a.mask & FO_M_TTCE;
 
@@ -228,14 +238,21 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
     double oh_at_cp = 0.0;
     int idx_or = 0, idx_cp = 0;
 
+    // Software pipeline.  Ego samples: E(t) and E(t+1) are in registers when iteration t starts (CP reads t+1 early),
+    // the loads of E(t+2) are issued at the top of the iteration and first touched at its bottom.  Agent rows
+    // (wave-uniform -> scalar loads): row t in SGPRs, row t+1 requested at the top and first read by the CP step.
     double ex = tj[0 * Mp], ey = tj[1 * Mp], ec = tj[2 * Mp], es = tj[3 * Mp], eth = tj[4 * Mp], ev = tj[5 * Mp];
+    const double *tj1 = tj + (size_t)min(1, T - 1) * NEF * Mp;
+    double ex1 = tj1[0 * Mp], ey1 = tj1[1 * Mp], ec1 = tj1[2 * Mp], es1 = tj1[3 * Mp], eth1 = tj1[4 * Mp],
+           ev1 = tj1[5 * Mp];
+    double px = G[0], py = G[1], pc = G[2], ps = G[3], pth = G[4], pv = G[5], isx = G[6], isy = G[7];
     for (int t = 0; t < T; ++t) {
-      const int tn = min(t + 1, T - 1);
-      const double *tjn = tj + (size_t)tn * NEF * Mp;
-      const double ex1 = tjn[0 * Mp], ey1 = tjn[1 * Mp], ec1 = tjn[2 * Mp], es1 = tjn[3 * Mp], eth1 = tjn[4 * Mp],
-                   ev1 = tjn[5 * Mp];
-      const double *g = G + (size_t)min(t, L - 1) * NAF;
-      const double px = g[0], py = g[1], pc = g[2], ps = g[3], pth = g[4], pv = g[5], isx = g[6], isy = g[7];
+      const double *tj2 = tj + (size_t)min(t + 2, T - 1) * NEF * Mp;
+      const double ex2 = tj2[0 * Mp], ey2 = tj2[1 * Mp], ec2 = tj2[2 * Mp], es2 = tj2[3 * Mp], eth2 = tj2[4 * Mp],
+                   ev2 = tj2[5 * Mp];
+      const double *gn = G + (size_t)min(t + 1, L - 1) * NAF;
+      const double npx = gn[0], npy = gn[1], pc1 = gn[2], ps1 = gn[3], npth = gn[4], npv = gn[5], nisx = gn[6],
+                   nisy = gn[7];
       const double cr = pc * ec + ps * es;  // cos(yaw - theta)
       const double sr = ps * ec - pc * es;  // sin(yaw - theta)
 
@@ -271,7 +288,6 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
         // ---------------- CP (collision_probability.py:69-122): ego sample t+1, agent mean/cov t, agent yaw t+1 (Q1)
         double cp = 0.0;
         if (t + 1 < L) {
-          const double pc1 = g[NAF + 2], ps1 = g[NAF + 3];
           const double devx = pc1 * hdev, devy = ps1 * hdev;
           const double rx = ex1 - px, ry = ey1 - py;  // ego(t+1) - mean
           const double d0 = rx * rx + ry * ry;
@@ -333,6 +349,8 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
         }
       }
       ex = ex1; ey = ey1; ec = ec1; es = es1; eth = eth1; ev = ev1;
+      ex1 = ex2; ey1 = ey2; ec1 = ec2; es1 = es2; eth1 = eth2; ev1 = ev2;
+      px = npx; py = npy; pc = pc1; ps = ps1; pth = npth; pv = npv; isx = nisx; isy = nisy;
     }
 
     // ---------------- per-pair scalars
@@ -402,14 +420,328 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_kernel(const SweepArgs a
       w_max_hwc = fmax(w_max_hwc, rp[PS_MAX_HWC * TILE]);
       w_dce_flag = fmax(w_dce_flag, rp[PS_DCE_FLAG * TILE]);
     }
-    double *pp = a.partial + (size_t)chunk * NPS * Mp + (size_t)tile * TILE + lane;
-    pp[PS_MIN_DCE * Mp] = w_min_dce; pp[PS_ARG_DCE * Mp] = w_arg_dce; pp[PS_MIN_TTC * Mp] = w_min_ttc;
-    pp[PS_ARG_TTC * Mp] = w_arg_ttc; pp[PS_MIN_TTCE * Mp] = w_min_ttce; pp[PS_MAX_ER * Mp] = w_max_er;
-    pp[PS_MAX_OR * Mp] = w_max_or; pp[PS_ARG_OR * Mp] = w_arg_or; pp[PS_MAX_EH * Mp] = w_max_eh;
-    pp[PS_MAX_OH * Mp] = w_max_oh; pp[PS_MAX_CP * Mp] = w_max_cp; pp[PS_MAX_HWC * Mp] = w_max_hwc;
-    pp[PS_DCE_FLAG * Mp] = w_dce_flag; pp[PS_MAX_BTN * Mp] = 0.0;
+    const size_t PM = (size_t)a.Mp;
+    double *pp = a.partial + (size_t)chunk * NPS * PM + (size_t)tile * TILE + lane;
+    pp[PS_MIN_DCE * PM] = w_min_dce; pp[PS_ARG_DCE * PM] = w_arg_dce; pp[PS_MIN_TTC * PM] = w_min_ttc;
+    pp[PS_ARG_TTC * PM] = w_arg_ttc; pp[PS_MIN_TTCE * PM] = w_min_ttce; pp[PS_MAX_ER * PM] = w_max_er;
+    pp[PS_MAX_OR * PM] = w_max_or; pp[PS_ARG_OR * PM] = w_arg_or; pp[PS_MAX_EH * PM] = w_max_eh;
+    pp[PS_MAX_OH * PM] = w_max_oh; pp[PS_MAX_CP * PM] = w_max_cp; pp[PS_MAX_HWC * PM] = w_max_hwc;
+    pp[PS_DCE_FLAG * PM] = w_dce_flag; pp[PS_MAX_BTN * PM] = 0.0;
   }
 }
+
+// ================================================================================================ queue kernel
+// Same arithmetic as the generic kernel, restructured around what the first profiles showed (profiles/r01_*):
+// the kernel is fp64-VALU bound and 40 % of its instructions were the 36 erf evaluations of the CP box sums,
+// executed by whole waves although only ~7 % of the (trajectory, agent, t) samples are inside the 5 m gate.
+//   pass 1 (t loop)  DCE + gate test; in-gate (lane, t) samples are appended to a per-wave LDS queue with
+//                    ballot/mbcnt; whenever 64 samples are queued the wave evaluates them with all lanes busy
+//                    (each lane fetches "its" sample's ego/agent rows by index) and scatters cp into cpbuf[t][lane];
+//   pass 2 (t loop)  harm + risk + running maxima + coalesced list stores, cp read back from cpbuf.
+// exp() for the logistic models is a 64-entry 2^(j/64) table + degree-5 polynomial (~15 VALU ops).
+// Supports T-1 <= TQ; longer horizons take the generic kernel.
+constexpr int TQ = 30;
+constexpr int QCAP = 128;
+
+__device__ __forceinline__ double fo_exp_tab(const double *__restrict__ tab2, double z) {
+  z = fmin(fmax(z, -700.0), 700.0);
+  const double kf = __builtin_rint(z * 92.33248261689366);        // 64 / ln 2
+  double r = fma(-kf, 0.01083042469326756, z);                    // ln2/64 hi (32 significant bits)
+  r = fma(-kf, 2.9815858269852933e-12, r);                        // ln2/64 lo
+  const int k = (int)kf;
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(tab2[k & 63] * p, k >> 6);
+}
+
+// 1 / (1 + exp(nz))
+__device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab2, double nz) {
+  const double d = 1.0 + fo_exp_tab(tab2, nz);
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  return y;
+}
+
+template <bool PAIR, bool LISTS>
+__global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const SweepArgs a) {
+  __shared__ double2 erf_tab[ERF_N];
+  __shared__ double exp_tab[64];
+  __shared__ double cpbuf_all[WAVES * TQ * TILE];  // also the cross-wave reduction scratch at the end
+  __shared__ unsigned short queue_all[WAVES * QCAP];
+  for (int i = threadIdx.x; i < ERF_N; i += TILE * WAVES) erf_tab[i] = a.erf_tab[i];
+  if (threadIdx.x < 64) exp_tab[threadIdx.x] = a.exp_tab[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int tile = (j % a.nt8) * 8 + r;
+  const int chunk = j / a.nt8;
+  if (tile >= a.n_tiles) return;
+  const int m = tile * TILE + lane;
+  const bool valid = m < a.M;
+  const int T = a.T, Tm1 = a.T - 1, M = a.M, A = a.A;
+  const double *tjb = a.traj + (size_t)tile * T * NEF * TILE;  // uniform tile base
+  const double *tj = tjb + lane;
+  double *cpw = cpbuf_all + wave * (TQ * TILE);
+  unsigned short *q = queue_all + wave * QCAP;
+  const bool do_dce = a.mask & FO_M_DCE, do_cp = a.mask & FO_M_CP, do_hr = a.mask & FO_M_HR;
+  const bool do_ttc = a.mask & FO_M_TTC, do_ttce = a.mask & FO_M_TTCE;
+
+  double w_min_dce = INFINITY, w_min_ttc = INFINITY, w_min_ttce = INFINITY;
+  double w_max_er = 0.0, w_max_or = 0.0, w_max_eh = 0.0, w_max_oh = 0.0, w_max_cp = 0.0, w_max_hwc = 0.0;
+  double w_arg_dce = -1.0, w_arg_ttc = -1.0, w_arg_or = -1.0, w_dce_flag = 0.0;
+
+  const int k0 = (chunk * WAVES + wave) * a.apw;
+  for (int kk = 0; kk < a.apw; ++kk) {
+    const int k = k0 + kk;
+    if (k >= A) break;
+    const double *G = a.atab + (size_t)k * a.Ta * NAF;
+    const double *C = a.acst + (size_t)k * NAC;
+    const double hlB = C[0], hwB = C[1], hdev = C[2], f_ego = C[3], f_obs = C[4];
+    const int prot = a.aint[2 * k], L = a.aint[2 * k + 1];
+    const int Lh = min(Tm1, L);
+
+    // evaluates n (<= 64) queued in-gate samples, one per lane (collision_probability.py:77-122)
+    auto process = [&](int n) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane < n) {
+        const int item = q[lane];
+        const int src = item & 63, ti = item >> 6;
+        const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + src;  // ego sample ti+1 of trajectory `src`
+        const double qex = e[0 * TILE], qey = e[1 * TILE], qec = e[2 * TILE], qes = e[3 * TILE];
+        const double *g0 = G + (size_t)ti * NAF;                       // agent mean / covariance: sample ti
+        const double qpx = g0[0], qpy = g0[1], qisx = g0[6], qisy = g0[7];
+        const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1)
+        const double devx = qc1 * hdev, devy = qs1 * hdev;
+        const double rx = qex - qpx, ry = qey - qpy;
+        const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
+        double acc = 0.0;
+#pragma unroll
+        for (int jm = -1; jm <= 1; ++jm) {
+          const double qx = rx - jm * devx, qy = ry - jm * devy;
+#pragma unroll
+          for (int b = -1; b <= 1; ++b) {
+            const double cx = qx + b * bxs, cy = qy + b * bys;
+            const double fx = fo_phi_diff(erf_tab, (cx - a.off_x) * qisx, (cx + a.off_x) * qisx);
+            const double fy = fo_phi_diff(erf_tab, (cy - a.off_y) * qisy, (cy + a.off_y) * qisy);
+            acc += fx * fy;
+          }
+        }
+        cpw[ti * TILE + src] = acc / 3.0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    // ------------------------------------------------------------------ pass 1: DCE + gate -> queue
+    double dce = INFINITY;
+    int tdce = 0;
+    bool done = false;
+    unsigned gmask = 0u;
+    int qn = 0;
+    for (int t = 0; t < T; ++t) {
+      const double *e0 = tj + (size_t)t * NEF * TILE;
+      const double *e1 = tj + (size_t)min(t + 1, T - 1) * NEF * TILE;
+      const double ex = e0[0 * TILE], ey = e0[1 * TILE], ec = e0[2 * TILE], es = e0[3 * TILE];
+      const double ex1 = e1[0 * TILE], ey1 = e1[1 * TILE];
+      const double *g = G + (size_t)min(t, L - 1) * NAF;
+      const double px = g[0], py = g[1], pc = g[2], ps = g[3];
+      if (do_dce && t < L && !(a.ablate & 1)) {
+        const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
+        const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
+        const double dx = px - ccx, dy = py - ccy;
+        const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;
+        const double ux = hlB * cr, uy = hlB * sr, wx = -hwB * sr, wy = hwB * cr;
+        const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);
+        const double vx = a.hlA * cr, vy = -a.hlA * sr, zx = a.hwA * sr, zy = a.hwA * cr;
+        const bool sep = (fabs(ax) > a.hlA + fabs(ux) + fabs(wx)) || (fabs(ay) > a.hwA + fabs(uy) + fabs(wy)) ||
+                         (fabs(bx) > hlB + fabs(vx) + fabs(zx)) || (fabs(by) > hwB + fabs(vy) + fabs(zy));
+        double d2 = 0.0;
+        if (sep) {
+          d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, a.hlA, a.hwA);
+          d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, a.hlA, a.hwA));
+          d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, a.hlA, a.hwA));
+          d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, a.hlA, a.hwA));
+          d2 = fmin(d2, fo_pt_box2(bx + vx + zx, by + vy + zy, hlB, hwB));
+          d2 = fmin(d2, fo_pt_box2(bx + vx - zx, by + vy - zy, hlB, hwB));
+          d2 = fmin(d2, fo_pt_box2(bx - vx + zx, by - vy + zy, hlB, hwB));
+          d2 = fmin(d2, fo_pt_box2(bx - vx - zx, by - vy - zy, hlB, hwB));
+        }
+        // distance in whole millimetres: rint(1000 d) orders exactly like np.round(d, 3) (dce.py:79); the division
+        // by 1000 is done once per pair after the loop
+        const double nmm = __builtin_rint(sqrt(d2) * 1000.0);
+        if (!done && nmm < dce) { dce = nmm; tdce = t; }
+        if (dce == 0.0) done = true;
+      }
+      if (do_cp && t < Tm1 && t + 1 < L && !(a.ablate & 2)) {
+        // gate (collision_probability.py:44-67,75): ego sample t+1, agent mean t, agent heading t+1
+        const double pc1 = g[NAF + 2], ps1 = g[NAF + 3];
+        const double devx = pc1 * hdev, devy = ps1 * hdev;
+        const double rx = ex1 - px, ry = ey1 - py;
+        const double d0 = rx * rx + ry * ry;
+        const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
+        const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
+        const double m2 = fmin(d0, fmin(dp, dm));
+        bool ing = m2 <= 25.0;
+        if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);  // keep the reference's test on the rounded sqrt
+        ing = ing && valid;
+        const unsigned long long bal = __ballot(ing);
+        if (bal) {
+          const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          if (ing) {
+            q[pos] = (unsigned short)(lane | (t << 6));
+            gmask |= 1u << t;
+          }
+          qn += __popcll(bal);
+          if (qn >= 64) {
+            process(64);
+            const int rest = qn - 64;
+            unsigned short tmp = 0;
+            if (lane < rest) tmp = q[64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < rest) q[lane] = tmp;
+            qn = rest;
+          }
+        }
+      }
+    }
+    if (qn > 0) process(qn);
+
+    // ------------------------------------------------------------------ pass 2: harm, risk, maxima, lists
+    double max_er = -INFINITY, max_or = -INFINITY, max_eh = -INFINITY, max_oh = -INFINITY, max_cp = -INFINITY;
+    double oh_at_cp = 0.0;
+    int idx_or = 0, idx_cp = 0;
+    if (do_cp || do_hr) {
+      for (int t = 0; t < Tm1; ++t) {
+        const double cpv = cpw[t * TILE + lane];
+        const double cp = ((gmask >> t) & 1u) ? cpv : 0.0;
+        double eh = NAN, oh = NAN, er = NAN, orr = NAN;
+        if (do_hr && t < Lh && !(a.ablate & 4)) {
+          const double *e0 = tj + (size_t)t * NEF * TILE;
+          const double ec = e0[2 * TILE], es = e0[3 * TILE], ev = e0[5 * TILE];
+          const double *g = G + (size_t)t * NAF;
+          const double pc = g[2], ps = g[3], pv = g[5];
+          const double cr = pc * ec + ps * es;
+          const double dv = sqrt(fmax(ev * ev + pv * pv - 2.0 * ev * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
+          const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
+          if (prot == 1) {
+            const double ex = e0[0 * TILE], ey = e0[1 * TILE], eth = e0[4 * TILE];
+            const double rel = atan2(g[1] - ey, g[0] - ex);  // the impact angles only enter the LR4S model
+            const double ego_ang = rel - eth;
+            const double obs_ang = M_PI + rel - g[4];
+            eh = fo_logistic_neg(exp_tab, -a.hc.lr4s_const - a.hc.lr4s_speed * ego_dv -
+                                              fo_lr4s_coef(ego_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
+            oh = fo_logistic_neg(exp_tab, -a.hc.lr4s_const - a.hc.lr4s_speed * obs_dv -
+                                              fo_lr4s_coef(obs_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
+          } else if (prot == 0) {
+            eh = fo_logistic_neg(exp_tab, -a.hc.lr1s_const - a.hc.lr1s_speed * ego_dv);
+            oh = fo_logistic_neg(exp_tab, a.hc.ped_const - a.hc.ped_speed * obs_dv);
+          } else {
+            eh = 1.0;
+            oh = 1.0;
+          }
+          er = eh * cp;
+          orr = oh * cp;
+          max_er = fmax(max_er, er);
+          if (orr > max_or) { max_or = orr; idx_or = t; }
+          max_eh = fmax(max_eh, eh);
+          max_oh = fmax(max_oh, oh);
+        }
+        if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
+        if (LISTS && valid) {
+          double *l = a.lists + ((size_t)k * Tm1 + t) * M + m;
+          const size_t ls = (size_t)A * Tm1 * M;
+          __builtin_nontemporal_store(cp, l + FO_L_CP * ls);
+          __builtin_nontemporal_store(eh, l + FO_L_EGO_HARM * ls);
+          __builtin_nontemporal_store(oh, l + FO_L_OBST_HARM * ls);
+          __builtin_nontemporal_store(er, l + FO_L_EGO_RISK * ls);
+          __builtin_nontemporal_store(orr, l + FO_L_OBST_RISK * ls);
+        }
+      }
+    }
+
+    // ------------------------------------------------------------------ per-pair scalars
+    const double dce_m = dce / 1000.0;                                                      // np.round(d, 3)
+    const double ttc = (dce == 0.0) ? fo_round3((double)tdce * a.dt) : INFINITY;            // ttc.py:43-46
+    const double ttce = fo_round3((double)tdce * a.dt);                                     // ttce.py:39
+    const bool hr_valid = do_hr && Lh > 0;
+    const double hwc = (max_cp > 0.01) ? oh_at_cp : 0.0;                                    // hr.py:81-84
+    if (PAIR && valid) {
+      const size_t ps_ = (size_t)A * M;
+      double *pf = a.pair_f + (size_t)k * M + m;
+      pf[FO_PF_DCE * ps_] = do_dce ? dce_m : NAN;
+      pf[FO_PF_TTC * ps_] = do_ttc ? ttc : NAN;
+      pf[FO_PF_TTCE * ps_] = do_ttce ? ttce : NAN;
+      pf[FO_PF_MAX_EGO_RISK * ps_] = hr_valid ? max_er : NAN;
+      pf[FO_PF_MAX_OBST_RISK * ps_] = hr_valid ? max_or : NAN;
+      pf[FO_PF_HARM_WITH_CP * ps_] = hr_valid ? hwc : NAN;
+      pf[FO_PF_MAX_EGO_HARM * ps_] = hr_valid ? max_eh : NAN;
+      pf[FO_PF_MAX_OBST_HARM * ps_] = hr_valid ? max_oh : NAN;
+      pf[FO_PF_MAX_CP * ps_] = hr_valid ? max_cp : NAN;
+      pf[FO_PF_BE_DECEL * ps_] = NAN;
+      pf[FO_PF_BE_BTN * ps_] = NAN;
+      pf[FO_PF_SPARE * ps_] = NAN;
+      int32_t *pi = a.pair_i + (size_t)k * M + m;
+      pi[FO_PI_TIME_DCE * ps_] = do_dce ? tdce : 0;
+      pi[FO_PI_RISK_INDEX * ps_] = hr_valid ? idx_or : 0;
+      pi[FO_PI_CP_ARGMAX * ps_] = hr_valid ? idx_cp : 0;
+      pi[FO_PI_HR_VALID * ps_] = hr_valid ? 1 : 0;
+    }
+    if (do_dce) {
+      if (dce_m < w_min_dce) { w_min_dce = dce_m; w_arg_dce = (double)k; }
+      if (dce_m < a.thr_dce) w_dce_flag = 1.0;
+      if (do_ttc && ttc < w_min_ttc) { w_min_ttc = ttc; w_arg_ttc = (double)k; }
+      if (do_ttce) w_min_ttce = fmin(w_min_ttce, ttce);
+    }
+    if (hr_valid) {
+      w_max_er = fmax(w_max_er, max_er);
+      if (max_or > w_max_or) { w_max_or = max_or; w_arg_or = (double)k; }
+      w_max_eh = fmax(w_max_eh, max_eh);
+      w_max_oh = fmax(w_max_oh, max_oh);
+      w_max_cp = fmax(w_max_cp, max_cp);
+      w_max_hwc = fmax(w_max_hwc, hwc);
+    }
+  }
+
+  // ---------------- combine the four waves (ascending agent order); scratch aliases the cp buffers
+  __syncthreads();
+  double *red = cpbuf_all;
+  if (wave > 0) {
+    double *rp = red + (size_t)(wave - 1) * NPS * TILE + lane;
+    rp[PS_MIN_DCE * TILE] = w_min_dce; rp[PS_ARG_DCE * TILE] = w_arg_dce; rp[PS_MIN_TTC * TILE] = w_min_ttc;
+    rp[PS_ARG_TTC * TILE] = w_arg_ttc; rp[PS_MIN_TTCE * TILE] = w_min_ttce; rp[PS_MAX_ER * TILE] = w_max_er;
+    rp[PS_MAX_OR * TILE] = w_max_or; rp[PS_ARG_OR * TILE] = w_arg_or; rp[PS_MAX_EH * TILE] = w_max_eh;
+    rp[PS_MAX_OH * TILE] = w_max_oh; rp[PS_MAX_CP * TILE] = w_max_cp; rp[PS_MAX_HWC * TILE] = w_max_hwc;
+    rp[PS_DCE_FLAG * TILE] = w_dce_flag; rp[PS_MAX_BTN * TILE] = 0.0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 0; w < WAVES - 1; ++w) {
+      const double *rp = red + (size_t)w * NPS * TILE + lane;
+      if (rp[PS_MIN_DCE * TILE] < w_min_dce) { w_min_dce = rp[PS_MIN_DCE * TILE]; w_arg_dce = rp[PS_ARG_DCE * TILE]; }
+      if (rp[PS_MIN_TTC * TILE] < w_min_ttc) { w_min_ttc = rp[PS_MIN_TTC * TILE]; w_arg_ttc = rp[PS_ARG_TTC * TILE]; }
+      w_min_ttce = fmin(w_min_ttce, rp[PS_MIN_TTCE * TILE]);
+      w_max_er = fmax(w_max_er, rp[PS_MAX_ER * TILE]);
+      if (rp[PS_MAX_OR * TILE] > w_max_or) { w_max_or = rp[PS_MAX_OR * TILE]; w_arg_or = rp[PS_ARG_OR * TILE]; }
+      w_max_eh = fmax(w_max_eh, rp[PS_MAX_EH * TILE]);
+      w_max_oh = fmax(w_max_oh, rp[PS_MAX_OH * TILE]);
+      w_max_cp = fmax(w_max_cp, rp[PS_MAX_CP * TILE]);
+      w_max_hwc = fmax(w_max_hwc, rp[PS_MAX_HWC * TILE]);
+      w_dce_flag = fmax(w_dce_flag, rp[PS_DCE_FLAG * TILE]);
+    }
+    const size_t PM = (size_t)a.Mp;
+    double *pp = a.partial + (size_t)chunk * NPS * PM + (size_t)tile * TILE + lane;
+    pp[PS_MIN_DCE * PM] = w_min_dce; pp[PS_ARG_DCE * PM] = w_arg_dce; pp[PS_MIN_TTC * PM] = w_min_ttc;
+    pp[PS_ARG_TTC * PM] = w_arg_ttc; pp[PS_MIN_TTCE * PM] = w_min_ttce; pp[PS_MAX_ER * PM] = w_max_er;
+    pp[PS_MAX_OR * PM] = w_max_or; pp[PS_ARG_OR * PM] = w_arg_or; pp[PS_MAX_EH * PM] = w_max_eh;
+    pp[PS_MAX_OH * PM] = w_max_oh; pp[PS_MAX_CP * PM] = w_max_cp; pp[PS_MAX_HWC * PM] = w_max_hwc;
+    pp[PS_DCE_FLAG * PM] = w_dce_flag; pp[PS_MAX_BTN * PM] = 0.0;
+  }
+}
+
 
 // fold the per-chunk partials into the cost vector + safety flag (metric.py:50-100, hr.py:101-114, wttc.py:32-42)
 __global__ void fo_reduce_kernel(int M, int Mp, int A, int n_chunks, const double *__restrict__ partial,
@@ -473,6 +805,8 @@ extern "C" {
 int fo_sweep_init_(fo_ctx *ctx) {
   FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_erf_tab, sizeof(double2) * ERF_N));
   hipLaunchKernelGGL(fo_erf_table_kernel, dim3((ERF_N + 255) / 256), dim3(256), 0, 0, (double2 *)ctx->d_erf_tab);
+  FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_exp_tab, sizeof(double) * 64));
+  hipLaunchKernelGGL(fo_exp_table_kernel, dim3(1), dim3(64), 0, 0, (double *)ctx->d_exp_tab);
   FO_HIP_TRY(ctx, hipGetLastError());
   FO_HIP_TRY(ctx, hipDeviceSynchronize());
   return FO_OK;
@@ -500,6 +834,7 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, chunks * NPS * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) * NAF))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(max_A > 0 ? max_A : 1) * NAC))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(max_A > 0 ? max_A : 1) * 2))) return rc;
   return FO_OK;
 }
 
@@ -515,6 +850,7 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
   int rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(A > 0 ? A : 1) * Ta * NAF))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(A > 0 ? A : 1) * NAC))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(A > 0 ? A : 1) * 2))) return rc;
   ctx->A = A;
   ctx->Ta = Ta;
   FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), s));
@@ -522,7 +858,7 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
     const int n = A * Ta;
     hipLaunchKernelGGL(fo_prep_agents_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, Ta, d_pos, d_yaw, d_v, d_cov,
                        d_shape, d_raw_dims, d_type, d_len, ctx->veh.mass, ctx->d_agent_tab, ctx->d_agent_const,
-                       ctx->d_status);
+                       ctx->d_agent_int, ctx->d_status);
     FO_HIP_TRY(ctx, hipGetLastError());
   }
   return FO_OK;
@@ -559,6 +895,8 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     SweepArgs a{};
     a.M = M; a.Mp = Mp; a.T = T; a.A = A; a.Ta = Ta; a.n_tiles = n_tiles; a.nt8 = (n_tiles + 7) / 8; a.apw = apw;
     a.erf_tab = (const double2 *)ctx->d_erf_tab;
+    a.exp_tab = (const double *)ctx->d_exp_tab;
+    a.aint = ctx->d_agent_int;
     a.traj = ctx->d_traj_tab; a.atab = ctx->d_agent_tab; a.acst = ctx->d_agent_const; a.partial = ctx->d_partial;
     a.pair_f = d_pair_f; a.pair_i = d_pair_i; a.lists = d_lists;
     a.hlA = 0.5 * ctx->veh.length; a.hwA = 0.5 * ctx->veh.width; a.wb = ctx->veh.wb_rear_axle;
@@ -573,9 +911,17 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     ctx->last_grid = grid; ctx->last_block = TILE * WAVES; ctx->last_apw = apw;
     const bool timed = ctx->timing && ctx->n_timed < fo_ctx::kMaxTimed;
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[ctx->n_timed], s));
-    if (d_lists) hipLaunchKernelGGL((fo_sweep_kernel<true, true>), dim3(grid), dim3(TILE * WAVES), 0, s, a);
-    else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_kernel<true, false>), dim3(grid), dim3(TILE * WAVES), 0, s, a);
-    else hipLaunchKernelGGL((fo_sweep_kernel<false, false>), dim3(grid), dim3(TILE * WAVES), 0, s, a);
+    const dim3 g(grid), b(TILE * WAVES);
+    const char *force_generic = getenv("FO_SWEEP_GENERIC");  // debug / A-B aid
+    if (T - 1 <= TQ && !(force_generic && force_generic[0] == '1')) {
+      if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true>), g, b, 0, s, a);
+      else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false>), g, b, 0, s, a);
+    } else {
+      if (d_lists) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, true>), g, b, 0, s, a);
+      else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, false>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((fo_sweep_generic_kernel<false, false>), g, b, 0, s, a);
+    }
     FO_HIP_TRY(ctx, hipGetLastError());
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop[ctx->n_timed++], s));
   }

@@ -16,13 +16,23 @@ TYPE_CODE = {"car": 0, "truck": 1, "bicycle": 3, "pedestrian": 4}
 INFLATE_S, INFLATE_L = (1.2, 1.3), (1.4, 2.5)  # size_factor_{length,width}_{s,l}; bicycles use _l (agent.py:402-405)
 
 
-def make_trajectories(M, T=31, dt=0.1, seed=20240131, ego_pos=(0.0, 0.0), ego_yaw=0.0):
+def make_trajectories(M, T=31, dt=0.1, seed=20240131, ego_pos=(0.0, 0.0), ego_yaw=0.0, order="sampler"):
     """M candidate trajectories from one ego pose: v0 ~ U(3,12), end speed v0*U(0.3,1.3), lateral target U(-3,3),
-    quintic blend over the horizon.  Returns dict of float64 [M,T] arrays x,y,theta,v,a."""
+    quintic blend over the horizon.  Returns dict of float64 [M,T] arrays x,y,theta,v,a.
+
+    order="sampler": the draws are emitted the way a Frenet sampler emits its candidates -- nested loops, here
+    (start-speed bucket, end-speed bucket, lateral target) like the sampling matrix of utils/frenetix_handler.py:82-105
+    -- so neighbouring rows are neighbouring trajectories.  order="random": i.i.d. order (worst case for a wave)."""
     rng = np.random.default_rng(seed)
     v0 = rng.uniform(3.0, 12.0, (M, 1))
     v1 = v0 * rng.uniform(0.3, 1.3, (M, 1))
     d1 = rng.uniform(-3.0, 3.0, (M, 1))
+    if order == "sampler":
+        nb = max(1, int(round(M ** (1.0 / 3.0))))
+        b0 = np.minimum((v0[:, 0] - 3.0) / 9.0 * nb, nb - 1).astype(np.int64)
+        b1 = np.minimum(v1[:, 0] / (12.0 * 1.3) * nb, nb - 1).astype(np.int64)
+        idx = np.lexsort((d1[:, 0], b1, b0))
+        v0, v1, d1 = v0[idx], v1[idx], d1[idx]
     tau = np.linspace(0.0, 1.0, T)[None, :]
     blend = 10 * tau ** 3 - 15 * tau ** 4 + 6 * tau ** 5
     dblend = (30 * tau ** 2 - 60 * tau ** 3 + 30 * tau ** 4) / ((T - 1) * dt)

@@ -128,6 +128,23 @@ def test_hip_matches_oracle_on_synthetic_batches(torch_cuda, oracle, M, A, cfg):
         assert 0 < ref["safe"].mean() < 1  # both verdicts occur
 
 
+def test_generic_kernel_and_long_horizon(torch_cuda, oracle, monkeypatch):
+    """The queue kernel serves T-1 <= 30; longer horizons (and FO_SWEEP_GENERIC=1) take the generic kernel."""
+    from frenetix_occlusion import synthetic as S
+    traj, agents = S.make_batch(200, 12, config_id=11)
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.3})
+    monkeypatch.setenv("FO_SWEEP_GENERIC", "1")
+    got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.3})
+    _compare(oracle, ref, got)
+    monkeypatch.delenv("FO_SWEEP_GENERIC")
+    traj = S.make_trajectories(150, T=45, seed=5)
+    agents = S.make_agents(7, T=45, seed=5)
+    agents["len"][:] = [45, 31, 40, 44, 45, 2, 45]
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1)
+    got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1)
+    _compare(oracle, ref, got)
+
+
 def test_output_modes_agree(torch_cuda):
     from frenetix_occlusion import synthetic as S
     traj, agents = S.make_batch(500, 24, config_id=6)
