@@ -1,3 +1,657 @@
-// fo_scene.hip -- visibility ray-cast, occluded-cell grid, spawn sampling (placeholder until the kernels land).
+// fo_scene.hip -- visibility ray fan, occluded-cell grid, phantom spawn sampling and constant-velocity predictions
+// for gfx950.  Replaces, per planning step, SensorModel.calc_visible_and_occluded_area (ref: sensor_model.py:41-193),
+// the cell-based core of SpawnLocator.find_spawn_points (ref: spawn_locator.py:80-139) and the pedestrian-style
+// prediction generator (ref: agent.py:451-536).  The reference does this with GEOS polygon algebra (one
+// `difference` per boundary vertex); there is no ray or cell in it -- the discretisation is defined in
+// DESIGN.md and is the same one oracle/ restates on the CPU.
+//
+// Compiled with -ffp-contract=off: every integer output (hit ids, cell classes, occluded-cell indices, spawn cells)
+// must be bit-identical to the CPU restatement, so only + - * / sqrt and comparisons on float64 are used and no
+// FMA is formed.
+//
+// Kernels (all latency-bound at one ego; launch-overhead discipline matters more than bandwidth here):
+//   fo_raster_kernel     one-off: world-aligned road raster (cell centre inside any lanelet polygon)
+//   fo_obst_edges_kernel obstacle corner points -> 4 occluder segments each
+//   fo_raycast_kernel    one WAVE per ray: lanes stride over the occluder soup staged through LDS, lexicographic
+//                        (t, id) minimum by cross-lane shuffles = first hit
+//   fo_obst_vis_kernel   5 probe rays (corners + centre) per obstacle, one wave each
+//   fo_grid_kernel       one thread per cell: fan sector by binary search on cross products, inside-the-ring test,
+//                        half-disc test -> class bits
+//   fo_flag_* kernels    deterministic stream compaction (ballot prefix inside a block, scanned block counts)
+//   fo_spawn_* kernels   frontier candidates -> evenly spaced pick -> headings -> predictions in the sweep's layout
+#include <hip/hip_runtime.h>
+#include <math.h>
 #include "fo_ctx.hpp"
-extern "C" void fo_scene_destroy_(fo_ctx *ctx) { (void)ctx; }
+
+namespace {
+
+constexpr int RC_WAVES = 4;      // rays per workgroup
+constexpr int RC_CHUNK = 1024;   // occluder segments staged in LDS at a time (32 KB)
+
+struct Scene {
+  // static map
+  int P = 0, E = 0;
+  double cs = 0.5, x0 = 0, y0 = 0;
+  int rnx = 0, rny = 0;
+  double *d_edges = nullptr;      // [E][4]
+  uint8_t *d_raster = nullptr;    // [rny][rnx]
+  double *d_lane_yaw = nullptr;   // [rny][rnx] or null
+  // per-step workspace
+  double *d_dyn_edges = nullptr;  // [O*4][4]
+  int32_t *d_dyn_ids = nullptr;   // [O*4]
+  size_t cap_dyn = 0, cap_dyn_ids = 0, cap_cand = 0;
+  uint8_t *d_flags = nullptr;     // [cells]
+  int32_t *d_blk = nullptr;       // block counts / offsets
+  size_t cap_cells = 0, cap_blk = 0;
+  int32_t *d_cand = nullptr;      // candidate cell list
+  int32_t *d_ncand = nullptr;
+};
+
+Scene *scene_of(fo_ctx *ctx) {
+  if (!ctx->scene) ctx->scene = new Scene();
+  return (Scene *)ctx->scene;
+}
+
+// ------------------------------------------------------------------------------------------------ road raster
+__global__ void fo_raster_kernel(int P, const int32_t *__restrict__ poly_off, const double *__restrict__ poly_xy,
+                                 const double *__restrict__ pbox, double x0, double y0, double cs, int nx, int ny,
+                                 uint8_t *__restrict__ mask) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nx * ny) return;
+  const int ix = idx % nx, iy = idx / nx;
+  const double px = x0 + ((double)ix + 0.5) * cs, py = y0 + ((double)iy + 0.5) * cs;
+  int inside_any = 0;
+  for (int p = 0; p < P && !inside_any; ++p) {
+    const double *bb = pbox + 4 * (size_t)p;  // xmin, ymin, xmax, ymax: pure early-out, cannot change the result
+    if (px < bb[0] || px > bb[2] || py < bb[1] || py > bb[3]) continue;
+    const int b = poly_off[p], e = poly_off[p + 1];
+    int c = 0;
+    for (int i = b, j = e - 1; i < e; j = i++) {
+      const double xi = poly_xy[2 * i], yi = poly_xy[2 * i + 1], xj = poly_xy[2 * j], yj = poly_xy[2 * j + 1];
+      if ((yi > py) != (yj > py)) {
+        const double xc = xi + (py - yi) * (xj - xi) / (yj - yi);
+        if (px < xc) c ^= 1;
+      }
+    }
+    inside_any = c;
+  }
+  mask[idx] = (uint8_t)inside_any;
+}
+
+// ------------------------------------------------------------------------------------------------ ray casting
+__device__ __forceinline__ double ray_segment(double ox, double oy, double dx, double dy, double ax, double ay,
+                                              double bx, double by) {
+  const double ex = bx - ax, ey = by - ay;
+  const double denom = dx * ey - dy * ex;
+  if (denom == 0.0) return INFINITY;
+  const double wx = ax - ox, wy = ay - oy;
+  const double t = (wx * ey - wy * ex) / denom;
+  const double u = (wx * dy - wy * dx) / denom;
+  if (t >= 0.0 && u >= 0.0 && u <= 1.0) return t;
+  return INFINITY;
+}
+
+// obstacle o (exists & occludes) -> 4 segments with id E + o; others get a degenerate segment that never hits
+__global__ void fo_obst_edges_kernel(int O, int E, const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags,
+                                     double *__restrict__ seg, int32_t *__restrict__ ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O * 4) return;
+  const int o = i >> 2, s = i & 3, s2 = (s + 1) & 3;
+  const bool on = (oflags[o] & 1) && (oflags[o] & 2);
+  const double *c = ocorn + 8 * (size_t)o;
+  seg[4 * (size_t)i + 0] = on ? c[2 * s] : 0.0;
+  seg[4 * (size_t)i + 1] = on ? c[2 * s + 1] : 0.0;
+  seg[4 * (size_t)i + 2] = on ? c[2 * s2] : 0.0;
+  seg[4 * (size_t)i + 3] = on ? c[2 * s2 + 1] : 0.0;
+  ids[i] = on ? E + o : -2;  // -2 = inactive
+}
+
+// lexicographic (t, id) minimum across the wave
+__device__ __forceinline__ void wave_min_hit(double &t, int &id) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double t2 = __shfl_xor(t, off);
+    const int id2 = __shfl_xor(id, off);
+    if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
+  }
+}
+
+// First hit of one ray per wave.  Static edges and dynamic (obstacle) segments are staged through LDS in chunks
+// shared by the workgroup's waves.  skip_id: occluder id to ignore (probe rays of that obstacle), or -3.
+__device__ void wave_first_hit(double *sh, int E, const double *__restrict__ edges, int nd,
+                               const double *__restrict__ dseg, const int32_t *__restrict__ dids, double ox, double oy,
+                               double dx, double dy, bool active, int skip_id, double &best, int &best_id) {
+  const int lane = threadIdx.x & 63;
+  best = INFINITY;
+  best_id = 0x7fffffff;
+  const int total = E + nd;
+  for (int base = 0; base < total; base += RC_CHUNK) {
+    const int n = min(RC_CHUNK, total - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * 4; i += blockDim.x) {
+      const int g = base * 4 + i;
+      sh[i] = g < E * 4 ? edges[g] : dseg[g - E * 4];
+    }
+    __syncthreads();
+    if (active) {
+      for (int i = lane; i < n; i += 64) {
+        const int gi = base + i;
+        int id = gi;
+        if (gi >= E) {
+          id = dids[gi - E];
+          if (id < 0 || id == skip_id) continue;
+        }
+        const double t = ray_segment(ox, oy, dx, dy, sh[4 * i], sh[4 * i + 1], sh[4 * i + 2], sh[4 * i + 3]);
+        if (t < best || (t == best && id < best_id)) { best = t; best_id = id; }
+      }
+    }
+  }
+  wave_min_hit(best, best_id);
+}
+
+__global__ __launch_bounds__(64 * RC_WAVES) void fo_raycast_kernel(int E, const double *__restrict__ edges, int nd,
+                                                                   const double *__restrict__ dseg,
+                                                                   const int32_t *__restrict__ dids, double ex,
+                                                                   double ey, int n_rays,
+                                                                   const double *__restrict__ dirs, double r,
+                                                                   double *__restrict__ range,
+                                                                   int32_t *__restrict__ hit_id,
+                                                                   double *__restrict__ ring) {
+  __shared__ double sh[RC_CHUNK * 4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * RC_WAVES + wave;
+  const bool active = i < n_rays;
+  const double dx = active ? dirs[2 * i] : 1.0, dy = active ? dirs[2 * i + 1] : 0.0;
+  double best;
+  int id;
+  wave_first_hit(sh, E, edges, nd, dseg, dids, ex, ey, dx, dy, active, -3, best, id);
+  if (active && lane == 0) {
+    if (!(best <= r)) { best = r; id = -1; }
+    range[i] = best;
+    hit_id[i] = id;
+    if (ring) {
+      ring[2 * i] = ex + best * dx;
+      ring[2 * i + 1] = ey + best * dy;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fan sector
+__device__ __forceinline__ int fan_ccw(int n_rays, const double *__restrict__ dirs, int i, double rx, double ry) {
+  const double *d = dirs + 2 * (size_t)(i == n_rays ? 0 : i);
+  const double c = d[0] * ry - d[1] * rx;
+  if (c > 0.0) return 1;
+  if (c < 0.0) return 0;
+  return (d[0] * rx + d[1] * ry) > 0.0;
+}
+__device__ int fan_search(int n_rays, const double *__restrict__ dirs, int a, int b, double rx, double ry) {
+  if (!fan_ccw(n_rays, dirs, a, rx, ry) || fan_ccw(n_rays, dirs, b, rx, ry)) return -1;
+  int lo = a, hi = b;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (fan_ccw(n_rays, dirs, mid, rx, ry)) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full, double rx, double ry) {
+  const int m = full ? n_rays / 2 : (n_rays - 1) / 2;
+  const int last = full ? n_rays : n_rays - 1;
+  const int s = fan_search(n_rays, dirs, 0, m, rx, ry);
+  if (s >= 0) return s;
+  return fan_search(n_rays, dirs, m, last, rx, ry);
+}
+
+// ------------------------------------------------------------------------------------------------ obstacle visibility
+// one workgroup (5 waves) per obstacle, one probe per wave (sensor_model.py:59-76 restated, see oracle)
+__global__ __launch_bounds__(320) void fo_obst_vis_kernel(int E, const double *__restrict__ edges, int nd,
+                                                          const double *__restrict__ dseg,
+                                                          const int32_t *__restrict__ dids,
+                                                          const double *__restrict__ ocorn,
+                                                          const double *__restrict__ ocen,
+                                                          const uint8_t *__restrict__ oflags, double ex, double ey,
+                                                          double r, int full, int n_rays,
+                                                          const double *__restrict__ dirs, uint8_t *__restrict__ vis) {
+  __shared__ double sh[RC_CHUNK * 4];
+  __shared__ int any;
+  const int o = blockIdx.x, p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) any = 0;
+  const bool exists = oflags[o] & 1;
+  const double qx = p < 4 ? ocorn[8 * (size_t)o + 2 * p] : ocen[2 * o];
+  const double qy = p < 4 ? ocorn[8 * (size_t)o + 2 * p + 1] : ocen[2 * o + 1];
+  const double rx = qx - ex, ry = qy - ey;
+  const double dist = sqrt(rx * rx + ry * ry);
+  bool cand = exists && !(dist > r + 0.01);
+  bool direct = false;
+  if (cand && dist == 0.0) { direct = true; cand = false; }
+  if (cand && fan_sector(n_rays, dirs, full, rx, ry) < 0) cand = false;
+  const double dx = cand ? rx / dist : 1.0, dy = cand ? ry / dist : 0.0;
+  double best;
+  int id;
+  wave_first_hit(sh, E, edges, nd, dseg, dids, ex, ey, dx, dy, cand, E + o, best, id);
+  if (lane == 0) {
+    bool v = direct;
+    if (cand) {
+      double t = best;
+      if (!(t <= dist)) t = dist;  // first_hit(..., rmax = dist)
+      if (t >= dist - 0.01) v = true;
+    }
+    if (v) atomicOr(&any, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) vis[o] = (uint8_t)(any ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------ cell grid
+__global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int rny, double rx0, double ry0, double cs,
+                               int ix0, int iy0, int nx, int ny, double ex, double ey, double hx, double hy, double r,
+                               int full, int n_rays, const double *__restrict__ dirs,
+                               const double *__restrict__ range, uint8_t *__restrict__ cls,
+                               uint8_t *__restrict__ occ_flag) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nx * ny) return;
+  const int ix = idx % nx, iy = idx / nx;
+  const int wx = ix0 + ix, wy = iy0 + iy;
+  uint8_t c = 0;
+  if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny && raster[(size_t)wy * rnx + wx]) c |= 1;
+  const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
+  const double rx = px - ex, ry = py - ey;
+  const double d2 = rx * rx + ry * ry;
+  const double r2 = r * r, ro2 = (1.5 * r) * (1.5 * r);
+  int vis = 0;
+  if ((c & 1) && d2 <= r2) {
+    const int i = fan_sector(n_rays, dirs, full, rx, ry);
+    if (rx == 0.0 && ry == 0.0) {
+      vis = 1;
+    } else if (i >= 0) {
+      const int j = (i + 1 == n_rays) ? 0 : i + 1;
+      const double hix = range[i] * dirs[2 * i], hiy = range[i] * dirs[2 * i + 1];
+      const double hjx = range[j] * dirs[2 * j], hjy = range[j] * dirs[2 * j + 1];
+      const double cr = (hjx - hix) * (ry - hiy) - (hjy - hiy) * (rx - hix);
+      vis = cr >= 0.0;
+    }
+  }
+  if (vis) c |= 2;
+  if ((c & 1) && !vis && d2 <= ro2 && (rx * hx + ry * hy) >= 0.0) c |= 4;
+  cls[idx] = c;
+  occ_flag[idx] = (c & 4) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ compaction
+// flags[n] -> ascending index list + count; three launches, no atomics (deterministic order)
+__global__ __launch_bounds__(256) void fo_flag_count_kernel(const uint8_t *__restrict__ flags, int n,
+                                                            int32_t *__restrict__ blk) {
+  __shared__ int wsum[4];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool f = idx < n && flags[idx];
+  const unsigned long long b = __ballot(f);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void fo_flag_scan_kernel(int32_t *__restrict__ blk, int nb,
+                                                            int32_t *__restrict__ total) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? blk[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nb) blk[i] = carry + sh[threadIdx.x] - v;  // exclusive
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void fo_flag_scatter_kernel(const uint8_t *__restrict__ flags, int n,
+                                                              const int32_t *__restrict__ blk,
+                                                              int32_t *__restrict__ out) {
+  __shared__ int wsum[4];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool f = idx < n && flags[idx];
+  const unsigned long long b = __ballot(f);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int before = __popcll(b & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[w] = __popcll(b);
+  __syncthreads();
+  int off = blk[blockIdx.x];
+  for (int k = 0; k < w; ++k) off += wsum[k];
+  if (f) out[off + before] = idx;
+}
+
+// ------------------------------------------------------------------------------------------------ spawn sampling
+__global__ void fo_spawn_flag_kernel(const uint8_t *__restrict__ cls, int nx, int ny, double rx0, double ry0, double cs,
+                                     int ix0, int iy0, double ex, double ey, double hx, double hy, double min_ahead,
+                                     double max_dist, uint8_t *__restrict__ flag) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nx * ny) return;
+  const int ix = idx % nx, iy = idx / nx;
+  uint8_t f = 0;
+  if (cls[idx] & 4) {
+    int front = 0;
+    if (ix > 0 && (cls[idx - 1] & 2)) front = 1;
+    if (ix + 1 < nx && (cls[idx + 1] & 2)) front = 1;
+    if (iy > 0 && (cls[idx - nx] & 2)) front = 1;
+    if (iy + 1 < ny && (cls[idx + nx] & 2)) front = 1;
+    if (front) {
+      const double px = rx0 + ((double)(ix0 + ix) + 0.5) * cs, py = ry0 + ((double)(iy0 + iy) + 0.5) * cs;
+      const double rx = px - ex, ry = py - ey;
+      if (!(rx * hx + ry * hy < min_ahead) && !(rx * rx + ry * ry > max_dist * max_dist)) f = 1;
+    }
+  }
+  flag[idx] = f;
+}
+
+__global__ void fo_spawn_pick_kernel(const int32_t *__restrict__ cand, const int32_t *__restrict__ n_cand, int nx,
+                                     double rx0, double ry0, double cs, int ix0, int iy0, int max_agents,
+                                     int32_t *__restrict__ cell, double *__restrict__ pos,
+                                     int32_t *__restrict__ n_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = *n_cand;
+  const int m = n < max_agents ? n : max_agents;
+  if (j == 0) *n_out = m;
+  if (j >= max_agents) return;
+  if (j < m) {
+    const int pick = (n <= max_agents) ? j : (int)(((long long)j * n) / max_agents);
+    const int ci = cand[pick];
+    cell[j] = ci;
+    pos[2 * j] = rx0 + ((double)(ix0 + ci % nx) + 0.5) * cs;
+    pos[2 * j + 1] = ry0 + ((double)(iy0 + ci / nx) + 0.5) * cs;
+  } else {
+    cell[j] = -1;
+    pos[2 * j] = 0.0;
+    pos[2 * j + 1] = 0.0;
+  }
+}
+
+struct SpawnTypes {  // per pattern slot (j % 4): type code, speed, raw dims, inflated dims
+  int32_t type[4];
+  double speed[4], raw_l[4], raw_w[4], infl_l[4], infl_w[4];
+};
+
+// heading per phantom: pedestrians -> unit vector to the closest point of the ego reference path
+// (agent.py:475-481 + helper_functions.py:38-76); vehicles -> lane heading raster at their cell
+__global__ void fo_spawn_heading_kernel(int max_agents, const int32_t *__restrict__ n_ptr,
+                                        const int32_t *__restrict__ cell, const double *__restrict__ pos,
+                                        SpawnTypes st, int N, const double *__restrict__ path,
+                                        const double *__restrict__ lane_yaw, int rnx, int rny, int nx, int ix0, int iy0,
+                                        double *__restrict__ yaw) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= max_agents) return;
+  if (j >= *n_ptr) { yaw[j] = 0.0; return; }
+  const int type = st.type[j & 3];
+  double a = NAN;
+  if (type != FO_TYPE_PEDESTRIAN && lane_yaw) {
+    const int ci = cell[j];
+    const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
+    if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny) a = lane_yaw[(size_t)wy * rnx + wx];
+  }
+  if (isnan(a)) {
+    const double px = pos[2 * j], py = pos[2 * j + 1];
+    double best = INFINITY, qx = px, qy = py;
+    for (int i = 0; i + 1 < N; ++i) {
+      const double ax = path[2 * i], ay = path[2 * i + 1], bx = path[2 * i + 2], by = path[2 * i + 3];
+      const double ex = bx - ax, ey = by - ay;
+      const double l2 = ex * ex + ey * ey;
+      double t = 0.0;
+      if (l2 > 0.0) {
+        t = ((px - ax) * ex + (py - ay) * ey) / l2;
+        if (t < 0.0) t = 0.0;
+        if (t > 1.0) t = 1.0;
+      }
+      const double cx = ax + t * ex, cy = ay + t * ey;
+      const double d2 = (px - cx) * (px - cx) + (py - cy) * (py - cy);
+      if (d2 < best) { best = d2; qx = cx; qy = cy; }
+    }
+    const double vx = qx - px, vy = qy - py;
+    const double n = sqrt(vx * vx + vy * vy);
+    double ux = 1.0, uy = 0.0;
+    if (n > 0.0) { ux = vx / n; uy = vy / n; }
+    a = atan2(uy, ux);
+    if (a < 0.0) a += 2.0 * M_PI;
+  }
+  yaw[j] = a;
+}
+
+// predictions in the layout fo_sweep_set_agents consumes; slots j >= n are inactive (len = 0)
+__global__ void fo_spawn_predict_kernel(int max_agents, const int32_t *__restrict__ n_ptr,
+                                        const double *__restrict__ pos0, const double *__restrict__ yaw0, SpawnTypes st,
+                                        int T, double dt, double var0, double factor, double *__restrict__ pos,
+                                        double *__restrict__ yaw, double *__restrict__ v, double *__restrict__ cov,
+                                        double *__restrict__ shape, double *__restrict__ raw, int32_t *__restrict__ type,
+                                        int32_t *__restrict__ len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= max_agents * T) return;
+  const int j = i / T, k = i % T;
+  const bool on = j < *n_ptr;
+  const int s = j & 3;
+  const double spd = st.speed[s];
+  const double a = yaw0[j];
+  const double vx = __builtin_rint(spd * cos(a) * 1000.0) / 1000.0;  // round(v cos psi, 3)  (agent.py:492, Q12)
+  const double vy = __builtin_rint(spd * sin(a) * 1000.0) / 1000.0;
+  const double t = (double)k * dt;
+  pos[2 * (size_t)i] = on ? pos0[2 * j] + t * vx : 0.0;
+  pos[2 * (size_t)i + 1] = on ? pos0[2 * j + 1] + t * vy : 0.0;
+  yaw[i] = on ? a : 0.0;
+  v[i] = on ? spd : 0.0;
+  const double var = var0 * pow(factor, (double)k);  // agent.py:273
+  double *c = cov + 4 * (size_t)i;
+  c[0] = var; c[1] = 0.0; c[2] = 0.0; c[3] = var;
+  if (k == 0) {
+    shape[2 * j] = st.infl_l[s]; shape[2 * j + 1] = st.infl_w[s];
+    raw[2 * j] = st.raw_l[s]; raw[2 * j + 1] = st.raw_w[s];
+    type[j] = st.type[s];
+    len[j] = on ? T : 0;
+  }
+}
+
+int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
+  int rc;
+  if ((rc = fo_reserve(ctx, &sc->d_flags, &sc->cap_cells, cells))) return rc;
+  const size_t nb = (cells + 255) / 256 + 1;
+  if ((rc = fo_reserve(ctx, &sc->d_blk, &sc->cap_blk, nb))) return rc;
+  if (!sc->d_ncand) FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_ncand, sizeof(int32_t)));
+  return FO_OK;
+}
+
+// flags -> ascending indices (out) + count (d_total)
+int compact(fo_ctx *ctx, Scene *sc, const uint8_t *flags, int n, int32_t *out, int32_t *d_total, hipStream_t s) {
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(fo_flag_count_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk);
+  hipLaunchKernelGGL(fo_flag_scan_kernel, dim3(1), dim3(1024), 0, s, sc->d_blk, nb, d_total);
+  hipLaunchKernelGGL(fo_flag_scatter_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk, out);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  return FO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fo_scene_destroy_(fo_ctx *ctx) {
+  if (!ctx || !ctx->scene) return;
+  Scene *sc = (Scene *)ctx->scene;
+  void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_dyn_edges, sc->d_dyn_ids, sc->d_flags, sc->d_blk,
+                  sc->d_cand, sc->d_ncand};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  delete sc;
+  ctx->scene = nullptr;
+}
+
+int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double *h_poly_xy, int E,
+                     const double *h_edges, double cs, double margin, const double *h_lane_yaw_or_null,
+                     const double *h_raster_origin_or_null, const int32_t *h_raster_dims_or_null) {
+  if (!ctx) return FO_E_ARG;
+  if (P < 1 || !h_poly_off || !h_poly_xy || E < 0 || (E > 0 && !h_edges) || !(cs > 0))
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_set_map: bad arguments (P=%d E=%d cs=%g)", P, E, cs);
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scene *sc = scene_of(ctx);
+  const int V = h_poly_off[P];
+  double xmin = INFINITY, ymin = INFINITY, xmax = -INFINITY, ymax = -INFINITY;
+  double *pbox = new double[4 * (size_t)P];
+  for (int p = 0; p < P; ++p) {
+    double bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+    for (int i = h_poly_off[p]; i < h_poly_off[p + 1]; ++i) {
+      bx0 = fmin(bx0, h_poly_xy[2 * i]); bx1 = fmax(bx1, h_poly_xy[2 * i]);
+      by0 = fmin(by0, h_poly_xy[2 * i + 1]); by1 = fmax(by1, h_poly_xy[2 * i + 1]);
+    }
+    pbox[4 * p] = bx0; pbox[4 * p + 1] = by0; pbox[4 * p + 2] = bx1; pbox[4 * p + 3] = by1;
+    xmin = fmin(xmin, bx0); ymin = fmin(ymin, by0); xmax = fmax(xmax, bx1); ymax = fmax(ymax, by1);
+  }
+  if (h_raster_origin_or_null && h_raster_dims_or_null) {
+    sc->x0 = h_raster_origin_or_null[0]; sc->y0 = h_raster_origin_or_null[1];
+    sc->rnx = h_raster_dims_or_null[0]; sc->rny = h_raster_dims_or_null[1];
+  } else {  // origin snapped to whole cells so that windows of different steps share cell boundaries
+    sc->x0 = floor((xmin - margin) / cs) * cs;
+    sc->y0 = floor((ymin - margin) / cs) * cs;
+    sc->rnx = (int)ceil((xmax + margin - sc->x0) / cs);
+    sc->rny = (int)ceil((ymax + margin - sc->y0) / cs);
+  }
+  if (sc->rnx < 1 || sc->rny < 1 || (long)sc->rnx * sc->rny > (1L << 28)) {
+    delete[] pbox;
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_set_map: raster %d x %d out of range", sc->rnx, sc->rny);
+  }
+  sc->P = P; sc->E = E; sc->cs = cs;
+  for (void **p : {(void **)&sc->d_edges, (void **)&sc->d_raster, (void **)&sc->d_lane_yaw}) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  }
+  int32_t *d_off = nullptr;
+  double *d_xy = nullptr, *d_box = nullptr;
+  const size_t cells = (size_t)sc->rnx * sc->rny;
+  FO_HIP_TRY(ctx, hipMalloc((void **)&d_off, sizeof(int32_t) * (P + 1)));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&d_xy, sizeof(double) * 2 * V));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&d_box, sizeof(double) * 4 * P));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_raster, cells));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_edges, sizeof(double) * 4 * (size_t)(E > 0 ? E : 1)));
+  FO_HIP_TRY(ctx, hipMemcpy(d_off, h_poly_off, sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMemcpy(d_xy, h_poly_xy, sizeof(double) * 2 * V, hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMemcpy(d_box, pbox, sizeof(double) * 4 * P, hipMemcpyHostToDevice));
+  delete[] pbox;
+  if (E > 0) FO_HIP_TRY(ctx, hipMemcpy(sc->d_edges, h_edges, sizeof(double) * 4 * (size_t)E, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(fo_raster_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, P, d_off, d_xy, d_box,
+                     sc->x0, sc->y0, cs, sc->rnx, sc->rny, sc->d_raster);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  FO_HIP_TRY(ctx, hipDeviceSynchronize());
+  (void)hipFree(d_off); (void)hipFree(d_xy); (void)hipFree(d_box);
+  if (h_lane_yaw_or_null) {
+    FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_lane_yaw, sizeof(double) * cells));
+    FO_HIP_TRY(ctx, hipMemcpy(sc->d_lane_yaw, h_lane_yaw_or_null, sizeof(double) * cells, hipMemcpyHostToDevice));
+  }
+  return FO_OK;
+}
+
+int fo_scene_map_info(fo_ctx *ctx, double *x0, double *y0, double *cs, int *nx, int *ny, int *n_edges) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_map_info: no map set");
+  Scene *sc = (Scene *)ctx->scene;
+  if (x0) *x0 = sc->x0;
+  if (y0) *y0 = sc->y0;
+  if (cs) *cs = sc->cs;
+  if (nx) *nx = sc->rnx;
+  if (ny) *ny = sc->rny;
+  if (n_edges) *n_edges = sc->E;
+  return FO_OK;
+}
+
+int fo_scene_copy_raster(fo_ctx *ctx, uint8_t *h_out) {
+  if (!ctx || !ctx->scene || !h_out) return fo_fail(ctx, FO_E_STATE, "fo_scene_copy_raster: no map set");
+  Scene *sc = (Scene *)ctx->scene;
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  FO_HIP_TRY(ctx, hipMemcpy(h_out, sc->d_raster, (size_t)sc->rnx * sc->rny, hipMemcpyDeviceToHost));
+  return FO_OK;
+}
+
+int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, double head_y, double r, int full_circle,
+                        int n_rays, const double *d_dirs, int O, const double *d_ocorn, const double *d_ocen,
+                        const uint8_t *d_oflags, int win_ix0, int win_iy0, int win_nx, int win_ny, double *d_range,
+                        int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
+                        int32_t *d_n_occ, void *stream) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_visibility: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  if (n_rays < 4 || !d_dirs || !d_range || !d_hit_id || O < 0 || (O > 0 && (!d_ocorn || !d_ocen || !d_oflags)) ||
+      win_nx < 1 || win_ny < 1 || !d_cls || !d_occ_idx || !d_n_occ || !(r > 0))
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: bad arguments");
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  const int nd = O * 4;
+  if (nd > 0) {
+    if ((rc = fo_reserve(ctx, &sc->d_dyn_edges, &sc->cap_dyn, (size_t)nd * 4))) return rc;
+    if ((rc = fo_reserve(ctx, &sc->d_dyn_ids, &sc->cap_dyn_ids, (size_t)nd))) return rc;
+    hipLaunchKernelGGL(fo_obst_edges_kernel, dim3((nd + 255) / 256), dim3(256), 0, s, O, sc->E, d_ocorn, d_oflags,
+                       sc->d_dyn_edges, sc->d_dyn_ids);
+  }
+  hipLaunchKernelGGL(fo_raycast_kernel, dim3((n_rays + RC_WAVES - 1) / RC_WAVES), dim3(64 * RC_WAVES), 0, s, sc->E,
+                     sc->d_edges, nd, sc->d_dyn_edges, sc->d_dyn_ids, ego_x, ego_y, n_rays, d_dirs, r, d_range,
+                     d_hit_id, d_ring);
+  if (O > 0 && d_obst_vis)
+    hipLaunchKernelGGL(fo_obst_vis_kernel, dim3(O), dim3(320), 0, s, sc->E, sc->d_edges, nd, sc->d_dyn_edges,
+                       sc->d_dyn_ids, d_ocorn, d_ocen, d_oflags, ego_x, ego_y, r, full_circle, n_rays, d_dirs,
+                       d_obst_vis);
+  const int cells = win_nx * win_ny;
+  if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
+  hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->d_raster, sc->rnx, sc->rny, sc->x0,
+                     sc->y0, sc->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
+                     n_rays, d_dirs, d_range, d_cls, sc->d_flags);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  return compact(ctx, sc, sc->d_flags, cells, d_occ_idx, d_n_occ, s);
+}
+
+int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
+                   double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int max_agents,
+                   const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
+                   const double *infl_l4, const double *infl_w4, int n_path, const double *d_path, int T, double dt,
+                   double var0, double var_factor, int32_t *d_cell, double *d_pos0, double *d_yaw0, int32_t *d_n,
+                   double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,
+                   int32_t *d_type, int32_t *d_len, void *stream) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  if (!d_cls || max_agents < 1 || !type4 || !speed4 || !raw_l4 || !raw_w4 || !infl_l4 || !infl_w4 || n_path < 2 ||
+      !d_path || T < 1 || !d_cell || !d_pos0 || !d_yaw0 || !d_n || !d_pos || !d_yaw || !d_v || !d_cov || !d_shape ||
+      !d_raw_dims || !d_type || !d_len)
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn: bad arguments");
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int cells = win_nx * win_ny;
+  int rc;
+  if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
+  if ((rc = fo_reserve(ctx, &sc->d_cand, &sc->cap_cand, (size_t)cells))) return rc;
+  hipLaunchKernelGGL(fo_spawn_flag_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, d_cls, win_nx, win_ny, sc->x0,
+                     sc->y0, sc->cs, win_ix0, win_iy0, ego_x, ego_y, head_x, head_y, min_ahead, max_dist, sc->d_flags);
+  if ((rc = compact(ctx, sc, sc->d_flags, cells, sc->d_cand, sc->d_ncand, s))) return rc;
+  hipLaunchKernelGGL(fo_spawn_pick_kernel, dim3((max_agents + 63) / 64), dim3(64), 0, s, sc->d_cand, sc->d_ncand, win_nx,
+                     sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, max_agents, d_cell, d_pos0, d_n);
+  SpawnTypes st;
+  for (int i = 0; i < 4; ++i) {
+    st.type[i] = type4[i]; st.speed[i] = speed4[i]; st.raw_l[i] = raw_l4[i]; st.raw_w[i] = raw_w4[i];
+    st.infl_l[i] = infl_l4[i]; st.infl_w[i] = infl_w4[i];
+  }
+  hipLaunchKernelGGL(fo_spawn_heading_kernel, dim3((max_agents + 63) / 64), dim3(64), 0, s, max_agents, d_n, d_cell,
+                     d_pos0, st, n_path, d_path, sc->d_lane_yaw, sc->rnx, sc->rny, win_nx, win_ix0, win_iy0, d_yaw0);
+  const int n = max_agents * T;
+  hipLaunchKernelGGL(fo_spawn_predict_kernel, dim3((n + 255) / 256), dim3(256), 0, s, max_agents, d_n, d_pos0, d_yaw0, st,
+                     T, dt, var0, var_factor, d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  return FO_OK;
+}
+
+int fo_scene_candidate_count(fo_ctx *ctx, int32_t *h_n, void *stream) {
+  if (!ctx || !ctx->scene || !h_n) return FO_E_ARG;
+  Scene *sc = (Scene *)ctx->scene;
+  FO_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+  FO_HIP_TRY(ctx, hipMemcpy(h_n, sc->d_ncand, sizeof(int32_t), hipMemcpyDeviceToHost));
+  return FO_OK;
+}
+
+}  // extern "C"

@@ -231,6 +231,20 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
     const int prot = (int)C[5], L = (int)C[6];
     const int Lh = min(Tm1, L);
 
+    if (L <= 0) {  // inactive slot (a spawn buffer that is only partly filled): no outputs enter any reduction
+      if (PAIR && valid) {
+        const size_t ps_ = (size_t)A * M;
+        for (int f = 0; f < FO_NPF; ++f) a.pair_f[(size_t)f * ps_ + (size_t)k * M + m] = NAN;
+        for (int f = 0; f < FO_NPI; ++f) a.pair_i[(size_t)f * ps_ + (size_t)k * M + m] = 0;
+      }
+      if (LISTS && valid) {
+        const size_t ls = (size_t)A * Tm1 * M;
+        for (int f = 0; f < FO_NL; ++f)
+          for (int t = 0; t < Tm1; ++t) a.lists[(size_t)f * ls + ((size_t)k * Tm1 + t) * M + m] = NAN;
+      }
+      continue;
+    }
+
     double dce = INFINITY;
     int tdce = 0;
     bool done = false;
@@ -504,6 +518,20 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
     const double hlB = C[0], hwB = C[1], hdev = C[2], f_ego = C[3], f_obs = C[4];
     const int prot = a.aint[2 * k], L = a.aint[2 * k + 1];
     const int Lh = min(Tm1, L);
+
+    if (L <= 0) {  // inactive slot (a spawn buffer that is only partly filled): no outputs enter any reduction
+      if (PAIR && valid) {
+        const size_t ps_ = (size_t)A * M;
+        for (int f = 0; f < FO_NPF; ++f) a.pair_f[(size_t)f * ps_ + (size_t)k * M + m] = NAN;
+        for (int f = 0; f < FO_NPI; ++f) a.pair_i[(size_t)f * ps_ + (size_t)k * M + m] = 0;
+      }
+      if (LISTS && valid) {
+        const size_t ls = (size_t)A * Tm1 * M;
+        for (int f = 0; f < FO_NL; ++f)
+          for (int t = 0; t < Tm1; ++t) a.lists[(size_t)f * ls + ((size_t)k * Tm1 + t) * M + m] = NAN;
+      }
+      continue;
+    }
 
     // evaluates n (<= 64) queued in-gate samples, one per lane (collision_probability.py:77-122)
     auto process = [&](int n) {

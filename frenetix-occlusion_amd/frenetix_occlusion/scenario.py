@@ -1,0 +1,369 @@
+"""Scene description without commonroad-io: CommonRoad 2020a XML -> plain arrays, plus the synthetic urban grid of
+BASELINE config 3.  (SURVEY §8f rank 1 "CommonRoad XML -> device map loader" and the harness row a18.)
+
+What the hot path needs from a scenario (ref: sensor_model.py:195-199, fo_obstacle.py:79-116, spawn_locator.py):
+lanelet polygons, the occluding boundary of their union, obstacle rectangles per time step, lanelet headings.
+Everything here is one-off host work (numpy); the per-step work happens in libfo_hip.so.
+"""
+import math
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+
+@dataclass
+class Lanelet:
+    lanelet_id: int
+    left: np.ndarray            # [n,2]
+    right: np.ndarray           # [n,2]
+    successors: List[int] = field(default_factory=list)
+    predecessors: List[int] = field(default_factory=list)
+    adj_left: Optional[int] = None
+    adj_left_same_direction: Optional[bool] = None
+    adj_right: Optional[int] = None
+    adj_right_same_direction: Optional[bool] = None
+    lanelet_type: str = "urban"
+
+    @property
+    def center(self):
+        return 0.5 * (self.left + self.right)
+
+    @property
+    def polygon(self):
+        """left bound followed by the reversed right bound (CommonRoad lanelet polygon [ext])"""
+        return np.concatenate((self.left, self.right[::-1]), axis=0)
+
+
+@dataclass
+class Obstacle:
+    obstacle_id: int
+    role: str                   # "static" | "dynamic"
+    obstacle_type: str          # commonroad ObstacleType value, e.g. "car", "bicycle"
+    length: float
+    width: float
+    initial_time_step: int
+    initial: np.ndarray         # x, y, yaw, v
+    states: np.ndarray          # [n,4] x, y, yaw, v for time steps initial+1 ...
+
+    def pose_at(self, timestep):
+        """fo_obstacle.py:79-93: rel = step - initial; 0 -> initial state, >= 1 -> state_list[rel-1], else absent."""
+        if self.role == "static":
+            return self.initial
+        rel = timestep - self.initial_time_step
+        if rel == 0:
+            return self.initial
+        if rel >= 1 and rel - 1 < len(self.states):
+            return self.states[rel - 1]
+        return None
+
+    def corners(self, pose):
+        """helper_functions.py:99-112: Rectangle vertices (-l/2,-w/2), (-l/2,w/2), (l/2,w/2), (l/2,-w/2) rotated + shifted"""
+        l2, w2 = self.length / 2.0, self.width / 2.0
+        v = np.array([[-l2, -w2], [-l2, w2], [l2, w2], [l2, -w2]])
+        c, s = math.cos(pose[2]), math.sin(pose[2])
+        rot = np.array([[c, -s], [s, c]])
+        return (rot @ v.T).T + pose[:2]
+
+
+@dataclass
+class Scenario:
+    dt: float
+    lanelets: List[Lanelet]
+    obstacles: List[Obstacle]
+    intersections: List[dict] = field(default_factory=list)
+    ego_initial: Optional[np.ndarray] = None  # x, y, yaw, v
+    benchmark_id: str = ""
+
+    def lanelet_by_id(self, lid) -> Lanelet:
+        for ll in self.lanelets:
+            if ll.lanelet_id == lid:
+                return ll
+        raise KeyError(lid)
+
+    def obstacle_arrays(self, timestep):
+        """corner points [O,4,2], centres [O,2], flags [O] (bit0 present, bit1 occludes: not a bicycle, Q10)"""
+        O = len(self.obstacles)
+        corn = np.zeros((O, 4, 2))
+        cen = np.zeros((O, 2))
+        flags = np.zeros(O, dtype=np.uint8)
+        yaw = np.zeros(O)
+        for i, ob in enumerate(self.obstacles):
+            pose = ob.pose_at(timestep)
+            if pose is None:
+                continue
+            corn[i] = ob.corners(pose)
+            cen[i] = pose[:2]
+            yaw[i] = pose[2]
+            flags[i] = 1 | (0 if ob.obstacle_type == "bicycle" else 2)
+        return corn, cen, flags, yaw
+
+
+# ------------------------------------------------------------------------------------------------ XML
+def _pts(node):
+    return np.array([[float(p.find("x").text), float(p.find("y").text)] for p in node.findall("point")])
+
+
+def _exact(node, name, default=0.0):
+    n = node.find(name)
+    if n is None:
+        return default
+    e = n.find("exact")
+    if e is not None:
+        return float(e.text)
+    lo, hi = n.find("intervalStart"), n.find("intervalEnd")
+    if lo is not None and hi is not None:
+        return 0.5 * (float(lo.text) + float(hi.text))
+    return default
+
+
+def _state(node):
+    p = node.find("position").find("point")
+    return np.array([float(p.find("x").text), float(p.find("y").text), _exact(node, "orientation"),
+                     _exact(node, "velocity")]), int(round(_exact(node, "time")))
+
+
+def load_commonroad_xml(path) -> Scenario:
+    root = ET.parse(path).getroot()
+    dt = float(root.attrib.get("timeStepSize", 0.1))
+    lanelets = []
+    for ln in root.findall("lanelet"):
+        ll = Lanelet(int(ln.attrib["id"]), _pts(ln.find("leftBound")), _pts(ln.find("rightBound")))
+        ll.successors = [int(s.attrib["ref"]) for s in ln.findall("successor")]
+        ll.predecessors = [int(s.attrib["ref"]) for s in ln.findall("predecessor")]
+        al, ar = ln.find("adjacentLeft"), ln.find("adjacentRight")
+        if al is not None:
+            ll.adj_left, ll.adj_left_same_direction = int(al.attrib["ref"]), al.attrib.get("drivingDir") == "same"
+        if ar is not None:
+            ll.adj_right, ll.adj_right_same_direction = int(ar.attrib["ref"]), ar.attrib.get("drivingDir") == "same"
+        lt = ln.find("laneletType")
+        if lt is not None and lt.text:
+            ll.lanelet_type = lt.text
+        lanelets.append(ll)
+    obstacles = []
+    for tag, role in (("staticObstacle", "static"), ("dynamicObstacle", "dynamic")):
+        for ob in root.findall(tag):
+            rect = ob.find("shape").find("rectangle")
+            if rect is None:
+                continue  # circles / polygons do not occur in the example scenarios
+            init, t0 = _state(ob.find("initialState"))
+            states = []
+            traj = ob.find("trajectory")
+            if traj is not None:
+                states = [_state(s)[0] for s in traj.findall("state")]
+            obstacles.append(Obstacle(int(ob.attrib["id"]), role, ob.find("type").text, float(rect.find("length").text),
+                                      float(rect.find("width").text), t0, init,
+                                      np.array(states).reshape(-1, 4)))
+    inters = []
+    for it in root.findall("intersection"):
+        incs = []
+        for inc in it.findall("incoming"):
+            incs.append({"incoming": [int(x.attrib["ref"]) for x in inc.findall("incomingLanelet")],
+                         "right": [int(x.attrib["ref"]) for x in inc.findall("successorsRight")],
+                         "straight": [int(x.attrib["ref"]) for x in inc.findall("successorsStraight")],
+                         "left": [int(x.attrib["ref"]) for x in inc.findall("successorsLeft")]})
+        inters.append({"id": int(it.attrib["id"]), "incomings": incs})
+    ego = None
+    pp = root.find("planningProblem")
+    if pp is not None:
+        ego, _ = _state(pp.find("initialState"))
+    return Scenario(dt, lanelets, obstacles, inters, ego, root.attrib.get("benchmarkID", ""))
+
+
+# ------------------------------------------------------------------------------------------------ map geometry
+def _signed_area(p):
+    x, y = p[:, 0], p[:, 1]
+    return 0.5 * float(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y))
+
+
+def points_in_polygon(q, poly):
+    """crossing-number test, same rule as the raster kernel (half-open in y); q [n,2] -> bool [n]"""
+    x, y = q[:, 0][:, None], q[:, 1][:, None]
+    xi, yi = poly[:, 0][None, :], poly[:, 1][None, :]
+    xj, yj = np.roll(poly[:, 0], 1)[None, :], np.roll(poly[:, 1], 1)[None, :]
+    cond = (yi > y) != (yj > y)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xc = xi + (y - yi) * (xj - xi) / (yj - yi)
+    return (np.sum(cond & (x < xc), axis=1) % 2) == 1
+
+
+def union_boundary_edges(polys, eps=1e-4, tol=1e-9):
+    """Occluding boundary of the union of the lanelet polygons (sensor_model.py:195-199 takes the union with GEOS and
+    then walks its exterior, :131-139).  Every polygon edge is split where other polygons cross or touch it; a piece
+    is boundary iff the point `eps` outside of its midpoint lies in no polygon.  Returns [E,4] (ax, ay, bx, by).
+    Interior rings (city blocks enclosed by roads) are kept: they occlude physically."""
+    polys = [np.asarray(p, dtype=np.float64) for p in polys]
+    boxes = np.array([[p[:, 0].min(), p[:, 1].min(), p[:, 0].max(), p[:, 1].max()] for p in polys])
+    out = []
+    for pi, p in enumerate(polys):
+        n = len(p)
+        a, b = p, np.roll(p, -1, axis=0)
+        ccw = _signed_area(p) > 0
+        near = [qi for qi in range(len(polys)) if qi != pi and not (
+            boxes[qi, 0] > boxes[pi, 2] + tol or boxes[qi, 2] < boxes[pi, 0] - tol or
+            boxes[qi, 1] > boxes[pi, 3] + tol or boxes[qi, 3] < boxes[pi, 1] - tol)]
+        splits = [[0.0, 1.0] for _ in range(n)]
+        for qi in near:
+            q = polys[qi]
+            c, d = q, np.roll(q, -1, axis=0)
+            e = (b - a)[:, None, :]                 # [n,1,2]
+            f = (d - c)[None, :, :]                 # [1,m,2]
+            w = c[None, :, :] - a[:, None, :]       # [n,m,2]
+            den = e[..., 0] * f[..., 1] - e[..., 1] * f[..., 0]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (w[..., 0] * f[..., 1] - w[..., 1] * f[..., 0]) / den
+                u = (w[..., 0] * e[..., 1] - w[..., 1] * e[..., 0]) / den
+            hit = (np.abs(den) > 1e-14) & (t > tol) & (t < 1 - tol) & (u >= -tol) & (u <= 1 + tol)
+            for i, j in zip(*np.nonzero(hit)):
+                splits[i].append(float(t[i, j]))
+            # vertices of q lying on an edge of p (collinear overlaps start/stop there)
+            l2 = np.sum(e[..., :] ** 2, axis=-1)                      # [n,1]
+            tt = np.sum(w * e, axis=-1) / l2                          # [n,m]
+            proj = a[:, None, :] + tt[..., None] * e
+            dist = np.linalg.norm(c[None, :, :] - proj, axis=-1)
+            on = (dist < 1e-7) & (tt > tol) & (tt < 1 - tol)
+            for i, j in zip(*np.nonzero(on)):
+                splits[i].append(float(tt[i, j]))
+        seg_a, seg_b = [], []
+        for i in range(n):
+            ts = np.unique(np.round(np.array(splits[i]), 12))
+            for t0, t1 in zip(ts[:-1], ts[1:]):
+                if t1 - t0 < 1e-12:
+                    continue
+                seg_a.append(a[i] + t0 * (b[i] - a[i]))
+                seg_b.append(a[i] + t1 * (b[i] - a[i]))
+        if not seg_a:
+            continue
+        sa, sb = np.array(seg_a), np.array(seg_b)
+        ev = sb - sa
+        ln = np.linalg.norm(ev, axis=1, keepdims=True)
+        nrm = np.concatenate((ev[:, 1:2], -ev[:, 0:1]), axis=1) / np.maximum(ln, 1e-300)
+        if not ccw:
+            nrm = -nrm
+        probe = 0.5 * (sa + sb) + eps * nrm
+        covered = np.zeros(len(probe), dtype=bool)
+        for qi in near:
+            bx = boxes[qi]
+            cand = (~covered) & (probe[:, 0] >= bx[0]) & (probe[:, 0] <= bx[2]) & (probe[:, 1] >= bx[1]) & (probe[:, 1] <= bx[3])
+            if cand.any():
+                idx = np.nonzero(cand)[0]
+                covered[idx] |= points_in_polygon(probe[idx], polys[qi])
+        keep = ~covered
+        out.append(np.concatenate((sa[keep], sb[keep]), axis=1))
+    return np.concatenate(out, axis=0) if out else np.zeros((0, 4))
+
+
+def lane_yaw_raster(lanelets, x0, y0, cs, nx, ny):
+    """per raster cell: heading of the nearest centre-line segment of a lanelet containing the cell centre
+    (what lanelet_orientation_at_position [ext] gives spawn_locator.py:653-660); NaN off-lane."""
+    out = np.full((ny, nx), np.nan)
+    for ll in lanelets:
+        poly = ll.polygon
+        ix0 = max(int(math.floor((poly[:, 0].min() - x0) / cs)), 0)
+        ix1 = min(int(math.ceil((poly[:, 0].max() - x0) / cs)), nx)
+        iy0 = max(int(math.floor((poly[:, 1].min() - y0) / cs)), 0)
+        iy1 = min(int(math.ceil((poly[:, 1].max() - y0) / cs)), ny)
+        if ix1 <= ix0 or iy1 <= iy0:
+            continue
+        gx, gy = np.meshgrid(x0 + (np.arange(ix0, ix1) + 0.5) * cs, y0 + (np.arange(iy0, iy1) + 0.5) * cs)
+        q = np.stack((gx.ravel(), gy.ravel()), -1)
+        inside = points_in_polygon(q, poly)
+        if not inside.any():
+            continue
+        qi = q[inside]
+        c = ll.center
+        a, b = c[:-1], c[1:]
+        e = b - a
+        l2 = np.maximum(np.sum(e * e, axis=1), 1e-300)
+        t = np.clip(np.sum((qi[:, None, :] - a[None]) * e[None], axis=2) / l2[None], 0.0, 1.0)
+        proj = a[None] + t[..., None] * e[None]
+        k = np.argmin(np.sum((qi[:, None, :] - proj) ** 2, axis=2), axis=1)
+        yaw = np.arctan2(e[k, 1], e[k, 0])
+        sub = out[iy0:iy1, ix0:ix1].ravel()
+        idx = np.nonzero(inside)[0]
+        free = np.isnan(sub[idx])       # first lanelet in list order wins where lanelets overlap
+        sub[idx[free]] = yaw[free]
+        out[iy0:iy1, ix0:ix1] = sub.reshape(iy1 - iy0, ix1 - ix0)
+    return out
+
+
+@dataclass
+class MapGeometry:
+    poly_off: np.ndarray     # int32 [P+1]
+    poly_xy: np.ndarray      # [V,2]
+    edges: np.ndarray        # [E,4]
+
+    @classmethod
+    def from_lanelets(cls, lanelets):
+        polys = [ll.polygon for ll in lanelets]
+        off = np.zeros(len(polys) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(p) for p in polys])
+        return cls(off, np.concatenate(polys, axis=0), union_boundary_edges(polys))
+
+
+# ------------------------------------------------------------------------------------------------ synthetic city
+def synthetic_urban_grid(n_blocks=8, block=60.0, lane_w=3.5, lanes_per_dir=2, ds=2.0, n_parked=64, seed=20240134):
+    """BASELINE config 3: Manhattan grid, n_blocks x n_blocks blocks of `block` m, `lanes_per_dir` lanes per direction;
+    bounds sampled every `ds` m => O(10^4) boundary edges.  Parked cars (4.5 x 1.8 m, static) on the outer lanes."""
+    rng = np.random.default_rng(seed)
+    W = 2 * lanes_per_dir * lane_w
+    pitch = block + W
+    lanelets, lid = [], 1
+    n_lines = n_blocks + 1
+
+    def straight(p0, p1, off_l, off_r):
+        d = p1 - p0
+        L = np.linalg.norm(d)
+        u = d / L
+        nvec = np.array([-u[1], u[0]])
+        k = max(int(round(L / ds)), 1)
+        s = np.linspace(0.0, L, k + 1)[:, None]
+        base = p0[None] + s * u[None]
+        return base + off_l * nvec[None], base + off_r * nvec[None]
+
+    for axis in (0, 1):
+        for line in range(n_lines):
+            c = line * pitch
+            for seg in range(-1, 2 * n_lines - 1):  # even: intersection square, odd: street between squares
+                if seg % 2 == 0:
+                    a0 = (seg // 2) * pitch - W / 2
+                    a1 = a0 + W
+                else:
+                    a0 = ((seg - 1) // 2) * pitch + W / 2
+                    a1 = a0 + block
+                if seg == -1:
+                    continue
+                for lane in range(2 * lanes_per_dir):
+                    off_hi = W / 2 - lane * lane_w
+                    off_lo = off_hi - lane_w
+                    fwd = lane >= lanes_per_dir
+                    if axis == 0:
+                        p0, p1 = np.array([a0, c]), np.array([a1, c])
+                    else:
+                        p0, p1 = np.array([c, a0]), np.array([c, a1])
+                    if not fwd:
+                        p0, p1 = p1, p0
+                        left, right = straight(p0, p1, -off_lo, -off_hi)
+                    else:
+                        left, right = straight(p0, p1, off_hi, off_lo)
+                    lanelets.append(Lanelet(lid, left, right))
+                    lid += 1
+    # parked cars near the central intersection, on the outermost lanes
+    mid = (n_lines // 2) * pitch
+    obstacles = []
+    for i in range(n_parked):
+        axis = i % 2
+        side = 1 if (i // 2) % 2 else -1
+        along = mid + rng.uniform(-2.2 * pitch, 2.2 * pitch)
+        k = round((along - mid) / pitch)
+        if abs(along - (mid + k * pitch)) < W / 2 + 4.0:   # keep the intersections free
+            along += math.copysign(W / 2 + 6.0, along - (mid + k * pitch) if along != mid + k * pitch else 1.0)
+        line_c = mid + rng.integers(-1, 2) * pitch
+        lat = line_c + side * (W / 2 - 1.0)
+        pos = np.array([along, lat]) if axis == 0 else np.array([lat, along])
+        yaw = 0.0 if axis == 0 else math.pi / 2
+        obstacles.append(Obstacle(1000 + i, "static", "parkedVehicle", 4.5, 1.8, 0,
+                                  np.array([pos[0], pos[1], yaw, 0.0]), np.zeros((0, 4))))
+    ego = np.array([mid - 20.0, mid - lane_w / 2, 0.0, 8.0])
+    return Scenario(0.1, lanelets, obstacles, [], ego, "synthetic_urban_grid")

@@ -14,7 +14,7 @@
  *   agent predictions           : pos [A][Ta][2], yaw [A][Ta], v [A][Ta], cov [A][Ta][4] (xx,xy,yx,yy),
  *                                 shape [A][2] = prediction['shape'] (inflated length,width; ref: agent.py:404-409,523-524),
  *                                 raw_dims [A][2] = agent.shape (ref: agent.py:216), type int32 [A] (FO_TYPE_*),
- *                                 len int32 [A] = number of valid samples of that prediction (1..Ta)
+ *                                 len int32 [A] = number of valid samples of that prediction (1..Ta; 0 = inactive slot)
  *   outputs, trajectory index fastest (lane = trajectory):
  *     cost   [M][FO_NC]                 per-trajectory cost vector (the unit all-gathered across GPUs)
  *     safe   uint8 [M]                  safety_assessment of metric.py:50-100
@@ -104,6 +104,48 @@ int fo_sweep_timing_read(fo_ctx *ctx, double *total_ms, int *launches);
 
 /* launch geometry of the last sweep launch (for profiling scripts) */
 int fo_sweep_last_launch(const fo_ctx *ctx, int *grid, int *block, int *agents_per_wave);
+
+/* ---- scene: visibility / occlusion / phantom spawn ------------------------------------------------------------
+ * The reference computes these with GEOS polygon algebra; this library uses a polar ray fan + a cell grid (the
+ * discretisation is specified in DESIGN.md).  Occluder ids: 0..E-1 = map boundary edge, E + o = obstacle o, -1 = none
+ * within range.  Cell class bits: 1 road, 2 visible, 4 occluded.  Cells are indexed iy * win_nx + ix inside the
+ * window whose lower-left raster cell is (win_ix0, win_iy0). */
+
+/* One-off (replaces SensorModel.__init__ / _convert_lanelet_network, sensor_model.py:17-39,195-199): HOST arrays.
+ * polygons: P lanelet polygons, vertices poly_xy[poly_off[p] .. poly_off[p+1]); edges [E][4] = occluding boundary
+ * segments (ax, ay, bx, by); cs = cell size; margin = raster margin around the polygons' bounding box.
+ * lane_yaw (optional, [rny][rnx], NaN off-lane) must match the raster geometry, which the caller may fix with
+ * raster_origin[2] / raster_dims[2] (else it is derived from the bounding box and reported by fo_scene_map_info). */
+int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double *h_poly_xy, int E,
+                     const double *h_edges, double cs, double margin, const double *h_lane_yaw_or_null,
+                     const double *h_raster_origin_or_null, const int32_t *h_raster_dims_or_null);
+int fo_scene_map_info(fo_ctx *ctx, double *x0, double *y0, double *cs, int *nx, int *ny, int *n_edges);
+int fo_scene_copy_raster(fo_ctx *ctx, uint8_t *h_out);
+
+/* Per step (replaces SensorModel.calc_visible_and_occluded_area, sensor_model.py:41-101).  d_dirs [n_rays][2] unit
+ * ray directions in counter-clockwise order (full_circle: ray n_rays == ray 0); obstacles at this step:
+ * d_ocorn [O][4][2] corner points (fo_obstacle.py:79-93), d_ocen [O][2], d_oflags [O] (bit0 present, bit1 occludes --
+ * clear for bicycles, sensor_model.py:177).  Outputs: d_range/d_hit_id [n_rays], d_ring [n_rays][2] (vertices of the
+ * visible polygon = what evaluate_scenario returns), d_obst_vis [O] (visible_objects_timestep), d_cls [ny][nx],
+ * d_occ_idx (ascending, capacity nx*ny) + d_n_occ [1]. */
+int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, double head_y, double r, int full_circle,
+                        int n_rays, const double *d_dirs, int O, const double *d_ocorn, const double *d_ocen,
+                        const uint8_t *d_oflags, int win_ix0, int win_iy0, int win_nx, int win_ny, double *d_range,
+                        int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
+                        int32_t *d_n_occ, void *stream);
+
+/* Phantom sampling in the occluded cells + constant-velocity predictions (replaces the cell-based core of
+ * SpawnLocator.find_spawn_points, spawn_locator.py:80-139, and agent.py:451-536).  Agent j takes pattern slot j % 4
+ * (type4/speed4/raw/inflated dims: HOST arrays of 4).  d_path [n_path][2] = ego reference path.  Outputs for
+ * max_agents slots, directly in the layout fo_sweep_set_agents consumes (slots >= *d_n have len 0 = inactive). */
+int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
+                   double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int max_agents,
+                   const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
+                   const double *infl_l4, const double *infl_w4, int n_path, const double *d_path, int T, double dt,
+                   double var0, double var_factor, int32_t *d_cell, double *d_pos0, double *d_yaw0, int32_t *d_n,
+                   double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,
+                   int32_t *d_type, int32_t *d_len, void *stream);
+int fo_scene_candidate_count(fo_ctx *ctx, int32_t *h_n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -292,6 +292,11 @@ static int eval_trajectory(int T, const double *x, const double *y, const double
     double pf[FO_NPF];
     int32_t pi[FO_NPI] = {0, 0, 0, 0};
     for (int i = 0; i < FO_NPF; ++i) pf[i] = NAN;
+    if (L <= 0) { /* inactive slot of a partly filled spawn buffer (extension of this build): contributes nothing */
+      if (pair_f) memcpy(pair_f + (size_t)k * FO_NPF, pf, sizeof pf);
+      if (pair_i) memcpy(pair_i + (size_t)k * FO_NPI, pi, sizeof pi);
+      continue;
+    }
     /* --- cp (cp.py:25-42) */
     if (mask & FO_M_CP) {
       int rc = cp_pair(T, x, y, th, veh, L, pos, yaw, cov, ashape[2 * k], cp);
@@ -376,7 +381,7 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
                     double *lists, double *cost, uint8_t *safe, int nthreads) {
   (void)a;
   if (M < 0 || T < 1 || A < 0) return -1;
-  for (int k = 0; k < A; ++k) if (alen[k] < 1 || alen[k] > Ta) return -1;
+  for (int k = 0; k < A; ++k) if (alen[k] < 0 || alen[k] > Ta) return -1;
   uint32_t mask = fo_oracle_required_metrics(metric_mask);
   const int Tm1 = T - 1;
   int err = 0;

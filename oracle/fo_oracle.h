@@ -78,6 +78,27 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
                     const fo_thresholds_t *thr, uint32_t metric_mask, double *pair_f, int32_t *pair_i,
                     double *lists, double *cost, uint8_t *safe, int nthreads);
 
+/* ---- scene half (fo_oracle_scene.c): discretisation defined in DESIGN.md, "parity unpinned" vs the reference ---- */
+int fo_oracle_road_raster(int P, const int32_t *poly_off, const double *poly_xy, double x0, double y0, double cs,
+                          int nx, int ny, uint8_t *mask);
+int fo_oracle_raycast(int E, const double *edges, int O, const double *ocorn, const uint8_t *oflags,
+                      const double *ego, int n_rays, const double *dirs, double r, double *range, int32_t *hit_id,
+                      double *ring);
+int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double ry0, double cs, int ix0, int iy0,
+                   int nx, int ny, const double *ego, const double *hdir, double r, int full, int n_rays,
+                   const double *dirs, const double *range, uint8_t *cls, int32_t *occ_idx, int32_t *n_occ);
+int fo_oracle_obstacle_visibility(int E, const double *edges, int O, const double *ocorn, const double *ocen,
+                                  const uint8_t *oflags, const double *ego, double r, int full, int n_rays,
+                                  const double *dirs, uint8_t *vis);
+int fo_oracle_spawn_cells(const uint8_t *cls, int nx, int ny, double rx0, double ry0, double cs, int ix0, int iy0,
+                          const double *ego, const double *hdir, double min_ahead, double max_dist, int max_agents,
+                          int32_t *cell, double *pos, int32_t *n_out, int32_t *n_cand_out);
+void fo_oracle_normal_to_polyline(int N, const double *path, double px, double py, double *nx_, double *ny_);
+int fo_oracle_spawn_headings(int n, const double *pos, const int32_t *type, int N, const double *path,
+                             const double *lane_yaw_at, double *yaw);
+int fo_oracle_cv_predictions(int n, const double *pos0, const double *yaw, const double *speed, int T, double dt,
+                             double var0, double factor, double *pos, double *yaw_l, double *v_l, double *cov);
+
 /* metric.py:125-147 dependency closure on the activated-metric bit mask */
 uint32_t fo_oracle_required_metrics(uint32_t mask);
 

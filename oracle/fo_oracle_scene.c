@@ -1,0 +1,309 @@
+/* fo_oracle_scene.c -- CPU restatement of the scene half of the hot path: visibility, occluded cells, phantom
+ * spawn sampling, pedestrian predictions.  TEST INFRASTRUCTURE ONLY (see fo_oracle.h).
+ *
+ * PARITY UNPINNED against the reference: the reference computes visibility by exact polygon algebra in
+ * shapely/GEOS (sensor_model.py:103-193) -- there are no rays and no cells in it and GEOS is not
+ * available here.  What this file restates is the discretisation DESIGN.md defines (polar ray fan + cell grid)
+ * whose continuum limit is the reference's construction:
+ *   visible  = road  ∩  sensor footprint  −  shadow of every road-boundary edge  −  obstacles and their shadow wedges
+ *              (sensor_model.py:112-157,159-193; helper_functions.py:79-96,139-176); bicycles never occlude (Q10)
+ *   occluded = road  ∩  half-disc(heading ± 90°, 1.5 r)  −  visible                    (sensor_model.py:85-93)
+ * and is pinned by analytic known-answer tests (tests/test_scene_kat.py).  The HIP kernels must agree with this
+ * file bit-for-bit on every integer output; both sides use only + - * / sqrt and comparisons on float64 and are
+ * compiled without FMA contraction.
+ */
+#define _GNU_SOURCE
+#include "fo_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- static map: road raster
+ * mask[iy*nx+ix] = 1 iff the centre of world cell (ix,iy) lies in at least one lanelet polygon
+ * (= inside road_polygon, the union of sensor_model.py:195-199).  Crossing-number rule, half-open in y. */
+int fo_oracle_road_raster(int P, const int32_t *poly_off, const double *poly_xy, double x0, double y0, double cs,
+                          int nx, int ny, uint8_t *mask) {
+  for (int iy = 0; iy < ny; ++iy) {
+    for (int ix = 0; ix < nx; ++ix) {
+      const double px = x0 + ((double)ix + 0.5) * cs, py = y0 + ((double)iy + 0.5) * cs;
+      int inside_any = 0;
+      for (int p = 0; p < P && !inside_any; ++p) {
+        const int b = poly_off[p], e = poly_off[p + 1];
+        int c = 0;
+        for (int i = b, j = e - 1; i < e; j = i++) {
+          const double xi = poly_xy[2 * i], yi = poly_xy[2 * i + 1], xj = poly_xy[2 * j], yj = poly_xy[2 * j + 1];
+          if ((yi > py) != (yj > py)) {
+            const double xc = xi + (py - yi) * (xj - xi) / (yj - yi);
+            if (px < xc) c ^= 1;
+          }
+        }
+        inside_any = c;
+      }
+      mask[(size_t)iy * nx + ix] = (uint8_t)inside_any;
+    }
+  }
+  return 0;
+}
+
+/* ---------------------------------------------------------------- first hit of one ray against the occluder soup
+ * Ray o + t d (d unit), segment a + u (b - a):  denom = d x e;  t = (w x e)/denom, u = (w x d)/denom, w = a - o.
+ * Hit iff denom != 0, t >= 0, 0 <= u <= 1.  First hit = lexicographic minimum of (t, id).  Returns t (or +inf). */
+static double ray_segment(double ox, double oy, double dx, double dy, double ax, double ay, double bx, double by) {
+  const double ex = bx - ax, ey = by - ay;
+  const double denom = dx * ey - dy * ex;
+  if (denom == 0.0) return INFINITY;
+  const double wx = ax - ox, wy = ay - oy;
+  const double t = (wx * ey - wy * ex) / denom;
+  const double u = (wx * dy - wy * dx) / denom;
+  if (t >= 0.0 && u >= 0.0 && u <= 1.0) return t;
+  return INFINITY;
+}
+
+/* occluder ids: 0..E-1 map boundary edges, E + o for obstacle o (any of its four sides); -1 = nothing within range.
+ * skip_obst >= 0 leaves that obstacle out (used by the visibility probes of that obstacle). */
+static void first_hit(int E, const double *edges, int O, const double *ocorn, const uint8_t *oflags, double ox,
+                      double oy, double dx, double dy, double rmax, int skip_obst, double *t_out, int *id_out) {
+  double best = INFINITY;
+  int id = -1;
+  for (int e = 0; e < E; ++e) {
+    const double *s = edges + 4 * (size_t)e;
+    const double t = ray_segment(ox, oy, dx, dy, s[0], s[1], s[2], s[3]);
+    if (t < best) { best = t; id = e; }
+  }
+  for (int o = 0; o < O; ++o) {
+    if (!(oflags[o] & 1) || !(oflags[o] & 2) || o == skip_obst) continue; /* absent, or a bicycle (Q10) */
+    const double *c = ocorn + 8 * (size_t)o;
+    for (int s = 0; s < 4; ++s) {
+      const int s2 = (s + 1) & 3;
+      const double t = ray_segment(ox, oy, dx, dy, c[2 * s], c[2 * s + 1], c[2 * s2], c[2 * s2 + 1]);
+      if (t < best) { best = t; id = E + o; }
+    }
+  }
+  if (!(best <= rmax)) { best = rmax; id = -1; }
+  *t_out = best;
+  *id_out = id;
+}
+
+/* the polar fan: range[i] = distance to the first occluder along dirs[i] (clamped to r), hit_id[i] as above,
+ * ring[i] = ego + range[i] * dirs[i] (vertices of the visible-area polygon handed back by evaluate_scenario) */
+int fo_oracle_raycast(int E, const double *edges, int O, const double *ocorn, const uint8_t *oflags,
+                      const double *ego, int n_rays, const double *dirs, double r, double *range, int32_t *hit_id,
+                      double *ring) {
+  for (int i = 0; i < n_rays; ++i) {
+    double t;
+    int id;
+    first_hit(E, edges, O, ocorn, oflags, ego[0], ego[1], dirs[2 * i], dirs[2 * i + 1], r, -1, &t, &id);
+    range[i] = t;
+    hit_id[i] = id;
+    if (ring) {
+      ring[2 * i] = ego[0] + t * dirs[2 * i];
+      ring[2 * i + 1] = ego[1] + t * dirs[2 * i + 1];
+    }
+  }
+  return 0;
+}
+
+/* sector of the fan that contains direction (rx, ry): the i with rel in [ray i, ray i+1) counter-clockwise.
+ * ccw(i) = d_i x rel > 0, or = 0 with d_i . rel > 0.  The fan is searched in two halves (each spans <= pi, so
+ * ccw() is monotone inside a half): full fan -> [0, n/2] and [n/2, n] with ray n == ray 0; open fan -> [0, m] and
+ * [m, n-1], m = (n-1)/2.  Returns -1 when rel is outside an open fan (or is the zero vector). */
+static int fan_ccw(int n_rays, const double *dirs, int i, double rx, double ry) {
+  const double *d = dirs + 2 * (size_t)(i == n_rays ? 0 : i);
+  const double c = d[0] * ry - d[1] * rx;
+  if (c > 0.0) return 1;
+  if (c < 0.0) return 0;
+  return (d[0] * rx + d[1] * ry) > 0.0;
+}
+
+static int fan_search(int n_rays, const double *dirs, int a, int b, double rx, double ry) {
+  if (!fan_ccw(n_rays, dirs, a, rx, ry) || fan_ccw(n_rays, dirs, b, rx, ry)) return -1;
+  int lo = a, hi = b;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (fan_ccw(n_rays, dirs, mid, rx, ry)) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+static int fan_sector(int n_rays, const double *dirs, int full, double rx, double ry) {
+  const int m = full ? n_rays / 2 : (n_rays - 1) / 2;
+  const int last = full ? n_rays : n_rays - 1;
+  int s = fan_search(n_rays, dirs, 0, m, rx, ry);
+  if (s >= 0) return s;
+  return fan_search(n_rays, dirs, m, last, rx, ry);
+}
+
+/* cell classes: bit0 road, bit1 visible, bit2 occluded.  Window of nx x ny cells whose lower-left world cell is
+ * (ix0, iy0) in the raster (rnx x rny, origin rx0, ry0, cell cs).  occ_idx = ascending window indices of the
+ * occluded cells. */
+int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double ry0, double cs, int ix0, int iy0,
+                   int nx, int ny, const double *ego, const double *hdir, double r, int full, int n_rays,
+                   const double *dirs, const double *range, uint8_t *cls, int32_t *occ_idx, int32_t *n_occ) {
+  int cnt = 0;
+  const double r2 = r * r, ro2 = (1.5 * r) * (1.5 * r);
+  for (int iy = 0; iy < ny; ++iy) {
+    for (int ix = 0; ix < nx; ++ix) {
+      const int wx = ix0 + ix, wy = iy0 + iy;
+      uint8_t c = 0;
+      if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny && raster[(size_t)wy * rnx + wx]) c |= 1;
+      const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
+      const double rx = px - ego[0], ry = py - ego[1];
+      const double d2 = rx * rx + ry * ry;
+      int vis = 0;
+      if ((c & 1) && d2 <= r2) {
+        const int i = fan_sector(n_rays, dirs, full, rx, ry);
+        if (rx == 0.0 && ry == 0.0) {
+          vis = 1; /* the ego's own cell centre */
+        } else if (i >= 0) {
+          const int j = (i + 1 == n_rays) ? 0 : i + 1;
+          const double hix = range[i] * dirs[2 * i], hiy = range[i] * dirs[2 * i + 1];
+          const double hjx = range[j] * dirs[2 * j], hjy = range[j] * dirs[2 * j + 1];
+          /* inside the triangle (ego, h_i, h_j): on the ego side of the chord h_i -> h_j */
+          const double cr = (hjx - hix) * (ry - hiy) - (hjy - hiy) * (rx - hix);
+          vis = cr >= 0.0;
+        }
+      }
+      if (vis) c |= 2;
+      /* sensor_model.py:85-93: half disc about the heading, radius 1.5 r, on the road, not visible */
+      if ((c & 1) && !vis && d2 <= ro2 && (rx * hdir[0] + ry * hdir[1]) >= 0.0) c |= 4;
+      cls[(size_t)iy * nx + ix] = c;
+      if (c & 4) {
+        if (occ_idx) occ_idx[cnt] = iy * nx + ix;
+        ++cnt;
+      }
+    }
+  }
+  *n_occ = cnt;
+  return 0;
+}
+
+/* obstacle visibility (sensor_model.py:59-76 restated): an obstacle that exists is visible iff one of its five
+ * probe points (4 corners + centre) lies within r + 1 cm of the ego, inside the fan, and the first occluder on the
+ * way (the obstacle itself excluded) is not nearer than the probe by more than 1 cm. */
+int fo_oracle_obstacle_visibility(int E, const double *edges, int O, const double *ocorn, const double *ocen,
+                                  const uint8_t *oflags, const double *ego, double r, int full, int n_rays,
+                                  const double *dirs, uint8_t *vis) {
+  for (int o = 0; o < O; ++o) {
+    vis[o] = 0;
+    if (!(oflags[o] & 1)) continue;
+    for (int p = 0; p < 5 && !vis[o]; ++p) {
+      const double qx = p < 4 ? ocorn[8 * (size_t)o + 2 * p] : ocen[2 * o];
+      const double qy = p < 4 ? ocorn[8 * (size_t)o + 2 * p + 1] : ocen[2 * o + 1];
+      const double rx = qx - ego[0], ry = qy - ego[1];
+      const double dist = sqrt(rx * rx + ry * ry);
+      if (dist > r + 0.01) continue;
+      if (dist == 0.0) { vis[o] = 1; break; }
+      if (fan_sector(n_rays, dirs, full, rx, ry) < 0) continue;
+      double t;
+      int id;
+      first_hit(E, edges, O, ocorn, oflags, ego[0], ego[1], rx / dist, ry / dist, dist, o, &t, &id);
+      if (t >= dist - 0.01) vis[o] = 1;
+    }
+  }
+  return 0;
+}
+
+/* ---------------------------------------------------------------- phantom spawn sampling in the occluded cells
+ * Candidates = occluded cells with a visible 4-neighbour (the frontier a hidden road user would emerge from),
+ * at least `min_ahead` metres ahead of the ego along its heading and not farther than `max_dist`
+ * (spawn_locator.py:113,234,381: s_threshold = max(4 v, 25), "ahead by >= 3 m").  Candidates are taken in
+ * ascending cell order; if there are more than max_agents, the ones at ranks floor(j * n / max_agents) are kept.
+ * Agent j gets type pattern[j % 4]; position = cell centre. */
+int fo_oracle_spawn_cells(const uint8_t *cls, int nx, int ny, double rx0, double ry0, double cs, int ix0, int iy0,
+                          const double *ego, const double *hdir, double min_ahead, double max_dist, int max_agents,
+                          int32_t *cell, double *pos, int32_t *n_out, int32_t *n_cand_out) {
+  int n = 0;
+  int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)nx * ny);
+  for (int iy = 0; iy < ny; ++iy) {
+    for (int ix = 0; ix < nx; ++ix) {
+      const uint8_t c = cls[(size_t)iy * nx + ix];
+      if (!(c & 4)) continue;
+      int front = 0;
+      if (ix > 0 && (cls[(size_t)iy * nx + ix - 1] & 2)) front = 1;
+      if (ix + 1 < nx && (cls[(size_t)iy * nx + ix + 1] & 2)) front = 1;
+      if (iy > 0 && (cls[(size_t)(iy - 1) * nx + ix] & 2)) front = 1;
+      if (iy + 1 < ny && (cls[(size_t)(iy + 1) * nx + ix] & 2)) front = 1;
+      if (!front) continue;
+      const double px = rx0 + ((double)(ix0 + ix) + 0.5) * cs, py = ry0 + ((double)(iy0 + iy) + 0.5) * cs;
+      const double rx = px - ego[0], ry = py - ego[1];
+      if (rx * hdir[0] + ry * hdir[1] < min_ahead) continue;
+      if (rx * rx + ry * ry > max_dist * max_dist) continue;
+      cand[n++] = iy * nx + ix;
+    }
+  }
+  int m = n < max_agents ? n : max_agents;
+  for (int j = 0; j < m; ++j) {
+    const int pick = (n <= max_agents) ? j : (int)(((long long)j * n) / max_agents);
+    const int ci = cand[pick];
+    cell[j] = ci;
+    pos[2 * j] = rx0 + ((double)(ix0 + ci % nx) + 0.5) * cs;
+    pos[2 * j + 1] = ry0 + ((double)(iy0 + ci / nx) + 0.5) * cs;
+  }
+  *n_out = m;
+  if (n_cand_out) *n_cand_out = n;
+  free(cand);
+  return 0;
+}
+
+/* unit vector from p to the closest point of the polyline (helper_functions.py:38-58; first closest segment) */
+void fo_oracle_normal_to_polyline(int N, const double *path, double px, double py, double *nx_, double *ny_) {
+  double best = INFINITY, qx = px, qy = py;
+  for (int i = 0; i + 1 < N; ++i) {
+    const double ax = path[2 * i], ay = path[2 * i + 1], bx = path[2 * i + 2], by = path[2 * i + 3];
+    const double ex = bx - ax, ey = by - ay;
+    const double l2 = ex * ex + ey * ey;
+    double t = 0.0;
+    if (l2 > 0.0) {
+      t = ((px - ax) * ex + (py - ay) * ey) / l2;
+      if (t < 0.0) t = 0.0;
+      if (t > 1.0) t = 1.0;
+    }
+    const double cx = ax + t * ex, cy = ay + t * ey;
+    const double d2 = (px - cx) * (px - cx) + (py - cy) * (py - cy);
+    if (d2 < best) { best = d2; qx = cx; qy = cy; }
+  }
+  const double vx = qx - px, vy = qy - py;
+  const double n = sqrt(vx * vx + vy * vy);
+  if (n > 0.0) { *nx_ = vx / n; *ny_ = vy / n; } else { *nx_ = 1.0; *ny_ = 0.0; }
+}
+
+/* phantom headings: pedestrians walk towards the ego reference path (agent.py:475-481, mode 'ref_path');
+ * vehicles / bicycles follow the lane heading raster at their cell (NaN -> fall back to the pedestrian rule).
+ * yaw in [0, 2 pi) like helper_functions.py:61-70. */
+int fo_oracle_spawn_headings(int n, const double *pos, const int32_t *type, int N, const double *path,
+                             const double *lane_yaw_at, double *yaw) {
+  for (int j = 0; j < n; ++j) {
+    double a;
+    if (type[j] != FO_TYPE_PEDESTRIAN && lane_yaw_at && !isnan(lane_yaw_at[j])) {
+      a = lane_yaw_at[j];
+    } else {
+      double ux, uy;
+      fo_oracle_normal_to_polyline(N, path, pos[2 * j], pos[2 * j + 1], &ux, &uy);
+      a = atan2(uy, ux); /* det([1,0],[ux,uy]) = uy, dot = ux */
+      if (a < 0.0) a += 2.0 * M_PI;
+    }
+    yaw[j] = a;
+  }
+  return 0;
+}
+
+/* constant-velocity straight-line predictions (agent.py:451-536): T = int(horizon/dt)+1 samples,
+ * pos_k = p0 + (k dt) (round(v cos yaw, 3), round(v sin yaw, 3)), v_k = v, yaw_k = yaw,
+ * cov_k = var0 * factor^k * I (agent.py:260-280) */
+int fo_oracle_cv_predictions(int n, const double *pos0, const double *yaw, const double *speed, int T, double dt,
+                             double var0, double factor, double *pos, double *yaw_l, double *v_l, double *cov) {
+  for (int j = 0; j < n; ++j) {
+    const double vx = fo_oracle_round3(speed[j] * cos(yaw[j])), vy = fo_oracle_round3(speed[j] * sin(yaw[j]));
+    for (int k = 0; k < T; ++k) {
+      const double t = (double)k * dt;
+      pos[((size_t)j * T + k) * 2] = pos0[2 * j] + t * vx;
+      pos[((size_t)j * T + k) * 2 + 1] = pos0[2 * j + 1] + t * vy;
+      yaw_l[(size_t)j * T + k] = yaw[j];
+      v_l[(size_t)j * T + k] = speed[j];
+      const double var = var0 * pow(factor, (double)k);
+      double *c = cov + ((size_t)j * T + k) * 4;
+      c[0] = var; c[1] = 0.0; c[2] = 0.0; c[3] = var;
+    }
+  }
+  return 0;
+}
