@@ -1,0 +1,248 @@
+"""Phantom-agent registry (mirrors ref: agent.py:28-199 ``FOAgentManager``).
+
+Holds the phantom agents of the current step and their predictions.  The predictions live on the GPU in the
+structure-of-arrays form the metric sweep consumes; ``predictions`` (the dict the reference exposes,
+agent.py:179-183) is materialised lazily for callers that want the reference's view.  Manually added agents
+(``add_agent``, scripted in the YAML ``agents:`` list) get constant-velocity straight-line predictions
+(agent.py:451-536); lane-following Frenet predictions for phantom vehicles need the un-vendored frenetix sampler
+and are out of scope -- vehicles are predicted along their lane heading at constant speed.
+"""
+from random import randint
+
+import numpy as np
+import torch
+
+from .spawn_locator import TYPE_CODE, TYPE_NAME, PhantomBatch
+
+
+class PhantomAgent:
+    def __init__(self, agent_id, agent_type, position, orientation, velocity, length, width):
+        self.agent_id, self.agent_type = agent_id, agent_type
+        self.initial_position, self.initial_orientation, self.initial_velocity = position, orientation, velocity
+        self.length, self.width = length, width
+        self.predictions = None
+
+
+class FOAgentManager:
+    def __init__(self, scenario, reference_path, config, timestep, visualization=None, dt=0.1, fo_obstacles=None,
+                 debug=False, device=None):
+        self.scenario = scenario
+        self.timestep = timestep
+        self.reference_path = np.asarray(reference_path, dtype=np.float64)
+        self.config = config
+        self.visualization = visualization
+        self.fo_obstacles = fo_obstacles
+        self.dt = dt
+        self.debug = debug
+        self.device = device if device is not None else torch.device("cuda", 0)
+        self.real_agents = []
+        self._batch = None            # PhantomBatch from the spawn kernel (device)
+        self._n_batch = 0             # active slots in it
+        self._batch_agents = None     # PhantomAgent objects of those slots (built on first access)
+        self._manual = []             # agents added through add_agent() (host-side predictions)
+        self._pred_cache = None
+        self.all_obstacle_id = [getattr(o, "obstacle_id", None) for o in getattr(scenario, "obstacles", [])]
+
+    # ---- reference API ------------------------------------------------------------------------------------
+    def reset(self):
+        self._batch, self._n_batch, self._batch_agents = None, 0, None
+        self._manual = []
+        self._pred_cache = None
+
+    def _create_id(self):
+        """agent.py:189-199: unique random id in [10000, 11000]"""
+        while True:
+            i = randint(10000, 11000)
+            if i not in self.all_obstacle_id:
+                self.all_obstacle_id.append(i)
+                return i
+
+    def _velocity(self, velocity, conf, allow_lanelet):
+        if velocity == "default":
+            return float(conf["default_velocity"])
+        if velocity == "lanelet":
+            if not allow_lanelet:
+                raise NotImplementedError
+            return 30 / 3.6                                     # agent.py:326-328 (urban); other lanelet types [ext]
+        if not isinstance(velocity, (int, float)):
+            raise ValueError('Only "default", "lanelet", int or float is allowed!')   # agent.py:86,100,114,131
+        return float(velocity)
+
+    def add_agent(self, pos, velocity="default", agent_type="Car", add_to_scenario=False, timestep=0, horizon=3.0,
+                  mode="ref_path", orientation=None):
+        if self.timestep != timestep:                            # agent.py:69-70
+            return None
+        key = agent_type.lower()
+        if key not in ("bicycle", "car", "truck", "pedestrian"):
+            raise NotImplementedError(f'OAPManager: Agent type "{agent_type}" is not implemented!')
+        if mode not in ("ref_path", "lane_center"):
+            raise NotImplementedError(f'Selected mode "{mode}" is not implemented: use "ref_path" or "lane_center"!')
+        conf = self.config[key]
+        v = self._velocity(velocity, conf, key in ("car", "truck"))
+        pos = np.asarray(pos, dtype=np.float64)
+        if orientation is None:
+            orientation = self._heading_towards_path(pos)
+        agent = PhantomAgent(self._create_id(), agent_type, pos, float(orientation), v, float(conf["length"]),
+                             float(conf["width"]))
+        agent.predictions = [self._cv_prediction(agent, horizon)]
+        if add_to_scenario:
+            self.real_agents.append(agent)
+            from .scenario import Obstacle
+            T = len(agent.predictions[0]["pos_list"])
+            st = np.column_stack((agent.predictions[0]["pos_list"][1:], np.full(T - 1, agent.initial_orientation),
+                                  np.full(T - 1, v)))
+            ob = Obstacle(agent.agent_id, "dynamic", key, agent.length, agent.width, int(timestep),
+                          np.array([pos[0], pos[1], agent.initial_orientation, v]), st)
+            if hasattr(self.scenario, "add_objects"):
+                self.scenario.add_objects(ob)
+            if self.fo_obstacles is not None:
+                self.fo_obstacles.add(ob)
+        else:
+            self._manual.append(agent)
+            self._pred_cache = None
+        return agent
+
+    def _heading_towards_path(self, pos):
+        """agent.py:475-481 + helper_functions.py:38-76: unit normal towards the reference path, angle in [0, 2 pi)"""
+        p = self.reference_path
+        a, b = p[:-1], p[1:]
+        e = b - a
+        l2 = np.maximum(np.sum(e * e, axis=1), 1e-300)
+        t = np.clip(np.sum((pos[None] - a) * e, axis=1) / l2, 0.0, 1.0)
+        q = a + t[:, None] * e
+        k = int(np.argmin(np.sum((q - pos[None]) ** 2, axis=1)))
+        d = q[k] - pos
+        n = float(np.hypot(d[0], d[1]))
+        ang = float(np.arctan2(d[1], d[0])) if n > 0 else 0.0
+        return ang + 2.0 * np.pi if ang < 0 else ang
+
+    def _cv_prediction(self, agent, horizon):
+        pr = self.config["prediction"]
+        big = agent.agent_type.lower() == "bicycle"
+        fl = pr["size_factor_length_l"] if big else pr["size_factor_length_s"]
+        fw = pr["size_factor_width_l"] if big else pr["size_factor_width_s"]
+        vx = round(agent.initial_velocity * np.cos(agent.initial_orientation), 3)     # agent.py:492-493 (Q12)
+        vy = round(agent.initial_velocity * np.sin(agent.initial_orientation), 3)
+        T = int(horizon / self.dt) + 1
+        t = np.arange(T)[:, None] * self.dt
+        pos = agent.initial_position[None] + t * np.array([[vx, vy]])
+        var = 0.1 * np.power(pr["variance_factor"], np.arange(T))
+        cov = np.zeros((T, 2, 2))
+        cov[:, 0, 0] = var
+        cov[:, 1, 1] = var
+        return {"orientation_list": np.full(T, agent.initial_orientation), "v_list": np.full(T, agent.initial_velocity),
+                "pos_list": pos, "shape": {"length": agent.length * fl, "width": agent.width * fw}, "cov_list": cov}
+
+    def agent_by_prediction_id(self, prediction_id):
+        agent_id = int(str(prediction_id)[:5])
+        for a in self.phantom_agents:
+            if a.agent_id == agent_id:
+                return a
+        return None
+
+    def update_real_agents(self, cr_scenario_predictions):
+        """agent.py:171-177: scripted real pedestrians overwrite their entry in the caller's prediction dict"""
+        if cr_scenario_predictions is None:
+            return
+        for a in self.real_agents:
+            if a.agent_type.lower() == "pedestrian" and a.agent_id in cr_scenario_predictions:
+                cr_scenario_predictions[a.agent_id] = a.predictions[0]
+
+    # ---- device side ------------------------------------------------------------------------------------------
+    def attach_batch(self, batch: PhantomBatch, n_active: int):
+        """take over the spawn kernel's output (n_active slots are live)"""
+        self._batch, self._n_batch, self._batch_agents = batch, int(n_active), None
+        self._pred_cache = None
+
+    def has_phantoms(self):
+        return self._n_batch > 0 or bool(self._manual)
+
+    def n_slots(self):
+        """length of the agent axis of the sweep outputs"""
+        return (self._batch.pos.shape[0] if self._batch is not None else 0) + len(self._manual)
+
+    @property
+    def phantom_agents(self):
+        """agent.py:39: list of phantom agents of this step (objects are created on first access)"""
+        if self._batch_agents is None:
+            self._batch_agents = []
+            n = self._n_batch
+            if n:
+                b = self._batch
+                pos0, yaw0 = b.pos0[:n].cpu().numpy(), b.yaw0[:n].cpu().numpy()
+                typ, raw, v0 = b.type[:n].cpu().numpy(), b.raw_dims[:n].cpu().numpy(), b.v[:n, 0].cpu().numpy()
+                for j in range(n):
+                    self._batch_agents.append(PhantomAgent(self._create_id(), TYPE_NAME[int(typ[j])], pos0[j],
+                                                           float(yaw0[j]), float(v0[j]), float(raw[j, 0]),
+                                                           float(raw[j, 1])))
+        return self._batch_agents + self._manual
+
+    def sweep_arrays(self):
+        """tensors for MetricSweep.set_agents: spawn-kernel slots first, then manually added agents"""
+        parts = []
+        if self._batch is not None:
+            parts.append(self._batch.sweep_args())
+        if self._manual:
+            dev = self.device
+            T = max(len(a.predictions[0]["pos_list"]) for a in self._manual)
+            n = len(self._manual)
+            pos, yaw, v = np.zeros((n, T, 2)), np.zeros((n, T)), np.zeros((n, T))
+            cov, shape, raw = np.zeros((n, T, 2, 2)), np.zeros((n, 2)), np.zeros((n, 2))
+            typ, ln = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+            for i, a in enumerate(self._manual):
+                p = a.predictions[0]
+                L = len(p["pos_list"])
+                pos[i, :L], yaw[i, :L], v[i, :L], cov[i, :L] = p["pos_list"], p["orientation_list"], p["v_list"], p["cov_list"]
+                shape[i] = (p["shape"]["length"], p["shape"]["width"])
+                raw[i] = (a.length, a.width)
+                typ[i], ln[i] = TYPE_CODE[a.agent_type.lower()], L
+            d = lambda x, dt=torch.float64: torch.as_tensor(x).to(dev, dt)
+            parts.append((d(pos), d(yaw), d(v), d(cov), d(shape), d(raw), d(typ, torch.int32), d(ln, torch.int32)))
+        if not parts:
+            return None
+        if len(parts) == 1:
+            return parts[0]
+        T = max(p[0].shape[1] for p in parts)
+
+        def pad_t(t):
+            if t.shape[1] == T:
+                return t
+            pad = torch.zeros((t.shape[0], T - t.shape[1]) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+            return torch.cat((t, pad), dim=1)
+        out = []
+        for k in range(8):
+            ts = [p[k] for p in parts]
+            if k < 4:
+                ts = [pad_t(t) for t in ts]
+            out.append(torch.cat(ts, dim=0).contiguous())
+        return tuple(out)
+
+    @property
+    def predictions(self):
+        """dict prediction_id -> {'pos_list','v_list','orientation_list','shape','cov_list'} (agent.py:179-183),
+        key = int(str(agent_id) + '0'); ``prediction_slots`` maps each id to its index on the sweep's agent axis."""
+        if self._pred_cache is not None:
+            return self._pred_cache
+        out, order = {}, []
+        agents = self.phantom_agents
+        n = self._n_batch
+        if n:
+            b = self._batch
+            pos, yaw, v = b.pos[:n].cpu().numpy(), b.yaw[:n].cpu().numpy(), b.v[:n].cpu().numpy()
+            cov, shape = b.cov[:n].cpu().numpy(), b.shape[:n].cpu().numpy()
+            for j in range(n):
+                a = agents[j]
+                a.predictions = [{"orientation_list": yaw[j], "v_list": v[j], "pos_list": pos[j],
+                                  "shape": {"length": float(shape[j, 0]), "width": float(shape[j, 1])},
+                                  "cov_list": cov[j]}]
+                pid = int(str(a.agent_id) + "0")
+                out[pid] = a.predictions[0]
+                order.append((pid, j))
+        base = self._batch.pos.shape[0] if self._batch is not None else 0
+        for i, a in enumerate(self._manual):
+            pid = int(str(a.agent_id) + "0")
+            out[pid] = a.predictions[0]
+            order.append((pid, base + i))
+        self._pred_cache = out
+        self.prediction_slots = order
+        return out

@@ -1,0 +1,145 @@
+"""``FOInterface`` -- the plugin surface the Frenetix-Motion-Planner loop talks to (ref: interface.py:18-238).
+
+Same constructor, same ``evaluate_scenario`` / ``trajectory_safety_assessment`` / ``set_coordinate_system``
+signatures and the same instance attributes as the reference, so the planner sees a drop-in; behind it every
+per-step stage runs in libfo_hip.so on one MI355X:
+
+    evaluate_scenario           obstacle poses -> ray fan + cell classes (fo_scene_visibility) -> phantom sampling and
+                                predictions in the occluded cells (fo_scene_spawn) -> agent table (fo_sweep_set_agents)
+    trajectory_safety_assessment_batch   all candidate trajectories x all phantom predictions in one launch
+    trajectory_safety_assessment         the reference's per-trajectory call, served from the cached batch
+
+Deviations from the reference (documented in DESIGN.md): ``visible_area`` is a ring polygon + cell mask
+(:class:`~frenetix_occlusion.sensor_model.VisibleArea`) instead of a shapely geometry; spawn points come from the
+occluded-cell frontier instead of the three GEOS rule families; no matplotlib (``plot`` is accepted and ignored).
+"""
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from . import _native as N
+from .agent import FOAgentManager
+from .metrics.metric import Metric
+from .sensor_model import SensorModel
+from .spawn_locator import SpawnLocator
+from .utils.fo_obstacle import FOObstacles
+
+
+class FOInterface:
+    def __init__(self, scenario, reference_path, vehicle_params, dt, config_path=None, cosy_cl=None):
+        self.config = self._load_config(config_path)
+        acc = self.config.get("accelerator") or {}
+        if not torch.cuda.is_available():
+            raise RuntimeError("FOInterface needs a ROCm GPU: this build has no CPU path")
+        self.device = torch.device("cuda", int(acc.get("device", 0)))
+
+        # things that never change (interface.py:74-82)
+        self.cr_scenario = scenario
+        self.lanelet_network = scenario.lanelet_network
+        self.ego_reference_path = np.asarray(reference_path, dtype=np.float64)
+        self.cosy_cl = cosy_cl
+        self.vehicle_params = vehicle_params
+        self.dt = dt
+        self.plot = self.config.get("plot", False)
+        self.debug = self.config.get("debug", False)
+
+        # per-step state (interface.py:85-90)
+        self.predictions = None
+        self.ego_pos = None
+        self.ego_orientation = None
+        self.ego_pos_cl = None
+        self.timestep = None
+        self.spawn_points = []
+
+        self.sensor_radius = self.config["sensor_model"]["sensor_radius"]
+        self.sensor_angle = self.config["sensor_model"]["sensor_angle"]
+        self.visualization = None   # debug drawing is out of scope (forces TkAgg upstream)
+
+        self.ctx = N.Context(self.device.index)
+        self.fo_obstacles = FOObstacles(self.cr_scenario.obstacles)
+        self.sensor_model = SensorModel(lanelet_network=self.lanelet_network, ref_path=self.ego_reference_path,
+                                        sensor_radius=self.sensor_radius, sensor_angle=self.sensor_angle,
+                                        visualization=None, debug=self.debug, ctx=self.ctx,
+                                        n_rays=int(acc.get("rays", 720)), cell_size=float(acc.get("cell_size", 0.5)),
+                                        device=self.device.index)
+        self.agent_manager = FOAgentManager(scenario=self.cr_scenario, reference_path=self.ego_reference_path,
+                                            config=self.config["agent_manager"], visualization=None,
+                                            timestep=self.timestep, dt=self.dt, debug=self.debug,
+                                            fo_obstacles=self.fo_obstacles, device=self.device)
+        self.spawn_locator = SpawnLocator(agent_manager=self.agent_manager, ref_path=self.ego_reference_path,
+                                          config=self.config, cosy_cl=self.cosy_cl, sensor_model=self.sensor_model,
+                                          fo_obstacles=self.fo_obstacles, visualization=None, debug=self.debug,
+                                          dt=self.dt)
+        self.metrics = Metric(self.config["metrics"], self.vehicle_params, self.agent_manager, dt=self.dt,
+                              device=self.device.index)
+
+    # ---------------------------------------------------------------------------------------- reference API
+    def set_coordinate_system(self, cosy_cl):
+        self.cosy_cl = cosy_cl
+        self.spawn_locator.cosy_cl = cosy_cl
+
+    def _add_real_agents(self):
+        if self.config.get("agents") is None:
+            return
+        for agent in self.config["agents"]:
+            self.agent_manager.add_agent(pos=agent["position"], velocity=agent["velocity"],
+                                         agent_type=agent["agent_type"], add_to_scenario=True,
+                                         timestep=agent["timestep"], horizon=agent["horizon"])
+
+    def evaluate_scenario(self, predictions, ego_pos, ego_orientation, ego_pos_cl, ego_v, timestep, cosy_cl=None):
+        self.set_coordinate_system(cosy_cl)
+        self._update_time_step(timestep)
+        self._add_real_agents()
+        self.predictions = predictions
+        self.ego_pos = np.asarray(ego_pos, dtype=np.float64)
+        self.ego_orientation = float(ego_orientation)
+        self.ego_pos_cl = ego_pos_cl
+        self.agent_manager.reset()
+        self.metrics.invalidate()
+        self.spawn_points = []
+
+        self.fo_obstacles.update(self.timestep)
+        self.sensor_model.calc_visible_and_occluded_area(timestep=self.timestep, ego_pos=self.ego_pos,
+                                                         ego_orientation=self.ego_orientation,
+                                                         obstacles=self.fo_obstacles)
+        self.fo_obstacles.update_multipolygon()
+
+        # phantom sampling + predictions stay on the device; the spawn-point list is the reference's host view
+        self.spawn_points = self.spawn_locator.find_spawn_points(self.ego_pos, self.ego_orientation, self.ego_pos_cl,
+                                                                 ego_v)
+        self.agent_manager.attach_batch(self.spawn_locator.batch, len(self.spawn_points))
+        if self.debug:
+            for sp in self.spawn_points:
+                print("Phantom agent of type {} added to scenario at position {}".format(sp.agent_type, sp.position))
+        self.agent_manager.update_real_agents(self.predictions)
+        return self.sensor_model.visible_area
+
+    def trajectory_safety_assessment(self, trajectory):
+        metrics, safety_assessment = self.metrics.evaluate_metrics(trajectory)
+        return metrics, safety_assessment
+
+    # ---------------------------------------------------------------------------------------- batched entry (new)
+    def trajectory_safety_assessment_batch(self, trajectories, mode="reduced"):
+        """All candidates of a planning step in one launch.  ``trajectories``: list of trajectory objects
+        (``.cartesian.{x,y,theta,v,a}``) or a dict of [M,T] arrays / device tensors.  Returns a
+        :class:`~frenetix_occlusion.metrics.metric.BatchAssessment` (``.cost [M,16]``, ``.safe [M]`` on the device), or
+        None when there are no phantom agents (every trajectory is then safe, metric.py:44-45).  With
+        ``mode='full'`` and a list input, later ``trajectory_safety_assessment(t)`` calls for the same objects are
+        served from this batch."""
+        remember = trajectories if (mode == "full" and not isinstance(trajectories, dict)) else None
+        return self.metrics.evaluate_batch(trajectories, mode=mode, remember=remember)
+
+    def _update_time_step(self, timestep):
+        self.timestep = timestep
+        self.sensor_model.timestep = timestep
+        self.agent_manager.timestep = timestep
+
+    @staticmethod
+    def _load_config(filepath=None):
+        """interface.py:227-238 (there the default path is computed but not used; here it is)"""
+        if not filepath:
+            filepath = os.path.join(os.path.dirname(__file__), "config", "config.yaml")
+        with open(filepath, "r") as f:
+            return yaml.safe_load(f)

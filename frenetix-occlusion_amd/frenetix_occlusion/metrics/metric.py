@@ -1,0 +1,203 @@
+"""Metric orchestrator + thresholds on top of the batched HIP sweep (mirrors ref: metrics/metric.py:18-147).
+
+``Metric.evaluate_metrics(trajectory)`` keeps the reference's per-trajectory contract -- ``(results, safety_check)``
+with the nested result dict of SURVEY Appendix B -- while the arithmetic for *all* candidate trajectories of a planning
+step happens in one launch (``evaluate_batch``).  The per-trajectory call is served from the cached batch when the
+trajectory object was part of it, otherwise a one-trajectory sweep is launched.  Threshold logic (metric.py:50-100) and
+the dependency closure (:125-147) run inside libfo_hip.so (fo_reduce_kernel / fo_sweep_configure).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from ..sweep import DEFAULT_HARM_COEFF, MetricSweep, SweepResult
+
+AVAILABLE = ("dce", "cp", "ttc", "ttce", "wttc", "be", "hr")   # metric.py:109-117
+
+
+def check_required_metrics(metric_names):
+    """metric.py:125-147 (order of evaluation; the kernel computes everything in one pass, the order only decides
+    the key order of the result dict)"""
+    names = list(metric_names)
+    if "wttc" in names:
+        if "ttc" in names:
+            names.remove("ttc")
+        names.insert(0, "ttc")
+    if "ttc" in names or "ttce" in names or "be" in names:
+        if "dce" in names:
+            names.remove("dce")
+        names.insert(0, "dce")
+    if "hr" in names:
+        if "cp" in names:
+            names.remove("cp")
+        names.insert(0, "cp")
+    return names
+
+
+def load_harm_coeff(path=None):
+    """the entries of harm_params.json the reference reads (hr.py:21-40, harm_model.py:109-155)"""
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(__file__)), "config", "harm_params.json")
+    if not os.path.exists(path):
+        return dict(DEFAULT_HARM_COEFF)
+    with open(path) as f:
+        d = json.load(f)
+    lr = d["log_reg"]
+    return dict(lr4s_const=lr["reduced_sym_angle_areas"]["const"], lr4s_speed=lr["reduced_sym_angle_areas"]["speed"],
+                lr4s_side=lr["reduced_sym_angle_areas"]["side"], lr4s_rear=lr["reduced_sym_angle_areas"]["rear"],
+                lr1s_const=lr["ignore_angle"]["const"], lr1s_speed=lr["ignore_angle"]["speed"],
+                ped_const=d["pedestrian"]["const"], ped_speed=d["pedestrian"]["speed"])
+
+
+def trajectories_to_arrays(trajectories):
+    """list of duck-typed trajectories (``.cartesian.{x,y,theta,v,a}``, ref: collision_probability.py:32,97;
+    harm_model.py:81-94) or a dict of [M,T] arrays/tensors -> dict of [M,T] float64"""
+    if isinstance(trajectories, dict):
+        return trajectories
+    out = {}
+    for k in ("x", "y", "theta", "v", "a"):
+        rows = [np.asarray(getattr(t.cartesian, k), dtype=np.float64) for t in trajectories]
+        T = len(rows[0])
+        if any(len(r) != T for r in rows):
+            raise ValueError("all trajectories of a batch must have the same number of samples")
+        out[k] = np.stack(rows, axis=0) if rows else np.zeros((0, 0))
+    return out
+
+
+class BatchAssessment:
+    """result of ``evaluate_batch``: device tensors of the sweep + accessors in the reference's vocabulary"""
+
+    def __init__(self, res: SweepResult, prediction_slots, metric_order, mode):
+        self.result = res
+        self.cost, self.safe = res.cost, res.safe
+        self.prediction_slots = prediction_slots
+        self.metric_order = metric_order
+        self.mode = mode
+        self._host = None
+
+    def __len__(self):
+        return int(self.cost.shape[0])
+
+    def safety(self):
+        return self.safe.bool()
+
+    def column(self, name):
+        return self.cost[:, N.COST[name]]
+
+    def _to_host(self):
+        if self._host is None:
+            r = self.result
+            self._host = {"cost": r.cost.cpu().numpy(), "safe": r.safe.cpu().numpy(),
+                          "pair_f": None if r.pair_f is None else r.pair_f.cpu().numpy(),
+                          "pair_i": None if r.pair_i is None else r.pair_i.cpu().numpy(),
+                          "lists": None if r.lists is None else r.lists.cpu().numpy()}
+        return self._host
+
+    def result_dict(self, m):
+        """the reference's nested dict for trajectory m; needs mode 'full'"""
+        h = self._to_host()
+        if h["lists"] is None:
+            raise RuntimeError("result_dict needs the batch to be evaluated with mode='full'")
+        pf, pi, ls, cost = h["pair_f"], h["pair_i"], h["lists"], h["cost"][m]
+        out = {}
+        for name in self.metric_order:
+            if name == "cp":
+                out["cp"] = {}
+                for pid, k in self.prediction_slots:
+                    v = ls[N.LST["cp"], k, :, m]
+                    out["cp"][pid] = v[~np.isnan(v)]
+            elif name == "dce":
+                out["dce"] = {pid: {"dce": float(pf[N.PF["dce"], k, m]), "time_dce": int(pi[N.PI["time_dce"], k, m])}
+                              for pid, k in self.prediction_slots}
+            elif name == "ttc":
+                out["ttc"] = {pid: float(pf[N.PF["ttc"], k, m]) for pid, k in self.prediction_slots}
+            elif name == "ttce":
+                out["ttce"] = {pid: float(pf[N.PF["ttce"], k, m]) for pid, k in self.prediction_slots}
+            elif name == "wttc":
+                out["wttc"] = float(cost[N.COST["wttc"]])
+            elif name == "hr":
+                hr = {}
+                for pid, k in self.prediction_slots:
+                    if not pi[N.PI["hr_valid"], k, m]:
+                        continue
+
+                    def lst(key):
+                        v = ls[N.LST[key], k, :, m]
+                        return [float(q) for q in v[~np.isnan(v)]]
+                    cpv = ls[N.LST["cp"], k, :, m]
+                    hr[pid] = {"max_ego_risk": float(pf[N.PF["max_ego_risk"], k, m]),
+                               "max_obst_risk": float(pf[N.PF["max_obst_risk"], k, m]),
+                               "max_obst_harm_with_cp": float(pf[N.PF["max_obst_harm_with_cp"], k, m]),
+                               "max_obst_risk_index": int(pi[N.PI["max_obst_risk_index"], k, m]),
+                               "max_ego_harm": float(pf[N.PF["max_ego_harm"], k, m]),
+                               "max_obst_harm": float(pf[N.PF["max_obst_harm"], k, m]),
+                               "ego_risk_traj": lst("ego_risk"), "obst_risk_traj": lst("obst_risk"),
+                               "ego_harm_traj": np.array(lst("ego_harm")), "obst_harm_traj": np.array(lst("obst_harm")),
+                               "collision_probability": cpv[~np.isnan(cpv)],
+                               "max_collision_probability": float(pf[N.PF["max_collision_probability"], k, m])}
+                for key in ("max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
+                            "max_collision_probability_all", "max_obst_harm_with_cp_all"):
+                    hr[key] = float(cost[N.COST[key]])
+                out["hr"] = hr
+        return out, bool(h["safe"][m])
+
+
+class Metric:
+    def __init__(self, config, vehicle_params, agent_manager, dt=None, harm_coeff=None, device=0):
+        self.config = config
+        self.metric_thresholds = config["metric_thresholds"]
+        self.vehicle_params = vehicle_params
+        self.agent_manager = agent_manager
+        names = list(config["activated_metrics"] or [])
+        for n in names:
+            if n not in AVAILABLE:
+                raise ValueError(f"unknown metric '{n}'")
+        self.metrics = check_required_metrics(names)           # ordered like the reference's dict
+        self.dt = float(dt if dt is not None else agent_manager.dt)
+        self.sweep = MetricSweep(vehicle_params, self.dt, metrics=self.metrics or ("dce",),
+                                 thresholds=self.metric_thresholds, harm_coeff=harm_coeff or load_harm_coeff(),
+                                 device=device)
+        self._agents_version = None
+        self._batch = None
+        self._batch_ids = {}
+
+    def invalidate(self):
+        """call when the phantom set changed (FOInterface.evaluate_scenario does)"""
+        self._agents_version = None
+        self._batch = None
+        self._batch_ids = {}
+
+    def _upload_agents(self):
+        if self._agents_version is not None:
+            return
+        arrs = self.agent_manager.sweep_arrays()
+        self.sweep.set_agents(*arrs, check=True)
+        self._agents_version = 1
+
+    def evaluate_batch(self, trajectories, mode="reduced", remember=None):
+        """one launch for the whole candidate set.  trajectories: list of trajectory objects or dict of [M,T] arrays."""
+        if not self.agent_manager.has_phantoms() or not self.metrics:
+            return None                                          # metric.py:44-45: ({}, True) for every trajectory
+        arr = trajectories_to_arrays(trajectories)
+        self._upload_agents()
+        res = self.sweep.run(arr["x"], arr["y"], arr["theta"], arr["v"], arr.get("a"), mode=mode)
+        _ = self.agent_manager.predictions if mode == "full" else None
+        slots = getattr(self.agent_manager, "prediction_slots", None) if mode == "full" else None
+        ba = BatchAssessment(res, slots, self.metrics, mode)
+        if remember is not None:
+            self._batch = ba
+            self._batch_ids = {id(t): i for i, t in enumerate(remember)}
+        return ba
+
+    def evaluate_metrics(self, trajectory):
+        """reference contract (metric.py:35-100): ``(results, safety_check)`` for one trajectory"""
+        if not self.agent_manager.has_phantoms() or not self.metrics:
+            return {}, True
+        m = self._batch_ids.get(id(trajectory)) if self._batch is not None else None
+        if m is not None and self._batch.mode == "full":
+            return self._batch.result_dict(m)
+        ba = self.evaluate_batch([trajectory], mode="full")
+        return ba.result_dict(0)

@@ -218,7 +218,7 @@ def union_boundary_edges(polys, eps=1e-4, tol=1e-9):
             for i, j in zip(*np.nonzero(hit)):
                 splits[i].append(float(t[i, j]))
             # vertices of q lying on an edge of p (collinear overlaps start/stop there)
-            l2 = np.sum(e[..., :] ** 2, axis=-1)                      # [n,1]
+            l2 = np.maximum(np.sum(e[..., :] ** 2, axis=-1), 1e-300)  # [n,1] (zero-length edges stay inert)
             tt = np.sum(w * e, axis=-1) / l2                          # [n,m]
             proj = a[:, None, :] + tt[..., None] * e
             dist = np.linalg.norm(c[None, :, :] - proj, axis=-1)
@@ -367,3 +367,105 @@ def synthetic_urban_grid(n_blocks=8, block=60.0, lane_w=3.5, lanes_per_dir=2, ds
                                   np.array([pos[0], pos[1], yaw, 0.0]), np.zeros((0, 4))))
     ego = np.array([mid - 20.0, mid - lane_w / 2, 0.0, 8.0])
     return Scenario(0.1, lanelets, obstacles, [], ego, "synthetic_urban_grid")
+
+
+# ------------------------------------------------------------------------------------------------ duck-typed CommonRoad
+def _cr_type(t):
+    v = getattr(t, "value", t)
+    return str(v)
+
+
+def obstacle_from_commonroad(ob) -> Obstacle:
+    """commonroad-io obstacle (duck-typed: .obstacle_id, .obstacle_type, .obstacle_role, .obstacle_shape.length/width,
+    .initial_state.{position, orientation, velocity, time_step}, .prediction.trajectory.state_list) -> Obstacle.
+    Only the attributes fo_obstacle.py:60-116 reads are touched."""
+    st = ob.initial_state
+    init = np.array([st.position[0], st.position[1], getattr(st, "orientation", 0.0), getattr(st, "velocity", 0.0)],
+                    dtype=np.float64)
+    states = []
+    pred = getattr(ob, "prediction", None)
+    if pred is not None and getattr(pred, "trajectory", None) is not None:
+        for s in pred.trajectory.state_list:
+            states.append([s.position[0], s.position[1], getattr(s, "orientation", 0.0), getattr(s, "velocity", 0.0)])
+    role = _cr_type(getattr(ob, "obstacle_role", "dynamic")).lower()
+    role = "static" if "static" in role else "dynamic"
+    return Obstacle(int(ob.obstacle_id), role, _cr_type(ob.obstacle_type), float(ob.obstacle_shape.length),
+                    float(ob.obstacle_shape.width), int(getattr(st, "time_step", 0)), init,
+                    np.array(states, dtype=np.float64).reshape(-1, 4))
+
+
+def lanelets_of(net) -> List[Lanelet]:
+    """list[Lanelet] | Scenario | duck-typed CommonRoad LaneletNetwork (.lanelets with .left_vertices/.right_vertices)"""
+    if isinstance(net, Scenario):
+        return net.lanelets
+    items = net.lanelets if hasattr(net, "lanelets") else list(net)
+    out = []
+    for ll in items:
+        if isinstance(ll, Lanelet):
+            out.append(ll)
+            continue
+        new = Lanelet(int(ll.lanelet_id), np.asarray(ll.left_vertices, dtype=np.float64),
+                      np.asarray(ll.right_vertices, dtype=np.float64))
+        new.successors = list(getattr(ll, "successor", []) or [])
+        new.predecessors = list(getattr(ll, "predecessor", []) or [])
+        new.adj_left = getattr(ll, "adj_left", None)
+        new.adj_left_same_direction = getattr(ll, "adj_left_same_direction", None)
+        new.adj_right = getattr(ll, "adj_right", None)
+        new.adj_right_same_direction = getattr(ll, "adj_right_same_direction", None)
+        out.append(new)
+    return out
+
+
+class LaneletNetworkView:
+    """what ``scenario.lanelet_network`` is for a :class:`Scenario` (keeps interface.py:75 attribute access working)"""
+
+    def __init__(self, lanelets):
+        self.lanelets = lanelets
+
+    @property
+    def lanelet_polygons(self):
+        return [ll.polygon for ll in self.lanelets]
+
+
+Scenario.lanelet_network = property(lambda self: LaneletNetworkView(self.lanelets))
+
+
+def _scenario_add_objects(self, objs):
+    """Scenario.add_objects of commonroad (agent.py:250 appends scripted real agents)"""
+    for o in (objs if isinstance(objs, (list, tuple)) else [objs]):
+        self.obstacles.append(o if isinstance(o, Obstacle) else obstacle_from_commonroad(o))
+
+
+Scenario.add_objects = _scenario_add_objects
+
+
+def load_geometry_npz(path) -> Scenario:
+    """Scenario from the compact array form (what tests/golden/gen_scenario_fixture.py writes)"""
+    g = np.load(path, allow_pickle=False)
+    off = g["lanelet_off"]
+    lanelets = []
+    for i, lid in enumerate(g["lanelet_id"]):
+        ll = Lanelet(int(lid), g["lanelet_left"][off[i]:off[i + 1]], g["lanelet_right"][off[i]:off[i + 1]])
+        ll.successors = [int(q) for q in g["lanelet_successors"][i] if q >= 0]
+        ll.predecessors = [int(q) for q in g["lanelet_predecessors"][i] if q >= 0]
+        a = g["lanelet_adjacent"][i]
+        if a[0] >= 0:
+            ll.adj_left, ll.adj_left_same_direction = int(a[0]), bool(a[1])
+        if a[2] >= 0:
+            ll.adj_right, ll.adj_right_same_direction = int(a[2]), bool(a[3])
+        lanelets.append(ll)
+    so = g["obstacle_state_off"]
+    obstacles = []
+    for i, oid in enumerate(g["obstacle_id"]):
+        obstacles.append(Obstacle(int(oid), str(g["obstacle_role"][i]), str(g["obstacle_type"][i]),
+                                  float(g["obstacle_dims"][i, 0]), float(g["obstacle_dims"][i, 1]),
+                                  int(g["obstacle_t0"][i]), g["obstacle_initial"][i],
+                                  g["obstacle_states"][so[i]:so[i + 1]]))
+    inters = {}
+    names = {0: "incoming", 1: "right", 2: "straight", 3: "left"}
+    for iid, k, code, lid in g["intersection_rows"]:
+        it = inters.setdefault(int(iid), {})
+        inc = it.setdefault(int(k), {"incoming": [], "right": [], "straight": [], "left": []})
+        inc[names[int(code)]].append(int(lid))
+    ilist = [{"id": iid, "incomings": [v[k] for k in sorted(v)]} for iid, v in inters.items()]
+    return Scenario(float(g["dt"]), lanelets, obstacles, ilist, g["ego_initial"], str(g["benchmark_id"]))

@@ -1,0 +1,236 @@
+"""Visibility / occlusion of one ego pose on the GPU (host side of ``fo_scene_visibility``, include/fo_hip.h).
+
+Mirrors the reference's ``SensorModel`` (ref: sensor_model.py:16-101): same constructor arguments (plus the
+discretisation parameters), same ``calc_visible_and_occluded_area(timestep, ego_pos, ego_orientation, obstacles)``
+entry, same attributes afterwards (``visible_area``, ``occluded_area``, ``visible_objects_timestep``,
+``obstacle_occlusions``).  The reference builds the areas with GEOS polygon algebra; here they are a polar ray fan
+(first hit per ray) plus a class per raster cell -- the discretisation DESIGN.md specifies.  ``visible_area`` is
+therefore a :class:`VisibleArea` (ring polygon + cell mask) instead of a shapely geometry (documented deviation,
+SURVEY 8b).  All arithmetic happens in libfo_hip.so; numpy here only packs small inputs.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .scenario import MapGeometry
+
+ROAD, VISIBLE, OCCLUDED = 1, 2, 4  # cell class bits (include/fo_hip.h)
+
+
+def ray_dirs(n_rays, ego_yaw=0.0, fov_deg=360.0):
+    """Unit ray directions, counter-clockwise.  Full circle (sensor_angle >= 359.9, sensor_model.py:121-122):
+    angle_i = yaw + 2 pi i / n; open fan: n rays from yaw - fov/2 to yaw + fov/2 inclusive (:115-124)."""
+    if fov_deg >= 359.9:
+        ang = ego_yaw + 2.0 * np.pi * np.arange(n_rays) / n_rays
+    else:
+        half = np.radians(fov_deg) / 2.0
+        ang = ego_yaw + np.linspace(-half, half, n_rays)
+    return np.stack((np.cos(ang), np.sin(ang)), -1)
+
+
+@dataclass
+class CellWindow:
+    """raster window the per-step cell classes live in: window cell (ix, iy) = world raster cell (ix0+ix, iy0+iy)"""
+    x0: float
+    y0: float
+    cs: float
+    ix0: int
+    iy0: int
+    nx: int
+    ny: int
+
+    def centers(self, idx):
+        idx = np.asarray(idx)
+        ix, iy = idx % self.nx, idx // self.nx
+        return np.stack((self.x0 + (self.ix0 + ix + 0.5) * self.cs, self.y0 + (self.iy0 + iy + 0.5) * self.cs), -1)
+
+    def cell_of(self, xy):
+        xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+        ix = np.floor((xy[:, 0] - self.x0) / self.cs).astype(np.int64) - self.ix0
+        iy = np.floor((xy[:, 1] - self.y0) / self.cs).astype(np.int64) - self.iy0
+        ok = (ix >= 0) & (ix < self.nx) & (iy >= 0) & (iy < self.ny)
+        return np.where(ok, iy * self.nx + ix, -1)
+
+
+class VisibleArea:
+    """What ``evaluate_scenario`` hands back instead of a shapely geometry: the visible polygon's ring (device
+    tensor [n_rays, 2]; for an open fan the ego position closes the polygon) and the per-cell classes."""
+
+    def __init__(self, ego_pos, ring, rng, hit_id, cls, window: CellWindow, full_circle, bit=VISIBLE):
+        self.ego_pos = np.asarray(ego_pos, dtype=np.float64)
+        self.ring, self.range, self.hit_id, self.cls, self.window = ring, rng, hit_id, cls, window
+        self.full_circle = full_circle
+        self._bit = bit
+        self._ring_h = None
+
+    @property
+    def exterior(self):
+        """polygon vertices as numpy [n,2] (host copy, lazily)"""
+        if self._ring_h is None:
+            r = self.ring.cpu().numpy()
+            self._ring_h = r if self.full_circle else np.concatenate((self.ego_pos[None], r), axis=0)
+        return self._ring_h
+
+    @property
+    def area(self):
+        """area of the cells of this class (cell count x cell area)"""
+        return float(((self.cls & self._bit) != 0).sum().item()) * self.window.cs ** 2
+
+    @property
+    def ring_area(self):
+        p = self.exterior
+        x, y = p[:, 0], p[:, 1]
+        return 0.5 * abs(float(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y)))
+
+    @property
+    def is_empty(self):
+        return not bool(((self.cls & self._bit) != 0).any().item())
+
+    def mask(self):
+        """bool device tensor [ny, nx]"""
+        return (self.cls & self._bit) != 0
+
+    def contains(self, xy):
+        """class bit of the cell containing each point (bool numpy [n])"""
+        idx = self.window.cell_of(xy)
+        flat = self.cls.reshape(-1).cpu().numpy()
+        out = np.zeros(len(idx), dtype=bool)
+        ok = idx >= 0
+        out[ok] = (flat[idx[ok]] & self._bit) != 0
+        return out
+
+
+class SensorModel:
+    def __init__(self, lanelet_network, ref_path, sensor_radius=30, sensor_angle=90, debug=True, visualization=None,
+                 ctx: Optional[N.Context] = None, n_rays=720, cell_size=0.5, device=0):
+        """lanelet_network: a :class:`~frenetix_occlusion.scenario.MapGeometry`, a list of
+        :class:`~frenetix_occlusion.scenario.Lanelet`, or an object with ``.lanelets`` (duck-typed CommonRoad)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("SensorModel needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device("cuda", int(device))
+        self.ctx = ctx or N.Context(self.device.index)
+        self.lanelet_network = lanelet_network
+        self.ref_path = ref_path
+        self.visualization = visualization
+        self.sensor_radius = float(sensor_radius)
+        self.sensor_angle = float(sensor_angle)
+        self.debug = debug
+        self.n_rays = int(n_rays)
+        self.cell_size = float(cell_size)
+        # state of the last step (names of sensor_model.py:26-35)
+        self.visible_area = None
+        self.occluded_area = None
+        self.obstacle_occlusions = {}
+        self.visible_objects_timestep = None
+        self.timestep = None
+        self.ego_pos = None
+        self.ego_orientation = None
+        self.window = None
+        self._set_map(lanelet_network)
+
+    # ---- one-off: replaces _convert_lanelet_network (sensor_model.py:195-199)
+    def _set_map(self, net):
+        from .scenario import Lanelet, lane_yaw_raster, lanelets_of
+        if isinstance(net, MapGeometry):
+            geo, lanelets = net, None
+        else:
+            lanelets = lanelets_of(net)
+            geo = MapGeometry.from_lanelets(lanelets)
+        self.map_geometry = geo
+        margin = 2.0 * self.cell_size
+        xy = geo.poly_xy
+        cs = self.cell_size
+        x0 = math.floor((xy[:, 0].min() - margin) / cs) * cs
+        y0 = math.floor((xy[:, 1].min() - margin) / cs) * cs
+        nx = int(math.ceil((xy[:, 0].max() + margin - x0) / cs))
+        ny = int(math.ceil((xy[:, 1].max() + margin - y0) / cs))
+        self.raster_origin, self.raster_dims = (x0, y0), (nx, ny)
+        lane_yaw = lane_yaw_raster(lanelets, x0, y0, cs, nx, ny) if lanelets is not None else None
+        self.lane_yaw = lane_yaw
+        off = np.ascontiguousarray(geo.poly_off, dtype=np.int32)
+        pxy = np.ascontiguousarray(geo.poly_xy, dtype=np.float64)
+        edges = np.ascontiguousarray(geo.edges, dtype=np.float64)
+        org = np.array([x0, y0], dtype=np.float64)
+        dims = np.array([nx, ny], dtype=np.int32)
+        ly = np.ascontiguousarray(lane_yaw, dtype=np.float64) if lane_yaw is not None else None
+        self.ctx.call("fo_scene_set_map", len(off) - 1, off.ctypes.data, pxy.ctypes.data, len(edges),
+                      edges.ctypes.data if len(edges) else None, cs, margin,
+                      ly.ctypes.data if ly is not None else None, org.ctypes.data, dims.ctypes.data)
+
+    def road_raster(self):
+        nx, ny = self.raster_dims
+        out = np.zeros((ny, nx), dtype=np.uint8)
+        self.ctx.call("fo_scene_copy_raster", out.ctypes.data)
+        return out
+
+    def _window_for(self, ego_pos):
+        """cells covering the 1.5 r disc about the ego (the occluded area reaches 1.5 r, sensor_model.py:85-90)"""
+        cs, (x0, y0) = self.cell_size, self.raster_origin
+        reach = 1.5 * self.sensor_radius
+        ix0 = int(math.floor((ego_pos[0] - reach - x0) / cs))
+        iy0 = int(math.floor((ego_pos[1] - reach - y0) / cs))
+        n = int(math.ceil(2.0 * reach / cs)) + 1
+        return CellWindow(x0, y0, cs, ix0, iy0, n, n)
+
+    # ---- per step: replaces calc_visible_and_occluded_area (sensor_model.py:41-101)
+    def calc_visible_and_occluded_area(self, timestep, ego_pos, ego_orientation, obstacles):
+        """obstacles: an FOObstacles (already updated to `timestep`) or None."""
+        self.timestep = timestep
+        self.ego_pos = np.asarray(ego_pos, dtype=np.float64)
+        self.ego_orientation = float(ego_orientation)
+        self.visible_objects_timestep = []
+        self.obstacle_occlusions.clear()
+        dev = self.device
+        full = self.sensor_angle >= 359.9
+        dirs = torch.as_tensor(ray_dirs(self.n_rays, self.ego_orientation, self.sensor_angle)).to(dev)
+        if obstacles is not None and len(obstacles) > 0:
+            corn, cen, flags = obstacles.arrays()
+            d_corn = torch.as_tensor(corn).to(dev)
+            d_cen = torch.as_tensor(cen).to(dev)
+            d_flags = torch.as_tensor(flags).to(dev)
+            O = len(flags)
+        else:
+            d_corn = d_cen = d_flags = None
+            O = 0
+        w = self._window_for(self.ego_pos)
+        n = self.n_rays
+        rng = torch.empty(n, dtype=torch.float64, device=dev)
+        hit = torch.empty(n, dtype=torch.int32, device=dev)
+        ring = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        ovis = torch.zeros(max(O, 1), dtype=torch.uint8, device=dev)
+        cls = torch.empty((w.ny, w.nx), dtype=torch.uint8, device=dev)
+        occ = torch.empty(w.nx * w.ny, dtype=torch.int32, device=dev)
+        n_occ = torch.zeros(1, dtype=torch.int32, device=dev)
+        p = lambda t: t.data_ptr() if t is not None else None
+        hx, hy = math.cos(self.ego_orientation), math.sin(self.ego_orientation)
+        self._keep = (dirs, d_corn, d_cen, d_flags)
+        self.ctx.call("fo_scene_visibility", float(self.ego_pos[0]), float(self.ego_pos[1]), hx, hy,
+                      self.sensor_radius, 1 if full else 0, n, p(dirs), O, p(d_corn), p(d_cen), p(d_flags), w.ix0,
+                      w.iy0, w.nx, w.ny, p(rng), p(hit), p(ring), p(ovis), p(cls), p(occ), p(n_occ),
+                      torch.cuda.current_stream().cuda_stream)
+        self.window = w
+        self.dirs, self.range, self.hit_id, self.cell_class = dirs, rng, hit, cls
+        self.occluded_idx_buffer, self.n_occluded = occ, n_occ
+        self.visible_area = VisibleArea(self.ego_pos, ring, rng, hit, cls, w, full, VISIBLE)
+        self.occluded_area = VisibleArea(self.ego_pos, ring, rng, hit, cls, w, full, OCCLUDED)
+        if O:
+            vis = ovis[:O].cpu().numpy().astype(bool)
+            hit_h = hit.cpu().numpy()
+            E = len(self.map_geometry.edges)
+            for i, obst in enumerate(obstacles):
+                obst.current_visible = bool(vis[i])
+                if vis[i]:
+                    self.visible_objects_timestep.append(obst.obstacle_id)
+                    obst.last_visible_at_ts = timestep
+                    # rays stopped by this obstacle = its shadow wedge (sensor_model.py:183: obstacle_occlusions[id])
+                    self.obstacle_occlusions[obst.obstacle_id] = np.nonzero(hit_h == E + i)[0]
+        return self.visible_area
+
+    def occluded_cells(self):
+        """ascending window indices of the occluded cells (device tensor view; synchronises to read the count)"""
+        k = int(self.n_occluded.item())
+        return self.occluded_idx_buffer[:k]

@@ -1,0 +1,149 @@
+"""Phantom-agent spawn sampling in the occluded cells (host side of ``fo_scene_spawn``, include/fo_hip.h).
+
+Mirrors the reference's ``SpawnLocator.find_spawn_points(ego_pos, ego_orientation, ego_pos_cl, ego_v)``
+(ref: spawn_locator.py:80-139) and its ``SpawnPoint`` record (:18-27).  The reference finds <= ~5 spawn points with
+three GEOS-based rule families; this build samples the *frontier* of the occluded cell set (occluded cells with a
+visible 4-neighbour -- where a hidden road user would emerge from), gated like the reference: at least 3 m ahead of
+the ego (:234,381) and not beyond max(4 v_ego, 25) m (:113, constants :65-66).  The kernel also writes the
+constant-velocity predictions of the spawned agents straight into the layout ``fo_sweep_set_agents`` reads, so the
+phantom set never leaves HBM between sampling and the metric sweep.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+MIN_AHEAD = 3.0            # spawn_locator.py:234,381 "ahead by >= 3 m"
+S_THRESHOLD_TIME = 4.0     # spawn_locator.py:65-66,113: s_threshold = s_ego + max(4 v, 25)
+S_THRESHOLD_MIN = 25.0
+
+TYPE_NAME = {0: "Car", 1: "Truck", 3: "Bicycle", 4: "Pedestrian"}
+TYPE_CODE = {"car": 0, "truck": 1, "bicycle": 3, "pedestrian": 4}
+
+
+@dataclass
+class SpawnPoint:
+    """spawn_locator.py:18-27"""
+    position: np.ndarray
+    agent_type: str
+    cl_pos: Optional[np.ndarray] = None
+    source: str = "occluded frontier"
+    orientation: Optional[float] = None
+
+
+@dataclass
+class PhantomBatch:
+    """device-resident phantom predictions, exactly the argument list of ``MetricSweep.set_agents``"""
+    n: torch.Tensor          # int32 [1]  number of active slots
+    cell: torch.Tensor       # int32 [max_agents] window cell index (-1 = unused slot)
+    pos0: torch.Tensor       # [max_agents,2]
+    yaw0: torch.Tensor       # [max_agents]
+    pos: torch.Tensor        # [max_agents,T,2]
+    yaw: torch.Tensor        # [max_agents,T]
+    v: torch.Tensor          # [max_agents,T]
+    cov: torch.Tensor        # [max_agents,T,2,2]
+    shape: torch.Tensor      # [max_agents,2] inflated
+    raw_dims: torch.Tensor   # [max_agents,2]
+    type: torch.Tensor       # int32 [max_agents]
+    len: torch.Tensor        # int32 [max_agents]  (T for active slots, 0 otherwise)
+
+    def sweep_args(self):
+        return self.pos, self.yaw, self.v, self.cov, self.shape, self.raw_dims, self.type, self.len
+
+
+class SpawnLocator:
+    def __init__(self, agent_manager, ref_path, config, sensor_model, cosy_cl=None, fo_obstacles=None,
+                 visualization=None, debug=False, max_agents=None, pattern=None, dt=0.1, horizon=3.0):
+        self.agent_manager = agent_manager
+        self.ref_path = np.ascontiguousarray(ref_path, dtype=np.float64)
+        self.config = config
+        self.cosy_cl = cosy_cl
+        self.sensor_model = sensor_model
+        self.fo_obstacles = fo_obstacles
+        self.visualization = visualization
+        self.debug = debug
+        self.ctx = sensor_model.ctx
+        self.device = sensor_model.device
+        acc = (config.get("accelerator") or {}).get("spawn", {}) if isinstance(config, dict) else {}
+        self.max_agents = int(max_agents if max_agents is not None else acc.get("max_agents", 32))
+        self.pattern = list(pattern if pattern is not None else acc.get("pattern",
+                                                                         ["Pedestrian", "Pedestrian", "Bicycle", "Car"]))
+        if len(self.pattern) != 4:
+            raise ValueError("spawn pattern needs exactly 4 agent types")
+        self.dt = float(dt)
+        self.T = int(horizon / self.dt) + 1                      # agent.py:496
+        self.min_ahead = float(acc.get("min_ahead", MIN_AHEAD))
+        am = config["agent_manager"]
+        pr = am["prediction"]
+        self.var0, self.var_factor = 0.1, float(pr["variance_factor"])   # agent.py:416-417,527-528
+        t4, s4, rl, rw, il, iw = [], [], [], [], [], []
+        for name in self.pattern:
+            key = name.lower()
+            if key not in TYPE_CODE:
+                raise NotImplementedError(f'SpawnLocator: Agent type "{name}" is not implemented!')   # agent.py:120
+            c = am[key]
+            big = key == "bicycle"                                        # agent.py:402-405
+            fl = pr["size_factor_length_l"] if big else pr["size_factor_length_s"]
+            fw = pr["size_factor_width_l"] if big else pr["size_factor_width_s"]
+            t4.append(TYPE_CODE[key]); s4.append(float(c["default_velocity"]))
+            rl.append(float(c["length"])); rw.append(float(c["width"]))
+            il.append(float(c["length"]) * fl); iw.append(float(c["width"]) * fw)
+        self._t4 = np.array(t4, dtype=np.int32)
+        self._s4, self._rl, self._rw = np.array(s4), np.array(rl), np.array(rw)
+        self._il, self._iw = np.array(il), np.array(iw)
+        self._d_path = torch.as_tensor(self.ref_path).to(self.device)
+        self.batch: Optional[PhantomBatch] = None
+        self.spawn_points = []
+
+    def _alloc(self):
+        dev, A, T = self.device, self.max_agents, self.T
+        f = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
+        i = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        return PhantomBatch(n=torch.zeros(1, dtype=torch.int32, device=dev), cell=i(A), pos0=f(A, 2), yaw0=f(A),
+                            pos=f(A, T, 2), yaw=f(A, T), v=f(A, T), cov=f(A, T, 2, 2), shape=f(A, 2),
+                            raw_dims=f(A, 2), type=i(A), len=i(A))
+
+    def max_distance(self, ego_v):
+        return max(S_THRESHOLD_TIME * float(ego_v), S_THRESHOLD_MIN)
+
+    def sample(self, ego_pos, ego_orientation, ego_v) -> PhantomBatch:
+        """device-only path: frontier candidates -> evenly spaced pick -> headings -> predictions (no host sync)"""
+        sm = self.sensor_model
+        if sm.cell_class is None:
+            raise RuntimeError("SpawnLocator: call SensorModel.calc_visible_and_occluded_area first")
+        if self.batch is None:
+            self.batch = self._alloc()
+        b, w = self.batch, sm.window
+        c = lambda a: a.ctypes.data
+        self.ctx.call("fo_scene_spawn", sm.cell_class.data_ptr(), w.ix0, w.iy0, w.nx, w.ny, float(ego_pos[0]),
+                      float(ego_pos[1]), math.cos(ego_orientation), math.sin(ego_orientation), self.min_ahead,
+                      self.max_distance(ego_v), self.max_agents, c(self._t4), c(self._s4), c(self._rl), c(self._rw),
+                      c(self._il), c(self._iw), int(self.ref_path.shape[0]), self._d_path.data_ptr(), self.T, self.dt,
+                      self.var0, self.var_factor, b.cell.data_ptr(), b.pos0.data_ptr(), b.yaw0.data_ptr(),
+                      b.n.data_ptr(), b.pos.data_ptr(), b.yaw.data_ptr(), b.v.data_ptr(), b.cov.data_ptr(),
+                      b.shape.data_ptr(), b.raw_dims.data_ptr(), b.type.data_ptr(), b.len.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+        return b
+
+    def find_spawn_points(self, ego_pos, ego_orientation, ego_pos_cl, ego_v):
+        """reference signature (spawn_locator.py:80): returns list[SpawnPoint] (one small D2H copy)"""
+        b = self.sample(ego_pos, ego_orientation, ego_v)
+        n = int(b.n.item())
+        pos0 = b.pos0[:n].cpu().numpy()
+        yaw0 = b.yaw0[:n].cpu().numpy()
+        typ = b.type[:n].cpu().numpy()
+        self.spawn_points = []
+        for j in range(n):
+            cl = None
+            if self.cosy_cl is not None:
+                try:
+                    cl = np.asarray(self.cosy_cl.convert_to_curvilinear_coords(pos0[j, 0], pos0[j, 1]))
+                except Exception:   # out of the projection domain: the reference skips silently (:228-231)
+                    cl = None
+            self.spawn_points.append(SpawnPoint(pos0[j].copy(), TYPE_NAME[int(typ[j])], cl, "occluded frontier",
+                                                float(yaw0[j])))
+        return self.spawn_points

@@ -1,0 +1,86 @@
+"""Per-timestep obstacle state cache (mirrors ref: utils/fo_obstacle.py:14-116, helper_functions.py:99-112).
+
+Wraps each scenario obstacle -- a :class:`~frenetix_occlusion.scenario.Obstacle` or a duck-typed CommonRoad obstacle --
+and caches pose / corner points / visibility for the current global time step.  ``arrays()`` packs what
+``fo_scene_visibility`` consumes.  Pure host bookkeeping (a handful of obstacles); no polygons are built.
+"""
+import numpy as np
+
+from ..scenario import Obstacle, obstacle_from_commonroad
+
+
+class FOObstacle:
+    def __init__(self, obst):
+        self.cr_obstacle = obst
+        self._o = obst if isinstance(obst, Obstacle) else obstacle_from_commonroad(obst)
+        self.obstacle_id = self._o.obstacle_id
+        self.obstacle_type = self._o.obstacle_type
+        self.obstacle_role = self._o.role
+        self.initial_timestep = self._o.initial_time_step
+        self.global_timestep = None
+        self.relative_time_step = None
+        self.current_pos = None
+        self.current_orientation = None
+        self.current_corner_points = None
+        self.current_visible = False
+        self.last_visible_at_ts = None
+
+    @property
+    def length(self):
+        return self._o.length
+
+    @property
+    def width(self):
+        return self._o.width
+
+    def update_at_timestep(self, timestep):
+        """fo_obstacle.py:79-116: rel = step - initial; 0 -> initial state, >= 1 -> state_list[rel-1], else absent"""
+        self.global_timestep = timestep
+        self.relative_time_step = timestep - self.initial_timestep
+        self.current_visible = False
+        pose = self._o.pose_at(timestep)
+        if pose is None:
+            self.current_pos = self.current_orientation = self.current_corner_points = None
+            return
+        self.current_pos = np.array(pose[:2], dtype=np.float64)
+        self.current_orientation = float(pose[2])
+        self.current_corner_points = self._o.corners(pose)
+
+    @property
+    def occludes(self):
+        return str(self.obstacle_type).lower() != "bicycle"  # sensor_model.py:177 (Q10)
+
+
+class FOObstacles:
+    def __init__(self, cr_obstacles):
+        self.cr_obstacles = list(cr_obstacles)
+        self.fo_obstacles = [FOObstacle(o) for o in self.cr_obstacles]
+        self.visible_obstacle_multipolygon = None  # list of [4,2] corner arrays of the visible obstacles
+
+    def __iter__(self):
+        return iter(self.fo_obstacles)
+
+    def __len__(self):
+        return len(self.fo_obstacles)
+
+    def add(self, cr_obstacle):
+        self.cr_obstacles.append(cr_obstacle)
+        self.fo_obstacles.append(FOObstacle(cr_obstacle))
+
+    def update(self, timestep):
+        for o in self.fo_obstacles:
+            o.update_at_timestep(timestep)
+
+    def update_multipolygon(self):
+        self.visible_obstacle_multipolygon = [o.current_corner_points for o in self.fo_obstacles if o.current_visible]
+
+    def arrays(self):
+        """corner points [O,4,2], centres [O,2], flags uint8 [O] (bit0 present at this step, bit1 occludes)"""
+        O = len(self.fo_obstacles)
+        corn, cen, flags = np.zeros((O, 4, 2)), np.zeros((O, 2)), np.zeros(O, dtype=np.uint8)
+        for i, o in enumerate(self.fo_obstacles):
+            if o.current_pos is None:
+                continue
+            corn[i], cen[i] = o.current_corner_points, o.current_pos
+            flags[i] = 1 | (2 if o.occludes else 0)
+        return corn, cen, flags

@@ -144,3 +144,101 @@ def sweep(traj, agents, vehicle, dt, metrics=("hr", "ttc", "ttce", "dce", "wttc"
     if rc != 0:
         raise RuntimeError(f"fo_oracle_sweep failed with code {rc}")
     return {"pair_f": pair_f, "pair_i": pair_i, "lists": lists, "cost": cost, "safe": safe}
+
+
+# ---------------------------------------------------------------------------------------------- scene half
+# (fo_oracle_scene.c; discretisation defined in DESIGN.md, "parity unpinned" against the reference's GEOS algebra)
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def ray_dirs(n_rays, ego_yaw=0.0, fov_deg=360.0):
+    """Unit ray directions, counter-clockwise.  Full circle: angle_i = yaw + 2 pi i / n (ray n == ray 0);
+    open fan: n rays from yaw - fov/2 to yaw + fov/2 inclusive.  Shared definition (host layer uses the same)."""
+    if fov_deg >= 359.9:
+        ang = ego_yaw + 2.0 * np.pi * np.arange(n_rays) / n_rays
+    else:
+        half = np.radians(fov_deg) / 2.0
+        ang = ego_yaw + np.linspace(-half, half, n_rays)
+    return np.stack((np.cos(ang), np.sin(ang)), -1)
+
+
+def road_raster(poly_off, poly_xy, x0, y0, cs, nx, ny):
+    poly_off, poly_xy = _i32(poly_off), _f64(poly_xy)
+    mask = np.zeros((ny, nx), dtype=np.uint8)
+    lib().fo_oracle_road_raster(C.c_int(len(poly_off) - 1), _p(poly_off, C.c_int32), _p(poly_xy), C.c_double(x0),
+                                C.c_double(y0), C.c_double(cs), C.c_int(nx), C.c_int(ny), _p(mask, C.c_uint8))
+    return mask
+
+
+def raycast(edges, ocorn, oflags, ego, dirs, r):
+    edges, ocorn, oflags = _f64(edges).reshape(-1, 4), _f64(ocorn).reshape(-1, 8), _u8(oflags)
+    ego, dirs = _f64(ego), _f64(dirs)
+    n = dirs.shape[0]
+    rng, hid, ring = np.zeros(n), np.zeros(n, dtype=np.int32), np.zeros((n, 2))
+    lib().fo_oracle_raycast(C.c_int(edges.shape[0]), _p(edges), C.c_int(ocorn.shape[0]), _p(ocorn),
+                            _p(oflags, C.c_uint8), _p(ego), C.c_int(n), _p(dirs), C.c_double(r), _p(rng),
+                            _p(hid, C.c_int32), _p(ring))
+    return rng, hid, ring
+
+
+def grid(raster, rx0, ry0, cs, ix0, iy0, nx, ny, ego, hdir, r, full, dirs, rng):
+    raster = _u8(raster)
+    rny, rnx = raster.shape
+    ego, hdir, dirs, rng = _f64(ego), _f64(hdir), _f64(dirs), _f64(rng)
+    cls = np.zeros((ny, nx), dtype=np.uint8)
+    occ = np.zeros(nx * ny, dtype=np.int32)
+    n_occ = C.c_int32(0)
+    lib().fo_oracle_grid(_p(raster, C.c_uint8), C.c_int(rnx), C.c_int(rny), C.c_double(rx0), C.c_double(ry0),
+                         C.c_double(cs), C.c_int(ix0), C.c_int(iy0), C.c_int(nx), C.c_int(ny), _p(ego), _p(hdir),
+                         C.c_double(r), C.c_int(1 if full else 0), C.c_int(dirs.shape[0]), _p(dirs), _p(rng),
+                         _p(cls, C.c_uint8), _p(occ, C.c_int32), C.byref(n_occ))
+    return cls, occ[:n_occ.value].copy()
+
+
+def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs):
+    edges, ocorn, ocen, oflags = _f64(edges).reshape(-1, 4), _f64(ocorn).reshape(-1, 8), _f64(ocen), _u8(oflags)
+    ego, dirs = _f64(ego), _f64(dirs)
+    O = ocorn.shape[0]
+    vis = np.zeros(O, dtype=np.uint8)
+    lib().fo_oracle_obstacle_visibility(C.c_int(edges.shape[0]), _p(edges), C.c_int(O), _p(ocorn), _p(ocen),
+                                        _p(oflags, C.c_uint8), _p(ego), C.c_double(r), C.c_int(1 if full else 0),
+                                        C.c_int(dirs.shape[0]), _p(dirs), _p(vis, C.c_uint8))
+    return vis
+
+
+def spawn_cells(cls, rx0, ry0, cs, ix0, iy0, ego, hdir, min_ahead, max_dist, max_agents):
+    cls = _u8(cls)
+    ny, nx = cls.shape
+    ego, hdir = _f64(ego), _f64(hdir)
+    cell = np.full(max_agents, -1, dtype=np.int32)
+    pos = np.zeros((max_agents, 2))
+    n, nc = C.c_int32(0), C.c_int32(0)
+    lib().fo_oracle_spawn_cells(_p(cls, C.c_uint8), C.c_int(nx), C.c_int(ny), C.c_double(rx0), C.c_double(ry0),
+                                C.c_double(cs), C.c_int(ix0), C.c_int(iy0), _p(ego), _p(hdir), C.c_double(min_ahead),
+                                C.c_double(max_dist), C.c_int(max_agents), _p(cell, C.c_int32), _p(pos), C.byref(n),
+                                C.byref(nc))
+    return cell, pos, n.value, nc.value
+
+
+def spawn_headings(pos, types, path, lane_yaw_at=None):
+    pos, types, path = _f64(pos), _i32(types), _f64(path)
+    n = pos.shape[0]
+    lya = _f64(lane_yaw_at) if lane_yaw_at is not None else None
+    yaw = np.zeros(n)
+    lib().fo_oracle_spawn_headings(C.c_int(n), _p(pos), _p(types, C.c_int32), C.c_int(path.shape[0]), _p(path),
+                                   _p(lya), _p(yaw))
+    return yaw
+
+
+def cv_predictions(pos0, yaw, speed, T, dt, var0=0.1, factor=1.05):
+    pos0, yaw, speed = _f64(pos0), _f64(yaw), _f64(speed)
+    n = pos0.shape[0]
+    pos, yl, vl, cov = np.zeros((n, T, 2)), np.zeros((n, T)), np.zeros((n, T)), np.zeros((n, T, 4))
+    lib().fo_oracle_cv_predictions(C.c_int(n), _p(pos0), _p(yaw), _p(speed), C.c_int(T), C.c_double(dt),
+                                   C.c_double(var0), C.c_double(factor), _p(pos), _p(yl), _p(vl), _p(cov))
+    return pos, yl, vl, cov.reshape(n, T, 2, 2)

@@ -1,0 +1,144 @@
+"""End-to-end check of the drop-in boundary on a real MI355X: FOInterface.evaluate_scenario +
+trajectory_safety_assessment(_batch) against the oracle fed with the same phantom predictions."""
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _traj_objects(traj):
+    return [SimpleNamespace(cartesian=SimpleNamespace(**{k: v[i] for k, v in traj.items()})) for i in range(len(traj["x"]))]
+
+
+def _setup(tmp_path, thresholds=None, max_agents=16, metrics=None):
+    import yaml
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion import synthetic as SY
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"]["max_agents"] = max_agents
+    if thresholds:
+        cfg["metrics"]["metric_thresholds"].update(thresholds)
+    if metrics:
+        cfg["metrics"]["activated_metrics"] = list(metrics)
+    p = tmp_path / "occlusion.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    s = np.linspace(0.0, 80.0, 81)
+    ref_path = ego[None, :2] + s[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+    veh = SimpleNamespace(length=SY.VEHICLE_BMW320I[0], width=SY.VEHICLE_BMW320I[1], wb_rear_axle=SY.VEHICLE_BMW320I[2],
+                          mass=SY.VEHICLE_BMW320I[3], a_max=SY.VEHICLE_BMW320I[4])
+    fo = interface.FOInterface(sc, ref_path, veh, 0.1, config_path=str(p))
+    return fo, sc, ego, SY
+
+
+def _oracle_agents(fo):
+    b = fo.spawn_locator.batch
+    return {"pos": b.pos.cpu().numpy(), "yaw": b.yaw.cpu().numpy(), "v": b.v.cpu().numpy(), "cov": b.cov.cpu().numpy(),
+            "shape": b.shape.cpu().numpy(), "raw_dims": b.raw_dims.cpu().numpy(), "type": b.type.cpu().numpy(),
+            "len": b.len.cpu().numpy()}
+
+
+def test_evaluate_scenario_then_batch_and_per_trajectory_calls(torch_cuda, oracle, tmp_path):
+    thr = {"harm": 0.1, "risk": 0.05}
+    fo, sc, ego, SY = _setup(tmp_path, thr)
+    vis = fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    assert vis is fo.sensor_model.visible_area and not vis.is_empty
+    assert vis.exterior.shape == (720, 2) and vis.area > 50.0
+    assert len(fo.spawn_points) > 0 and len(fo.agent_manager.phantom_agents) == len(fo.spawn_points)
+    preds = fo.agent_manager.predictions
+    assert len(preds) == len(fo.spawn_points)
+    for pid, p in preds.items():
+        assert set(p) == {"orientation_list", "v_list", "pos_list", "shape", "cov_list"}
+        assert p["pos_list"].shape == (31, 2) and p["cov_list"].shape == (31, 2, 2)
+        assert fo.agent_manager.agent_by_prediction_id(pid) is not None
+
+    traj = SY.make_trajectories(64, seed=99, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    objs = _traj_objects(traj)
+    ref = oracle.sweep(traj, _oracle_agents(fo), SY.VEHICLE_BMW320I, 0.1, thr=thr)
+
+    ba = fo.trajectory_safety_assessment_batch(objs, mode="reduced")
+    torch_cuda.cuda.synchronize()
+    cost = ba.cost.cpu().numpy()
+    fin = np.isfinite(ref["cost"])
+    assert np.array_equal(np.isfinite(cost), fin)
+    np.testing.assert_allclose(cost[fin], ref["cost"][fin], rtol=0, atol=1e-9)
+    assert np.array_equal(ba.safe.cpu().numpy(), ref["safe"])
+
+    # the reference's per-trajectory contract, served from a cached full batch
+    fo.trajectory_safety_assessment_batch(objs, mode="full")
+    slots = dict(fo.agent_manager.prediction_slots)
+    for m in (0, 17, 63):
+        res, safe = fo.trajectory_safety_assessment(objs[m])
+        assert safe == bool(ref["safe"][m])
+        assert list(res.keys()) == ["cp", "dce", "ttc", "hr", "ttce", "wttc"]      # metric.py:125-147 order
+        for pid, k in slots.items():
+            np.testing.assert_allclose(res["cp"][pid], ref["lists"][m, k, 0][:len(res["cp"][pid])], atol=1e-9)
+            assert len(res["cp"][pid]) == 30
+            assert res["dce"][pid]["time_dce"] == ref["pair_i"][m, k, oracle.PI["time_dce"]]
+            assert res["dce"][pid]["dce"] == pytest.approx(ref["pair_f"][m, k, oracle.PF["dce"]], abs=1e-9)
+            assert res["ttce"][pid] == pytest.approx(ref["pair_f"][m, k, oracle.PF["ttce"]], abs=1e-12)
+            h = res["hr"][pid]
+            assert h["max_obst_risk"] == pytest.approx(ref["pair_f"][m, k, oracle.PF["max_obst_risk"]], abs=1e-9)
+            assert len(h["ego_harm_traj"]) == 30 and len(h["obst_risk_traj"]) == 30
+        assert res["hr"]["max_obst_risk_all"] == pytest.approx(ref["cost"][m, oracle.COST["max_obst_risk_all"]], abs=1e-9)
+        w = ref["cost"][m, oracle.COST["wttc"]]
+        assert res["wttc"] == w or (math.isinf(w) and math.isinf(res["wttc"]))
+    # a trajectory that was not part of the batch: one-trajectory launch
+    other = _traj_objects(SY.make_trajectories(3, seed=5, ego_pos=ego[:2], ego_yaw=float(ego[2])))[1]
+    res, safe = fo.trajectory_safety_assessment(other)
+    assert "hr" in res and isinstance(safe, bool)
+
+
+def test_no_phantoms_means_empty_result_and_safe(torch_cuda, tmp_path):
+    fo, sc, ego, SY = _setup(tmp_path)
+    fo.spawn_locator.min_ahead = 1e6          # no candidate survives the gate
+    fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    assert fo.spawn_points == [] and not fo.agent_manager.phantom_agents
+    obj = _traj_objects(SY.make_trajectories(2, seed=1))[0]
+    assert fo.trajectory_safety_assessment(obj) == ({}, True)           # metric.py:44-45
+    assert fo.trajectory_safety_assessment_batch([obj]) is None
+
+
+def test_manual_agents_and_error_conventions(torch_cuda, oracle, tmp_path):
+    fo, sc, ego, SY = _setup(tmp_path, max_agents=4)
+    fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    am = fo.agent_manager
+    n0 = len(am.phantom_agents)
+    a = am.add_agent(pos=np.array([15.0, 3.0]), velocity="default", agent_type="Pedestrian", timestep=0)
+    assert a is not None and len(am.phantom_agents) == n0 + 1
+    assert am.add_agent(pos=[0, 0], agent_type="Car", timestep=5) is None            # agent.py:69-70
+    with pytest.raises(NotImplementedError):
+        am.add_agent(pos=[0, 0], agent_type="Tank", timestep=0)                       # agent.py:120
+    with pytest.raises(ValueError):
+        am.add_agent(pos=[0, 0], agent_type="Car", velocity="fast", timestep=0)       # agent.py:100
+    fo.metrics.invalidate()
+    traj = SY.make_trajectories(16, seed=4, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    ba = fo.trajectory_safety_assessment_batch(traj, mode="pair")
+    torch_cuda.cuda.synchronize()
+    arrs = am.sweep_arrays()
+    agents = dict(zip(("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len"), [t.cpu().numpy() for t in arrs]))
+    assert agents["pos"].shape[0] == 4 + 1
+    ref = oracle.sweep(traj, agents, SY.VEHICLE_BMW320I, 0.1, thr={"harm": 1, "risk": 1})
+    got = ba.result.pair_f.permute(2, 1, 0).cpu().numpy()
+    f = np.isfinite(ref["pair_f"])
+    assert np.array_equal(np.isnan(got), np.isnan(ref["pair_f"]))
+    np.testing.assert_allclose(got[f], ref["pair_f"][f], rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        from frenetix_occlusion.metrics.metric import Metric
+        Metric({"activated_metrics": ["nope"], "metric_thresholds": {}}, fo.vehicle_params, am, dt=0.1)

@@ -1,0 +1,154 @@
+"""Parity of the HIP scene kernels (ray fan, cell grid, obstacle visibility, phantom spawn + predictions; through the
+C ABI) against the CPU restatement in oracle/.  Integer outputs (hit ids, cell classes, occluded-cell indices, spawn
+cells) must be bit-exact; ranges are float64 with identical operation order on both sides (no FMA contraction) and are
+compared exactly as well.  Needs a real MI355X: `pytest -m gpu`."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available(), "GPU test selected but no GPU visible"
+    return torch
+
+
+def _default_config():
+    import yaml
+    from frenetix_occlusion import interface
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        return yaml.safe_load(f)
+
+
+def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_rays=720, radius=50.0, max_agents=32,
+                ref_path=None):
+    from frenetix_occlusion.sensor_model import SensorModel, ray_dirs
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    ego = np.asarray(ego, dtype=np.float64)
+    yaw = float(ego[2])
+    if ref_path is None:
+        s = np.linspace(0.0, 60.0, 61)
+        ref_path = ego[None, :2] + s[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    sm = SensorModel(sc.lanelets, ref_path, sensor_radius=radius, sensor_angle=sensor_angle, n_rays=n_rays)
+    obst = FOObstacles(sc.obstacles)
+    obst.update(timestep)
+    sm.calc_visible_and_occluded_area(timestep, ego[:2], yaw, obst)
+    torch.cuda.synchronize()
+    geo = sm.map_geometry
+    (x0, y0), (rnx, rny) = sm.raster_origin, sm.raster_dims
+    cs = sm.cell_size
+
+    # one-off raster
+    raster_ref = oracle.road_raster(geo.poly_off, geo.poly_xy, x0, y0, cs, rnx, rny)
+    assert np.array_equal(sm.road_raster(), raster_ref)
+
+    # ray fan
+    dirs = ray_dirs(n_rays, yaw, sensor_angle)
+    assert np.array_equal(dirs, oracle.ray_dirs(n_rays, yaw, sensor_angle))
+    corn, cen, flags = obst.arrays()
+    rng_ref, hid_ref, ring_ref = oracle.raycast(geo.edges, corn, flags, ego[:2], dirs, radius)
+    assert np.array_equal(sm.hit_id.cpu().numpy(), hid_ref)
+    assert np.array_equal(sm.range.cpu().numpy(), rng_ref)
+    assert np.array_equal(sm.visible_area.ring.cpu().numpy(), ring_ref)
+
+    # cell classes + occluded-cell indices (bit-exact, north_star)
+    w = sm.window
+    full = sensor_angle >= 359.9
+    hd = np.array([math.cos(yaw), math.sin(yaw)])
+    cls_ref, occ_ref = oracle.grid(raster_ref, x0, y0, cs, w.ix0, w.iy0, w.nx, w.ny, ego[:2], hd, radius, full, dirs,
+                                   rng_ref)
+    assert np.array_equal(sm.cell_class.cpu().numpy(), cls_ref)
+    assert np.array_equal(sm.occluded_cells().cpu().numpy(), occ_ref)
+
+    # obstacle visibility
+    if len(flags):
+        vis_ref = oracle.obstacle_visibility(geo.edges, corn, cen, flags, ego[:2], radius, full, dirs)
+        got = np.array([o.current_visible for o in obst], dtype=np.uint8)
+        assert np.array_equal(got, vis_ref)
+        assert sm.visible_objects_timestep == [o.obstacle_id for o, v in zip(obst, vis_ref) if v]
+
+    # phantom sampling + predictions
+    cfg = _default_config()
+    cfg["accelerator"]["spawn"]["max_agents"] = max_agents
+    sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1)
+    pts = sl.find_spawn_points(ego[:2], yaw, None, v_ego)
+    torch.cuda.synchronize()
+    b = sl.batch
+    cell_ref, pos_ref, n_ref, n_cand = oracle.spawn_cells(cls_ref, x0, y0, cs, w.ix0, w.iy0, ego[:2], hd, sl.min_ahead,
+                                                          sl.max_distance(v_ego), max_agents)
+    assert int(b.n.item()) == n_ref == len(pts)
+    assert np.array_equal(b.cell.cpu().numpy(), cell_ref)
+    assert np.array_equal(b.pos0.cpu().numpy()[:n_ref], pos_ref[:n_ref])
+    types = np.array([sl._t4[j % 4] for j in range(n_ref)], dtype=np.int32)
+    assert np.array_equal(b.type.cpu().numpy()[:n_ref], types)
+    ln = b.len.cpu().numpy()
+    assert (ln[:n_ref] == sl.T).all() and (ln[n_ref:] == 0).all()
+    if n_ref:
+        lya = None
+        if sm.lane_yaw is not None:
+            ci = cell_ref[:n_ref]
+            wx, wy = w.ix0 + ci % w.nx, w.iy0 + ci // w.nx
+            ok = (wx >= 0) & (wx < rnx) & (wy >= 0) & (wy < rny)
+            lya = np.where(ok, sm.lane_yaw[np.clip(wy, 0, rny - 1), np.clip(wx, 0, rnx - 1)], np.nan)
+        yaw_ref = oracle.spawn_headings(pos_ref[:n_ref], types, ref_path, lya)
+        np.testing.assert_allclose(b.yaw0.cpu().numpy()[:n_ref], yaw_ref, rtol=0, atol=1e-12)
+        speed = np.array([sl._s4[j % 4] for j in range(n_ref)])
+        p, yl, vl, cov = oracle.cv_predictions(pos_ref[:n_ref], yaw_ref, speed, sl.T, 0.1, 0.1, sl.var_factor)
+        np.testing.assert_allclose(b.pos.cpu().numpy()[:n_ref], p, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(b.yaw.cpu().numpy()[:n_ref], yl, rtol=0, atol=1e-12)
+        assert np.array_equal(b.v.cpu().numpy()[:n_ref], vl)
+        np.testing.assert_allclose(b.cov.cpu().numpy()[:n_ref], cov, rtol=1e-13, atol=0)
+    return dict(n_spawn=n_ref, n_cand=n_cand, n_occ=len(occ_ref), vis_cells=int(((cls_ref & 2) != 0).sum()))
+
+
+@pytest.mark.parametrize("timestep", [0, 8, 25, 60])
+def test_scenario1_steps_match_the_oracle(torch_cuda, oracle, timestep):
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial.copy()
+    ego[0] += 0.7 * timestep * math.cos(ego[2])      # the ego advances ~7 m/s along its heading
+    ego[1] += 0.7 * timestep * math.sin(ego[2])
+    st = _check_step(torch_cuda, oracle, sc, ego, 7.63, timestep)
+    assert st["vis_cells"] > 100 and st["n_occ"] > 0
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_scenario2_and_3_match_the_oracle(torch_cuda, oracle, k):
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, f"scenario{k}_geometry.npz"))
+    st = _check_step(torch_cuda, oracle, sc, sc.ego_initial, float(sc.ego_initial[3]), 0)
+    assert st["vis_cells"] > 100
+
+
+def test_open_fan_and_odd_ray_counts(torch_cuda, oracle):
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    _check_step(torch_cuda, oracle, sc, sc.ego_initial, 7.63, 0, sensor_angle=90.0, n_rays=181, radius=30.0)
+    _check_step(torch_cuda, oracle, sc, sc.ego_initial, 7.63, 3, sensor_angle=200.0, n_rays=400, radius=40.0)
+    _check_step(torch_cuda, oracle, sc, sc.ego_initial, 7.63, 3, sensor_angle=360.0, n_rays=97, radius=25.0, max_agents=5)
+
+
+def test_synthetic_urban_grid_config3(torch_cuda, oracle):
+    """BASELINE configs[2] scene: O(10^4) boundary edges, 64 parked cars, 720 rays @ 0.5 deg, 256 phantom slots."""
+    from frenetix_occlusion import scenario as S
+    sc = S.synthetic_urban_grid()
+    st = _check_step(torch_cuda, oracle, sc, sc.ego_initial, 8.0, 0, max_agents=256)
+    assert st["n_occ"] > 500 and st["n_cand"] > 0
+
+
+def test_no_obstacles_and_ego_off_the_raster_edge(torch_cuda, oracle):
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario2_geometry.npz"))
+    sc.obstacles = []
+    ego = sc.ego_initial.copy()
+    _check_step(torch_cuda, oracle, sc, ego, 5.0, 0)
+    ego[:2] = sc.lanelets[0].center[0]      # window hangs over the raster border
+    _check_step(torch_cuda, oracle, sc, ego, 5.0, 0)
