@@ -43,6 +43,31 @@ __global__ void fo_erf_table_kernel(double2 *tab) {
   tab[i] = make_double2(erf(x0), 1.1283791670955125738961589031 * exp(-x0 * x0));
 }
 
+// Same table, fewer VALU operations (used by the queue kernel): the node index comes from the low word of
+// au * 128 + 1.5 * 2^52 (no rint / convert instruction), and the Taylor polynomial is evaluated in y = x0 d and
+// s = d^2:  erf(x0 + d) = e + g d P,
+//   P = (1 - s/3 + s^2/10) + y (-1 + s/2) + y^2 (2/3 - 2 s/5) - y^3/3 + 2 y^4/15 + O(5th order) ,
+// which is the expansion of fo_erf_lds regrouped (same truncation error, < 3e-16 absolute).
+__device__ __forceinline__ double fo_erf_fast(const double2 *__restrict__ tab, double u) {
+  const double au = fmin(fabs(u), 6.0);
+  const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+  const double tm = fma(au, ERF_SCALE, MAGIC);
+  const double fi = tm - MAGIC;               // rint(au * 128), exact
+  const int i = __double2loint(tm);           // the same integer, read from the mantissa
+  const double d = fma(fi, -1.0 / ERF_SCALE, au);
+  const double y = (fi * (1.0 / ERF_SCALE)) * d;
+  const double sq = d * d;
+  const double2 e = tab[i];
+  const double a0 = fma(sq, fma(sq, 0.1, -1.0 / 3.0), 1.0);
+  const double a1 = fma(sq, 0.5, -1.0);
+  const double a2 = fma(sq, -0.4, 2.0 / 3.0);
+  double p = fma(y, 2.0 / 15.0, -1.0 / 3.0);
+  p = fma(p, y, a2);
+  p = fma(p, y, a1);
+  p = fma(p, y, a0);
+  return copysign(fma(e.y * d, p, e.x), u);
+}
+
 __global__ void fo_exp_table_kernel(double *tab) {
   if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x / 64.0);
 }
@@ -59,6 +84,17 @@ __device__ __forceinline__ double fo_erf_lds(const double2 *__restrict__ tab, do
   const double a4 = (4.0 * q * q - 12.0 * q + 3.0) * (1.0 / 30.0);
   const double p = 1.0 + d * (-x0 + d * (a2 + d * (a3 + d * a4)));
   return copysign(e.x + e.y * d * p, u);
+}
+
+// sqrt by one Goldschmidt step on v_rsq_f64 (relative error ~1e-14 instead of the correctly rounded ~25-instruction
+// expansion of sqrt()); x >= 0, x = 0 -> 0.  Consumers are rounded to 1e-3 / compared at 1e-9.
+__device__ __forceinline__ double fo_sqrt(double x) {
+  const double g = __builtin_amdgcn_rsq(fmax(x, 1e-300));
+  double y = x * g;
+  const double h = 0.5 * g;
+  const double r = fma(-h, y, 0.5);
+  y = fma(y, r, y);
+  return y;
 }
 
 __device__ __forceinline__ double fo_round3(double v) { return __builtin_rint(v * 1000.0) / 1000.0; }  // np.round(v,3)
@@ -454,7 +490,13 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 //   pass 2 (t loop)  harm + risk + running maxima + coalesced list stores, cp read back from cpbuf.
 // exp() for the logistic models is a 64-entry 2^(j/64) table + degree-5 polynomial (~15 VALU ops).
 // Supports T-1 <= TQ; longer horizons take the generic kernel.
-constexpr int TQ = 30;
+#ifndef FO_TQ
+#define FO_TQ 30
+#endif
+#ifndef FO_MINW
+#define FO_MINW 2
+#endif
+constexpr int TQ = FO_TQ;
 constexpr int QCAP = 128;
 
 __device__ __forceinline__ double fo_exp_tab(const double *__restrict__ tab2, double z) {
@@ -480,8 +522,16 @@ __device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab
   return y;
 }
 
+// wave-uniform tables are read through the constant address space: the loads become s_load (scalar cache, results in
+// SGPRs) instead of 64-lane broadcasts through the vector memory path.  The tables are written by an earlier launch
+// (fo_prep_agents_kernel), so the scalar cache is coherent with them.
+typedef const double __attribute__((address_space(4))) *cdp_t;
+typedef const int32_t __attribute__((address_space(4))) *cip_t;
+__device__ __forceinline__ cdp_t fo_const(const double *p) { return (cdp_t)(unsigned long long)p; }
+__device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(unsigned long long)p; }
+
 template <bool PAIR, bool LISTS>
-__global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const SweepArgs a) {
+__global__ __launch_bounds__(TILE *WAVES, FO_MINW) void fo_sweep_queue_kernel(const SweepArgs a) {
   __shared__ double2 erf_tab[ERF_N];
   __shared__ double exp_tab[64];
   __shared__ double cpbuf_all[WAVES * TQ * TILE];  // also the cross-wave reduction scratch at the end
@@ -504,6 +554,7 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
   unsigned short *q = queue_all + wave * QCAP;
   const bool do_dce = a.mask & FO_M_DCE, do_cp = a.mask & FO_M_CP, do_hr = a.mask & FO_M_HR;
   const bool do_ttc = a.mask & FO_M_TTC, do_ttce = a.mask & FO_M_TTCE;
+  const double hlA = a.hlA, hwA = a.hwA;
 
   double w_min_dce = INFINITY, w_min_ttc = INFINITY, w_min_ttce = INFINITY;
   double w_max_er = 0.0, w_max_or = 0.0, w_max_eh = 0.0, w_max_oh = 0.0, w_max_cp = 0.0, w_max_hwc = 0.0;
@@ -513,10 +564,10 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
   for (int kk = 0; kk < a.apw; ++kk) {
     const int k = k0 + kk;
     if (k >= A) break;
-    const double *G = a.atab + (size_t)k * a.Ta * NAF;
-    const double *C = a.acst + (size_t)k * NAC;
+    const cdp_t G = fo_const(a.atab) + (size_t)k * a.Ta * NAF;
+    const cdp_t C = fo_const(a.acst) + (size_t)k * NAC;
     const double hlB = C[0], hwB = C[1], hdev = C[2], f_ego = C[3], f_obs = C[4];
-    const int prot = a.aint[2 * k], L = a.aint[2 * k + 1];
+    const int prot = fo_const(a.aint)[2 * k], L = fo_const(a.aint)[2 * k + 1];
     const int Lh = min(Tm1, L);
 
     if (L <= 0) {  // inactive slot (a spawn buffer that is only partly filled): no outputs enter any reduction
@@ -541,9 +592,9 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
         const int src = item & 63, ti = item >> 6;
         const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + src;  // ego sample ti+1 of trajectory `src`
         const double qex = e[0 * TILE], qey = e[1 * TILE], qec = e[2 * TILE], qes = e[3 * TILE];
-        const double *g0 = G + (size_t)ti * NAF;                       // agent mean / covariance: sample ti
+        const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti (per lane)
         const double qpx = g0[0], qpy = g0[1], qisx = g0[6], qisy = g0[7];
-        const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1)
+        const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
         const double devx = qc1 * hdev, devy = qs1 * hdev;
         const double rx = qex - qpx, ry = qey - qpy;
         const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
@@ -554,61 +605,75 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
 #pragma unroll
           for (int b = -1; b <= 1; ++b) {
             const double cx = qx + b * bxs, cy = qy + b * bys;
-            const double fx = fo_phi_diff(erf_tab, (cx - a.off_x) * qisx, (cx + a.off_x) * qisx);
-            const double fy = fo_phi_diff(erf_tab, (cy - a.off_y) * qisy, (cy + a.off_y) * qisy);
-            acc += fx * fy;
+            const double fx = fo_erf_fast(erf_tab, (cx + a.off_x) * qisx) - fo_erf_fast(erf_tab, (cx - a.off_x) * qisx);
+            const double fy = fo_erf_fast(erf_tab, (cy + a.off_y) * qisy) - fo_erf_fast(erf_tab, (cy - a.off_y) * qisy);
+            acc = fma(fx, fy, acc);
           }
         }
-        cpw[ti * TILE + src] = acc / 3.0;
+        cpw[ti * TILE + src] = acc * (0.25 / 3.0);  // (1/2)(1/2) of the two Phi differences, /3 (:122)
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
 
     // ------------------------------------------------------------------ pass 1: DCE + gate -> queue
-    double dce = INFINITY;
+    // dce is kept in whole millimetres: rint(1000 d) orders exactly like np.round(d, 3) (dce.py:79); dce_m2 is the
+    // squared distance a sample has to undercut to be a new strict minimum, so the corner work and the square root
+    // are skipped (per wave / per lane) whenever a cheap lower bound already exceeds it.
+    double dce = INFINITY, dce_m2 = INFINITY;
     int tdce = 0;
-    bool done = false;
     unsigned gmask = 0u;
     int qn = 0;
+    // Iteration t evaluates DCE(t) and the gate of sample t-1 (ego t, agent mean t-1, agent heading t: Q1), so every
+    // operand it touches was requested one full iteration earlier: the ego row t+1 (vector loads) and the agent row
+    // t+1 (scalar loads) are issued at the top and first used at the top of the next iteration.
+    double nx_ = tj[0 * TILE], ny_ = tj[1 * TILE], nc_ = tj[2 * TILE], ns_ = tj[3 * TILE];
+    double npx = G[0], npy = G[1], npc = G[2], nps = G[3];
+    double ppx = 0.0, ppy = 0.0;  // agent mean of the previous sample
     for (int t = 0; t < T; ++t) {
-      const double *e0 = tj + (size_t)t * NEF * TILE;
-      const double *e1 = tj + (size_t)min(t + 1, T - 1) * NEF * TILE;
-      const double ex = e0[0 * TILE], ey = e0[1 * TILE], ec = e0[2 * TILE], es = e0[3 * TILE];
-      const double ex1 = e1[0 * TILE], ey1 = e1[1 * TILE];
-      const double *g = G + (size_t)min(t, L - 1) * NAF;
-      const double px = g[0], py = g[1], pc = g[2], ps = g[3];
-      if (do_dce && t < L && !(a.ablate & 1)) {
+      const double ex = nx_, ey = ny_, ec = nc_, es = ns_;
+      const double px = npx, py = npy, pc = npc, ps = nps;
+      {
+        const double *e1 = tj + (size_t)min(t + 1, T - 1) * NEF * TILE;
+        nx_ = e1[0 * TILE]; ny_ = e1[1 * TILE]; nc_ = e1[2 * TILE]; ns_ = e1[3 * TILE];
+        const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
+        npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3];
+      }
+      if (do_dce && t < L && !(a.ablate & 1)) {  // dce == 0: the reference stops scanning (dce.py:85-88)
         const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
         const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
         const double dx = px - ccx, dy = py - ccy;
-        const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;
+        const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;   // agent centre in the ego frame
         const double ux = hlB * cr, uy = hlB * sr, wx = -hwB * sr, wy = hwB * cr;
-        const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);
-        const double vx = a.hlA * cr, vy = -a.hlA * sr, zx = a.hwA * sr, zy = a.hwA * cr;
-        const bool sep = (fabs(ax) > a.hlA + fabs(ux) + fabs(wx)) || (fabs(ay) > a.hwA + fabs(uy) + fabs(wy)) ||
-                         (fabs(bx) > hlB + fabs(vx) + fabs(zx)) || (fabs(by) > hwB + fabs(vy) + fabs(zy));
-        double d2 = 0.0;
-        if (sep) {
-          d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, a.hlA, a.hwA);
-          d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, a.hlA, a.hwA));
-          d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, a.hlA, a.hwA));
-          d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, a.hlA, a.hwA));
+        const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);  // ego centre in the agent frame
+        const double vx = hlA * cr, vy = -hlA * sr, zx = hwA * sr, zy = hwA * cr;
+        // separations along the four face normals: each is a lower bound of the distance, all <= 0 iff overlapping
+        const double s1 = fabs(ax) - (hlA + fabs(ux) + fabs(wx)), s2 = fabs(ay) - (hwA + fabs(uy) + fabs(wy));
+        const double s3 = fabs(bx) - (hlB + fabs(vx) + fabs(zx)), s4 = fabs(by) - (hwB + fabs(vy) + fabs(zy));
+        const double lb = fmax(fmax(s1, s2), fmax(s3, s4));
+        const bool live = dce != 0.0;
+        if (live && !(lb > 0.0)) {  // overlapping rectangles: distance 0, the scan ends here
+          dce = 0.0; dce_m2 = 0.0; tdce = t;
+        }
+        const bool need = live && lb > 0.0 && lb * lb < dce_m2;
+        if (__ballot(need)) {  // wave-uniform: no lane can reach a new minimum -> the corner work is skipped
+          double d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, hlA, hwA);
+          d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, hlA, hwA));
+          d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, hlA, hwA));
+          d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, hlA, hwA));
           d2 = fmin(d2, fo_pt_box2(bx + vx + zx, by + vy + zy, hlB, hwB));
           d2 = fmin(d2, fo_pt_box2(bx + vx - zx, by + vy - zy, hlB, hwB));
           d2 = fmin(d2, fo_pt_box2(bx - vx + zx, by - vy + zy, hlB, hwB));
           d2 = fmin(d2, fo_pt_box2(bx - vx - zx, by - vy - zy, hlB, hwB));
+          if (need && d2 < dce_m2) {
+            const double nmm = __builtin_rint(fo_sqrt(d2) * 1000.0);
+            if (nmm < dce) { dce = nmm; tdce = t; dce_m2 = (nmm * 1e-3) * (nmm * 1e-3); }
+          }
         }
-        // distance in whole millimetres: rint(1000 d) orders exactly like np.round(d, 3) (dce.py:79); the division
-        // by 1000 is done once per pair after the loop
-        const double nmm = __builtin_rint(sqrt(d2) * 1000.0);
-        if (!done && nmm < dce) { dce = nmm; tdce = t; }
-        if (dce == 0.0) done = true;
       }
-      if (do_cp && t < Tm1 && t + 1 < L && !(a.ablate & 2)) {
-        // gate (collision_probability.py:44-67,75): ego sample t+1, agent mean t, agent heading t+1
-        const double pc1 = g[NAF + 2], ps1 = g[NAF + 3];
-        const double devx = pc1 * hdev, devy = ps1 * hdev;
-        const double rx = ex1 - px, ry = ey1 - py;
+      if (do_cp && t >= 1 && t < L && !(a.ablate & 2)) {
+        // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
+        const double devx = pc * hdev, devy = ps * hdev;
+        const double rx = ex - ppx, ry = ey - ppy;
         const double d0 = rx * rx + ry * ry;
         const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
         const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
@@ -620,8 +685,8 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
         if (bal) {
           const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
           if (ing) {
-            q[pos] = (unsigned short)(lane | (t << 6));
-            gmask |= 1u << t;
+            q[pos] = (unsigned short)(lane | ((t - 1) << 6));
+            gmask |= 1u << (t - 1);
           }
           qn += __popcll(bal);
           if (qn >= 64) {
@@ -635,6 +700,7 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
           }
         }
       }
+      ppx = px; ppy = py;
     }
     if (qn > 0) process(qn);
 
@@ -643,29 +709,47 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
     double oh_at_cp = 0.0;
     int idx_or = 0, idx_cp = 0;
     if (do_cp || do_hr) {
+      const size_t ls = (size_t)A * Tm1 * M;
+      double *lp = LISTS ? a.lists + (size_t)k * Tm1 * M + m : nullptr;
+      const double c4 = -a.hc.lr4s_const, s4c = -a.hc.lr4s_speed, c1 = -a.hc.lr1s_const, s1c = -a.hc.lr1s_speed;
+      // Ego samples are fetched two iterations ahead: on gfx9-family hardware vmcnt retires vector memory operations
+      // in issue order, loads and stores alike, so a load issued after the list stores of the previous iteration
+      // would not return before those stores are acknowledged.  With the loads of t+2 in flight before the stores of
+      // t, the wait at t+2 only covers stores that are two iterations old.
+      const bool lr4s = prot == 1;
+      const double *e_ = tj;
+      double ec0 = e_[2 * TILE], es0 = e_[3 * TILE], ev0 = e_[5 * TILE];
+      double ex0 = 0.0, ey0 = 0.0, eth0 = 0.0, ex1 = 0.0, ey1 = 0.0, eth1 = 0.0;
+      if (lr4s) { ex0 = e_[0 * TILE]; ey0 = e_[1 * TILE]; eth0 = e_[4 * TILE]; }
+      e_ = tj + (size_t)min(1, T - 1) * NEF * TILE;
+      double ec1 = e_[2 * TILE], es1 = e_[3 * TILE], ev1 = e_[5 * TILE];
+      if (lr4s) { ex1 = e_[0 * TILE]; ey1 = e_[1 * TILE]; eth1 = e_[4 * TILE]; }
+      double gx1 = G[0], gy1 = G[1], gc1 = G[2], gs1 = G[3], gyaw1 = G[4], gv1 = G[5];  // agent row t (one ahead)
       for (int t = 0; t < Tm1; ++t) {
+        const double gx = gx1, gy = gy1, pc = gc1, ps = gs1, gyaw = gyaw1, pv = gv1;
+        {
+          const cdp_t gn = G + (size_t)min(t + 1, L - 1) * NAF;
+          gx1 = gn[0]; gy1 = gn[1]; gc1 = gn[2]; gs1 = gn[3]; gyaw1 = gn[4]; gv1 = gn[5];
+        }
+        e_ = tj + (size_t)min(t + 2, T - 1) * NEF * TILE;
+        const double ec2 = e_[2 * TILE], es2 = e_[3 * TILE], ev2 = e_[5 * TILE];
+        double ex2 = 0.0, ey2 = 0.0, eth2 = 0.0;
+        if (lr4s) { ex2 = e_[0 * TILE]; ey2 = e_[1 * TILE]; eth2 = e_[4 * TILE]; }
         const double cpv = cpw[t * TILE + lane];
         const double cp = ((gmask >> t) & 1u) ? cpv : 0.0;
         double eh = NAN, oh = NAN, er = NAN, orr = NAN;
         if (do_hr && t < Lh && !(a.ablate & 4)) {
-          const double *e0 = tj + (size_t)t * NEF * TILE;
-          const double ec = e0[2 * TILE], es = e0[3 * TILE], ev = e0[5 * TILE];
-          const double *g = G + (size_t)t * NAF;
-          const double pc = g[2], ps = g[3], pv = g[5];
-          const double cr = pc * ec + ps * es;
-          const double dv = sqrt(fmax(ev * ev + pv * pv - 2.0 * ev * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
+          const double cr = pc * ec0 + ps * es0;
+          const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
           const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
-          if (prot == 1) {
-            const double ex = e0[0 * TILE], ey = e0[1 * TILE], eth = e0[4 * TILE];
-            const double rel = atan2(g[1] - ey, g[0] - ex);  // the impact angles only enter the LR4S model
-            const double ego_ang = rel - eth;
-            const double obs_ang = M_PI + rel - g[4];
-            eh = fo_logistic_neg(exp_tab, -a.hc.lr4s_const - a.hc.lr4s_speed * ego_dv -
-                                              fo_lr4s_coef(ego_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
-            oh = fo_logistic_neg(exp_tab, -a.hc.lr4s_const - a.hc.lr4s_speed * obs_dv -
-                                              fo_lr4s_coef(obs_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
+          if (lr4s) {
+            const double rel = atan2(gy - ey0, gx - ex0);  // the impact angles only enter the LR4S model
+            const double ego_ang = rel - eth0;
+            const double obs_ang = M_PI + rel - gyaw;
+            eh = fo_logistic_neg(exp_tab, c4 + s4c * ego_dv - fo_lr4s_coef(ego_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
+            oh = fo_logistic_neg(exp_tab, c4 + s4c * obs_dv - fo_lr4s_coef(obs_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
           } else if (prot == 0) {
-            eh = fo_logistic_neg(exp_tab, -a.hc.lr1s_const - a.hc.lr1s_speed * ego_dv);
+            eh = fo_logistic_neg(exp_tab, c1 + s1c * ego_dv);
             oh = fo_logistic_neg(exp_tab, a.hc.ped_const - a.hc.ped_speed * obs_dv);
           } else {
             eh = 1.0;
@@ -680,14 +764,15 @@ __global__ __launch_bounds__(TILE *WAVES, 2) void fo_sweep_queue_kernel(const Sw
         }
         if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
         if (LISTS && valid) {
-          double *l = a.lists + ((size_t)k * Tm1 + t) * M + m;
-          const size_t ls = (size_t)A * Tm1 * M;
-          __builtin_nontemporal_store(cp, l + FO_L_CP * ls);
-          __builtin_nontemporal_store(eh, l + FO_L_EGO_HARM * ls);
-          __builtin_nontemporal_store(oh, l + FO_L_OBST_HARM * ls);
-          __builtin_nontemporal_store(er, l + FO_L_EGO_RISK * ls);
-          __builtin_nontemporal_store(orr, l + FO_L_OBST_RISK * ls);
+          __builtin_nontemporal_store(cp, lp + FO_L_CP * ls);
+          __builtin_nontemporal_store(eh, lp + FO_L_EGO_HARM * ls);
+          __builtin_nontemporal_store(oh, lp + FO_L_OBST_HARM * ls);
+          __builtin_nontemporal_store(er, lp + FO_L_EGO_RISK * ls);
+          __builtin_nontemporal_store(orr, lp + FO_L_OBST_RISK * ls);
+          lp += M;
         }
+        ec0 = ec1; es0 = es1; ev0 = ev1; ex0 = ex1; ey0 = ey1; eth0 = eth1;
+        ec1 = ec2; es1 = es2; ev1 = ev2; ex1 = ex2; ey1 = ey2; eth1 = eth2;
       }
     }
 
@@ -910,7 +995,8 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     FO_HIP_TRY(ctx, hipMemsetAsync(d_lists, 0xFF, sizeof(double) * FO_NL * (size_t)A * (T - 1) * M, s));
   const int Mp = round_up(M, TILE);
   const int n_tiles = Mp / TILE;
-  const int apw = pick_apw(n_tiles, A);
+  int apw = pick_apw(n_tiles, A);
+  if (const char *e = getenv("FO_SWEEP_APW")) { const int v = atoi(e); if (v >= 1 && v <= 64) apw = v; }  // tuning aid
   const int n_chunks = A > 0 ? (A + WAVES * apw - 1) / (WAVES * apw) : 0;
   int rc;
   if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)T * NEF * Mp))) return rc;

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfo_hip.so")
+LIB_PATH = os.environ.get("FO_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libfo_hip.so")  # env: tuning builds
 
 FO_OK, FO_E_ARG, FO_E_UNSUPPORTED_COV, FO_E_HIP, FO_E_NOMEM, FO_E_STATE = 0, -1, -2, -3, -4, -5
 NPF, NPI, NL, NC = 12, 4, 5, 16

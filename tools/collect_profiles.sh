@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): kernel-trace stats + PMC passes of the bench command.
+# usage: tools/collect_profiles.sh <tag> [bench args...]     -> gpurun_out/<tag>_{stats,pmcN}/...
+# PMC passes are separate runs (rocprofv3 refuses nothing here: --pmc only with --kernel-trace).
+set -u
+TAG=$1; shift
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+           "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/${TAG}_pmc$i -o run -- python3 bench.py $ARGS > $OUT/${TAG}_pmc$i.log 2>&1
+done
+ls -R $OUT | grep -c csv
