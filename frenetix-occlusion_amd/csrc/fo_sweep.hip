@@ -68,6 +68,37 @@ __device__ __forceinline__ double fo_erf_fast(const double2 *__restrict__ tab, d
   return copysign(fma(e.y * d, p, e.x), u);
 }
 
+// four erf evaluations with the four LDS gathers issued back to back (one lgkmcnt wait instead of four)
+__device__ __forceinline__ void fo_erf_fast4(const double2 *__restrict__ tab, double u0, double u1, double u2, double u3,
+                                             double *out) {
+  const double MAGIC = 6755399441055744.0;
+  const double u[4] = {u0, u1, u2, u3};
+  double au[4], tm[4];
+  double2 e[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    au[i] = fmin(fabs(u[i]), 6.0);
+    tm[i] = fma(au[i], ERF_SCALE, MAGIC);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = tab[__double2loint(tm[i])];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double fi = tm[i] - MAGIC;
+    const double d = fma(fi, -1.0 / ERF_SCALE, au[i]);
+    const double y = (fi * (1.0 / ERF_SCALE)) * d;
+    const double sq = d * d;
+    const double a0 = fma(sq, fma(sq, 0.1, -1.0 / 3.0), 1.0);
+    const double a1 = fma(sq, 0.5, -1.0);
+    const double a2 = fma(sq, -0.4, 2.0 / 3.0);
+    double p = fma(y, 2.0 / 15.0, -1.0 / 3.0);
+    p = fma(p, y, a2);
+    p = fma(p, y, a1);
+    p = fma(p, y, a0);
+    out[i] = copysign(fma(e[i].y * d, p, e[i].x), u[i]);
+  }
+}
+
 __global__ void fo_exp_table_kernel(double *tab) {
   if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x / 64.0);
 }
@@ -490,30 +521,39 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 //   pass 2 (t loop)  harm + risk + running maxima + coalesced list stores, cp read back from cpbuf.
 // exp() for the logistic models is a 64-entry 2^(j/64) table + degree-5 polynomial (~15 VALU ops).
 // Supports T-1 <= TQ; longer horizons take the generic kernel.
-#ifndef FO_TQ
-#define FO_TQ 30
+#ifndef FO_TC
+#define FO_TC 16     // timesteps per chunk of the two-pass scheme (rows of the per-wave cp buffer)
+#endif
+#ifndef FO_QWAVES
+#define FO_QWAVES 4  // waves per workgroup of the queue kernel (45 KB of LDS -> three workgroups per CU)
 #endif
 #ifndef FO_MINW
-#define FO_MINW 2
+#define FO_MINW 3    // waves per SIMD the register allocation has to allow (<= 168 VGPRs)
 #endif
-constexpr int TQ = FO_TQ;
+constexpr int TC = FO_TC;
+constexpr int QWAVES = FO_QWAVES;
 constexpr int QCAP = 128;
 
+// exp(z) = 2^(k/64) * e^r, k = rint(64 z / ln 2), |r| <= ln2/128: 64-entry table of 2^(j/64) in LDS and a degree-4
+// polynomial (remainder r^5/120 < 4e-14 relative).  Few distinct float64 constants on purpose: every one of them
+// occupies an SGPR pair for the whole loop, and the kernel is short of SGPRs, not of LDS bandwidth.
 __device__ __forceinline__ double fo_exp_tab(const double *__restrict__ tab2, double z) {
   z = fmin(fmax(z, -700.0), 700.0);
-  const double kf = __builtin_rint(z * 92.33248261689366);        // 64 / ln 2
-  double r = fma(-kf, 0.01083042469326756, z);                    // ln2/64 hi (32 significant bits)
-  r = fma(-kf, 2.9815858269852933e-12, r);                        // ln2/64 lo
-  const int k = (int)kf;
-  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
+  const double MAGIC = 6755399441055744.0;                          // 1.5 * 2^52
+  const double tm = fma(z, 92.33248261689366, MAGIC);               // 64 / ln 2
+  const double kf = tm - MAGIC;
+  const int k = __double2loint(tm);
+  double r = fma(kf, -0.01083042469326756, z);                      // ln2/64 hi (32 significant bits)
+  r = fma(kf, -2.9815858269852933e-12, r);                          // ln2/64 lo
+  const double tv = tab2[k & 63];
+  double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(tab2[k & 63] * p, k >> 6);
+  return ldexp(tv * p, k >> 6);
 }
 
-// 1 / (1 + exp(nz))
+// 1 / (1 + exp(nz)); v_rcp_f64 (~2^-23 relative, ISA) + two Newton steps
 __device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab2, double nz) {
   const double d = 1.0 + fo_exp_tab(tab2, nz);
   double y = __builtin_amdgcn_rcp(d);
@@ -531,12 +571,14 @@ __device__ __forceinline__ cdp_t fo_const(const double *p) { return (cdp_t)(unsi
 __device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(unsigned long long)p; }
 
 template <bool PAIR, bool LISTS>
-__global__ __launch_bounds__(TILE *WAVES, FO_MINW) void fo_sweep_queue_kernel(const SweepArgs a) {
+__global__ __launch_bounds__(TILE *QWAVES) __attribute__((amdgpu_waves_per_eu(FO_MINW, FO_MINW)))
+void fo_sweep_queue_kernel(const SweepArgs a) {
   __shared__ double2 erf_tab[ERF_N];
   __shared__ double exp_tab[64];
-  __shared__ double cpbuf_all[WAVES * TQ * TILE];  // also the cross-wave reduction scratch at the end
-  __shared__ unsigned short queue_all[WAVES * QCAP];
-  for (int i = threadIdx.x; i < ERF_N; i += TILE * WAVES) erf_tab[i] = a.erf_tab[i];
+  __shared__ double cpbuf_all[QWAVES * TC * TILE];  // also the cross-wave reduction scratch at the end
+  __shared__ unsigned short queue_all[QWAVES * QCAP];
+  static_assert(QWAVES * TC >= (QWAVES - 1) * NPS, "reduction scratch must fit into the cp buffers");
+  for (int i = threadIdx.x; i < ERF_N; i += TILE * QWAVES) erf_tab[i] = a.erf_tab[i];
   if (threadIdx.x < 64) exp_tab[threadIdx.x] = a.exp_tab[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -550,7 +592,7 @@ __global__ __launch_bounds__(TILE *WAVES, FO_MINW) void fo_sweep_queue_kernel(co
   const int T = a.T, Tm1 = a.T - 1, M = a.M, A = a.A;
   const double *tjb = a.traj + (size_t)tile * T * NEF * TILE;  // uniform tile base
   const double *tj = tjb + lane;
-  double *cpw = cpbuf_all + wave * (TQ * TILE);
+  double *cpw = cpbuf_all + wave * (TC * TILE);
   unsigned short *q = queue_all + wave * QCAP;
   const bool do_dce = a.mask & FO_M_DCE, do_cp = a.mask & FO_M_CP, do_hr = a.mask & FO_M_HR;
   const bool do_ttc = a.mask & FO_M_TTC, do_ttce = a.mask & FO_M_TTCE;
@@ -560,7 +602,7 @@ __global__ __launch_bounds__(TILE *WAVES, FO_MINW) void fo_sweep_queue_kernel(co
   double w_max_er = 0.0, w_max_or = 0.0, w_max_eh = 0.0, w_max_oh = 0.0, w_max_cp = 0.0, w_max_hwc = 0.0;
   double w_arg_dce = -1.0, w_arg_ttc = -1.0, w_arg_or = -1.0, w_dce_flag = 0.0;
 
-  const int k0 = (chunk * WAVES + wave) * a.apw;
+  const int k0 = (chunk * QWAVES + wave) * a.apw;
   for (int kk = 0; kk < a.apw; ++kk) {
     const int k = k0 + kk;
     if (k >= A) break;
@@ -584,195 +626,222 @@ __global__ __launch_bounds__(TILE *WAVES, FO_MINW) void fo_sweep_queue_kernel(co
       continue;
     }
 
-    // evaluates n (<= 64) queued in-gate samples, one per lane (collision_probability.py:77-122)
-    auto process = [&](int n) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (lane < n) {
-        const int item = q[lane];
-        const int src = item & 63, ti = item >> 6;
-        const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + src;  // ego sample ti+1 of trajectory `src`
-        const double qex = e[0 * TILE], qey = e[1 * TILE], qec = e[2 * TILE], qes = e[3 * TILE];
-        const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti (per lane)
-        const double qpx = g0[0], qpy = g0[1], qisx = g0[6], qisy = g0[7];
-        const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
-        const double devx = qc1 * hdev, devy = qs1 * hdev;
-        const double rx = qex - qpx, ry = qey - qpy;
-        const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
-        double acc = 0.0;
-#pragma unroll
-        for (int jm = -1; jm <= 1; ++jm) {
-          const double qx = rx - jm * devx, qy = ry - jm * devy;
-#pragma unroll
-          for (int b = -1; b <= 1; ++b) {
-            const double cx = qx + b * bxs, cy = qy + b * bys;
-            const double fx = fo_erf_fast(erf_tab, (cx + a.off_x) * qisx) - fo_erf_fast(erf_tab, (cx - a.off_x) * qisx);
-            const double fy = fo_erf_fast(erf_tab, (cy + a.off_y) * qisy) - fo_erf_fast(erf_tab, (cy - a.off_y) * qisy);
-            acc = fma(fx, fy, acc);
-          }
-        }
-        cpw[ti * TILE + src] = acc * (0.25 / 3.0);  // (1/2)(1/2) of the two Phi differences, /3 (:122)
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-
-    // ------------------------------------------------------------------ pass 1: DCE + gate -> queue
-    // dce is kept in whole millimetres: rint(1000 d) orders exactly like np.round(d, 3) (dce.py:79); dce_m2 is the
-    // squared distance a sample has to undercut to be a new strict minimum, so the corner work and the square root
-    // are skipped (per wave / per lane) whenever a cheap lower bound already exceeds it.
+    // Per-agent state that lives across the time chunks.  dce is kept in whole millimetres: rint(1000 d) orders
+    // exactly like np.round(d, 3) (dce.py:79); dce_m2 is the squared distance a sample has to undercut to become a
+    // new strict minimum, so the corner work and the square root are skipped whenever a cheap lower bound exceeds it.
     double dce = INFINITY, dce_m2 = INFINITY;
     int tdce = 0;
-    unsigned gmask = 0u;
-    int qn = 0;
-    // Iteration t evaluates DCE(t) and the gate of sample t-1 (ego t, agent mean t-1, agent heading t: Q1), so every
-    // operand it touches was requested one full iteration earlier: the ego row t+1 (vector loads) and the agent row
-    // t+1 (scalar loads) are issued at the top and first used at the top of the next iteration.
-    double nx_ = tj[0 * TILE], ny_ = tj[1 * TILE], nc_ = tj[2 * TILE], ns_ = tj[3 * TILE];
-    double npx = G[0], npy = G[1], npc = G[2], nps = G[3];
-    double ppx = 0.0, ppy = 0.0;  // agent mean of the previous sample
-    for (int t = 0; t < T; ++t) {
-      const double ex = nx_, ey = ny_, ec = nc_, es = ns_;
-      const double px = npx, py = npy, pc = npc, ps = nps;
-      {
-        const double *e1 = tj + (size_t)min(t + 1, T - 1) * NEF * TILE;
-        nx_ = e1[0 * TILE]; ny_ = e1[1 * TILE]; nc_ = e1[2 * TILE]; ns_ = e1[3 * TILE];
-        const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
-        npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3];
-      }
-      if (do_dce && t < L && !(a.ablate & 1)) {  // dce == 0: the reference stops scanning (dce.py:85-88)
-        const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
-        const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
-        const double dx = px - ccx, dy = py - ccy;
-        const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;   // agent centre in the ego frame
-        const double ux = hlB * cr, uy = hlB * sr, wx = -hwB * sr, wy = hwB * cr;
-        const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);  // ego centre in the agent frame
-        const double vx = hlA * cr, vy = -hlA * sr, zx = hwA * sr, zy = hwA * cr;
-        // separations along the four face normals: each is a lower bound of the distance, all <= 0 iff overlapping
-        const double s1 = fabs(ax) - (hlA + fabs(ux) + fabs(wx)), s2 = fabs(ay) - (hwA + fabs(uy) + fabs(wy));
-        const double s3 = fabs(bx) - (hlB + fabs(vx) + fabs(zx)), s4 = fabs(by) - (hwB + fabs(vy) + fabs(zy));
-        const double lb = fmax(fmax(s1, s2), fmax(s3, s4));
-        const bool live = dce != 0.0;
-        if (live && !(lb > 0.0)) {  // overlapping rectangles: distance 0, the scan ends here
-          dce = 0.0; dce_m2 = 0.0; tdce = t;
-        }
-        const bool need = live && lb > 0.0 && lb * lb < dce_m2;
-        if (__ballot(need)) {  // wave-uniform: no lane can reach a new minimum -> the corner work is skipped
-          double d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, hlA, hwA);
-          d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, hlA, hwA));
-          d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, hlA, hwA));
-          d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, hlA, hwA));
-          d2 = fmin(d2, fo_pt_box2(bx + vx + zx, by + vy + zy, hlB, hwB));
-          d2 = fmin(d2, fo_pt_box2(bx + vx - zx, by + vy - zy, hlB, hwB));
-          d2 = fmin(d2, fo_pt_box2(bx - vx + zx, by - vy + zy, hlB, hwB));
-          d2 = fmin(d2, fo_pt_box2(bx - vx - zx, by - vy - zy, hlB, hwB));
-          if (need && d2 < dce_m2) {
-            const double nmm = __builtin_rint(fo_sqrt(d2) * 1000.0);
-            if (nmm < dce) { dce = nmm; tdce = t; dce_m2 = (nmm * 1e-3) * (nmm * 1e-3); }
-          }
-        }
-      }
-      if (do_cp && t >= 1 && t < L && !(a.ablate & 2)) {
-        // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
-        const double devx = pc * hdev, devy = ps * hdev;
-        const double rx = ex - ppx, ry = ey - ppy;
-        const double d0 = rx * rx + ry * ry;
-        const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
-        const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
-        const double m2 = fmin(d0, fmin(dp, dm));
-        bool ing = m2 <= 25.0;
-        if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);  // keep the reference's test on the rounded sqrt
-        ing = ing && valid;
-        const unsigned long long bal = __ballot(ing);
-        if (bal) {
-          const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (ing) {
-            q[pos] = (unsigned short)(lane | ((t - 1) << 6));
-            gmask |= 1u << (t - 1);
-          }
-          qn += __popcll(bal);
-          if (qn >= 64) {
-            process(64);
-            const int rest = qn - 64;
-            unsigned short tmp = 0;
-            if (lane < rest) tmp = q[64 + lane];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (lane < rest) q[lane] = tmp;
-            qn = rest;
-          }
-        }
-      }
-      ppx = px; ppy = py;
-    }
-    if (qn > 0) process(qn);
-
-    // ------------------------------------------------------------------ pass 2: harm, risk, maxima, lists
     double max_er = -INFINITY, max_or = -INFINITY, max_eh = -INFINITY, max_oh = -INFINITY, max_cp = -INFINITY;
     double oh_at_cp = 0.0;
     int idx_or = 0, idx_cp = 0;
-    if (do_cp || do_hr) {
-      const size_t ls = (size_t)A * Tm1 * M;
-      double *lp = LISTS ? a.lists + (size_t)k * Tm1 * M + m : nullptr;
-      const double c4 = -a.hc.lr4s_const, s4c = -a.hc.lr4s_speed, c1 = -a.hc.lr1s_const, s1c = -a.hc.lr1s_speed;
-      // Ego samples are fetched two iterations ahead: on gfx9-family hardware vmcnt retires vector memory operations
-      // in issue order, loads and stores alike, so a load issued after the list stores of the previous iteration
-      // would not return before those stores are acknowledged.  With the loads of t+2 in flight before the stores of
-      // t, the wait at t+2 only covers stores that are two iterations old.
-      const bool lr4s = prot == 1;
-      const double *e_ = tj;
-      double ec0 = e_[2 * TILE], es0 = e_[3 * TILE], ev0 = e_[5 * TILE];
-      double ex0 = 0.0, ey0 = 0.0, eth0 = 0.0, ex1 = 0.0, ey1 = 0.0, eth1 = 0.0;
-      if (lr4s) { ex0 = e_[0 * TILE]; ey0 = e_[1 * TILE]; eth0 = e_[4 * TILE]; }
-      e_ = tj + (size_t)min(1, T - 1) * NEF * TILE;
-      double ec1 = e_[2 * TILE], es1 = e_[3 * TILE], ev1 = e_[5 * TILE];
-      if (lr4s) { ex1 = e_[0 * TILE]; ey1 = e_[1 * TILE]; eth1 = e_[4 * TILE]; }
-      double gx1 = G[0], gy1 = G[1], gc1 = G[2], gs1 = G[3], gyaw1 = G[4], gv1 = G[5];  // agent row t (one ahead)
-      for (int t = 0; t < Tm1; ++t) {
-        const double gx = gx1, gy = gy1, pc = gc1, ps = gs1, gyaw = gyaw1, pv = gv1;
-        {
-          const cdp_t gn = G + (size_t)min(t + 1, L - 1) * NAF;
-          gx1 = gn[0]; gy1 = gn[1]; gc1 = gn[2]; gs1 = gn[3]; gyaw1 = gn[4]; gv1 = gn[5];
-        }
-        e_ = tj + (size_t)min(t + 2, T - 1) * NEF * TILE;
-        const double ec2 = e_[2 * TILE], es2 = e_[3 * TILE], ev2 = e_[5 * TILE];
-        double ex2 = 0.0, ey2 = 0.0, eth2 = 0.0;
-        if (lr4s) { ex2 = e_[0 * TILE]; ey2 = e_[1 * TILE]; eth2 = e_[4 * TILE]; }
-        const double cpv = cpw[t * TILE + lane];
-        const double cp = ((gmask >> t) & 1u) ? cpv : 0.0;
-        double eh = NAN, oh = NAN, er = NAN, orr = NAN;
-        if (do_hr && t < Lh && !(a.ablate & 4)) {
-          const double cr = pc * ec0 + ps * es0;
-          const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
-          const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
-          if (lr4s) {
-            const double rel = atan2(gy - ey0, gx - ex0);  // the impact angles only enter the LR4S model
-            const double ego_ang = rel - eth0;
-            const double obs_ang = M_PI + rel - gyaw;
-            eh = fo_logistic_neg(exp_tab, c4 + s4c * ego_dv - fo_lr4s_coef(ego_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
-            oh = fo_logistic_neg(exp_tab, c4 + s4c * obs_dv - fo_lr4s_coef(obs_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
-          } else if (prot == 0) {
-            eh = fo_logistic_neg(exp_tab, c1 + s1c * ego_dv);
-            oh = fo_logistic_neg(exp_tab, a.hc.ped_const - a.hc.ped_speed * obs_dv);
-          } else {
-            eh = 1.0;
-            oh = 1.0;
+    const size_t ls = (size_t)A * Tm1 * M;
+    double *lp = LISTS ? a.lists + (size_t)k * Tm1 * M + m : nullptr;
+    const double c4 = -a.hc.lr4s_const, s4c = -a.hc.lr4s_speed, c1 = -a.hc.lr1s_const, s1c = -a.hc.lr1s_speed;
+    const bool lr4s = prot == 1;
+
+    // The horizon is walked in chunks of TC iterations.  Iteration t evaluates DCE(t) and the gate of sample t-1
+    // (ego t, agent mean t-1, agent heading t: Q1), so chunk [t0, t1) owns the gate samples [t0-1, t1-1); their
+    // collision probabilities go to row (g - t0 + 1) of the wave's cp buffer, and pass 2 of the chunk (harm, risk,
+    // maxima, lists) consumes them before the next chunk overwrites the rows.
+    for (int t0 = 0; t0 < T; t0 += TC) {
+      const int t1 = min(t0 + TC, T);
+      const int gbase = t0 - 1;  // gate sample of buffer row 0
+
+      // evaluates n (<= 64) queued in-gate samples, one per lane (collision_probability.py:77-122)
+      auto process = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < n) {
+          const int item = q[lane];
+          const int src = item & 63, row = item >> 6, ti = gbase + row;
+          const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + src;  // ego sample ti+1 of trajectory `src`
+          const double qex = e[0 * TILE], qey = e[1 * TILE], qec = e[2 * TILE], qes = e[3 * TILE];
+          const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti
+          const double qpx = g0[0], qpy = g0[1], qisx = g0[6], qisy = g0[7];
+          const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
+          const double devx = qc1 * hdev, devy = qs1 * hdev;
+          const double rx = qex - qpx, ry = qey - qpy;
+          const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
+          double acc = 0.0;
+#pragma unroll 1
+          for (int jm = -1; jm <= 1; ++jm) {
+            const double qx = rx - jm * devx, qy = ry - jm * devy;
+#pragma unroll 1
+            for (int b = -1; b <= 1; ++b) {
+              const double cx = qx + b * bxs, cy = qy + b * bys;
+              double e4[4];  // the four table gathers of one box are issued together, then evaluated
+              fo_erf_fast4(erf_tab, (cx + a.off_x) * qisx, (cx - a.off_x) * qisx, (cy + a.off_y) * qisy,
+                           (cy - a.off_y) * qisy, e4);
+              acc = fma(e4[0] - e4[1], e4[2] - e4[3], acc);
+            }
           }
-          er = eh * cp;
-          orr = oh * cp;
-          max_er = fmax(max_er, er);
-          if (orr > max_or) { max_or = orr; idx_or = t; }
-          max_eh = fmax(max_eh, eh);
-          max_oh = fmax(max_oh, oh);
+          cpw[row * TILE + src] = acc * (0.25 / 3.0);  // (1/2)(1/2) of the two Phi differences, /3 (:122)
         }
-        if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
-        if (LISTS && valid) {
-          __builtin_nontemporal_store(cp, lp + FO_L_CP * ls);
-          __builtin_nontemporal_store(eh, lp + FO_L_EGO_HARM * ls);
-          __builtin_nontemporal_store(oh, lp + FO_L_OBST_HARM * ls);
-          __builtin_nontemporal_store(er, lp + FO_L_EGO_RISK * ls);
-          __builtin_nontemporal_store(orr, lp + FO_L_OBST_RISK * ls);
-          lp += M;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      };
+
+      // ---------------------------------------------------------------- pass 1: DCE + gate -> queue
+      // Every operand of iteration t was requested one iteration earlier: the ego row t+1 (vector loads) and the
+      // agent row t+1 (scalar loads) are issued at the top and first used at the top of the next iteration.
+      unsigned gmask = 0u;  // bit row: gate sample gbase + row is inside the 5 m gate for this lane
+      int qn = 0;
+      const double *e0_ = tj + (size_t)t0 * NEF * TILE;
+      double nx_ = e0_[0 * TILE], ny_ = e0_[1 * TILE], nc_ = e0_[2 * TILE], ns_ = e0_[3 * TILE];
+      const cdp_t gr0 = G + (size_t)min(t0, L - 1) * NAF;
+      double npx = gr0[0], npy = gr0[1], npc = gr0[2], nps = gr0[3];
+      const cdp_t grp = G + (size_t)min(max(t0 - 1, 0), L - 1) * NAF;
+      double ppx = grp[0], ppy = grp[1];  // agent mean of the previous sample
+      // Scalar loads return out of order, so any use of an s_load result waits for lgkmcnt(0).  Pinning the per-agent
+      // constants and the first rows here (an empty asm that names them as SGPR inputs) drains the counter before the
+      // loop, which leaves the in-loop wait to cover only the row that was prefetched one iteration ago.
+      asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(f_ego), "s"(f_obs), "s"(npx),
+                   "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy));
+      for (int t = t0; t < t1; ++t) {
+        const double ex = nx_, ey = ny_, ec = nc_, es = ns_;
+        const double px = npx, py = npy, pc = npc, ps = nps;
+        {
+          const double *e1 = tj + (size_t)min(t + 1, T - 1) * NEF * TILE;
+          nx_ = e1[0 * TILE]; ny_ = e1[1 * TILE]; nc_ = e1[2 * TILE]; ns_ = e1[3 * TILE];
+          const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
+          npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3];
         }
-        ec0 = ec1; es0 = es1; ev0 = ev1; ex0 = ex1; ey0 = ey1; eth0 = eth1;
-        ec1 = ec2; es1 = es2; ev1 = ev2; ex1 = ex2; ey1 = ey2; eth1 = eth2;
+        if (do_dce && t < L && !(a.ablate & 1)) {  // dce == 0: the reference stops scanning (dce.py:85-88)
+          const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
+          const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
+          const double dx = px - ccx, dy = py - ccy;
+          const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;   // agent centre in the ego frame
+          const double ux = hlB * cr, uy = hlB * sr, wx = -hwB * sr, wy = hwB * cr;
+          const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);  // ego centre in the agent frame
+          const double vx = hlA * cr, vy = -hlA * sr, zx = hwA * sr, zy = hwA * cr;
+          // separations along the four face normals: each is a lower bound of the distance, all <= 0 iff overlapping
+          const double s1 = fabs(ax) - (hlA + fabs(ux) + fabs(wx)), s2 = fabs(ay) - (hwA + fabs(uy) + fabs(wy));
+          const double s3 = fabs(bx) - (hlB + fabs(vx) + fabs(zx)), s4 = fabs(by) - (hwB + fabs(vy) + fabs(zy));
+          const double lb = fmax(fmax(s1, s2), fmax(s3, s4));
+          const bool live = dce != 0.0;
+          if (live && !(lb > 0.0)) {  // overlapping rectangles: distance 0, the scan ends here
+            dce = 0.0; dce_m2 = 0.0; tdce = t;
+          }
+          const bool need = live && lb > 0.0 && lb * lb < dce_m2;
+          if (__ballot(need)) {  // wave-uniform: no lane can reach a new minimum -> the corner work is skipped
+            double d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, hlA, hwA);
+            d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, hlA, hwA));
+            d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, hlA, hwA));
+            d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, hlA, hwA));
+            d2 = fmin(d2, fo_pt_box2(bx + vx + zx, by + vy + zy, hlB, hwB));
+            d2 = fmin(d2, fo_pt_box2(bx + vx - zx, by + vy - zy, hlB, hwB));
+            d2 = fmin(d2, fo_pt_box2(bx - vx + zx, by - vy + zy, hlB, hwB));
+            d2 = fmin(d2, fo_pt_box2(bx - vx - zx, by - vy - zy, hlB, hwB));
+            if (need && d2 < dce_m2) {
+              const double nmm = __builtin_rint(fo_sqrt(d2) * 1000.0);
+              if (nmm < dce) { dce = nmm; tdce = t; dce_m2 = (nmm * 1e-3) * (nmm * 1e-3); }
+            }
+          }
+        }
+        if (do_cp && t >= 1 && t < L && !(a.ablate & 2)) {
+          // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
+          const double devx = pc * hdev, devy = ps * hdev;
+          const double rx = ex - ppx, ry = ey - ppy;
+          const double d0 = rx * rx + ry * ry;
+          const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
+          const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
+          const double m2 = fmin(d0, fmin(dp, dm));
+          bool ing = m2 <= 25.0;
+          if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);  // keep the reference's test on the rounded sqrt
+          ing = ing && valid;
+          const unsigned long long bal = __ballot(ing);
+          if (bal) {
+            const int row = t - t0;  // = (t - 1) - gbase
+            const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (ing) {
+              q[pos] = (unsigned short)(lane | (row << 6));
+              gmask |= 1u << row;
+            }
+            qn += __popcll(bal);
+            if (qn >= 64) {
+              process(64);
+              const int rest = qn - 64;
+              unsigned short tmp = 0;
+              if (lane < rest) tmp = q[64 + lane];
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              if (lane < rest) q[lane] = tmp;
+              qn = rest;
+            }
+          }
+        }
+        ppx = px; ppy = py;
+      }
+      if (qn > 0) process(qn);
+
+      // ---------------------------------------------------------------- pass 2: harm, risk, maxima, lists
+      // of the gate samples g in [max(t0-1, 0), t1-1) -- harm index g, cp index g (Q6)
+      const int g0s = max(gbase, 0), g1s = t1 - 1;
+      if ((do_cp || do_hr) && g0s < g1s) {
+        // Ego samples are fetched two iterations ahead: vmcnt retires vector memory operations in issue order, loads
+        // and stores alike, so a load issued after the list stores of the previous iteration would not return
+        // before those stores are acknowledged.
+        const double *e_ = tj + (size_t)g0s * NEF * TILE;
+        double ec0 = e_[2 * TILE], es0 = e_[3 * TILE], ev0 = e_[5 * TILE];
+        double ex0 = 0.0, ey0 = 0.0, eth0 = 0.0, ex1 = 0.0, ey1 = 0.0, eth1 = 0.0;
+        if (lr4s) { ex0 = e_[0 * TILE]; ey0 = e_[1 * TILE]; eth0 = e_[4 * TILE]; }
+        e_ = tj + (size_t)min(g0s + 1, T - 1) * NEF * TILE;
+        double ec1 = e_[2 * TILE], es1 = e_[3 * TILE], ev1 = e_[5 * TILE];
+        if (lr4s) { ex1 = e_[0 * TILE]; ey1 = e_[1 * TILE]; eth1 = e_[4 * TILE]; }
+        const cdp_t gq = G + (size_t)min(g0s, L - 1) * NAF;
+        double gx1 = gq[0], gy1 = gq[1], gc1 = gq[2], gs1 = gq[3], gyaw1 = gq[4], gv1 = gq[5];  // agent row (one ahead)
+        double cpv = cpw[(g0s - gbase) * TILE + lane];
+        asm volatile("; scalar operands resident" ::"s"(gx1), "s"(gy1), "s"(gc1), "s"(gs1), "s"(gyaw1), "s"(gv1),
+                     "v"(cpv), "s"(f_ego), "s"(f_obs));
+        for (int t = g0s; t < g1s; ++t) {
+          const double gx = gx1, gy = gy1, pc = gc1, ps = gs1, gyaw = gyaw1, pv = gv1;
+          const int row = t - gbase;
+          const double cp = ((gmask >> row) & 1u) ? cpv : 0.0;
+          // the only LDS read of the iteration (next cp) goes out together with the scalar prefetch of the next agent
+          // row; both are first touched at the top of the next iteration (LDS and SMEM share lgkmcnt)
+          cpv = cpw[min(row + 1, TC - 1) * TILE + lane];
+          {
+            const cdp_t gn = G + (size_t)min(t + 1, L - 1) * NAF;
+            gx1 = gn[0]; gy1 = gn[1]; gc1 = gn[2]; gs1 = gn[3]; gyaw1 = gn[4]; gv1 = gn[5];
+          }
+          e_ = tj + (size_t)min(t + 2, T - 1) * NEF * TILE;
+          const double ec2 = e_[2 * TILE], es2 = e_[3 * TILE], ev2 = e_[5 * TILE];
+          double ex2 = 0.0, ey2 = 0.0, eth2 = 0.0;
+          if (lr4s) { ex2 = e_[0 * TILE]; ey2 = e_[1 * TILE]; eth2 = e_[4 * TILE]; }
+          double eh = NAN, oh = NAN, er = NAN, orr = NAN;
+          if (do_hr && t < Lh && !(a.ablate & 4)) {
+            const double cr = pc * ec0 + ps * es0;
+            const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
+            const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
+            if (lr4s) {
+              const double rel = atan2(gy - ey0, gx - ex0);  // the impact angles only enter the LR4S model
+              const double ego_ang = rel - eth0;
+              const double obs_ang = M_PI + rel - gyaw;
+              eh = fo_logistic_neg(exp_tab, c4 + s4c * ego_dv - fo_lr4s_coef(ego_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
+              oh = fo_logistic_neg(exp_tab, c4 + s4c * obs_dv - fo_lr4s_coef(obs_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
+            } else if (prot == 0) {
+              eh = fo_logistic_neg(exp_tab, c1 + s1c * ego_dv);
+              oh = fo_logistic_neg(exp_tab, a.hc.ped_const - a.hc.ped_speed * obs_dv);
+            } else {
+              eh = 1.0;
+              oh = 1.0;
+            }
+            er = eh * cp;
+            orr = oh * cp;
+            max_er = fmax(max_er, er);
+            if (orr > max_or) { max_or = orr; idx_or = t; }
+            max_eh = fmax(max_eh, eh);
+            max_oh = fmax(max_oh, oh);
+          }
+          if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
+          if (LISTS && valid) {
+            __builtin_nontemporal_store(cp, lp + FO_L_CP * ls);
+            __builtin_nontemporal_store(eh, lp + FO_L_EGO_HARM * ls);
+            __builtin_nontemporal_store(oh, lp + FO_L_OBST_HARM * ls);
+            __builtin_nontemporal_store(er, lp + FO_L_EGO_RISK * ls);
+            __builtin_nontemporal_store(orr, lp + FO_L_OBST_RISK * ls);
+            lp += M;
+          }
+          ec0 = ec1; es0 = es1; ev0 = ev1; ex0 = ex1; ey0 = ey1; eth0 = eth1;
+          ec1 = ec2; es1 = es2; ev1 = ev2; ex1 = ex2; ey1 = ey2; eth1 = eth2;
+        }
       }
     }
 
@@ -819,7 +888,7 @@ __global__ __launch_bounds__(TILE *WAVES, FO_MINW) void fo_sweep_queue_kernel(co
     }
   }
 
-  // ---------------- combine the four waves (ascending agent order); scratch aliases the cp buffers
+  // ---------------- combine the waves of the workgroup (ascending agent order); scratch aliases the cp buffers
   __syncthreads();
   double *red = cpbuf_all;
   if (wave > 0) {
@@ -832,7 +901,7 @@ __global__ __launch_bounds__(TILE *WAVES, FO_MINW) void fo_sweep_queue_kernel(co
   }
   __syncthreads();
   if (wave == 0) {
-    for (int w = 0; w < WAVES - 1; ++w) {
+    for (int w = 0; w < QWAVES - 1; ++w) {
       const double *rp = red + (size_t)w * NPS * TILE + lane;
       if (rp[PS_MIN_DCE * TILE] < w_min_dce) { w_min_dce = rp[PS_MIN_DCE * TILE]; w_arg_dce = rp[PS_ARG_DCE * TILE]; }
       if (rp[PS_MIN_TTC * TILE] < w_min_ttc) { w_min_ttc = rp[PS_MIN_TTC * TILE]; w_arg_ttc = rp[PS_ARG_TTC * TILE]; }
@@ -904,9 +973,9 @@ uint32_t required_metrics(uint32_t m) {  // metric.py:125-147
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
 // agents per wave: enough workgroups to fill 256 CUs several times over, but no more partial rows than needed
-int pick_apw(int n_tiles, int A) {
+int pick_apw(int n_tiles, int A, int wpb) {
   int apw = 8;
-  while (apw > 1 && (long)n_tiles * ((A + WAVES * apw - 1) / (WAVES * apw)) < 2048) apw >>= 1;
+  while (apw > 1 && (long)n_tiles * ((A + wpb * apw - 1) / (wpb * apw)) * wpb < 8192) apw >>= 1;
   return apw;
 }
 
@@ -943,7 +1012,7 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
   int rc;
   if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)max_T * NEF * Mp))) return rc;
   // worst case number of chunks: one agent per wave
-  const size_t chunks = (size_t)(max_A + WAVES - 1) / WAVES + 1;
+  const size_t chunks = (size_t)(max_A + WAVES - 1) / WAVES + 1;  // WAVES <= QWAVES: the larger count
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, chunks * NPS * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) * NAF))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(max_A > 0 ? max_A : 1) * NAC))) return rc;
@@ -995,9 +1064,12 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     FO_HIP_TRY(ctx, hipMemsetAsync(d_lists, 0xFF, sizeof(double) * FO_NL * (size_t)A * (T - 1) * M, s));
   const int Mp = round_up(M, TILE);
   const int n_tiles = Mp / TILE;
-  int apw = pick_apw(n_tiles, A);
+  const char *force_generic = getenv("FO_SWEEP_GENERIC");  // debug / A-B aid
+  const bool use_queue = !(force_generic && force_generic[0] == '1');
+  const int wpb = use_queue ? QWAVES : WAVES;  // waves per workgroup of the kernel that will run
+  int apw = pick_apw(n_tiles, A, wpb);
   if (const char *e = getenv("FO_SWEEP_APW")) { const int v = atoi(e); if (v >= 1 && v <= 64) apw = v; }  // tuning aid
-  const int n_chunks = A > 0 ? (A + WAVES * apw - 1) / (WAVES * apw) : 0;
+  const int n_chunks = A > 0 ? (A + wpb * apw - 1) / (wpb * apw) : 0;
   int rc;
   if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)T * NEF * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)(n_chunks + 1) * NPS * Mp))) return rc;
@@ -1022,12 +1094,11 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
       a.ablate = ab ? (uint32_t)atoi(ab) : 0u;
     }
     const int grid = a.nt8 * 8 * n_chunks;
-    ctx->last_grid = grid; ctx->last_block = TILE * WAVES; ctx->last_apw = apw;
+    ctx->last_grid = grid; ctx->last_block = TILE * wpb; ctx->last_apw = apw;
     const bool timed = ctx->timing && ctx->n_timed < fo_ctx::kMaxTimed;
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[ctx->n_timed], s));
-    const dim3 g(grid), b(TILE * WAVES);
-    const char *force_generic = getenv("FO_SWEEP_GENERIC");  // debug / A-B aid
-    if (T - 1 <= TQ && !(force_generic && force_generic[0] == '1')) {
+    const dim3 g(grid), b(TILE * wpb);
+    if (use_queue) {
       if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true>), g, b, 0, s, a);
       else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false>), g, b, 0, s, a);
       else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false>), g, b, 0, s, a);
