@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""Benchmark of the Frenetix-Occlusion hot path on MI355X.
+"""Benchmark of the Frenetix-Occlusion per-planning-step hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode full|pair|reduced] [--M 10000] [--A 256]
 
-One "step" = one pass of the per-planning-step hot path over one synthetic batch that is already resident in HBM:
-agent-table preparation + trajectory-tile preparation + the trajectory x agent metric sweep (DCE/TTC/TTCE/WTTC/CP/
-harm/risk) + threshold reduction (+ one RCCL all-gather of the per-trajectory cost vectors when N > 1).
-Workload at N = 1: BASELINE.json configs[2] (synthetic 10 000 trajectories x 256 phantom predictions, T = 31), the
-configuration the north-star target is quoted on.  N > 1: every rank gets its own 10 000-trajectory shard (weak
-scaling), agents are replicated, cost vectors are all-gathered.
+One "step" = one planning step of BASELINE.json configs[2] with every input already resident in HBM:
+    visibility ray fan (720 rays @ 0.5 deg, r = 50 m) over the synthetic urban lanelet net (~9.4e3 boundary edges,
+    64 parked cars)  ->  cell classes + occluded-cell list (0.5 m cells)  ->  256 phantom agents sampled in the
+    occluded cells + their predictions  ->  agent table  ->  trajectory x agent metric sweep (DCE / TTC / TTCE / WTTC /
+    CP / harm / risk over T = 31) for 10 000 candidate trajectories  ->  threshold reduction
+    (+ one RCCL all-gather of the per-trajectory cost vectors when N > 1).
+N > 1: every rank holds its own 10 000-trajectory shard (weak scaling); the scene stage and the agents are replicated
+(SURVEY 8e), cost vectors are all-gathered.  `--scene synthetic` replaces the scene stage by a fixed synthetic agent
+set (the sweep-only workload of earlier profiles).
 
 Prints ONE JSON line on rank 0.  `value` = trajectory x agent metric evaluations per second over all ranks.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,30 +33,47 @@ def algorithmic_bytes(M, A, T, mode):
     """float64 storage.  Inputs read once, outputs written once (DESIGN.md 'Algorithmic bytes')."""
     traj_in = M * T * 6 * 8              # tile table the sweep kernel reads: x, y, cos, sin, theta, v
     agent_in = A * (T * 8 * 8 + 8 * 8)   # agent table rows + per-agent constants
-    out = M * (16 * 8 + 1)               # cost vector + safe flag (written by the reduce kernel; counted with the path)
+    out = 0
     if mode in ("pair", "full"):
         out += M * A * (12 * 8 + 4 * 4)
     if mode == "full":
         out += M * A * 5 * (T - 1) * 8
+    # per-chunk partial maxima the sweep kernel writes for the reduce kernel are workspace, not counted
     return traj_in + agent_in + out
 
 
-def cpu_baseline(S, traj, agents, M_sample, threads):
+def usable_cores():
+    """cores this process may really use: cgroup quota if there is one, else the affinity mask"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(S, traj, agents, thr, threads):
+    """oracle/fo_oracle.c (a C port of the reference's per-trajectory loops) on the host cores: bounded sample"""
     from oracle import fo_oracle as O  # checker / baseline only
     O.build()
-    sub = {k: v[:M_sample] for k, v in traj.items()}
-    O.sweep({k: v[:8] for k, v in sub.items()}, agents, S.VEHICLE_BMW320I, 0.1, nthreads=threads)  # warm-up
-    best = float("inf")
-    bufs = None
+    A = agents["pos"].shape[0]
+    probe = {k: v[: 4 * threads] for k, v in traj.items()}
+    t0 = time.perf_counter()
+    O.sweep(probe, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, nthreads=threads)
+    rate = 4 * threads * A / max(time.perf_counter() - t0, 1e-6)           # first guess (includes page faults)
+    Ms = int(min(len(traj["x"]), max(8 * threads, rate * 6.0 / A)))         # ~6 s per pass, 3 passes
+    sub = {k: v[:Ms] for k, v in traj.items()}
+    best, bufs = float("inf"), None
     for _ in range(3):  # first pass page-faults the output buffers; they are reused afterwards
         t0 = time.perf_counter()
-        bufs = O.sweep(sub, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.1, "risk": 1}, want_lists=True,
-                       nthreads=threads, out=bufs)
+        bufs = O.sweep(sub, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, want_lists=True, nthreads=threads, out=bufs)
         best = min(best, time.perf_counter() - t0)
-    A = agents["pos"].shape[0]
-    return {"value": M_sample * A / best, "unit": "pair-evals/s", "cores": threads, "kind": "port",
-            "sample": f"first {M_sample} trajectories x {A} agents of the same batch, full outputs, "
-                      f"oracle/fo_oracle.c with OpenMP over trajectories, best of 3 with reused output buffers ({best:.2f} s)"}
+    return {"value": Ms * A / best, "unit": "pair-evals/s", "cores": threads, "kind": "port",
+            "sample": f"first {Ms} trajectories x {A} agents of the same batch (same phantom set the GPU step produced), "
+                      f"full outputs, oracle/fo_oracle.c, OpenMP over trajectories on {threads} threads, best of 3 "
+                      f"passes ({best:.2f} s each)"}
 
 
 def main():
@@ -64,6 +85,8 @@ def main():
     ap.add_argument("--M", type=int, default=10000)
     ap.add_argument("--A", type=int, default=256)
     ap.add_argument("--T", type=int, default=31)
+    ap.add_argument("--scene", default="urban", choices=["urban", "synthetic"],
+                    help="urban: full planning step on the synthetic urban grid; synthetic: sweep only, fixed agents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--order", default="sampler", choices=["sampler", "random"],
                     help="row order of the synthetic trajectories (synthetic.make_trajectories)")
@@ -71,15 +94,15 @@ def main():
 
     import numpy as np
     import torch
+    from frenetix_occlusion import _native as N
     from frenetix_occlusion import synthetic as S
     from frenetix_occlusion.sweep import MetricSweep
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -90,20 +113,52 @@ def main():
     torch.cuda.set_device(dev)
 
     M, A, T = args.M, args.A, args.T
-    traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3 + 1000 * rank, order=args.order)   # config 3; one shard per rank
-    agents = S.make_agents(A, T, 0.1, seed=20240131 + 3)                      # replicated
-    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, device=local_rank)
+    thr = {"harm": 0.1, "risk": 1}   # configurations/simulation/occlusion.yaml:20-28 of the reference's example
+    ctx = N.Context(local_rank)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds=thr, device=local_rank, ctx=ctx)
     sw.reserve(M, T, A, T)
     d = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a)).to(dev, dt)
+
+    scene = None
+    if args.scene == "urban":
+        import yaml
+        from frenetix_occlusion import interface
+        from frenetix_occlusion import scenario as SC
+        from frenetix_occlusion.sensor_model import SensorModel, ray_dirs
+        from frenetix_occlusion.spawn_locator import SpawnLocator
+        sc = SC.synthetic_urban_grid()
+        ego = sc.ego_initial
+        with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+            cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=45.0)
+        ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+        sm = SensorModel(sc.lanelets, ref_path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5,
+                         ctx=ctx, device=local_rank)
+        sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
+        sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
+        dirs = d(ray_dirs(720, float(ego[2]), 360.0))
+        scene = dict(sm=sm, sl=sl, ego=ego, dirs=dirs, edges=len(sm.map_geometry.edges), obstacles=len(sc.obstacles))
+        traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3 + 1000 * rank, ego_pos=ego[:2], ego_yaw=float(ego[2]),
+                                   order=args.order)
+        agents = None
+    else:
+        traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3 + 1000 * rank, order=args.order)
+        agents = S.make_agents(A, T, 0.1, seed=20240131 + 3)
+        ag = [d(agents[k]) for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims")] + \
+             [d(agents["type"], torch.int32), d(agents["len"], torch.int32)]
     tx, ty, tth, tv, ta = (d(traj[k]) for k in ("x", "y", "theta", "v", "a"))
-    ag = [d(agents[k]) for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims")] + \
-         [d(agents["type"], torch.int32), d(agents["len"], torch.int32)]
     out = None
-    gathered = torch.empty((world * M, 16), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty((world * M, N.NC), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def scene_stage():
+        sm, sl, ego = scene["sm"], scene["sl"], scene["ego"]
+        sm.launch(ego[:2], float(ego[2]), scene["dirs"])
+        return sl.sample(ego[:2], float(ego[2]), float(ego[3])).sweep_args()
 
     def step():
         nonlocal out
-        sw.set_agents(*ag, check=False)
+        a_args = scene_stage() if scene is not None else ag
+        sw.set_agents(*a_args, check=False)
         out = sw.run(tx, ty, tth, tv, ta, mode=args.mode, out=out)
         if world > 1:
             dist.all_gather_into_tensor(gathered, out.cost)
@@ -111,6 +166,9 @@ def main():
     for _ in range(args.warmup):
         step()
     sw.ctx.call("fo_sweep_check", torch.cuda.current_stream().cuda_stream)
+    n_active = A
+    if scene is not None:
+        n_active = int(scene["sl"].batch.n.item())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -130,34 +188,64 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # stage breakdown (outside the timed region): the scene stage alone, HIP events on the launch stream
+    scene_ms = None
+    if scene is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            scene_stage()
+        e1.record()
+        torch.cuda.synchronize()
+        scene_ms = e0.elapsed_time(e1) / 20
+
     if rank == 0:
-        pairs = world * M * A * args.steps
+        pairs = world * M * n_active * args.steps
         kern_s = kern_ms / 1e3 / max(kern_n, 1)
-        abytes = algorithmic_bytes(M, A, T, args.mode)
+        abytes = algorithmic_bytes(M, n_active, T, args.mode)
         achieved = abytes / kern_s / 1e9
         launch = sw.ctx.last_launch()
+        # HBM traffic of the dominant kernel from the PMC passes of the same command (profiles/, see README there):
+        # WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), KB -> bytes; null when no summary has been committed
+        traffic = None
+        try:
+            import csv
+            tag = os.environ.get("FO_PROFILE_TAG", "r01_final")
+            with open(os.path.join(ROOT, "profiles", f"{tag}_summary.csv")) as f:
+                for row in csv.DictReader(f):
+                    if row["kernel"].startswith("fo_sweep_queue_kernel") and row.get("WRITE_SIZE") and row.get("FETCH_SIZE"):
+                        traffic = (float(row["WRITE_SIZE"]) + 2.0 * float(row["FETCH_SIZE"])) * 1024.0
+        except Exception:
+            traffic = None
         res = {
             "metric": "trajectory_x_agent_metric_evals_per_sec", "value": pairs / elapsed, "unit": "pair-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: synthetic 10k trajectories x 256 phantom predictions, T=31 "
-                                   "(metric sweep; per-rank shard when n_gpus>1)",
-                       "M_per_gpu": M, "A": A, "T": T, "output_mode": args.mode, "traj_order": args.order,
-                       "metrics": ["hr", "ttc", "ttce", "dce", "wttc", "cp"], "parallelism": f"traj-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "fo_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "config": {"workload": "BASELINE configs[2]: synthetic urban lanelet net, 10k trajectories x 256 phantoms, "
+                                   "360 deg ray-cast @ 0.5 deg, T=31 (full planning step; per-rank trajectory shard when "
+                                   "n_gpus>1)" if scene is not None else
+                                   "sweep only: 10k synthetic trajectories x 256 synthetic phantom predictions, T=31",
+                       "M_per_gpu": M, "A": A, "A_active": n_active, "T": T, "output_mode": args.mode,
+                       "traj_order": args.order, "metrics": ["hr", "ttc", "ttce", "dce", "wttc", "cp"],
+                       "scene_stage_ms": scene_ms, "sweep_kernel_ms": kern_s * 1e3,
+                       "boundary_edges": scene["edges"] if scene else None, "rays": 720 if scene else None,
+                       "parallelism": f"traj-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "fo_sweep_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_s * 1e3, "launches_timed": kern_n,
                          "grid": launch["grid"], "block": launch["block"],
-                         "kernel_pair_evals_per_sec": M * A / kern_s},
+                         "kernel_pair_evals_per_sec": M * n_active / kern_s},
         }
         if out.pair_f is not None:
-            from frenetix_occlusion import _native as N
             res["config"]["gate_pair_frac"] = float((out.pair_f[N.PF["max_collision_probability"]] > 0).double().mean())
             res["config"]["collision_pair_frac"] = float((out.pair_f[N.PF["dce"]] == 0).double().mean())
             res["config"]["safe_traj_frac"] = float(out.safe.double().mean())
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
-            res["cpu_baseline"] = cpu_baseline(S, traj, agents, min(M, 50 * threads), threads)
+            if scene is not None:
+                b = scene["sl"].batch
+                agents = {k: getattr(b, k).cpu().numpy() for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")}
+            res["cpu_baseline"] = cpu_baseline(S, traj, agents, thr, usable_cores())
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))

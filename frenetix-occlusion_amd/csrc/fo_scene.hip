@@ -333,13 +333,13 @@ __global__ __launch_bounds__(256) void fo_flag_scatter_kernel(const uint8_t *__r
 // ------------------------------------------------------------------------------------------------ spawn sampling
 __global__ void fo_spawn_flag_kernel(const uint8_t *__restrict__ cls, int nx, int ny, double rx0, double ry0, double cs,
                                      int ix0, int iy0, double ex, double ey, double hx, double hy, double min_ahead,
-                                     double max_dist, uint8_t *__restrict__ flag) {
+                                     double max_dist, int all_occluded, uint8_t *__restrict__ flag) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nx * ny) return;
   const int ix = idx % nx, iy = idx / nx;
   uint8_t f = 0;
   if (cls[idx] & 4) {
-    int front = 0;
+    int front = all_occluded;
     if (ix > 0 && (cls[idx - 1] & 2)) front = 1;
     if (ix + 1 < nx && (cls[idx + 1] & 2)) front = 1;
     if (iy > 0 && (cls[idx - nx] & 2)) front = 1;
@@ -609,8 +609,8 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
 }
 
 int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
-                   double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int max_agents,
-                   const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
+                   double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int all_occluded,
+                   int max_agents, const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
                    const double *infl_l4, const double *infl_w4, int n_path, const double *d_path, int T, double dt,
                    double var0, double var_factor, int32_t *d_cell, double *d_pos0, double *d_yaw0, int32_t *d_n,
                    double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,
@@ -628,7 +628,8 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
   if ((rc = fo_reserve(ctx, &sc->d_cand, &sc->cap_cand, (size_t)cells))) return rc;
   hipLaunchKernelGGL(fo_spawn_flag_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, d_cls, win_nx, win_ny, sc->x0,
-                     sc->y0, sc->cs, win_ix0, win_iy0, ego_x, ego_y, head_x, head_y, min_ahead, max_dist, sc->d_flags);
+                     sc->y0, sc->cs, win_ix0, win_iy0, ego_x, ego_y, head_x, head_y, min_ahead, max_dist, all_occluded ? 1 : 0,
+                     sc->d_flags);
   if ((rc = compact(ctx, sc, sc->d_flags, cells, sc->d_cand, sc->d_ncand, s))) return rc;
   hipLaunchKernelGGL(fo_spawn_pick_kernel, dim3((max_agents + 63) / 64), dim3(64), 0, s, sc->d_cand, sc->d_ncand, win_nx,
                      sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, max_agents, d_cell, d_pos0, d_n);

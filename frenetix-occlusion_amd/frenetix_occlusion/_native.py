@@ -86,7 +86,7 @@ def load():
     lib.fo_scene_copy_raster.argtypes = [vp, vp]
     lib.fo_scene_visibility.argtypes = ([vp, D, D, D, D, D, C.c_int, C.c_int, dp, C.c_int, dp, dp, dp]
                                         + [C.c_int] * 4 + [dp] * 7 + [vp])
-    lib.fo_scene_spawn.argtypes = ([vp, dp] + [C.c_int] * 4 + [D] * 6 + [C.c_int] + [ip] + [dp] * 5 + [C.c_int, dp, C.c_int]
+    lib.fo_scene_spawn.argtypes = ([vp, dp] + [C.c_int] * 4 + [D] * 6 + [C.c_int] * 2 + [ip] + [dp] * 5 + [C.c_int, dp, C.c_int]
                                    + [D] * 3 + [dp] * 12 + [vp])
     lib.fo_scene_candidate_count.argtypes = [vp, ip, vp]
     for name in EXPORTS:

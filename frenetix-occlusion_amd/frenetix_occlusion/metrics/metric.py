@@ -146,7 +146,7 @@ class BatchAssessment:
 
 
 class Metric:
-    def __init__(self, config, vehicle_params, agent_manager, dt=None, harm_coeff=None, device=0):
+    def __init__(self, config, vehicle_params, agent_manager, dt=None, harm_coeff=None, device=0, ctx=None):
         self.config = config
         self.metric_thresholds = config["metric_thresholds"]
         self.vehicle_params = vehicle_params
@@ -159,7 +159,7 @@ class Metric:
         self.dt = float(dt if dt is not None else agent_manager.dt)
         self.sweep = MetricSweep(vehicle_params, self.dt, metrics=self.metrics or ("dce",),
                                  thresholds=self.metric_thresholds, harm_coeff=harm_coeff or load_harm_coeff(),
-                                 device=device)
+                                 device=device, ctx=ctx)
         self._agents_version = None
         self._batch = None
         self._batch_ids = {}

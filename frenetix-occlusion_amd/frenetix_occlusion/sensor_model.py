@@ -130,6 +130,7 @@ class SensorModel:
         self.ego_pos = None
         self.ego_orientation = None
         self.window = None
+        self.cell_class = None
         self._set_map(lanelet_network)
 
     # ---- one-off: replaces _convert_lanelet_network (sensor_model.py:195-199)
@@ -177,49 +178,67 @@ class SensorModel:
         return CellWindow(x0, y0, cs, ix0, iy0, n, n)
 
     # ---- per step: replaces calc_visible_and_occluded_area (sensor_model.py:41-101)
-    def calc_visible_and_occluded_area(self, timestep, ego_pos, ego_orientation, obstacles):
-        """obstacles: an FOObstacles (already updated to `timestep`) or None."""
-        self.timestep = timestep
+    def upload_obstacles(self, obstacles):
+        """obstacle corner points / centres / flags of the current step -> HBM (a few hundred bytes)"""
+        dev = self.device
+        if obstacles is not None and len(obstacles) > 0:
+            corn, cen, flags = obstacles.arrays() if hasattr(obstacles, "arrays") else obstacles
+            self._obst = (torch.as_tensor(np.ascontiguousarray(corn)).to(dev), torch.as_tensor(np.ascontiguousarray(cen)).to(dev),
+                          torch.as_tensor(np.ascontiguousarray(flags)).to(dev), len(flags))
+        else:
+            self._obst = (None, None, None, 0)
+        return self._obst
+
+    def _buffers(self, w, O):
+        """per-step outputs, allocated once per (window size, obstacle count) and reused"""
+        key = (w.nx, w.ny, O, self.n_rays)
+        if getattr(self, "_buf_key", None) != key:
+            dev, n = self.device, self.n_rays
+            self._buf = dict(rng=torch.empty(n, dtype=torch.float64, device=dev),
+                             hit=torch.empty(n, dtype=torch.int32, device=dev),
+                             ring=torch.empty((n, 2), dtype=torch.float64, device=dev),
+                             ovis=torch.zeros(max(O, 1), dtype=torch.uint8, device=dev),
+                             cls=torch.empty((w.ny, w.nx), dtype=torch.uint8, device=dev),
+                             occ=torch.empty(w.nx * w.ny, dtype=torch.int32, device=dev),
+                             n_occ=torch.zeros(1, dtype=torch.int32, device=dev))
+            self._buf_key = key
+        return self._buf
+
+    def launch(self, ego_pos, ego_orientation, dirs=None):
+        """queue the visibility kernels for one ego pose on the current stream; no host synchronisation.
+        Obstacles are the ones of the last ``upload_obstacles``; ``dirs`` (device [n_rays,2]) defaults to the fan
+        about ``ego_orientation``."""
         self.ego_pos = np.asarray(ego_pos, dtype=np.float64)
         self.ego_orientation = float(ego_orientation)
-        self.visible_objects_timestep = []
-        self.obstacle_occlusions.clear()
-        dev = self.device
         full = self.sensor_angle >= 359.9
-        dirs = torch.as_tensor(ray_dirs(self.n_rays, self.ego_orientation, self.sensor_angle)).to(dev)
-        if obstacles is not None and len(obstacles) > 0:
-            corn, cen, flags = obstacles.arrays()
-            d_corn = torch.as_tensor(corn).to(dev)
-            d_cen = torch.as_tensor(cen).to(dev)
-            d_flags = torch.as_tensor(flags).to(dev)
-            O = len(flags)
-        else:
-            d_corn = d_cen = d_flags = None
-            O = 0
+        if dirs is None:
+            dirs = torch.as_tensor(ray_dirs(self.n_rays, self.ego_orientation, self.sensor_angle)).to(self.device)
+        d_corn, d_cen, d_flags, O = getattr(self, "_obst", (None, None, None, 0))
         w = self._window_for(self.ego_pos)
-        n = self.n_rays
-        rng = torch.empty(n, dtype=torch.float64, device=dev)
-        hit = torch.empty(n, dtype=torch.int32, device=dev)
-        ring = torch.empty((n, 2), dtype=torch.float64, device=dev)
-        ovis = torch.zeros(max(O, 1), dtype=torch.uint8, device=dev)
-        cls = torch.empty((w.ny, w.nx), dtype=torch.uint8, device=dev)
-        occ = torch.empty(w.nx * w.ny, dtype=torch.int32, device=dev)
-        n_occ = torch.zeros(1, dtype=torch.int32, device=dev)
+        b = self._buffers(w, O)
         p = lambda t: t.data_ptr() if t is not None else None
         hx, hy = math.cos(self.ego_orientation), math.sin(self.ego_orientation)
-        self._keep = (dirs, d_corn, d_cen, d_flags)
         self.ctx.call("fo_scene_visibility", float(self.ego_pos[0]), float(self.ego_pos[1]), hx, hy,
-                      self.sensor_radius, 1 if full else 0, n, p(dirs), O, p(d_corn), p(d_cen), p(d_flags), w.ix0,
-                      w.iy0, w.nx, w.ny, p(rng), p(hit), p(ring), p(ovis), p(cls), p(occ), p(n_occ),
-                      torch.cuda.current_stream().cuda_stream)
+                      self.sensor_radius, 1 if full else 0, self.n_rays, p(dirs), O, p(d_corn), p(d_cen), p(d_flags),
+                      w.ix0, w.iy0, w.nx, w.ny, p(b["rng"]), p(b["hit"]), p(b["ring"]), p(b["ovis"]), p(b["cls"]),
+                      p(b["occ"]), p(b["n_occ"]), torch.cuda.current_stream().cuda_stream)
         self.window = w
-        self.dirs, self.range, self.hit_id, self.cell_class = dirs, rng, hit, cls
-        self.occluded_idx_buffer, self.n_occluded = occ, n_occ
-        self.visible_area = VisibleArea(self.ego_pos, ring, rng, hit, cls, w, full, VISIBLE)
-        self.occluded_area = VisibleArea(self.ego_pos, ring, rng, hit, cls, w, full, OCCLUDED)
+        self.dirs, self.range, self.hit_id, self.cell_class = dirs, b["rng"], b["hit"], b["cls"]
+        self.occluded_idx_buffer, self.n_occluded = b["occ"], b["n_occ"]
+        self.visible_area = VisibleArea(self.ego_pos, b["ring"], b["rng"], b["hit"], b["cls"], w, full, VISIBLE)
+        self.occluded_area = VisibleArea(self.ego_pos, b["ring"], b["rng"], b["hit"], b["cls"], w, full, OCCLUDED)
+        return self.visible_area
+
+    def calc_visible_and_occluded_area(self, timestep, ego_pos, ego_orientation, obstacles):
+        """reference entry point.  obstacles: an FOObstacles (already updated to `timestep`) or None."""
+        self.timestep = timestep
+        self.visible_objects_timestep = []
+        self.obstacle_occlusions.clear()
+        _, _, _, O = self.upload_obstacles(obstacles)
+        self.launch(ego_pos, ego_orientation)
         if O:
-            vis = ovis[:O].cpu().numpy().astype(bool)
-            hit_h = hit.cpu().numpy()
+            vis = self._buf["ovis"][:O].cpu().numpy().astype(bool)
+            hit_h = self.hit_id.cpu().numpy()
             E = len(self.map_geometry.edges)
             for i, obst in enumerate(obstacles):
                 obst.current_visible = bool(vis[i])

@@ -77,6 +77,8 @@ class SpawnLocator:
         self.dt = float(dt)
         self.T = int(horizon / self.dt) + 1                      # agent.py:496
         self.min_ahead = float(acc.get("min_ahead", MIN_AHEAD))
+        self.all_occluded = bool(acc.get("all_occluded", False))   # False: only the visible/occluded frontier
+        self.max_dist_override = acc.get("max_dist")               # None: the reference's max(4 v, 25) m
         am = config["agent_manager"]
         pr = am["prediction"]
         self.var0, self.var_factor = 0.1, float(pr["variance_factor"])   # agent.py:416-417,527-528
@@ -108,6 +110,8 @@ class SpawnLocator:
                             raw_dims=f(A, 2), type=i(A), len=i(A))
 
     def max_distance(self, ego_v):
+        if self.max_dist_override is not None:
+            return float(self.max_dist_override)
         return max(S_THRESHOLD_TIME * float(ego_v), S_THRESHOLD_MIN)
 
     def sample(self, ego_pos, ego_orientation, ego_v) -> PhantomBatch:
@@ -121,7 +125,7 @@ class SpawnLocator:
         c = lambda a: a.ctypes.data
         self.ctx.call("fo_scene_spawn", sm.cell_class.data_ptr(), w.ix0, w.iy0, w.nx, w.ny, float(ego_pos[0]),
                       float(ego_pos[1]), math.cos(ego_orientation), math.sin(ego_orientation), self.min_ahead,
-                      self.max_distance(ego_v), self.max_agents, c(self._t4), c(self._s4), c(self._rl), c(self._rw),
+                      self.max_distance(ego_v), 1 if self.all_occluded else 0, self.max_agents, c(self._t4), c(self._s4), c(self._rl), c(self._rw),
                       c(self._il), c(self._iw), int(self.ref_path.shape[0]), self._d_path.data_ptr(), self.T, self.dt,
                       self.var0, self.var_factor, b.cell.data_ptr(), b.pos0.data_ptr(), b.yaw0.data_ptr(),
                       b.n.data_ptr(), b.pos.data_ptr(), b.yaw.data_ptr(), b.v.data_ptr(), b.cov.data_ptr(),

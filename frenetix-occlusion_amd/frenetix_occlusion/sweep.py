@@ -34,11 +34,11 @@ def _vehicle_tuple(vp):
 
 
 class MetricSweep:
-    def __init__(self, vehicle_params, dt, metrics=DEFAULT_METRICS, thresholds=None, harm_coeff=None, device=0):
+    def __init__(self, vehicle_params, dt, metrics=DEFAULT_METRICS, thresholds=None, harm_coeff=None, device=0, ctx=None):
         if not torch.cuda.is_available():
             raise RuntimeError("MetricSweep needs a ROCm GPU (no CPU fallback)")
         self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
-        self.ctx = N.Context(self.device.index)
+        self.ctx = ctx or N.Context(self.device.index)   # one fo_ctx per ego per GPU; shared with the scene stage
         self.dt = float(dt)
         self.metrics = tuple(metrics)
         self.A = 0

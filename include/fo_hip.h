@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 1
+#define FO_ABI_VERSION 2
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -135,12 +135,14 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
                         int32_t *d_n_occ, void *stream);
 
 /* Phantom sampling in the occluded cells + constant-velocity predictions (replaces the cell-based core of
- * SpawnLocator.find_spawn_points, spawn_locator.py:80-139, and agent.py:451-536).  Agent j takes pattern slot j % 4
+ * SpawnLocator.find_spawn_points, spawn_locator.py:80-139, and agent.py:451-536).  Candidates: occluded cells at least
+ * min_ahead ahead of the ego and within max_dist, on the visible/occluded frontier (all_occluded = 0) or anywhere in
+ * the occluded set (all_occluded = 1); evenly spaced ranks are kept.  Agent j takes pattern slot j % 4
  * (type4/speed4/raw/inflated dims: HOST arrays of 4).  d_path [n_path][2] = ego reference path.  Outputs for
  * max_agents slots, directly in the layout fo_sweep_set_agents consumes (slots >= *d_n have len 0 = inactive). */
 int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
-                   double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int max_agents,
-                   const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
+                   double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int all_occluded,
+                   int max_agents, const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
                    const double *infl_l4, const double *infl_w4, int n_path, const double *d_path, int T, double dt,
                    double var0, double var_factor, int32_t *d_cell, double *d_pos0, double *d_yaw0, int32_t *d_n,
                    double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,

@@ -92,7 +92,7 @@ int fo_oracle_obstacle_visibility(int E, const double *edges, int O, const doubl
                                   const double *dirs, uint8_t *vis);
 int fo_oracle_spawn_cells(const uint8_t *cls, int nx, int ny, double rx0, double ry0, double cs, int ix0, int iy0,
                           const double *ego, const double *hdir, double min_ahead, double max_dist, int max_agents,
-                          int32_t *cell, double *pos, int32_t *n_out, int32_t *n_cand_out);
+                          int all_occluded, int32_t *cell, double *pos, int32_t *n_out, int32_t *n_cand_out);
 void fo_oracle_normal_to_polyline(int N, const double *path, double px, double py, double *nx_, double *ny_);
 int fo_oracle_spawn_headings(int n, const double *pos, const int32_t *type, int N, const double *path,
                              const double *lane_yaw_at, double *yaw);

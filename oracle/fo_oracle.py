@@ -211,7 +211,7 @@ def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs):
     return vis
 
 
-def spawn_cells(cls, rx0, ry0, cs, ix0, iy0, ego, hdir, min_ahead, max_dist, max_agents):
+def spawn_cells(cls, rx0, ry0, cs, ix0, iy0, ego, hdir, min_ahead, max_dist, max_agents, all_occluded=False):
     cls = _u8(cls)
     ny, nx = cls.shape
     ego, hdir = _f64(ego), _f64(hdir)
@@ -220,7 +220,8 @@ def spawn_cells(cls, rx0, ry0, cs, ix0, iy0, ego, hdir, min_ahead, max_dist, max
     n, nc = C.c_int32(0), C.c_int32(0)
     lib().fo_oracle_spawn_cells(_p(cls, C.c_uint8), C.c_int(nx), C.c_int(ny), C.c_double(rx0), C.c_double(ry0),
                                 C.c_double(cs), C.c_int(ix0), C.c_int(iy0), _p(ego), _p(hdir), C.c_double(min_ahead),
-                                C.c_double(max_dist), C.c_int(max_agents), _p(cell, C.c_int32), _p(pos), C.byref(n),
+                                C.c_double(max_dist), C.c_int(max_agents), C.c_int(1 if all_occluded else 0),
+                                _p(cell, C.c_int32), _p(pos), C.byref(n),
                                 C.byref(nc))
     return cell, pos, n.value, nc.value
 

@@ -23,11 +23,22 @@
  * (= inside road_polygon, the union of sensor_model.py:195-199).  Crossing-number rule, half-open in y. */
 int fo_oracle_road_raster(int P, const int32_t *poly_off, const double *poly_xy, double x0, double y0, double cs,
                           int nx, int ny, uint8_t *mask) {
+  /* per-polygon bounding boxes: a pure early-out (a point outside the box is outside the polygon) */
+  double *bb = (double *)malloc(sizeof(double) * 4 * (size_t)(P > 0 ? P : 1));
+  for (int p = 0; p < P; ++p) {
+    double bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+    for (int i = poly_off[p]; i < poly_off[p + 1]; ++i) {
+      bx0 = fmin(bx0, poly_xy[2 * i]); bx1 = fmax(bx1, poly_xy[2 * i]);
+      by0 = fmin(by0, poly_xy[2 * i + 1]); by1 = fmax(by1, poly_xy[2 * i + 1]);
+    }
+    bb[4 * p] = bx0; bb[4 * p + 1] = by0; bb[4 * p + 2] = bx1; bb[4 * p + 3] = by1;
+  }
   for (int iy = 0; iy < ny; ++iy) {
     for (int ix = 0; ix < nx; ++ix) {
       const double px = x0 + ((double)ix + 0.5) * cs, py = y0 + ((double)iy + 0.5) * cs;
       int inside_any = 0;
       for (int p = 0; p < P && !inside_any; ++p) {
+        if (px < bb[4 * p] || px > bb[4 * p + 2] || py < bb[4 * p + 1] || py > bb[4 * p + 3]) continue;
         const int b = poly_off[p], e = poly_off[p + 1];
         int c = 0;
         for (int i = b, j = e - 1; i < e; j = i++) {
@@ -42,6 +53,7 @@ int fo_oracle_road_raster(int P, const int32_t *poly_off, const double *poly_xy,
       mask[(size_t)iy * nx + ix] = (uint8_t)inside_any;
     }
   }
+  free(bb);
   return 0;
 }
 
@@ -204,14 +216,15 @@ int fo_oracle_obstacle_visibility(int E, const double *edges, int O, const doubl
 }
 
 /* ---------------------------------------------------------------- phantom spawn sampling in the occluded cells
- * Candidates = occluded cells with a visible 4-neighbour (the frontier a hidden road user would emerge from),
+ * Candidates = occluded cells with a visible 4-neighbour (the frontier a hidden road user would emerge from; with
+ * all_occluded != 0: every occluded cell -- "sampling in the occluded cells" of the BASELINE configs),
  * at least `min_ahead` metres ahead of the ego along its heading and not farther than `max_dist`
  * (spawn_locator.py:113,234,381: s_threshold = max(4 v, 25), "ahead by >= 3 m").  Candidates are taken in
  * ascending cell order; if there are more than max_agents, the ones at ranks floor(j * n / max_agents) are kept.
  * Agent j gets type pattern[j % 4]; position = cell centre. */
 int fo_oracle_spawn_cells(const uint8_t *cls, int nx, int ny, double rx0, double ry0, double cs, int ix0, int iy0,
                           const double *ego, const double *hdir, double min_ahead, double max_dist, int max_agents,
-                          int32_t *cell, double *pos, int32_t *n_out, int32_t *n_cand_out) {
+                          int all_occluded, int32_t *cell, double *pos, int32_t *n_out, int32_t *n_cand_out) {
   int n = 0;
   int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)nx * ny);
   for (int iy = 0; iy < ny; ++iy) {
@@ -223,7 +236,7 @@ int fo_oracle_spawn_cells(const uint8_t *cls, int nx, int ny, double rx0, double
       if (ix + 1 < nx && (cls[(size_t)iy * nx + ix + 1] & 2)) front = 1;
       if (iy > 0 && (cls[(size_t)(iy - 1) * nx + ix] & 2)) front = 1;
       if (iy + 1 < ny && (cls[(size_t)(iy + 1) * nx + ix] & 2)) front = 1;
-      if (!front) continue;
+      if (!front && !all_occluded) continue; /* all_occluded: every occluded cell in range is a candidate */
       const double px = rx0 + ((double)(ix0 + ix) + 0.5) * cs, py = ry0 + ((double)(iy0 + iy) + 0.5) * cs;
       const double rx = px - ego[0], ry = py - ego[1];
       if (rx * hdir[0] + ry * hdir[1] < min_ahead) continue;

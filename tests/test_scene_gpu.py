@@ -28,7 +28,7 @@ def _default_config():
 
 
 def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_rays=720, radius=50.0, max_agents=32,
-                ref_path=None):
+                ref_path=None, all_occluded=False, max_dist=None):
     from frenetix_occlusion.sensor_model import SensorModel, ray_dirs
     from frenetix_occlusion.spawn_locator import SpawnLocator
     from frenetix_occlusion.utils.fo_obstacle import FOObstacles
@@ -78,12 +78,14 @@ def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_r
     # phantom sampling + predictions
     cfg = _default_config()
     cfg["accelerator"]["spawn"]["max_agents"] = max_agents
+    cfg["accelerator"]["spawn"]["all_occluded"] = all_occluded
+    cfg["accelerator"]["spawn"]["max_dist"] = max_dist
     sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1)
     pts = sl.find_spawn_points(ego[:2], yaw, None, v_ego)
     torch.cuda.synchronize()
     b = sl.batch
     cell_ref, pos_ref, n_ref, n_cand = oracle.spawn_cells(cls_ref, x0, y0, cs, w.ix0, w.iy0, ego[:2], hd, sl.min_ahead,
-                                                          sl.max_distance(v_ego), max_agents)
+                                                          sl.max_distance(v_ego), max_agents, all_occluded)
     assert int(b.n.item()) == n_ref == len(pts)
     assert np.array_equal(b.cell.cpu().numpy(), cell_ref)
     assert np.array_equal(b.pos0.cpu().numpy()[:n_ref], pos_ref[:n_ref])
@@ -142,6 +144,9 @@ def test_synthetic_urban_grid_config3(torch_cuda, oracle):
     sc = S.synthetic_urban_grid()
     st = _check_step(torch_cuda, oracle, sc, sc.ego_initial, 8.0, 0, max_agents=256)
     assert st["n_occ"] > 500 and st["n_cand"] > 0
+    # the bench configuration: every occluded cell within 45 m is a candidate -> all 256 phantom slots are filled
+    st = _check_step(torch_cuda, oracle, sc, sc.ego_initial, 8.0, 0, max_agents=256, all_occluded=True, max_dist=45.0)
+    assert st["n_spawn"] == 256 and st["n_cand"] > 256
 
 
 def test_no_obstacles_and_ego_off_the_raster_edge(torch_cuda, oracle):

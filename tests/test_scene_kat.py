@@ -198,6 +198,14 @@ def test_spawn_sampling_takes_evenly_spaced_frontier_cells(oracle):
     _, pos3, n3, _ = oracle.spawn_cells(s["cls"], s["x0"], s["y0"], s["cs"], 0, 0, ego, s["hd"], 32.0, 34.0, 4096)
     rel = pos3[:n3] - ego
     assert (rel[:, 0] >= 32.0).all() and (np.hypot(rel[:, 0], rel[:, 1]) <= 34.0).all()
+    # all_occluded: every occluded cell in range qualifies, frontier or not
+    cell4, _, n4, nc4 = oracle.spawn_cells(s["cls"], s["x0"], s["y0"], s["cs"], 0, 0, ego, s["hd"], 3.0, 60.0, 100000, True)
+    rel_all = np.stack(((np.arange(s["nx"]) + 0.5) * s["cs"] + s["x0"] - ego[0],), 0)
+    occ = np.nonzero(cls & 4)[0]
+    cx = s["x0"] + (occ % nx + 0.5) * s["cs"] - ego[0]
+    cy = s["y0"] + (occ // nx + 0.5) * s["cs"] - ego[1]
+    expect = occ[(cx >= 3.0) & (cx * cx + cy * cy <= 3600.0)]
+    assert nc4 == n4 == len(expect) > n_cand and np.array_equal(cell4[:n4], expect)
 
 
 def test_pedestrian_heading_and_constant_velocity_prediction(oracle):
