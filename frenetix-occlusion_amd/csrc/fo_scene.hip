@@ -9,24 +9,22 @@
 // must be bit-identical to the CPU restatement, so only + - * / sqrt and comparisons on float64 are used and no
 // FMA is formed.
 //
-// Kernels (all latency-bound at one ego; launch-overhead discipline matters more than bandwidth here):
-//   fo_raster_kernel     one-off: world-aligned road raster (cell centre inside any lanelet polygon)
-//   fo_obst_edges_kernel obstacle corner points -> 4 occluder segments each
-//   fo_raycast_kernel    one WAVE per ray: lanes stride over the occluder soup staged through LDS, lexicographic
-//                        (t, id) minimum by cross-lane shuffles = first hit
-//   fo_obst_vis_kernel   5 probe rays (corners + centre) per obstacle, one wave each
-//   fo_grid_kernel       one thread per cell: fan sector by binary search on cross products, inside-the-ring test,
-//                        half-disc test -> class bits
-//   fo_flag_* kernels    deterministic stream compaction (ballot prefix inside a block, scanned block counts)
-//   fo_spawn_* kernels   frontier candidates -> evenly spaced pick -> headings -> predictions in the sweep's layout
+// Kernels (all latency-bound at one ego; launch count matters more than bandwidth here -- nine launches per step):
+//   fo_raster_kernel       one-off: world-aligned road raster (cell centre inside any lanelet polygon)
+//   fo_rays_kernel         ray fan + obstacle-visibility probes in one launch: a workgroup per ray (five waves scan
+//                          interleaved fifths of the occluder soup, lexicographic (t, id) minimum by cross-lane
+//                          shuffles = first hit) and a workgroup per obstacle (one probe per wave)
+//   fo_grid_kernel         one thread per cell: fan sector by binary search on cross products, inside-the-chord test,
+//                          half-disc test -> class bits; also the per-block counts of the occluded-cell compaction
+//   fo_flag_scan/scatter   deterministic stream compaction (ballot prefix inside a block, scanned block counts)
+//   fo_spawn_flag_kernel   candidate cells (+ block counts), fo_spawn_pick_kernel (evenly spaced pick + heading),
+//                          fo_spawn_predict_kernel (predictions in the sweep's agent layout)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "fo_ctx.hpp"
 
 namespace {
 
-constexpr int RC_WAVES = 4;      // rays per workgroup
-constexpr int RC_CHUNK = 1024;   // occluder segments staged in LDS at a time (32 KB)
 
 struct Scene {
   // static map
@@ -37,9 +35,7 @@ struct Scene {
   uint8_t *d_raster = nullptr;    // [rny][rnx]
   double *d_lane_yaw = nullptr;   // [rny][rnx] or null
   // per-step workspace
-  double *d_dyn_edges = nullptr;  // [O*4][4]
-  int32_t *d_dyn_ids = nullptr;   // [O*4]
-  size_t cap_dyn = 0, cap_dyn_ids = 0, cap_cand = 0;
+  size_t cap_cand = 0;
   uint8_t *d_flags = nullptr;     // [cells]
   int32_t *d_blk = nullptr;       // block counts / offsets
   size_t cap_cells = 0, cap_blk = 0;
@@ -79,31 +75,20 @@ __global__ void fo_raster_kernel(int P, const int32_t *__restrict__ poly_off, co
 }
 
 // ------------------------------------------------------------------------------------------------ ray casting
+// Ray o + t d against segment a + u (b - a):  denom = d x e,  tn = w x e,  un = w x d  (w = a - o).
+// Hit iff denom != 0 and 0 <= tn/denom and 0 <= un/denom <= 1, decided on the signs of the numerators (no division
+// on the rejection path); t = tn / denom is formed for hits only.  Same predicate, same operation order as the CPU
+// restatement used by the tests, compiled without FMA contraction on both sides.
 __device__ __forceinline__ double ray_segment(double ox, double oy, double dx, double dy, double ax, double ay,
                                               double bx, double by) {
   const double ex = bx - ax, ey = by - ay;
   const double denom = dx * ey - dy * ex;
   if (denom == 0.0) return INFINITY;
   const double wx = ax - ox, wy = ay - oy;
-  const double t = (wx * ey - wy * ex) / denom;
-  const double u = (wx * dy - wy * dx) / denom;
-  if (t >= 0.0 && u >= 0.0 && u <= 1.0) return t;
-  return INFINITY;
-}
-
-// obstacle o (exists & occludes) -> 4 segments with id E + o; others get a degenerate segment that never hits
-__global__ void fo_obst_edges_kernel(int O, int E, const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags,
-                                     double *__restrict__ seg, int32_t *__restrict__ ids) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= O * 4) return;
-  const int o = i >> 2, s = i & 3, s2 = (s + 1) & 3;
-  const bool on = (oflags[o] & 1) && (oflags[o] & 2);
-  const double *c = ocorn + 8 * (size_t)o;
-  seg[4 * (size_t)i + 0] = on ? c[2 * s] : 0.0;
-  seg[4 * (size_t)i + 1] = on ? c[2 * s + 1] : 0.0;
-  seg[4 * (size_t)i + 2] = on ? c[2 * s2] : 0.0;
-  seg[4 * (size_t)i + 3] = on ? c[2 * s2 + 1] : 0.0;
-  ids[i] = on ? E + o : -2;  // -2 = inactive
+  const double tn = wx * ey - wy * ex;
+  const double un = wx * dy - wy * dx;
+  const bool hit = denom > 0.0 ? (tn >= 0.0 && un >= 0.0 && un <= denom) : (tn <= 0.0 && un <= 0.0 && un >= denom);
+  return hit ? tn / denom : INFINITY;
 }
 
 // lexicographic (t, id) minimum across the wave
@@ -116,63 +101,29 @@ __device__ __forceinline__ void wave_min_hit(double &t, int &id) {
   }
 }
 
-// First hit of one ray per wave.  Static edges and dynamic (obstacle) segments are staged through LDS in chunks
-// shared by the workgroup's waves.  skip_id: occluder id to ignore (probe rays of that obstacle), or -3.
-__device__ void wave_first_hit(double *sh, int E, const double *__restrict__ edges, int nd,
-                               const double *__restrict__ dseg, const int32_t *__restrict__ dids, double ox, double oy,
-                               double dx, double dy, bool active, int skip_id, double &best, int &best_id) {
-  const int lane = threadIdx.x & 63;
-  best = INFINITY;
-  best_id = 0x7fffffff;
-  const int total = E + nd;
-  for (int base = 0; base < total; base += RC_CHUNK) {
-    const int n = min(RC_CHUNK, total - base);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n * 4; i += blockDim.x) {
-      const int g = base * 4 + i;
-      sh[i] = g < E * 4 ? edges[g] : dseg[g - E * 4];
+// one lane's share of the occluder soup: segments first + lane, first + lane + stride, ...  Static edges come from
+// the [E][4] table (a wave reads 2 KB contiguous per step, L2 resident); obstacle o contributes its four sides with
+// id E + o when it is present and occludes (bicycles do not, Q10), derived from the corner points on the fly.
+__device__ __forceinline__ void scan_soup(int E, const double *__restrict__ edges, int O, const double *__restrict__ ocorn,
+                                          const uint8_t *__restrict__ oflags, int first, int stride, double ox, double oy,
+                                          double dx, double dy, int skip_id, double &best, int &best_id) {
+  const int total = E + 4 * O;
+  for (int gi = first; gi < total; gi += stride) {
+    double ax, ay, bx, by;
+    int id;
+    if (gi < E) {
+      const double *sg = edges + 4 * (size_t)gi;
+      ax = sg[0]; ay = sg[1]; bx = sg[2]; by = sg[3];
+      id = gi;
+    } else {
+      const int o = (gi - E) >> 2, sd = (gi - E) & 3, s2 = (sd + 1) & 3;
+      if (!((oflags[o] & 1) && (oflags[o] & 2)) || E + o == skip_id) continue;
+      const double *c = ocorn + 8 * (size_t)o;
+      ax = c[2 * sd]; ay = c[2 * sd + 1]; bx = c[2 * s2]; by = c[2 * s2 + 1];
+      id = E + o;
     }
-    __syncthreads();
-    if (active) {
-      for (int i = lane; i < n; i += 64) {
-        const int gi = base + i;
-        int id = gi;
-        if (gi >= E) {
-          id = dids[gi - E];
-          if (id < 0 || id == skip_id) continue;
-        }
-        const double t = ray_segment(ox, oy, dx, dy, sh[4 * i], sh[4 * i + 1], sh[4 * i + 2], sh[4 * i + 3]);
-        if (t < best || (t == best && id < best_id)) { best = t; best_id = id; }
-      }
-    }
-  }
-  wave_min_hit(best, best_id);
-}
-
-__global__ __launch_bounds__(64 * RC_WAVES) void fo_raycast_kernel(int E, const double *__restrict__ edges, int nd,
-                                                                   const double *__restrict__ dseg,
-                                                                   const int32_t *__restrict__ dids, double ex,
-                                                                   double ey, int n_rays,
-                                                                   const double *__restrict__ dirs, double r,
-                                                                   double *__restrict__ range,
-                                                                   int32_t *__restrict__ hit_id,
-                                                                   double *__restrict__ ring) {
-  __shared__ double sh[RC_CHUNK * 4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * RC_WAVES + wave;
-  const bool active = i < n_rays;
-  const double dx = active ? dirs[2 * i] : 1.0, dy = active ? dirs[2 * i + 1] : 0.0;
-  double best;
-  int id;
-  wave_first_hit(sh, E, edges, nd, dseg, dids, ex, ey, dx, dy, active, -3, best, id);
-  if (active && lane == 0) {
-    if (!(best <= r)) { best = r; id = -1; }
-    range[i] = best;
-    hit_id[i] = id;
-    if (ring) {
-      ring[2 * i] = ex + best * dx;
-      ring[2 * i + 1] = ey + best * dy;
-    }
+    const double t = ray_segment(ox, oy, dx, dy, ax, ay, bx, by);
+    if (t < best || (t == best && id < best_id)) { best = t; best_id = id; }
   }
 }
 
@@ -201,20 +152,46 @@ __device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full,
   return fan_search(n_rays, dirs, m, last, rx, ry);
 }
 
-// ------------------------------------------------------------------------------------------------ obstacle visibility
-// one workgroup (5 waves) per obstacle, one probe per wave (sensor_model.py:59-76 restated, see oracle)
-__global__ __launch_bounds__(320) void fo_obst_vis_kernel(int E, const double *__restrict__ edges, int nd,
-                                                          const double *__restrict__ dseg,
-                                                          const int32_t *__restrict__ dids,
-                                                          const double *__restrict__ ocorn,
-                                                          const double *__restrict__ ocen,
-                                                          const uint8_t *__restrict__ oflags, double ex, double ey,
-                                                          double r, int full, int n_rays,
-                                                          const double *__restrict__ dirs, uint8_t *__restrict__ vis) {
-  __shared__ double sh[RC_CHUNK * 4];
-  __shared__ int any;
-  const int o = blockIdx.x, p = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (threadIdx.x == 0) any = 0;
+// ------------------------------------------------------------------------------------------------ rays + probes
+// One launch for the ray fan and the obstacle-visibility probes.  Workgroups [0, n_rays): one ray each, its five
+// waves scan interleaved fifths of the soup and the (t, id) minima are combined through LDS.  Workgroups
+// [n_rays, n_rays + O): one obstacle each, wave p casts probe p (4 corners + centre; sensor_model.py:59-76 restated,
+// see oracle) against the whole soup with the obstacle itself left out.
+constexpr int RAY_WAVES = 5;
+__global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const double *__restrict__ edges, int O,
+                                                                 const double *__restrict__ ocorn,
+                                                                 const double *__restrict__ ocen,
+                                                                 const uint8_t *__restrict__ oflags, double ex, double ey,
+                                                                 int n_rays, const double *__restrict__ dirs, double r,
+                                                                 int full, double *__restrict__ range,
+                                                                 int32_t *__restrict__ hit_id, double *__restrict__ ring,
+                                                                 uint8_t *__restrict__ vis) {
+  __shared__ double sh_t[RAY_WAVES];
+  __shared__ int sh_id[RAY_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if ((int)blockIdx.x < n_rays) {
+    const int i = blockIdx.x;
+    const double dx = dirs[2 * i], dy = dirs[2 * i + 1];
+    double best = INFINITY;
+    int id = 0x7fffffff;
+    scan_soup(E, edges, O, ocorn, oflags, wave * 64 + lane, 64 * RAY_WAVES, ex, ey, dx, dy, -3, best, id);
+    wave_min_hit(best, id);
+    if (lane == 0) { sh_t[wave] = best; sh_id[wave] = id; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < RAY_WAVES; ++w)
+        if (sh_t[w] < best || (sh_t[w] == best && sh_id[w] < id)) { best = sh_t[w]; id = sh_id[w]; }
+      if (!(best <= r)) { best = r; id = -1; }
+      range[i] = best;
+      hit_id[i] = id;
+      if (ring) {
+        ring[2 * i] = ex + best * dx;
+        ring[2 * i + 1] = ey + best * dy;
+      }
+    }
+    return;
+  }
+  const int o = blockIdx.x - n_rays, p = wave;
   const bool exists = oflags[o] & 1;
   const double qx = p < 4 ? ocorn[8 * (size_t)o + 2 * p] : ocen[2 * o];
   const double qy = p < 4 ? ocorn[8 * (size_t)o + 2 * p + 1] : ocen[2 * o + 1];
@@ -224,21 +201,24 @@ __global__ __launch_bounds__(320) void fo_obst_vis_kernel(int E, const double *_
   bool direct = false;
   if (cand && dist == 0.0) { direct = true; cand = false; }
   if (cand && fan_sector(n_rays, dirs, full, rx, ry) < 0) cand = false;
-  const double dx = cand ? rx / dist : 1.0, dy = cand ? ry / dist : 0.0;
-  double best;
-  int id;
-  wave_first_hit(sh, E, edges, nd, dseg, dids, ex, ey, dx, dy, cand, E + o, best, id);
-  if (lane == 0) {
-    bool v = direct;
-    if (cand) {
-      double t = best;
-      if (!(t <= dist)) t = dist;  // first_hit(..., rmax = dist)
-      if (t >= dist - 0.01) v = true;
-    }
-    if (v) atomicOr(&any, 1);
+  int v = direct ? 1 : 0;
+  if (cand) {  // wave-uniform
+    const double dx = rx / dist, dy = ry / dist;
+    double best = INFINITY;
+    int id = 0x7fffffff;
+    scan_soup(E, edges, O, ocorn, oflags, lane, 64, ex, ey, dx, dy, E + o, best, id);
+    wave_min_hit(best, id);
+    double t = best;
+    if (!(t <= dist)) t = dist;  // first_hit(..., rmax = dist)
+    if (t >= dist - 0.01) v = 1;
   }
+  if (lane == 0) sh_id[wave] = v;
   __syncthreads();
-  if (threadIdx.x == 0) vis[o] = (uint8_t)(any ? 1 : 0);
+  if (threadIdx.x == 0) {
+    int any = 0;
+    for (int w = 0; w < RAY_WAVES; ++w) any |= sh_id[w];
+    vis[o] = (uint8_t)any;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ cell grid
@@ -246,12 +226,14 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
                                int ix0, int iy0, int nx, int ny, double ex, double ey, double hx, double hy, double r,
                                int full, int n_rays, const double *__restrict__ dirs,
                                const double *__restrict__ range, uint8_t *__restrict__ cls,
-                               uint8_t *__restrict__ occ_flag) {
+                               uint8_t *__restrict__ occ_flag, int32_t *__restrict__ blk) {
+  __shared__ int wsum[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nx * ny) return;
+  const bool in = idx < nx * ny;
+  uint8_t c = 0;
+  if (in) {
   const int ix = idx % nx, iy = idx / nx;
   const int wx = ix0 + ix, wy = iy0 + iy;
-  uint8_t c = 0;
   if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny && raster[(size_t)wy * rnx + wx]) c |= 1;
   const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
   const double rx = px - ex, ry = py - ey;
@@ -274,21 +256,17 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
   if ((c & 1) && !vis && d2 <= ro2 && (rx * hx + ry * hy) >= 0.0) c |= 4;
   cls[idx] = c;
   occ_flag[idx] = (c & 4) ? 1 : 0;
-}
-
-// ------------------------------------------------------------------------------------------------ compaction
-// flags[n] -> ascending index list + count; three launches, no atomics (deterministic order)
-__global__ __launch_bounds__(256) void fo_flag_count_kernel(const uint8_t *__restrict__ flags, int n,
-                                                            int32_t *__restrict__ blk) {
-  __shared__ int wsum[4];
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const bool f = idx < n && flags[idx];
-  const unsigned long long b = __ballot(f);
+  }
+  // block count of the occluded cells (first stage of the compaction, saves a launch)
+  const unsigned long long b = __ballot(in && (c & 4));
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
   __syncthreads();
   if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// ------------------------------------------------------------------------------------------------ compaction
+// flags[n] (+ per-256 block counts from the producing kernel) -> ascending index list + count; two launches, no
+// atomics (deterministic order)
 __global__ __launch_bounds__(1024) void fo_flag_scan_kernel(int32_t *__restrict__ blk, int nb,
                                                             int32_t *__restrict__ total) {
   __shared__ int sh[1024];
@@ -333,12 +311,14 @@ __global__ __launch_bounds__(256) void fo_flag_scatter_kernel(const uint8_t *__r
 // ------------------------------------------------------------------------------------------------ spawn sampling
 __global__ void fo_spawn_flag_kernel(const uint8_t *__restrict__ cls, int nx, int ny, double rx0, double ry0, double cs,
                                      int ix0, int iy0, double ex, double ey, double hx, double hy, double min_ahead,
-                                     double max_dist, int all_occluded, uint8_t *__restrict__ flag) {
+                                     double max_dist, int all_occluded, uint8_t *__restrict__ flag,
+                                     int32_t *__restrict__ blk) {
+  __shared__ int wsum[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nx * ny) return;
-  const int ix = idx % nx, iy = idx / nx;
+  const bool in = idx < nx * ny;
+  const int ix = in ? idx % nx : 0, iy = in ? idx / nx : 0;
   uint8_t f = 0;
-  if (cls[idx] & 4) {
+  if (in && (cls[idx] & 4)) {
     int front = all_occluded;
     if (ix > 0 && (cls[idx - 1] & 2)) front = 1;
     if (ix + 1 < nx && (cls[idx + 1] & 2)) front = 1;
@@ -350,29 +330,11 @@ __global__ void fo_spawn_flag_kernel(const uint8_t *__restrict__ cls, int nx, in
       if (!(rx * hx + ry * hy < min_ahead) && !(rx * rx + ry * ry > max_dist * max_dist)) f = 1;
     }
   }
-  flag[idx] = f;
-}
-
-__global__ void fo_spawn_pick_kernel(const int32_t *__restrict__ cand, const int32_t *__restrict__ n_cand, int nx,
-                                     double rx0, double ry0, double cs, int ix0, int iy0, int max_agents,
-                                     int32_t *__restrict__ cell, double *__restrict__ pos,
-                                     int32_t *__restrict__ n_out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = *n_cand;
-  const int m = n < max_agents ? n : max_agents;
-  if (j == 0) *n_out = m;
-  if (j >= max_agents) return;
-  if (j < m) {
-    const int pick = (n <= max_agents) ? j : (int)(((long long)j * n) / max_agents);
-    const int ci = cand[pick];
-    cell[j] = ci;
-    pos[2 * j] = rx0 + ((double)(ix0 + ci % nx) + 0.5) * cs;
-    pos[2 * j + 1] = ry0 + ((double)(iy0 + ci / nx) + 0.5) * cs;
-  } else {
-    cell[j] = -1;
-    pos[2 * j] = 0.0;
-    pos[2 * j + 1] = 0.0;
-  }
+  if (in) flag[idx] = f;
+  const unsigned long long b = __ballot(f != 0);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 struct SpawnTypes {  // per pattern slot (j % 4): type code, speed, raw dims, inflated dims
@@ -380,25 +342,37 @@ struct SpawnTypes {  // per pattern slot (j % 4): type code, speed, raw dims, in
   double speed[4], raw_l[4], raw_w[4], infl_l[4], infl_w[4];
 };
 
-// heading per phantom: pedestrians -> unit vector to the closest point of the ego reference path
-// (agent.py:475-481 + helper_functions.py:38-76); vehicles -> lane heading raster at their cell
-__global__ void fo_spawn_heading_kernel(int max_agents, const int32_t *__restrict__ n_ptr,
-                                        const int32_t *__restrict__ cell, const double *__restrict__ pos,
-                                        SpawnTypes st, int N, const double *__restrict__ path,
-                                        const double *__restrict__ lane_yaw, int rnx, int rny, int nx, int ix0, int iy0,
-                                        double *__restrict__ yaw) {
+// evenly spaced pick of the candidates + heading per phantom: pedestrians -> unit vector to the closest point of the
+// ego reference path (agent.py:475-481 + helper_functions.py:38-76); vehicles -> lane heading raster at their cell
+__global__ void fo_spawn_pick_kernel(const int32_t *__restrict__ cand, const int32_t *__restrict__ n_cand, int nx,
+                                     double rx0, double ry0, double cs, int ix0, int iy0, int max_agents, SpawnTypes st,
+                                     int N, const double *__restrict__ path, const double *__restrict__ lane_yaw,
+                                     int rnx, int rny, int32_t *__restrict__ cell, double *__restrict__ pos,
+                                     double *__restrict__ yaw, int32_t *__restrict__ n_out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = *n_cand;
+  const int m = n < max_agents ? n : max_agents;
+  if (j == 0) *n_out = m;
   if (j >= max_agents) return;
-  if (j >= *n_ptr) { yaw[j] = 0.0; return; }
+  if (j >= m) {
+    cell[j] = -1;
+    pos[2 * j] = 0.0;
+    pos[2 * j + 1] = 0.0;
+    yaw[j] = 0.0;
+    return;
+  }
+  const int pick = (n <= max_agents) ? j : (int)(((long long)j * n) / max_agents);
+  const int ci = cand[pick];
+  const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
+  const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
+  cell[j] = ci;
+  pos[2 * j] = px;
+  pos[2 * j + 1] = py;
   const int type = st.type[j & 3];
   double a = NAN;
-  if (type != FO_TYPE_PEDESTRIAN && lane_yaw) {
-    const int ci = cell[j];
-    const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
-    if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny) a = lane_yaw[(size_t)wy * rnx + wx];
-  }
+  if (type != FO_TYPE_PEDESTRIAN && lane_yaw && wx >= 0 && wx < rnx && wy >= 0 && wy < rny)
+    a = lane_yaw[(size_t)wy * rnx + wx];
   if (isnan(a)) {
-    const double px = pos[2 * j], py = pos[2 * j + 1];
     double best = INFINITY, qx = px, qy = py;
     for (int i = 0; i + 1 < N; ++i) {
       const double ax = path[2 * i], ay = path[2 * i + 1], bx = path[2 * i + 2], by = path[2 * i + 3];
@@ -415,9 +389,9 @@ __global__ void fo_spawn_heading_kernel(int max_agents, const int32_t *__restric
       if (d2 < best) { best = d2; qx = cx; qy = cy; }
     }
     const double vx = qx - px, vy = qy - py;
-    const double n = sqrt(vx * vx + vy * vy);
+    const double nn = sqrt(vx * vx + vy * vy);
     double ux = 1.0, uy = 0.0;
-    if (n > 0.0) { ux = vx / n; uy = vy / n; }
+    if (nn > 0.0) { ux = vx / nn; uy = vy / nn; }
     a = atan2(uy, ux);
     if (a < 0.0) a += 2.0 * M_PI;
   }
@@ -467,8 +441,7 @@ int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
 
 // flags -> ascending indices (out) + count (d_total)
 int compact(fo_ctx *ctx, Scene *sc, const uint8_t *flags, int n, int32_t *out, int32_t *d_total, hipStream_t s) {
-  const int nb = (n + 255) / 256;
-  hipLaunchKernelGGL(fo_flag_count_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk);
+  const int nb = (n + 255) / 256;  // block counts were written by the kernel that produced the flags
   hipLaunchKernelGGL(fo_flag_scan_kernel, dim3(1), dim3(1024), 0, s, sc->d_blk, nb, d_total);
   hipLaunchKernelGGL(fo_flag_scatter_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk, out);
   FO_HIP_TRY(ctx, hipGetLastError());
@@ -482,7 +455,7 @@ extern "C" {
 void fo_scene_destroy_(fo_ctx *ctx) {
   if (!ctx || !ctx->scene) return;
   Scene *sc = (Scene *)ctx->scene;
-  void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_dyn_edges, sc->d_dyn_ids, sc->d_flags, sc->d_blk,
+  void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_flags, sc->d_blk,
                   sc->d_cand, sc->d_ncand};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -585,25 +558,15 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  const int nd = O * 4;
-  if (nd > 0) {
-    if ((rc = fo_reserve(ctx, &sc->d_dyn_edges, &sc->cap_dyn, (size_t)nd * 4))) return rc;
-    if ((rc = fo_reserve(ctx, &sc->d_dyn_ids, &sc->cap_dyn_ids, (size_t)nd))) return rc;
-    hipLaunchKernelGGL(fo_obst_edges_kernel, dim3((nd + 255) / 256), dim3(256), 0, s, O, sc->E, d_ocorn, d_oflags,
-                       sc->d_dyn_edges, sc->d_dyn_ids);
-  }
-  hipLaunchKernelGGL(fo_raycast_kernel, dim3((n_rays + RC_WAVES - 1) / RC_WAVES), dim3(64 * RC_WAVES), 0, s, sc->E,
-                     sc->d_edges, nd, sc->d_dyn_edges, sc->d_dyn_ids, ego_x, ego_y, n_rays, d_dirs, r, d_range,
-                     d_hit_id, d_ring);
-  if (O > 0 && d_obst_vis)
-    hipLaunchKernelGGL(fo_obst_vis_kernel, dim3(O), dim3(320), 0, s, sc->E, sc->d_edges, nd, sc->d_dyn_edges,
-                       sc->d_dyn_ids, d_ocorn, d_ocen, d_oflags, ego_x, ego_y, r, full_circle, n_rays, d_dirs,
-                       d_obst_vis);
+  const int n_probe_blocks = (O > 0 && d_obst_vis) ? O : 0;
+  hipLaunchKernelGGL(fo_rays_kernel, dim3(n_rays + n_probe_blocks), dim3(64 * RAY_WAVES), 0, s, sc->E, sc->d_edges, O,
+                     d_ocorn, d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, full_circle, d_range, d_hit_id, d_ring,
+                     d_obst_vis);
   const int cells = win_nx * win_ny;
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
   hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->d_raster, sc->rnx, sc->rny, sc->x0,
                      sc->y0, sc->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
-                     n_rays, d_dirs, d_range, d_cls, sc->d_flags);
+                     n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk);
   FO_HIP_TRY(ctx, hipGetLastError());
   return compact(ctx, sc, sc->d_flags, cells, d_occ_idx, d_n_occ, s);
 }
@@ -629,17 +592,16 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
   if ((rc = fo_reserve(ctx, &sc->d_cand, &sc->cap_cand, (size_t)cells))) return rc;
   hipLaunchKernelGGL(fo_spawn_flag_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, d_cls, win_nx, win_ny, sc->x0,
                      sc->y0, sc->cs, win_ix0, win_iy0, ego_x, ego_y, head_x, head_y, min_ahead, max_dist, all_occluded ? 1 : 0,
-                     sc->d_flags);
+                     sc->d_flags, sc->d_blk);
   if ((rc = compact(ctx, sc, sc->d_flags, cells, sc->d_cand, sc->d_ncand, s))) return rc;
-  hipLaunchKernelGGL(fo_spawn_pick_kernel, dim3((max_agents + 63) / 64), dim3(64), 0, s, sc->d_cand, sc->d_ncand, win_nx,
-                     sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, max_agents, d_cell, d_pos0, d_n);
   SpawnTypes st;
   for (int i = 0; i < 4; ++i) {
     st.type[i] = type4[i]; st.speed[i] = speed4[i]; st.raw_l[i] = raw_l4[i]; st.raw_w[i] = raw_w4[i];
     st.infl_l[i] = infl_l4[i]; st.infl_w[i] = infl_w4[i];
   }
-  hipLaunchKernelGGL(fo_spawn_heading_kernel, dim3((max_agents + 63) / 64), dim3(64), 0, s, max_agents, d_n, d_cell,
-                     d_pos0, st, n_path, d_path, sc->d_lane_yaw, sc->rnx, sc->rny, win_nx, win_ix0, win_iy0, d_yaw0);
+  hipLaunchKernelGGL(fo_spawn_pick_kernel, dim3((max_agents + 63) / 64), dim3(64), 0, s, sc->d_cand, sc->d_ncand, win_nx,
+                     sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, max_agents, st, n_path, d_path, sc->d_lane_yaw, sc->rnx,
+                     sc->rny, d_cell, d_pos0, d_yaw0, d_n);
   const int n = max_agents * T;
   hipLaunchKernelGGL(fo_spawn_predict_kernel, dim3((n + 255) / 256), dim3(256), 0, s, max_agents, d_n, d_pos0, d_yaw0, st,
                      T, dt, var0, var_factor, d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len);

@@ -58,17 +58,19 @@ int fo_oracle_road_raster(int P, const int32_t *poly_off, const double *poly_xy,
 }
 
 /* ---------------------------------------------------------------- first hit of one ray against the occluder soup
- * Ray o + t d (d unit), segment a + u (b - a):  denom = d x e;  t = (w x e)/denom, u = (w x d)/denom, w = a - o.
- * Hit iff denom != 0, t >= 0, 0 <= u <= 1.  First hit = lexicographic minimum of (t, id).  Returns t (or +inf). */
+ * Ray o + t d (d unit), segment a + u (b - a):  denom = d x e,  tn = w x e,  un = w x d,  w = a - o.
+ * Hit iff denom != 0, 0 <= tn/denom and 0 <= un/denom <= 1 -- decided on the signs of the numerators, so the
+ * rejection path has no division; t = tn / denom for hits.  First hit = lexicographic minimum of (t, id).
+ * Returns t (or +inf). */
 static double ray_segment(double ox, double oy, double dx, double dy, double ax, double ay, double bx, double by) {
   const double ex = bx - ax, ey = by - ay;
   const double denom = dx * ey - dy * ex;
   if (denom == 0.0) return INFINITY;
   const double wx = ax - ox, wy = ay - oy;
-  const double t = (wx * ey - wy * ex) / denom;
-  const double u = (wx * dy - wy * dx) / denom;
-  if (t >= 0.0 && u >= 0.0 && u <= 1.0) return t;
-  return INFINITY;
+  const double tn = wx * ey - wy * ex;
+  const double un = wx * dy - wy * dx;
+  const int hit = denom > 0.0 ? (tn >= 0.0 && un >= 0.0 && un <= denom) : (tn <= 0.0 && un <= 0.0 && un >= denom);
+  return hit ? tn / denom : INFINITY;
 }
 
 /* occluder ids: 0..E-1 map boundary edges, E + o for obstacle o (any of its four sides); -1 = nothing within range.
