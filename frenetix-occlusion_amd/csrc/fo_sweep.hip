@@ -251,6 +251,35 @@ __device__ __forceinline__ double fo_lr4s_coef(double ang, double side, double r
   return rear;  // un-wrapped angle: everything else is "rear" (Q5)
 }
 
+// LR4S angle classes without atan2 (queue kernel).  The reference bins the UN-wrapped angle ang = rel - heading,
+// rel = atan2(dy, dx) in (-pi, pi]  (logistic_regression.py:28-42, Q5): front |ang| < pi/4, side pi/4 <= |ang| < 3pi/4,
+// rear otherwise.  Write ang = phi + 2 pi k with phi the wrapped angle: k != 0 implies |ang| >= pi, i.e. rear, and for
+// k == 0 the class of phi follows exactly from the signs of  S = d x h  and  C = d . h  (h = unit heading):
+// front  C > |S|,  rear  -C >= |S|,  side otherwise.  k != 0 <=> |rel - heading| > pi only has to be decided when phi is
+// not rear, where |rel - heading| is either < 3pi/4 or > 5pi/4 -- a float32 atan2 estimate (error < 0.01) is enough.
+__device__ __forceinline__ float fo_atan2_crude(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float a = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
+  float r = a * (0.78539816f + 0.273f * (1.0f - a));
+  if (ay > ax) r = 1.57079633f - r;
+  if (x < 0.0f) r = 3.14159265f - r;
+  return copysignf(r, y);
+}
+// coefficient of the class: 0 (front), side, rear.  (dx, dy): from the vehicle whose occupants are rated to the other
+// party, as seen by atan2; `turn` = what is added to rel before the heading is subtracted (0 for the ego, pi for the
+// obstacle: obs_ang = pi + rel - yaw, harm_model.py:89-90).
+__device__ __forceinline__ double fo_lr4s_coef_dir(double dx, double dy, double hc, double hs, float rel_crude, float turn,
+                                                   double heading, double side, double rear) {
+  const double sg = (turn != 0.0f) ? -1.0 : 1.0;  // direction of angle rel + turn
+  const double S = sg * (dy * hc - dx * hs), Cc = sg * (dx * hc + dy * hs);
+  const double aS = fabs(S);
+  const bool unwrapped_far = fabsf(turn + rel_crude - (float)heading) > 3.14159265f;
+  if (unwrapped_far || -Cc >= aS) return rear;
+  if (Cc > aS) return 0.0;
+  return side;
+}
+
 // squared distance from point (px,py) to the axis-aligned box [-hl,hl]x[-hw,hw]
 __device__ __forceinline__ double fo_pt_box2(double px, double py, double hl, double hw) {
   const double qx = fmax(fabs(px) - hl, 0.0), qy = fmax(fabs(py) - hw, 0.0);
@@ -811,11 +840,14 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
             const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
             if (lr4s) {
-              const double rel = atan2(gy - ey0, gx - ex0);  // the impact angles only enter the LR4S model
-              const double ego_ang = rel - eth0;
-              const double obs_ang = M_PI + rel - gyaw;
-              eh = fo_logistic_neg(exp_tab, c4 + s4c * ego_dv - fo_lr4s_coef(ego_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
-              oh = fo_logistic_neg(exp_tab, c4 + s4c * obs_dv - fo_lr4s_coef(obs_ang, a.hc.lr4s_side, a.hc.lr4s_rear));
+              // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
+              double ddx = gx - ex0, ddy = gy - ey0;
+              if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;  // atan2(0, 0) = 0
+              const float relc = fo_atan2_crude((float)ddy, (float)ddx);
+              const double ke = fo_lr4s_coef_dir(ddx, ddy, ec0, es0, relc, 0.0f, eth0, a.hc.lr4s_side, a.hc.lr4s_rear);
+              const double ko = fo_lr4s_coef_dir(ddx, ddy, pc, ps, relc, 3.14159265f, gyaw, a.hc.lr4s_side, a.hc.lr4s_rear);
+              eh = fo_logistic_neg(exp_tab, c4 + s4c * ego_dv - ke);
+              oh = fo_logistic_neg(exp_tab, c4 + s4c * obs_dv - ko);
             } else if (prot == 0) {
               eh = fo_logistic_neg(exp_tab, c1 + s1c * ego_dv);
               oh = fo_logistic_neg(exp_tab, a.hc.ped_const - a.hc.ped_speed * obs_dv);
