@@ -591,6 +591,32 @@ __device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab
   return y;
 }
 
+// Rounded distance (whole millimetres, rint(1000 d) = 1000 np.round(d, 3), dce.py:79) between the ego rectangle at
+// rear-axle pose (ex, ey, heading (ec, es)) and the agent rectangle at (px, py, heading (pc, ps)): four-axis SAT
+// (overlap -> 0), otherwise the minimum over the eight corner-to-box distances.
+__device__ __forceinline__ double fo_rect_mm(double ex, double ey, double ec, double es, double px, double py, double pc,
+                                             double ps, double hlA, double hwA, double wb, double hlB, double hwB) {
+  const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
+  const double ccx = ex + wb * ec, ccy = ey + wb * es;  // convert_dynamic_obstacle.py:73
+  const double dx = px - ccx, dy = py - ccy;
+  const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;
+  const double ux = hlB * cr, uy = hlB * sr, wx = -hwB * sr, wy = hwB * cr;
+  const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);
+  const double vx = hlA * cr, vy = -hlA * sr, zx = hwA * sr, zy = hwA * cr;
+  const double s1 = fabs(ax) - (hlA + fabs(ux) + fabs(wx)), s2 = fabs(ay) - (hwA + fabs(uy) + fabs(wy));
+  const double s3 = fabs(bx) - (hlB + fabs(vx) + fabs(zx)), s4 = fabs(by) - (hwB + fabs(vy) + fabs(zy));
+  if (!(fmax(fmax(s1, s2), fmax(s3, s4)) > 0.0)) return 0.0;
+  double d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, hlA, hwA);
+  d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, hlA, hwA));
+  d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, hlA, hwA));
+  d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, hlA, hwA));
+  d2 = fmin(d2, fo_pt_box2(bx + vx + zx, by + vy + zy, hlB, hwB));
+  d2 = fmin(d2, fo_pt_box2(bx + vx - zx, by + vy - zy, hlB, hwB));
+  d2 = fmin(d2, fo_pt_box2(bx - vx + zx, by - vy + zy, hlB, hwB));
+  d2 = fmin(d2, fo_pt_box2(bx - vx - zx, by - vy - zy, hlB, hwB));
+  return __builtin_rint(fo_sqrt(d2) * 1000.0);
+}
+
 // wave-uniform tables are read through the constant address space: the loads become s_load (scalar cache, results in
 // SGPRs) instead of 64-lane broadcasts through the vector memory path.  The tables are written by an earlier launch
 // (fo_prep_agents_kernel), so the scalar cache is coherent with them.
@@ -655,11 +681,38 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       continue;
     }
 
-    // Per-agent state that lives across the time chunks.  dce is kept in whole millimetres: rint(1000 d) orders
-    // exactly like np.round(d, 3) (dce.py:79); dce_m2 is the squared distance a sample has to undercut to become a
-    // new strict minimum, so the corner work and the square root are skipped whenever a cheap lower bound exceeds it.
-    double dce = INFINITY, dce_m2 = INFINITY;
+    // Per-agent state that lives across the time chunks.
+    // DCE (dce.py:69-99) = the minimum over t of the rounded rectangle distance and the EARLIEST t that attains it (the
+    // reference's early stop at 0 only cuts samples after the first zero) -- a result that does not depend on the
+    // order in which the samples are visited.  So a probe phase first finds, per lane, the sample where the reference
+    // points are closest (a cheap loop over t) and evaluates the exact distance there; the time-ordered loop below
+    // then only pays for the exact geometry of samples whose lower bound (centre distance minus circumradii, then
+    // the four SAT separations) can still reach the running minimum or tie it -- a wave-level skip otherwise.
+    // dce is kept in whole millimetres; thr2 = ((dce + 0.51) mm)^2 and thrR2 = ((dce + 0.51) mm + R)^2 are what the SAT
+    // bound and the centre distance have to undercut (0.51: a sample that rounds to the same millimetre may still
+    // win the tie on t).
+    double dce = INFINITY, thr2 = INFINITY, thrR2 = INFINITY;
     int tdce = 0;
+    const double Rsum = sqrt(hlA * hlA + hwA * hwA) + sqrt(hlB * hlB + hwB * hwB);
+    if (do_dce && !(a.ablate & 1)) {
+      const int Ld = min(L, T);
+      double bestc = INFINITY;
+      int tb = 0;
+      for (int t = 0; t < Ld; ++t) {
+        const double *e = tj + (size_t)t * NEF * TILE;
+        const cdp_t g = G + (size_t)t * NAF;
+        const double rx = g[0] - e[0 * TILE], ry = g[1] - e[1 * TILE];
+        const double c2 = rx * rx + ry * ry;
+        if (c2 < bestc) { bestc = c2; tb = t; }
+      }
+      const double *e = tj + (size_t)tb * NEF * TILE;                   // per-lane sample: gathers
+      const double *g = a.atab + ((size_t)k * a.Ta + tb) * NAF;
+      dce = fo_rect_mm(e[0 * TILE], e[1 * TILE], e[2 * TILE], e[3 * TILE], g[0], g[1], g[2], g[3], hlA, hwA, a.wb, hlB, hwB);
+      tdce = tb;
+      const double thr = (dce + 0.51) * 1e-3;
+      thr2 = thr * thr;
+      thrR2 = (thr + Rsum) * (thr + Rsum);
+    }
     double max_er = -INFINITY, max_or = -INFINITY, max_eh = -INFINITY, max_oh = -INFINITY, max_cp = -INFINITY;
     double oh_at_cp = 0.0;
     int idx_or = 0, idx_cp = 0;
@@ -667,6 +720,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     double *lp = LISTS ? a.lists + (size_t)k * Tm1 * M + m : nullptr;
     const double c4 = -a.hc.lr4s_const, s4c = -a.hc.lr4s_speed, c1 = -a.hc.lr1s_const, s1c = -a.hc.lr1s_speed;
     const bool lr4s = prot == 1;
+    const double gate_far2 = (5.0 + hdev + 1e-6) * (5.0 + hdev + 1e-6);
 
     // The horizon is walked in chunks of TC iterations.  Iteration t evaluates DCE(t) and the gate of sample t-1
     // (ego t, agent mean t-1, agent heading t: Q1), so chunk [t0, t1) owns the gate samples [t0-1, t1-1); their
@@ -733,49 +787,61 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
           const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
           npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3];
         }
-        if (do_dce && t < L && !(a.ablate & 1)) {  // dce == 0: the reference stops scanning (dce.py:85-88)
-          const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
+        if (do_dce && t < L && !(a.ablate & 1)) {
           const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
           const double dx = px - ccx, dy = py - ccy;
-          const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;   // agent centre in the ego frame
-          const double ux = hlB * cr, uy = hlB * sr, wx = -hwB * sr, wy = hwB * cr;
-          const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);  // ego centre in the agent frame
-          const double vx = hlA * cr, vy = -hlA * sr, zx = hwA * sr, zy = hwA * cr;
-          // separations along the four face normals: each is a lower bound of the distance, all <= 0 iff overlapping
-          const double s1 = fabs(ax) - (hlA + fabs(ux) + fabs(wx)), s2 = fabs(ay) - (hwA + fabs(uy) + fabs(wy));
-          const double s3 = fabs(bx) - (hlB + fabs(vx) + fabs(zx)), s4 = fabs(by) - (hwB + fabs(vy) + fabs(zy));
-          const double lb = fmax(fmax(s1, s2), fmax(s3, s4));
-          const bool live = dce != 0.0;
-          if (live && !(lb > 0.0)) {  // overlapping rectangles: distance 0, the scan ends here
-            dce = 0.0; dce_m2 = 0.0; tdce = t;
-          }
-          const bool need = live && lb > 0.0 && lb * lb < dce_m2;
-          if (__ballot(need)) {  // wave-uniform: no lane can reach a new minimum -> the corner work is skipped
-            double d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, hlA, hwA);
-            d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, hlA, hwA));
-            d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, hlA, hwA));
-            d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, hlA, hwA));
-            d2 = fmin(d2, fo_pt_box2(bx + vx + zx, by + vy + zy, hlB, hwB));
-            d2 = fmin(d2, fo_pt_box2(bx + vx - zx, by + vy - zy, hlB, hwB));
-            d2 = fmin(d2, fo_pt_box2(bx - vx + zx, by - vy + zy, hlB, hwB));
-            d2 = fmin(d2, fo_pt_box2(bx - vx - zx, by - vy - zy, hlB, hwB));
-            if (need && d2 < dce_m2) {
-              const double nmm = __builtin_rint(fo_sqrt(d2) * 1000.0);
-              if (nmm < dce) { dce = nmm; tdce = t; dce_m2 = (nmm * 1e-3) * (nmm * 1e-3); }
+          // nothing to gain after the (earliest) zero; otherwise the centres must be close enough
+          const bool near = !(dce == 0.0 && t > tdce) && (dx * dx + dy * dy < thrR2);
+          if (__ballot(near)) {
+            const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
+            const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;   // agent centre in the ego frame
+            const double ux = hlB * cr, uy = hlB * sr, wx = -hwB * sr, wy = hwB * cr;
+            const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);  // ego centre in the agent frame
+            const double vx = hlA * cr, vy = -hlA * sr, zx = hwA * sr, zy = hwA * cr;
+            // separations along the four face normals: each is a lower bound of the distance, all <= 0 iff overlapping
+            const double s1 = fabs(ax) - (hlA + fabs(ux) + fabs(wx)), s2 = fabs(ay) - (hwA + fabs(uy) + fabs(wy));
+            const double s3 = fabs(bx) - (hlB + fabs(vx) + fabs(zx)), s4 = fabs(by) - (hwB + fabs(vy) + fabs(zy));
+            const double lb = fmax(fmax(s1, s2), fmax(s3, s4));
+            const bool overlap = !(lb > 0.0);
+            const bool need = near && (overlap || lb * lb < thr2);
+            if (__ballot(need)) {
+              double nmm = 0.0;
+              if (__ballot(need && !overlap)) {
+                double d2 = fo_pt_box2(ax + ux + wx, ay + uy + wy, hlA, hwA);
+                d2 = fmin(d2, fo_pt_box2(ax + ux - wx, ay + uy - wy, hlA, hwA));
+                d2 = fmin(d2, fo_pt_box2(ax - ux + wx, ay - uy + wy, hlA, hwA));
+                d2 = fmin(d2, fo_pt_box2(ax - ux - wx, ay - uy - wy, hlA, hwA));
+                d2 = fmin(d2, fo_pt_box2(bx + vx + zx, by + vy + zy, hlB, hwB));
+                d2 = fmin(d2, fo_pt_box2(bx + vx - zx, by + vy - zy, hlB, hwB));
+                d2 = fmin(d2, fo_pt_box2(bx - vx + zx, by - vy + zy, hlB, hwB));
+                d2 = fmin(d2, fo_pt_box2(bx - vx - zx, by - vy - zy, hlB, hwB));
+                if (!overlap) nmm = __builtin_rint(fo_sqrt(d2) * 1000.0);
+              }
+              if (need && (nmm < dce || (nmm == dce && t < tdce))) {
+                dce = nmm;
+                tdce = t;
+                const double thr = (nmm + 0.51) * 1e-3;
+                thr2 = thr * thr;
+                thrR2 = (thr + Rsum) * (thr + Rsum);
+              }
             }
           }
         }
         if (do_cp && t >= 1 && t < L && !(a.ablate & 2)) {
           // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
-          const double devx = pc * hdev, devy = ps * hdev;
           const double rx = ex - ppx, ry = ey - ppy;
           const double d0 = rx * rx + ry * ry;
-          const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
-          const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
-          const double m2 = fmin(d0, fmin(dp, dm));
-          bool ing = m2 <= 25.0;
-          if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);  // keep the reference's test on the rounded sqrt
-          ing = ing && valid;
+          bool ing = false;
+          // the two displaced means are hdev away from the mean: beyond 5 m + hdev none of the three can be in the gate
+          if (__ballot(d0 <= gate_far2)) {
+            const double devx = pc * hdev, devy = ps * hdev;
+            const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
+            const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
+            const double m2 = fmin(d0, fmin(dp, dm));
+            ing = m2 <= 25.0;
+            if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);  // keep the reference's test on the rounded sqrt
+            ing = ing && valid;
+          }
           const unsigned long long bal = __ballot(ing);
           if (bal) {
             const int row = t - t0;  // = (t - 1) - gbase
