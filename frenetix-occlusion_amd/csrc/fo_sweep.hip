@@ -698,12 +698,24 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       const int Ld = min(L, T);
       double bestc = INFINITY;
       int tb = 0;
-      for (int t = 0; t < Ld; ++t) {
-        const double *e = tj + (size_t)t * NEF * TILE;
-        const cdp_t g = G + (size_t)t * NAF;
-        const double rx = g[0] - e[0 * TILE], ry = g[1] - e[1 * TILE];
-        const double c2 = rx * rx + ry * ry;
-        if (c2 < bestc) { bestc = c2; tb = t; }
+      // latency-bound by construction (two loads, five operations per sample): eight samples in flight at a time
+#pragma unroll 1
+      for (int t8 = 0; t8 < Ld; t8 += 8) {
+        double vx[8], vy[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double *e = tj + (size_t)min(t8 + u, Ld - 1) * NEF * TILE;
+          vx[u] = e[0 * TILE];
+          vy[u] = e[1 * TILE];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = min(t8 + u, Ld - 1);  // repeats of the last sample cannot win (strict <)
+          const cdp_t g = G + (size_t)t * NAF;
+          const double rx = g[0] - vx[u], ry = g[1] - vy[u];
+          const double c2 = rx * rx + ry * ry;
+          if (c2 < bestc) { bestc = c2; tb = t; }
+        }
       }
       const double *e = tj + (size_t)tb * NEF * TILE;                   // per-lane sample: gathers
       const double *g = a.atab + ((size_t)k * a.Ta + tb) * NAF;

@@ -1,0 +1,137 @@
+"""The BASELINE.json configurations as parity cases on a real MI355X (configs[2] is the bench line; the others are
+exercised here): each runs through FOInterface -- visibility, phantom sampling, batched assessment -- and is compared
+with the oracle fed with the same phantom predictions."""
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+COLS = ("wttc", "min_dce", "max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
+        "max_collision_probability_all", "max_obst_harm_with_cp_all", "min_ttce", "argmin_dce", "argmin_ttc", "safe")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _interface(tmp_path, scenario_file, ego, metrics=None, thresholds=None, spawn=None, name="occ.yaml"):
+    import yaml
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion import synthetic as SY
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    if metrics:
+        cfg["metrics"]["activated_metrics"] = list(metrics)
+    if thresholds:
+        cfg["metrics"]["metric_thresholds"].update(thresholds)
+    if spawn:
+        cfg["accelerator"]["spawn"].update(spawn)
+    p = tmp_path / name
+    p.write_text(yaml.safe_dump(cfg))
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, scenario_file))
+    ego = sc.ego_initial if ego is None else np.asarray(ego, dtype=np.float64)
+    ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+    v = SY.VEHICLE_BMW320I
+    veh = SimpleNamespace(length=v[0], width=v[1], wb_rear_axle=v[2], mass=v[3], a_max=v[4])
+    return interface.FOInterface(sc, ref_path, veh, 0.1, config_path=str(p)), sc, ego, SY
+
+
+def _agents_of(fo):
+    arrs = fo.agent_manager.sweep_arrays()
+    return dict(zip(("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len"), [t.cpu().numpy() for t in arrs]))
+
+
+def _compare_cost(oracle, got, ref):
+    for name in COLS:
+        a, b = ref[:, oracle.COST[name]], got[:, oracle.COST[name]]
+        assert np.array_equal(np.isinf(a), np.isinf(b)), name
+        f = np.isfinite(a)
+        np.testing.assert_allclose(b[f], a[f], rtol=0, atol=1e-9, err_msg=name)
+
+
+def test_config1_scenario1_default_sampling_hr_ttc(torch_cuda, oracle, tmp_path):
+    """configs[0]: scenario1, ~200 candidate trajectories, activated metrics ['hr', 'ttc'] (=> cp, dce, ttc, hr)."""
+    thr = {"harm": 0.1, "risk": 1}
+    fo, sc, ego, SY = _interface(tmp_path, "scenario1_geometry.npz", None, metrics=("hr", "ttc"), thresholds=thr)
+    for timestep in (0, 5):
+        e = ego.copy()
+        e[0] += 0.7634 * timestep * math.cos(e[2])
+        e[1] += 0.7634 * timestep * math.sin(e[2])
+        fo.evaluate_scenario({}, e[:2], float(e[2]), (0.0, 0.0), float(e[3]), timestep, None)
+        assert len(fo.spawn_points) > 0
+        traj = SY.make_trajectories(200, seed=7 + timestep, ego_pos=e[:2], ego_yaw=float(e[2]))
+        ba = fo.trajectory_safety_assessment_batch(traj, mode="pair")
+        torch_cuda.cuda.synchronize()
+        ref = oracle.sweep(traj, _agents_of(fo), SY.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), thr=thr, want_lists=False)
+        got = ba.cost.cpu().numpy()
+        _compare_cost(oracle, got, ref["cost"])
+        assert np.array_equal(ba.safe.cpu().numpy(), ref["safe"])
+        assert np.isnan(ba.result.pair_f[oracle.PF["ttce"]].cpu().numpy()).all()       # ttce was not activated
+
+
+def test_config2_scenario1_2k_x_32_full_metric_set(torch_cuda, oracle, tmp_path):
+    """configs[1]: scenario1, 2 000 trajectories x 32 phantom predictions, the default six metrics."""
+    thr = {"harm": 0.1, "risk": 1}
+    fo, sc, ego, SY = _interface(tmp_path, "scenario1_geometry.npz", None, thresholds=thr,
+                                 spawn=dict(max_agents=32, all_occluded=True, max_dist=40.0))
+    fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    assert len(fo.spawn_points) == 32
+    kinds = {sp.agent_type for sp in fo.spawn_points}
+    assert kinds == {"Pedestrian", "Bicycle", "Car"}
+    traj = SY.make_trajectories(2000, seed=2, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    ba = fo.trajectory_safety_assessment_batch(traj, mode="full")
+    torch_cuda.cuda.synchronize()
+    ref = oracle.sweep(traj, _agents_of(fo), SY.VEHICLE_BMW320I, 0.1, thr=thr, nthreads=8)
+    _compare_cost(oracle, ba.cost.cpu().numpy(), ref["cost"])
+    assert np.array_equal(ba.safe.cpu().numpy(), ref["safe"])
+    lists = ba.result.lists.permute(3, 1, 0, 2).cpu().numpy()
+    assert np.array_equal(np.isnan(lists), np.isnan(ref["lists"]))
+    f = np.isfinite(ref["lists"])
+    assert np.abs(lists[f] - ref["lists"][f]).max() < 1e-9
+    tdce = ba.result.pair_i.permute(2, 1, 0).cpu().numpy()[..., oracle.PI["time_dce"]]
+    assert np.array_equal(tdce, ref["pair_i"][..., oracle.PI["time_dce"]])
+    assert 0 < ref["safe"].mean() < 1
+
+
+def test_config5_multi_ego_four_interfaces_share_the_gpu(torch_cuda, oracle, tmp_path):
+    """configs[4]: 4 egos x 2 000 trajectories on the scenario2/3 geometry, one FOInterface (one fo_ctx) per ego.
+    The XMLs hold one planning problem each: three more ego poses are placed along lanelet centre lines."""
+    from frenetix_occlusion import scenario as S
+    sc0 = S.load_geometry_npz(os.path.join(GOLDEN, "scenario2_geometry.npz"))
+    poses = [sc0.ego_initial.copy()]
+    for ll in sc0.lanelets:
+        c = ll.center
+        if len(c) >= 4 and len(poses) < 4:
+            i = len(c) // 3
+            yaw = math.atan2(c[i + 1, 1] - c[i, 1], c[i + 1, 0] - c[i, 0])
+            poses.append(np.array([c[i, 0], c[i, 1], yaw, 6.0]))
+    assert len(poses) == 4
+    thr = {"harm": 0.1, "risk": 1}
+    egos = [_interface(tmp_path, "scenario2_geometry.npz" if i % 2 == 0 else "scenario3_geometry.npz", p, thresholds=thr,
+                       spawn=dict(max_agents=16, all_occluded=True, max_dist=40.0), name=f"occ{i}.yaml")
+            for i, p in enumerate(poses)]
+    results = []
+    for fo, sc, ego, SY in egos:          # all four steps are queued before anything is read back
+        fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+        traj = SY.make_trajectories(2000, seed=11, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+        results.append((traj, fo.trajectory_safety_assessment_batch(traj, mode="reduced")))
+    torch_cuda.cuda.synchronize()
+    n_with_agents = 0
+    for (fo, sc, ego, SY), (traj, ba) in zip(egos, results):
+        if ba is None:                    # an ego pose without occluded cells ahead: nothing to assess (metric.py:44-45)
+            assert not fo.agent_manager.has_phantoms()
+            continue
+        n_with_agents += 1
+        sub = {k: v[:300] for k, v in traj.items()}
+        ref = oracle.sweep(sub, _agents_of(fo), SY.VEHICLE_BMW320I, 0.1, thr=thr, want_lists=False, nthreads=8)
+        _compare_cost(oracle, ba.cost.cpu().numpy()[:300], ref["cost"])
+    assert n_with_agents >= 2
