@@ -33,6 +33,10 @@ struct fo_ctx {
   double *d_traj_tab = nullptr;     // [T][NEF][Mp]
   double *d_partial = nullptr;      // [n_chunks][NPS][Mp]
   size_t cap_traj_tab = 0, cap_partial = 0;
+  // ---- BE metric workspace (only allocated when FO_M_BE is active)
+  double *d_be_dist = nullptr, *d_be_btn = nullptr;
+  signed char *d_be_mask = nullptr;
+  size_t cap_be_dist = 0, cap_be_btn = 0, cap_be_mask = 0;
 
   // ---- last launch (profiling aid) + optional HIP-event timing of the sweep kernel alone
   int last_grid = 0, last_block = 0, last_apw = 0;

@@ -236,6 +236,7 @@ struct SweepArgs {
   double *pair_f;        // [NPF][A][M] or null
   int32_t *pair_i;       // [NPI][A][M] or null
   double *lists;         // [NL][A][T-1][M] or null
+  signed char *be_mask;  // [A][Mp] 1 where the pair collides at ttc > 0 (only with FO_M_BE), else null
   double hlA, hwA, wb, len3, off_x, off_y;  // ego half dims, rear-axle offset, L/3, L/6, W/2
   fo_harm_coeff_t hc;
   double dt, thr_dce;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
     const int Lh = min(Tm1, L);
 
     if (L <= 0) {  // inactive slot (a spawn buffer that is only partly filled): no outputs enter any reduction
+      if (a.be_mask) a.be_mask[(size_t)k * a.Mp + m] = 0;
       if (PAIR && valid) {
         const size_t ps_ = (size_t)A * M;
         for (int f = 0; f < FO_NPF; ++f) a.pair_f[(size_t)f * ps_ + (size_t)k * M + m] = NAN;
@@ -466,6 +468,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
     // ---------------- per-pair scalars
     const double ttc = (fabs(dce) <= 1e-8) ? fo_round3((double)tdce * a.dt) : INFINITY;  // ttc.py:43-46
     const double ttce = fo_round3((double)tdce * a.dt);                                   // ttce.py:39
+    if (a.be_mask) a.be_mask[(size_t)k * a.Mp + m] = (do_ttc && ttc < INFINITY && ttc > 0.0) ? 1 : 0;  // be.py:49-50
     const bool hr_valid = do_hr && Lh > 0;
     const double hwc = (max_cp > 0.01) ? oh_at_cp : 0.0;                                   // hr.py:81-84
     if (PAIR && valid) {
@@ -668,6 +671,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     const int Lh = min(Tm1, L);
 
     if (L <= 0) {  // inactive slot (a spawn buffer that is only partly filled): no outputs enter any reduction
+      if (a.be_mask) a.be_mask[(size_t)k * a.Mp + m] = 0;
       if (PAIR && valid) {
         const size_t ps_ = (size_t)A * M;
         for (int f = 0; f < FO_NPF; ++f) a.pair_f[(size_t)f * ps_ + (size_t)k * M + m] = NAN;
@@ -959,6 +963,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     const double dce_m = dce / 1000.0;                                                      // np.round(d, 3)
     const double ttc = (dce == 0.0) ? fo_round3((double)tdce * a.dt) : INFINITY;            // ttc.py:43-46
     const double ttce = fo_round3((double)tdce * a.dt);                                     // ttce.py:39
+    if (a.be_mask) a.be_mask[(size_t)k * a.Mp + m] = (do_ttc && ttc < INFINITY && ttc > 0.0) ? 1 : 0;  // be.py:49-50
     const bool hr_valid = do_hr && Lh > 0;
     const double hwc = (max_cp > 0.01) ? oh_at_cp : 0.0;                                    // hr.py:81-84
     if (PAIR && valid) {
@@ -1035,12 +1040,111 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
 }
 
 
+// ================================================================================================ BE (optional)
+// Brake evaluation (metrics/be.py:31-193), active only with FO_M_BE: for every pair that collides at ttc > 0 the minimum
+// constant deceleration found by the reference's bisection (<= 10 iterations on [round(|min(a_min, 0)|, 2), 5] m/s^2,
+// stop below 0.1) and the brake threat number decel / a_max.  For one candidate deceleration the ego keeps its path,
+// the speed profile becomes [v0, max(v1 - decel j dt, 0) ...], poses are re-sampled by linear interpolation over the
+// travelled chord length (scipy interp1d semantics: searchsorted-left segment, clipped), rectangles are tested for
+// intersection (SAT, touching counts) at every step the agent exists.  Where the re-sampled arc length exceeds the
+// path length the reference raises ValueError; here it is clamped to the end of the path.
+__global__ void fo_be_prep_kernel(int M, int Mp, int T, const double *__restrict__ x, const double *__restrict__ y,
+                                  const double *__restrict__ acc, double *__restrict__ dist, double *__restrict__ mina) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mp) return;
+  const int ms = min(m, M - 1);
+  const double *xs = x + (size_t)ms * T, *ys = y + (size_t)ms * T, *as = acc + (size_t)ms * T;
+  double d = 0.0, mn = 0.0;
+  dist[m] = 0.0;
+  for (int i = 0; i < T; ++i) {
+    if (i > 0) {
+      const double dx = xs[i] - xs[i - 1], dy = ys[i] - ys[i - 1];
+      d += sqrt(dx * dx + dy * dy);
+      dist[(size_t)i * Mp + m] = d;
+    }
+    mn = fmin(mn, as[i]);
+  }
+  mina[m] = mn;
+}
+
+__global__ __launch_bounds__(256) void fo_be_kernel(int M, int Mp, int T, int A, int Ta, const double *__restrict__ traj,
+                                                    const double *__restrict__ dist, const double *__restrict__ mina,
+                                                    const double *__restrict__ atab, const double *__restrict__ acst,
+                                                    const int32_t *__restrict__ aint,
+                                                    const signed char *__restrict__ be_mask, double hlA, double hwA,
+                                                    double wb, double a_max, double dt, double *__restrict__ be_btn,
+                                                    double *__restrict__ pair_f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x, k = blockIdx.y * 4 + wave;
+  if (k >= A) return;
+  const int m = tile * TILE + lane;
+  const int L = aint[2 * k + 1];
+  const double hlB = acst[(size_t)k * NAC + 0], hwB = acst[(size_t)k * NAC + 1];
+  const double *tjl = traj + (size_t)tile * T * NEF * TILE + lane;  // this lane's column of the tile
+  const double *G = atab + (size_t)k * Ta * NAF;
+  const bool active = m < M && L > 0 && T >= 2 && be_mask[(size_t)k * Mp + m];
+  double decel = 0.0, btn = 0.0;
+  if (active) {
+    const double v0 = tjl[5 * TILE], v1 = tjl[(size_t)(NEF + 5) * TILE];
+    const double dend = dist[(size_t)(T - 1) * Mp + m];
+    double min_d = __builtin_rint(fabs(mina[m]) * 100.0) / 100.0, max_d = 5.0;  // np.round(abs(min(min(a), 0)), 2)
+    for (int it = 0; it < 10; ++it) {
+      const double cur = (min_d + max_d) / 2.0;
+      decel = cur;
+      bool hit = false;
+      double s = 0.0;
+      int j = 0;
+      for (int i = 0; i < T && !hit; ++i) {
+        if (i < L) {
+          const double sc = fmin(s, dend);
+          while (j < T && dist[(size_t)j * Mp + m] < sc) ++j;  // searchsorted (left); s never decreases
+          const int idx = min(max(j, 1), T - 1);
+          const double xlo = dist[(size_t)(idx - 1) * Mp + m], xhi = dist[(size_t)idx * Mp + m];
+          const double *r0 = tjl + (size_t)(idx - 1) * NEF * TILE, *r1 = tjl + (size_t)idx * NEF * TILE;
+          double xn = r0[0 * TILE], yn = r0[1 * TILE], tn = r0[4 * TILE];
+          if (xhi != xlo) {
+            const double w = sc - xlo, inv = xhi - xlo;
+            xn = (r1[0 * TILE] - xn) / inv * w + xn;
+            yn = (r1[1 * TILE] - yn) / inv * w + yn;
+            tn = (r1[4 * TILE] - tn) / inv * w + tn;
+          }
+          double es, ec;
+          sincos(tn, &es, &ec);
+          const double *g = G + (size_t)i * NAF;
+          const double px = g[0], py = g[1], pc = g[2], ps = g[3];
+          const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
+          const double dx = px - (xn + wb * ec), dy = py - (yn + wb * es);
+          const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;
+          const double bx = -(pc * dx + ps * dy), by = -(pc * dy - ps * dx);
+          const double s1 = fabs(ax) - (hlA + fabs(hlB * cr) + fabs(hwB * sr)), s2 = fabs(ay) - (hwA + fabs(hlB * sr) + fabs(hwB * cr));
+          const double s3 = fabs(bx) - (hlB + fabs(hlA * cr) + fabs(hwA * sr)), s4 = fabs(by) - (hwB + fabs(hlA * sr) + fabs(hwA * cr));
+          if (!(fmax(fmax(s1, s2), fmax(s3, s4)) > 0.0)) hit = true;  // shapely intersects
+        }
+        const double vn = (i == 0) ? v0 : fmax(v1 - cur * ((double)(i - 1) * dt), 0.0);
+        s += vn * dt;
+      }
+      if (!hit) max_d = cur; else min_d = cur;
+      if (max_d - min_d < 0.1) break;
+    }
+    btn = decel / a_max;
+  }
+  if (m < Mp) be_btn[(size_t)k * Mp + m] = btn;
+  if (pair_f && m < M && L > 0) {
+    const size_t ps_ = (size_t)A * M;
+    pair_f[FO_PF_BE_DECEL * ps_ + (size_t)k * M + m] = decel;
+    pair_f[FO_PF_BE_BTN * ps_ + (size_t)k * M + m] = btn;
+  }
+}
+
 // fold the per-chunk partials into the cost vector + safety flag (metric.py:50-100, hr.py:101-114, wttc.py:32-42)
 __global__ void fo_reduce_kernel(int M, int Mp, int A, int n_chunks, const double *__restrict__ partial,
-                                 fo_thresholds_t thr, uint32_t mask, double *__restrict__ cost,
-                                 uint8_t *__restrict__ safe) {
+                                 fo_thresholds_t thr, uint32_t mask, const double *__restrict__ be_btn,
+                                 double *__restrict__ cost, uint8_t *__restrict__ safe) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
+  double max_btn = 0.0;
+  if (be_btn)
+    for (int k = 0; k < A; ++k) max_btn = fmax(max_btn, be_btn[(size_t)k * Mp + m]);
   double min_dce = INFINITY, arg_dce = -1, min_ttc = INFINITY, arg_ttc = -1, min_ttce = INFINITY;
   double max_er = 0, max_or = 0, arg_or = -1, max_eh = 0, max_oh = 0, max_cp = 0, max_hwc = 0, flag = 0;
   for (int c = 0; c < n_chunks; ++c) {
@@ -1063,18 +1167,20 @@ __global__ void fo_reduce_kernel(int M, int Mp, int A, int n_chunks, const doubl
     if ((mask & FO_M_HR) && max_cp > thr.cp) ok = false;
     if ((mask & FO_M_TTC) && min_ttc < thr.ttc) ok = false;
     if ((mask & FO_M_DCE) && flag > 0.0) ok = false;
+    if ((mask & FO_M_BE) && max_btn > thr.be) ok = false;  // metric.py:54-61
   }
   double *c = cost + (size_t)m * FO_NC;
   c[FO_C_WTTC] = min_ttc; c[FO_C_MIN_DCE] = min_dce; c[FO_C_MAX_EGO_RISK] = max_er; c[FO_C_MAX_OBST_RISK] = max_or;
   c[FO_C_MAX_EGO_HARM] = max_eh; c[FO_C_MAX_OBST_HARM] = max_oh; c[FO_C_MAX_CP] = max_cp;
   c[FO_C_HARM_WITH_CP] = max_hwc; c[FO_C_MIN_TTCE] = min_ttce; c[FO_C_ARGMIN_DCE] = arg_dce;
-  c[FO_C_ARGMIN_TTC] = arg_ttc; c[FO_C_ARGMAX_RISK] = arg_or; c[FO_C_SAFE] = ok ? 1.0 : 0.0; c[FO_C_MAX_BTN] = 0.0;
+  c[FO_C_ARGMIN_TTC] = arg_ttc; c[FO_C_ARGMAX_RISK] = arg_or; c[FO_C_SAFE] = ok ? 1.0 : 0.0; c[FO_C_MAX_BTN] = max_btn;
   c[FO_C_RES0] = 0.0; c[FO_C_RES1] = 0.0;
   safe[m] = ok ? 1 : 0;
 }
 
 uint32_t required_metrics(uint32_t m) {  // metric.py:125-147
   if (m & FO_M_WTTC) m |= FO_M_TTC;
+  if (m & FO_M_BE) m |= FO_M_TTC;  // be.py:39 reads results['ttc'] (the reference raises KeyError without it)
   if (m & (FO_M_TTC | FO_M_TTCE | FO_M_BE)) m |= FO_M_DCE;
   if (m & FO_M_HR) m |= FO_M_CP;
   return m;
@@ -1108,7 +1214,6 @@ int fo_sweep_configure(fo_ctx *ctx, const fo_vehicle_t *veh, const fo_harm_coeff
                        uint32_t metric_mask, double dt) {
   if (!ctx || !veh || !hc || !thr) return fo_fail(ctx, FO_E_ARG, "fo_sweep_configure: null argument");
   if (!(veh->length > 0) || !(veh->width > 0) || !(dt > 0)) return fo_fail(ctx, FO_E_ARG, "fo_sweep_configure: bad vehicle/dt");
-  if (metric_mask & FO_M_BE) return fo_fail(ctx, FO_E_ARG, "fo_sweep_configure: metric 'be' is not implemented in this build");
   ctx->veh = *veh; ctx->hc = *hc; ctx->thr = *thr; ctx->dt = dt;
   ctx->mask = required_metrics(metric_mask);
   ctx->configured = true;
@@ -1159,13 +1264,14 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
 int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
                  const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
                  int32_t *d_pair_i, double *d_lists, void *stream) {
-  (void)d_a;
   if (!ctx) return FO_E_ARG;
   if (!ctx->configured) return fo_fail(ctx, FO_E_STATE, "fo_sweep_run: call fo_sweep_configure first");
   if (M < 0 || T < 1 || (M > 0 && (!d_x || !d_y || !d_theta || !d_v || !d_cost || !d_safe)))
     return fo_fail(ctx, FO_E_ARG, "fo_sweep_run: bad arguments (M=%d T=%d)", M, T);
   if ((d_pair_f == nullptr) != (d_pair_i == nullptr)) return fo_fail(ctx, FO_E_ARG, "fo_sweep_run: pair_f and pair_i go together");
   if (d_lists && !d_pair_f) return fo_fail(ctx, FO_E_ARG, "fo_sweep_run: lists output requires the pair outputs");
+  const bool do_be = (ctx->mask & FO_M_BE) != 0;
+  if (do_be && M > 0 && !d_a) return fo_fail(ctx, FO_E_ARG, "fo_sweep_run: metric 'be' needs the acceleration profile d_a");
   if (M == 0) return FO_OK;
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1183,6 +1289,11 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   int rc;
   if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)T * NEF * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)(n_chunks + 1) * NPS * Mp))) return rc;
+  if (do_be && A > 0) {
+    if ((rc = fo_reserve(ctx, &ctx->d_be_dist, &ctx->cap_be_dist, (size_t)(T + 1) * Mp))) return rc;  // [T][Mp] + min(a) [Mp]
+    if ((rc = fo_reserve(ctx, &ctx->d_be_btn, &ctx->cap_be_btn, (size_t)A * Mp))) return rc;
+    if ((rc = fo_reserve(ctx, &ctx->d_be_mask, &ctx->cap_be_mask, (size_t)A * Mp))) return rc;
+  }
 
   if (A > 0) {
     hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles), dim3(256), (size_t)T * (TILE + 1) * sizeof(double), s, M, T,
@@ -1195,6 +1306,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     a.aint = ctx->d_agent_int;
     a.traj = ctx->d_traj_tab; a.atab = ctx->d_agent_tab; a.acst = ctx->d_agent_const; a.partial = ctx->d_partial;
     a.pair_f = d_pair_f; a.pair_i = d_pair_i; a.lists = d_lists;
+    a.be_mask = do_be ? ctx->d_be_mask : nullptr;
     a.hlA = 0.5 * ctx->veh.length; a.hwA = 0.5 * ctx->veh.width; a.wb = ctx->veh.wb_rear_axle;
     a.len3 = ctx->veh.length / 2.0 * (2.0 / 3.0);  // r_x * (2/3)  (collision_probability.py:160-161)
     a.off_x = ctx->veh.length / 6.0; a.off_y = ctx->veh.width / 2.0;
@@ -1220,8 +1332,18 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     FO_HIP_TRY(ctx, hipGetLastError());
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop[ctx->n_timed++], s));
   }
+  const double *be_btn = nullptr;
+  if (do_be && A > 0 && T >= 1) {
+    double *dist = ctx->d_be_dist, *mina = ctx->d_be_dist + (size_t)T * Mp;
+    hipLaunchKernelGGL(fo_be_prep_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, M, Mp, T, d_x, d_y, d_a, dist, mina);
+    hipLaunchKernelGGL(fo_be_kernel, dim3(n_tiles, (A + 3) / 4), dim3(256), 0, s, M, Mp, T, A, Ta, ctx->d_traj_tab, dist,
+                       mina, ctx->d_agent_tab, ctx->d_agent_const, ctx->d_agent_int, ctx->d_be_mask, 0.5 * ctx->veh.length,
+                       0.5 * ctx->veh.width, ctx->veh.wb_rear_axle, ctx->veh.a_max, ctx->dt, ctx->d_be_btn, d_pair_f);
+    FO_HIP_TRY(ctx, hipGetLastError());
+    be_btn = ctx->d_be_btn;
+  }
   hipLaunchKernelGGL(fo_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, Mp, A, n_chunks, ctx->d_partial,
-                     ctx->thr, ctx->mask, d_cost, d_safe);
+                     ctx->thr, ctx->mask, be_btn, d_cost, d_safe);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
 }

@@ -11,7 +11,8 @@ per-step stage runs in libfo_hip.so on one MI355X:
 
 Deviations from the reference (documented in DESIGN.md): ``visible_area`` is a ring polygon + cell mask
 (:class:`~frenetix_occlusion.sensor_model.VisibleArea`) instead of a shapely geometry; spawn points come from the
-occluded-cell frontier instead of the three GEOS rule families; no matplotlib (``plot`` is accepted and ignored).
+occluded-cell frontier instead of the three GEOS rule families; no matplotlib (``plot`` is accepted and ignored);
+metric ``'be'`` implies ``'ttc'`` (the reference raises KeyError when ``'be'`` is activated without it).
 """
 import os
 

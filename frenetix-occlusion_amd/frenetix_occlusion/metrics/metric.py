@@ -118,6 +118,10 @@ class BatchAssessment:
                 out["ttce"] = {pid: float(pf[N.PF["ttce"], k, m]) for pid, k in self.prediction_slots}
             elif name == "wttc":
                 out["wttc"] = float(cost[N.COST["wttc"]])
+            elif name == "be":
+                out["be"] = {pid: {"required_constant_deceleration": float(pf[N.PF["be_decel"], k, m]),
+                                   "break_threat_number": float(pf[N.PF["be_btn"], k, m])}
+                             for pid, k in self.prediction_slots}
             elif name == "hr":
                 hr = {}
                 for pid, k in self.prediction_slots:

@@ -87,7 +87,10 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
                         const int32_t *d_len, void *stream);
 
 /* d_pair_f / d_pair_i / d_lists may be NULL (reduced output mode); d_cost and d_safe are required.
- * d_a may be NULL unless FO_M_BE is active. */
+ * d_a (acceleration profile) may be NULL unless FO_M_BE is active (ref: metrics/be.py:66-68 reads cartesian.a).
+ * FO_M_BE implies FO_M_TTC and FO_M_DCE (be.py:39,49 read results['ttc']); its per-pair outputs are
+ * pair_f[FO_PF_BE_DECEL], pair_f[FO_PF_BE_BTN] (0 for pairs that do not collide, be.py:45-46) and the per-trajectory
+ * maximum goes to cost[FO_C_MAX_BTN]; thresholds.be is applied like metric.py:54-61. */
 int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
                  const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
                  int32_t *d_pair_i, double *d_lists, void *stream);

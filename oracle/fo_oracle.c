@@ -262,23 +262,82 @@ static void harm_pair(int Lh, const double *x, const double *y, const double *th
   }
 }
 
+/* ------------------------------------------------------------------ be (metrics/be.py:31-193)
+ * Minimum constant deceleration (bisection, <= 10 iterations, be.py:66-82) that avoids the collision with one agent
+ * prediction.  For a candidate deceleration the ego follows its own path with the speed profile
+ * v_new = [v0, max(v1 - decel * j dt, 0) ...] (be.py:110-111), positions are re-sampled by linear interpolation over the
+ * travelled chord length (scipy interp1d, be.py:114-126), and the rectangles are tested for intersection at every
+ * step the agent exists (be.py:148-193).  Deviation: where the re-sampled arc length exceeds the original path
+ * length scipy raises ValueError; here the arc length is clamped to the end of the path. */
+static double interp_lin(int T, const double *xs, const double *ys, double s) {
+  int idx = 0; /* np.searchsorted(xs, s) (left): first index with xs[idx] >= s */
+  while (idx < T && xs[idx] < s) ++idx;
+  if (idx < 1) idx = 1;
+  if (idx > T - 1) idx = T - 1;
+  const double xlo = xs[idx - 1], xhi = xs[idx], ylo = ys[idx - 1], yhi = ys[idx];
+  if (xhi == xlo) return ylo; /* stationary stretch: scipy would divide by zero */
+  const double slope = (yhi - ylo) / (xhi - xlo);
+  return slope * (s - xlo) + ylo;
+}
+
+static int be_collides(int T, const double *x, const double *y, const double *th, const double *v, const double *dist,
+                       double dt, double decel, const fo_vehicle_t *veh, int L, const double *pos, const double *yaw,
+                       double raw_l, double raw_w) {
+  double s = 0.0; /* dist_new[i] = sum_{j<i} v_new[j] dt */
+  for (int i = 0; i < T; ++i) {
+    const double sc = s > dist[T - 1] ? dist[T - 1] : s;
+    if (i < L) {
+      const double xn = interp_lin(T, dist, x, sc), yn = interp_lin(T, dist, y, sc), tn = interp_lin(T, dist, th, sc);
+      double qa[8], qb[8];
+      fo_oracle_rect_vertices(xn + veh->wb_rear_axle * cos(tn), yn + veh->wb_rear_axle * sin(tn), tn, veh->length,
+                              veh->width, qa);
+      fo_oracle_rect_vertices(pos[2 * i], pos[2 * i + 1], yaw[i], raw_l, raw_w, qb);
+      if (fo_oracle_quad_distance(qa, qb) == 0.0) return 1; /* shapely intersects */
+    }
+    const double vn = (i == 0) ? v[0] : fmax(v[1] - decel * ((double)(i - 1) * dt), 0.0);
+    s += vn * dt;
+  }
+  return 0;
+}
+
+static double be_pair(int T, const double *x, const double *y, const double *th, const double *v, const double *a,
+                      double dt, const fo_vehicle_t *veh, int L, const double *pos, const double *yaw, double raw_l,
+                      double raw_w, double *dist) {
+  dist[0] = 0.0;
+  for (int i = 1; i < T; ++i) {
+    const double dx = x[i] - x[i - 1], dy = y[i] - y[i - 1];
+    dist[i] = dist[i - 1] + sqrt(dx * dx + dy * dy);
+  }
+  double mina = 0.0;
+  for (int i = 0; i < T; ++i) if (a[i] < mina) mina = a[i];
+  double min_d = nearbyint(fabs(mina) * 100.0) / 100.0, max_d = 5.0, cur = 0.0; /* np.round(abs(min(min(a), 0)), 2) */
+  for (int it = 0; it < 10; ++it) {
+    cur = (min_d + max_d) / 2.0;
+    if (!be_collides(T, x, y, th, v, dist, dt, cur, veh, L, pos, yaw, raw_l, raw_w)) max_d = cur; else min_d = cur;
+    if (max_d - min_d < 0.1) break;
+  }
+  return cur;
+}
+
 /* ------------------------------------------------------------------ metric ordering (metric.py:125-147) */
 uint32_t fo_oracle_required_metrics(uint32_t m) {
   if (m & FO_M_WTTC) m |= FO_M_TTC;
+  if (m & FO_M_BE) m |= FO_M_TTC; /* be.py:39 reads results['ttc']: the reference raises KeyError without it; here it is implied */
   if (m & (FO_M_TTC | FO_M_TTCE | FO_M_BE)) m |= FO_M_DCE;
   if (m & FO_M_HR) m |= FO_M_CP;
   return m;
 }
 
 /* ------------------------------------------------------------------ one trajectory (metric.py:35-100) */
-static int eval_trajectory(int T, const double *x, const double *y, const double *th, const double *v, int A, int Ta,
+static int eval_trajectory(int T, const double *x, const double *y, const double *th, const double *v, const double *acc,
+                           int A, int Ta,
                            const double *apos, const double *ayaw, const double *av, const double *acov,
                            const double *ashape, const double *araw, const int32_t *atype, const int32_t *alen,
                            const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, double dt, const fo_thresholds_t *thr,
                            uint32_t mask, double *pair_f, int32_t *pair_i, double *lists, double *cost,
                            uint8_t *safe, double *scratch) {
   const int Tm1 = T - 1 > 0 ? T - 1 : 0;
-  double *cp = scratch, *eh = scratch + Tm1, *oh = scratch + 2 * Tm1;
+  double *cp = scratch, *eh = scratch + Tm1, *oh = scratch + 2 * Tm1, *dist = scratch + 3 * Tm1;
   double c[FO_NC];
   for (int i = 0; i < FO_NC; ++i) c[i] = 0.0;
   c[FO_C_WTTC] = INFINITY; c[FO_C_MIN_DCE] = INFINITY; c[FO_C_MIN_TTCE] = INFINITY;
@@ -319,6 +378,16 @@ static int eval_trajectory(int T, const double *x, const double *y, const double
         double ttce = fo_oracle_round3(tdce * dt); /* ttce.py:39 */
         pf[FO_PF_TTCE] = ttce;
         if (ttce < c[FO_C_MIN_TTCE]) c[FO_C_MIN_TTCE] = ttce;
+      }
+      if (mask & FO_M_BE) { /* be.py:31-62 */
+        double decel = 0.0, btn = 0.0;
+        const double ttc = pf[FO_PF_TTC];
+        if (isfinite(ttc) && ttc > 0.0 && T >= 2) {
+          decel = be_pair(T, x, y, th, v, acc, dt, veh, L, pos, yaw, araw[2 * k], araw[2 * k + 1], dist);
+          btn = decel / veh->a_max;
+        }
+        pf[FO_PF_BE_DECEL] = decel; pf[FO_PF_BE_BTN] = btn;
+        if (btn > c[FO_C_MAX_BTN]) c[FO_C_MAX_BTN] = btn;
       }
     }
     /* --- hr (hr.py:43-116) */
@@ -366,6 +435,7 @@ static int eval_trajectory(int T, const double *x, const double *y, const double
     if ((mask & FO_M_HR) && !isnan(thr->cp) && c[FO_C_MAX_CP] > thr->cp) ok = 0;
     if ((mask & FO_M_TTC) && !isnan(thr->ttc) && min_ttc < thr->ttc) ok = 0;
     if ((mask & FO_M_DCE) && dce_flag) ok = 0;
+    if ((mask & FO_M_BE) && !isnan(thr->be) && c[FO_C_MAX_BTN] > thr->be) ok = 0; /* metric.py:54-61 */
   }
   c[FO_C_SAFE] = ok;
   if (cost) memcpy(cost, c, sizeof c);
@@ -379,8 +449,8 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
                     const int32_t *alen, const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, double dt,
                     const fo_thresholds_t *thr, uint32_t metric_mask, double *pair_f, int32_t *pair_i,
                     double *lists, double *cost, uint8_t *safe, int nthreads) {
-  (void)a;
   if (M < 0 || T < 1 || A < 0) return -1;
+  if ((metric_mask & FO_M_BE) && !a) return -1;
   for (int k = 0; k < A; ++k) if (alen[k] < 0 || alen[k] > Ta) return -1;
   uint32_t mask = fo_oracle_required_metrics(metric_mask);
   const int Tm1 = T - 1;
@@ -390,7 +460,7 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
 #pragma omp parallel if (nthreads > 1)
 #endif
   {
-    double *scratch = (double *)malloc(sizeof(double) * 3 * (size_t)(Tm1 > 0 ? Tm1 : 1));
+    double *scratch = (double *)malloc(sizeof(double) * (3 * (size_t)(Tm1 > 0 ? Tm1 : 1) + (size_t)T));
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 8)
 #endif
@@ -399,8 +469,8 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
         double *lm = lists + (size_t)m * A * FO_NL * Tm1;
         for (size_t i = 0; i < (size_t)A * FO_NL * Tm1; ++i) lm[i] = NAN;
       }
-      int rc = eval_trajectory(T, x + (size_t)m * T, y + (size_t)m * T, theta + (size_t)m * T, v + (size_t)m * T, A,
-                               Ta, apos, ayaw, av, acov, ashape, araw, atype, alen, veh, hc, dt, thr, mask,
+      int rc = eval_trajectory(T, x + (size_t)m * T, y + (size_t)m * T, theta + (size_t)m * T, v + (size_t)m * T,
+                               a ? a + (size_t)m * T : NULL, A, Ta, apos, ayaw, av, acov, ashape, araw, atype, alen, veh, hc, dt, thr, mask,
                                pair_f ? pair_f + (size_t)m * A * FO_NPF : NULL,
                                pair_i ? pair_i + (size_t)m * A * FO_NPI : NULL,
                                lists ? lists + (size_t)m * A * FO_NL * Tm1 : NULL,

@@ -158,3 +158,50 @@ def test_box_prob_closed_form_against_scipy_mvn(oracle):
         ref = mvn.mvnun(lo, hi, mu, np.eye(2) * var)[0]
         worst = max(worst, abs(ref - oracle.box_prob(lo, hi, mu, var, var)))
     assert worst < 1e-15
+
+
+# ---------------------------------------------------------------------------------------------- BE (metrics/be.py)
+ALL7 = ("hr", "ttc", "ttce", "dce", "wttc", "cp", "be")
+
+
+def _ped(x, y, T=31):
+    return {"pos": np.tile(np.array([[x, y]]), (T, 1))[None], "yaw": np.zeros((1, T)), "v": np.zeros((1, T)),
+            "cov": np.tile(0.1 * np.eye(2), (1, T, 1, 1)), "shape": np.array([[0.36, 0.65]]),
+            "raw_dims": np.array([[0.3, 0.5]]), "type": np.array([4], dtype=np.int32), "len": np.array([T], dtype=np.int32)}
+
+
+def test_be_bisection_finds_the_braking_that_just_avoids_a_standing_pedestrian(oracle):
+    T, v0 = 31, 10.0
+    t = np.arange(T) * 0.1
+    traj = {"x": (v0 * t)[None], "y": np.zeros((1, T)), "theta": np.zeros((1, T)), "v": np.full((1, T), v0),
+            "a": np.zeros((1, T))}
+    out = oracle.sweep(traj, _ped(20.0, 0.0), VEH, 0.1, metrics=ALL7, thr={"be": 0.25})
+    pf = out["pair_f"][0, 0]
+    assert np.isfinite(pf[oracle.PF["ttc"]]) and pf[oracle.PF["ttc"]] > 0
+    decel = pf[oracle.PF["be_decel"]]
+    # front of the ego is wb + L/2 = 3.677 m ahead of the rear axle, the pedestrian's near face at 19.85 m: 16.17 m
+    # of travel; the left-Riemann speed profile [v0, v0, v0 - d dt, ...] travels v0 dt + v0^2/(2 d) + v0 dt/2
+    d_star = v0 * v0 / (2.0 * (16.173 - 1.0 - 0.5))
+    assert d_star - 0.15 < decel < d_star + 0.15
+    assert (decel * 1024) == int(decel * 1024)                       # a bisection midpoint of [0, 5]
+    assert pf[oracle.PF["be_btn"]] == decel / VEH[4]
+    assert out["cost"][0, oracle.COST["max_btn"]] == decel / VEH[4]
+    assert out["safe"][0] == (0 if decel / VEH[4] > 0.25 else 1)
+    # the bracket starts at round(|min(a)|, 2) (be.py:68): a trajectory that already brakes with 4.004 m/s^2 somewhere
+    traj["a"][0, 7] = -4.004
+    d2 = oracle.sweep(traj, _ped(20.0, 0.0), VEH, 0.1, metrics=ALL7)["pair_f"][0, 0, oracle.PF["be_decel"]]
+    assert 4.0 <= d2 <= 5.0 and d2 != decel
+
+
+def test_be_is_zero_without_a_collision_and_for_a_collision_at_t0(oracle):
+    T = 31
+    t = np.arange(T) * 0.1
+    traj = {"x": (5.0 * t)[None], "y": np.zeros((1, T)), "theta": np.zeros((1, T)), "v": np.full((1, T), 5.0),
+            "a": np.zeros((1, T))}
+    far = oracle.sweep(traj, _ped(60.0, 0.0), VEH, 0.1, metrics=ALL7)["pair_f"][0, 0]
+    assert far[oracle.PF["be_decel"]] == 0.0 and far[oracle.PF["be_btn"]] == 0.0 and np.isinf(far[oracle.PF["ttc"]])
+    now = oracle.sweep(traj, _ped(2.0, 0.0), VEH, 0.1, metrics=ALL7)["pair_f"][0, 0]   # overlapping at t = 0: ttc = 0
+    assert now[oracle.PF["ttc"]] == 0.0 and now[oracle.PF["be_decel"]] == 0.0           # be.py:50 "if ttc > 0"
+    # 'be' alone pulls in ttc and dce (metric.py:135-139; be.py:39 needs results['ttc'])
+    m = oracle.lib().fo_oracle_required_metrics(oracle.METRIC_BITS["be"])
+    assert m & oracle.METRIC_BITS["dce"] and m & oracle.METRIC_BITS["ttc"]

@@ -240,3 +240,32 @@ def test_full_size_properties_10k_x_256(torch_cuda):
     part = sw.run(traj["x"][sl], traj["y"][sl], traj["theta"][sl], traj["v"][sl], mode="reduced")
     torch.cuda.synchronize()
     assert np.array_equal(part.cost.cpu().numpy(), cost[sl])
+
+
+def test_be_metric_matches_oracle(torch_cuda, oracle):
+    """metrics/be.py (optional metric): required constant deceleration + brake threat number per colliding pair."""
+    from frenetix_occlusion import synthetic as S
+    metrics = ("hr", "ttc", "ttce", "dce", "wttc", "cp", "be")
+    for M, A, cfg, thr in ((300, 16, 1, {"be": 0.2, "harm": 0.9}), (130, 9, 8, {"be": 0.05})):
+        traj, agents = S.make_batch(M, A, config_id=cfg)
+        traj["a"][::3, 4] -= 1.237                               # some trajectories already brake
+        if cfg == 8:
+            agents["len"] = np.array([31, 1, 2, 30, 17, 31, 5, 29, 3], dtype=np.int32)
+        ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr)
+        got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr)
+        _compare(oracle, ref, got)
+        for name in ("be_decel", "be_btn"):
+            a, b = ref["pair_f"][..., oracle.PF[name]], got["pair_f"][..., oracle.PF[name]]
+            assert np.array_equal(np.isnan(a), np.isnan(b)), name
+            np.testing.assert_allclose(np.nan_to_num(b), np.nan_to_num(a), rtol=0, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(got["cost"][:, oracle.COST["max_btn"]], ref["cost"][:, oracle.COST["max_btn"]], atol=1e-12)
+        assert (ref["pair_f"][..., oracle.PF["be_decel"]] > 0).sum() > 5
+        red = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr, mode="reduced")
+        assert np.array_equal(red["safe"], ref["safe"]) and np.array_equal(red["cost"], got["cost"])
+    # without the acceleration profile the call fails loudly
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion.sweep import MetricSweep
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, metrics=metrics)
+    sw.set_agents(*[agents[k] for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")])
+    with pytest.raises(N.NativeError):
+        sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], None)
