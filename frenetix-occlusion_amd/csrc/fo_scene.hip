@@ -35,7 +35,8 @@ struct Scene {
   uint8_t *d_raster = nullptr;    // [rny][rnx]
   double *d_lane_yaw = nullptr;   // [rny][rnx] or null
   // per-step workspace
-  size_t cap_cand = 0;
+  size_t cap_cand = 0, cap_vis32 = 0;
+  int32_t *d_vis32 = nullptr;     // [O] probe results (zero between steps)
   uint8_t *d_flags = nullptr;     // [cells]
   int32_t *d_blk = nullptr;       // block counts / offsets
   size_t cap_cells = 0, cap_blk = 0;
@@ -107,22 +108,35 @@ __device__ __forceinline__ void wave_min_hit(double &t, int &id) {
 __device__ __forceinline__ void scan_soup(int E, const double *__restrict__ edges, int O, const double *__restrict__ ocorn,
                                           const uint8_t *__restrict__ oflags, int first, int stride, double ox, double oy,
                                           double dx, double dy, int skip_id, double &best, int &best_id) {
-  const int total = E + 4 * O;
-  for (int gi = first; gi < total; gi += stride) {
-    double ax, ay, bx, by;
-    int id;
-    if (gi < E) {
-      const double *sg = edges + 4 * (size_t)gi;
-      ax = sg[0]; ay = sg[1]; bx = sg[2]; by = sg[3];
-      id = gi;
-    } else {
-      const int o = (gi - E) >> 2, sd = (gi - E) & 3, s2 = (sd + 1) & 3;
-      if (!((oflags[o] & 1) && (oflags[o] & 2)) || E + o == skip_id) continue;
-      const double *c = ocorn + 8 * (size_t)o;
-      ax = c[2 * sd]; ay = c[2 * sd + 1]; bx = c[2 * s2]; by = c[2 * s2 + 1];
-      id = E + o;
+  // static edges, four per lane in flight (the loop is bound by L2 latency, not by arithmetic)
+  int gi = first;
+  for (; gi + 3 * stride < E; gi += 4 * stride) {
+    double sg[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double *p = edges + 4 * (size_t)(gi + u * stride);
+      sg[u][0] = p[0]; sg[u][1] = p[1]; sg[u][2] = p[2]; sg[u][3] = p[3];
     }
-    const double t = ray_segment(ox, oy, dx, dy, ax, ay, bx, by);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int id = gi + u * stride;
+      const double t = ray_segment(ox, oy, dx, dy, sg[u][0], sg[u][1], sg[u][2], sg[u][3]);
+      if (t < best || (t == best && id < best_id)) { best = t; best_id = id; }
+    }
+  }
+  for (; gi < E; gi += stride) {
+    const double *p = edges + 4 * (size_t)gi;
+    const double t = ray_segment(ox, oy, dx, dy, p[0], p[1], p[2], p[3]);
+    if (t < best || (t == best && gi < best_id)) { best = t; best_id = gi; }
+  }
+  // obstacle sides (gi continues the same interleaving over [E, E + 4 O))
+  const int total = E + 4 * O;
+  for (; gi < total; gi += stride) {
+    const int o = (gi - E) >> 2, sd = (gi - E) & 3, s2 = (sd + 1) & 3;
+    if (!((oflags[o] & 1) && (oflags[o] & 2)) || E + o == skip_id) continue;
+    const double *c = ocorn + 8 * (size_t)o;
+    const int id = E + o;
+    const double t = ray_segment(ox, oy, dx, dy, c[2 * sd], c[2 * sd + 1], c[2 * s2], c[2 * s2 + 1]);
     if (t < best || (t == best && id < best_id)) { best = t; best_id = id; }
   }
 }
@@ -155,8 +169,9 @@ __device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full,
 // ------------------------------------------------------------------------------------------------ rays + probes
 // One launch for the ray fan and the obstacle-visibility probes.  Workgroups [0, n_rays): one ray each, its five
 // waves scan interleaved fifths of the soup and the (t, id) minima are combined through LDS.  Workgroups
-// [n_rays, n_rays + O): one obstacle each, wave p casts probe p (4 corners + centre; sensor_model.py:59-76 restated,
-// see oracle) against the whole soup with the obstacle itself left out.
+// [n_rays, n_rays + 5 O): one visibility probe each (obstacle o, probe p: 4 corners + centre; sensor_model.py:59-76
+// restated) against the soup with the obstacle itself left out; a visible probe sets vis32[o], which the cell-grid
+// kernel turns into the byte flag and clears again for the next step.
 constexpr int RAY_WAVES = 5;
 __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const double *__restrict__ edges, int O,
                                                                  const double *__restrict__ ocorn,
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
                                                                  int n_rays, const double *__restrict__ dirs, double r,
                                                                  int full, double *__restrict__ range,
                                                                  int32_t *__restrict__ hit_id, double *__restrict__ ring,
-                                                                 uint8_t *__restrict__ vis) {
+                                                                 int32_t *__restrict__ vis32) {
   __shared__ double sh_t[RAY_WAVES];
   __shared__ int sh_id[RAY_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -191,33 +206,32 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
     }
     return;
   }
-  const int o = blockIdx.x - n_rays, p = wave;
+  // probe workgroup: obstacle o, probe p (4 corners + centre); all five waves share the soup like a ray workgroup
+  const int o = (blockIdx.x - n_rays) / 5, p = (blockIdx.x - n_rays) % 5;
   const bool exists = oflags[o] & 1;
   const double qx = p < 4 ? ocorn[8 * (size_t)o + 2 * p] : ocen[2 * o];
   const double qy = p < 4 ? ocorn[8 * (size_t)o + 2 * p + 1] : ocen[2 * o + 1];
   const double rx = qx - ex, ry = qy - ey;
   const double dist = sqrt(rx * rx + ry * ry);
   bool cand = exists && !(dist > r + 0.01);
-  bool direct = false;
-  if (cand && dist == 0.0) { direct = true; cand = false; }
-  if (cand && fan_sector(n_rays, dirs, full, rx, ry) < 0) cand = false;
-  int v = direct ? 1 : 0;
-  if (cand) {  // wave-uniform
-    const double dx = rx / dist, dy = ry / dist;
-    double best = INFINITY;
-    int id = 0x7fffffff;
-    scan_soup(E, edges, O, ocorn, oflags, lane, 64, ex, ey, dx, dy, E + o, best, id);
-    wave_min_hit(best, id);
-    double t = best;
-    if (!(t <= dist)) t = dist;  // first_hit(..., rmax = dist)
-    if (t >= dist - 0.01) v = 1;
+  if (cand && dist == 0.0) {
+    if (threadIdx.x == 0) atomicOr(&vis32[o], 1);
+    return;
   }
-  if (lane == 0) sh_id[wave] = v;
+  if (cand && fan_sector(n_rays, dirs, full, rx, ry) < 0) cand = false;
+  if (!cand) return;  // uniform over the workgroup
+  const double dx = rx / dist, dy = ry / dist;
+  double best = INFINITY;
+  int id = 0x7fffffff;
+  scan_soup(E, edges, O, ocorn, oflags, wave * 64 + lane, 64 * RAY_WAVES, ex, ey, dx, dy, E + o, best, id);
+  wave_min_hit(best, id);
+  if (lane == 0) sh_t[wave] = best;
   __syncthreads();
   if (threadIdx.x == 0) {
-    int any = 0;
-    for (int w = 0; w < RAY_WAVES; ++w) any |= sh_id[w];
-    vis[o] = (uint8_t)any;
+    for (int w = 1; w < RAY_WAVES; ++w) best = fmin(best, sh_t[w]);
+    double t = best;
+    if (!(t <= dist)) t = dist;  // first_hit(..., rmax = dist)
+    if (t >= dist - 0.01) atomicOr(&vis32[o], 1);
   }
 }
 
@@ -226,9 +240,14 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
                                int ix0, int iy0, int nx, int ny, double ex, double ey, double hx, double hy, double r,
                                int full, int n_rays, const double *__restrict__ dirs,
                                const double *__restrict__ range, uint8_t *__restrict__ cls,
-                               uint8_t *__restrict__ occ_flag, int32_t *__restrict__ blk) {
+                               uint8_t *__restrict__ occ_flag, int32_t *__restrict__ blk, int O,
+                               int32_t *__restrict__ vis32, uint8_t *__restrict__ vis) {
   __shared__ int wsum[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vis && idx < O) {  // obstacle-visibility flags of the probe workgroups (previous launch); self-cleaning
+    vis[idx] = vis32[idx] ? 1 : 0;
+    vis32[idx] = 0;
+  }
   const bool in = idx < nx * ny;
   uint8_t c = 0;
   if (in) {
@@ -344,37 +363,36 @@ struct SpawnTypes {  // per pattern slot (j % 4): type code, speed, raw dims, in
 
 // evenly spaced pick of the candidates + heading per phantom: pedestrians -> unit vector to the closest point of the
 // ego reference path (agent.py:475-481 + helper_functions.py:38-76); vehicles -> lane heading raster at their cell
-__global__ void fo_spawn_pick_kernel(const int32_t *__restrict__ cand, const int32_t *__restrict__ n_cand, int nx,
-                                     double rx0, double ry0, double cs, int ix0, int iy0, int max_agents, SpawnTypes st,
-                                     int N, const double *__restrict__ path, const double *__restrict__ lane_yaw,
-                                     int rnx, int rny, int32_t *__restrict__ cell, double *__restrict__ pos,
-                                     double *__restrict__ yaw, int32_t *__restrict__ n_out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void fo_spawn_pick_kernel(const int32_t *__restrict__ cand,
+                                                            const int32_t *__restrict__ n_cand, int nx, double rx0,
+                                                            double ry0, double cs, int ix0, int iy0, int max_agents,
+                                                            SpawnTypes st, int N, const double *__restrict__ path,
+                                                            const double *__restrict__ lane_yaw, int rnx, int rny,
+                                                            int32_t *__restrict__ cell, double *__restrict__ pos,
+                                                            double *__restrict__ yaw, int32_t *__restrict__ n_out) {
+  // one wave per phantom slot; the lanes share the search for the closest reference-path segment
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n = *n_cand;
   const int m = n < max_agents ? n : max_agents;
-  if (j == 0) *n_out = m;
+  if (j == 0 && lane == 0) *n_out = m;
   if (j >= max_agents) return;
   if (j >= m) {
-    cell[j] = -1;
-    pos[2 * j] = 0.0;
-    pos[2 * j + 1] = 0.0;
-    yaw[j] = 0.0;
+    if (lane == 0) { cell[j] = -1; pos[2 * j] = 0.0; pos[2 * j + 1] = 0.0; yaw[j] = 0.0; }
     return;
   }
   const int pick = (n <= max_agents) ? j : (int)(((long long)j * n) / max_agents);
   const int ci = cand[pick];
   const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
   const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
-  cell[j] = ci;
-  pos[2 * j] = px;
-  pos[2 * j + 1] = py;
   const int type = st.type[j & 3];
   double a = NAN;
   if (type != FO_TYPE_PEDESTRIAN && lane_yaw && wx >= 0 && wx < rnx && wy >= 0 && wy < rny)
     a = lane_yaw[(size_t)wy * rnx + wx];
-  if (isnan(a)) {
+  if (isnan(a)) {  // wave-uniform
     double best = INFINITY, qx = px, qy = py;
-    for (int i = 0; i + 1 < N; ++i) {
+    int bi = 0x7fffffff;
+    for (int i = lane; i + 1 < N; i += 64) {
       const double ax = path[2 * i], ay = path[2 * i + 1], bx = path[2 * i + 2], by = path[2 * i + 3];
       const double ex = bx - ax, ey = by - ay;
       const double l2 = ex * ex + ey * ey;
@@ -386,7 +404,13 @@ __global__ void fo_spawn_pick_kernel(const int32_t *__restrict__ cand, const int
       }
       const double cx = ax + t * ex, cy = ay + t * ey;
       const double d2 = (px - cx) * (px - cx) + (py - cy) * (py - cy);
-      if (d2 < best) { best = d2; qx = cx; qy = cy; }
+      if (d2 < best) { best = d2; qx = cx; qy = cy; bi = i; }   // per lane: ascending i, first minimum
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {                    // across lanes: smallest (d2, i) = first minimum
+      const double b2 = __shfl_xor(best, off), x2 = __shfl_xor(qx, off), y2 = __shfl_xor(qy, off);
+      const int i2 = __shfl_xor(bi, off);
+      if (b2 < best || (b2 == best && i2 < bi)) { best = b2; qx = x2; qy = y2; bi = i2; }
     }
     const double vx = qx - px, vy = qy - py;
     const double nn = sqrt(vx * vx + vy * vy);
@@ -395,7 +419,7 @@ __global__ void fo_spawn_pick_kernel(const int32_t *__restrict__ cand, const int
     a = atan2(uy, ux);
     if (a < 0.0) a += 2.0 * M_PI;
   }
-  yaw[j] = a;
+  if (lane == 0) { cell[j] = ci; pos[2 * j] = px; pos[2 * j + 1] = py; yaw[j] = a; }
 }
 
 // predictions in the layout fo_sweep_set_agents consumes; slots j >= n are inactive (len = 0)
@@ -455,7 +479,7 @@ extern "C" {
 void fo_scene_destroy_(fo_ctx *ctx) {
   if (!ctx || !ctx->scene) return;
   Scene *sc = (Scene *)ctx->scene;
-  void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_flags, sc->d_blk,
+  void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_vis32, sc->d_flags, sc->d_blk,
                   sc->d_cand, sc->d_ncand};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -558,15 +582,21 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  const int n_probe_blocks = (O > 0 && d_obst_vis) ? O : 0;
-  hipLaunchKernelGGL(fo_rays_kernel, dim3(n_rays + n_probe_blocks), dim3(64 * RAY_WAVES), 0, s, sc->E, sc->d_edges, O,
-                     d_ocorn, d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, full_circle, d_range, d_hit_id, d_ring,
-                     d_obst_vis);
+  const bool probes = O > 0 && d_obst_vis;
+  if (probes && (size_t)O > sc->cap_vis32) {
+    if ((rc = fo_reserve(ctx, &sc->d_vis32, &sc->cap_vis32, (size_t)O))) return rc;
+    FO_HIP_TRY(ctx, hipMemsetAsync(sc->d_vis32, 0, sizeof(int32_t) * sc->cap_vis32, s));
+  }
+  hipLaunchKernelGGL(fo_rays_kernel, dim3(n_rays + (probes ? 5 * O : 0)), dim3(64 * RAY_WAVES), 0, s, sc->E, sc->d_edges,
+                     O, d_ocorn, d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, full_circle, d_range, d_hit_id,
+                     d_ring, sc->d_vis32);
   const int cells = win_nx * win_ny;
+  if (probes && O > cells) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: more obstacles than window cells");
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
   hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->d_raster, sc->rnx, sc->rny, sc->x0,
                      sc->y0, sc->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
-                     n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk);
+                     n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk, probes ? O : 0, sc->d_vis32,
+                     probes ? d_obst_vis : nullptr);
   FO_HIP_TRY(ctx, hipGetLastError());
   return compact(ctx, sc, sc->d_flags, cells, d_occ_idx, d_n_occ, s);
 }
@@ -599,7 +629,7 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
     st.type[i] = type4[i]; st.speed[i] = speed4[i]; st.raw_l[i] = raw_l4[i]; st.raw_w[i] = raw_w4[i];
     st.infl_l[i] = infl_l4[i]; st.infl_w[i] = infl_w4[i];
   }
-  hipLaunchKernelGGL(fo_spawn_pick_kernel, dim3((max_agents + 63) / 64), dim3(64), 0, s, sc->d_cand, sc->d_ncand, win_nx,
+  hipLaunchKernelGGL(fo_spawn_pick_kernel, dim3((max_agents + 3) / 4), dim3(256), 0, s, sc->d_cand, sc->d_ncand, win_nx,
                      sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, max_agents, st, n_path, d_path, sc->d_lane_yaw, sc->rnx,
                      sc->rny, d_cell, d_pos0, d_yaw0, d_n);
   const int n = max_agents * T;

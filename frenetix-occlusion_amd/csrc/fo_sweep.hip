@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int /*M
   const int n = min(TILE, M - m0);
   const int ld = TILE + 1;
   const double *src[4] = {x, y, th, v};
-  for (int f = 0; f < 4; ++f) {
+  {
+    const int f = blockIdx.y;  // one input array per workgroup: 4 x n_tiles workgroups instead of n_tiles
     const double *s = src[f] + (size_t)m0 * T;
     for (int i = threadIdx.x; i < n * T; i += blockDim.x) sh[(i % T) * ld + (i / T)] = s[i];
     __syncthreads();
@@ -1147,6 +1148,7 @@ __global__ void fo_reduce_kernel(int M, int Mp, int A, int n_chunks, const doubl
     for (int k = 0; k < A; ++k) max_btn = fmax(max_btn, be_btn[(size_t)k * Mp + m]);
   double min_dce = INFINITY, arg_dce = -1, min_ttc = INFINITY, arg_ttc = -1, min_ttce = INFINITY;
   double max_er = 0, max_or = 0, arg_or = -1, max_eh = 0, max_oh = 0, max_cp = 0, max_hwc = 0, flag = 0;
+#pragma unroll 4
   for (int c = 0; c < n_chunks; ++c) {
     const double *p = partial + (size_t)c * NPS * Mp + m;
     if (p[PS_MIN_DCE * (size_t)Mp] < min_dce) { min_dce = p[PS_MIN_DCE * (size_t)Mp]; arg_dce = p[PS_ARG_DCE * (size_t)Mp]; }
@@ -1296,7 +1298,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   }
 
   if (A > 0) {
-    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles), dim3(256), (size_t)T * (TILE + 1) * sizeof(double), s, M, T,
+    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 4), dim3(256), (size_t)T * (TILE + 1) * sizeof(double), s, M, T,
                        Mp, d_x, d_y, d_theta, d_v, ctx->d_traj_tab);
     FO_HIP_TRY(ctx, hipGetLastError());
     SweepArgs a{};
@@ -1342,7 +1344,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     FO_HIP_TRY(ctx, hipGetLastError());
     be_btn = ctx->d_be_btn;
   }
-  hipLaunchKernelGGL(fo_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, M, Mp, A, n_chunks, ctx->d_partial,
+  hipLaunchKernelGGL(fo_reduce_kernel, dim3((M + 63) / 64), dim3(64), 0, s, M, Mp, A, n_chunks, ctx->d_partial,
                      ctx->thr, ctx->mask, be_btn, d_cost, d_safe);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
