@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <cstdlib>
+#include <type_traits>
 #include "fo_ctx.hpp"
 
 namespace {
@@ -887,76 +888,82 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       // of the gate samples g in [max(t0-1, 0), t1-1) -- harm index g, cp index g (Q6)
       const int g0s = max(gbase, 0), g1s = t1 - 1;
       if ((do_cp || do_hr) && g0s < g1s) {
-        // Ego samples are fetched two iterations ahead: vmcnt retires vector memory operations in issue order, loads
-        // and stores alike, so a load issued after the list stores of the previous iteration would not return
-        // before those stores are acknowledged.
-        const double *e_ = tj + (size_t)g0s * NEF * TILE;
-        double ec0 = e_[2 * TILE], es0 = e_[3 * TILE], ev0 = e_[5 * TILE];
-        double ex0 = 0.0, ey0 = 0.0, eth0 = 0.0, ex1 = 0.0, ey1 = 0.0, eth1 = 0.0;
-        if (lr4s) { ex0 = e_[0 * TILE]; ey0 = e_[1 * TILE]; eth0 = e_[4 * TILE]; }
-        e_ = tj + (size_t)min(g0s + 1, T - 1) * NEF * TILE;
-        double ec1 = e_[2 * TILE], es1 = e_[3 * TILE], ev1 = e_[5 * TILE];
-        if (lr4s) { ex1 = e_[0 * TILE]; ey1 = e_[1 * TILE]; eth1 = e_[4 * TILE]; }
-        const cdp_t gq = G + (size_t)min(g0s, L - 1) * NAF;
-        double gx1 = gq[0], gy1 = gq[1], gc1 = gq[2], gs1 = gq[3], gyaw1 = gq[4], gv1 = gq[5];  // agent row (one ahead)
-        double cpv = cpw[(g0s - gbase) * TILE + lane];
-        asm volatile("; scalar operands resident" ::"s"(gx1), "s"(gy1), "s"(gc1), "s"(gs1), "s"(gyaw1), "s"(gv1),
-                     "v"(cpv), "s"(f_ego), "s"(f_obs));
-        for (int t = g0s; t < g1s; ++t) {
-          const double gx = gx1, gy = gy1, pc = gc1, ps = gs1, gyaw = gyaw1, pv = gv1;
-          const int row = t - gbase;
-          const double cp = ((gmask >> row) & 1u) ? cpv : 0.0;
-          // the only LDS read of the iteration (next cp) goes out together with the scalar prefetch of the next agent
-          // row; both are first touched at the top of the next iteration (LDS and SMEM share lgkmcnt)
-          cpv = cpw[min(row + 1, TC - 1) * TILE + lane];
-          {
-            const cdp_t gn = G + (size_t)min(t + 1, L - 1) * NAF;
-            gx1 = gn[0]; gy1 = gn[1]; gc1 = gn[2]; gs1 = gn[3]; gyaw1 = gn[4]; gv1 = gn[5];
-          }
-          e_ = tj + (size_t)min(t + 2, T - 1) * NEF * TILE;
-          const double ec2 = e_[2 * TILE], es2 = e_[3 * TILE], ev2 = e_[5 * TILE];
-          double ex2 = 0.0, ey2 = 0.0, eth2 = 0.0;
-          if (lr4s) { ex2 = e_[0 * TILE]; ey2 = e_[1 * TILE]; eth2 = e_[4 * TILE]; }
-          double eh = NAN, oh = NAN, er = NAN, orr = NAN;
-          if (do_hr && t < Lh && !(a.ablate & 4)) {
-            const double cr = pc * ec0 + ps * es0;
-            const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
-            const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
-            if (lr4s) {
-              // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
-              double ddx = gx - ex0, ddy = gy - ey0;
-              if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;  // atan2(0, 0) = 0
-              const float relc = fo_atan2_crude((float)ddy, (float)ddx);
-              const double ke = fo_lr4s_coef_dir(ddx, ddy, ec0, es0, relc, 0.0f, eth0, a.hc.lr4s_side, a.hc.lr4s_rear);
-              const double ko = fo_lr4s_coef_dir(ddx, ddy, pc, ps, relc, 3.14159265f, gyaw, a.hc.lr4s_side, a.hc.lr4s_rear);
-              eh = fo_logistic_neg(exp_tab, c4 + s4c * ego_dv - ke);
-              oh = fo_logistic_neg(exp_tab, c4 + s4c * obs_dv - ko);
-            } else if (prot == 0) {
-              eh = fo_logistic_neg(exp_tab, c1 + s1c * ego_dv);
-              oh = fo_logistic_neg(exp_tab, a.hc.ped_const - a.hc.ped_speed * obs_dv);
-            } else {
-              eh = 1.0;
-              oh = 1.0;
+        // one instantiation per harm model: the LR4S path (impact-angle classes, three more ego fields in flight)
+        // and the pedestrian / LR1S path keep separate register and constant sets
+        auto pass2 = [&](auto lr4s_tag) {
+          constexpr bool LR4S = decltype(lr4s_tag)::value;
+          // Ego samples are fetched two iterations ahead: vmcnt retires vector memory operations in issue order, loads
+          // and stores alike, so a load issued after the list stores of the previous iteration would not return
+          // before those stores are acknowledged.
+          const double *e_ = tj + (size_t)g0s * NEF * TILE;
+          double ec0 = e_[2 * TILE], es0 = e_[3 * TILE], ev0 = e_[5 * TILE];
+          double ex0 = 0.0, ey0 = 0.0, eth0 = 0.0, ex1 = 0.0, ey1 = 0.0, eth1 = 0.0;
+          if (LR4S) { ex0 = e_[0 * TILE]; ey0 = e_[1 * TILE]; eth0 = e_[4 * TILE]; }
+          e_ = tj + (size_t)min(g0s + 1, T - 1) * NEF * TILE;
+          double ec1 = e_[2 * TILE], es1 = e_[3 * TILE], ev1 = e_[5 * TILE];
+          if (LR4S) { ex1 = e_[0 * TILE]; ey1 = e_[1 * TILE]; eth1 = e_[4 * TILE]; }
+          const cdp_t gq = G + (size_t)min(g0s, L - 1) * NAF;
+          double gx1 = gq[0], gy1 = gq[1], gc1 = gq[2], gs1 = gq[3], gyaw1 = gq[4], gv1 = gq[5];  // agent row (one ahead)
+          double cpv = cpw[(g0s - gbase) * TILE + lane];
+          asm volatile("; scalar operands resident" ::"s"(gx1), "s"(gy1), "s"(gc1), "s"(gs1), "s"(gyaw1), "s"(gv1),
+                       "v"(cpv), "s"(f_ego), "s"(f_obs));
+          for (int t = g0s; t < g1s; ++t) {
+            const double gx = gx1, gy = gy1, pc = gc1, ps = gs1, gyaw = gyaw1, pv = gv1;
+            const int row = t - gbase;
+            const double cp = ((gmask >> row) & 1u) ? cpv : 0.0;
+            // the only LDS read of the iteration (next cp) goes out together with the scalar prefetch of the next agent
+            // row; both are first touched at the top of the next iteration (LDS and SMEM share lgkmcnt)
+            cpv = cpw[min(row + 1, TC - 1) * TILE + lane];
+            {
+              const cdp_t gn = G + (size_t)min(t + 1, L - 1) * NAF;
+              gx1 = gn[0]; gy1 = gn[1]; gc1 = gn[2]; gs1 = gn[3]; gyaw1 = gn[4]; gv1 = gn[5];
             }
-            er = eh * cp;
-            orr = oh * cp;
-            max_er = fmax(max_er, er);
-            if (orr > max_or) { max_or = orr; idx_or = t; }
-            max_eh = fmax(max_eh, eh);
-            max_oh = fmax(max_oh, oh);
+            e_ = tj + (size_t)min(t + 2, T - 1) * NEF * TILE;
+            const double ec2 = e_[2 * TILE], es2 = e_[3 * TILE], ev2 = e_[5 * TILE];
+            double ex2 = 0.0, ey2 = 0.0, eth2 = 0.0;
+            if (LR4S) { ex2 = e_[0 * TILE]; ey2 = e_[1 * TILE]; eth2 = e_[4 * TILE]; }
+            double eh = NAN, oh = NAN, er = NAN, orr = NAN;
+            if (do_hr && t < Lh && !(a.ablate & 4)) {
+              const double cr = pc * ec0 + ps * es0;
+              const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
+              const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
+              if (LR4S) {
+                // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
+                double ddx = gx - ex0, ddy = gy - ey0;
+                if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;  // atan2(0, 0) = 0
+                const float relc = fo_atan2_crude((float)ddy, (float)ddx);
+                const double ke = fo_lr4s_coef_dir(ddx, ddy, ec0, es0, relc, 0.0f, eth0, a.hc.lr4s_side, a.hc.lr4s_rear);
+                const double ko = fo_lr4s_coef_dir(ddx, ddy, pc, ps, relc, 3.14159265f, gyaw, a.hc.lr4s_side, a.hc.lr4s_rear);
+                eh = fo_logistic_neg(exp_tab, c4 + s4c * ego_dv - ke);
+                oh = fo_logistic_neg(exp_tab, c4 + s4c * obs_dv - ko);
+              } else if (prot == 0) {
+                eh = fo_logistic_neg(exp_tab, c1 + s1c * ego_dv);
+                oh = fo_logistic_neg(exp_tab, a.hc.ped_const - a.hc.ped_speed * obs_dv);
+              } else {
+                eh = 1.0;
+                oh = 1.0;
+              }
+              er = eh * cp;
+              orr = oh * cp;
+              max_er = fmax(max_er, er);
+              if (orr > max_or) { max_or = orr; idx_or = t; }
+              max_eh = fmax(max_eh, eh);
+              max_oh = fmax(max_oh, oh);
+            }
+            if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
+            if (LISTS && valid) {
+              __builtin_nontemporal_store(cp, lp + FO_L_CP * ls);
+              __builtin_nontemporal_store(eh, lp + FO_L_EGO_HARM * ls);
+              __builtin_nontemporal_store(oh, lp + FO_L_OBST_HARM * ls);
+              __builtin_nontemporal_store(er, lp + FO_L_EGO_RISK * ls);
+              __builtin_nontemporal_store(orr, lp + FO_L_OBST_RISK * ls);
+              lp += M;
+            }
+            ec0 = ec1; es0 = es1; ev0 = ev1; ex0 = ex1; ey0 = ey1; eth0 = eth1;
+            ec1 = ec2; es1 = es2; ev1 = ev2; ex1 = ex2; ey1 = ey2; eth1 = eth2;
           }
-          if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
-          if (LISTS && valid) {
-            __builtin_nontemporal_store(cp, lp + FO_L_CP * ls);
-            __builtin_nontemporal_store(eh, lp + FO_L_EGO_HARM * ls);
-            __builtin_nontemporal_store(oh, lp + FO_L_OBST_HARM * ls);
-            __builtin_nontemporal_store(er, lp + FO_L_EGO_RISK * ls);
-            __builtin_nontemporal_store(orr, lp + FO_L_OBST_RISK * ls);
-            lp += M;
-          }
-          ec0 = ec1; es0 = es1; ev0 = ev1; ex0 = ex1; ey0 = ey1; eth0 = eth1;
-          ec1 = ec2; es1 = es2; ev1 = ev2; ex1 = ex2; ey1 = ey2; eth1 = eth2;
-        }
+        };
+        if (lr4s) pass2(std::true_type{}); else pass2(std::false_type{});
       }
     }
 
