@@ -1,0 +1,127 @@
+"""Host-side logic that needs no GPU: metric ordering, trajectory packing, obstacle state cache, ray fan definition,
+cell-window arithmetic, config / coefficient loading, agent-manager conventions."""
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_metric_dependency_order_matches_the_reference_rules():
+    """metric.py:125-147: wttc pulls ttc to the front, ttc/ttce/be pull dce to the front, hr pulls cp to the front"""
+    from frenetix_occlusion.metrics.metric import check_required_metrics as order
+    assert order(["hr", "ttc", "ttce", "dce", "wttc", "cp"]) == ["cp", "dce", "ttc", "hr", "ttce", "wttc"]
+    assert order(["hr", "ttc"]) == ["cp", "dce", "hr", "ttc"]
+    assert order(["wttc"]) == ["dce", "ttc", "wttc"]
+    assert order(["be"]) == ["dce", "be"]
+    assert order(["cp"]) == ["cp"] and order([]) == []
+    lst = ["ttce"]
+    assert order(lst) == ["dce", "ttce"] and lst == ["ttce"]          # the caller's list is not mutated
+
+
+def test_trajectory_packing_accepts_objects_and_dicts():
+    from frenetix_occlusion.metrics.metric import trajectories_to_arrays
+    mk = lambda off: SimpleNamespace(cartesian=SimpleNamespace(x=np.arange(5.0) + off, y=np.zeros(5), theta=np.zeros(5),
+                                                              v=np.ones(5), a=np.zeros(5)))
+    arr = trajectories_to_arrays([mk(0.0), mk(10.0)])
+    assert set(arr) == {"x", "y", "theta", "v", "a"} and arr["x"].shape == (2, 5) and arr["x"][1, 0] == 10.0
+    d = {"x": np.zeros((3, 4))}
+    assert trajectories_to_arrays(d) is d
+    bad = mk(0.0)
+    bad.cartesian.x = np.arange(4.0)
+    with pytest.raises(ValueError):
+        trajectories_to_arrays([mk(0.0), bad])
+
+
+def test_obstacle_cache_follows_the_reference_timestep_semantics():
+    """fo_obstacle.py:79-116: rel = step - initial; 0 -> initial state; >= 1 -> state_list[rel-1]; else absent"""
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    obs = FOObstacles(sc.obstacles)
+    assert len(obs) == 5
+    o = sc.obstacles[0]
+    obs.update(o.initial_time_step)
+    first = next(iter(obs))
+    np.testing.assert_array_equal(first.current_pos, o.initial[:2])
+    obs.update(o.initial_time_step + 3)
+    np.testing.assert_array_equal(first.current_pos, o.states[2, :2])
+    c = first.current_corner_points
+    assert c.shape == (4, 2)
+    np.testing.assert_allclose(np.linalg.norm(c[0] - c[1]), o.width, atol=1e-12)       # (-l/2,-w/2) -> (-l/2,+w/2)
+    np.testing.assert_allclose(np.linalg.norm(c[1] - c[2]), o.length, atol=1e-12)
+    obs.update(o.initial_time_step + len(o.states) + 5)
+    assert first.current_pos is None
+    corn, cen, flags = obs.arrays()
+    assert flags[0] == 0 and corn.shape == (5, 4, 2)
+    # bicycles exist but do not occlude (sensor_model.py:177)
+    bike = S.Obstacle(99, "dynamic", "bicycle", 2.0, 0.9, 0, np.array([1.0, 2.0, 0.3, 5.0]), np.zeros((0, 4)))
+    obs.add(bike)
+    obs.update(0)
+    assert obs.arrays()[2][-1] == 1
+
+
+def test_duck_typed_commonroad_objects_are_accepted():
+    from frenetix_occlusion import scenario as S
+    st = lambda x, y, yaw, v, ts=0: SimpleNamespace(position=np.array([x, y]), orientation=yaw, velocity=v, time_step=ts)
+    cr = SimpleNamespace(obstacle_id=7, obstacle_type=SimpleNamespace(value="car"), obstacle_role=SimpleNamespace(value="dynamic"),
+                         obstacle_shape=SimpleNamespace(length=4.5, width=1.8), initial_state=st(1, 2, 0.1, 3, 4),
+                         prediction=SimpleNamespace(trajectory=SimpleNamespace(state_list=[st(2, 2, 0.1, 3), st(3, 2, 0.1, 3)])))
+    o = S.obstacle_from_commonroad(cr)
+    assert (o.obstacle_id, o.role, o.obstacle_type, o.initial_time_step) == (7, "dynamic", "car", 4)
+    assert o.pose_at(5)[0] == 2.0 and o.pose_at(7) is None
+    ll = SimpleNamespace(lanelet_id=3, left_vertices=np.array([[0, 1], [5, 1.0]]), right_vertices=np.array([[0, -1], [5, -1.0]]),
+                         successor=[4], predecessor=[], adj_left=None, adj_right=None)
+    out = S.lanelets_of(SimpleNamespace(lanelets=[ll]))
+    assert out[0].lanelet_id == 3 and out[0].successors == [4] and out[0].polygon.shape == (4, 2)
+
+
+def test_ray_fan_definition():
+    from frenetix_occlusion.sensor_model import ray_dirs
+    d = ray_dirs(720, 0.3, 360.0)
+    assert d.shape == (720, 2)
+    np.testing.assert_allclose(np.hypot(d[:, 0], d[:, 1]), 1.0, atol=1e-15)
+    np.testing.assert_allclose(np.arctan2(d[1, 1], d[1, 0]) - 0.3, 2 * math.pi / 720, atol=1e-12)      # 0.5 degrees
+    f = ray_dirs(181, 1.0, 90.0)
+    np.testing.assert_allclose(np.arctan2(f[0, 1], f[0, 0]), 1.0 - math.pi / 4, atol=1e-12)
+    np.testing.assert_allclose(np.arctan2(f[-1, 1], f[-1, 0]), 1.0 + math.pi / 4, atol=1e-12)
+    cross = f[:-1, 0] * f[1:, 1] - f[:-1, 1] * f[1:, 0]
+    assert (cross > 0).all()                                                                             # counter-clockwise
+
+
+def test_cell_window_round_trip():
+    from frenetix_occlusion.sensor_model import CellWindow
+    w = CellWindow(x0=-10.0, y0=4.0, cs=0.5, ix0=3, iy0=-2, nx=7, ny=5)
+    idx = np.arange(35)
+    c = w.centers(idx)
+    assert np.array_equal(w.cell_of(c), idx)
+    assert c[0, 0] == -10.0 + 3.5 * 0.5 and c[0, 1] == 4.0 - 1.5 * 0.5
+    assert w.cell_of([[100.0, 100.0]])[0] == -1
+
+
+def test_default_config_and_coefficients_load():
+    import yaml
+    from frenetix_occlusion import interface
+    from frenetix_occlusion.metrics.metric import load_harm_coeff
+    from frenetix_occlusion.sweep import DEFAULT_HARM_COEFF
+    cfg = interface.FOInterface._load_config(None)          # the reference computes this default but does not use it
+    assert cfg["sensor_model"] == {"sensor_radius": 50, "sensor_angle": 360}
+    assert cfg["metrics"]["activated_metrics"] == ["hr", "ttc", "ttce", "dce", "wttc", "cp"]
+    assert cfg["agent_manager"]["prediction"]["variance_factor"] == 1.05
+    assert set(cfg["agent_manager"]) >= {"bicycle", "car", "truck", "pedestrian", "prediction"}
+    assert load_harm_coeff() == DEFAULT_HARM_COEFF            # harm_params.json entries the reference reads
+
+
+def test_no_gpu_interface_refuses_to_start():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario2_geometry.npz"))
+    with pytest.raises(RuntimeError):
+        interface.FOInterface(sc, np.zeros((2, 2)), SimpleNamespace(length=4.5, width=1.6, wb_rear_axle=1.4, mass=1000.0,
+                                                                     a_max=11.5), 0.1)
