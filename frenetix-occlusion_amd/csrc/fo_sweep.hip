@@ -736,7 +736,11 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     int idx_or = 0, idx_cp = 0;
     const size_t ls = (size_t)A * Tm1 * M;
     double *lp = LISTS ? a.lists + (size_t)k * Tm1 * M + m : nullptr;
-    const double c4 = -a.hc.lr4s_const, s4c = -a.hc.lr4s_speed, c1 = -a.hc.lr1s_const, s1c = -a.hc.lr1s_speed;
+    // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
+    // (harm_model.py:96-97: ego_dv = m_obs/(m_ego+m_obs) dv, obs_dv = m_ego/(m_ego+m_obs) dv)
+    const double c4 = -a.hc.lr4s_const, c1 = -a.hc.lr1s_const;
+    const double k4e = -a.hc.lr4s_speed * f_ego, k4o = -a.hc.lr4s_speed * f_obs;
+    const double k1e = -a.hc.lr1s_speed * f_ego, kpo = -a.hc.ped_speed * f_obs;
     const bool lr4s = prot == 1;
     const double gate_far2 = (5.0 + hdev + 1e-6) * (5.0 + hdev + 1e-6);
 
@@ -906,7 +910,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
           double gx1 = gq[0], gy1 = gq[1], gc1 = gq[2], gs1 = gq[3], gyaw1 = gq[4], gv1 = gq[5];  // agent row (one ahead)
           double cpv = cpw[(g0s - gbase) * TILE + lane];
           asm volatile("; scalar operands resident" ::"s"(gx1), "s"(gy1), "s"(gc1), "s"(gs1), "s"(gyaw1), "s"(gv1),
-                       "v"(cpv), "s"(f_ego), "s"(f_obs));
+                       "v"(cpv));
           for (int t = g0s; t < g1s; ++t) {
             const double gx = gx1, gy = gy1, pc = gc1, ps = gs1, gyaw = gyaw1, pv = gv1;
             const int row = t - gbase;
@@ -926,7 +930,6 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             if (do_hr && t < Lh && !(a.ablate & 4)) {
               const double cr = pc * ec0 + ps * es0;
               const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
-              const double ego_dv = f_ego * dv, obs_dv = f_obs * dv;
               if (LR4S) {
                 // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
                 double ddx = gx - ex0, ddy = gy - ey0;
@@ -934,11 +937,11 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
                 const float relc = fo_atan2_crude((float)ddy, (float)ddx);
                 const double ke = fo_lr4s_coef_dir(ddx, ddy, ec0, es0, relc, 0.0f, eth0, a.hc.lr4s_side, a.hc.lr4s_rear);
                 const double ko = fo_lr4s_coef_dir(ddx, ddy, pc, ps, relc, 3.14159265f, gyaw, a.hc.lr4s_side, a.hc.lr4s_rear);
-                eh = fo_logistic_neg(exp_tab, c4 + s4c * ego_dv - ke);
-                oh = fo_logistic_neg(exp_tab, c4 + s4c * obs_dv - ko);
+                eh = fo_logistic_neg(exp_tab, fma(k4e, dv, c4) - ke);
+                oh = fo_logistic_neg(exp_tab, fma(k4o, dv, c4) - ko);
               } else if (prot == 0) {
-                eh = fo_logistic_neg(exp_tab, c1 + s1c * ego_dv);
-                oh = fo_logistic_neg(exp_tab, a.hc.ped_const - a.hc.ped_speed * obs_dv);
+                eh = fo_logistic_neg(exp_tab, fma(k1e, dv, c1));
+                oh = fo_logistic_neg(exp_tab, fma(kpo, dv, a.hc.ped_const));
               } else {
                 eh = 1.0;
                 oh = 1.0;
