@@ -157,3 +157,22 @@ def test_no_obstacles_and_ego_off_the_raster_edge(torch_cuda, oracle):
     _check_step(torch_cuda, oracle, sc, ego, 5.0, 0)
     ego[:2] = sc.lanelets[0].center[0]      # window hangs over the raster border
     _check_step(torch_cuda, oracle, sc, ego, 5.0, 0)
+
+
+def test_map_without_obstacles_or_with_everything_absent(torch_cuda, oracle):
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    # time step far beyond every obstacle's state list: all flags 0
+    _check_step(torch_cuda, oracle, sc, sc.ego_initial, 7.63, 10_000)
+    # a bicycle in front of the ego must not cast a shadow (Q10) but is itself visible
+    bike = S.Obstacle(555, "static", "bicycle", 2.0, 0.9, 0, np.array([8.0, 0.0, 0.0, 0.0]), np.zeros((0, 4)))
+    sc.obstacles = [bike]
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    sm = SensorModel(sc.lanelets, None, sensor_radius=50.0, sensor_angle=360.0)
+    ob = FOObstacles(sc.obstacles)
+    ob.update(0)
+    sm.calc_visible_and_occluded_area(0, sc.ego_initial[:2], float(sc.ego_initial[2]), ob)
+    E = len(sm.map_geometry.edges)
+    assert (sm.hit_id.cpu().numpy() < E).all() and sm.visible_objects_timestep == [555]
+    _check_step(torch_cuda, oracle, sc, sc.ego_initial, 7.63, 0)

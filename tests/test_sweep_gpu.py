@@ -269,3 +269,29 @@ def test_be_metric_matches_oracle(torch_cuda, oracle):
     sw.set_agents(*[agents[k] for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")])
     with pytest.raises(N.NativeError):
         sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], None)
+
+
+def test_empty_trajectory_batch_and_single_lane(torch_cuda, oracle):
+    from frenetix_occlusion import synthetic as S
+    traj, agents = S.make_batch(65, 3, config_id=12)
+    empty = {k: v[:0] for k, v in traj.items()}
+    got = _hip_sweep(torch_cuda, empty, agents, S.VEHICLE_BMW320I, 0.1, mode="full")
+    assert got["cost"].shape == (0, 16) and got["safe"].shape == (0,) and got["lists"].shape == (0, 3, 5, 30)
+    # 65 trajectories: one full tile + one tile with a single valid lane
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.2})
+    _compare(oracle, ref, _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.2}))
+    # agents standing exactly on the ego's start pose (atan2(0, 0) branch of the angle classes, overlap at t = 0)
+    agents["pos"][0] = np.array([traj["x"][0, 0], traj["y"][0, 0]])
+    agents["type"][0] = 0
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1)
+    _compare(oracle, ref, _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1))
+
+
+def test_every_obstacle_type_and_many_agents(torch_cuda, oracle):
+    """all ObstacleType codes (mass / protection tables of harm_model.py:15-32,158-190) and A > one agent chunk"""
+    from frenetix_occlusion import synthetic as S
+    traj, agents = S.make_batch(96, 70, config_id=13)
+    agents["type"] = (np.arange(70) % 12).astype(np.int32)
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"risk": 0.3}, nthreads=8)
+    got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"risk": 0.3})
+    _compare(oracle, ref, got)
