@@ -81,7 +81,10 @@ class FOAgentManager:
         v = self._velocity(velocity, conf, key in ("car", "truck"))
         pos = np.asarray(pos, dtype=np.float64)
         if orientation is None:
-            orientation = self._heading_towards_path(pos)
+            curve = self.reference_path
+            if mode == "lane_center":                            # agent.py:459-467; off-lanelet -> reference path (Q12)
+                curve = self._lane_center_at(pos)
+            orientation = self._heading_towards_path(pos, curve)
         agent = PhantomAgent(self._create_id(), agent_type, pos, float(orientation), v, float(conf["length"]),
                              float(conf["width"]))
         agent.predictions = [self._cv_prediction(agent, horizon)]
@@ -102,9 +105,21 @@ class FOAgentManager:
             self._pred_cache = None
         return agent
 
-    def _heading_towards_path(self, pos):
-        """agent.py:475-481 + helper_functions.py:38-76: unit normal towards the reference path, angle in [0, 2 pi)"""
-        p = self.reference_path
+    def _lane_center_at(self, pos):
+        from .scenario import lanelets_of, points_in_polygon
+        try:
+            lanelets = lanelets_of(self.scenario.lanelet_network if hasattr(self.scenario, "lanelet_network") else self.scenario)
+        except Exception:
+            return self.reference_path
+        q = np.asarray(pos, dtype=np.float64).reshape(1, 2)
+        for ll in lanelets:
+            if points_in_polygon(q, ll.polygon)[0]:
+                return ll.center
+        return self.reference_path
+
+    def _heading_towards_path(self, pos, curve=None):
+        """agent.py:475-481 + helper_functions.py:38-76: unit normal towards the curve, angle in [0, 2 pi)"""
+        p = self.reference_path if curve is None else np.asarray(curve, dtype=np.float64)
         a, b = p[:-1], p[1:]
         e = b - a
         l2 = np.maximum(np.sum(e * e, axis=1), 1e-300)

@@ -110,7 +110,12 @@ class FOInterface:
         # phantom sampling + predictions stay on the device; the spawn-point list is the reference's host view
         self.spawn_points = self.spawn_locator.find_spawn_points(self.ego_pos, self.ego_orientation, self.ego_pos_cl,
                                                                  ego_v)
-        self.agent_manager.attach_batch(self.spawn_locator.batch, len(self.spawn_points))
+        if self.spawn_locator.batch is not None:
+            self.agent_manager.attach_batch(self.spawn_locator.batch, self.spawn_locator.n_cell_points)
+        for sp in self.spawn_locator.rule_points:       # rule-based points become agents the reference's way (:192-198)
+            mode = "lane_center" if sp.source in ("left turn", "right turn") else "ref_path"
+            self.agent_manager.add_agent(pos=sp.position, velocity="default", agent_type=sp.agent_type,
+                                         timestep=self.timestep, horizon=3.0, mode=mode, orientation=sp.orientation)
         if self.debug:
             for sp in self.spawn_points:
                 print("Phantom agent of type {} added to scenario at position {}".format(sp.agent_type, sp.position))

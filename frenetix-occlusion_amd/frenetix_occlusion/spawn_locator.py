@@ -77,6 +77,11 @@ class SpawnLocator:
         self.dt = float(dt)
         self.T = int(horizon / self.dt) + 1                      # agent.py:496
         self.min_ahead = float(acc.get("min_ahead", MIN_AHEAD))
+        self.mode = str(acc.get("mode", "cells"))                  # "cells" | "rules" | "both" (spawn_rules.py)
+        if self.mode not in ("cells", "rules", "both"):
+            raise ValueError("accelerator.spawn.mode must be 'cells', 'rules' or 'both'")
+        self.rule_points = []
+        self._rules = None
         self.all_occluded = bool(acc.get("all_occluded", False))   # False: only the visible/occluded frontier
         self.max_dist_override = acc.get("max_dist")               # None: the reference's max(4 v, 25) m
         am = config["agent_manager"]
@@ -133,21 +138,69 @@ class SpawnLocator:
                       torch.cuda.current_stream().cuda_stream)
         return b
 
+    def _rule_engine(self):
+        if self._rules is None:
+            from .scenario import lanelets_of, points_in_polygon
+            from .spawn_rules import SpawnRules
+            from .utils.curvilinear import PolylineCS
+            sm = self.sensor_model
+            if self.cosy_cl is None:
+                self.cosy_cl = PolylineCS(self.ref_path)     # interface.py docstring: "initialized if not provided"
+            try:
+                lanelets = lanelets_of(sm.lanelet_network)
+            except Exception:
+                lanelets = []
+
+            def lane_yaw_at(xy):
+                if sm.lane_yaw is None:
+                    return None
+                (x0, y0), (nx, ny) = sm.raster_origin, sm.raster_dims
+                ix, iy = int(math.floor((xy[0] - x0) / sm.cell_size)), int(math.floor((xy[1] - y0) / sm.cell_size))
+                if not (0 <= ix < nx and 0 <= iy < ny) or np.isnan(sm.lane_yaw[iy, ix]):
+                    return None
+                return float(sm.lane_yaw[iy, ix])
+
+            def lanelet_of(xy):
+                q = np.asarray(xy, dtype=np.float64).reshape(1, 2)
+                for ll in lanelets:
+                    if points_in_polygon(q, ll.polygon)[0]:
+                        return ll
+                return None
+            self._rules = SpawnRules(self.config, self.ref_path, self.cosy_cl, lane_yaw_at, lanelet_of, self.fo_obstacles,
+                                     self.debug)
+        self._rules.cosy_cl = self.cosy_cl or self._rules.cosy_cl
+        return self._rules
+
     def find_spawn_points(self, ego_pos, ego_orientation, ego_pos_cl, ego_v):
-        """reference signature (spawn_locator.py:80): returns list[SpawnPoint] (one small D2H copy)"""
-        b = self.sample(ego_pos, ego_orientation, ego_v)
-        n = int(b.n.item())
-        pos0 = b.pos0[:n].cpu().numpy()
-        yaw0 = b.yaw0[:n].cpu().numpy()
-        typ = b.type[:n].cpu().numpy()
-        self.spawn_points = []
-        for j in range(n):
-            cl = None
-            if self.cosy_cl is not None:
-                try:
-                    cl = np.asarray(self.cosy_cl.convert_to_curvilinear_coords(pos0[j, 0], pos0[j, 1]))
-                except Exception:   # out of the projection domain: the reference skips silently (:228-231)
-                    cl = None
-            self.spawn_points.append(SpawnPoint(pos0[j].copy(), TYPE_NAME[int(typ[j])], cl, "occluded frontier",
-                                                float(yaw0[j])))
+        """reference signature (spawn_locator.py:80): returns list[SpawnPoint].  Cell-sampled points come from the
+        device (one small D2H copy); rule-based points (mode 'rules' / 'both') are evaluated on a host copy of the
+        cell classes and are turned into agents by the caller through ``FOAgentManager.add_agent``."""
+        self.spawn_points, self.rule_points = [], []
+        if self.mode in ("cells", "both"):
+            b = self.sample(ego_pos, ego_orientation, ego_v)
+            n = int(b.n.item())
+            pos0 = b.pos0[:n].cpu().numpy()
+            yaw0 = b.yaw0[:n].cpu().numpy()
+            typ = b.type[:n].cpu().numpy()
+            for j in range(n):
+                cl = None
+                if self.cosy_cl is not None:
+                    try:
+                        cl = np.asarray(self.cosy_cl.convert_to_curvilinear_coords(pos0[j, 0], pos0[j, 1]))
+                    except Exception:   # out of the projection domain: the reference skips silently (:228-231)
+                        cl = None
+                self.spawn_points.append(SpawnPoint(pos0[j].copy(), TYPE_NAME[int(typ[j])], cl, "occluded frontier",
+                                                    float(yaw0[j])))
+        else:
+            self.batch = None
+        self.n_cell_points = len(self.spawn_points)
+        if self.mode in ("rules", "both"):
+            from .spawn_rules import CellView
+            rules = self._rule_engine()
+            sm = self.sensor_model
+            view = CellView(sm.cell_class.cpu().numpy(), sm.window)
+            if ego_pos_cl is None:
+                ego_pos_cl = rules.cosy_cl.convert_to_curvilinear_coords(float(ego_pos[0]), float(ego_pos[1]))
+            self.rule_points = rules.find(view, ego_pos, ego_pos_cl, ego_v)
+            self.spawn_points = self.spawn_points + self.rule_points
         return self.spawn_points

@@ -142,3 +142,53 @@ def test_manual_agents_and_error_conventions(torch_cuda, oracle, tmp_path):
     with pytest.raises(ValueError):
         from frenetix_occlusion.metrics.metric import Metric
         Metric({"activated_metrics": ["nope"], "metric_thresholds": {}}, fo.vehicle_params, am, dt=0.1)
+
+
+def test_rule_based_spawn_points_through_the_interface(torch_cuda, oracle, tmp_path):
+    """accelerator.spawn.mode = rules / both on scenario 3 (right turn at an intersection, parked car in the side
+    street): the reference's 'behind turn' rule evaluated on the GPU's cell classes puts a pedestrian behind the
+    corner; rule points become agents through add_agent and are assessed like every other phantom."""
+    import yaml
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion import synthetic as SY
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario3_geometry.npz"))
+    by = {l.lanelet_id: l for l in sc.lanelets}
+    parts = [by[1].center]
+    for lid in (12, 9):                                   # incoming lanelet -> right-turn lanelet -> side street
+        c = by[lid].center
+        parts.append(c[1:] if np.linalg.norm(c[0] - parts[-1][-1]) < 1e-2 else c)
+    ref_path = np.concatenate(parts)
+    ego = np.array([12.0, 0.0, 0.0, 8.0])
+    veh = SimpleNamespace(length=SY.VEHICLE_BMW320I[0], width=SY.VEHICLE_BMW320I[1], wb_rear_axle=SY.VEHICLE_BMW320I[2],
+                          mass=SY.VEHICLE_BMW320I[3], a_max=SY.VEHICLE_BMW320I[4])
+    found = {}
+    for mode in ("rules", "both"):
+        cfg["accelerator"]["spawn"]["mode"] = mode
+        cfg["accelerator"]["spawn"]["max_agents"] = 6
+        p = tmp_path / f"occ_{mode}.yaml"
+        p.write_text(yaml.safe_dump(cfg))
+        fo = interface.FOInterface(sc, ref_path, veh, 0.1, config_path=str(p))
+        fo.evaluate_scenario({}, ego[:2], float(ego[2]), None, float(ego[3]), 0, None)
+        rule_pts = fo.spawn_locator.rule_points
+        found[mode] = (len(fo.spawn_points), len(rule_pts))
+        assert len(rule_pts) == 1 and rule_pts[0].source == "right turn" and rule_pts[0].agent_type == "Pedestrian"
+        pos = rule_pts[0].position
+        assert 31.0 < pos[0] < 33.5 and -4.5 < pos[1] < -1.0          # behind the corner, right of the reference path
+        assert not fo.sensor_model.visible_area.contains(pos[None])[0]
+        assert len(fo.agent_manager.phantom_agents) == len(fo.spawn_points)
+        ped = fo.agent_manager.phantom_agents[-1]
+        assert ped.agent_type == "Pedestrian" and 0.0 <= ped.initial_orientation < 2 * math.pi
+        traj = SY.make_trajectories(40, seed=3, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+        ba = fo.trajectory_safety_assessment_batch(traj, mode="pair")
+        torch_cuda.cuda.synchronize()
+        arrs = fo.agent_manager.sweep_arrays()
+        agents = dict(zip(("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len"), [t.cpu().numpy() for t in arrs]))
+        ref = oracle.sweep(traj, agents, SY.VEHICLE_BMW320I, 0.1, thr={"harm": 1, "risk": 1}, want_lists=False)
+        got = ba.cost.cpu().numpy()
+        f = np.isfinite(ref["cost"])
+        assert np.array_equal(np.isfinite(got), f)
+        np.testing.assert_allclose(got[f], ref["cost"][f], rtol=0, atol=1e-9)
+    assert found["rules"] == (1, 1) and found["both"][0] > 1 and found["both"][1] == 1
