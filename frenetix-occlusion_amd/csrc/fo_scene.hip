@@ -34,6 +34,10 @@ struct Scene {
   double *d_edges = nullptr;      // [E][4]
   uint8_t *d_raster = nullptr;    // [rny][rnx]
   double *d_lane_yaw = nullptr;   // [rny][rnx] or null
+  // phantom vehicle routes (optional): routes r < R of lanelet p = vertices route_first[p*R+r] .. +route_count[p*R+r]
+  int R = 0, n_lanelets = 0;
+  int32_t *d_route_first = nullptr, *d_route_count = nullptr, *d_lanelet_raster = nullptr;
+  double *d_route_xy = nullptr, *d_route_s = nullptr;
   // per-step workspace
   size_t cap_cand = 0, cap_vis32 = 0;
   int32_t *d_vis32 = nullptr;     // [O] probe results (zero between steps)
@@ -422,36 +426,113 @@ __global__ __launch_bounds__(256) void fo_spawn_pick_kernel(const int32_t *__res
   if (lane == 0) { cell[j] = ci; pos[2 * j] = px; pos[2 * j + 1] = py; yaw[j] = a; }
 }
 
-// predictions in the layout fo_sweep_set_agents consumes; slots j >= n are inactive (len = 0)
-__global__ void fo_spawn_predict_kernel(int max_agents, const int32_t *__restrict__ n_ptr,
-                                        const double *__restrict__ pos0, const double *__restrict__ yaw0, SpawnTypes st,
-                                        int T, double dt, double var0, double factor, double *__restrict__ pos,
-                                        double *__restrict__ yaw, double *__restrict__ v, double *__restrict__ cov,
-                                        double *__restrict__ shape, double *__restrict__ raw, int32_t *__restrict__ type,
-                                        int32_t *__restrict__ len) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= max_agents * T) return;
-  const int j = i / T, k = i % T;
+// Predictions in the layout fo_sweep_set_agents consumes, one wave per prediction slot (j, r), r < R:
+//   vehicle whose cell lies on a lanelet with routes -> route r of that lanelet: constant speed along the route's
+//     centre line, initial lateral offset kept (what the reference's min-var(v) Frenet sample amounts to; replaces
+//     route_planner.py:31-90 + frenetix_handler.py + agent.py:283-426); the prediction ends where the route ends;
+//   pedestrian / off-lane vehicle / no route table -> r = 0: straight constant velocity (agent.py:451-536), r > 0 empty.
+// Slots of agents j >= n are inactive (len = 0).
+__global__ __launch_bounds__(64) void fo_spawn_predict_kernel(int max_agents, int R, const int32_t *__restrict__ n_ptr,
+                                                              const int32_t *__restrict__ cell,
+                                                              const double *__restrict__ pos0,
+                                                              const double *__restrict__ yaw0, SpawnTypes st, int T,
+                                                              double dt, double var0, double factor, int nx, int ix0,
+                                                              int iy0, int rnx, int rny,
+                                                              const int32_t *__restrict__ lanelet_raster, int RT,
+                                                              const int32_t *__restrict__ route_first,
+                                                              const int32_t *__restrict__ route_count,
+                                                              const double *__restrict__ route_xy,
+                                                              const double *__restrict__ route_s,
+                                                              double *__restrict__ pos, double *__restrict__ yaw,
+                                                              double *__restrict__ v, double *__restrict__ cov,
+                                                              double *__restrict__ shape, double *__restrict__ raw,
+                                                              int32_t *__restrict__ type, int32_t *__restrict__ len) {
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x, j = slot / R, r = slot % R;
   const bool on = j < *n_ptr;
-  const int s = j & 3;
-  const double spd = st.speed[s];
-  const double a = yaw0[j];
-  const double vx = __builtin_rint(spd * cos(a) * 1000.0) / 1000.0;  // round(v cos psi, 3)  (agent.py:492, Q12)
-  const double vy = __builtin_rint(spd * sin(a) * 1000.0) / 1000.0;
-  const double t = (double)k * dt;
-  pos[2 * (size_t)i] = on ? pos0[2 * j] + t * vx : 0.0;
-  pos[2 * (size_t)i + 1] = on ? pos0[2 * j + 1] + t * vy : 0.0;
-  yaw[i] = on ? a : 0.0;
-  v[i] = on ? spd : 0.0;
-  const double var = var0 * pow(factor, (double)k);  // agent.py:273
-  double *c = cov + 4 * (size_t)i;
-  c[0] = var; c[1] = 0.0; c[2] = 0.0; c[3] = var;
-  if (k == 0) {
-    shape[2 * j] = st.infl_l[s]; shape[2 * j + 1] = st.infl_w[s];
-    raw[2 * j] = st.raw_l[s]; raw[2 * j + 1] = st.raw_w[s];
-    type[j] = st.type[s];
-    len[j] = on ? T : 0;
+  const int sdx = j & 3;
+  const double spd = st.speed[sdx];
+  double *P = pos + (size_t)slot * T * 2, *Y = yaw + (size_t)slot * T, *V = v + (size_t)slot * T;
+  double *C = cov + (size_t)slot * T * 4;
+  for (int k = lane; k < T; k += 64) {
+    const double var = var0 * pow(factor, (double)k);  // agent.py:273
+    C[4 * k] = var; C[4 * k + 1] = 0.0; C[4 * k + 2] = 0.0; C[4 * k + 3] = var;
   }
+  if (lane == 0) {
+    shape[2 * slot] = st.infl_l[sdx]; shape[2 * slot + 1] = st.infl_w[sdx];
+    raw[2 * slot] = st.raw_l[sdx]; raw[2 * slot + 1] = st.raw_w[sdx];
+    type[slot] = st.type[sdx];
+  }
+  int ll = -1;
+  if (on && lanelet_raster && st.type[sdx] != FO_TYPE_PEDESTRIAN) {
+    const int ci = cell[j];
+    const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
+    if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny) ll = lanelet_raster[(size_t)wy * rnx + wx];
+  }
+  const bool routed = on && ll >= 0 && r < RT && route_count[(size_t)ll * RT] > 0;
+  int L = 0;
+  if (on && !routed && r == 0) {  // straight constant velocity
+    const double a = yaw0[j];
+    const double vx = __builtin_rint(spd * cos(a) * 1000.0) / 1000.0;  // round(v cos psi, 3)  (agent.py:492, Q12)
+    const double vy = __builtin_rint(spd * sin(a) * 1000.0) / 1000.0;
+    for (int k = lane; k < T; k += 64) {
+      const double t = (double)k * dt;
+      P[2 * k] = pos0[2 * j] + t * vx; P[2 * k + 1] = pos0[2 * j + 1] + t * vy; Y[k] = a; V[k] = spd;
+    }
+    L = T;
+  } else if (routed && route_count[(size_t)ll * RT + r] >= 2) {
+    const int nv = route_count[(size_t)ll * RT + r];
+    const double *q = route_xy + 2 * (size_t)route_first[(size_t)ll * RT + r];
+    const double *sq = route_s + route_first[(size_t)ll * RT + r];
+    const double px = pos0[2 * j], py = pos0[2 * j + 1];
+    double best = INFINITY, s0 = 0.0, d0 = 0.0;
+    int bi = 0x7fffffff;
+    for (int i = lane; i + 1 < nv; i += 64) {  // closest point of the route: per lane ascending i, first minimum
+      const double ax = q[2 * i], ay = q[2 * i + 1], ex = q[2 * i + 2] - ax, ey = q[2 * i + 3] - ay;
+      const double l2 = ex * ex + ey * ey;
+      double t = ((px - ax) * ex + (py - ay) * ey) / l2;
+      if (t < 0.0) t = 0.0;
+      if (t > 1.0) t = 1.0;
+      const double cx = ax + t * ex, cy = ay + t * ey;
+      const double d2 = (px - cx) * (px - cx) + (py - cy) * (py - cy);
+      if (d2 < best) {
+        const double l = sqrt(l2);
+        best = d2; bi = i;
+        s0 = sq[i] + t * l;
+        d0 = ((px - cx) * (-ey) + (py - cy) * ex) / l;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {  // across lanes: smallest (d2, i)
+      const double b2 = __shfl_xor(best, off), s2 = __shfl_xor(s0, off), dd2 = __shfl_xor(d0, off);
+      const int i2 = __shfl_xor(bi, off);
+      if (b2 < best || (b2 == best && i2 < bi)) { best = b2; bi = i2; s0 = s2; d0 = dd2; }
+    }
+    const double s_end = sq[nv - 1];
+    for (int k = lane; k < T; k += 64) {
+      const double sk = s0 + spd * ((double)k * dt);
+      if (sk > s_end) continue;
+      int lo = 0, hi = nv - 2;  // largest m <= nv-2 with sq[m] <= sk
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (sq[mid] <= sk) lo = mid; else hi = mid - 1;
+      }
+      const int m = lo;
+      const double ex = q[2 * m + 2] - q[2 * m], ey = q[2 * m + 3] - q[2 * m + 1];
+      const double l = sqrt(ex * ex + ey * ey), ux = ex / l, uy = ey / l, loc = sk - sq[m];
+      P[2 * k] = q[2 * m] + loc * ux + d0 * (-uy);
+      P[2 * k + 1] = q[2 * m + 1] + loc * uy + d0 * ux;
+      Y[k] = atan2(uy, ux);
+      V[k] = spd;
+    }
+    // number of samples on the route: sk is non-decreasing in k, so the valid samples are a prefix
+    int cnt = 0;
+    for (int k = 0; k < T; ++k) cnt += (s0 + spd * ((double)k * dt) > s_end) ? 0 : 1;
+    L = cnt;
+  }
+  for (int k = lane; k < T; k += 64)
+    if (k >= L) { P[2 * k] = 0.0; P[2 * k + 1] = 0.0; Y[k] = 0.0; V[k] = 0.0; }
+  if (lane == 0) len[slot] = L;
 }
 
 int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
@@ -479,7 +560,8 @@ extern "C" {
 void fo_scene_destroy_(fo_ctx *ctx) {
   if (!ctx || !ctx->scene) return;
   Scene *sc = (Scene *)ctx->scene;
-  void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_vis32, sc->d_flags, sc->d_blk,
+  void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_vis32, sc->d_route_first, sc->d_route_count, sc->d_lanelet_raster, sc->d_route_xy,
+                  sc->d_route_s, sc->d_flags, sc->d_blk,
                   sc->d_cand, sc->d_ncand};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -521,6 +603,8 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
     return fo_fail(ctx, FO_E_ARG, "fo_scene_set_map: raster %d x %d out of range", sc->rnx, sc->rny);
   }
   sc->P = P; sc->E = E; sc->cs = cs;
+  sc->R = 0;  // a new raster invalidates the route table
+  if (sc->d_lanelet_raster) { (void)hipFree(sc->d_lanelet_raster); sc->d_lanelet_raster = nullptr; }
   for (void **p : {(void **)&sc->d_edges, (void **)&sc->d_raster, (void **)&sc->d_lane_yaw}) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   }
@@ -546,6 +630,38 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
     FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_lane_yaw, sizeof(double) * cells));
     FO_HIP_TRY(ctx, hipMemcpy(sc->d_lane_yaw, h_lane_yaw_or_null, sizeof(double) * cells, hipMemcpyHostToDevice));
   }
+  return FO_OK;
+}
+
+int fo_scene_set_routes(fo_ctx *ctx, int P, int R, const int32_t *h_first, const int32_t *h_count, int NV,
+                        const double *h_xy, const double *h_s, const int32_t *h_lanelet_raster) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_set_routes: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  if (P < 1 || R < 1 || !h_first || !h_count || NV < 0 || (NV > 0 && (!h_xy || !h_s)) || !h_lanelet_raster)
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_set_routes: bad arguments (P=%d R=%d NV=%d)", P, R, NV);
+  for (int i = 0; i < P * R; ++i)
+    if (h_count[i] < 0 || h_first[i] < 0 || (long)h_first[i] + h_count[i] > NV)
+      return fo_fail(ctx, FO_E_ARG, "fo_scene_set_routes: route %d leaves the vertex table", i);
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (void **p : {(void **)&sc->d_route_first, (void **)&sc->d_route_count, (void **)&sc->d_lanelet_raster,
+                   (void **)&sc->d_route_xy, (void **)&sc->d_route_s}) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  }
+  const size_t cells = (size_t)sc->rnx * sc->rny, nvs = (size_t)(NV > 0 ? NV : 1);
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_route_first, sizeof(int32_t) * P * R));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_route_count, sizeof(int32_t) * P * R));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_lanelet_raster, sizeof(int32_t) * cells));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_route_xy, sizeof(double) * 2 * nvs));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_route_s, sizeof(double) * nvs));
+  FO_HIP_TRY(ctx, hipMemcpy(sc->d_route_first, h_first, sizeof(int32_t) * P * R, hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMemcpy(sc->d_route_count, h_count, sizeof(int32_t) * P * R, hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMemcpy(sc->d_lanelet_raster, h_lanelet_raster, sizeof(int32_t) * cells, hipMemcpyHostToDevice));
+  if (NV > 0) {
+    FO_HIP_TRY(ctx, hipMemcpy(sc->d_route_xy, h_xy, sizeof(double) * 2 * NV, hipMemcpyHostToDevice));
+    FO_HIP_TRY(ctx, hipMemcpy(sc->d_route_s, h_s, sizeof(double) * NV, hipMemcpyHostToDevice));
+  }
+  sc->R = R;
+  sc->n_lanelets = P;
   return FO_OK;
 }
 
@@ -603,7 +719,7 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
 
 int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
                    double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int all_occluded,
-                   int max_agents, const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
+                   int max_agents, int routes, const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
                    const double *infl_l4, const double *infl_w4, int n_path, const double *d_path, int T, double dt,
                    double var0, double var_factor, int32_t *d_cell, double *d_pos0, double *d_yaw0, int32_t *d_n,
                    double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,
@@ -614,6 +730,8 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
       !d_path || T < 1 || !d_cell || !d_pos0 || !d_yaw0 || !d_n || !d_pos || !d_yaw || !d_v || !d_cov || !d_shape ||
       !d_raw_dims || !d_type || !d_len)
     return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn: bad arguments");
+  if (routes < 0 || (routes > 0 && !sc->d_lanelet_raster))
+    return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn: routes = %d needs fo_scene_set_routes first", routes);
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   const int cells = win_nx * win_ny;
@@ -632,9 +750,11 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
   hipLaunchKernelGGL(fo_spawn_pick_kernel, dim3((max_agents + 3) / 4), dim3(256), 0, s, sc->d_cand, sc->d_ncand, win_nx,
                      sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, max_agents, st, n_path, d_path, sc->d_lane_yaw, sc->rnx,
                      sc->rny, d_cell, d_pos0, d_yaw0, d_n);
-  const int n = max_agents * T;
-  hipLaunchKernelGGL(fo_spawn_predict_kernel, dim3((n + 255) / 256), dim3(256), 0, s, max_agents, d_n, d_pos0, d_yaw0, st,
-                     T, dt, var0, var_factor, d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len);
+  const int R = routes > 0 ? routes : 1;
+  hipLaunchKernelGGL(fo_spawn_predict_kernel, dim3(max_agents * R), dim3(64), 0, s, max_agents, R, d_n, d_cell, d_pos0,
+                     d_yaw0, st, T, dt, var0, var_factor, win_nx, win_ix0, win_iy0, sc->rnx, sc->rny,
+                     routes > 0 ? sc->d_lanelet_raster : nullptr, sc->R, sc->d_route_first, sc->d_route_count,
+                     sc->d_route_xy, sc->d_route_s, d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
 }

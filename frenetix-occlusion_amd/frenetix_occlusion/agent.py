@@ -185,10 +185,13 @@ class FOAgentManager:
             if n:
                 b = self._batch
                 pos0, yaw0 = b.pos0[:n].cpu().numpy(), b.yaw0[:n].cpu().numpy()
-                typ, raw, v0 = b.type[:n].cpu().numpy(), b.raw_dims[:n].cpu().numpy(), b.v[:n, 0].cpu().numpy()
+                R = b.R
+                typ, raw = b.type[:n * R:R].cpu().numpy(), b.raw_dims[:n * R:R].cpu().numpy()
+                ln, v0 = b.len[:n * R].cpu().numpy().reshape(n, R), b.v[:n * R, 0].cpu().numpy().reshape(n, R)
                 for j in range(n):
+                    r0 = int(np.argmax(ln[j] > 0))     # first prediction that exists carries the speed
                     self._batch_agents.append(PhantomAgent(self._create_id(), TYPE_NAME[int(typ[j])], pos0[j],
-                                                           float(yaw0[j]), float(v0[j]), float(raw[j, 0]),
+                                                           float(yaw0[j]), float(v0[j, r0]), float(raw[j, 0]),
                                                            float(raw[j, 1])))
         return self._batch_agents + self._manual
 
@@ -243,16 +246,23 @@ class FOAgentManager:
         n = self._n_batch
         if n:
             b = self._batch
-            pos, yaw, v = b.pos[:n].cpu().numpy(), b.yaw[:n].cpu().numpy(), b.v[:n].cpu().numpy()
-            cov, shape = b.cov[:n].cpu().numpy(), b.shape[:n].cpu().numpy()
+            R = b.R
+            pos, yaw, v = b.pos[:n * R].cpu().numpy(), b.yaw[:n * R].cpu().numpy(), b.v[:n * R].cpu().numpy()
+            cov, shape, ln = b.cov[:n * R].cpu().numpy(), b.shape[:n * R].cpu().numpy(), b.len[:n * R].cpu().numpy()
             for j in range(n):
                 a = agents[j]
-                a.predictions = [{"orientation_list": yaw[j], "v_list": v[j], "pos_list": pos[j],
-                                  "shape": {"length": float(shape[j, 0]), "width": float(shape[j, 1])},
-                                  "cov_list": cov[j]}]
-                pid = int(str(a.agent_id) + "0")
-                out[pid] = a.predictions[0]
-                order.append((pid, j))
+                a.predictions = []
+                for r in range(R):                      # one prediction per candidate route (agent.py:410-424)
+                    slot, L = j * R + r, int(ln[j * R + r])
+                    if L <= 0:
+                        continue
+                    pred = {"orientation_list": yaw[slot, :L], "v_list": v[slot, :L], "pos_list": pos[slot, :L],
+                            "shape": {"length": float(shape[slot, 0]), "width": float(shape[slot, 1])},
+                            "cov_list": cov[slot, :L]}
+                    pid = int(str(a.agent_id) + str(len(a.predictions)))       # agent.py:179-183
+                    a.predictions.append(pred)
+                    out[pid] = pred
+                    order.append((pid, slot))
         base = self._batch.pos.shape[0] if self._batch is not None else 0
         for i, a in enumerate(self._manual):
             pid = int(str(a.agent_id) + "0")

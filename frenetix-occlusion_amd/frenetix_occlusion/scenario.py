@@ -469,3 +469,106 @@ def load_geometry_npz(path) -> Scenario:
         inc[names[int(code)]].append(int(lid))
     ilist = [{"id": iid, "incomings": [v[k] for k in sorted(v)]} for iid, v in inters.items()]
     return Scenario(float(g["dt"]), lanelets, obstacles, ilist, g["ego_initial"], str(g["benchmark_id"]))
+
+
+# ------------------------------------------------------------------------------------------------ phantom vehicle routes
+def enumerate_routes(lanelets, max_depth=2) -> Dict[int, List[List[int]]]:
+    """candidate routes per start lanelet: depth-first over successors and over same-direction neighbours that have
+    successors, down to `max_depth` hops (route_planner.py:54-90)"""
+    by = {ll.lanelet_id: ll for ll in lanelets}
+    out = {}
+
+    def explore(cur, route, routes, depth):
+        ll = by[cur]
+        route.append(cur)
+        nxt = [s for s in ll.successors if s in by]
+        for adj, same in ((ll.adj_right, ll.adj_right_same_direction), (ll.adj_left, ll.adj_left_same_direction)):
+            if adj is not None and same and adj in by and by[adj].successors:
+                nxt.append(adj)
+        if depth >= max_depth:
+            nxt = []
+        if not nxt:
+            routes.append(list(route))
+            return
+        for s in nxt:
+            explore(s, route, routes, depth + 1)
+            route.pop()
+
+    for ll in lanelets:
+        routes = []
+        explore(ll.lanelet_id, [], routes, 0)
+        out[ll.lanelet_id] = routes
+    return out
+
+
+def route_polyline(lanelets_by_id, route):
+    """reference path of a route: centre lines joined end to start; a lanelet that is left sideways (its follower is a
+    neighbour, not a successor) contributes nothing -- the vehicle keeps its lateral offset to the neighbour's centre
+    line, which is what the reference's min-var(v) Frenet sample does (agent.py:349-379, d1 = d0)"""
+    parts = []
+    for i, lid in enumerate(route):
+        ll = lanelets_by_id[lid]
+        if i + 1 < len(route) and route[i + 1] not in ll.successors:
+            continue
+        c = ll.center
+        if parts and np.linalg.norm(c[0] - parts[-1][-1]) < 1e-2:
+            c = c[1:]
+        if len(c):
+            parts.append(c)
+    if not parts:
+        parts = [lanelets_by_id[route[-1]].center]
+    p = np.concatenate(parts, axis=0)
+    keep = np.concatenate(([True], np.hypot(np.diff(p[:, 0]), np.diff(p[:, 1])) > 0.0))
+    return p[keep]
+
+
+@dataclass
+class RouteTable:
+    """flat device form: routes r < R of lanelet index p occupy vertices first[p*R+r] .. +count[p*R+r] of xy / s"""
+    R: int
+    first: np.ndarray    # int32 [P*R]
+    count: np.ndarray    # int32 [P*R]  (0 = no such route)
+    xy: np.ndarray       # [NV,2]
+    s: np.ndarray        # [NV] arc length from the route's first vertex
+
+    @classmethod
+    def from_lanelets(cls, lanelets, R=3, max_depth=2):
+        by = {ll.lanelet_id: ll for ll in lanelets}
+        routes = enumerate_routes(lanelets, max_depth)
+        first = np.zeros(len(lanelets) * R, dtype=np.int32)
+        count = np.zeros(len(lanelets) * R, dtype=np.int32)
+        xy, ss, nv = [], [], 0
+        for p, ll in enumerate(lanelets):
+            polys, seen = [], set()
+            for rt in routes[ll.lanelet_id]:
+                poly = route_polyline(by, rt)
+                key = poly.tobytes()
+                if len(poly) >= 2 and key not in seen:     # lane-change variants can collapse onto the same polyline
+                    seen.add(key)
+                    polys.append(poly)
+            for r, poly in enumerate(polys[:R]):
+                first[p * R + r], count[p * R + r] = nv, len(poly)
+                xy.append(poly)
+                ss.append(np.concatenate(([0.0], np.cumsum(np.hypot(np.diff(poly[:, 0]), np.diff(poly[:, 1]))))))
+                nv += len(poly)
+        return cls(R, first, count, np.concatenate(xy) if xy else np.zeros((0, 2)),
+                   np.concatenate(ss) if ss else np.zeros(0))
+
+
+def lanelet_index_raster(lanelets, x0, y0, cs, nx, ny):
+    """per raster cell: list index of the first lanelet containing the cell centre (same rule as lane_yaw_raster);
+    -1 off-lane"""
+    out = np.full((ny, nx), -1, dtype=np.int32)
+    for p, ll in enumerate(lanelets):
+        poly = ll.polygon
+        ix0 = max(int(math.floor((poly[:, 0].min() - x0) / cs)), 0)
+        ix1 = min(int(math.ceil((poly[:, 0].max() - x0) / cs)), nx)
+        iy0 = max(int(math.floor((poly[:, 1].min() - y0) / cs)), 0)
+        iy1 = min(int(math.ceil((poly[:, 1].max() - y0) / cs)), ny)
+        if ix1 <= ix0 or iy1 <= iy0:
+            continue
+        gx, gy = np.meshgrid(x0 + (np.arange(ix0, ix1) + 0.5) * cs, y0 + (np.arange(iy0, iy1) + 0.5) * cs)
+        inside = points_in_polygon(np.stack((gx.ravel(), gy.ravel()), -1), poly).reshape(iy1 - iy0, ix1 - ix0)
+        sub = out[iy0:iy1, ix0:ix1]
+        sub[inside & (sub < 0)] = p
+    return out

@@ -106,7 +106,7 @@ class VisibleArea:
 
 class SensorModel:
     def __init__(self, lanelet_network, ref_path, sensor_radius=30, sensor_angle=90, debug=True, visualization=None,
-                 ctx: Optional[N.Context] = None, n_rays=720, cell_size=0.5, device=0):
+                 ctx: Optional[N.Context] = None, n_rays=720, cell_size=0.5, device=0, routes=0):
         """lanelet_network: a :class:`~frenetix_occlusion.scenario.MapGeometry`, a list of
         :class:`~frenetix_occlusion.scenario.Lanelet`, or an object with ``.lanelets`` (duck-typed CommonRoad)."""
         if not torch.cuda.is_available():
@@ -121,6 +121,7 @@ class SensorModel:
         self.debug = debug
         self.n_rays = int(n_rays)
         self.cell_size = float(cell_size)
+        self.routes = int(routes)   # candidate routes per lanelet uploaded for phantom vehicle predictions (0 = none)
         # state of the last step (names of sensor_model.py:26-35)
         self.visible_area = None
         self.occluded_area = None
@@ -161,6 +162,16 @@ class SensorModel:
         self.ctx.call("fo_scene_set_map", len(off) - 1, off.ctypes.data, pxy.ctypes.data, len(edges),
                       edges.ctypes.data if len(edges) else None, cs, margin,
                       ly.ctypes.data if ly is not None else None, org.ctypes.data, dims.ctypes.data)
+        self.route_table = self.lanelet_raster = None
+        if self.routes > 0 and lanelets is not None:
+            from .scenario import RouteTable, lanelet_index_raster
+            tab = RouteTable.from_lanelets(lanelets, R=self.routes)
+            ras = np.ascontiguousarray(lanelet_index_raster(lanelets, x0, y0, cs, nx, ny), dtype=np.int32)
+            first, count = np.ascontiguousarray(tab.first, np.int32), np.ascontiguousarray(tab.count, np.int32)
+            rxy, rs = np.ascontiguousarray(tab.xy, np.float64), np.ascontiguousarray(tab.s, np.float64)
+            self.ctx.call("fo_scene_set_routes", len(lanelets), tab.R, first.ctypes.data, count.ctypes.data, len(rs),
+                          rxy.ctypes.data if len(rs) else None, rs.ctypes.data if len(rs) else None, ras.ctypes.data)
+            self.route_table, self.lanelet_raster = tab, ras
 
     def road_raster(self):
         nx, ny = self.raster_dims

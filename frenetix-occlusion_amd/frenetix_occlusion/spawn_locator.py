@@ -42,14 +42,15 @@ class PhantomBatch:
     cell: torch.Tensor       # int32 [max_agents] window cell index (-1 = unused slot)
     pos0: torch.Tensor       # [max_agents,2]
     yaw0: torch.Tensor       # [max_agents]
-    pos: torch.Tensor        # [max_agents,T,2]
-    yaw: torch.Tensor        # [max_agents,T]
-    v: torch.Tensor          # [max_agents,T]
-    cov: torch.Tensor        # [max_agents,T,2,2]
-    shape: torch.Tensor      # [max_agents,2] inflated
-    raw_dims: torch.Tensor   # [max_agents,2]
-    type: torch.Tensor       # int32 [max_agents]
-    len: torch.Tensor        # int32 [max_agents]  (T for active slots, 0 otherwise)
+    pos: torch.Tensor        # [slots,T,2]      slots = max_agents * R
+    yaw: torch.Tensor        # [slots,T]
+    v: torch.Tensor          # [slots,T]
+    cov: torch.Tensor        # [slots,T,2,2]
+    shape: torch.Tensor      # [slots,2] inflated
+    raw_dims: torch.Tensor   # [slots,2]
+    type: torch.Tensor       # int32 [slots]
+    len: torch.Tensor        # int32 [slots]  (valid samples of the prediction, 0 = unused slot)
+    R: int = 1               # prediction slots per agent: slot j * R + r (r = candidate route of a phantom vehicle)
 
     def sweep_args(self):
         return self.pos, self.yaw, self.v, self.cov, self.shape, self.raw_dims, self.type, self.len
@@ -82,6 +83,8 @@ class SpawnLocator:
             raise ValueError("accelerator.spawn.mode must be 'cells', 'rules' or 'both'")
         self.rule_points = []
         self._rules = None
+        self.routes = int(acc.get("routes", 0)) if sensor_model.route_table is not None else 0
+        self.R = max(self.routes, 1)                               # prediction slots per agent
         self.all_occluded = bool(acc.get("all_occluded", False))   # False: only the visible/occluded frontier
         self.max_dist_override = acc.get("max_dist")               # None: the reference's max(4 v, 25) m
         am = config["agent_manager"]
@@ -108,11 +111,12 @@ class SpawnLocator:
 
     def _alloc(self):
         dev, A, T = self.device, self.max_agents, self.T
+        S_ = A * self.R                                            # prediction slots: slot j * R + r
         f = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
         i = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
         return PhantomBatch(n=torch.zeros(1, dtype=torch.int32, device=dev), cell=i(A), pos0=f(A, 2), yaw0=f(A),
-                            pos=f(A, T, 2), yaw=f(A, T), v=f(A, T), cov=f(A, T, 2, 2), shape=f(A, 2),
-                            raw_dims=f(A, 2), type=i(A), len=i(A))
+                            pos=f(S_, T, 2), yaw=f(S_, T), v=f(S_, T), cov=f(S_, T, 2, 2), shape=f(S_, 2),
+                            raw_dims=f(S_, 2), type=i(S_), len=i(S_), R=self.R)
 
     def max_distance(self, ego_v):
         if self.max_dist_override is not None:
@@ -130,7 +134,7 @@ class SpawnLocator:
         c = lambda a: a.ctypes.data
         self.ctx.call("fo_scene_spawn", sm.cell_class.data_ptr(), w.ix0, w.iy0, w.nx, w.ny, float(ego_pos[0]),
                       float(ego_pos[1]), math.cos(ego_orientation), math.sin(ego_orientation), self.min_ahead,
-                      self.max_distance(ego_v), 1 if self.all_occluded else 0, self.max_agents, c(self._t4), c(self._s4), c(self._rl), c(self._rw),
+                      self.max_distance(ego_v), 1 if self.all_occluded else 0, self.max_agents, self.routes, c(self._t4), c(self._s4), c(self._rl), c(self._rw),
                       c(self._il), c(self._iw), int(self.ref_path.shape[0]), self._d_path.data_ptr(), self.T, self.dt,
                       self.var0, self.var_factor, b.cell.data_ptr(), b.pos0.data_ptr(), b.yaw0.data_ptr(),
                       b.n.data_ptr(), b.pos.data_ptr(), b.yaw.data_ptr(), b.v.data_ptr(), b.cov.data_ptr(),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 2
+#define FO_ABI_VERSION 3
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -122,6 +122,13 @@ int fo_sweep_last_launch(const fo_ctx *ctx, int *grid, int *block, int *agents_p
 int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double *h_poly_xy, int E,
                      const double *h_edges, double cs, double margin, const double *h_lane_yaw_or_null,
                      const double *h_raster_origin_or_null, const int32_t *h_raster_dims_or_null);
+/* One-off, after fo_scene_set_map (replaces FORoutePlanner, route_planner.py:15-90, evaluated for every lanelet up
+ * front): HOST arrays.  Lanelet index p (order of the polygons given to fo_scene_set_map) has up to R candidate routes;
+ * route r occupies vertices [first[p*R+r], first[p*R+r] + count[p*R+r]) of xy [NV][2] / s [NV] (arc length from the
+ * route's first vertex); count 0 = no such route.  lanelet_raster int32 [rny][rnx]: lanelet index per raster cell, -1
+ * off-lane. */
+int fo_scene_set_routes(fo_ctx *ctx, int P, int R, const int32_t *h_first, const int32_t *h_count, int NV,
+                        const double *h_xy, const double *h_s, const int32_t *h_lanelet_raster);
 int fo_scene_map_info(fo_ctx *ctx, double *x0, double *y0, double *cs, int *nx, int *ny, int *n_edges);
 int fo_scene_copy_raster(fo_ctx *ctx, uint8_t *h_out);
 
@@ -140,12 +147,16 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
 /* Phantom sampling in the occluded cells + constant-velocity predictions (replaces the cell-based core of
  * SpawnLocator.find_spawn_points, spawn_locator.py:80-139, and agent.py:451-536).  Candidates: occluded cells at least
  * min_ahead ahead of the ego and within max_dist, on the visible/occluded frontier (all_occluded = 0) or anywhere in
- * the occluded set (all_occluded = 1); evenly spaced ranks are kept.  Agent j takes pattern slot j % 4
+ * the occluded set (all_occluded = 1); evenly spaced ranks are kept.  Prediction slots: R = max(routes, 1) per
+ * agent, slot j * R + r; with routes > 0 (needs fo_scene_set_routes) a vehicle on a lanelet gets one prediction per
+ * candidate route r (constant speed along the route, lateral offset kept; replaces route_planner.py:31-90 +
+ * utils/frenetix_handler.py + agent.py:283-426), everything else one straight constant-velocity prediction in r = 0.
+ * The per-prediction outputs (d_pos ... d_len) therefore hold max_agents * R slots.  Agent j takes pattern slot j % 4
  * (type4/speed4/raw/inflated dims: HOST arrays of 4).  d_path [n_path][2] = ego reference path.  Outputs for
  * max_agents slots, directly in the layout fo_sweep_set_agents consumes (slots >= *d_n have len 0 = inactive). */
 int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
                    double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int all_occluded,
-                   int max_agents, const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
+                   int max_agents, int routes, const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
                    const double *infl_l4, const double *infl_w4, int n_path, const double *d_path, int T, double dt,
                    double var0, double var_factor, int32_t *d_cell, double *d_pos0, double *d_yaw0, int32_t *d_n,
                    double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,

@@ -99,6 +99,12 @@ int fo_oracle_spawn_headings(int n, const double *pos, const int32_t *type, int 
 int fo_oracle_cv_predictions(int n, const double *pos0, const double *yaw, const double *speed, int T, double dt,
                              double var0, double factor, double *pos, double *yaw_l, double *v_l, double *cov);
 
+int fo_oracle_route_predictions(int n, const double *pos0, const int32_t *type, const double *speed,
+                                const int32_t *lanelet, int R, const int32_t *first, const int32_t *count,
+                                const double *xy, const double *sarr, const double *yaw_fallback, int T, double dt,
+                                double var0, double factor, double *pos, double *yaw_l, double *v_l, double *cov,
+                                int32_t *len);
+
 /* metric.py:125-147 dependency closure on the activated-metric bit mask */
 uint32_t fo_oracle_required_metrics(uint32_t mask);
 

@@ -243,3 +243,17 @@ def cv_predictions(pos0, yaw, speed, T, dt, var0=0.1, factor=1.05):
     lib().fo_oracle_cv_predictions(C.c_int(n), _p(pos0), _p(yaw), _p(speed), C.c_int(T), C.c_double(dt),
                                    C.c_double(var0), C.c_double(factor), _p(pos), _p(yl), _p(vl), _p(cov))
     return pos, yl, vl, cov.reshape(n, T, 2, 2)
+
+
+def route_predictions(pos0, types, speed, lanelet, R, first, count, xy, s, yaw_fallback, T, dt, var0=0.1, factor=1.05):
+    pos0, speed, yaw_fallback = _f64(pos0), _f64(speed), _f64(yaw_fallback)
+    types, lanelet, first, count = _i32(types), _i32(lanelet), _i32(first), _i32(count)
+    xy, s = _f64(xy).reshape(-1, 2), _f64(s)
+    n = pos0.shape[0]
+    pos, yl, vl = np.zeros((n * R, T, 2)), np.zeros((n * R, T)), np.zeros((n * R, T))
+    cov, ln = np.zeros((n * R, T, 4)), np.zeros(n * R, dtype=np.int32)
+    lib().fo_oracle_route_predictions(C.c_int(n), _p(pos0), _p(types, C.c_int32), _p(speed), _p(lanelet, C.c_int32),
+                                      C.c_int(R), _p(first, C.c_int32), _p(count, C.c_int32), _p(xy), _p(s),
+                                      _p(yaw_fallback), C.c_int(T), C.c_double(dt), C.c_double(var0), C.c_double(factor),
+                                      _p(pos), _p(yl), _p(vl), _p(cov), _p(ln, C.c_int32))
+    return pos, yl, vl, cov.reshape(n * R, T, 2, 2), ln

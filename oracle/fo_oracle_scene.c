@@ -322,3 +322,77 @@ int fo_oracle_cv_predictions(int n, const double *pos0, const double *yaw, const
   }
   return 0;
 }
+
+/* ---------------------------------------------------------------- phantom vehicle predictions along lanelet routes
+ * Replaces route_planner.py:31-90 + utils/frenetix_handler.py + agent.py:283-426 (C++ frenetix sampler, un-vendored):
+ * per candidate route of the start lanelet one prediction that keeps the initial speed and the initial lateral offset
+ * to the route's centre line -- what the reference's min-var(v) Frenet sample (d1 = d0, ss1 = v0) amounts to.
+ * Slot (j, r), r < R:  vehicle on a lanelet with routes -> route r of that lanelet (len 0 if it has fewer);
+ * pedestrian, or vehicle off-lane / without routes -> r = 0 is the straight constant-velocity prediction with
+ * yaw_fallback[j], r > 0 empty.  A prediction ends (len < T) where the route polyline ends.  PARITY UNPINNED. */
+int fo_oracle_route_predictions(int n, const double *pos0, const int32_t *type, const double *speed,
+                                const int32_t *lanelet, int R, const int32_t *first, const int32_t *count,
+                                const double *xy, const double *sarr, const double *yaw_fallback, int T, double dt,
+                                double var0, double factor, double *pos, double *yaw_l, double *v_l, double *cov,
+                                int32_t *len) {
+  for (int j = 0; j < n; ++j) {
+    const int ll = lanelet[j];
+    const int routed = type[j] != FO_TYPE_PEDESTRIAN && ll >= 0 && count[(size_t)ll * R] > 0;
+    for (int r = 0; r < R; ++r) {
+      const size_t slot = (size_t)j * R + r;
+      double *P = pos + slot * T * 2, *Y = yaw_l + slot * T, *V = v_l + slot * T, *C = cov + slot * T * 4;
+      for (int k = 0; k < T; ++k) {
+        P[2 * k] = P[2 * k + 1] = Y[k] = V[k] = 0.0;
+        const double var = var0 * pow(factor, (double)k);
+        C[4 * k] = var; C[4 * k + 1] = 0.0; C[4 * k + 2] = 0.0; C[4 * k + 3] = var;
+      }
+      len[slot] = 0;
+      if (!routed) {
+        if (r > 0) continue;
+        const double a = yaw_fallback[j];
+        const double vx = fo_oracle_round3(speed[j] * cos(a)), vy = fo_oracle_round3(speed[j] * sin(a));
+        for (int k = 0; k < T; ++k) {
+          const double t = (double)k * dt;
+          P[2 * k] = pos0[2 * j] + t * vx; P[2 * k + 1] = pos0[2 * j + 1] + t * vy; Y[k] = a; V[k] = speed[j];
+        }
+        len[slot] = T;
+        continue;
+      }
+      const int nv = count[(size_t)ll * R + r];
+      if (nv < 2) continue;
+      const double *q = xy + 2 * (size_t)first[(size_t)ll * R + r], *sq = sarr + first[(size_t)ll * R + r];
+      const double px = pos0[2 * j], py = pos0[2 * j + 1];
+      double best = INFINITY, s0 = 0.0, d0 = 0.0;
+      for (int i = 0; i + 1 < nv; ++i) { /* closest point of the route (first minimum) */
+        const double ax = q[2 * i], ay = q[2 * i + 1], ex = q[2 * i + 2] - ax, ey = q[2 * i + 3] - ay;
+        const double l2 = ex * ex + ey * ey;
+        double t = ((px - ax) * ex + (py - ay) * ey) / l2;
+        if (t < 0.0) t = 0.0;
+        if (t > 1.0) t = 1.0;
+        const double cx = ax + t * ex, cy = ay + t * ey;
+        const double d2 = (px - cx) * (px - cx) + (py - cy) * (py - cy);
+        if (d2 < best) {
+          const double l = sqrt(l2);
+          best = d2;
+          s0 = sq[i] + t * l;
+          d0 = ((px - cx) * (-ey) + (py - cy) * ex) / l; /* offset along the left normal */
+        }
+      }
+      const double s_end = sq[nv - 1];
+      int m = 0, k = 0;
+      for (; k < T; ++k) {
+        const double sk = s0 + speed[j] * ((double)k * dt);
+        if (sk > s_end) break;
+        while (m + 2 < nv && sq[m + 1] <= sk) ++m; /* segment with s[m] <= sk (last segment at the very end) */
+        const double ex = q[2 * m + 2] - q[2 * m], ey = q[2 * m + 3] - q[2 * m + 1];
+        const double l = sqrt(ex * ex + ey * ey), ux = ex / l, uy = ey / l, loc = sk - sq[m];
+        P[2 * k] = q[2 * m] + loc * ux + d0 * (-uy);
+        P[2 * k + 1] = q[2 * m + 1] + loc * uy + d0 * ux;
+        Y[k] = atan2(uy, ux);
+        V[k] = speed[j];
+      }
+      len[slot] = k;
+    }
+  }
+  return 0;
+}

@@ -62,11 +62,14 @@ def test_evaluate_scenario_then_batch_and_per_trajectory_calls(torch_cuda, oracl
     assert vis.exterior.shape == (720, 2) and vis.area > 50.0
     assert len(fo.spawn_points) > 0 and len(fo.agent_manager.phantom_agents) == len(fo.spawn_points)
     preds = fo.agent_manager.predictions
-    assert len(preds) == len(fo.spawn_points)
+    assert len(preds) >= len(fo.spawn_points)            # a phantom vehicle has one prediction per candidate route
     for pid, p in preds.items():
         assert set(p) == {"orientation_list", "v_list", "pos_list", "shape", "cov_list"}
-        assert p["pos_list"].shape == (31, 2) and p["cov_list"].shape == (31, 2, 2)
+        L = len(p["pos_list"])
+        assert 1 <= L <= 31 and p["pos_list"].shape == (L, 2) and p["cov_list"].shape == (L, 2, 2)
         assert fo.agent_manager.agent_by_prediction_id(pid) is not None
+    peds = [a for a in fo.agent_manager.phantom_agents if a.agent_type == "Pedestrian"]
+    assert all(len(a.predictions) == 1 and len(a.predictions[0]["pos_list"]) == 31 for a in peds)
 
     traj = SY.make_trajectories(64, seed=99, ego_pos=ego[:2], ego_yaw=float(ego[2]))
     objs = _traj_objects(traj)
@@ -89,13 +92,14 @@ def test_evaluate_scenario_then_batch_and_per_trajectory_calls(torch_cuda, oracl
         assert list(res.keys()) == ["cp", "dce", "ttc", "hr", "ttce", "wttc"]      # metric.py:125-147 order
         for pid, k in slots.items():
             np.testing.assert_allclose(res["cp"][pid], ref["lists"][m, k, 0][:len(res["cp"][pid])], atol=1e-9)
-            assert len(res["cp"][pid]) == 30
+            assert len(res["cp"][pid]) == 30                            # collision_probability.py: always T-1 entries
             assert res["dce"][pid]["time_dce"] == ref["pair_i"][m, k, oracle.PI["time_dce"]]
             assert res["dce"][pid]["dce"] == pytest.approx(ref["pair_f"][m, k, oracle.PF["dce"]], abs=1e-9)
             assert res["ttce"][pid] == pytest.approx(ref["pair_f"][m, k, oracle.PF["ttce"]], abs=1e-12)
             h = res["hr"][pid]
             assert h["max_obst_risk"] == pytest.approx(ref["pair_f"][m, k, oracle.PF["max_obst_risk"]], abs=1e-9)
-            assert len(h["ego_harm_traj"]) == 30 and len(h["obst_risk_traj"]) == 30
+            Lh = min(30, len(preds[pid]["pos_list"]))                   # harm_model.py:66
+            assert len(h["ego_harm_traj"]) == Lh and len(h["obst_risk_traj"]) == Lh
         assert res["hr"]["max_obst_risk_all"] == pytest.approx(ref["cost"][m, oracle.COST["max_obst_risk_all"]], abs=1e-9)
         w = ref["cost"][m, oracle.COST["wttc"]]
         assert res["wttc"] == w or (math.isinf(w) and math.isinf(res["wttc"]))
@@ -133,7 +137,7 @@ def test_manual_agents_and_error_conventions(torch_cuda, oracle, tmp_path):
     torch_cuda.cuda.synchronize()
     arrs = am.sweep_arrays()
     agents = dict(zip(("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len"), [t.cpu().numpy() for t in arrs]))
-    assert agents["pos"].shape[0] == 4 + 1
+    assert agents["pos"].shape[0] == 4 * fo.spawn_locator.R + 1          # 4 agents x R route slots + 1 manual
     ref = oracle.sweep(traj, agents, SY.VEHICLE_BMW320I, 0.1, thr={"harm": 1, "risk": 1})
     got = ba.result.pair_f.permute(2, 1, 0).cpu().numpy()
     f = np.isfinite(ref["pair_f"])

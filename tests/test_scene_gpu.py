@@ -176,3 +176,50 @@ def test_map_without_obstacles_or_with_everything_absent(torch_cuda, oracle):
     E = len(sm.map_geometry.edges)
     assert (sm.hit_id.cpu().numpy() < E).all() and sm.visible_objects_timestep == [555]
     _check_step(torch_cuda, oracle, sc, sc.ego_initial, 7.63, 0)
+
+
+def test_phantom_vehicle_predictions_follow_lanelet_routes(torch_cuda, oracle):
+    """routes > 0: one prediction per candidate route for vehicles (slot j * R + r), compared with the oracle"""
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    for name, R in (("scenario3_geometry.npz", 3), ("scenario1_geometry.npz", 2)):
+        sc = S.load_geometry_npz(os.path.join(GOLDEN, name))
+        ego = sc.ego_initial
+        yaw = float(ego[2])
+        ref_path = ego[None, :2] + np.linspace(0.0, 60.0, 61)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+        sm = SensorModel(sc.lanelets, ref_path, sensor_radius=50.0, sensor_angle=360.0, routes=R)
+        obst = FOObstacles(sc.obstacles)
+        obst.update(0)
+        sm.calc_visible_and_occluded_area(0, ego[:2], yaw, obst)
+        cfg = _default_config()
+        cfg["accelerator"]["spawn"].update(max_agents=24, all_occluded=True, max_dist=45.0, routes=R,
+                                           pattern=["Car", "Bicycle", "Pedestrian", "Car"])
+        sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1)
+        assert sl.R == R
+        sl.find_spawn_points(ego[:2], yaw, None, float(ego[3]))
+        torch_cuda.cuda.synchronize()
+        b = sl.batch
+        n = int(b.n.item())
+        assert n > 4 and b.pos.shape[0] == 24 * R
+        w = sm.window
+        ci = b.cell.cpu().numpy()[:n]
+        wx, wy = w.ix0 + ci % w.nx, w.iy0 + ci // w.nx
+        lan = sm.lanelet_raster[wy, wx]
+        types = np.array([sl._t4[j % 4] for j in range(n)], dtype=np.int32)
+        speed = np.array([sl._s4[j % 4] for j in range(n)])
+        tab = sm.route_table
+        pos, yl, vl, cov, ln = oracle.route_predictions(b.pos0.cpu().numpy()[:n], types, speed, lan, R, tab.first,
+                                                        tab.count, tab.xy, tab.s, b.yaw0.cpu().numpy()[:n], sl.T, 0.1,
+                                                        0.1, sl.var_factor)
+        got_len = b.len.cpu().numpy()
+        assert np.array_equal(got_len[:n * R], ln) and (got_len[n * R:] == 0).all()
+        np.testing.assert_allclose(b.pos.cpu().numpy()[:n * R], pos, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(b.yaw.cpu().numpy()[:n * R], yl, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(b.v.cpu().numpy()[:n * R], vl, rtol=0, atol=0)
+        np.testing.assert_allclose(b.cov.cpu().numpy()[:n * R], cov, rtol=1e-13, atol=0)
+        assert np.array_equal(b.type.cpu().numpy()[:n * R], np.repeat(types, R))
+        veh_routes = ln.reshape(n, R)[types != 4]
+        assert (veh_routes[:, 0] > 0).all() and (veh_routes > 0).sum() > len(veh_routes)    # some vehicle has 2 routes
+        assert (ln.reshape(n, R)[types == 4][:, 1:] == 0).all()

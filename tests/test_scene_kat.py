@@ -251,3 +251,44 @@ def test_scenario1_visibility_sanity(oracle):
     # the ego's own cell is visible
     iy, ix = int((ego[1] - s["y0"]) / s["cs"]), int((ego[0] - s["x0"]) / s["cs"])
     assert vis[iy, ix]
+
+
+def test_route_enumeration_and_vehicle_predictions_along_routes(oracle):
+    """route_planner.py:54-90 restated (depth-2 DFS over successors / same-direction neighbours) + one constant-speed
+    prediction per candidate route that keeps the initial lateral offset"""
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario3_geometry.npz"))
+    routes = S.enumerate_routes(sc.lanelets)
+    assert routes[1] == [[1, 3, 5], [1, 12, 9]]                    # incoming lanelet: left-ish and right turn
+    tab = S.RouteTable.from_lanelets(sc.lanelets, R=3)
+    idx = {l.lanelet_id: i for i, l in enumerate(sc.lanelets)}
+    assert list(tab.count[idx[1] * 3: idx[1] * 3 + 3] > 0) == [True, True, False]
+    pos0 = np.array([[10.0, 0.3], [20.0, -0.2], [5.0, 9.0], [12.0, 0.0]])
+    types = np.array([0, 3, 4, 0])
+    speed = np.array([10.0, 5.0, 1.4, 10.0])
+    lan = np.array([idx[1], idx[1], -1, -1])
+    pos, yaw, v, cov, ln = oracle.route_predictions(pos0, types, speed, lan, 3, tab.first, tab.count, tab.xy, tab.s,
+                                                    np.array([0.0, 0.0, 1.0, 0.5]), 31, 0.1)
+    assert ln.reshape(4, 3).tolist() == [[31, 31, 0], [31, 31, 0], [31, 0, 0], [31, 0, 0]]
+    # car 0, route 0: straight part keeps y = 0.3 (offset to the centre line y = 0), x advances 1 m per step
+    np.testing.assert_allclose(pos[0, :15, 1], 0.3, atol=1e-12)
+    np.testing.assert_allclose(pos[0, :15, 0], 10.0 + np.arange(15), atol=1e-9)
+    # the two routes of car 0 part ways at the intersection: left (y grows) and right (y falls), heading follows
+    assert pos[0, 30, 1] > 3.0 and pos[1, 30, 1] < -3.0 and yaw[0, 30] > 1.0 and yaw[1, 30] < -1.0
+    step = np.hypot(np.diff(pos[1, :, 0]), np.diff(pos[1, :, 1]))
+    assert np.all(np.abs(step - 1.0) < 0.12)                        # constant speed along the centre line (offset 0.3 m)
+    # pedestrian / off-lane vehicle: one straight prediction with the fallback heading, velocity components rounded
+    np.testing.assert_allclose(pos[6, 10], pos0[2] + 1.0 * np.round(1.4 * np.array([math.cos(1.0), math.sin(1.0)]), 3))
+    np.testing.assert_allclose(pos[9, 10], pos0[3] + 1.0 * np.round(10.0 * np.array([math.cos(0.5), math.sin(0.5)]), 3))
+    # a route shorter than the horizon ends the prediction early
+    short = S.Lanelet(1, np.array([[0, 1.75], [12.0, 1.75]]), np.array([[0, -1.75], [12.0, -1.75]]))
+    t1 = S.RouteTable.from_lanelets([short], R=2)
+    _, _, _, _, l1 = oracle.route_predictions(np.array([[2.0, 0.5]]), np.array([0]), np.array([10.0]), np.array([0]), 2,
+                                              t1.first, t1.count, t1.xy, t1.s, np.array([0.0]), 31, 0.1)
+    assert l1.tolist() == [11, 0]                                   # s = 2, 3, ..., 12
+
+
+def test_lanelet_index_raster_matches_the_lane_heading_raster():
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ras = S.lanelet_index_raster(sc.lanelets, -60.0, -60.0, 0.5, 400, 300)
+    yaw = S.lane_yaw_raster(sc.lanelets, -60.0, -60.0, 0.5, 400, 300)
+    assert np.array_equal(ras >= 0, ~np.isnan(yaw)) and (ras >= 0).sum() > 1000 and ras.max() < len(sc.lanelets)
