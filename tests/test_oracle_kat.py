@@ -205,3 +205,59 @@ def test_be_is_zero_without_a_collision_and_for_a_collision_at_t0(oracle):
     # 'be' alone pulls in ttc and dce (metric.py:135-139; be.py:39 needs results['ttc'])
     m = oracle.lib().fo_oracle_required_metrics(oracle.METRIC_BITS["be"])
     assert m & oracle.METRIC_BITS["dce"] and m & oracle.METRIC_BITS["ttc"]
+
+
+# ---------------------------------------------------------------------------------------------- DCE geometry: properties
+def _brute_distance(a, b, n=200):
+    """independent check: densely sampled boundary-to-boundary distance (0 if a vertex of one lies inside the other)"""
+    def boundary(q):
+        t = np.linspace(0.0, 1.0, n, endpoint=False)[:, None]
+        return np.concatenate([q[i] + t * (q[(i + 1) % 4] - q[i]) for i in range(4)])
+
+    def inside(p, q):
+        s = np.array([(q[(i + 1) % 4][0] - q[i][0]) * (p[1] - q[i][1]) - (q[(i + 1) % 4][1] - q[i][1]) * (p[0] - q[i][0])
+                      for i in range(4)])
+        return (s >= 0).all() or (s <= 0).all()
+    if any(inside(p, b) for p in a) or any(inside(p, a) for p in b):
+        return 0.0
+    pa, pb = boundary(a), boundary(b)
+    d = np.sqrt(((pa[:, None, :] - pb[None, :, :]) ** 2).sum(-1))
+    return float(d.min())
+
+
+def test_rect_distance_properties_randomised(oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(150):
+        la, wa, lb, wb = rng.uniform(0.2, 6.0, 4)
+        ca, cb = rng.uniform(-8, 8, 2), rng.uniform(-8, 8, 2)
+        ya, yb = rng.uniform(-4, 4, 2)
+        if rng.random() < 0.3:
+            yb = ya + rng.choice([0.0, math.pi / 2, math.pi])         # parallel / perpendicular boxes
+        a, b = rect(oracle, ca[0], ca[1], ya, la, wa), rect(oracle, cb[0], cb[1], yb, lb, wb)
+        d = oracle.quad_distance(a, b)
+        assert d >= 0.0 and d == pytest.approx(oracle.quad_distance(b, a), abs=1e-12)          # symmetric
+        # invariant under a common rigid motion
+        phi, sh = rng.uniform(-3, 3), rng.uniform(-50, 50, 2)
+        R = np.array([[math.cos(phi), -math.sin(phi)], [math.sin(phi), math.cos(phi)]])
+        assert oracle.quad_distance(a @ R.T + sh, b @ R.T + sh) == pytest.approx(d, abs=1e-10)
+        # scales with the scene
+        assert oracle.quad_distance(2.5 * a, 2.5 * b) == pytest.approx(2.5 * d, abs=1e-10)
+        # never larger than the centre distance, never smaller than centre distance minus the circumradii
+        cd = float(np.linalg.norm(ca - cb))
+        assert d <= cd + 1e-12 and d >= cd - 0.5 * (math.hypot(la, wa) + math.hypot(lb, wb)) - 1e-12
+        # agrees with a dense boundary sampling (which can only overestimate, by less than one sample spacing)
+        bd = _brute_distance(a, b)
+        assert d <= bd + 1e-9 and bd - d < 0.1
+        assert (d == 0.0) == (bd == 0.0) or bd < 0.1
+
+
+def test_dce_is_independent_of_the_order_of_equal_minima_and_uses_the_earliest(oracle):
+    """two timesteps with exactly the same rounded distance: time_dce is the earlier one (dce.py:82 strict <)"""
+    T = 9
+    x = np.array([0.0, 1.0, 2.0, 3.0, 4.0, 3.0, 2.0, 3.0, 4.0])       # approaches, recedes, approaches to the same x
+    traj = {"x": x[None], "y": np.zeros((1, T)), "theta": np.zeros((1, T)), "v": np.ones((1, T)), "a": np.zeros((1, T))}
+    ag = _ped(12.0, 0.0, T)
+    out = oracle.sweep(traj, ag, VEH, 0.1)
+    assert out["pair_i"][0, 0, oracle.PI["time_dce"]] == 4
+    gap = 12.0 - 0.15 - (4.0 + VEH[2] + VEH[0] / 2)
+    assert out["pair_f"][0, 0, oracle.PF["dce"]] == pytest.approx(round(gap, 3), abs=1e-12)
