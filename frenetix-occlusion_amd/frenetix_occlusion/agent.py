@@ -80,20 +80,24 @@ class FOAgentManager:
         conf = self.config[key]
         v = self._velocity(velocity, conf, key in ("car", "truck"))
         pos = np.asarray(pos, dtype=np.float64)
-        if orientation is None:
+        routes = self._routes_at(pos) if (key != "pedestrian" and orientation is None) else []
+        if routes:                                               # vehicles follow their lanelet (agent.py:283-312)
+            seg = routes[0][1:2] - routes[0][0:1]
+            orientation = float(np.arctan2(seg[0, 1], seg[0, 0]))
+        elif orientation is None:
             curve = self.reference_path
             if mode == "lane_center":                            # agent.py:459-467; off-lanelet -> reference path (Q12)
                 curve = self._lane_center_at(pos)
             orientation = self._heading_towards_path(pos, curve)
         agent = PhantomAgent(self._create_id(), agent_type, pos, float(orientation), v, float(conf["length"]),
                              float(conf["width"]))
-        agent.predictions = [self._cv_prediction(agent, horizon)]
+        agent.predictions = [self._route_prediction(agent, horizon, r) for r in routes] or [self._cv_prediction(agent, horizon)]
+        agent.predictions = [p for p in agent.predictions if p is not None] or [self._cv_prediction(agent, horizon)]
         if add_to_scenario:
             self.real_agents.append(agent)
             from .scenario import Obstacle
-            T = len(agent.predictions[0]["pos_list"])
-            st = np.column_stack((agent.predictions[0]["pos_list"][1:], np.full(T - 1, agent.initial_orientation),
-                                  np.full(T - 1, v)))
+            p0 = agent.predictions[0]
+            st = np.column_stack((p0["pos_list"][1:], p0["orientation_list"][1:], p0["v_list"][1:]))
             ob = Obstacle(agent.agent_id, "dynamic", key, agent.length, agent.width, int(timestep),
                           np.array([pos[0], pos[1], agent.initial_orientation, v]), st)
             if hasattr(self.scenario, "add_objects"):
@@ -104,6 +108,60 @@ class FOAgentManager:
             self._manual.append(agent)
             self._pred_cache = None
         return agent
+
+    def _routes_at(self, pos, R=3):
+        """candidate route polylines of the lanelet containing pos (route_planner.py:31-90), cached per scenario"""
+        from .scenario import enumerate_routes, lanelets_of, points_in_polygon, route_polyline
+        try:
+            lanelets = lanelets_of(self.scenario.lanelet_network if hasattr(self.scenario, "lanelet_network") else self.scenario)
+        except Exception:
+            return []
+        if getattr(self, "_route_cache", None) is None:
+            self._route_cache = (enumerate_routes(lanelets), {ll.lanelet_id: ll for ll in lanelets})
+        routes, by = self._route_cache
+        q = np.asarray(pos, dtype=np.float64).reshape(1, 2)
+        for ll in lanelets:
+            if points_in_polygon(q, ll.polygon)[0]:
+                polys, seen = [], set()
+                for rt in routes.get(ll.lanelet_id, []):
+                    pl = route_polyline(by, rt)
+                    if len(pl) >= 2 and pl.tobytes() not in seen:
+                        seen.add(pl.tobytes())
+                        polys.append(pl)
+                return polys[:R]
+        return []
+
+    def _route_prediction(self, agent, horizon, poly):
+        """constant speed along a route polyline, initial lateral offset kept (same construction as
+        fo_spawn_predict_kernel; replaces the frenetix sampler of agent.py:283-426)"""
+        pr = self.config["prediction"]
+        big = agent.agent_type.lower() == "bicycle"
+        fl = pr["size_factor_length_l"] if big else pr["size_factor_length_s"]
+        fw = pr["size_factor_width_l"] if big else pr["size_factor_width_s"]
+        p = agent.initial_position
+        a, e = poly[:-1], poly[1:] - poly[:-1]
+        l = np.hypot(e[:, 0], e[:, 1])
+        t = np.clip(np.sum((p[None] - a) * e, axis=1) / (l * l), 0.0, 1.0)
+        foot = a + t[:, None] * e
+        k = int(np.argmin(np.sum((p[None] - foot) ** 2, axis=1)))
+        sarr = np.concatenate(([0.0], np.cumsum(l)))
+        s0 = sarr[k] + t[k] * l[k]
+        d0 = float(((p - foot[k])[0] * (-e[k, 1]) + (p - foot[k])[1] * e[k, 0]) / l[k])
+        T = int(horizon / self.dt) + 1
+        sk = s0 + agent.initial_velocity * (np.arange(T) * self.dt)
+        sk = sk[sk <= sarr[-1]]
+        if len(sk) == 0:
+            return None
+        m = np.clip(np.searchsorted(sarr, sk, side="right") - 1, 0, len(l) - 1)
+        u = e[m] / l[m][:, None]
+        pos = a[m] + (sk - sarr[m])[:, None] * u + d0 * np.stack((-u[:, 1], u[:, 0]), -1)
+        L = len(sk)
+        var = 0.1 * np.power(pr["variance_factor"], np.arange(L))
+        cov = np.zeros((L, 2, 2))
+        cov[:, 0, 0] = var
+        cov[:, 1, 1] = var
+        return {"orientation_list": np.arctan2(u[:, 1], u[:, 0]), "v_list": np.full(L, agent.initial_velocity),
+                "pos_list": pos, "shape": {"length": agent.length * fl, "width": agent.width * fw}, "cov_list": cov}
 
     def _lane_center_at(self, pos):
         from .scenario import lanelets_of, points_in_polygon
@@ -174,7 +232,7 @@ class FOAgentManager:
 
     def n_slots(self):
         """length of the agent axis of the sweep outputs"""
-        return (self._batch.pos.shape[0] if self._batch is not None else 0) + len(self._manual)
+        return (self._batch.pos.shape[0] if self._batch is not None else 0) + sum(len(a.predictions) for a in self._manual)
 
     @property
     def phantom_agents(self):
@@ -202,13 +260,13 @@ class FOAgentManager:
             parts.append(self._batch.sweep_args())
         if self._manual:
             dev = self.device
-            T = max(len(a.predictions[0]["pos_list"]) for a in self._manual)
-            n = len(self._manual)
+            preds = [(a, p) for a in self._manual for p in a.predictions]     # one sweep slot per prediction
+            T = max(len(p["pos_list"]) for _, p in preds)
+            n = len(preds)
             pos, yaw, v = np.zeros((n, T, 2)), np.zeros((n, T)), np.zeros((n, T))
             cov, shape, raw = np.zeros((n, T, 2, 2)), np.zeros((n, 2)), np.zeros((n, 2))
             typ, ln = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
-            for i, a in enumerate(self._manual):
-                p = a.predictions[0]
+            for i, (a, p) in enumerate(preds):
                 L = len(p["pos_list"])
                 pos[i, :L], yaw[i, :L], v[i, :L], cov[i, :L] = p["pos_list"], p["orientation_list"], p["v_list"], p["cov_list"]
                 shape[i] = (p["shape"]["length"], p["shape"]["width"])
@@ -264,10 +322,13 @@ class FOAgentManager:
                     out[pid] = pred
                     order.append((pid, slot))
         base = self._batch.pos.shape[0] if self._batch is not None else 0
-        for i, a in enumerate(self._manual):
-            pid = int(str(a.agent_id) + "0")
-            out[pid] = a.predictions[0]
-            order.append((pid, base + i))
+        slot = base
+        for a in self._manual:
+            for i, p in enumerate(a.predictions):
+                pid = int(str(a.agent_id) + str(i))                  # agent.py:179-183
+                out[pid] = p
+                order.append((pid, slot))
+                slot += 1
         self._pred_cache = out
         self.prediction_slots = order
         return out

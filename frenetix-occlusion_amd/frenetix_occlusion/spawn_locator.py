@@ -170,8 +170,9 @@ class SpawnLocator:
                     if points_in_polygon(q, ll.polygon)[0]:
                         return ll
                 return None
+            inters = getattr(getattr(self.agent_manager, "scenario", None), "intersections", None) or []
             self._rules = SpawnRules(self.config, self.ref_path, self.cosy_cl, lane_yaw_at, lanelet_of, self.fo_obstacles,
-                                     self.debug)
+                                     self.debug, lanelets=lanelets, intersections=inters)
         self._rules.cosy_cl = self.cosy_cl or self._rules.cosy_cl
         return self._rules
 
@@ -205,6 +206,6 @@ class SpawnLocator:
             view = CellView(sm.cell_class.cpu().numpy(), sm.window)
             if ego_pos_cl is None:
                 ego_pos_cl = rules.cosy_cl.convert_to_curvilinear_coords(float(ego_pos[0]), float(ego_pos[1]))
-            self.rule_points = rules.find(view, ego_pos, ego_pos_cl, ego_v)
+            self.rule_points = rules.find(view, ego_pos, ego_pos_cl, ego_v, ego_orientation)
             self.spawn_points = self.spawn_points + self.rule_points
         return self.spawn_points

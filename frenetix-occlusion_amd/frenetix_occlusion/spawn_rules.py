@@ -8,9 +8,10 @@ asked of the per-step cell classes (fo_scene_visibility):
     point.buffer(r).within(road)         -> every cell square the disc touches is road
     area.buffer(b).exterior & line       -> samples where "disc of radius b touches the area" flips along the line
 Rules restated: ego intention from the curvature of the next 40 m of the reference path (:729-741), pedestrian behind a
-visible static obstacle (:323-476), pedestrian behind a turn (:481-578).  Not restated: Car / Bicycle behind a dynamic
-obstacle (:145-317; needs the intersection topology and the Jaccard rectangle fit) -- the occluded-cell sampling of
-fo_scene_spawn covers vehicles.  PARITY UNPINNED (no GEOS here, no reference test): pinned by tests/test_spawn_rules.py.
+visible static obstacle (:323-476), pedestrian behind a turn (:481-578), Car / Bicycle behind a visible dynamic
+obstacle (:145-317; the candidate region is sampled on a 0.25 m lattice with exact lanelet / wedge / distance tests
+and the cell classes for "occluded", the rectangle fit on a 0.1 m lattice).
+PARITY UNPINNED (no GEOS here, no reference test): pinned by tests/test_spawn_rules.py.
 """
 import math
 from typing import List, Optional
@@ -24,6 +25,10 @@ from .utils.curvilinear import curvature, pathlength
 S_THRESHOLD_TIME, MIN_S_THRESHOLD = 4.0, 25.0              # spawn_locator.py:65-66
 MAX_DISTANCE_TO_OTHER_OBSTACLE = 30.0                      # :69
 MIN_DISTANCE_BETWEEN_PEDESTRIANS = 5.0                     # :73
+TOLERANCE_SAME_DIRECTION = math.radians(20.0)              # :68
+BUFFER_AROUND_VEHICLE_FROM_SIDE = 12.0                     # :70
+MIN_AREA_THRESHOLD = 10.0                                  # :71
+AGENT_AREA_LIMITS = {"Car": 9.0, "Bicycle": 1.7}           # :72
 OFFSET_REF_PATH = {"left turn": 3.0, "right turn": 0.0}    # :76-78
 PHANTOM_OFFSET_S = {"left turn": -0.5, "right turn": 0.0}
 PHANTOM_OFFSET_D = {"left turn": 1.0, "right turn": -1.0}
@@ -135,9 +140,16 @@ def segment_rect_distance(a, b, corners):
 
 
 class SpawnRules:
-    def __init__(self, config, ref_path, cosy_cl, lane_yaw_at, lanelet_of, fo_obstacles, debug=False):
-        """lane_yaw_at(xy) -> lanelet heading or None; lanelet_of(xy) -> Lanelet or None"""
+    def __init__(self, config, ref_path, cosy_cl, lane_yaw_at, lanelet_of, fo_obstacles, debug=False, lanelets=None,
+                 intersections=None):
+        """lane_yaw_at(xy) -> lanelet heading or None; lanelet_of(xy) -> Lanelet or None; lanelets / intersections
+        (scenario.Lanelet list, list of {'incomings': [{'incoming','right','straight','left'}]}) feed the
+        dynamic-obstacle rule"""
         sl = config["spawn_locator"]
+        self.behind_dynamic = bool(sl.get("spawn_point_behind_dynamic_obstacle", True)) and lanelets is not None
+        self.max_dynamic = int(sl.get("max_dynamic_spawn_points", 1))
+        self.lanelets = list(lanelets or [])
+        self.intersections = list(intersections or [])
         self.behind_turn = bool(sl.get("spawn_points_behind_turn", True))
         self.behind_static = bool(sl.get("spawn_point_behind_static_obstacle", True))
         self.max_static = int(sl.get("max_static_spawn_points", 1))
@@ -167,12 +179,15 @@ class SpawnRules:
             return "right turn"
         return "straight ahead"
 
-    def find(self, view: CellView, ego_pos, ego_cl, ego_v) -> List[SpawnPoint]:
+    def find(self, view: CellView, ego_pos, ego_cl, ego_v, ego_orientation=0.0) -> List[SpawnPoint]:
+        self.ego_orientation = float(ego_orientation)
         self.ego_pos, self.ego_cl = np.asarray(ego_pos, dtype=np.float64), np.asarray(ego_cl, dtype=np.float64)
         self.s_threshold = self.ego_cl[0] + max(float(ego_v) * S_THRESHOLD_TIME, MIN_S_THRESHOLD)     # :113
         self.reference, self.reference_s = self.reference_window(self.ego_cl)
         intention = self.ego_intention(self.reference)
         out: List[SpawnPoint] = []
+        if self.behind_dynamic and intention in ("straight ahead", "left turn"):          # :124-126
+            out += self.behind_dynamic_obstacle(view)
         if self.behind_static:
             out += self.behind_static_obstacle(view)
         if self.behind_turn and intention in ("left turn", "right turn"):
@@ -294,3 +309,177 @@ class SpawnRules:
         if abs(yaw_p - yaw_e) % (2.0 * math.pi) < math.radians(45.0):
             return None
         return SpawnPoint(np.array(pos), "Pedestrian", np.array([s_ph, PHANTOM_OFFSET_D[intention]]), intention, None)
+
+    # ---- spawn_locator.py:145-317
+    def _lanelets_at(self, xy):
+        from .scenario import points_in_polygon
+        q = np.asarray(xy, dtype=np.float64).reshape(1, 2)
+        return [ll for ll in self.lanelets if points_in_polygon(q, ll.polygon)[0]]
+
+    def _relevant_lanelet_ids(self):
+        """other incomings / inner lanelets of the intersection the ego approaches, or -- without an intersection --
+        the oncoming neighbours of the lanelets along the reference path (:171-202)"""
+        ego_ll = self.lanelet_of(self.ego_pos)
+        if ego_ll is None:
+            return None, set(), set()
+        for it in self.intersections:
+            inc, inner = set(), set()
+            for e in it["incomings"]:
+                inc.update(e["incoming"])
+                inner.update(e["left"]); inner.update(e["right"]); inner.update(e["straight"])
+            if ego_ll.lanelet_id in inc or ego_ll.lanelet_id in inner:
+                rel = (inc | inner) - {ego_ll.lanelet_id}
+                return it, rel, inner
+        rel = set()
+        for i in range(0, len(self.reference), 5):
+            ll = self.lanelet_of(self.reference[i])
+            if ll is not None and ll.adj_left is not None:
+                rel.add(ll.adj_left)
+        return None, rel, set()
+
+    def behind_dynamic_obstacle(self, view: CellView) -> List[SpawnPoint]:
+        from scipy import ndimage
+        from .scenario import points_in_polygon
+        pts: List[SpawnPoint] = []
+        vis = [o for o in self.fo_obstacles if o.current_visible and o.obstacle_role == "dynamic"]
+        vis.sort(key=lambda o: float(np.linalg.norm(self.ego_pos - o.current_pos)))
+        if not vis:
+            return pts
+        intersection, relevant, inner = self._relevant_lanelet_ids()
+        by_id = {ll.lanelet_id: ll for ll in self.lanelets}
+        for ob in vis:
+            if str(ob.obstacle_type).lower() in ("bicycle", "pedestrian"):
+                continue
+            if len(pts) > self.max_dynamic:                                            # :212 (Q11)
+                break
+            if np.linalg.norm(self.ego_pos - ob.current_pos) > MAX_DISTANCE_TO_OTHER_OBSTACLE:
+                continue
+            ob_lls = self._lanelets_at(ob.current_pos)
+            if not any(ll.lanelet_id in relevant for ll in ob_lls):
+                continue
+            try:
+                ob_cl = self.cosy_cl.convert_to_curvilinear_coords(ob.current_pos[0], ob.current_pos[1])
+            except Exception:
+                continue
+            if ob_cl[0] < self.ego_cl[0] + 3.0 or abs(ob_cl[1]) > 15.0:                # :234
+                continue
+            polys = [ll.polygon for ll in ob_lls if ll.lanelet_id in relevant]
+            if intersection is not None and all(ll.lanelet_id in inner for ll in ob_lls):
+                first = next(ll for ll in ob_lls if ll.lanelet_id in relevant)
+                if first.predecessors and first.predecessors[0] in by_id:
+                    polys.append(by_id[first.predecessors[0]].polygon)                # :249-252
+            # candidate region on a 0.25 m lattice around the obstacle
+            h = 0.25
+            rad = BUFFER_AROUND_VEHICLE_FROM_SIDE
+            ax = np.arange(-rad, rad + 0.5 * h, h)
+            gx, gy = np.meshgrid(ob.current_pos[0] + ax, ob.current_pos[1] + ax)
+            q = np.stack((gx.ravel(), gy.ravel()), -1)
+
+            def member(q):
+                ok = np.zeros(len(q), dtype=bool)
+                for pl in polys:
+                    ok |= points_in_polygon(q, pl)                                      # possible_polygon (:255)
+                diff = abs(ob.current_orientation - self.ego_orientation) % (2.0 * math.pi)
+                if math.pi - TOLERANCE_SAME_DIRECTION <= diff <= math.pi + TOLERANCE_SAME_DIRECTION:
+                    ok &= _behind_rect(self.ego_pos, q, ob.current_corner_points)       # the obstacle's own shadow (:264)
+                else:
+                    ok &= np.array([bool(view.class_at(p) & OCCLUDED) for p in q])      # global occluded area (:272)
+                ok &= np.hypot(q[:, 0] - ob.current_pos[0], q[:, 1] - ob.current_pos[1]) <= rad
+                ok &= _rect_distance_points(q, ob.current_pos, ob.current_orientation, ob.length, ob.width) > 1.0
+                return ok
+            inside = member(q).reshape(gx.shape)
+            lab, n_lab = ndimage.label(inside)                                           # largest part (:279-281)
+            if n_lab == 0:
+                continue
+            sizes = ndimage.sum(inside, lab, index=np.arange(1, n_lab + 1))
+            k = int(np.argmax(sizes)) + 1
+            region = lab == k
+            if sizes[k - 1] * h * h < MIN_AREA_THRESHOLD:
+                continue
+            center = np.array([gx[region].mean(), gy[region].mean()])
+            if not any(ll.lanelet_id in relevant for ll in self._lanelets_at(center)):
+                continue
+
+            def in_region(p):
+                """membership of arbitrary points: predicate true and nearest lattice node belongs to the chosen part"""
+                p = np.asarray(p, dtype=np.float64).reshape(-1, 2)
+                ix = np.rint((p[:, 0] - gx[0, 0]) / h).astype(int)
+                iy = np.rint((p[:, 1] - gy[0, 0]) / h).astype(int)
+                okb = (ix >= 0) & (ix < gx.shape[1]) & (iy >= 0) & (iy < gx.shape[0])
+                out = np.zeros(len(p), dtype=bool)
+                out[okb] = region[iy[okb], ix[okb]]
+                return out & member(p)
+            ahead = ob.current_pos + 4.0 * np.array([math.cos(ob.current_orientation), math.sin(ob.current_orientation)])
+            if in_region(ahead)[0]:                                                       # region in front of it (:297)
+                continue
+            yaw = self.lane_yaw_at(center)
+            if yaw is None:
+                continue
+            car = _fit_rectangle(center, 5.5, 2.5, yaw, in_region)                       # :695-711
+            if car is None:
+                continue
+            bike = _fit_rectangle(car["centroid"], 2.0, 1.0, yaw, in_region)
+            for key, fit in (("Car", car), ("Bicycle", bike)):
+                if fit is not None and fit["area"] >= AGENT_AREA_LIMITS[key] and fit["jaccard"] > 0.98:
+                    pts.append(SpawnPoint(np.array(fit["centroid"]), key, None, "behind_dynamic_obstacle", None))
+        return pts
+
+
+def _behind_rect(ego, q, corners):
+    """points whose sight line from `ego` crosses the convex quadrilateral (the obstacle's shadow wedge)"""
+    c = np.asarray(corners, dtype=np.float64)
+    d = q - ego[None]
+    hit = np.zeros(len(q), dtype=bool)
+    for i in range(4):
+        a, e = c[i], c[(i + 1) % 4] - c[i]
+        den = d[:, 0] * e[1] - d[:, 1] * e[0]
+        w = a - ego
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (w[0] * e[1] - w[1] * e[0]) / den          # along the sight line, 1 = the point itself
+            u = (w[0] * d[:, 1] - w[1] * d[:, 0]) / den
+        hit |= (np.abs(den) > 1e-14) & (t >= 0.0) & (t <= 1.0) & (u >= 0.0) & (u <= 1.0)
+    return hit
+
+
+def _rect_distance_points(q, center, yaw, length, width):
+    c, s_ = math.cos(yaw), math.sin(yaw)
+    dx, dy = q[:, 0] - center[0], q[:, 1] - center[1]
+    lx, ly = c * dx + s_ * dy, -s_ * dx + c * dy
+    ex, ey = np.maximum(np.abs(lx) - length / 2.0, 0.0), np.maximum(np.abs(ly) - width / 2.0, 0.0)
+    return np.hypot(ex, ey)
+
+
+def _fit_rectangle(center, length, width, yaw, in_region, h=0.1):
+    """oriented rectangle clipped to the region, on a 0.1 m lattice: area, centroid and the Jaccard similarity of the
+    clipped shape with its minimum rotated rectangle (spawn_locator.py:695-726)"""
+    nx_, ny_ = int(round(length / h)), int(round(width / h))
+    u = (np.arange(nx_) + 0.5) * h - length / 2.0
+    v = (np.arange(ny_) + 0.5) * h - width / 2.0
+    uu, vv = np.meshgrid(u, v)
+    c, s_ = math.cos(yaw), math.sin(yaw)
+    p = np.stack((center[0] + c * uu.ravel() - s_ * vv.ravel(), center[1] + s_ * uu.ravel() + c * vv.ravel()), -1)
+    ok = in_region(p)
+    if not ok.any():
+        return None
+    area = float(ok.sum()) * h * h
+    pts = p[ok]
+    centroid = pts.mean(axis=0)
+    if ok.all():
+        return {"area": area, "centroid": centroid, "jaccard": 1.0}
+    # minimum rotated rectangle of the clipped cells (edge directions of the convex hull), cells have size h
+    from scipy.spatial import ConvexHull
+    try:
+        hull = pts[ConvexHull(pts).vertices]
+    except Exception:
+        return {"area": area, "centroid": centroid, "jaccard": 0.0}
+    best = np.inf
+    for i in range(len(hull)):
+        e = hull[(i + 1) % len(hull)] - hull[i]
+        n = np.linalg.norm(e)
+        if n == 0:
+            continue
+        e = e / n
+        a1 = hull @ e
+        a2 = hull @ np.array([-e[1], e[0]])
+        best = min(best, (a1.max() - a1.min() + h) * (a2.max() - a2.min() + h))
+    return {"area": area, "centroid": centroid, "jaccard": min(1.0, area / best)}

@@ -146,3 +146,39 @@ def test_pedestrian_behind_a_right_turn(oracle):
     straight = np.stack((np.linspace(-30, 40, 141), np.full(141, -1.75)), -1)
     r2 = SpawnRules(CFG, straight, PolylineCS(straight), lane_yaw_at, lanelet_of, obs)
     assert r2.find(view, ego, PolylineCS(straight).convert_to_curvilinear_coords(ego[0], ego[1]), 6.0) == []
+
+
+def test_car_and_bicycle_behind_an_oncoming_truck(oracle):
+    """two-way road without an intersection: an oncoming truck hides the stretch of the oncoming lane behind it; the
+    dynamic-obstacle rule fits a car (5.5 x 2.5 m) and then a bicycle (2 x 1 m) into the truck's shadow on that lane"""
+    xs = np.linspace(-10, 70, 41)
+    lane1 = S.Lanelet(1, np.stack((xs, np.zeros(41)), -1), np.stack((xs, np.full(41, -3.5)), -1))
+    lane2 = S.Lanelet(2, np.stack((xs[::-1], np.zeros(41)), -1), np.stack((xs[::-1], np.full(41, 3.5)), -1))
+    lane1.adj_left, lane1.adj_left_same_direction = 2, False
+    lane2.adj_left, lane2.adj_left_same_direction = 1, False
+    truck = S.Obstacle(31, "dynamic", "truck", 9.0, 3.2, 0, np.array([20.0, 1.75, math.pi, 8.0]), np.zeros((0, 4)))
+    ego = np.array([0.0, -1.75])
+    view, obs, lane_yaw_at, lanelet_of = _view(oracle, [lane1, lane2], [truck], ego, 0.0)
+    assert next(iter(obs)).current_visible
+    path = np.stack((np.linspace(-5, 65, 141), np.full(141, -1.75)), -1)
+    cs = PolylineCS(path)
+    rules = SpawnRules(CFG | {"spawn_locator": CFG["spawn_locator"] | {"spawn_point_behind_dynamic_obstacle": True,
+                                                                       "max_dynamic_spawn_points": 1}},
+                       path, cs, lane_yaw_at, lanelet_of, obs, lanelets=[lane1, lane2], intersections=[])
+    ego_cl = cs.convert_to_curvilinear_coords(ego[0], ego[1])
+    pts = [p for p in rules.find(view, ego, ego_cl, 8.0, 0.0) if p.source == "behind_dynamic_obstacle"]
+    kinds = [p.agent_type for p in pts]
+    assert kinds == ["Car", "Bicycle"]
+    for p in pts:
+        assert 25.5 < p.position[0] < 32.0 and 0.0 < p.position[1] < 3.5          # on the oncoming lane, behind the truck
+        assert not view.class_at(p.position) & 2
+    # a pedestrian-type or bicycle-type obstacle never triggers the rule; neither does a truck driving the same way
+    for typ, yaw in (("bicycle", math.pi), ("truck", 0.0)):
+        other = S.Obstacle(32, "dynamic", typ, 9.0, 2.5, 0, np.array([20.0, 1.75, yaw, 8.0]), np.zeros((0, 4)))
+        v2, o2, ly, lo = _view(oracle, [lane1, lane2], [other], ego, 0.0)
+        r2 = SpawnRules(CFG, path, cs, ly, lo, o2, lanelets=[lane1, lane2], intersections=[])
+        got = [p for p in r2.find(v2, ego, ego_cl, 8.0, 0.0) if p.source == "behind_dynamic_obstacle"]
+        if typ == "bicycle":
+            assert got == []
+        else:                                     # same direction: the global occluded area is used instead of the wedge
+            assert all(p.agent_type in ("Car", "Bicycle") for p in got)
