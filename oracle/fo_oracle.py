@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libfo_oracle.so")
+_LIB = os.environ.get("FO_ORACLE_LIB") or os.path.join(_HERE, "libfo_oracle.so")   # env: sanitizer build (make asan)
 
 NPF, NPI, NL, NC = 12, 4, 5, 16
 PF = {"dce": 0, "ttc": 1, "ttce": 2, "max_ego_risk": 3, "max_obst_risk": 4, "max_obst_harm_with_cp": 5,
