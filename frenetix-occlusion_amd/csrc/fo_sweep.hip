@@ -710,18 +710,24 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       // latency-bound by construction (two loads, five operations per sample): eight samples in flight at a time
 #pragma unroll 1
       for (int t8 = 0; t8 < Ld; t8 += 8) {
-        double vx[8], vy[8];
+        double vx[8], vy[8], gpx[8], gpy[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const double *e = tj + (size_t)min(t8 + u, Ld - 1) * NEF * TILE;
+          const int t = min(t8 + u, Ld - 1);
+          const double *e = tj + (size_t)t * NEF * TILE;
           vx[u] = e[0 * TILE];
           vy[u] = e[1 * TILE];
+          const cdp_t g = G + (size_t)t * NAF;   // eight scalar loads in flight as well (one lgkmcnt wait for all)
+          gpx[u] = g[0];
+          gpy[u] = g[1];
         }
+        asm volatile("; probe operands resident" ::"s"(gpx[0]), "s"(gpy[0]), "s"(gpx[1]), "s"(gpy[1]), "s"(gpx[2]),
+                     "s"(gpy[2]), "s"(gpx[3]), "s"(gpy[3]), "s"(gpx[4]), "s"(gpy[4]), "s"(gpx[5]), "s"(gpy[5]),
+                     "s"(gpx[6]), "s"(gpy[6]), "s"(gpx[7]), "s"(gpy[7]));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int t = min(t8 + u, Ld - 1);  // repeats of the last sample cannot win (strict <)
-          const cdp_t g = G + (size_t)t * NAF;
-          const double rx = g[0] - vx[u], ry = g[1] - vy[u];
+          const double rx = gpx[u] - vx[u], ry = gpy[u] - vy[u];
           const double c2 = rx * rx + ry * ry;
           if (c2 < bestc) { bestc = c2; tb = t; }
         }
