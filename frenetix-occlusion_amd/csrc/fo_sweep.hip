@@ -555,6 +555,9 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 //   pass 2 (t loop)  harm + risk + running maxima + coalesced list stores, cp read back from cpbuf.
 // exp() for the logistic models is a 64-entry 2^(j/64) table + degree-5 polynomial (~15 VALU ops).
 // Supports T-1 <= TQ; longer horizons take the generic kernel.
+#ifndef FO_ERF_GROUP
+#define FO_ERF_GROUP 1  // table gathers of the CP boxes issued together (4) or one at a time (1: fewer live registers)
+#endif
 #ifndef FO_TC
 #define FO_TC 16     // timesteps per chunk of the two-pass scheme (rows of the per-wave cp buffer)
 #endif
@@ -661,9 +664,12 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   const bool do_ttc = a.mask & FO_M_TTC, do_ttce = a.mask & FO_M_TTCE;
   const double hlA = a.hlA, hwA = a.hwA;
 
-  double w_min_dce = INFINITY, w_min_ttc = INFINITY, w_min_ttce = INFINITY;
+  double w_min_dce = INFINITY;
+  // ttc / ttce are round3(time_dce * dt), monotone in time_dce: the minima over agents are kept as integer steps
+  int w_min_tttc = 0x7fffffff, w_min_tttce = 0x7fffffff;
   double w_max_er = 0.0, w_max_or = 0.0, w_max_eh = 0.0, w_max_oh = 0.0, w_max_cp = 0.0, w_max_hwc = 0.0;
-  double w_arg_dce = -1.0, w_arg_ttc = -1.0, w_arg_or = -1.0, w_dce_flag = 0.0;
+  int w_arg_dce = -1, w_arg_ttc = -1, w_arg_or = -1;  // agent indices as integers: three VGPRs less than as doubles
+  bool w_dce_flag = false;
 
   const int k0 = (chunk * QWAVES + wave) * a.apw;
   for (int kk = 0; kk < a.apw; ++kk) {
@@ -782,10 +788,16 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
 #pragma unroll 1
             for (int b = -1; b <= 1; ++b) {
               const double cx = qx + b * bxs, cy = qy + b * bys;
+#if FO_ERF_GROUP == 4
               double e4[4];  // the four table gathers of one box are issued together, then evaluated
               fo_erf_fast4(erf_tab, (cx + a.off_x) * qisx, (cx - a.off_x) * qisx, (cy + a.off_y) * qisy,
                            (cy - a.off_y) * qisy, e4);
               acc = fma(e4[0] - e4[1], e4[2] - e4[3], acc);
+#else
+              const double fx = fo_erf_fast(erf_tab, (cx + a.off_x) * qisx) - fo_erf_fast(erf_tab, (cx - a.off_x) * qisx);
+              const double fy = fo_erf_fast(erf_tab, (cy + a.off_y) * qisy) - fo_erf_fast(erf_tab, (cy - a.off_y) * qisy);
+              acc = fma(fx, fy, acc);
+#endif
             }
           }
           cpw[row * TILE + src] = acc * (0.25 / 3.0);  // (1/2)(1/2) of the two Phi differences, /3 (:122)
@@ -1008,14 +1020,14 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       pi[FO_PI_HR_VALID * ps_] = hr_valid ? 1 : 0;
     }
     if (do_dce) {
-      if (dce_m < w_min_dce) { w_min_dce = dce_m; w_arg_dce = (double)k; }
-      if (dce_m < a.thr_dce) w_dce_flag = 1.0;
-      if (do_ttc && ttc < w_min_ttc) { w_min_ttc = ttc; w_arg_ttc = (double)k; }
-      if (do_ttce) w_min_ttce = fmin(w_min_ttce, ttce);
+      if (dce_m < w_min_dce) { w_min_dce = dce_m; w_arg_dce = k; }
+      if (dce_m < a.thr_dce) w_dce_flag = true;
+      if (do_ttc && dce == 0.0 && tdce < w_min_tttc) { w_min_tttc = tdce; w_arg_ttc = k; }
+      if (do_ttce) w_min_tttce = min(w_min_tttce, tdce);
     }
     if (hr_valid) {
       w_max_er = fmax(w_max_er, max_er);
-      if (max_or > w_max_or) { w_max_or = max_or; w_arg_or = (double)k; }
+      if (max_or > w_max_or) { w_max_or = max_or; w_arg_or = k; }
       w_max_eh = fmax(w_max_eh, max_eh);
       w_max_oh = fmax(w_max_oh, max_oh);
       w_max_cp = fmax(w_max_cp, max_cp);
@@ -1026,36 +1038,38 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   // ---------------- combine the waves of the workgroup (ascending agent order); scratch aliases the cp buffers
   __syncthreads();
   double *red = cpbuf_all;
+  double w_min_ttc = w_min_tttc == 0x7fffffff ? INFINITY : fo_round3((double)w_min_tttc * a.dt);
+  double w_min_ttce = w_min_tttce == 0x7fffffff ? INFINITY : fo_round3((double)w_min_tttce * a.dt);
   if (wave > 0) {
     double *rp = red + (size_t)(wave - 1) * NPS * TILE + lane;
-    rp[PS_MIN_DCE * TILE] = w_min_dce; rp[PS_ARG_DCE * TILE] = w_arg_dce; rp[PS_MIN_TTC * TILE] = w_min_ttc;
-    rp[PS_ARG_TTC * TILE] = w_arg_ttc; rp[PS_MIN_TTCE * TILE] = w_min_ttce; rp[PS_MAX_ER * TILE] = w_max_er;
-    rp[PS_MAX_OR * TILE] = w_max_or; rp[PS_ARG_OR * TILE] = w_arg_or; rp[PS_MAX_EH * TILE] = w_max_eh;
+    rp[PS_MIN_DCE * TILE] = w_min_dce; rp[PS_ARG_DCE * TILE] = (double)w_arg_dce; rp[PS_MIN_TTC * TILE] = w_min_ttc;
+    rp[PS_ARG_TTC * TILE] = (double)w_arg_ttc; rp[PS_MIN_TTCE * TILE] = w_min_ttce; rp[PS_MAX_ER * TILE] = w_max_er;
+    rp[PS_MAX_OR * TILE] = w_max_or; rp[PS_ARG_OR * TILE] = (double)w_arg_or; rp[PS_MAX_EH * TILE] = w_max_eh;
     rp[PS_MAX_OH * TILE] = w_max_oh; rp[PS_MAX_CP * TILE] = w_max_cp; rp[PS_MAX_HWC * TILE] = w_max_hwc;
-    rp[PS_DCE_FLAG * TILE] = w_dce_flag; rp[PS_MAX_BTN * TILE] = 0.0;
+    rp[PS_DCE_FLAG * TILE] = w_dce_flag ? 1.0 : 0.0; rp[PS_MAX_BTN * TILE] = 0.0;
   }
   __syncthreads();
   if (wave == 0) {
     for (int w = 0; w < QWAVES - 1; ++w) {
       const double *rp = red + (size_t)w * NPS * TILE + lane;
-      if (rp[PS_MIN_DCE * TILE] < w_min_dce) { w_min_dce = rp[PS_MIN_DCE * TILE]; w_arg_dce = rp[PS_ARG_DCE * TILE]; }
-      if (rp[PS_MIN_TTC * TILE] < w_min_ttc) { w_min_ttc = rp[PS_MIN_TTC * TILE]; w_arg_ttc = rp[PS_ARG_TTC * TILE]; }
+      if (rp[PS_MIN_DCE * TILE] < w_min_dce) { w_min_dce = rp[PS_MIN_DCE * TILE]; w_arg_dce = (int)rp[PS_ARG_DCE * TILE]; }
+      if (rp[PS_MIN_TTC * TILE] < w_min_ttc) { w_min_ttc = rp[PS_MIN_TTC * TILE]; w_arg_ttc = (int)rp[PS_ARG_TTC * TILE]; }
       w_min_ttce = fmin(w_min_ttce, rp[PS_MIN_TTCE * TILE]);
       w_max_er = fmax(w_max_er, rp[PS_MAX_ER * TILE]);
-      if (rp[PS_MAX_OR * TILE] > w_max_or) { w_max_or = rp[PS_MAX_OR * TILE]; w_arg_or = rp[PS_ARG_OR * TILE]; }
+      if (rp[PS_MAX_OR * TILE] > w_max_or) { w_max_or = rp[PS_MAX_OR * TILE]; w_arg_or = (int)rp[PS_ARG_OR * TILE]; }
       w_max_eh = fmax(w_max_eh, rp[PS_MAX_EH * TILE]);
       w_max_oh = fmax(w_max_oh, rp[PS_MAX_OH * TILE]);
       w_max_cp = fmax(w_max_cp, rp[PS_MAX_CP * TILE]);
       w_max_hwc = fmax(w_max_hwc, rp[PS_MAX_HWC * TILE]);
-      w_dce_flag = fmax(w_dce_flag, rp[PS_DCE_FLAG * TILE]);
+      w_dce_flag = w_dce_flag || rp[PS_DCE_FLAG * TILE] > 0.0;
     }
     const size_t PM = (size_t)a.Mp;
     double *pp = a.partial + (size_t)chunk * NPS * PM + (size_t)tile * TILE + lane;
-    pp[PS_MIN_DCE * PM] = w_min_dce; pp[PS_ARG_DCE * PM] = w_arg_dce; pp[PS_MIN_TTC * PM] = w_min_ttc;
-    pp[PS_ARG_TTC * PM] = w_arg_ttc; pp[PS_MIN_TTCE * PM] = w_min_ttce; pp[PS_MAX_ER * PM] = w_max_er;
-    pp[PS_MAX_OR * PM] = w_max_or; pp[PS_ARG_OR * PM] = w_arg_or; pp[PS_MAX_EH * PM] = w_max_eh;
+    pp[PS_MIN_DCE * PM] = w_min_dce; pp[PS_ARG_DCE * PM] = (double)w_arg_dce; pp[PS_MIN_TTC * PM] = w_min_ttc;
+    pp[PS_ARG_TTC * PM] = (double)w_arg_ttc; pp[PS_MIN_TTCE * PM] = w_min_ttce; pp[PS_MAX_ER * PM] = w_max_er;
+    pp[PS_MAX_OR * PM] = w_max_or; pp[PS_ARG_OR * PM] = (double)w_arg_or; pp[PS_MAX_EH * PM] = w_max_eh;
     pp[PS_MAX_OH * PM] = w_max_oh; pp[PS_MAX_CP * PM] = w_max_cp; pp[PS_MAX_HWC * PM] = w_max_hwc;
-    pp[PS_DCE_FLAG * PM] = w_dce_flag; pp[PS_MAX_BTN * PM] = 0.0;
+    pp[PS_DCE_FLAG * PM] = w_dce_flag ? 1.0 : 0.0; pp[PS_MAX_BTN * PM] = 0.0;
   }
 }
 
