@@ -653,8 +653,11 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   const int tile = (j % a.nt8) * 8 + r;
   const int chunk = j / a.nt8;
   if (tile >= a.n_tiles) return;
-  const int m = tile * TILE + lane;
-  const bool valid = m < a.M;
+  // Lanes past the last trajectory hold copies of trajectory M-1 (fo_prep_traj_kernel pads the tile that way) and
+  // run as its duplicates: they compute the same values and store them to the same addresses.  No output store is
+  // predicated, on purpose: a skipped store path makes the compiler's s_waitcnt for the prefetched loads assume
+  // that no store lies between issue and use, which drains the store queue in every iteration of pass 2.
+  const int m = min(tile * TILE + lane, a.M - 1);
   const int T = a.T, Tm1 = a.T - 1, M = a.M, A = a.A;
   const double *tjb = a.traj + (size_t)tile * T * NEF * TILE;  // uniform tile base
   const double *tj = tjb + lane;
@@ -683,12 +686,12 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
 
     if (L <= 0) {  // inactive slot (a spawn buffer that is only partly filled): no outputs enter any reduction
       if (a.be_mask) a.be_mask[(size_t)k * a.Mp + m] = 0;
-      if (PAIR && valid) {
+      if (PAIR) {
         const size_t ps_ = (size_t)A * M;
         for (int f = 0; f < FO_NPF; ++f) a.pair_f[(size_t)f * ps_ + (size_t)k * M + m] = NAN;
         for (int f = 0; f < FO_NPI; ++f) a.pair_i[(size_t)f * ps_ + (size_t)k * M + m] = 0;
       }
-      if (LISTS && valid) {
+      if (LISTS) {
         const size_t ls = (size_t)A * Tm1 * M;
         for (int f = 0; f < FO_NL; ++f)
           for (int t = 0; t < Tm1; ++t) a.lists[(size_t)f * ls + ((size_t)k * Tm1 + t) * M + m] = NAN;
@@ -883,7 +886,6 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             const double m2 = fmin(d0, fmin(dp, dm));
             ing = m2 <= 25.0;
             if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);  // keep the reference's test on the rounded sqrt
-            ing = ing && valid;
           }
           const unsigned long long bal = __ballot(ing);
           if (bal) {
@@ -975,7 +977,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
               max_oh = fmax(max_oh, oh);
             }
             if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
-            if (LISTS && valid) {
+            if (LISTS) {
               __builtin_nontemporal_store(cp, lp + FO_L_CP * ls);
               __builtin_nontemporal_store(eh, lp + FO_L_EGO_HARM * ls);
               __builtin_nontemporal_store(oh, lp + FO_L_OBST_HARM * ls);
@@ -998,7 +1000,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     if (a.be_mask) a.be_mask[(size_t)k * a.Mp + m] = (do_ttc && ttc < INFINITY && ttc > 0.0) ? 1 : 0;  // be.py:49-50
     const bool hr_valid = do_hr && Lh > 0;
     const double hwc = (max_cp > 0.01) ? oh_at_cp : 0.0;                                    // hr.py:81-84
-    if (PAIR && valid) {
+    if (PAIR) {
       const size_t ps_ = (size_t)A * M;
       double *pf = a.pair_f + (size_t)k * M + m;
       pf[FO_PF_DCE * ps_] = do_dce ? dce_m : NAN;
