@@ -636,7 +636,9 @@ typedef const int32_t __attribute__((address_space(4))) *cip_t;
 __device__ __forceinline__ cdp_t fo_const(const double *p) { return (cdp_t)(unsigned long long)p; }
 __device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(unsigned long long)p; }
 
-template <bool PAIR, bool LISTS>
+// ALLM: the default metric set (dce, cp, ttc, ttce, hr all active, no debug ablation) is compiled with the flags as
+// constants -- fewer wave-uniform masks to keep in SGPRs, fewer branches; any other selection takes the generic copy.
+template <bool PAIR, bool LISTS, bool ALLM>
 __global__ __launch_bounds__(TILE *QWAVES) __attribute__((amdgpu_waves_per_eu(FO_MINW, FO_MINW)))
 void fo_sweep_queue_kernel(const SweepArgs a) {
   __shared__ double2 erf_tab[ERF_N];
@@ -663,8 +665,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   const double *tj = tjb + lane;
   double *cpw = cpbuf_all + wave * (TC * TILE);
   unsigned short *q = queue_all + wave * QCAP;
-  const bool do_dce = a.mask & FO_M_DCE, do_cp = a.mask & FO_M_CP, do_hr = a.mask & FO_M_HR;
-  const bool do_ttc = a.mask & FO_M_TTC, do_ttce = a.mask & FO_M_TTCE;
+  const bool do_dce = ALLM || (a.mask & FO_M_DCE), do_cp = ALLM || (a.mask & FO_M_CP), do_hr = ALLM || (a.mask & FO_M_HR);
+  const bool do_ttc = ALLM || (a.mask & FO_M_TTC), do_ttce = ALLM || (a.mask & FO_M_TTCE);
+  const uint32_t ablate = ALLM ? 0u : a.ablate;
   const double hlA = a.hlA, hwA = a.hwA;
 
   double w_min_dce = INFINITY;
@@ -712,7 +715,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     double dce = INFINITY, thr2 = INFINITY, thrR2 = INFINITY;
     int tdce = 0;
     const double Rsum = sqrt(hlA * hlA + hwA * hwA) + sqrt(hlB * hlB + hwB * hwB);
-    if (do_dce && !(a.ablate & 1)) {
+    if (do_dce && !(ablate & 1)) {
       const int Ld = min(L, T);
       double bestc = INFINITY;
       int tb = 0;
@@ -833,7 +836,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
           const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
           npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3];
         }
-        if (do_dce && t < L && !(a.ablate & 1)) {
+        if (do_dce && t < L && !(ablate & 1)) {
           const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
           const double dx = px - ccx, dy = py - ccy;
           // nothing to gain after the (earliest) zero; otherwise the centres must be close enough
@@ -873,7 +876,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             }
           }
         }
-        if (do_cp && t >= 1 && t < L && !(a.ablate & 2)) {
+        if (do_cp && t >= 1 && t < L && !(ablate & 2)) {
           // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
           const double rx = ex - ppx, ry = ey - ppy;
           const double d0 = rx * rx + ry * ry;
@@ -950,7 +953,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             double ex2 = 0.0, ey2 = 0.0, eth2 = 0.0;
             if (LR4S) { ex2 = e_[0 * TILE]; ey2 = e_[1 * TILE]; eth2 = e_[4 * TILE]; }
             double eh = NAN, oh = NAN, er = NAN, orr = NAN;
-            if (do_hr && t < Lh && !(a.ablate & 4)) {
+            if (do_hr && t < Lh && !(ablate & 4)) {
               const double cr = pc * ec0 + ps * es0;
               const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
               if (LR4S) {
@@ -1358,9 +1361,17 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[ctx->n_timed], s));
     const dim3 g(grid), b(TILE * wpb);
     if (use_queue) {
-      if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true>), g, b, 0, s, a);
-      else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false>), g, b, 0, s, a);
-      else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false>), g, b, 0, s, a);
+      const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
+      const bool allm = (a.mask & all5) == all5 && a.ablate == 0;
+      if (allm) {
+        if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, true>), g, b, 0, s, a);
+        else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, true>), g, b, 0, s, a);
+      } else {
+        if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, false>), g, b, 0, s, a);
+        else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, false>), g, b, 0, s, a);
+      }
     } else {
       if (d_lists) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, true>), g, b, 0, s, a);
       else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, false>), g, b, 0, s, a);
