@@ -571,11 +571,20 @@ constexpr int TC = FO_TC;
 constexpr int QWAVES = FO_QWAVES;
 constexpr int QCAP = 128;
 
+// v_max_f64 / v_min_f64 without the canonicalisation fmax()/fmin() add for loop-carried operands (IEEE quieting of
+// signalling NaNs: two extra instructions per call); operands here are results of arithmetic, never signalling
+__device__ __forceinline__ double fo_vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // exp(z) = 2^(k/64) * e^r, k = rint(64 z / ln 2), |r| <= ln2/128: 64-entry table of 2^(j/64) in LDS and a degree-4
 // polynomial (remainder r^5/120 < 4e-14 relative).  Few distinct float64 constants on purpose: every one of them
 // occupies an SGPR pair for the whole loop, and the kernel is short of SGPRs, not of LDS bandwidth.
+template <bool CLAMP = true>
 __device__ __forceinline__ double fo_exp_tab(const double *__restrict__ tab2, double z) {
-  z = fmin(fmax(z, -700.0), 700.0);
+  if (CLAMP) z = fmin(fmax(z, -700.0), 700.0);  // CLAMP = false: the caller bounds the argument
   const double MAGIC = 6755399441055744.0;                          // 1.5 * 2^52
   const double tm = fma(z, 92.33248261689366, MAGIC);               // 64 / ln 2
   const double kf = tm - MAGIC;
@@ -594,8 +603,9 @@ __device__ __forceinline__ double fo_exp_tab(const double *__restrict__ tab2, do
 #ifndef FO_RCP_NR
 #define FO_RCP_NR 1
 #endif
+template <bool CLAMP = true>
 __device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab2, double nz) {
-  const double d = 1.0 + fo_exp_tab(tab2, nz);
+  const double d = 1.0 + fo_exp_tab<CLAMP>(tab2, nz);
   double y = __builtin_amdgcn_rcp(d);
 #pragma unroll
   for (int i = 0; i < FO_RCP_NR; ++i) y = fma(fma(-d, y, 1.0), y, y);
@@ -955,7 +965,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             double eh = NAN, oh = NAN, er = NAN, orr = NAN;
             if (do_hr && t < Lh && !(ablate & 4)) {
               const double cr = pc * ec0 + ps * es0;
-              const double dv = fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0));  // cos(pdof) = -cos(yaw - theta)
+              // cos(pdof) = -cos(yaw - theta); dv is capped (1e4 m/s) so that the logistic arguments below stay in
+              // the range of the table exp without a clamp of their own
+              const double dv = fmin(fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0)), 1.0e4);
               if (LR4S) {
                 // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
                 double ddx = gx - ex0, ddy = gy - ey0;
@@ -963,21 +975,21 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
                 const float relc = fo_atan2_crude((float)ddy, (float)ddx);
                 const double ke = fo_lr4s_coef_dir(ddx, ddy, ec0, es0, relc, 0.0f, eth0, a.hc.lr4s_side, a.hc.lr4s_rear);
                 const double ko = fo_lr4s_coef_dir(ddx, ddy, pc, ps, relc, 3.14159265f, gyaw, a.hc.lr4s_side, a.hc.lr4s_rear);
-                eh = fo_logistic_neg(exp_tab, fma(k4e, dv, c4) - ke);
-                oh = fo_logistic_neg(exp_tab, fma(k4o, dv, c4) - ko);
+                eh = fo_logistic_neg<false>(exp_tab, fma(k4e, dv, c4) - ke);
+                oh = fo_logistic_neg<false>(exp_tab, fma(k4o, dv, c4) - ko);
               } else if (prot == 0) {
-                eh = fo_logistic_neg(exp_tab, fma(k1e, dv, c1));
-                oh = fo_logistic_neg(exp_tab, fma(kpo, dv, a.hc.ped_const));
+                eh = fo_logistic_neg<false>(exp_tab, fma(k1e, dv, c1));
+                oh = fo_logistic_neg<false>(exp_tab, fma(kpo, dv, a.hc.ped_const));
               } else {
                 eh = 1.0;
                 oh = 1.0;
               }
               er = eh * cp;
               orr = oh * cp;
-              max_er = fmax(max_er, er);
+              max_er = fo_vmax(max_er, er);
               if (orr > max_or) { max_or = orr; idx_or = t; }
-              max_eh = fmax(max_eh, eh);
-              max_oh = fmax(max_oh, oh);
+              max_eh = fo_vmax(max_eh, eh);
+              max_oh = fo_vmax(max_oh, oh);
             }
             if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
             if (LISTS) {
