@@ -295,3 +295,61 @@ def test_every_obstacle_type_and_many_agents(torch_cuda, oracle):
     ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"risk": 0.3}, nthreads=8)
     got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"risk": 0.3})
     _compare(oracle, ref, got)
+
+
+def test_dce_ties_stationary_and_random_geometry(torch_cuda, oracle):
+    """the order-independent DCE scan (probe + lower-bound skips) must reproduce 'first strict minimum' exactly:
+    stationary pairs (every timestep ties), symmetric pass-bys (two equal minima), touching rectangles, and a
+    randomised batch with arbitrary headings, speeds, sizes and prediction lengths"""
+    from frenetix_occlusion import synthetic as S
+    T = 31
+    t = np.arange(T) * 0.1
+    rows = []
+    rows.append((np.zeros(T), np.zeros(T), np.zeros(T), np.zeros(T)))                       # ego at rest
+    rows.append((6.0 * t, np.zeros(T), np.zeros(T), np.full(T, 6.0)))                        # straight
+    x = np.concatenate((np.linspace(0, 9, 16), np.linspace(9, 0, 16)[1:]))                   # out and back: symmetric
+    rows.append((x, np.zeros(T), np.zeros(T), np.full(T, 6.0)))
+    rows.append((np.full(T, 11.2), np.full(T, 0.4), np.full(T, 0.3), np.zeros(T)))           # at rest next to agent 1
+    traj = {k: np.stack([r[i] for r in rows]) for i, k in enumerate(("x", "y", "theta", "v"))}
+    traj["a"] = np.zeros_like(traj["x"])
+    pos = np.zeros((5, T, 2))
+    pos[0] = [30.0, 0.0]                                                                     # at rest ahead
+    pos[1] = [15.0, 0.0]                                                                     # at rest, will be hit
+    pos[2, :, 0], pos[2, :, 1] = 20.0, 6.0 - 4.0 * t                                          # crossing
+    pos[3, :, 0], pos[3, :, 1] = 12.0 + 0.0 * t, -3.0                                         # beside the path
+    pos[4] = [VEH_TOUCH_X, 0.0]                                                              # touching the ego at rest
+    yaw = np.zeros((5, T))
+    yaw[2] = -math.pi / 2
+    agents = {"pos": pos, "yaw": yaw, "v": np.zeros((5, T)), "cov": np.tile(0.1 * np.eye(2), (5, T, 1, 1)),
+              "shape": np.tile([5.76, 2.6], (5, 1)), "raw_dims": np.tile([4.8, 2.0], (5, 1)),
+              "type": np.array([0, 0, 4, 3, 0], dtype=np.int32), "len": np.array([T, T, T, 20, T], dtype=np.int32)}
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1)
+    got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1)
+    _compare(oracle, ref, got)
+    td = ref["pair_i"][..., oracle.PI["time_dce"]]
+    assert td[0, 0] == 0 and td[2, 0] == 15 and td[0, 4] == 0                 # ties -> earliest; symmetric -> first
+    assert ref["pair_f"][0, 4, oracle.PF["dce"]] == 0.0                        # touching counts as distance 0
+    rng = np.random.default_rng(123)
+    for trial in range(3):
+        M, A = 256, 24
+        traj = S.make_trajectories(M, T, 0.1, seed=1000 + trial, order="random")
+        th0 = rng.uniform(-math.pi, math.pi, (M, 1))
+        c, s_ = np.cos(th0), np.sin(th0)
+        traj["x"], traj["y"] = c * traj["x"] - s_ * traj["y"], s_ * traj["x"] + c * traj["y"]
+        traj["theta"] = traj["theta"] + th0 + rng.choice([0.0, 2 * math.pi, -4 * math.pi], (M, 1))   # un-wrapped headings
+        p0 = rng.uniform(-25, 25, (A, 2))
+        ya = rng.uniform(-7, 7, A)
+        sp = rng.uniform(0, 12, A) * (rng.random(A) > 0.25)
+        pos = p0[:, None, :] + t[None, :, None] * (sp[:, None] * np.stack((np.cos(ya), np.sin(ya)), -1))[:, None, :]
+        raw = np.stack((rng.uniform(0.3, 12, A), rng.uniform(0.3, 3, A)), -1)
+        agents = {"pos": pos, "yaw": np.repeat(ya[:, None], T, 1), "v": np.repeat(sp[:, None], T, 1),
+                  "cov": np.tile(np.eye(2), (A, T, 1, 1)) * rng.uniform(0.05, 0.8, (A, 1, 1, 1)),
+                  "shape": raw * 1.25, "raw_dims": raw, "type": rng.integers(0, 12, A).astype(np.int32),
+                  "len": rng.integers(1, T + 1, A).astype(np.int32)}
+        ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.4}, nthreads=8)
+        got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.4})
+        _compare(oracle, ref, got)
+
+
+VEH_TOUCH_X = 1.4227 + 4.508 / 2 + 2.4   # ego centre offset + half ego length + half agent length: faces touch
+import math  # noqa: E402
