@@ -104,7 +104,8 @@ def main():
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FO_BENCH_FORCE_DIST") == "1"   # env: exercise the RCCL path on one rank
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -148,7 +149,7 @@ def main():
              [d(agents["type"], torch.int32), d(agents["len"], torch.int32)]
     tx, ty, tth, tv, ta = (d(traj[k]) for k in ("x", "y", "theta", "v", "a"))
     out = None
-    gathered = torch.empty((world * M, N.NC), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty((world * M, N.NC), dtype=torch.float64, device=dev) if use_dist else None
 
     def scene_stage():
         sm, sl, ego = scene["sm"], scene["sl"], scene["ego"]
@@ -160,7 +161,7 @@ def main():
         a_args = scene_stage() if scene is not None else ag
         sw.set_agents(*a_args, check=False)
         out = sw.run(tx, ty, tth, tv, ta, mode=args.mode, out=out)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, out.cost)
 
     for _ in range(args.warmup):
@@ -169,7 +170,7 @@ def main():
     n_active = A
     if scene is not None:
         n_active = int(scene["sl"].batch.n.item())
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     sw.ctx.timing(True)
@@ -177,13 +178,13 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = sw.ctx.timing_read()
     sw.ctx.timing(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -249,7 +250,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
