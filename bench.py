@@ -125,7 +125,7 @@ def main():
         import yaml
         from frenetix_occlusion import interface
         from frenetix_occlusion import scenario as SC
-        from frenetix_occlusion.sensor_model import SensorModel, ray_dirs
+        from frenetix_occlusion.sensor_model import SensorModel
         from frenetix_occlusion.spawn_locator import SpawnLocator
         sc = SC.synthetic_urban_grid()
         ego = sc.ego_initial
@@ -137,8 +137,7 @@ def main():
                          ctx=ctx, device=local_rank)
         sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
         sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
-        dirs = d(ray_dirs(720, float(ego[2]), 360.0))
-        scene = dict(sm=sm, sl=sl, ego=ego, dirs=dirs, edges=len(sm.map_geometry.edges), obstacles=len(sc.obstacles))
+        scene = dict(sm=sm, sl=sl, ego=ego, edges=len(sm.map_geometry.edges), obstacles=len(sc.obstacles))
         traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3 + 1000 * rank, ego_pos=ego[:2], ego_yaw=float(ego[2]),
                                    order=args.order)
         agents = None
@@ -153,7 +152,7 @@ def main():
 
     def scene_stage():
         sm, sl, ego = scene["sm"], scene["sl"], scene["ego"]
-        sm.launch(ego[:2], float(ego[2]), scene["dirs"])
+        sm.launch(ego[:2], float(ego[2]))
         return sl.sample(ego[:2], float(ego[2]), float(ego[3])).sweep_args()
 
     def step():

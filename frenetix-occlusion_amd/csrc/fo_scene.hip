@@ -32,6 +32,8 @@ struct Scene {
   double cs = 0.5, x0 = 0, y0 = 0;
   int rnx = 0, rny = 0;
   double *d_edges = nullptr;      // [E][4]
+  int32_t *d_edge_line = nullptr; // [E] straight-line chain of each piece (optional)
+  double *d_chunk_box = nullptr;  // [ceil(E/64)][4] xmin, ymin, xmax, ymax of 64 consecutive pieces
   uint8_t *d_raster = nullptr;    // [rny][rnx]
   double *d_lane_yaw = nullptr;   // [rny][rnx] or null
   // phantom vehicle routes (optional): routes r < R of lanelet p = vertices route_first[p*R+r] .. +route_count[p*R+r]
@@ -46,6 +48,9 @@ struct Scene {
   size_t cap_cells = 0, cap_blk = 0;
   int32_t *d_cand = nullptr;      // candidate cell list
   int32_t *d_ncand = nullptr;
+  int32_t *d_amb = nullptr;       // [cells] window indices of the cells the fan cannot decide
+  int32_t *d_namb = nullptr;      // [1]; zeroed by the ray kernel of the step
+  size_t cap_amb = 0;
 };
 
 Scene *scene_of(fo_ctx *ctx) {
@@ -106,37 +111,55 @@ __device__ __forceinline__ void wave_min_hit(double &t, int &id) {
   }
 }
 
-// one lane's share of the occluder soup: segments first + lane, first + lane + stride, ...  Static edges come from
-// the [E][4] table (a wave reads 2 KB contiguous per step, L2 resident); obstacle o contributes its four sides with
-// id E + o when it is present and occludes (bicycles do not, Q10), derived from the corner points on the fly.
-__device__ __forceinline__ void scan_soup(int E, const double *__restrict__ edges, int O, const double *__restrict__ ocorn,
-                                          const uint8_t *__restrict__ oflags, int first, int stride, double ox, double oy,
-                                          double dx, double dy, int skip_id, double &best, int &best_id) {
-  // static edges, four per lane in flight (the loop is bound by L2 latency, not by arithmetic)
-  int gi = first;
-  for (; gi + 3 * stride < E; gi += 4 * stride) {
-    double sg[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double *p = edges + 4 * (size_t)(gi + u * stride);
-      sg[u][0] = p[0]; sg[u][1] = p[1]; sg[u][2] = p[2]; sg[u][3] = p[3];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int id = gi + u * stride;
-      const double t = ray_segment(ox, oy, dx, dy, sg[u][0], sg[u][1], sg[u][2], sg[u][3]);
-      if (t < best || (t == best && id < best_id)) { best = t; best_id = id; }
+// A wave's share of the occluder soup.  Static pieces come in chunks of 64 consecutive table entries (a lane each, 2 KB
+// contiguous per chunk, L2 resident); wave w takes chunks [64 w, 64 w + 64), [64 (w + n_waves), ...).  A chunk is skipped
+// -- decided a lane per chunk box, then shared by ballot -- when the box misses the bounding box of the ray segment [o, o + tmax d] or lies
+// entirely on one side of the ray's line; both tests carry a margin far above rounding (1e-7 m), so culling never
+// changes a result, it only saves the reads (the maps are hundreds of metres wide, a ray reaches tens).
+// Obstacle o contributes its four sides with id E + o when it is present and occludes (bicycles do not, Q10).
+// SKIP: eskip[e] != 0 marks boundary pieces that cast no shadow this step (rings of the road union enclosed by the
+// sensor footprint: the reference walks exterior rings of road ∩ footprint only, sensor_model.py:126-131).
+__device__ __forceinline__ bool chunk_culled(const double *__restrict__ box, double ox, double oy, double dx, double dy,
+                                             double tmax) {
+  const double m = 1e-7;
+  const double px = ox + tmax * dx, py = oy + tmax * dy;
+  const double sx0 = fmin(ox, px) - m, sx1 = fmax(ox, px) + m, sy0 = fmin(oy, py) - m, sy1 = fmax(oy, py) + m;
+  const double bx0 = box[0], by0 = box[1], bx1 = box[2], by1 = box[3];
+  if (bx0 > sx1 || bx1 < sx0 || by0 > sy1 || by1 < sy0) return true;
+  // signed offsets of the four box corners from the ray's line, scaled by |d| (<= 1.5 r for the settle kernel)
+  const double mm = m * (fabs(dx) + fabs(dy)) * 1.0e2;
+  const double c00 = dx * (by0 - oy) - dy * (bx0 - ox), c10 = dx * (by0 - oy) - dy * (bx1 - ox);
+  const double c01 = dx * (by1 - oy) - dy * (bx0 - ox), c11 = dx * (by1 - oy) - dy * (bx1 - ox);
+  if (c00 > mm && c10 > mm && c01 > mm && c11 > mm) return true;
+  if (c00 < -mm && c10 < -mm && c01 < -mm && c11 < -mm) return true;
+  return false;
+}
+
+template <bool SKIP>
+__device__ __forceinline__ void scan_soup(int E, const double *__restrict__ edges, const double *__restrict__ chunk_box,
+                                          const uint8_t *__restrict__ eskip, int O, const double *__restrict__ ocorn,
+                                          const uint8_t *__restrict__ oflags, int wave, int n_waves, int lane, double ox,
+                                          double oy, double dx, double dy, double tmax, int skip_id, double &best,
+                                          int &best_id) {
+  const int nc = (E + 63) >> 6;
+  for (int cb = wave * 64; cb < nc; cb += n_waves * 64) {
+    // a lane per chunk box: one round trip culls 64 chunks; the survivors are then scanned a lane per piece
+    const int cc = cb + lane;
+    unsigned long long live = __ballot(cc < nc && !chunk_culled(chunk_box + 4 * (size_t)(cc < nc ? cc : 0), ox, oy, dx, dy, tmax));
+    while (live) {
+      const int c = cb + __builtin_ctzll(live);
+      live &= live - 1;
+      const int gi = (c << 6) + lane;
+      if (gi >= E) continue;
+      if (SKIP && eskip[gi]) continue;
+      const double *p = edges + 4 * (size_t)gi;
+      const double t = ray_segment(ox, oy, dx, dy, p[0], p[1], p[2], p[3]);
+      if (t < best || (t == best && gi < best_id)) { best = t; best_id = gi; }
     }
   }
-  for (; gi < E; gi += stride) {
-    const double *p = edges + 4 * (size_t)gi;
-    const double t = ray_segment(ox, oy, dx, dy, p[0], p[1], p[2], p[3]);
-    if (t < best || (t == best && gi < best_id)) { best = t; best_id = gi; }
-  }
-  // obstacle sides (gi continues the same interleaving over [E, E + 4 O))
-  const int total = E + 4 * O;
-  for (; gi < total; gi += stride) {
-    const int o = (gi - E) >> 2, sd = (gi - E) & 3, s2 = (sd + 1) & 3;
+  // obstacle sides, interleaved over the whole workgroup
+  for (int k = wave * 64 + lane; k < 4 * O; k += 64 * n_waves) {
+    const int o = k >> 2, sd = k & 3, s2 = (sd + 1) & 3;
     if (!((oflags[o] & 1) && (oflags[o] & 2)) || E + o == skip_id) continue;
     const double *c = ocorn + 8 * (size_t)o;
     const int id = E + o;
@@ -170,6 +193,48 @@ __device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full,
   return fan_search(n_rays, dirs, m, last, rx, ry);
 }
 
+// ------------------------------------------------------------------------------------------------ ray fan
+// Directions and footprint ranges of the fan about the ego heading, written where the ray and cell kernels read them
+// (no host trigonometry, no per-step upload).  Full circle: angle_i = yaw + 2 pi i / n; open fan: n rays from
+// yaw - fov/2 to yaw + fov/2 inclusive (sensor_model.py:115-124).  rmax: range of the reference's polygonal footprint
+// along the ray -- regular 64-gon with a vertex at world angle 0 (Point.buffer(r)) or the 100-point fan of
+// _calc_relevant_sector (:201-209): r cos(d/2) / cos(rel mod d - d/2) with d the angular pitch of the arc points.
+__global__ void fo_fan_kernel(int n, double yaw, double fov, int full, double r, int polygon,
+                              double *__restrict__ dirs, double *__restrict__ rmax, double *__restrict__ half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double two_pi = 6.283185307179586476925286766559;
+  if (half && i < 100) {  // unit directions of the 100-point half fan (radius 1.5 r) of sensor_model.py:85-87
+    const double a = i == 99 ? yaw + 0.25 * two_pi : yaw - 0.25 * two_pi + 0.5 * two_pi * (double)i / 99.0;
+    double sn, cs;
+    sincos(a, &sn, &cs);
+    half[2 * i] = cs;
+    half[2 * i + 1] = sn;
+  }
+  if (i >= n) return;
+  double ang, rel, d;
+  if (full) {
+    ang = yaw + two_pi * (double)i / (double)n;
+    rel = ang;
+    d = two_pi / 64.0;
+  } else {
+    rel = i == n - 1 ? fov : fov * (double)i / (double)(n - 1);
+    ang = yaw - 0.5 * fov + rel;
+    d = fov / 99.0;
+  }
+  double sn, cs;
+  sincos(ang, &sn, &cs);
+  dirs[2 * i] = cs;
+  dirs[2 * i + 1] = sn;
+  if (rmax) {
+    double v = r;
+    if (polygon) {
+      const double m = rel - d * floor(rel / d);
+      v = r * cos(0.5 * d) / cos(m - 0.5 * d);
+    }
+    rmax[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ rays + probes
 // One launch for the ray fan and the obstacle-visibility probes.  Workgroups [0, n_rays): one ray each, its five
 // waves scan interleaved fifths of the soup and the (t, id) minima are combined through LDS.  Workgroups
@@ -177,30 +242,38 @@ __device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full,
 // restated) against the soup with the obstacle itself left out; a visible probe sets vis32[o], which the cell-grid
 // kernel turns into the byte flag and clears again for the next step.
 constexpr int RAY_WAVES = 5;
-__global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const double *__restrict__ edges, int O,
+constexpr int SETTLE_BLOCKS = 1024;  // grid of the settle kernel (grid-stride over the undecided cells)
+template <bool SKIP>
+__global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const double *__restrict__ edges,
+                                                                 const double *__restrict__ chunk_box,
+                                                                 const uint8_t *__restrict__ eskip, int O,
                                                                  const double *__restrict__ ocorn,
                                                                  const double *__restrict__ ocen,
                                                                  const uint8_t *__restrict__ oflags, double ex, double ey,
                                                                  int n_rays, const double *__restrict__ dirs, double r,
-                                                                 int full, double *__restrict__ range,
+                                                                 const double *__restrict__ rmax, int full,
+                                                                 double *__restrict__ range,
                                                                  int32_t *__restrict__ hit_id, double *__restrict__ ring,
-                                                                 int32_t *__restrict__ vis32) {
+                                                                 int32_t *__restrict__ vis32,
+                                                                 int32_t *__restrict__ n_amb) {
   __shared__ double sh_t[RAY_WAVES];
   __shared__ int sh_id[RAY_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_amb) *n_amb = 0;  // list of undecided cells of this step (grid kernel)
   if ((int)blockIdx.x < n_rays) {
     const int i = blockIdx.x;
     const double dx = dirs[2 * i], dy = dirs[2 * i + 1];
     double best = INFINITY;
     int id = 0x7fffffff;
-    scan_soup(E, edges, O, ocorn, oflags, wave * 64 + lane, 64 * RAY_WAVES, ex, ey, dx, dy, -3, best, id);
+    const double rm = rmax ? rmax[i] : r;  // range of the sensor footprint along this ray
+    scan_soup<SKIP>(E, edges, chunk_box, eskip, O, ocorn, oflags, wave, RAY_WAVES, lane, ex, ey, dx, dy, rm, -3, best, id);
     wave_min_hit(best, id);
     if (lane == 0) { sh_t[wave] = best; sh_id[wave] = id; }
     __syncthreads();
     if (threadIdx.x == 0) {
       for (int w = 1; w < RAY_WAVES; ++w)
         if (sh_t[w] < best || (sh_t[w] == best && sh_id[w] < id)) { best = sh_t[w]; id = sh_id[w]; }
-      if (!(best <= r)) { best = r; id = -1; }
+      if (!(best <= rm)) { best = rm; id = -1; }
       range[i] = best;
       hit_id[i] = id;
       if (ring) {
@@ -227,7 +300,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
   const double dx = rx / dist, dy = ry / dist;
   double best = INFINITY;
   int id = 0x7fffffff;
-  scan_soup(E, edges, O, ocorn, oflags, wave * 64 + lane, 64 * RAY_WAVES, ex, ey, dx, dy, E + o, best, id);
+  scan_soup<SKIP>(E, edges, chunk_box, eskip, O, ocorn, oflags, wave, RAY_WAVES, lane, ex, ey, dx, dy, dist, E + o, best, id);
   wave_min_hit(best, id);
   if (lane == 0) sh_t[wave] = best;
   __syncthreads();
@@ -239,13 +312,58 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
   }
 }
 
+// The reference's 1.5 r half disc is the 100-point fan of _calc_relevant_sector (sensor_model.py:85-87,201-209).  A
+// centre in the thin rim between that polygon and the circle (d2 above 0.9994 ro2; the polygon's inscribed radius
+// squared is 0.99975 ro2) is tested against the chord of its sector; half = its 100 unit directions or null.
+__device__ __forceinline__ int in_half_fan(const double *__restrict__ half, double r, double rx, double ry, double d2,
+                                           double ro2) {
+  if (!half || !(d2 > 0.9994 * ro2)) return 1;
+  const int k = fan_search(100, half, 0, 99, rx, ry);
+  if (k < 0) return 1;
+  const double R = 1.5 * r;
+  const double ax = R * half[2 * k], ay = R * half[2 * k + 1];
+  const double bx = R * half[2 * k + 2], by = R * half[2 * k + 3];
+  return ((bx - ax) * (ry - ay) - (by - ay) * (rx - ax)) >= 0.0;
+}
+
+// sensor_model.py:183: the obstacle rectangle grown by 5 mm (mitred corners) is taken out of the visible area.  Inside
+// iff the signed distance to each side is <= 5 mm: cross(e, q - a) against 0.005 |e|, either ring orientation;
+// present, non-bicycle obstacles only.
+__device__ __forceinline__ int in_obstacle_skin(int O, const double *__restrict__ ocorn,
+                                                const uint8_t *__restrict__ oflags, double px, double py) {
+  for (int o = 0; o < O; ++o) {
+    if (!(oflags[o] & 1) || !(oflags[o] & 2)) continue;
+    const double *c = ocorn + 8 * (size_t)o;
+    {  // pure early-out: farther from the rectangle's centre than its grown half diagonal (hd + 0.005 sqrt 2)
+      const double mx = 0.5 * (c[0] + c[4]), my = 0.5 * (c[1] + c[5]);
+      const double hd2 = (c[0] - mx) * (c[0] - mx) + (c[1] - my) * (c[1] - my);
+      const double d2c = (px - mx) * (px - mx) + (py - my) * (py - my);
+      if (d2c > hd2 + 0.0071 * (1.0 + hd2) + 1e-4) continue;
+    }
+    const double area2 = (c[2] - c[0]) * (c[5] - c[1]) - (c[3] - c[1]) * (c[4] - c[0]);
+    const double sg = area2 >= 0.0 ? 1.0 : -1.0;
+    int inside = 1;
+    for (int sd = 0; sd < 4 && inside; ++sd) {
+      const int s2 = (sd + 1) & 3;
+      const double ex = c[2 * s2] - c[2 * sd], ey = c[2 * s2 + 1] - c[2 * sd + 1];
+      const double cr = ex * (py - c[2 * sd + 1]) - ey * (px - c[2 * sd]);
+      if (-(sg * cr) > 0.005 * sqrt(ex * ex + ey * ey)) inside = 0;
+    }
+    if (inside) return 1;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ cell grid
 __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int rny, double rx0, double ry0, double cs,
                                int ix0, int iy0, int nx, int ny, double ex, double ey, double hx, double hy, double r,
                                int full, int n_rays, const double *__restrict__ dirs,
                                const double *__restrict__ range, uint8_t *__restrict__ cls,
                                uint8_t *__restrict__ occ_flag, int32_t *__restrict__ blk, int O,
-                               int32_t *__restrict__ vis32, uint8_t *__restrict__ vis) {
+                               int32_t *__restrict__ vis32, uint8_t *__restrict__ vis, int exact, int E,
+                               const int32_t *__restrict__ hit_id, const double *__restrict__ rmax,
+                               int32_t *__restrict__ amb, int32_t *__restrict__ n_amb,
+                               const double *__restrict__ half, const int32_t *__restrict__ edge_line) {
   __shared__ int wsum[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (vis && idx < O) {  // obstacle-visibility flags of the probe workgroups (previous launch); self-cleaning
@@ -254,37 +372,186 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
   }
   const bool in = idx < nx * ny;
   uint8_t c = 0;
-  if (in) {
-  const int ix = idx % nx, iy = idx / nx;
-  const int wx = ix0 + ix, wy = iy0 + iy;
-  if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny && raster[(size_t)wy * rnx + wx]) c |= 1;
-  const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
-  const double rx = px - ex, ry = py - ey;
-  const double d2 = rx * rx + ry * ry;
+  bool pending = false;
+  int visible = 0;
+  double px = 0.0, py = 0.0, rx = 0.0, ry = 0.0, d2 = 0.0;
   const double r2 = r * r, ro2 = (1.5 * r) * (1.5 * r);
-  int vis = 0;
-  if ((c & 1) && d2 <= r2) {
-    const int i = fan_sector(n_rays, dirs, full, rx, ry);
-    if (rx == 0.0 && ry == 0.0) {
-      vis = 1;
-    } else if (i >= 0) {
-      const int j = (i + 1 == n_rays) ? 0 : i + 1;
-      const double hix = range[i] * dirs[2 * i], hiy = range[i] * dirs[2 * i + 1];
-      const double hjx = range[j] * dirs[2 * j], hjy = range[j] * dirs[2 * j + 1];
-      const double cr = (hjx - hix) * (ry - hiy) - (hjy - hiy) * (rx - hix);
-      vis = cr >= 0.0;
+  if (in) {
+    const int ix = idx % nx, iy = idx / nx;
+    const int wx = ix0 + ix, wy = iy0 + iy;
+    if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny && raster[(size_t)wy * rnx + wx]) c |= 1;
+    px = rx0 + ((double)wx + 0.5) * cs;
+    py = ry0 + ((double)wy + 0.5) * cs;
+    rx = px - ex;
+    ry = py - ey;
+    d2 = rx * rx + ry * ry;
+    if ((c & 1) && d2 <= r2) {
+      const int i = fan_sector(n_rays, dirs, full, rx, ry);
+      if (rx == 0.0 && ry == 0.0) {
+        visible = 1;
+      } else if (i >= 0) {
+        const int j = (i + 1 == n_rays) ? 0 : i + 1;
+        const double hix = range[i] * dirs[2 * i], hiy = range[i] * dirs[2 * i + 1];
+        const double hjx = range[j] * dirs[2 * j], hjy = range[j] * dirs[2 * j + 1];
+        const double cr = (hjx - hix) * (ry - hiy) - (hjy - hiy) * (rx - hix);
+        visible = cr >= 0.0;
+        if (exact) {
+          // the two enclosing rays stop at different occluders (or at an obstacle) and the centre is not nearer than
+          // the shorter of them by more than a cell: the fan cannot decide (at grazing incidence the centre's own
+          // ray may reach well past both); inside the footprint chord the settle kernel does
+          int idi = hit_id[i], idj = hit_id[j];
+          if (edge_line && idi >= 0 && idi < E && idj >= 0 && idj < E) {  // same straight chain = one occluder
+            idi = edge_line[idi];
+            idj = edge_line[idj];
+          }
+          if (idi != idj || idi >= E) {
+            const double lo = range[i] < range[j] ? range[i] : range[j];
+            double lom = lo - cs;
+            if (lom < 0.0) lom = 0.0;
+            if (d2 >= lom * lom) {
+              const double fi = rmax ? rmax[i] : r, fj = rmax ? rmax[j] : r;
+              const double fix = fi * dirs[2 * i], fiy = fi * dirs[2 * i + 1];
+              const double fjx = fj * dirs[2 * j], fjy = fj * dirs[2 * j + 1];
+              const double cf = (fjx - fix) * (ry - fiy) - (fjy - fiy) * (rx - fix);
+              visible = 0;
+              pending = cf >= 0.0;
+            }
+          }
+        }
+      }
     }
   }
-  if (vis) c |= 2;
-  if ((c & 1) && !vis && d2 <= ro2 && (rx * hx + ry * hy) >= 0.0) c |= 4;
-  cls[idx] = c;
-  occ_flag[idx] = (c & 4) ? 1 : 0;
+  if (in) {
+    if (visible) c |= 2;
+    if ((c & 1) && !visible && !pending && d2 <= ro2 && (rx * hx + ry * hy) >= 0.0 &&
+        in_half_fan(half, r, rx, ry, d2, ro2))
+      c |= 4;
+    cls[idx] = c;
+    occ_flag[idx] = (c & 4) ? 1 : 0;
+  }
+  if (exact) {  // append the undecided cells (wave-aggregated; order is irrelevant, each cell is settled on its own)
+    const unsigned long long pb = __ballot(pending);
+    if (pb) {
+      const int lane = threadIdx.x & 63;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(n_amb, __popcll(pb));
+      base = __shfl(base, 0);
+      if (pending) amb[base + __popcll(pb & ((1ull << lane) - 1ull))] = idx;
+    }
   }
   // block count of the occluded cells (first stage of the compaction, saves a launch)
   const unsigned long long b = __ballot(in && (c & 4));
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
   __syncthreads();
   if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ------------------------------------------------------------------------------------------------ settle
+// The cells the fan could not decide, settled by the reference's own rule at the cell centre: the shadow quads
+// [v1, v2, v2 + 100 (v2 - ego), v1 + 100 (v1 - ego)] (helper_functions.py:79-96) and the obstacle occlusion polygons
+// (:133-141) contain a point iff an occluding piece crosses the open segment ego -> point.  A workgroup per cell
+// (grid-stride over the list), its threads share the soup like a ray workgroup; "t < 1" along the unnormalised
+// direction is decided on tn and denom, no division.  Thread 0 writes the class and keeps the per-block counts of
+// the occluded-cell compaction in step.
+template <bool SKIP>
+__global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
+    int E, const double *__restrict__ edges, const double *__restrict__ chunk_box, const uint8_t *__restrict__ eskip,
+    int O, const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags, double rx0, double ry0, double cs, int ix0, int iy0, int nx, double ex,
+    double ey, double hx, double hy, double r, const double *__restrict__ half, const int32_t *__restrict__ amb,
+    const int32_t *__restrict__ n_amb, uint8_t *__restrict__ cls, uint8_t *__restrict__ occ_flag,
+    int32_t *__restrict__ blk, int ny) {
+  if ((int)blockIdx.x >= SETTLE_BLOCKS) {
+    // Workgroups past the cell part: one per obstacle.  sensor_model.py:183 takes the obstacle grown by 5 mm out of
+    // the visible area, so a centre the grid kernel found visible inside that skin loses the bit here (the undecided
+    // cells get the same test below).  The bit is cleared with a 32-bit atomic on the word holding the class byte, so
+    // two obstacles with overlapping skins cannot both count the cell.
+    const int o = blockIdx.x - SETTLE_BLOCKS;
+    if (!((oflags[o] & 1) && (oflags[o] & 2))) return;
+    const double *q = ocorn + 8 * (size_t)o;
+    const double xa = fmin(fmin(q[0], q[2]), fmin(q[4], q[6])) - 0.0072, xb = fmax(fmax(q[0], q[2]), fmax(q[4], q[6])) + 0.0072;
+    const double ya = fmin(fmin(q[1], q[3]), fmin(q[5], q[7])) - 0.0072, yb = fmax(fmax(q[1], q[3]), fmax(q[5], q[7])) + 0.0072;
+    int ixa = (int)floor((xa - rx0) / cs - 0.5) - ix0 - 1, ixb = (int)ceil((xb - rx0) / cs - 0.5) - ix0 + 1;
+    int iya = (int)floor((ya - ry0) / cs - 0.5) - iy0 - 1, iyb = (int)ceil((yb - ry0) / cs - 0.5) - iy0 + 1;
+    ixa = ixa < 0 ? 0 : ixa; iya = iya < 0 ? 0 : iya;
+    ixb = ixb > nx - 1 ? nx - 1 : ixb; iyb = iyb > ny - 1 ? ny - 1 : iyb;
+    if (ixb < ixa || iyb < iya) return;
+    const int w = ixb - ixa + 1, h = iyb - iya + 1;
+    unsigned int *words = (unsigned int *)cls;
+    for (int t = threadIdx.x; t < w * h; t += 64 * RAY_WAVES) {
+      const int ix = ixa + t % w, iy = iya + t / w;
+      const int idx = iy * nx + ix;
+      const int sh = 8 * (idx & 3);
+      if (!((words[idx >> 2] >> sh) & 2u)) continue;
+      const double px = rx0 + ((double)(ix0 + ix) + 0.5) * cs, py = ry0 + ((double)(iy0 + iy) + 0.5) * cs;
+      if (!in_obstacle_skin(1, q, oflags + o, px, py)) continue;
+      const unsigned int old = atomicAnd(&words[idx >> 2], ~(2u << sh));
+      if (!((old >> sh) & 2u)) continue;  // another obstacle's workgroup took it first
+      const double rx = px - ex, ry = py - ey;
+      const double d2 = rx * rx + ry * ry, ro2 = (1.5 * r) * (1.5 * r);
+      if (d2 <= ro2 && (rx * hx + ry * hy) >= 0.0 && in_half_fan(half, r, rx, ry, d2, ro2)) {
+        atomicOr(&words[idx >> 2], 4u << sh);
+        occ_flag[idx] = 1;
+        atomicAdd(&blk[idx >> 8], 1);
+      }
+    }
+    return;
+  }
+  const int n = *n_amb;
+  for (int k = blockIdx.x; k < n; k += SETTLE_BLOCKS) {
+    const int idx = amb[k];
+    const int ix = idx % nx, iy = idx / nx;
+    const int wx = ix0 + ix, wy = iy0 + iy;
+    const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
+    const double rx = px - ex, ry = py - ey;
+    int hit = 0;
+    constexpr int stride = 64 * RAY_WAVES;
+    auto crosses = [&](double ax, double ay, double bx, double by) -> int {
+      const double sx = bx - ax, sy = by - ay;
+      const double denom = rx * sy - ry * sx;
+      if (denom == 0.0) return 0;
+      const double wx_ = ax - ex, wy_ = ay - ey;
+      const double tn = wx_ * sy - wy_ * sx;
+      const double un = wx_ * ry - wy_ * rx;
+      return denom > 0.0 ? (tn >= 0.0 && un >= 0.0 && un <= denom && tn < denom)
+                         : (tn <= 0.0 && un <= 0.0 && un >= denom && tn > denom);
+    };
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nc = (E + 63) >> 6;
+    for (int cb = wave * 64; cb < nc; cb += RAY_WAVES * 64) {  // culled like the ray scan (segment ego -> centre)
+      const int cc = cb + lane;
+      unsigned long long live = __ballot(cc < nc && !chunk_culled(chunk_box + 4 * (size_t)(cc < nc ? cc : 0), ex, ey, rx, ry, 1.0));
+      while (live) {
+        const int c = cb + __builtin_ctzll(live);
+        live &= live - 1;
+        const int gi = (c << 6) + lane;
+        if (gi >= E) continue;
+        if (SKIP && eskip[gi]) continue;
+        const double *p = edges + 4 * (size_t)gi;
+        hit |= crosses(p[0], p[1], p[2], p[3]);
+      }
+    }
+    // a centre within 5 mm of an obstacle is not visible either (sensor_model.py:183): an obstacle per thread
+    for (int o = threadIdx.x; o < O; o += stride) hit |= in_obstacle_skin(1, ocorn + 8 * (size_t)o, oflags + o, px, py);
+    for (int gi = threadIdx.x; gi < 4 * O; gi += stride) {
+      const int o = gi >> 2, sd = gi & 3, s2 = (sd + 1) & 3;
+      if (!((oflags[o] & 1) && (oflags[o] & 2))) continue;
+      const double *c = ocorn + 8 * (size_t)o;
+      hit |= crosses(c[2 * sd], c[2 * sd + 1], c[2 * s2], c[2 * s2 + 1]);
+    }
+    int blocked = __syncthreads_or(hit);
+    if (threadIdx.x == 0) {
+      uint8_t c = 1;
+      if (!blocked) c |= 2;
+      const double d2 = rx * rx + ry * ry;
+      const double ro2 = (1.5 * r) * (1.5 * r);
+      if (blocked && d2 <= ro2 && (rx * hx + ry * hy) >= 0.0 && in_half_fan(half, r, rx, ry, d2, ro2)) c |= 4;
+      cls[idx] = c;
+      if (c & 4) {
+        occ_flag[idx] = 1;
+        atomicAdd(&blk[idx >> 8], 1);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ compaction
@@ -541,6 +808,11 @@ int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
   const size_t nb = (cells + 255) / 256 + 1;
   if ((rc = fo_reserve(ctx, &sc->d_blk, &sc->cap_blk, nb))) return rc;
   if (!sc->d_ncand) FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_ncand, sizeof(int32_t)));
+  if ((rc = fo_reserve(ctx, &sc->d_amb, &sc->cap_amb, cells))) return rc;
+  if (!sc->d_namb) {
+    FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_namb, sizeof(int32_t)));
+    FO_HIP_TRY(ctx, hipMemset(sc->d_namb, 0, sizeof(int32_t)));
+  }
   return FO_OK;
 }
 
@@ -562,7 +834,7 @@ void fo_scene_destroy_(fo_ctx *ctx) {
   Scene *sc = (Scene *)ctx->scene;
   void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_vis32, sc->d_route_first, sc->d_route_count, sc->d_lanelet_raster, sc->d_route_xy,
                   sc->d_route_s, sc->d_flags, sc->d_blk,
-                  sc->d_cand, sc->d_ncand};
+                  sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_edge_line, sc->d_chunk_box};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete sc;
@@ -605,7 +877,8 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
   sc->P = P; sc->E = E; sc->cs = cs;
   sc->R = 0;  // a new raster invalidates the route table
   if (sc->d_lanelet_raster) { (void)hipFree(sc->d_lanelet_raster); sc->d_lanelet_raster = nullptr; }
-  for (void **p : {(void **)&sc->d_edges, (void **)&sc->d_raster, (void **)&sc->d_lane_yaw}) {
+  for (void **p : {(void **)&sc->d_edges, (void **)&sc->d_raster, (void **)&sc->d_lane_yaw, (void **)&sc->d_chunk_box,
+                   (void **)&sc->d_edge_line}) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   }
   int32_t *d_off = nullptr;
@@ -621,6 +894,24 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
   FO_HIP_TRY(ctx, hipMemcpy(d_box, pbox, sizeof(double) * 4 * P, hipMemcpyHostToDevice));
   delete[] pbox;
   if (E > 0) FO_HIP_TRY(ctx, hipMemcpy(sc->d_edges, h_edges, sizeof(double) * 4 * (size_t)E, hipMemcpyHostToDevice));
+  {  // bounding boxes of the 64-piece chunks the scans cull by (tight when the caller's order is spatially coherent)
+    const int nc = (E + 63) / 64;
+    double *cb = new double[4 * (size_t)(nc > 0 ? nc : 1)];
+    for (int c = 0; c < nc; ++c) {
+      double bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+      for (int e = 64 * c; e < E && e < 64 * (c + 1); ++e) {
+        const double *q = h_edges + 4 * (size_t)e;
+        bx0 = fmin(bx0, fmin(q[0], q[2])); bx1 = fmax(bx1, fmax(q[0], q[2]));
+        by0 = fmin(by0, fmin(q[1], q[3])); by1 = fmax(by1, fmax(q[1], q[3]));
+      }
+      cb[4 * c] = bx0; cb[4 * c + 1] = by0; cb[4 * c + 2] = bx1; cb[4 * c + 3] = by1;
+    }
+    hipError_t e1 = hipMalloc((void **)&sc->d_chunk_box, sizeof(double) * 4 * (size_t)(nc > 0 ? nc : 1));
+    if (e1 == hipSuccess && nc > 0)
+      e1 = hipMemcpy(sc->d_chunk_box, cb, sizeof(double) * 4 * (size_t)nc, hipMemcpyHostToDevice);
+    delete[] cb;
+    FO_HIP_TRY(ctx, e1);
+  }
   hipLaunchKernelGGL(fo_raster_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, P, d_off, d_xy, d_box,
                      sc->x0, sc->y0, cs, sc->rnx, sc->rny, sc->d_raster);
   FO_HIP_TRY(ctx, hipGetLastError());
@@ -685,8 +976,36 @@ int fo_scene_copy_raster(fo_ctx *ctx, uint8_t *h_out) {
   return FO_OK;
 }
 
+int fo_scene_set_edge_lines(fo_ctx *ctx, int E, const int32_t *h_line) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_set_edge_lines: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  if (E != sc->E || (E > 0 && !h_line)) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_edge_lines: E must match the map");
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (sc->d_edge_line) { (void)hipFree(sc->d_edge_line); sc->d_edge_line = nullptr; }
+  if (E == 0) return FO_OK;
+  for (int e = 0; e < E; ++e)
+    if (h_line[e] < 0 || h_line[e] >= E) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_edge_lines: label out of [0, E)");
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_edge_line, sizeof(int32_t) * (size_t)E));
+  FO_HIP_TRY(ctx, hipMemcpy(sc->d_edge_line, h_line, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice));
+  return FO_OK;
+}
+
+int fo_scene_fan(fo_ctx *ctx, int n_rays, double ego_yaw, double fov_deg, double r, int polygon_footprint,
+                 double *d_dirs, double *d_rmax, double *d_half, void *stream) {
+  if (!ctx) return FO_E_ARG;
+  if (n_rays < 4 || !d_dirs || !(r > 0) || !(fov_deg > 0))
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_fan: bad arguments");
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int full = fov_deg >= 359.9;
+  hipLaunchKernelGGL(fo_fan_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_rays, ego_yaw,
+                     fov_deg * (3.14159265358979323846 / 180.0), full, r, polygon_footprint, d_dirs, d_rmax, d_half);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  return FO_OK;
+}
+
 int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, double head_y, double r, int full_circle,
-                        int n_rays, const double *d_dirs, int O, const double *d_ocorn, const double *d_ocen,
+                        int exact_cells, int n_rays, const double *d_dirs, const double *d_rmax, const double *d_half,
+                        const uint8_t *d_edge_skip, int O, const double *d_ocorn, const double *d_ocen,
                         const uint8_t *d_oflags, int win_ix0, int win_iy0, int win_nx, int win_ny, double *d_range,
                         int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
                         int32_t *d_n_occ, void *stream) {
@@ -703,16 +1022,35 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
     if ((rc = fo_reserve(ctx, &sc->d_vis32, &sc->cap_vis32, (size_t)O))) return rc;
     FO_HIP_TRY(ctx, hipMemsetAsync(sc->d_vis32, 0, sizeof(int32_t) * sc->cap_vis32, s));
   }
-  hipLaunchKernelGGL(fo_rays_kernel, dim3(n_rays + (probes ? 5 * O : 0)), dim3(64 * RAY_WAVES), 0, s, sc->E, sc->d_edges,
-                     O, d_ocorn, d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, full_circle, d_range, d_hit_id,
-                     d_ring, sc->d_vis32);
   const int cells = win_nx * win_ny;
   if (probes && O > cells) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: more obstacles than window cells");
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
+  const dim3 rgrid(n_rays + (probes ? 5 * O : 0)), rblock(64 * RAY_WAVES);
+  if (d_edge_skip)
+    hipLaunchKernelGGL(fo_rays_kernel<true>, rgrid, rblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O, d_ocorn,
+                       d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
+                       sc->d_vis32, sc->d_namb);
+  else
+    hipLaunchKernelGGL(fo_rays_kernel<false>, rgrid, rblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O, d_ocorn,
+                       d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
+                       sc->d_vis32, sc->d_namb);
   hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->d_raster, sc->rnx, sc->rny, sc->x0,
                      sc->y0, sc->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
                      n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk, probes ? O : 0, sc->d_vis32,
-                     probes ? d_obst_vis : nullptr);
+                     probes ? d_obst_vis : nullptr, exact_cells ? 1 : 0, sc->E, d_hit_id, d_rmax, sc->d_amb,
+                     sc->d_namb, d_half, sc->d_edge_line);
+  if (exact_cells) {
+    if ((uintptr_t)d_cls & 3) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: d_cls must be 4-byte aligned");
+    const dim3 sgrid(SETTLE_BLOCKS + O), sblock(64 * RAY_WAVES);
+    if (d_edge_skip)
+      hipLaunchKernelGGL(fo_settle_kernel<true>, sgrid, sblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O,
+                         d_ocorn, d_oflags, sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
+                         d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny);
+    else
+      hipLaunchKernelGGL(fo_settle_kernel<false>, sgrid, sblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O,
+                         d_ocorn, d_oflags, sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
+                         d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny);
+  }
   FO_HIP_TRY(ctx, hipGetLastError());
   return compact(ctx, sc, sc->d_flags, cells, d_occ_idx, d_n_occ, s);
 }

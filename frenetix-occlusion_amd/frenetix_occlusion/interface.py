@@ -64,7 +64,10 @@ class FOInterface:
                                         sensor_radius=self.sensor_radius, sensor_angle=self.sensor_angle,
                                         visualization=None, debug=self.debug, ctx=self.ctx,
                                         n_rays=int(acc.get("rays", 720)), cell_size=float(acc.get("cell_size", 0.5)),
-                                        device=self.device.index, routes=int((acc.get("spawn") or {}).get("routes", 0)))
+                                        device=self.device.index, routes=int((acc.get("spawn") or {}).get("routes", 0)),
+                                        footprint=str(acc.get("footprint", "polygon")),
+                                        enclosed_holes=str(acc.get("enclosed_holes", "transparent")),
+                                        cell_visibility=str(acc.get("cell_visibility", "exact")))
         self.agent_manager = FOAgentManager(scenario=self.cr_scenario, reference_path=self.ego_reference_path,
                                             config=self.config["agent_manager"], visualization=None,
                                             timestep=self.timestep, dt=self.dt, debug=self.debug,

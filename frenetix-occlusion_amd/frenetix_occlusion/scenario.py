@@ -192,7 +192,8 @@ def union_boundary_edges(polys, eps=1e-4, tol=1e-9):
     """Occluding boundary of the union of the lanelet polygons (sensor_model.py:195-199 takes the union with GEOS and
     then walks its exterior, :131-139).  Every polygon edge is split where other polygons cross or touch it; a piece
     is boundary iff the point `eps` outside of its midpoint lies in no polygon.  Returns [E,4] (ax, ay, bx, by).
-    Interior rings (city blocks enclosed by roads) are kept: they occlude physically."""
+    Interior rings (city blocks enclosed by roads) are part of the list; `boundary_rings` labels them so that the
+    sensor model can treat the ones enclosed by the sensor footprint the way the reference does."""
     polys = [np.asarray(p, dtype=np.float64) for p in polys]
     boxes = np.array([[p[:, 0].min(), p[:, 1].min(), p[:, 0].max(), p[:, 1].max()] for p in polys])
     out = []
@@ -288,18 +289,164 @@ def lane_yaw_raster(lanelets, x0, y0, cs, nx, ny):
     return out
 
 
+def spatial_order(edges, bits=16):
+    """Boundary pieces sorted along a Z-order (Morton) curve of their midpoints: 64 consecutive pieces then cover a
+    small patch of the map, which is what lets the ray and settle kernels skip whole chunks by bounding box.  The
+    order only affects speed and the tie-break between pieces hit at exactly the same range (lower index wins)."""
+    edges = np.asarray(edges, dtype=np.float64).reshape(-1, 4)
+    if len(edges) < 2:
+        return edges
+    mid = 0.5 * (edges[:, :2] + edges[:, 2:])
+    lo, hi = mid.min(axis=0), mid.max(axis=0)
+    span = np.maximum(hi - lo, 1e-9)
+    q = np.minimum(((mid - lo) / span * (2 ** bits - 1)).astype(np.uint64), 2 ** bits - 1)
+
+    def spread(v):
+        v = v & np.uint64(0xFFFF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x33333333)
+        v = (v | (v << np.uint64(1))) & np.uint64(0x55555555)
+        return v
+
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
+    return edges[np.argsort(key, kind="stable")]
+
+
+def _crossings(q, edges):
+    """number of boundary pieces a horizontal ray from q to +x crosses (half-open in y, like the raster rule)"""
+    ay, by = edges[:, 1], edges[:, 3]
+    cond = (ay > q[1]) != (by > q[1])
+    if not cond.any():
+        return 0
+    e = edges[cond]
+    xc = e[:, 0] + (q[1] - e[:, 1]) * (e[:, 2] - e[:, 0]) / (e[:, 3] - e[:, 1])
+    return int(np.count_nonzero(q[0] < xc))
+
+
+def boundary_rings(edges, tol=1e-6):
+    """Groups the boundary pieces into the connected rings of the road union's boundary and tells interior rings
+    (holes) from exterior ones.  Returns (ring [E] int32, is_hole [n_rings] bool).
+
+    Pieces are linked through shared end points (matched within `tol` on four staggered grids, so two points closer
+    than tol / 2 always meet in one of them); a ring is a hole iff an odd number of the other rings enclose it
+    (crossing number of one of its midpoints against the other ring's pieces).  The reference walks
+    `visible_area.exterior` only (sensor_model.py:126-131): a hole of road ∩ footprint casts no shadow there."""
+    E = len(edges)
+    if E == 0:
+        return np.zeros(0, dtype=np.int32), np.zeros(0, dtype=bool)
+    parent = np.arange(E)
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+
+    pts = np.concatenate((edges[:, :2], edges[:, 2:]), axis=0)          # point k belongs to edge k % E
+    for ox in (0.0, 0.5):
+        for oy in (0.0, 0.5):
+            kx = np.floor(pts[:, 0] / tol + ox).astype(np.int64)
+            ky = np.floor(pts[:, 1] / tol + oy).astype(np.int64)
+            order = np.lexsort((ky, kx))
+            same = (kx[order][1:] == kx[order][:-1]) & (ky[order][1:] == ky[order][:-1])
+            for i in np.nonzero(same)[0]:
+                a, b = find(order[i] % E), find(order[i + 1] % E)
+                if a != b:
+                    parent[b] = a
+    roots = np.array([find(i) for i in range(E)])
+    uniq, ring = np.unique(roots, return_inverse=True)
+    ring = ring.astype(np.int32)
+    n = len(uniq)
+    is_hole = np.zeros(n, dtype=bool)
+    if n > 1:
+        members = [np.nonzero(ring == k)[0] for k in range(n)]
+        boxes = np.array([[min(edges[m, 0].min(), edges[m, 2].min()), min(edges[m, 1].min(), edges[m, 3].min()),
+                           max(edges[m, 0].max(), edges[m, 2].max()), max(edges[m, 1].max(), edges[m, 3].max())]
+                          for m in members])
+        for k in range(n):
+            e = edges[members[k][0]]
+            q = 0.5 * (e[:2] + e[2:])
+            inside = 0
+            for j in range(n):
+                if j == k or q[0] < boxes[j, 0] or q[0] > boxes[j, 2] or q[1] < boxes[j, 1] or q[1] > boxes[j, 3]:
+                    continue
+                inside += _crossings(q, edges[members[j]]) & 1
+            is_hole[k] = (inside & 1) == 1
+    return ring, is_hole
+
+
+def edge_lines(edges, tol=1e-6, sin_tol=1e-9):
+    """Straight-line chains of the boundary pieces: two pieces get the same label when they share an end point that
+    no third piece touches and one continues the other in a straight line (|sin| of the angle between them <=
+    sin_tol).  Lanelet bounds are sampled polylines, so a straight kerb is dozens of collinear pieces; two rays that
+    stop on the same chain see one occluder, and the chord between their hit points lies on it."""
+    E = len(edges)
+    parent = np.arange(E)
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+
+    if E == 0:
+        return np.zeros(0, dtype=np.int32)
+    pts = np.concatenate((edges[:, :2], edges[:, 2:]), axis=0)          # point k: end (k // E) of edge k % E
+    d = edges[:, 2:] - edges[:, :2]
+    ln = np.maximum(np.hypot(d[:, 0], d[:, 1]), 1e-300)
+    # end points that coincide (rounded to `tol`; a pair split by the rounding only costs a missed merge)
+    key = np.round(pts / tol).astype(np.int64)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    order = np.argsort(inv, kind="stable")
+    starts = np.concatenate(([0], np.cumsum(cnt)[:-1]))
+    two = np.nonzero(cnt == 2)[0]                                       # a free end or a junction stops a chain
+    pa, pb = order[starts[two]], order[starts[two] + 1]
+    a, b = pa % E, pb % E
+    cross = d[a, 0] * d[b, 1] - d[a, 1] * d[b, 0]
+    da = np.where((pa >= E)[:, None], d[a], -d[a])                      # direction pointing INTO the shared point
+    db = np.where((pb >= E)[:, None], -d[b], d[b])                      # direction pointing OUT OF the shared point
+    ok = (a != b) & (np.abs(cross) <= sin_tol * ln[a] * ln[b]) & ((da * db).sum(axis=1) > 0.0)
+    for i, j in zip(a[ok], b[ok]):
+        ri, rj = find(int(i)), find(int(j))
+        if ri != rj:
+            parent[rj] = ri
+    lab = np.array([find(i) for i in range(E)])
+    _, out = np.unique(lab, return_inverse=True)
+    return out.astype(np.int32)
+
+
 @dataclass
 class MapGeometry:
     poly_off: np.ndarray     # int32 [P+1]
     poly_xy: np.ndarray      # [V,2]
     edges: np.ndarray        # [E,4]
+    edge_ring: Optional[np.ndarray] = None   # int32 [E]: connected ring of the union boundary each piece lies on
+    ring_is_hole: Optional[np.ndarray] = None  # bool [n_rings]
+    edge_line: Optional[np.ndarray] = None   # int32 [E]: straight-line chain each piece belongs to (edge_lines)
+
+    def __post_init__(self):
+        e = np.asarray(self.edges, dtype=np.float64).reshape(-1, 4)
+        if self.edge_ring is None or self.ring_is_hole is None:
+            self.edge_ring, self.ring_is_hole = boundary_rings(e)
+        if self.edge_line is None:
+            self.edge_line = edge_lines(e)
 
     @classmethod
     def from_lanelets(cls, lanelets):
         polys = [ll.polygon for ll in lanelets]
         off = np.zeros(len(polys) + 1, dtype=np.int32)
         off[1:] = np.cumsum([len(p) for p in polys])
-        return cls(off, np.concatenate(polys, axis=0), union_boundary_edges(polys))
+        return cls(off, np.concatenate(polys, axis=0), spatial_order(union_boundary_edges(polys)))
+
+    def holes(self):
+        """per interior ring: (ring id, its piece end points [n,2])"""
+        out = []
+        for k in np.nonzero(self.ring_is_hole)[0]:
+            e = self.edges[self.edge_ring == k]
+            out.append((int(k), np.concatenate((e[:, :2], e[:, 2:]), axis=0)))
+        return out
 
 
 # ------------------------------------------------------------------------------------------------ synthetic city

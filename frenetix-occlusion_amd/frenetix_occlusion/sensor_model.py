@@ -32,6 +32,82 @@ def ray_dirs(n_rays, ego_yaw=0.0, fov_deg=360.0):
     return np.stack((np.cos(ang), np.sin(ang)), -1)
 
 
+def footprint_ranges(n_rays, ego_yaw, fov_deg, r):
+    """Range of the reference's sensor footprint along each ray of ``ray_dirs``.  The footprint is a polygon
+    inscribed in the circle: ``Point(ego).buffer(r)`` = regular 64-gon with a vertex at world angle 0
+    (sensor_model.py:121-122; shapely's default of 16 segments per quarter circle [ext]) for a full-circle sensor,
+    else ego + 100 arc points (``_calc_relevant_sector``, :201-209).  Along direction phi the chord between two
+    neighbouring arc points (angular pitch d) is met at r cos(d/2) / cos((phi - a0) mod d - d/2)."""
+    if fov_deg >= 359.9:
+        d = 2.0 * np.pi / 64.0
+        rel = ego_yaw + 2.0 * np.pi * np.arange(n_rays) / n_rays
+    else:
+        d = np.radians(fov_deg) / 99.0
+        rel = np.linspace(0.0, np.radians(fov_deg), n_rays)
+    m = np.mod(rel, d)
+    return r * np.cos(0.5 * d) / np.cos(m - 0.5 * d)
+
+
+def half_fan_dirs(ego_yaw):
+    """unit directions of the 100-point half fan about the heading; times 1.5 r they are the arc points of the polygon
+    that bounds the reference's occluded area (sensor_model.py:85-87, 201-209)"""
+    ang = np.linspace(ego_yaw - 0.5 * np.pi, ego_yaw + 0.5 * np.pi, 100)
+    return np.stack((np.cos(ang), np.sin(ang)), -1)
+
+
+def footprint_polygon(ego, yaw, fov_deg, r):
+    """vertices of that polygon [n,2]"""
+    if fov_deg >= 359.9:
+        ang = np.arange(64) * (2.0 * np.pi / 64.0)
+        return np.stack((ego[0] + r * np.cos(ang), ego[1] + r * np.sin(ang)), -1)
+    half = np.radians(fov_deg) / 2.0
+    ang = np.linspace(yaw - half, yaw + half, 100)
+    arc = np.stack((ego[0] + r * np.cos(ang), ego[1] + r * np.sin(ang)), -1)
+    return np.concatenate((np.asarray(ego, dtype=np.float64)[None], arc), axis=0)
+
+
+class HoleIndex:
+    """Interior rings (holes) of the road union's boundary and the per-step test "does the sensor footprint enclose
+    this ring".  An enclosed ring is an interior ring of road ∩ footprint and casts no shadow in the reference, which
+    walks `visible_area.exterior` only (sensor_model.py:126-131); a ring the footprint cuts open lies on the exterior
+    of road ∩ footprint and does."""
+
+    def __init__(self, geo: MapGeometry):
+        self.edge_ring = np.asarray(geo.edge_ring)
+        self.holes = []
+        for k, pts in geo.holes():
+            self.holes.append((k, pts))
+        self.centres = np.array([pts.mean(axis=0) for _, pts in self.holes]).reshape(-1, 2)
+        self.radii = np.array([float(np.sqrt(((pts - pts.mean(axis=0)) ** 2).sum(axis=1).max())) for _, pts in self.holes])
+
+    def enclosed(self, ego_pos, ego_yaw, fov_deg, r, footprint="polygon"):
+        """ids of the enclosed rings (all end points inside the footprint).  Cheap rejection first: the farthest
+        vertex of a ring is at least as far from the ego as the ring's centroid."""
+        if not self.holes:
+            return ()
+        ego = np.asarray(ego_pos, dtype=np.float64)[:2]
+        d = np.hypot(self.centres[:, 0] - ego[0], self.centres[:, 1] - ego[1])
+        cand = np.nonzero((d <= r) & (self.radii <= 2.0 * r))[0]
+        if len(cand) == 0:
+            return ()
+        from .scenario import points_in_polygon
+        full = fov_deg >= 359.9
+        foot = footprint_polygon(ego, ego_yaw, fov_deg, r) if (footprint == "polygon" or not full) else None
+        out = []
+        for i in cand:
+            k, pts = self.holes[i]
+            inside = (np.hypot(pts[:, 0] - ego[0], pts[:, 1] - ego[1]) <= r).all()
+            if inside and foot is not None:
+                inside = points_in_polygon(pts, foot).all()
+            if inside:
+                out.append(k)
+        return tuple(out)
+
+    def edge_skip(self, rings):
+        """byte per boundary piece: 1 = on one of `rings`"""
+        return np.isin(self.edge_ring, np.array(rings, dtype=np.int64)).astype(np.uint8)
+
+
 @dataclass
 class CellWindow:
     """raster window the per-step cell classes live in: window cell (ix, iy) = world raster cell (ix0+ix, iy0+iy)"""
@@ -106,9 +182,21 @@ class VisibleArea:
 
 class SensorModel:
     def __init__(self, lanelet_network, ref_path, sensor_radius=30, sensor_angle=90, debug=True, visualization=None,
-                 ctx: Optional[N.Context] = None, n_rays=720, cell_size=0.5, device=0, routes=0):
+                 ctx: Optional[N.Context] = None, n_rays=720, cell_size=0.5, device=0, routes=0,
+                 footprint="polygon", enclosed_holes="transparent", cell_visibility="exact"):
         """lanelet_network: a :class:`~frenetix_occlusion.scenario.MapGeometry`, a list of
-        :class:`~frenetix_occlusion.scenario.Lanelet`, or an object with ``.lanelets`` (duck-typed CommonRoad)."""
+        :class:`~frenetix_occlusion.scenario.Lanelet`, or an object with ``.lanelets`` (duck-typed CommonRoad).
+
+        footprint: "polygon" = the reference's inscribed polygon (see :func:`footprint_ranges`), "circle" = exact
+        radius.  enclosed_holes: "transparent" = an interior ring of the road union that the footprint encloses casts
+        no shadow (the reference walks exterior rings only, sensor_model.py:126-131), "occlude" = every boundary piece
+        occludes.  cell_visibility: "exact" = cells the ray fan cannot decide (their two enclosing rays stop at
+        different occluders) are settled by the reference's set algebra at the cell centre, "fan" = chord rule only."""
+        if (footprint not in ("polygon", "circle") or enclosed_holes not in ("transparent", "occlude")
+                or cell_visibility not in ("exact", "fan")):
+            raise ValueError("footprint: 'polygon' | 'circle'; enclosed_holes: 'transparent' | 'occlude'; "
+                             "cell_visibility: 'exact' | 'fan'")
+        self.footprint, self.enclosed_holes, self.cell_visibility = footprint, enclosed_holes, cell_visibility
         if not torch.cuda.is_available():
             raise RuntimeError("SensorModel needs a ROCm GPU (no CPU fallback)")
         self.device = torch.device("cuda", int(device))
@@ -143,6 +231,8 @@ class SensorModel:
             lanelets = lanelets_of(net)
             geo = MapGeometry.from_lanelets(lanelets)
         self.map_geometry = geo
+        self.hole_index = HoleIndex(geo)
+        self._skip_key, self._edge_skip = (), None
         margin = 2.0 * self.cell_size
         xy = geo.poly_xy
         cs = self.cell_size
@@ -162,6 +252,9 @@ class SensorModel:
         self.ctx.call("fo_scene_set_map", len(off) - 1, off.ctypes.data, pxy.ctypes.data, len(edges),
                       edges.ctypes.data if len(edges) else None, cs, margin,
                       ly.ctypes.data if ly is not None else None, org.ctypes.data, dims.ctypes.data)
+        if len(edges):
+            line = np.ascontiguousarray(geo.edge_line, dtype=np.int32)
+            self.ctx.call("fo_scene_set_edge_lines", len(edges), line.ctypes.data)
         self.route_table = self.lanelet_raster = None
         if self.routes > 0 and lanelets is not None:
             from .scenario import RouteTable, lanelet_index_raster
@@ -209,32 +302,69 @@ class SensorModel:
                              hit=torch.empty(n, dtype=torch.int32, device=dev),
                              ring=torch.empty((n, 2), dtype=torch.float64, device=dev),
                              ovis=torch.zeros(max(O, 1), dtype=torch.uint8, device=dev),
-                             cls=torch.empty((w.ny, w.nx), dtype=torch.uint8, device=dev),
+                             # whole 32-bit words: the settle kernel clears class bits with word atomics
+                             cls=torch.empty((w.ny * w.nx + 3) // 4 * 4, dtype=torch.uint8,
+                                             device=dev)[:w.ny * w.nx].view(w.ny, w.nx),
                              occ=torch.empty(w.nx * w.ny, dtype=torch.int32, device=dev),
                              n_occ=torch.zeros(1, dtype=torch.int32, device=dev))
             self._buf_key = key
         return self._buf
 
-    def launch(self, ego_pos, ego_orientation, dirs=None):
+    def fan(self, ego_orientation):
+        """(dirs [n_rays,2], rmax [n_rays] or None, half [100,2] or None): the ray fan about ``ego_orientation``, the
+        footprint range along each ray and the half fan that bounds the occluded area, written by the device
+        (``fo_scene_fan``) into buffers owned by this object -- valid until the next call.  :func:`ray_dirs`,
+        :func:`footprint_ranges` and :func:`half_fan_dirs` are the host statement of the same definitions."""
+        if getattr(self, "_fan_buf", None) is None:
+            self._fan_buf = (torch.empty((self.n_rays, 2), dtype=torch.float64, device=self.device),
+                             torch.empty(self.n_rays, dtype=torch.float64, device=self.device),
+                             torch.empty((100, 2), dtype=torch.float64, device=self.device))
+        dirs, rmax, half = self._fan_buf
+        poly = self.footprint == "polygon"
+        self.ctx.call("fo_scene_fan", self.n_rays, float(ego_orientation), self.sensor_angle, self.sensor_radius,
+                      1 if poly else 0, dirs.data_ptr(), rmax.data_ptr() if poly else None,
+                      half.data_ptr() if poly else None, torch.cuda.current_stream().cuda_stream)
+        return dirs, (rmax if poly else None), (half if poly else None)
+
+    def enclosed_hole_rings(self, ego_pos, ego_orientation):
+        if self.enclosed_holes != "transparent":
+            return ()
+        return self.hole_index.enclosed(ego_pos, ego_orientation, self.sensor_angle, self.sensor_radius, self.footprint)
+
+    def _edge_skip_for(self, rings):
+        """device byte per boundary piece: 1 = casts no shadow this step; None when nothing is skipped.  Re-uploaded
+        only when the set of enclosed rings changes."""
+        if not rings:
+            return None
+        if rings != self._skip_key:
+            self._edge_skip = torch.as_tensor(self.hole_index.edge_skip(rings)).to(self.device)
+            self._skip_key = rings
+        return self._edge_skip
+
+    def launch(self, ego_pos, ego_orientation, dirs=None, rmax=None, half=None):
         """queue the visibility kernels for one ego pose on the current stream; no host synchronisation.
-        Obstacles are the ones of the last ``upload_obstacles``; ``dirs`` (device [n_rays,2]) defaults to the fan
-        about ``ego_orientation``."""
+        Obstacles are the ones of the last ``upload_obstacles``; ``dirs`` / ``rmax`` / ``half`` (device tensors, see
+        :meth:`fan`) default to the fan about ``ego_orientation``."""
         self.ego_pos = np.asarray(ego_pos, dtype=np.float64)
         self.ego_orientation = float(ego_orientation)
         full = self.sensor_angle >= 359.9
         if dirs is None:
-            dirs = torch.as_tensor(ray_dirs(self.n_rays, self.ego_orientation, self.sensor_angle)).to(self.device)
+            dirs, rmax, half = self.fan(self.ego_orientation)
+        skip = self._edge_skip_for(self.enclosed_hole_rings(self.ego_pos, self.ego_orientation))
         d_corn, d_cen, d_flags, O = getattr(self, "_obst", (None, None, None, 0))
         w = self._window_for(self.ego_pos)
         b = self._buffers(w, O)
         p = lambda t: t.data_ptr() if t is not None else None
         hx, hy = math.cos(self.ego_orientation), math.sin(self.ego_orientation)
         self.ctx.call("fo_scene_visibility", float(self.ego_pos[0]), float(self.ego_pos[1]), hx, hy,
-                      self.sensor_radius, 1 if full else 0, self.n_rays, p(dirs), O, p(d_corn), p(d_cen), p(d_flags),
+                      self.sensor_radius, 1 if full else 0, 1 if self.cell_visibility == "exact" else 0, self.n_rays,
+                      p(dirs), p(rmax), p(half), p(skip), O, p(d_corn),
+                      p(d_cen), p(d_flags),
                       w.ix0, w.iy0, w.nx, w.ny, p(b["rng"]), p(b["hit"]), p(b["ring"]), p(b["ovis"]), p(b["cls"]),
                       p(b["occ"]), p(b["n_occ"]), torch.cuda.current_stream().cuda_stream)
         self.window = w
-        self.dirs, self.range, self.hit_id, self.cell_class = dirs, b["rng"], b["hit"], b["cls"]
+        self.dirs, self.rmax, self.half_dirs, self.edge_skip = dirs, rmax, half, skip
+        self.range, self.hit_id, self.cell_class = b["rng"], b["hit"], b["cls"]
         self.occluded_idx_buffer, self.n_occluded = b["occ"], b["n_occ"]
         self.visible_area = VisibleArea(self.ego_pos, b["ring"], b["rng"], b["hit"], b["cls"], w, full, VISIBLE)
         self.occluded_area = VisibleArea(self.ego_pos, b["ring"], b["rng"], b["hit"], b["cls"], w, full, OCCLUDED)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 3
+#define FO_ABI_VERSION 4
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -129,17 +129,46 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
  * off-lane. */
 int fo_scene_set_routes(fo_ctx *ctx, int P, int R, const int32_t *h_first, const int32_t *h_count, int NV,
                         const double *h_xy, const double *h_s, const int32_t *h_lanelet_raster);
+/* One-off, optional, after fo_scene_set_map: HOST int32 [E], label in [0, E) of the straight-line chain each boundary
+ * piece belongs to (pieces that continue one another in a straight line; lanelet bounds are sampled polylines).  Two
+ * rays that stop on the same chain see one occluder, which keeps the exact settlement of fo_scene_visibility to the
+ * cells at real corners and depth discontinuities.  Without it every piece is its own chain. */
+int fo_scene_set_edge_lines(fo_ctx *ctx, int E, const int32_t *h_line);
 int fo_scene_map_info(fo_ctx *ctx, double *x0, double *y0, double *cs, int *nx, int *ny, int *n_edges);
 int fo_scene_copy_raster(fo_ctx *ctx, uint8_t *h_out);
 
+/* Ray fan about the ego heading, written on the device (replaces the angle bookkeeping of
+ * _calc_visible_area_from_lanelet_geometry / _calc_relevant_sector, sensor_model.py:115-124,201-209).
+ * d_dirs [n_rays][2]: full circle (fov_deg >= 359.9) angle_i = yaw + 2 pi i / n, else n rays from yaw - fov/2 to
+ * yaw + fov/2 inclusive.  d_rmax [n_rays] (may be NULL): range of the sensor footprint along each ray; with
+ * polygon_footprint != 0 the reference's inscribed polygon (Point.buffer(r) = regular 64-gon with a vertex at world
+ * angle 0 [ext shapely default], or ego + 100 arc points), else r.  d_half [100][2] (may be NULL): unit directions of
+ * the 100-point half fan about the heading whose radius-1.5 r polygon bounds the occluded area (sensor_model.py:85-93);
+ * fo_scene_visibility takes it as d_half (NULL there = the true half disc). */
+int fo_scene_fan(fo_ctx *ctx, int n_rays, double ego_yaw, double fov_deg, double r, int polygon_footprint,
+                 double *d_dirs, double *d_rmax, double *d_half, void *stream);
+
 /* Per step (replaces SensorModel.calc_visible_and_occluded_area, sensor_model.py:41-101).  d_dirs [n_rays][2] unit
- * ray directions in counter-clockwise order (full_circle: ray n_rays == ray 0); obstacles at this step:
+ * ray directions in counter-clockwise order (full_circle: ray n_rays == ray 0); d_rmax [n_rays] (or NULL = r) range of
+ * the sensor footprint along each ray -- the reference's footprint is a polygon (Point.buffer(r): regular 64-gon,
+ * or the 100-point fan of _calc_relevant_sector, sensor_model.py:118-124,201-209); d_edge_skip [E] (or NULL = none)
+ * marks boundary pieces that cast no shadow this step: rings of the road union enclosed by the footprint are interior
+ * rings of road ∩ footprint and the reference walks exterior rings only (sensor_model.py:126-131).  Obstacles at this step:
  * d_ocorn [O][4][2] corner points (fo_obstacle.py:79-93), d_ocen [O][2], d_oflags [O] (bit0 present, bit1 occludes --
  * clear for bicycles, sensor_model.py:177).  Outputs: d_range/d_hit_id [n_rays], d_ring [n_rays][2] (vertices of the
  * visible polygon = what evaluate_scenario returns), d_obst_vis [O] (visible_objects_timestep), d_cls [ny][nx],
- * d_occ_idx (ascending, capacity nx*ny) + d_n_occ [1]. */
+ * d_occ_idx (ascending, capacity nx*ny) + d_n_occ [1].  d_cls: 4-byte aligned, capacity rounded up to whole 32-bit words
+ * (class bits are cleared with word atomics).
+ * Cell classes: a road cell within r is visible iff its centre lies on the ego side of the chord between the hit points
+ * of the two rays enclosing it.  exact_cells != 0: where those two rays stop at different occluders (or at an
+ * obstacle) and the centre is not nearer than the shorter of the two by more than a cell, the fan cannot decide and
+ * the cell is settled by the reference's own set algebra at the centre -- visible iff inside the footprint and no
+ * occluding piece crosses the open segment ego -> centre (= the centre is in none of the shadow quads of
+ * helper_functions.py:79-96 / occlusion polygons of :133-141); and no visible cell's centre lies within 5 mm of a
+ * present non-bicycle obstacle (the buffered obstacle the reference subtracts, sensor_model.py:183). */
 int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, double head_y, double r, int full_circle,
-                        int n_rays, const double *d_dirs, int O, const double *d_ocorn, const double *d_ocen,
+                        int exact_cells, int n_rays, const double *d_dirs, const double *d_rmax, const double *d_half,
+                        const uint8_t *d_edge_skip, int O, const double *d_ocorn, const double *d_ocen,
                         const uint8_t *d_oflags, int win_ix0, int win_iy0, int win_nx, int win_ny, double *d_range,
                         int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
                         int32_t *d_n_occ, void *stream);

@@ -81,15 +81,29 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
 /* ---- scene half (fo_oracle_scene.c): discretisation defined in DESIGN.md, "parity unpinned" vs the reference ---- */
 int fo_oracle_road_raster(int P, const int32_t *poly_off, const double *poly_xy, double x0, double y0, double cs,
                           int nx, int ny, uint8_t *mask);
-int fo_oracle_raycast(int E, const double *edges, int O, const double *ocorn, const uint8_t *oflags,
-                      const double *ego, int n_rays, const double *dirs, double r, double *range, int32_t *hit_id,
-                      double *ring);
+int fo_oracle_raycast(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
+                      const uint8_t *oflags, const double *ego, int n_rays, const double *dirs, double r,
+                      const double *rmax, double *range, int32_t *hit_id, double *ring);
+/* inputs of the exact settlement of the cells the fan cannot decide (NULL = fan rule only) */
+typedef struct {
+  const int32_t *hit_id; /* [n_rays] from fo_oracle_raycast */
+  const double *rmax;    /* [n_rays] or NULL */
+  int E;
+  const double *edges;
+  const uint8_t *edge_skip; /* or NULL */
+  int O;
+  const double *ocorn;
+  const uint8_t *oflags;
+  const double *half_dirs; /* [100][2] unit directions of the reference's 1.5 r half fan, or NULL = true half disc */
+  const int32_t *edge_line; /* [E] straight-line chain of each boundary piece, or NULL = every piece on its own */
+} fo_oracle_exact_t;
 int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double ry0, double cs, int ix0, int iy0,
                    int nx, int ny, const double *ego, const double *hdir, double r, int full, int n_rays,
-                   const double *dirs, const double *range, uint8_t *cls, int32_t *occ_idx, int32_t *n_occ);
-int fo_oracle_obstacle_visibility(int E, const double *edges, int O, const double *ocorn, const double *ocen,
-                                  const uint8_t *oflags, const double *ego, double r, int full, int n_rays,
-                                  const double *dirs, uint8_t *vis);
+                   const double *dirs, const double *range, uint8_t *cls, int32_t *occ_idx, int32_t *n_occ,
+                   const fo_oracle_exact_t *exact, int32_t *n_exact);
+int fo_oracle_obstacle_visibility(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
+                                  const double *ocen, const uint8_t *oflags, const double *ego, double r, int full,
+                                  int n_rays, const double *dirs, uint8_t *vis);
 int fo_oracle_spawn_cells(const uint8_t *cls, int nx, int ny, double rx0, double ry0, double cs, int ix0, int iy0,
                           const double *ego, const double *hdir, double min_ahead, double max_dist, int max_agents,
                           int all_occluded, int32_t *cell, double *pos, int32_t *n_out, int32_t *n_cand_out);

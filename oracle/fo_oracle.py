@@ -175,37 +175,72 @@ def road_raster(poly_off, poly_xy, x0, y0, cs, nx, ny):
     return mask
 
 
-def raycast(edges, ocorn, oflags, ego, dirs, r):
+def _opt(a, typ, conv):
+    return _p(conv(a), typ) if a is not None else None
+
+
+def raycast(edges, ocorn, oflags, ego, dirs, r, rmax=None, edge_skip=None):
     edges, ocorn, oflags = _f64(edges).reshape(-1, 4), _f64(ocorn).reshape(-1, 8), _u8(oflags)
     ego, dirs = _f64(ego), _f64(dirs)
     n = dirs.shape[0]
     rng, hid, ring = np.zeros(n), np.zeros(n, dtype=np.int32), np.zeros((n, 2))
-    lib().fo_oracle_raycast(C.c_int(edges.shape[0]), _p(edges), C.c_int(ocorn.shape[0]), _p(ocorn),
-                            _p(oflags, C.c_uint8), _p(ego), C.c_int(n), _p(dirs), C.c_double(r), _p(rng),
-                            _p(hid, C.c_int32), _p(ring))
+    rmax = _f64(rmax) if rmax is not None else None
+    edge_skip = _u8(edge_skip) if edge_skip is not None else None
+    lib().fo_oracle_raycast(C.c_int(edges.shape[0]), _p(edges), _opt(edge_skip, C.c_uint8, _u8),
+                            C.c_int(ocorn.shape[0]), _p(ocorn), _p(oflags, C.c_uint8), _p(ego), C.c_int(n), _p(dirs),
+                            C.c_double(r), _opt(rmax, C.c_double, _f64), _p(rng), _p(hid, C.c_int32), _p(ring))
     return rng, hid, ring
 
 
-def grid(raster, rx0, ry0, cs, ix0, iy0, nx, ny, ego, hdir, r, full, dirs, rng):
+class _Exact(C.Structure):
+    _fields_ = [("hit_id", C.c_void_p), ("rmax", C.c_void_p), ("E", C.c_int), ("edges", C.c_void_p),
+                ("edge_skip", C.c_void_p), ("O", C.c_int), ("ocorn", C.c_void_p), ("oflags", C.c_void_p),
+                ("half_dirs", C.c_void_p), ("edge_line", C.c_void_p)]
+
+
+def grid(raster, rx0, ry0, cs, ix0, iy0, nx, ny, ego, hdir, r, full, dirs, rng, exact=None, return_n_exact=False):
+    """exact: None (fan rule only) or dict(hit_id=, edges=, ocorn=, oflags=, rmax=None, edge_skip=None,
+    half_dirs=None, edge_line=None)"""
     raster = _u8(raster)
     rny, rnx = raster.shape
     ego, hdir, dirs, rng = _f64(ego), _f64(hdir), _f64(dirs), _f64(rng)
     cls = np.zeros((ny, nx), dtype=np.uint8)
     occ = np.zeros(nx * ny, dtype=np.int32)
-    n_occ = C.c_int32(0)
+    n_occ, n_ex = C.c_int32(0), C.c_int32(0)
+    ex, keep = None, []
+    if exact is not None:
+        hid = _i32(exact["hit_id"])
+        edges = _f64(exact["edges"]).reshape(-1, 4)
+        ocorn = _f64(exact["ocorn"]).reshape(-1, 8)
+        oflags = _u8(exact["oflags"])
+        rmax = _f64(exact["rmax"]) if exact.get("rmax") is not None else None
+        skip = _u8(exact["edge_skip"]) if exact.get("edge_skip") is not None else None
+        half = _f64(exact["half_dirs"]) if exact.get("half_dirs") is not None else None
+        assert half is None or half.shape == (100, 2)
+        line = _i32(exact["edge_line"]) if exact.get("edge_line") is not None else None
+        keep = [hid, edges, ocorn, oflags, rmax, skip, half, line]
+        adr = lambda a: a.ctypes.data if a is not None and a.size else None
+        ex = _Exact(adr(hid), adr(rmax), edges.shape[0], adr(edges), adr(skip), ocorn.shape[0], adr(ocorn), adr(oflags),
+                     adr(half), adr(line))
     lib().fo_oracle_grid(_p(raster, C.c_uint8), C.c_int(rnx), C.c_int(rny), C.c_double(rx0), C.c_double(ry0),
                          C.c_double(cs), C.c_int(ix0), C.c_int(iy0), C.c_int(nx), C.c_int(ny), _p(ego), _p(hdir),
                          C.c_double(r), C.c_int(1 if full else 0), C.c_int(dirs.shape[0]), _p(dirs), _p(rng),
-                         _p(cls, C.c_uint8), _p(occ, C.c_int32), C.byref(n_occ))
+                         _p(cls, C.c_uint8), _p(occ, C.c_int32), C.byref(n_occ),
+                         C.byref(ex) if ex is not None else None, C.byref(n_ex))
+    del keep
+    if return_n_exact:
+        return cls, occ[:n_occ.value].copy(), int(n_ex.value)
     return cls, occ[:n_occ.value].copy()
 
 
-def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs):
+def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs, edge_skip=None):
     edges, ocorn, ocen, oflags = _f64(edges).reshape(-1, 4), _f64(ocorn).reshape(-1, 8), _f64(ocen), _u8(oflags)
     ego, dirs = _f64(ego), _f64(dirs)
     O = ocorn.shape[0]
     vis = np.zeros(O, dtype=np.uint8)
-    lib().fo_oracle_obstacle_visibility(C.c_int(edges.shape[0]), _p(edges), C.c_int(O), _p(ocorn), _p(ocen),
+    edge_skip = _u8(edge_skip) if edge_skip is not None else None
+    lib().fo_oracle_obstacle_visibility(C.c_int(edges.shape[0]), _p(edges), _opt(edge_skip, C.c_uint8, _u8), C.c_int(O),
+                                        _p(ocorn), _p(ocen),
                                         _p(oflags, C.c_uint8), _p(ego), C.c_double(r), C.c_int(1 if full else 0),
                                         C.c_int(dirs.shape[0]), _p(dirs), _p(vis, C.c_uint8))
     return vis

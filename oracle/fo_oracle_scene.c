@@ -74,12 +74,17 @@ static double ray_segment(double ox, double oy, double dx, double dy, double ax,
 }
 
 /* occluder ids: 0..E-1 map boundary edges, E + o for obstacle o (any of its four sides); -1 = nothing within range.
- * skip_obst >= 0 leaves that obstacle out (used by the visibility probes of that obstacle). */
-static void first_hit(int E, const double *edges, int O, const double *ocorn, const uint8_t *oflags, double ox,
-                      double oy, double dx, double dy, double rmax, int skip_obst, double *t_out, int *id_out) {
+ * skip_obst >= 0 leaves that obstacle out (used by the visibility probes of that obstacle).  edge_skip (may be NULL)
+ * marks boundary pieces that cast no shadow this step: rings of the road union that lie entirely inside the sensor
+ * footprint are interior rings of road ∩ footprint, and the reference walks exterior rings only
+ * (sensor_model.py:126-131). */
+static void first_hit(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
+                      const uint8_t *oflags, double ox, double oy, double dx, double dy, double rmax, int skip_obst,
+                      double *t_out, int *id_out) {
   double best = INFINITY;
   int id = -1;
   for (int e = 0; e < E; ++e) {
+    if (edge_skip && edge_skip[e]) continue;
     const double *s = edges + 4 * (size_t)e;
     const double t = ray_segment(ox, oy, dx, dy, s[0], s[1], s[2], s[3]);
     if (t < best) { best = t; id = e; }
@@ -98,15 +103,17 @@ static void first_hit(int E, const double *edges, int O, const double *ocorn, co
   *id_out = id;
 }
 
-/* the polar fan: range[i] = distance to the first occluder along dirs[i] (clamped to r), hit_id[i] as above,
- * ring[i] = ego + range[i] * dirs[i] (vertices of the visible-area polygon handed back by evaluate_scenario) */
-int fo_oracle_raycast(int E, const double *edges, int O, const double *ocorn, const uint8_t *oflags,
-                      const double *ego, int n_rays, const double *dirs, double r, double *range, int32_t *hit_id,
-                      double *ring) {
+/* the polar fan: range[i] = distance to the first occluder along dirs[i] (clamped to the footprint range: rmax[i]
+ * when given -- the sensor footprint is a polygon in the reference, sensor_model.py:118-121 -- else r), hit_id[i] as
+ * above, ring[i] = ego + range[i] * dirs[i] (vertices of the visible-area polygon handed back by evaluate_scenario) */
+int fo_oracle_raycast(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
+                      const uint8_t *oflags, const double *ego, int n_rays, const double *dirs, double r,
+                      const double *rmax, double *range, int32_t *hit_id, double *ring) {
   for (int i = 0; i < n_rays; ++i) {
     double t;
     int id;
-    first_hit(E, edges, O, ocorn, oflags, ego[0], ego[1], dirs[2 * i], dirs[2 * i + 1], r, -1, &t, &id);
+    first_hit(E, edges, edge_skip, O, ocorn, oflags, ego[0], ego[1], dirs[2 * i], dirs[2 * i + 1], rmax ? rmax[i] : r,
+              -1, &t, &id);
     range[i] = t;
     hit_id[i] = id;
     if (ring) {
@@ -147,13 +154,76 @@ static int fan_sector(int n_rays, const double *dirs, int full, double rx, doubl
   return fan_search(n_rays, dirs, m, last, rx, ry);
 }
 
+/* "is there an occluder strictly before the point ego + (rx, ry)": the reference's shadow quads
+ * [v1, v2, v2 + 100 (v2 - ego), v1 + 100 (v1 - ego)] (helper_functions.py:79-96) and obstacle occlusion polygons
+ * (:133-141) contain a point iff the open segment ego -> point crosses the occluding piece.  Same predicate as
+ * ray_segment with the unnormalised direction (rx, ry); "t < 1" is decided on tn and denom without the division. */
+static int blocked_before(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
+                          const uint8_t *oflags, double ox, double oy, double rx, double ry) {
+  for (int e = 0; e < E + 4 * O; ++e) {
+    double ax, ay, bx, by;
+    if (e < E) {
+      if (edge_skip && edge_skip[e]) continue;
+      const double *s = edges + 4 * (size_t)e;
+      ax = s[0]; ay = s[1]; bx = s[2]; by = s[3];
+    } else {
+      const int o = (e - E) >> 2, sd = (e - E) & 3, s2 = (sd + 1) & 3;
+      if (!(oflags[o] & 1) || !(oflags[o] & 2)) continue;
+      const double *c = ocorn + 8 * (size_t)o;
+      ax = c[2 * sd]; ay = c[2 * sd + 1]; bx = c[2 * s2]; by = c[2 * s2 + 1];
+    }
+    const double ex = bx - ax, ey = by - ay;
+    const double denom = rx * ey - ry * ex;
+    if (denom == 0.0) continue;
+    const double wx = ax - ox, wy = ay - oy;
+    const double tn = wx * ey - wy * ex;
+    const double un = wx * ry - wy * rx;
+    const int hit = denom > 0.0 ? (tn >= 0.0 && un >= 0.0 && un <= denom && tn < denom)
+                                : (tn <= 0.0 && un <= 0.0 && un >= denom && tn > denom);
+    if (hit) return 1;
+  }
+  return 0;
+}
+
+/* sensor_model.py:183: `visible_area.difference(obst.current_polygon.buffer(0.005, join_style=2))` -- the obstacle
+ * rectangle grown by 5 mm with mitred (sharp) corners is taken out of the visible area: a point is inside iff its
+ * signed distance to each of the four sides is <= 5 mm.  cross(e, q - a) <= 0.005 |e| per side (corner order of
+ * fo_obstacle / helper_functions.py:99-112, either orientation); present, non-bicycle obstacles only (:177). */
+static int in_obstacle_skin(int O, const double *ocorn, const uint8_t *oflags, double px, double py) {
+  for (int o = 0; o < O; ++o) {
+    if (!(oflags[o] & 1) || !(oflags[o] & 2)) continue;
+    const double *c = ocorn + 8 * (size_t)o;
+    /* orientation of the ring */
+    const double area2 = (c[2] - c[0]) * (c[5] - c[1]) - (c[3] - c[1]) * (c[4] - c[0]);
+    const double sg = area2 >= 0.0 ? 1.0 : -1.0;
+    int inside = 1;
+    for (int sd = 0; sd < 4 && inside; ++sd) {
+      const int s2 = (sd + 1) & 3;
+      const double ex = c[2 * s2] - c[2 * sd], ey = c[2 * s2 + 1] - c[2 * sd + 1];
+      const double cr = ex * (py - c[2 * sd + 1]) - ey * (px - c[2 * sd]); /* > 0: left of the side */
+      /* inside a counter-clockwise ring = left of every side; outside distance = -sg * cr / |e| */
+      if (-(sg * cr) > 0.005 * sqrt(ex * ex + ey * ey)) inside = 0;
+    }
+    if (inside) return 1;
+  }
+  return 0;
+}
+
 /* cell classes: bit0 road, bit1 visible, bit2 occluded.  Window of nx x ny cells whose lower-left world cell is
  * (ix0, iy0) in the raster (rnx x rny, origin rx0, ry0, cell cs).  occ_idx = ascending window indices of the
- * occluded cells. */
+ * occluded cells.
+ *
+ * visible = road, within r, and on the ego side of the chord between the hit points of the two rays enclosing the
+ * cell centre.  With `exact` given, cells the fan cannot decide are settled by the reference's own rule at the cell
+ * centre: where the two enclosing rays stop at different occluders (or at an obstacle) and the centre's distance lies
+ * in [min range - cs, max range + cs], the cell is visible iff the centre lies inside the footprint chord of that
+ * sector and no occluder crosses the open segment ego -> centre (blocked_before); and no visible cell's centre may
+ * lie within 5 mm of an obstacle (in_obstacle_skin). */
 int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double ry0, double cs, int ix0, int iy0,
                    int nx, int ny, const double *ego, const double *hdir, double r, int full, int n_rays,
-                   const double *dirs, const double *range, uint8_t *cls, int32_t *occ_idx, int32_t *n_occ) {
-  int cnt = 0;
+                   const double *dirs, const double *range, uint8_t *cls, int32_t *occ_idx, int32_t *n_occ,
+                   const fo_oracle_exact_t *exact, int32_t *n_exact) {
+  int cnt = 0, n_ex = 0;
   const double r2 = r * r, ro2 = (1.5 * r) * (1.5 * r);
   for (int iy = 0; iy < ny; ++iy) {
     for (int ix = 0; ix < nx; ++ix) {
@@ -175,11 +245,50 @@ int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double r
           /* inside the triangle (ego, h_i, h_j): on the ego side of the chord h_i -> h_j */
           const double cr = (hjx - hix) * (ry - hiy) - (hjy - hiy) * (rx - hix);
           vis = cr >= 0.0;
+          if (exact) {
+            int idi = exact->hit_id[i], idj = exact->hit_id[j];
+            /* two rays stopping on the same straight chain of boundary pieces see one occluder */
+            if (exact->edge_line && idi >= 0 && idi < exact->E && idj >= 0 && idj < exact->E) {
+              idi = exact->edge_line[idi];
+              idj = exact->edge_line[idj];
+            }
+            if (idi != idj || idi >= exact->E) {
+              const double lo = range[i] < range[j] ? range[i] : range[j];
+              double lom = lo - cs;
+              if (lom < 0.0) lom = 0.0;
+              if (d2 >= lom * lom) {
+                const double fi = exact->rmax ? exact->rmax[i] : r, fj = exact->rmax ? exact->rmax[j] : r;
+                const double fix = fi * dirs[2 * i], fiy = fi * dirs[2 * i + 1];
+                const double fjx = fj * dirs[2 * j], fjy = fj * dirs[2 * j + 1];
+                const double cf = (fjx - fix) * (ry - fiy) - (fjy - fiy) * (rx - fix);
+                ++n_ex;
+                vis = cf >= 0.0 && !blocked_before(exact->E, exact->edges, exact->edge_skip, exact->O, exact->ocorn,
+                                                   exact->oflags, ego[0], ego[1], rx, ry);
+              }
+            }
+          }
         }
       }
+      if (vis && exact && in_obstacle_skin(exact->O, exact->ocorn, exact->oflags, px, py)) vis = 0;
       if (vis) c |= 2;
-      /* sensor_model.py:85-93: half disc about the heading, radius 1.5 r, on the road, not visible */
-      if ((c & 1) && !vis && d2 <= ro2 && (rx * hdir[0] + ry * hdir[1]) >= 0.0) c |= 4;
+      /* sensor_model.py:85-93: half disc about the heading, radius 1.5 r, on the road, not visible.  The reference's
+       * half disc is the 100-point fan of _calc_relevant_sector (:201-209): with its unit directions given
+       * (exact->half_dirs), a centre in the thin rim between that polygon and the circle (d2 above 0.9994 ro2; the
+       * polygon's inscribed radius squared is 0.99975 ro2) is tested against the chord of its sector. */
+      if ((c & 1) && !vis && d2 <= ro2 && (rx * hdir[0] + ry * hdir[1]) >= 0.0) {
+        int in_half = 1;
+        if (exact && exact->half_dirs && d2 > 0.9994 * ro2) {
+          const double *hd = exact->half_dirs;
+          const int k = fan_search(100, hd, 0, 99, rx, ry);
+          if (k >= 0) {
+            const double R = 1.5 * r;
+            const double ax = R * hd[2 * k], ay = R * hd[2 * k + 1];
+            const double bx = R * hd[2 * k + 2], by = R * hd[2 * k + 3];
+            in_half = ((bx - ax) * (ry - ay) - (by - ay) * (rx - ax)) >= 0.0;
+          }
+        }
+        if (in_half) c |= 4;
+      }
       cls[(size_t)iy * nx + ix] = c;
       if (c & 4) {
         if (occ_idx) occ_idx[cnt] = iy * nx + ix;
@@ -188,15 +297,16 @@ int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double r
     }
   }
   *n_occ = cnt;
+  if (n_exact) *n_exact = n_ex;
   return 0;
 }
 
 /* obstacle visibility (sensor_model.py:59-76 restated): an obstacle that exists is visible iff one of its five
  * probe points (4 corners + centre) lies within r + 1 cm of the ego, inside the fan, and the first occluder on the
  * way (the obstacle itself excluded) is not nearer than the probe by more than 1 cm. */
-int fo_oracle_obstacle_visibility(int E, const double *edges, int O, const double *ocorn, const double *ocen,
-                                  const uint8_t *oflags, const double *ego, double r, int full, int n_rays,
-                                  const double *dirs, uint8_t *vis) {
+int fo_oracle_obstacle_visibility(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
+                                  const double *ocen, const uint8_t *oflags, const double *ego, double r, int full,
+                                  int n_rays, const double *dirs, uint8_t *vis) {
   for (int o = 0; o < O; ++o) {
     vis[o] = 0;
     if (!(oflags[o] & 1)) continue;
@@ -210,7 +320,7 @@ int fo_oracle_obstacle_visibility(int E, const double *edges, int O, const doubl
       if (fan_sector(n_rays, dirs, full, rx, ry) < 0) continue;
       double t;
       int id;
-      first_hit(E, edges, O, ocorn, oflags, ego[0], ego[1], rx / dist, ry / dist, dist, o, &t, &id);
+      first_hit(E, edges, edge_skip, O, ocorn, oflags, ego[0], ego[1], rx / dist, ry / dist, dist, o, &t, &id);
       if (t >= dist - 0.01) vis[o] = 1;
     }
   }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(native):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fo_hip.h but not exported"
     assert sorted(native.EXPORTS) == declared
-    assert lib.fo_abi_version() == 3
+    assert lib.fo_abi_version() == 4
 
 
 def test_enums_match_header(native):

@@ -51,10 +51,22 @@ def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_r
     assert np.array_equal(sm.road_raster(), raster_ref)
 
     # ray fan
-    dirs = ray_dirs(n_rays, yaw, sensor_angle)
-    assert np.array_equal(dirs, oracle.ray_dirs(n_rays, yaw, sensor_angle))
+    # the fan is written by the device (fo_scene_fan): it must agree with the host statement of its definition to
+    # rounding; the oracle is then fed the very same directions so that everything downstream is bit-comparable
+    assert np.array_equal(ray_dirs(n_rays, yaw, sensor_angle), oracle.ray_dirs(n_rays, yaw, sensor_angle))
+    dirs = sm.dirs.cpu().numpy()
+    np.testing.assert_allclose(dirs, ray_dirs(n_rays, yaw, sensor_angle), rtol=0, atol=1e-15)
     corn, cen, flags = obst.arrays()
-    rng_ref, hid_ref, ring_ref = oracle.raycast(geo.edges, corn, flags, ego[:2], dirs, radius)
+    from frenetix_occlusion.sensor_model import HoleIndex, footprint_ranges
+    rmax = sm.rmax.cpu().numpy()
+    np.testing.assert_allclose(rmax, footprint_ranges(n_rays, yaw, sensor_angle, radius), rtol=0, atol=1e-11)
+    hi = HoleIndex(geo)
+    rings = hi.enclosed(ego[:2], yaw, sensor_angle, radius)
+    skip = hi.edge_skip(rings) if rings else None
+    assert (sm.edge_skip is None) == (skip is None)
+    if skip is not None:
+        assert np.array_equal(sm.edge_skip.cpu().numpy(), skip)
+    rng_ref, hid_ref, ring_ref = oracle.raycast(geo.edges, corn, flags, ego[:2], dirs, radius, rmax=rmax, edge_skip=skip)
     assert np.array_equal(sm.hit_id.cpu().numpy(), hid_ref)
     assert np.array_equal(sm.range.cpu().numpy(), rng_ref)
     assert np.array_equal(sm.visible_area.ring.cpu().numpy(), ring_ref)
@@ -63,14 +75,18 @@ def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_r
     w = sm.window
     full = sensor_angle >= 359.9
     hd = np.array([math.cos(yaw), math.sin(yaw)])
-    cls_ref, occ_ref = oracle.grid(raster_ref, x0, y0, cs, w.ix0, w.iy0, w.nx, w.ny, ego[:2], hd, radius, full, dirs,
-                                   rng_ref)
+    from frenetix_occlusion.sensor_model import half_fan_dirs
+    half = sm.half_dirs.cpu().numpy()
+    np.testing.assert_allclose(half, half_fan_dirs(yaw), rtol=0, atol=1e-15)
+    ex = dict(hit_id=hid_ref, edges=geo.edges, ocorn=corn, oflags=flags, rmax=rmax, edge_skip=skip, half_dirs=half, edge_line=geo.edge_line)
+    cls_ref, occ_ref, n_exact = oracle.grid(raster_ref, x0, y0, cs, w.ix0, w.iy0, w.nx, w.ny, ego[:2], hd, radius, full,
+                                            dirs, rng_ref, exact=ex, return_n_exact=True)
     assert np.array_equal(sm.cell_class.cpu().numpy(), cls_ref)
     assert np.array_equal(sm.occluded_cells().cpu().numpy(), occ_ref)
 
     # obstacle visibility
     if len(flags):
-        vis_ref = oracle.obstacle_visibility(geo.edges, corn, cen, flags, ego[:2], radius, full, dirs)
+        vis_ref = oracle.obstacle_visibility(geo.edges, corn, cen, flags, ego[:2], radius, full, dirs, edge_skip=skip)
         got = np.array([o.current_visible for o in obst], dtype=np.uint8)
         assert np.array_equal(got, vis_ref)
         assert sm.visible_objects_timestep == [o.obstacle_id for o, v in zip(obst, vis_ref) if v]
@@ -108,7 +124,8 @@ def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_r
         np.testing.assert_allclose(b.yaw.cpu().numpy()[:n_ref], yl, rtol=0, atol=1e-12)
         assert np.array_equal(b.v.cpu().numpy()[:n_ref], vl)
         np.testing.assert_allclose(b.cov.cpu().numpy()[:n_ref], cov, rtol=1e-13, atol=0)
-    return dict(n_spawn=n_ref, n_cand=n_cand, n_occ=len(occ_ref), vis_cells=int(((cls_ref & 2) != 0).sum()))
+    return dict(n_spawn=n_ref, n_cand=n_cand, n_occ=len(occ_ref), vis_cells=int(((cls_ref & 2) != 0).sum()),
+                skipped=0 if skip is None else int(skip.sum()), n_exact=n_exact)
 
 
 @pytest.mark.parametrize("timestep", [0, 8, 25, 60])
@@ -120,6 +137,9 @@ def test_scenario1_steps_match_the_oracle(torch_cuda, oracle, timestep):
     ego[1] += 0.7 * timestep * math.sin(ego[2])
     st = _check_step(torch_cuda, oracle, sc, ego, 7.63, timestep)
     assert st["vis_cells"] > 100 and st["n_occ"] > 0
+    assert st["n_exact"] > 20           # cells settled by the exact rule (shadow edges between two rays)
+    if timestep == 0:
+        assert st["skipped"] == 7      # the sliver hole behind the ego lies inside the footprint: no shadow (Q9)
 
 
 @pytest.mark.parametrize("k", [2, 3])
@@ -176,6 +196,37 @@ def test_map_without_obstacles_or_with_everything_absent(torch_cuda, oracle):
     E = len(sm.map_geometry.edges)
     assert (sm.hit_id.cpu().numpy() < E).all() and sm.visible_objects_timestep == [555]
     _check_step(torch_cuda, oracle, sc, sc.ego_initial, 7.63, 0)
+
+
+def test_footprint_and_hole_options(torch_cuda, oracle):
+    """footprint="circle" / enclosed_holes="occlude" restore the exact-radius, every-piece-occludes variant"""
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.sensor_model import SensorModel, ray_dirs
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    sm = SensorModel(sc.lanelets, None, sensor_radius=50.0, sensor_angle=360.0, footprint="circle",
+                     enclosed_holes="occlude", cell_visibility="fan")
+    sm.calc_visible_and_occluded_area(0, ego[:2], float(ego[2]), None)
+    assert sm.rmax is None and sm.edge_skip is None and sm.half_dirs is None
+    dirs = sm.dirs.cpu().numpy()
+    np.testing.assert_allclose(dirs, ray_dirs(720, float(ego[2]), 360.0), rtol=0, atol=1e-15)
+    rng_ref, hid_ref, _ = oracle.raycast(sm.map_geometry.edges, np.zeros((0, 8)), np.zeros(0, np.uint8), ego[:2], dirs, 50.0)
+    assert np.array_equal(sm.range.cpu().numpy(), rng_ref) and np.array_equal(sm.hit_id.cpu().numpy(), hid_ref)
+    w = sm.window
+    (x0, y0), (rnx, rny) = sm.raster_origin, sm.raster_dims
+    raster = oracle.road_raster(sm.map_geometry.poly_off, sm.map_geometry.poly_xy, x0, y0, sm.cell_size, rnx, rny)
+    hd = np.array([math.cos(ego[2]), math.sin(ego[2])])
+    cls_ref, occ_ref = oracle.grid(raster, x0, y0, sm.cell_size, w.ix0, w.iy0, w.nx, w.ny, ego[:2], hd, 50.0, True, dirs,
+                                   rng_ref)
+    assert np.array_equal(sm.cell_class.cpu().numpy(), cls_ref)
+    assert np.array_equal(sm.occluded_cells().cpu().numpy(), occ_ref)
+    # with the reference semantics more of the road behind the ego is visible (the sliver hole no longer blocks it)
+    vis_all = int(((sm.cell_class & 2) != 0).sum().item())
+    sm2 = SensorModel(sc.lanelets, None, sensor_radius=50.0, sensor_angle=360.0)
+    sm2.calc_visible_and_occluded_area(0, ego[:2], float(ego[2]), None)
+    assert int(((sm2.cell_class & 2) != 0).sum().item()) > vis_all + 100
+    with pytest.raises(ValueError):
+        SensorModel(sc.lanelets, None, footprint="square")
 
 
 def test_phantom_vehicle_predictions_follow_lanelet_routes(torch_cuda, oracle):

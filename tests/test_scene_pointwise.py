@@ -1,0 +1,137 @@
+"""The ray-fan / cell discretisation of the scene stage against a pointwise restatement of the reference's polygon set
+algebra (tests/ref_pointwise.py).  The reference's own arithmetic lives in GEOS (absent here), so this is what ties the
+discretisation to the reference's definition of "visible" and "occluded": at every cell centre the two must agree,
+except in cells within the discretisation error (ray pitch, chord sagitta) of a shadow or range boundary.  CPU only
+(oracle + host logic)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from frenetix_occlusion import scenario as S
+from frenetix_occlusion.sensor_model import HoleIndex, footprint_polygon, footprint_ranges, half_fan_dirs, ray_dirs
+
+import ref_pointwise as RP
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _classes(oracle, sc, ego, yaw, r, fov, timestep, n_rays=720, cs=0.5, exact=True):
+    g = S.MapGeometry.from_lanelets(sc.lanelets)
+    corn, cen, flags, _ = sc.obstacle_arrays(timestep)
+    xy = g.poly_xy
+    x0 = math.floor((xy[:, 0].min() - 1.0) / cs) * cs
+    y0 = math.floor((xy[:, 1].min() - 1.0) / cs) * cs
+    nx = int(math.ceil((xy[:, 0].max() + 1.0 - x0) / cs))
+    ny = int(math.ceil((xy[:, 1].max() + 1.0 - y0) / cs))
+    raster = oracle.road_raster(g.poly_off, g.poly_xy, x0, y0, cs, nx, ny)
+    dirs = ray_dirs(n_rays, yaw, fov)
+    rmax = footprint_ranges(n_rays, yaw, fov, r)
+    hi = HoleIndex(g)
+    rings = hi.enclosed(ego, yaw, fov, r)
+    skip = hi.edge_skip(rings) if rings else None
+    rng, hid, _ = oracle.raycast(g.edges, corn.reshape(-1, 8), flags, ego, dirs, r, rmax=rmax, edge_skip=skip)
+    hd = np.array([math.cos(yaw), math.sin(yaw)])
+    ex = dict(hit_id=hid, edges=g.edges, ocorn=corn.reshape(-1, 8), oflags=flags, rmax=rmax, edge_skip=skip,
+              half_dirs=half_fan_dirs(yaw), edge_line=g.edge_line) if exact else None
+    cls, _, n_exact = oracle.grid(raster, x0, y0, cs, 0, 0, nx, ny, ego, hd, r, fov >= 359.9, dirs, rng, exact=ex,
+                                  return_n_exact=True)
+    iy, ix = np.mgrid[0:ny, 0:nx]
+    q = np.stack((x0 + (ix.ravel() + 0.5) * cs, y0 + (iy.ravel() + 0.5) * cs), -1)
+    present = (flags & 1) != 0
+    road, vis, occ = RP.classify(q, [ll.polygon for ll in sc.lanelets], g.edges, ego, yaw, r, fov, corn[present],
+                                 [(f & 2) == 0 for f in flags[present]])
+    c = cls.ravel()
+    return dict(q=q, road=road, vis=vis, occ=occ, o_road=(c & 1) != 0, o_vis=(c & 2) != 0, o_occ=(c & 4) != 0,
+                rings=rings, g=g, cs=cs, n_exact=n_exact)
+
+
+CASES = [(1, 0, 360.0, 50.0), (1, 20, 360.0, 50.0), (2, 0, 360.0, 50.0), (3, 0, 360.0, 50.0), (1, 0, 120.0, 40.0),
+         (3, 5, 200.0, 30.0)]
+
+
+@pytest.mark.parametrize("k,timestep,fov,r", CASES)
+def test_cell_classes_equal_the_reference_set_algebra_at_every_cell_centre(oracle, k, timestep, fov, r):
+    """default configuration (polygon footprint, enclosed holes transparent, exact settlement of the cells the fan
+    cannot decide): visible and occluded cells are exactly the cells whose centre the reference's polygons contain"""
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, f"scenario{k}_geometry.npz"))
+    ego = sc.ego_initial
+    s = _classes(oracle, sc, ego[:2], float(ego[2]), r, fov, timestep)
+    assert np.array_equal(s["road"], s["o_road"])                   # same crossing-number rule
+    assert int(s["vis"].sum()) > 300 and int(s["occ"].sum()) > 100
+    assert np.array_equal(s["vis"], s["o_vis"])
+    assert np.array_equal(s["occ"], s["o_occ"])
+    assert 0 < s["n_exact"] < 0.5 * (s["vis"].sum() + s["occ"].sum())   # the fan decides most cells on its own
+
+
+def test_moving_ego_keeps_the_cell_classes_equal_to_the_reference_set_algebra(oracle):
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial.copy()
+    for step in (7, 33, 61):
+        pos = ego[:2] + 0.7 * step * np.array([math.cos(ego[2]), math.sin(ego[2])])
+        s = _classes(oracle, sc, pos, float(ego[2]) + 0.01 * step, 50.0, 360.0, step)
+        assert np.array_equal(s["vis"], s["o_vis"]) and np.array_equal(s["occ"], s["o_occ"]), step
+
+
+@pytest.mark.parametrize("k,timestep,fov,r", CASES[:3])
+def test_fan_rule_alone_differs_only_along_shadow_and_range_boundaries(oracle, k, timestep, fov, r):
+    """cell_visibility = "fan": the chord rule loses the cells a shadow edge between two rays cuts through"""
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, f"scenario{k}_geometry.npz"))
+    ego = sc.ego_initial
+    s = _classes(oracle, sc, ego[:2], float(ego[2]), r, fov, timestep, exact=False)
+    bad_vis, bad_occ = s["vis"] != s["o_vis"], s["occ"] != s["o_occ"]
+    assert 0 < bad_vis.sum() <= 0.03 * s["vis"].sum() and bad_occ.sum() <= 0.03 * s["occ"].sum()
+    q = s["q"]
+    for i in np.nonzero(bad_vis | bad_occ)[0]:
+        reach = 1.5 * s["cs"] + np.hypot(*(q[i] - ego[:2])) * math.radians(fov / 720.0) * 1.5
+        near = np.nonzero((np.abs(q[:, 0] - q[i, 0]) <= reach) & (np.abs(q[:, 1] - q[i, 1]) <= reach))[0]
+        assert (s["vis"][near] != s["vis"][i]).any(), (q[i], "isolated disagreement")
+
+
+def test_scenario1_has_a_hole_the_footprint_encloses_and_it_casts_no_shadow(oracle):
+    """the lanelets behind the scenario-1 ego leave a sliver between them -- an interior ring of the road
+    union, 11-33 m behind the ego.  The reference walks exterior rings only, so the road beyond the sliver stays
+    visible; with every piece occluding, ~190 cells behind the ego would be lost."""
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    s = _classes(oracle, sc, ego[:2], float(ego[2]), 50.0, 360.0, 0)
+    g = s["g"]
+    assert int(g.ring_is_hole.sum()) == 1 and len(s["rings"]) == 1
+    assert np.array_equal(~g.ring_is_hole[g.edge_ring], RP.exterior_edge_mask(g.edges))
+    hole = g.edges[g.ring_is_hole[g.edge_ring]]
+    assert len(hole) == 7 and hole[:, [0, 2]].max() < -11.0 and hole[:, [0, 2]].min() > -33.0
+    # far from the ego the footprint no longer encloses it: it is then part of the exterior of road ∩ footprint
+    hi = HoleIndex(g)
+    assert hi.enclosed(ego[:2] + np.array([35.0, 0.0]), float(ego[2]), 360.0, 50.0) == ()
+    assert hi.enclosed(ego[:2], float(ego[2]), 90.0, 50.0) == ()        # forward fan: the sliver is behind
+
+
+def test_footprint_ranges_trace_the_reference_polygons():
+    for fov, n in ((360.0, 720), (360.0, 97), (120.0, 241), (200.0, 400)):
+        yaw, r = -0.7, 42.0
+        d, rm = ray_dirs(n, yaw, fov), footprint_ranges(n, yaw, fov, r)
+        foot = footprint_polygon(np.zeros(2), yaw, fov, r)
+        inner = slice(1, -1) if fov < 359.9 else slice(None)          # the fan's first / last ray run along its sides
+        assert S.points_in_polygon((d * (rm - 1e-9)[:, None])[inner], foot).all()
+        assert not S.points_in_polygon((d * (rm + 1e-9)[:, None])[inner], foot).any()
+        assert rm.max() <= r + 1e-12 and rm.min() >= r * math.cos(math.pi / 64) - 1e-12
+    # shapely's Point.buffer(r) [ext]: 64 segments, one vertex on the +x axis
+    foot = footprint_polygon(np.array([1.0, 2.0]), 0.3, 360.0, 10.0)
+    assert foot.shape == (64, 2) and np.allclose(foot[0], [11.0, 2.0])
+    assert np.allclose(RP.footprint_polygon(np.array([1.0, 2.0]), 10.0, 0.3, 360.0)[0], foot[0])
+
+
+def test_boundary_rings_of_nested_squares():
+    """ring labelling: a square annulus road has one exterior ring and one hole; an island inside the hole is an
+    exterior ring again (enclosed by two rings)"""
+    def sq(a):
+        return np.array([[-a, -a], [a, -a], [a, a], [-a, a]], float)
+
+    def ring_edges(p):
+        return np.concatenate((p, np.roll(p, -1, axis=0)), axis=1)
+    edges = np.concatenate((ring_edges(sq(10)), ring_edges(sq(6)), ring_edges(sq(2))))
+    ring, hole = S.boundary_rings(edges)
+    assert len(hole) == 3 and [bool(hole[ring[i]]) for i in (0, 4, 8)] == [False, True, False]
+    lab, hole2 = RP.ring_labels(edges)
+    assert [bool(hole2[lab[i]]) for i in (0, 4, 8)] == [False, True, False]
