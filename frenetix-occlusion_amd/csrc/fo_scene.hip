@@ -9,13 +9,17 @@
 // must be bit-identical to the CPU restatement, so only + - * / sqrt and comparisons on float64 are used and no
 // FMA is formed.
 //
-// Kernels (all latency-bound at one ego; launch count matters more than bandwidth here -- nine launches per step):
+// Kernels (all latency-bound at one ego; launch count matters more than bandwidth here -- eleven launches per step):
 //   fo_raster_kernel       one-off: world-aligned road raster (cell centre inside any lanelet polygon)
-//   fo_rays_kernel         ray fan + obstacle-visibility probes in one launch: a workgroup per ray (five waves scan
-//                          interleaved fifths of the occluder soup, lexicographic (t, id) minimum by cross-lane
-//                          shuffles = first hit) and a workgroup per obstacle (one probe per wave)
+//   fo_fan_kernel          ray directions, footprint range per ray, half fan of the occluded area
+//   fo_rays_kernel         ray fan + obstacle-visibility probes in one launch: a workgroup per ray / per probe; the
+//                          boundary pieces come in 64-piece chunks with bounding boxes, culled a lane per box;
+//                          lexicographic (t, id) minimum by cross-lane shuffles = first hit
 //   fo_grid_kernel         one thread per cell: fan sector by binary search on cross products, inside-the-chord test,
-//                          half-disc test -> class bits; also the per-block counts of the occluded-cell compaction
+//                          half-fan test -> class bits; cells the fan cannot decide go to a list; also the per-block
+//                          counts of the occluded-cell compaction
+//   fo_settle_kernel       a workgroup per undecided cell (does an occluder cross the segment ego -> centre) and a
+//                          workgroup per obstacle (5 mm skin)
 //   fo_flag_scan/scatter   deterministic stream compaction (ballot prefix inside a block, scanned block counts)
 //   fo_spawn_flag_kernel   candidate cells (+ block counts), fo_spawn_pick_kernel (evenly spaced pick + heading),
 //                          fo_spawn_predict_kernel (predictions in the sweep's agent layout)

@@ -1188,29 +1188,63 @@ __global__ __launch_bounds__(256) void fo_be_kernel(int M, int Mp, int T, int A,
 }
 
 // fold the per-chunk partials into the cost vector + safety flag (metric.py:50-100, hr.py:101-114, wttc.py:32-42)
-__global__ void fo_reduce_kernel(int M, int Mp, int A, int n_chunks, const double *__restrict__ partial,
-                                 fo_thresholds_t thr, uint32_t mask, const double *__restrict__ be_btn,
-                                 double *__restrict__ cost, uint8_t *__restrict__ safe) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+// 64 trajectories per workgroup, four waves: wave w folds its quarter of the chunk rows (in chunk order), the four
+// partial results meet in LDS and wave 0 folds them in the same order -- ties keep the earliest chunk, exactly like one
+// sequential pass, with a quarter of the dependent-load chain.
+constexpr int RED_WAVES = 4;
+__global__ __launch_bounds__(64 * RED_WAVES) void fo_reduce_kernel(int M, int Mp, int A, int n_chunks,
+                                                                   const double *__restrict__ partial,
+                                                                   fo_thresholds_t thr, uint32_t mask,
+                                                                   const double *__restrict__ be_btn,
+                                                                   double *__restrict__ cost,
+                                                                   uint8_t *__restrict__ safe) {
+  __shared__ double sh[RED_WAVES][NPS + 1][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + lane;
+  const bool live = m < M;
   double max_btn = 0.0;
-  if (be_btn)
-    for (int k = 0; k < A; ++k) max_btn = fmax(max_btn, be_btn[(size_t)k * Mp + m]);
   double min_dce = INFINITY, arg_dce = -1, min_ttc = INFINITY, arg_ttc = -1, min_ttce = INFINITY;
   double max_er = 0, max_or = 0, arg_or = -1, max_eh = 0, max_oh = 0, max_cp = 0, max_hwc = 0, flag = 0;
+  if (live) {
+    if (be_btn)
+      for (int k = wave; k < A; k += RED_WAVES) max_btn = fmax(max_btn, be_btn[(size_t)k * Mp + m]);
+    const int per = (n_chunks + RED_WAVES - 1) / RED_WAVES;
+    const int c0 = wave * per, c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
 #pragma unroll 4
-  for (int c = 0; c < n_chunks; ++c) {
-    const double *p = partial + (size_t)c * NPS * Mp + m;
-    if (p[PS_MIN_DCE * (size_t)Mp] < min_dce) { min_dce = p[PS_MIN_DCE * (size_t)Mp]; arg_dce = p[PS_ARG_DCE * (size_t)Mp]; }
-    if (p[PS_MIN_TTC * (size_t)Mp] < min_ttc) { min_ttc = p[PS_MIN_TTC * (size_t)Mp]; arg_ttc = p[PS_ARG_TTC * (size_t)Mp]; }
-    min_ttce = fmin(min_ttce, p[PS_MIN_TTCE * (size_t)Mp]);
-    max_er = fmax(max_er, p[PS_MAX_ER * (size_t)Mp]);
-    if (p[PS_MAX_OR * (size_t)Mp] > max_or) { max_or = p[PS_MAX_OR * (size_t)Mp]; arg_or = p[PS_ARG_OR * (size_t)Mp]; }
-    max_eh = fmax(max_eh, p[PS_MAX_EH * (size_t)Mp]);
-    max_oh = fmax(max_oh, p[PS_MAX_OH * (size_t)Mp]);
-    max_cp = fmax(max_cp, p[PS_MAX_CP * (size_t)Mp]);
-    max_hwc = fmax(max_hwc, p[PS_MAX_HWC * (size_t)Mp]);
-    flag = fmax(flag, p[PS_DCE_FLAG * (size_t)Mp]);
+    for (int c = c0; c < c1; ++c) {
+      const double *p = partial + (size_t)c * NPS * Mp + m;
+      if (p[PS_MIN_DCE * (size_t)Mp] < min_dce) { min_dce = p[PS_MIN_DCE * (size_t)Mp]; arg_dce = p[PS_ARG_DCE * (size_t)Mp]; }
+      if (p[PS_MIN_TTC * (size_t)Mp] < min_ttc) { min_ttc = p[PS_MIN_TTC * (size_t)Mp]; arg_ttc = p[PS_ARG_TTC * (size_t)Mp]; }
+      min_ttce = fmin(min_ttce, p[PS_MIN_TTCE * (size_t)Mp]);
+      max_er = fmax(max_er, p[PS_MAX_ER * (size_t)Mp]);
+      if (p[PS_MAX_OR * (size_t)Mp] > max_or) { max_or = p[PS_MAX_OR * (size_t)Mp]; arg_or = p[PS_ARG_OR * (size_t)Mp]; }
+      max_eh = fmax(max_eh, p[PS_MAX_EH * (size_t)Mp]);
+      max_oh = fmax(max_oh, p[PS_MAX_OH * (size_t)Mp]);
+      max_cp = fmax(max_cp, p[PS_MAX_CP * (size_t)Mp]);
+      max_hwc = fmax(max_hwc, p[PS_MAX_HWC * (size_t)Mp]);
+      flag = fmax(flag, p[PS_DCE_FLAG * (size_t)Mp]);
+    }
+  }
+  double *q = &sh[wave][0][lane];
+  q[PS_MIN_DCE * 64] = min_dce; q[PS_ARG_DCE * 64] = arg_dce; q[PS_MIN_TTC * 64] = min_ttc; q[PS_ARG_TTC * 64] = arg_ttc;
+  q[PS_MIN_TTCE * 64] = min_ttce; q[PS_MAX_ER * 64] = max_er; q[PS_MAX_OR * 64] = max_or; q[PS_ARG_OR * 64] = arg_or;
+  q[PS_MAX_EH * 64] = max_eh; q[PS_MAX_OH * 64] = max_oh; q[PS_MAX_CP * 64] = max_cp; q[PS_MAX_HWC * 64] = max_hwc;
+  q[PS_DCE_FLAG * 64] = flag; q[NPS * 64] = max_btn;
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  for (int w = 1; w < RED_WAVES; ++w) {
+    const double *p = &sh[w][0][lane];
+    if (p[PS_MIN_DCE * 64] < min_dce) { min_dce = p[PS_MIN_DCE * 64]; arg_dce = p[PS_ARG_DCE * 64]; }
+    if (p[PS_MIN_TTC * 64] < min_ttc) { min_ttc = p[PS_MIN_TTC * 64]; arg_ttc = p[PS_ARG_TTC * 64]; }
+    min_ttce = fmin(min_ttce, p[PS_MIN_TTCE * 64]);
+    max_er = fmax(max_er, p[PS_MAX_ER * 64]);
+    if (p[PS_MAX_OR * 64] > max_or) { max_or = p[PS_MAX_OR * 64]; arg_or = p[PS_ARG_OR * 64]; }
+    max_eh = fmax(max_eh, p[PS_MAX_EH * 64]);
+    max_oh = fmax(max_oh, p[PS_MAX_OH * 64]);
+    max_cp = fmax(max_cp, p[PS_MAX_CP * 64]);
+    max_hwc = fmax(max_hwc, p[PS_MAX_HWC * 64]);
+    flag = fmax(flag, p[PS_DCE_FLAG * 64]);
+    max_btn = fmax(max_btn, p[NPS * 64]);
   }
   bool ok = true;
   if (A > 0) {  // no agents -> ({}, True)  (metric.py:44-45)
@@ -1402,7 +1436,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     FO_HIP_TRY(ctx, hipGetLastError());
     be_btn = ctx->d_be_btn;
   }
-  hipLaunchKernelGGL(fo_reduce_kernel, dim3((M + 63) / 64), dim3(64), 0, s, M, Mp, A, n_chunks, ctx->d_partial,
+  hipLaunchKernelGGL(fo_reduce_kernel, dim3((M + 63) / 64), dim3(64 * RED_WAVES), 0, s, M, Mp, A, n_chunks, ctx->d_partial,
                      ctx->thr, ctx->mask, be_btn, d_cost, d_safe);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;

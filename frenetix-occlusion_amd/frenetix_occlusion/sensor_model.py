@@ -85,9 +85,13 @@ class HoleIndex:
         vertex of a ring is at least as far from the ego as the ring's centroid."""
         if not self.holes:
             return ()
-        ego = np.asarray(ego_pos, dtype=np.float64)[:2]
-        d = np.hypot(self.centres[:, 0] - ego[0], self.centres[:, 1] - ego[1])
-        cand = np.nonzero((d <= r) & (self.radii <= 2.0 * r))[0]
+        ex, ey = float(ego_pos[0]), float(ego_pos[1])
+        dx, dy = self.centres[:, 0] - ex, self.centres[:, 1] - ey
+        near = dx * dx + dy * dy <= r * r
+        if not near.any():                      # the usual case: one comparison per ring, no further work
+            return ()
+        ego = np.array([ex, ey])
+        cand = np.nonzero(near & (self.radii <= 2.0 * r))[0]
         if len(cand) == 0:
             return ()
         from .scenario import points_in_polygon
