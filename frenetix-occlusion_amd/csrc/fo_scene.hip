@@ -280,6 +280,9 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
       if (!(best <= rm)) { best = rm; id = -1; }
       range[i] = best;
       hit_id[i] = id;
+      // a ray that stops at an obstacle has reached a lit point of its boundary: the obstacle touches the visible area
+      // (sensor_model.py:59-76); the probe workgroups below add the obstacles that slip between two rays
+      if (id >= E && vis32) atomicOr(&vis32[id - E], 1);
       if (ring) {
         ring[2 * i] = ex + best * dx;
         ring[2 * i + 1] = ey + best * dy;
@@ -1033,11 +1036,11 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
   if (d_edge_skip)
     hipLaunchKernelGGL(fo_rays_kernel<true>, rgrid, rblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
-                       sc->d_vis32, sc->d_namb);
+                       probes ? sc->d_vis32 : nullptr, sc->d_namb);
   else
     hipLaunchKernelGGL(fo_rays_kernel<false>, rgrid, rblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
-                       sc->d_vis32, sc->d_namb);
+                       probes ? sc->d_vis32 : nullptr, sc->d_namb);
   hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->d_raster, sc->rnx, sc->rny, sc->x0,
                      sc->y0, sc->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
                      n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk, probes ? O : 0, sc->d_vis32,

@@ -103,7 +103,7 @@ int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double r
                    const fo_oracle_exact_t *exact, int32_t *n_exact);
 int fo_oracle_obstacle_visibility(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
                                   const double *ocen, const uint8_t *oflags, const double *ego, double r, int full,
-                                  int n_rays, const double *dirs, uint8_t *vis);
+                                  int n_rays, const double *dirs, const int32_t *hit_id, uint8_t *vis);
 int fo_oracle_spawn_cells(const uint8_t *cls, int nx, int ny, double rx0, double ry0, double cs, int ix0, int iy0,
                           const double *ego, const double *hdir, double min_ahead, double max_dist, int max_agents,
                           int all_occluded, int32_t *cell, double *pos, int32_t *n_out, int32_t *n_cand_out);

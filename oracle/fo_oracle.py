@@ -233,7 +233,7 @@ def grid(raster, rx0, ry0, cs, ix0, iy0, nx, ny, ego, hdir, r, full, dirs, rng, 
     return cls, occ[:n_occ.value].copy()
 
 
-def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs, edge_skip=None):
+def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs, edge_skip=None, hit_id=None):
     edges, ocorn, ocen, oflags = _f64(edges).reshape(-1, 4), _f64(ocorn).reshape(-1, 8), _f64(ocen), _u8(oflags)
     ego, dirs = _f64(ego), _f64(dirs)
     O = ocorn.shape[0]
@@ -242,7 +242,8 @@ def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs, edge_ski
     lib().fo_oracle_obstacle_visibility(C.c_int(edges.shape[0]), _p(edges), _opt(edge_skip, C.c_uint8, _u8), C.c_int(O),
                                         _p(ocorn), _p(ocen),
                                         _p(oflags, C.c_uint8), _p(ego), C.c_double(r), C.c_int(1 if full else 0),
-                                        C.c_int(dirs.shape[0]), _p(dirs), _p(vis, C.c_uint8))
+                                        C.c_int(dirs.shape[0]), _p(dirs),
+                                        _p(_i32(hit_id), C.c_int32) if hit_id is not None else None, _p(vis, C.c_uint8))
     return vis
 
 

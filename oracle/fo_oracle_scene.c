@@ -301,12 +301,13 @@ int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double r
   return 0;
 }
 
-/* obstacle visibility (sensor_model.py:59-76 restated): an obstacle that exists is visible iff one of its five
- * probe points (4 corners + centre) lies within r + 1 cm of the ego, inside the fan, and the first occluder on the
- * way (the obstacle itself excluded) is not nearer than the probe by more than 1 cm. */
+/* obstacle visibility (sensor_model.py:59-76 restated: the obstacle polygon touches the visible area grown by 1 cm):
+ * an obstacle that exists is visible iff a fan ray stops at it, or one of its five probe points (4 corners + centre)
+ * lies within r + 1 cm of the ego, inside the fan, and the first occluder on the way (the obstacle itself excluded) is
+ * not nearer than the probe by more than 1 cm. */
 int fo_oracle_obstacle_visibility(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
                                   const double *ocen, const uint8_t *oflags, const double *ego, double r, int full,
-                                  int n_rays, const double *dirs, uint8_t *vis) {
+                                  int n_rays, const double *dirs, const int32_t *hit_id, uint8_t *vis) {
   for (int o = 0; o < O; ++o) {
     vis[o] = 0;
     if (!(oflags[o] & 1)) continue;
@@ -324,6 +325,10 @@ int fo_oracle_obstacle_visibility(int E, const double *edges, const uint8_t *edg
       if (t >= dist - 0.01) vis[o] = 1;
     }
   }
+  /* a fan ray that stops at an obstacle has reached a lit point of its boundary (hit_id from fo_oracle_raycast) */
+  if (hit_id)
+    for (int i = 0; i < n_rays; ++i)
+      if (hit_id[i] >= E && hit_id[i] < E + O) vis[hit_id[i] - E] = 1;
   return 0;
 }
 

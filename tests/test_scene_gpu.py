@@ -86,7 +86,8 @@ def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_r
 
     # obstacle visibility
     if len(flags):
-        vis_ref = oracle.obstacle_visibility(geo.edges, corn, cen, flags, ego[:2], radius, full, dirs, edge_skip=skip)
+        vis_ref = oracle.obstacle_visibility(geo.edges, corn, cen, flags, ego[:2], radius, full, dirs, edge_skip=skip,
+                                             hit_id=hid_ref)
         got = np.array([o.current_visible for o in obst], dtype=np.uint8)
         assert np.array_equal(got, vis_ref)
         assert sm.visible_objects_timestep == [o.obstacle_id for o, v in zip(obst, vis_ref) if v]
@@ -196,6 +197,27 @@ def test_map_without_obstacles_or_with_everything_absent(torch_cuda, oracle):
     E = len(sm.map_geometry.edges)
     assert (sm.hit_id.cpu().numpy() < E).all() and sm.visible_objects_timestep == [555]
     _check_step(torch_cuda, oracle, sc, sc.ego_initial, 7.63, 0)
+
+
+def test_obstacle_lit_between_its_probe_points_is_visible(torch_cuda, oracle):
+    """corners and centre of a long obstacle hidden behind three blockers, its side lit through the gaps: visible
+    because fan rays stop at it (tests/test_scene_kat.py has the same scene on the oracle alone)"""
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    xs = np.linspace(-5.0, 40.0, 2)
+    room = S.Lanelet(1, np.stack((xs, np.full(2, 15.0)), -1), np.stack((xs, np.full(2, -15.0)), -1))
+    mk = lambda i, x, y, l, w: S.Obstacle(i, "static", "car", l, w, 0, np.array([x, y, 0.0, 0.0]), np.zeros((0, 4)))
+    sc = S.Scenario(0.1, [room], [mk(1, 30, 0, 2.0, 20.0), mk(2, 10, -3.3, 1.0, 1.2), mk(3, 10, 0.0, 1.0, 1.0),
+                                  mk(4, 10, 3.3, 1.0, 1.2)])
+    ego = np.array([0.0, 0.0, 0.0, 5.0])
+    _check_step(torch_cuda, oracle, sc, ego, 5.0, 0)
+    sm = SensorModel(sc.lanelets, None, sensor_radius=50.0, sensor_angle=360.0)
+    ob = FOObstacles(sc.obstacles)
+    ob.update(0)
+    sm.calc_visible_and_occluded_area(0, ego[:2], 0.0, ob)
+    assert sm.visible_objects_timestep == [1, 2, 3, 4]
+    assert len(sm.obstacle_occlusions[1]) > 10          # the rays its side stops
 
 
 def test_footprint_and_hole_options(torch_cuda, oracle):

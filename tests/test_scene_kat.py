@@ -176,6 +176,25 @@ def test_obstacle_visibility_flags(oracle):
     assert list(vis) == [1, 0, 1, 0, 0, 0]
 
 
+def test_obstacle_seen_only_between_its_probe_points(oracle):
+    """a long obstacle whose four corners and centre are all hidden behind three small blockers, but whose side is lit
+    through the gaps between them: no probe point sees it, the fan rays that stop at it do (ref sensor_model.py:59-76:
+    the obstacle polygon touches the visible area)"""
+    g = room(-5, 40, -15, 15)
+    ego = np.array([0.0, 0.0])
+    mk = lambda i, x, y, l, w: S.Obstacle(i, "static", "car", l, w, 0, np.array([x, y, 0.0, 0.0]), np.zeros((0, 4)))
+    obs = [mk(1, 30, 0, 2.0, 20.0), mk(2, 10, -3.3, 1.0, 1.2), mk(3, 10, 0.0, 1.0, 1.0), mk(4, 10, 3.3, 1.0, 1.2)]
+    corn = np.stack([o.corners(o.initial) for o in obs])
+    cen = np.stack([o.initial[:2] for o in obs])
+    flags = np.full(4, 3, dtype=np.uint8)
+    dirs = oracle.ray_dirs(720)
+    E = len(g.edges)
+    _, hid, _ = oracle.raycast(g.edges, corn.reshape(-1, 8), flags, ego, dirs, 50.0)
+    assert (hid == E + 0).sum() > 10                                 # rays at ~10 degrees reach the long side
+    assert list(oracle.obstacle_visibility(g.edges, corn, cen, flags, ego, 50.0, True, dirs)) == [0, 1, 1, 1]
+    assert list(oracle.obstacle_visibility(g.edges, corn, cen, flags, ego, 50.0, True, dirs, hit_id=hid)) == [1, 1, 1, 1]
+
+
 def test_spawn_sampling_takes_evenly_spaced_frontier_cells(oracle):
     main = rect_lanelet(1, -30, 30, -3, 3, n=31)
     arm = S.Lanelet(2, np.stack((np.full(21, 10.0), np.linspace(3, 43, 21)), -1),
