@@ -38,6 +38,7 @@ struct Scene {
   double *d_edges = nullptr;      // [E][4]
   int32_t *d_edge_line = nullptr; // [E] straight-line chain of each piece (optional)
   double *d_chunk_box = nullptr;  // [ceil(E/64)][4] xmin, ymin, xmax, ymax of 64 consecutive pieces
+  double *d_sub_box = nullptr;    // [ceil(E/64)][4][4] the same for the four 16-piece quarters of each chunk
   uint8_t *d_raster = nullptr;    // [rny][rnx]
   double *d_lane_yaw = nullptr;   // [rny][rnx] or null
   // phantom vehicle routes (optional): routes r < R of lanelet p = vertices route_first[p*R+r] .. +route_count[p*R+r]
@@ -190,11 +191,18 @@ __device__ int fan_search(int n_rays, const double *__restrict__ dirs, int a, in
   return lo;
 }
 __device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full, double rx, double ry) {
-  const int m = full ? n_rays / 2 : (n_rays - 1) / 2;
-  const int last = full ? n_rays : n_rays - 1;
+  if (full) {  // thirds: each part spans < pi for every n >= 4 (halves exceed pi by a ray pitch when n is odd)
+    const int a = n_rays / 3, b = (2 * n_rays) / 3;
+    int s = fan_search(n_rays, dirs, 0, a, rx, ry);
+    if (s >= 0) return s;
+    s = fan_search(n_rays, dirs, a, b, rx, ry);
+    if (s >= 0) return s;
+    return fan_search(n_rays, dirs, b, n_rays, rx, ry);
+  }
+  const int m = (n_rays - 1) / 2;
   const int s = fan_search(n_rays, dirs, 0, m, rx, ry);
   if (s >= 0) return s;
-  return fan_search(n_rays, dirs, m, last, rx, ry);
+  return fan_search(n_rays, dirs, m, n_rays - 1, rx, ry);
 }
 
 // ------------------------------------------------------------------------------------------------ ray fan
@@ -561,6 +569,215 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
   }
 }
 
+// Sector of a uniform full fan (ray i at angle 2 pi i / n): a float atan2 proposes the index, the exact predicate of
+// fan_sector (ccw(i) and not ccw(i + 1)) confirms it or moves it by a step -- same answer as the binary search, a
+// fifth of the instructions.
+__device__ __forceinline__ int fan_sector_uniform(int n_rays, const double *__restrict__ dirs, double rx, double ry) {
+  const float ang = atan2f((float)ry, (float)rx);
+  int i = (int)floorf(ang * ((float)n_rays * 0.15915494309189535f));
+  if (i < 0) i += n_rays;
+  if (i >= n_rays) i -= n_rays;
+#pragma unroll 1
+  for (int it = 0; it < 3; ++it) {
+    const int j = i + 1 == n_rays ? 0 : i + 1;
+    const bool a = fan_ccw(n_rays, dirs, i, rx, ry), b = fan_ccw(n_rays, dirs, j, rx, ry);
+    if (a && !b) return i;
+    if (!a) i = i == 0 ? n_rays - 1 : i - 1; else i = j;
+  }
+  return fan_sector(n_rays, dirs, 1, rx, ry);
+}
+
+// ------------------------------------------------------------------------------------------------ future visibility
+// An extension, NOT part of the reference: how much of the currently occluded area a candidate trajectory
+// will come to see.  A workgroup per pose (trajectory m, every t_stride-th sample k): (1) the 64-piece chunks whose box
+// lies within r of the pose are listed in LDS; (2) a thread per ray of a world-aligned full fan walks that list --
+// per-ray box culling, and a wave whose rays all miss a chunk skips it -- keeping the first hit; (3) shoelace area of
+// the polygon of hit points; (4) the cells of the current occluded set are tested against the fan (chord rule of the
+// cell-grid kernel) and counted.  Ranges never leave LDS.
+constexpr int FV_THREADS = 256;   // = maximum number of rays
+constexpr int FV_BATCH = 48;      // 16-piece quarters staged in LDS at a time (24 KB)
+__global__ __launch_bounds__(FV_THREADS) void fo_future_visibility_kernel(
+    int T, const double *__restrict__ x, const double *__restrict__ y, int t_stride, int K, int n_rays,
+    const double *__restrict__ dirs, double r, int E, const double *__restrict__ edges,
+    const double *__restrict__ sub_box, int O, const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags,
+    const int32_t *__restrict__ occ_idx, const int32_t *__restrict__ n_occ_ptr, double rx0, double ry0, double cs,
+    int ix0, int iy0, int nx, int32_t *__restrict__ revealed, double *__restrict__ area) {
+  __shared__ double s_dir[2 * FV_THREADS];
+  __shared__ double s_rng[FV_THREADS];
+  __shared__ double s_seg[FV_BATCH][64];    // 16 pieces x (ax, ay, bx, by) per staged quarter
+  __shared__ float s_box[FV_BATCH][4];      // their boxes relative to the pose (float, grown by 1 mm)
+  __shared__ int s_ch[FV_BATCH];
+  __shared__ int s_nob;
+  __shared__ double s_ob[64][8];            // corner rows of the obstacles within reach (64 at a time)
+  __shared__ double s_red[FV_THREADS / 64];
+  __shared__ int s_cnt[FV_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.x / K, k = blockIdx.x % K;
+  const double px = x[(size_t)m * T + (size_t)k * t_stride], py = y[(size_t)m * T + (size_t)k * t_stride];
+  if (tid < n_rays) { s_dir[2 * tid] = dirs[2 * tid]; s_dir[2 * tid + 1] = dirs[2 * tid + 1]; }
+  __syncthreads();
+  const bool ray = tid < n_rays;
+  const double dx = ray ? s_dir[2 * tid] : 1.0, dy = ray ? s_dir[2 * tid + 1] : 0.0;
+  double best = INFINITY;
+  // (1) + (2): the 16-piece quarters whose box lies within r of the pose are listed FV_BATCH at a time, staged in LDS
+  // by the whole workgroup (one exposed round trip per batch), and every ray walks the staged list: box culling per
+  // ray, 16 segment tests per surviving quarter, all operands LDS broadcasts
+  const int nq = (E + 15) >> 4;
+  const double rr = r + 1e-7;
+  const size_t n_dbl = 4 * (size_t)E;
+  auto in_reach = [&](int c) {
+    const double *b = sub_box + 4 * (size_t)c;
+    const double ddx = fmax(fmax(b[0] - px, px - b[2]), 0.0), ddy = fmax(fmax(b[1] - py, py - b[3]), 0.0);
+    return ddx * ddx + ddy * ddy <= rr * rr;   // an empty box (inf, -inf) is never in reach
+  };
+  // rank of every quarter in reach (thread-major order): per-thread count, then an exclusive prefix over the workgroup
+  int mine = 0;
+  for (int c = tid; c < nq; c += FV_THREADS) mine += in_reach(c) ? 1 : 0;
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_cnt[wave] = incl;
+  __syncthreads();
+  int offset = incl - mine, n_total = 0;
+  for (int w = 0; w < FV_THREADS / 64; ++w) {
+    if (w < wave) offset += s_cnt[w];
+    n_total += s_cnt[w];
+  }
+  __syncthreads();
+  for (int b0 = 0; b0 < n_total; b0 += FV_BATCH) {
+    int rk = offset;
+    for (int c = tid; c < nq; c += FV_THREADS)
+      if (in_reach(c)) {
+        if (rk >= b0 && rk < b0 + FV_BATCH) s_ch[rk - b0] = c;
+        ++rk;
+      }
+    __syncthreads();
+    const int nch = n_total - b0 < FV_BATCH ? n_total - b0 : FV_BATCH;
+    // stage: four quarters per pass (thread -> quarter tid / 64, double tid % 64), loads back to back
+    for (int base = 0; base < nch; base += 4) {
+      const int slot = base + (tid >> 6);
+      if (slot < nch) {
+        const size_t g = 64 * (size_t)s_ch[slot] + (tid & 63);
+        s_seg[slot][tid & 63] = g < n_dbl ? edges[g] : 0.0;
+        if ((tid & 63) < 4) {  // box relative to the pose, in float, grown by 1 mm (>> float rounding at map scale)
+          const int u = tid & 63;
+          const double v = sub_box[4 * (size_t)s_ch[slot] + u] - ((u & 1) ? py : px);
+          s_box[slot][u] = (float)v + (u < 2 ? -1e-3f : 1e-3f);
+        }
+      }
+    }
+    __syncthreads();
+    if (ray) {
+      // the ray segment [0, r d] against the staged boxes, all in pose-relative float: bounding boxes, then "all four
+      // corners on one side of the ray's line" (1 mm margins; culling is conservative, it never changes a result)
+      const float fdx = (float)dx, fdy = (float)dy, fr = (float)r * 1.000001f;
+      const float ex_ = fr * fdx, ey_ = fr * fdy;
+      const float sx0 = fminf(0.0f, ex_) - 1e-3f, sx1 = fmaxf(0.0f, ex_) + 1e-3f;
+      const float sy0 = fminf(0.0f, ey_) - 1e-3f, sy1 = fmaxf(0.0f, ey_) + 1e-3f;
+      for (int q = 0; q < nch; ++q) {
+        const float bx0 = s_box[q][0], by0 = s_box[q][1], bx1 = s_box[q][2], by1 = s_box[q][3];
+        if (bx0 > sx1 || bx1 < sx0 || by0 > sy1 || by1 < sy0) continue;
+        const float c00 = fdx * by0 - fdy * bx0, c10 = fdx * by0 - fdy * bx1;
+        const float c01 = fdx * by1 - fdy * bx0, c11 = fdx * by1 - fdy * bx1;
+        const float mm = 2e-3f;
+        if ((c00 > mm && c10 > mm && c01 > mm && c11 > mm) || (c00 < -mm && c10 < -mm && c01 < -mm && c11 < -mm)) continue;
+        const int e_first = s_ch[q] << 4;
+        const int cnt = E - e_first < 16 ? E - e_first : 16;
+        const double *buf = s_seg[q];
+        for (int e = 0; e < cnt; ++e) {
+          const double t = ray_segment(px, py, dx, dy, buf[4 * e], buf[4 * e + 1], buf[4 * e + 2], buf[4 * e + 3]);
+          best = t < best ? t : best;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // obstacles within reach: corner rows staged in LDS (256 at a time)
+  for (int base = 0; base < O; base += 64) {
+    __syncthreads();
+    if (tid == 0) s_nob = 0;
+    __syncthreads();
+    const int o = base + tid;
+    if (tid < 64 && o < O && (oflags[o] & 1) && (oflags[o] & 2)) {
+      const double *c = ocorn + 8 * (size_t)o;
+      const double mx = 0.5 * (c[0] + c[4]), my = 0.5 * (c[1] + c[5]);
+      const double hd2 = (c[0] - mx) * (c[0] - mx) + (c[1] - my) * (c[1] - my);
+      const double d2c = (px - mx) * (px - mx) + (py - my) * (py - my);
+      // nearer than r + half diagonal ((r + hd)^2 <= r^2 + r (1 + hd2) + hd2; a pure early-out)
+      if (d2c <= r * r + r * (1.0 + hd2) + hd2 + 1e-6) {
+        const int slot = atomicAdd(&s_nob, 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s_ob[slot][u] = c[u];
+      }
+    }
+    __syncthreads();
+    if (ray) {
+      for (int q = 0; q < s_nob; ++q) {
+        const double *c = s_ob[q];
+        {  // per-ray early-out: the obstacle's circumscribed circle misses the ray segment (margin as for the boxes)
+          const double mx = 0.5 * (c[0] + c[4]) - px, my = 0.5 * (c[1] + c[5]) - py;
+          const double hd2 = (c[0] - px - mx) * (c[0] - px - mx) + (c[1] - py - my) * (c[1] - py - my);
+          const double cr = dx * my - dy * mx, al = dx * mx + dy * my;      // offset from the line, position along it
+          const double lim = hd2 + 1e-6 * (1.0 + hd2);
+          if (cr * cr > lim || (al < 0.0 && al * al > lim) || (al > r && (al - r) * (al - r) > lim)) continue;
+        }
+#pragma unroll
+        for (int sd = 0; sd < 4; ++sd) {
+          const int s2 = (sd + 1) & 3;
+          const double t = ray_segment(px, py, dx, dy, c[2 * sd], c[2 * sd + 1], c[2 * s2], c[2 * s2 + 1]);
+          best = t < best ? t : best;
+        }
+      }
+    }
+  }
+  if (!(best <= r)) best = r;
+  if (ray) s_rng[tid] = best;
+  __syncthreads();
+  // (3) shoelace area of the polygon of hit points: per-thread term, fixed-order tree sum
+  double term = 0.0;
+  if (ray) {
+    const int j = (tid + 1 == n_rays) ? 0 : tid + 1;
+    const double hix = s_rng[tid] * s_dir[2 * tid], hiy = s_rng[tid] * s_dir[2 * tid + 1];
+    const double hjx = s_rng[j] * s_dir[2 * j], hjy = s_rng[j] * s_dir[2 * j + 1];
+    term = hix * hjy - hjx * hiy;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) term += __shfl_xor(term, off);
+  if (lane == 0) s_red[wave] = term;
+  // (4) occluded cells inside the fan
+  const int n_occ = *n_occ_ptr;
+  const double r2 = r * r;
+  int cnt = 0;
+  for (int ci = tid; ci < n_occ; ci += FV_THREADS) {
+    const int idx = occ_idx[ci];
+    const int wx = ix0 + idx % nx, wy = iy0 + idx / nx;
+    const double cx = rx0 + ((double)wx + 0.5) * cs, cy = ry0 + ((double)wy + 0.5) * cs;
+    const double qx = cx - px, qy = cy - py;
+    if (qx * qx + qy * qy > r2) continue;
+    if (qx == 0.0 && qy == 0.0) { ++cnt; continue; }
+    const int i = fan_sector_uniform(n_rays, s_dir, qx, qy);
+    if (i < 0) continue;
+    const int j = (i + 1 == n_rays) ? 0 : i + 1;
+    const double hix = s_rng[i] * s_dir[2 * i], hiy = s_rng[i] * s_dir[2 * i + 1];
+    const double hjx = s_rng[j] * s_dir[2 * j], hjy = s_rng[j] * s_dir[2 * j + 1];
+    if ((hjx - hix) * (qy - hiy) - (hjy - hiy) * (qx - hix) >= 0.0) ++cnt;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (lane == 0) s_cnt[wave] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    double a2 = 0.0;
+    int total = 0;
+    for (int w = 0; w < FV_THREADS / 64; ++w) { a2 += s_red[w]; total += s_cnt[w]; }
+    area[blockIdx.x] = 0.5 * a2;
+    revealed[blockIdx.x] = total;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ compaction
 // flags[n] (+ per-256 block counts from the producing kernel) -> ascending index list + count; two launches, no
 // atomics (deterministic order)
@@ -841,7 +1058,7 @@ void fo_scene_destroy_(fo_ctx *ctx) {
   Scene *sc = (Scene *)ctx->scene;
   void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_vis32, sc->d_route_first, sc->d_route_count, sc->d_lanelet_raster, sc->d_route_xy,
                   sc->d_route_s, sc->d_flags, sc->d_blk,
-                  sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_edge_line, sc->d_chunk_box};
+                  sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_edge_line, sc->d_chunk_box, sc->d_sub_box};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete sc;
@@ -885,7 +1102,7 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
   sc->R = 0;  // a new raster invalidates the route table
   if (sc->d_lanelet_raster) { (void)hipFree(sc->d_lanelet_raster); sc->d_lanelet_raster = nullptr; }
   for (void **p : {(void **)&sc->d_edges, (void **)&sc->d_raster, (void **)&sc->d_lane_yaw, (void **)&sc->d_chunk_box,
-                   (void **)&sc->d_edge_line}) {
+                   (void **)&sc->d_edge_line, (void **)&sc->d_sub_box}) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   }
   int32_t *d_off = nullptr;
@@ -917,6 +1134,21 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
     if (e1 == hipSuccess && nc > 0)
       e1 = hipMemcpy(sc->d_chunk_box, cb, sizeof(double) * 4 * (size_t)nc, hipMemcpyHostToDevice);
     delete[] cb;
+    FO_HIP_TRY(ctx, e1);
+    double *sb = new double[16 * (size_t)(nc > 0 ? nc : 1)];
+    for (int c = 0; c < 4 * nc; ++c) {  // quarter c of the table: pieces [16 c, 16 c + 16); empty quarters get an empty box
+      double bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+      for (int e = 16 * c; e < E && e < 16 * (c + 1); ++e) {
+        const double *q = h_edges + 4 * (size_t)e;
+        bx0 = fmin(bx0, fmin(q[0], q[2])); bx1 = fmax(bx1, fmax(q[0], q[2]));
+        by0 = fmin(by0, fmin(q[1], q[3])); by1 = fmax(by1, fmax(q[1], q[3]));
+      }
+      sb[4 * c] = bx0; sb[4 * c + 1] = by0; sb[4 * c + 2] = bx1; sb[4 * c + 3] = by1;
+    }
+    e1 = hipMalloc((void **)&sc->d_sub_box, sizeof(double) * 16 * (size_t)(nc > 0 ? nc : 1));
+    if (e1 == hipSuccess && nc > 0)
+      e1 = hipMemcpy(sc->d_sub_box, sb, sizeof(double) * 16 * (size_t)nc, hipMemcpyHostToDevice);
+    delete[] sb;
     FO_HIP_TRY(ctx, e1);
   }
   hipLaunchKernelGGL(fo_raster_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, P, d_off, d_xy, d_box,
@@ -1060,6 +1292,25 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
   }
   FO_HIP_TRY(ctx, hipGetLastError());
   return compact(ctx, sc, sc->d_flags, cells, d_occ_idx, d_n_occ, s);
+}
+
+int fo_scene_future_visibility(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, int t_stride, int n_rays,
+                               const double *d_dirs, double r, int O, const double *d_ocorn, const uint8_t *d_oflags,
+                               const int32_t *d_occ_idx, const int32_t *d_n_occ, int win_ix0, int win_iy0, int win_nx,
+                               int32_t *d_revealed, double *d_area, void *stream) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_future_visibility: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  if (M < 0 || T < 1 || !d_x || !d_y || t_stride < 1 || n_rays < 4 || n_rays > FV_THREADS || !d_dirs || !(r > 0) || O < 0 ||
+      (O > 0 && (!d_ocorn || !d_oflags)) || !d_occ_idx || !d_n_occ || win_nx < 1 || !d_revealed || !d_area)
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_future_visibility: bad arguments (4 <= n_rays <= %d)", FV_THREADS);
+  if (M == 0) return FO_OK;
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int K = (T + t_stride - 1) / t_stride;
+  hipLaunchKernelGGL(fo_future_visibility_kernel, dim3((unsigned)((size_t)M * K)), dim3(FV_THREADS), 0, (hipStream_t)stream,
+                     T, d_x, d_y, t_stride, K, n_rays, d_dirs, r, sc->E, sc->d_edges, sc->d_sub_box, O, d_ocorn,
+                     d_oflags, d_occ_idx, d_n_occ, sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, win_nx, d_revealed, d_area);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  return FO_OK;
 }
 
 int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,

@@ -28,7 +28,7 @@ EXPORTS = [
     "fo_abi_version", "fo_create", "fo_destroy", "fo_last_error",
     "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read",
-    "fo_scene_set_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_spawn",
+    "fo_scene_set_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
     "fo_scene_candidate_count",
 ]
 
@@ -89,6 +89,8 @@ def load():
     lib.fo_scene_fan.argtypes = [vp, C.c_int, D, D, D, C.c_int, dp, dp, dp, vp]
     lib.fo_scene_visibility.argtypes = ([vp, D, D, D, D, D, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, C.c_int, dp, dp, dp]
                                         + [C.c_int] * 4 + [dp] * 7 + [vp])
+    lib.fo_scene_future_visibility.argtypes = ([vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, dp, D, C.c_int, dp, dp, ip, ip]
+                                               + [C.c_int] * 3 + [ip, dp, vp])
     lib.fo_scene_spawn.argtypes = ([vp, dp] + [C.c_int] * 4 + [D] * 6 + [C.c_int] * 3 + [ip] + [dp] * 5 + [C.c_int, dp, C.c_int]
                                    + [D] * 3 + [dp] * 12 + [vp])
     lib.fo_scene_candidate_count.argtypes = [vp, ip, vp]

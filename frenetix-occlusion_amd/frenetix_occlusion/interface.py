@@ -140,6 +140,15 @@ class FOInterface:
         remember = trajectories if (mode == "full" and not isinstance(trajectories, dict)) else None
         return self.metrics.evaluate_batch(trajectories, mode=mode, remember=remember)
 
+    def future_visibility_batch(self, trajectories, t_stride=5, n_rays=192):
+        """EXTENSION, not part of the reference: per candidate trajectory and every ``t_stride``-th sample, the number
+        of currently occluded cells the ego would see from there and the visible polygon's area
+        (:meth:`SensorModel.future_visibility`); a planner can turn it into the ``occ_*`` cost terms the reference
+        leaves unused.  Returns device tensors ``(revealed [M,K] int32, area [M,K] float64)``."""
+        from .metrics.metric import trajectories_to_arrays
+        arr = trajectories_to_arrays(trajectories)
+        return self.sensor_model.future_visibility(arr["x"], arr["y"], t_stride=t_stride, n_rays=n_rays)
+
     def _update_time_step(self, timestep):
         self.timestep = timestep
         self.sensor_model.timestep = timestep

@@ -374,6 +374,43 @@ class SensorModel:
         self.occluded_area = VisibleArea(self.ego_pos, b["ring"], b["rng"], b["hit"], b["cls"], w, full, OCCLUDED)
         return self.visible_area
 
+    # ---- extension, not part of the reference
+    def future_visibility(self, x, y, t_stride=5, n_rays=192, radius=None):
+        """How much of the currently occluded area each candidate trajectory will come to see.
+
+        x, y: [M, T] trajectory samples (numpy or device tensors).  From every ``t_stride``-th sample a world-aligned
+        full fan of ``n_rays`` rays (<= 256) of length ``radius`` (default: the sensor radius) is cast against the
+        static map and the obstacles of the last ``upload_obstacles``; returns device tensors
+        ``revealed [M, K]`` (int32: cells of the occluded set of the last ``launch`` that lie inside that fan) and
+        ``area [M, K]`` (float64: area of the polygon of hit points), K = ceil(T / t_stride).  Queued on the current
+        stream, no host synchronisation.  Uses the plain chord rule of the ray fan (no exact settlement, no
+        enclosed-hole or footprint-polygon refinements): it is a cost term, not a reproduction of reference output."""
+        if self.window is None:
+            raise RuntimeError("future_visibility needs the occluded set of a previous launch()")
+        dev = self.device
+        tx = x if torch.is_tensor(x) else torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64))
+        ty = y if torch.is_tensor(y) else torch.as_tensor(np.ascontiguousarray(y, dtype=np.float64))
+        tx, ty = tx.to(dev, torch.float64).contiguous(), ty.to(dev, torch.float64).contiguous()
+        M, T = tx.shape
+        K = (T + t_stride - 1) // t_stride
+        r = float(self.sensor_radius if radius is None else radius)
+        key = int(n_rays)
+        if getattr(self, "_fv_dirs_key", None) != key:
+            self._fv_dirs = torch.empty((key, 2), dtype=torch.float64, device=dev)
+            self.ctx.call("fo_scene_fan", key, 0.0, 360.0, r, 0, self._fv_dirs.data_ptr(), None, None,
+                          torch.cuda.current_stream().cuda_stream)
+            self._fv_dirs_key = key
+        revealed = torch.empty((M, K), dtype=torch.int32, device=dev)
+        area = torch.empty((M, K), dtype=torch.float64, device=dev)
+        d_corn, _, d_flags, O = getattr(self, "_obst", (None, None, None, 0))
+        w = self.window
+        p = lambda t: t.data_ptr() if t is not None else None
+        self.ctx.call("fo_scene_future_visibility", M, T, tx.data_ptr(), ty.data_ptr(), int(t_stride), key,
+                      self._fv_dirs.data_ptr(), r, O, p(d_corn), p(d_flags), self.occluded_idx_buffer.data_ptr(),
+                      self.n_occluded.data_ptr(), w.ix0, w.iy0, w.nx, revealed.data_ptr(), area.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+        return revealed, area
+
     def calc_visible_and_occluded_area(self, timestep, ego_pos, ego_orientation, obstacles):
         """reference entry point.  obstacles: an FOObstacles (already updated to `timestep`) or None."""
         self.timestep = timestep

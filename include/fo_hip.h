@@ -173,6 +173,19 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
                         int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
                         int32_t *d_n_occ, void *stream);
 
+/* EXTENSION, not part of the reference: how much of the currently occluded area each candidate trajectory
+ * will come to see.  d_x / d_y [M][T] as for fo_sweep_run; pose (m, k) = sample k * t_stride, K = ceil(T / t_stride).
+ * From every pose a full fan of n_rays (<= 256) rays of length r along d_dirs [n_rays][2] (world-aligned, counter-
+ * clockwise, e.g. fo_scene_fan with yaw 0) is cast against the static map and the obstacles where they stand now
+ * (d_ocorn / d_oflags as for fo_scene_visibility).  d_revealed [M][K] = number of cells of the current occluded set
+ * (d_occ_idx / d_n_occ and the window of the fo_scene_visibility call that produced them) whose centre lies within r
+ * of the pose and on its side of the chord between the hit points of the two rays enclosing it; d_area [M][K] = area
+ * of the polygon of hit points. */
+int fo_scene_future_visibility(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, int t_stride, int n_rays,
+                               const double *d_dirs, double r, int O, const double *d_ocorn, const uint8_t *d_oflags,
+                               const int32_t *d_occ_idx, const int32_t *d_n_occ, int win_ix0, int win_iy0, int win_nx,
+                               int32_t *d_revealed, double *d_area, void *stream);
+
 /* Phantom sampling in the occluded cells + constant-velocity predictions (replaces the cell-based core of
  * SpawnLocator.find_spawn_points, spawn_locator.py:80-139, and agent.py:451-536).  Candidates: occluded cells at least
  * min_ahead ahead of the ego and within max_dist, on the visible/occluded frontier (all_occluded = 0) or anywhere in

@@ -247,6 +247,25 @@ def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs, edge_ski
     return vis
 
 
+def future_visibility(x, y, t_stride, dirs, r, edges, ocorn, oflags, occ_idx, rx0, ry0, cs, ix0, iy0, nx):
+    """extension: (revealed [M,K] int32, area [M,K]) -- see fo_oracle_scene.c"""
+    x, y, dirs = _f64(x), _f64(y), _f64(dirs)
+    edges, ocorn, oflags = _f64(edges).reshape(-1, 4), _f64(ocorn).reshape(-1, 8), _u8(oflags)
+    occ_idx = _i32(occ_idx)
+    M, T = x.shape
+    K = (T + t_stride - 1) // t_stride
+    rev = np.zeros((M, K), dtype=np.int32)
+    area = np.zeros((M, K))
+    rc = lib().fo_oracle_future_visibility(C.c_int(M), C.c_int(T), _p(x), _p(y), C.c_int(t_stride), C.c_int(dirs.shape[0]),
+                                           _p(dirs), C.c_double(r), C.c_int(edges.shape[0]), _p(edges),
+                                           C.c_int(ocorn.shape[0]), _p(ocorn), _p(oflags, C.c_uint8),
+                                           C.c_int(len(occ_idx)), _p(occ_idx, C.c_int32), C.c_double(rx0),
+                                           C.c_double(ry0), C.c_double(cs), C.c_int(ix0), C.c_int(iy0), C.c_int(nx),
+                                           _p(rev, C.c_int32), _p(area))
+    assert rc == 0
+    return rev, area
+
+
 def spawn_cells(cls, rx0, ry0, cs, ix0, iy0, ego, hdir, min_ahead, max_dist, max_agents, all_occluded=False):
     cls = _u8(cls)
     ny, nx = cls.shape

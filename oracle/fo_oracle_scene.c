@@ -125,8 +125,9 @@ int fo_oracle_raycast(int E, const double *edges, const uint8_t *edge_skip, int 
 }
 
 /* sector of the fan that contains direction (rx, ry): the i with rel in [ray i, ray i+1) counter-clockwise.
- * ccw(i) = d_i x rel > 0, or = 0 with d_i . rel > 0.  The fan is searched in two halves (each spans <= pi, so
- * ccw() is monotone inside a half): full fan -> [0, n/2] and [n/2, n] with ray n == ray 0; open fan -> [0, m] and
+ * ccw(i) = d_i x rel > 0, or = 0 with d_i . rel > 0.  The fan is searched in parts that span < pi (so that ccw()
+ * is monotone inside a part): full fan -> thirds [0, n/3], [n/3, 2n/3], [2n/3, n] with ray n == ray 0 (halves would
+ * exceed pi by a ray pitch when n is odd); open fan -> [0, m] and
  * [m, n-1], m = (n-1)/2.  Returns -1 when rel is outside an open fan (or is the zero vector). */
 static int fan_ccw(int n_rays, const double *dirs, int i, double rx, double ry) {
   const double *d = dirs + 2 * (size_t)(i == n_rays ? 0 : i);
@@ -147,11 +148,18 @@ static int fan_search(int n_rays, const double *dirs, int a, int b, double rx, d
 }
 
 static int fan_sector(int n_rays, const double *dirs, int full, double rx, double ry) {
-  const int m = full ? n_rays / 2 : (n_rays - 1) / 2;
-  const int last = full ? n_rays : n_rays - 1;
-  int s = fan_search(n_rays, dirs, 0, m, rx, ry);
+  if (full) { /* three parts of at most 2 pi / 3 + one ray pitch: ccw() is monotone inside each for every n >= 4 */
+    const int a = n_rays / 3, b = (2 * n_rays) / 3;
+    int s = fan_search(n_rays, dirs, 0, a, rx, ry);
+    if (s >= 0) return s;
+    s = fan_search(n_rays, dirs, a, b, rx, ry);
+    if (s >= 0) return s;
+    return fan_search(n_rays, dirs, b, n_rays, rx, ry);
+  }
+  const int m = (n_rays - 1) / 2;
+  const int s = fan_search(n_rays, dirs, 0, m, rx, ry);
   if (s >= 0) return s;
-  return fan_search(n_rays, dirs, m, last, rx, ry);
+  return fan_search(n_rays, dirs, m, n_rays - 1, rx, ry);
 }
 
 /* "is there an occluder strictly before the point ego + (rx, ry)": the reference's shadow quads
@@ -509,5 +517,59 @@ int fo_oracle_route_predictions(int n, const double *pos0, const int32_t *type, 
       len[slot] = k;
     }
   }
+  return 0;
+}
+
+/* ---------------------------------------------------------------- future visibility (an extension)
+ * NOT part of the reference: how much of the currently occluded area a candidate trajectory will come to see.  For
+ * every trajectory m and every t_stride-th sample k (pose = (x, y)[m][k t_stride]) a world-aligned full fan of n_rays
+ * rays of length r is cast against the static soup (every boundary piece + the occluding obstacles where they stand
+ * now); revealed[m][k] = number of cells of the current occluded set (window indices occ_idx) whose centre lies within
+ * r of the pose and on the pose side of the chord between the hit points of the two rays enclosing it (the fan rule of
+ * fo_oracle_grid); area[m][k] = area of the polygon of hit points (shoelace).  K = (T + t_stride - 1) / t_stride. */
+int fo_oracle_future_visibility(int M, int T, const double *x, const double *y, int t_stride, int n_rays,
+                                const double *dirs, double r, int E, const double *edges, int O, const double *ocorn,
+                                const uint8_t *oflags, int n_occ, const int32_t *occ_idx, double rx0, double ry0,
+                                double cs, int ix0, int iy0, int nx, int32_t *revealed, double *area) {
+  const int K = (T + t_stride - 1) / t_stride;
+  double *rng = (double *)malloc(sizeof(double) * (size_t)n_rays);
+  if (!rng) return -1;
+  const double r2 = r * r;
+  for (int m = 0; m < M; ++m) {
+    for (int k = 0; k < K; ++k) {
+      const double px = x[(size_t)m * T + (size_t)k * t_stride], py = y[(size_t)m * T + (size_t)k * t_stride];
+      for (int i = 0; i < n_rays; ++i) {
+        double t;
+        int id;
+        first_hit(E, edges, NULL, O, ocorn, oflags, px, py, dirs[2 * i], dirs[2 * i + 1], r, -1, &t, &id);
+        rng[i] = t;
+      }
+      double a2 = 0.0;
+      for (int i = 0; i < n_rays; ++i) {
+        const int j = (i + 1 == n_rays) ? 0 : i + 1;
+        const double hix = rng[i] * dirs[2 * i], hiy = rng[i] * dirs[2 * i + 1];
+        const double hjx = rng[j] * dirs[2 * j], hjy = rng[j] * dirs[2 * j + 1];
+        a2 += hix * hjy - hjx * hiy;
+      }
+      int cnt = 0;
+      for (int c = 0; c < n_occ; ++c) {
+        const int idx = occ_idx[c];
+        const int wx = ix0 + idx % nx, wy = iy0 + idx / nx;
+        const double cx = rx0 + ((double)wx + 0.5) * cs, cy = ry0 + ((double)wy + 0.5) * cs;
+        const double qx = cx - px, qy = cy - py;
+        if (qx * qx + qy * qy > r2) continue;
+        if (qx == 0.0 && qy == 0.0) { ++cnt; continue; }
+        const int i = fan_sector(n_rays, dirs, 1, qx, qy);
+        if (i < 0) continue;
+        const int j = (i + 1 == n_rays) ? 0 : i + 1;
+        const double hix = rng[i] * dirs[2 * i], hiy = rng[i] * dirs[2 * i + 1];
+        const double hjx = rng[j] * dirs[2 * j], hjy = rng[j] * dirs[2 * j + 1];
+        if ((hjx - hix) * (qy - hiy) - (hjy - hiy) * (qx - hix) >= 0.0) ++cnt;
+      }
+      revealed[(size_t)m * K + k] = cnt;
+      area[(size_t)m * K + k] = 0.5 * a2;
+    }
+  }
+  free(rng);
   return 0;
 }

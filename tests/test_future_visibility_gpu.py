@@ -1,0 +1,98 @@
+"""The future-visibility extension (not part of the reference) on a real MI355X against its CPU
+restatement: revealed-cell counts bit-exact, polygon areas to rounding, plus properties that need no oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _scene(sc, ego, radius=50.0):
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    sm = SensorModel(sc.lanelets, None, sensor_radius=radius, sensor_angle=360.0)
+    ob = FOObstacles(sc.obstacles)
+    ob.update(0)
+    sm.calc_visible_and_occluded_area(0, ego[:2], float(ego[2]), ob)
+    return sm, ob
+
+
+def _check(torch, oracle, sc, ego, M, stride, n_rays, seed):
+    from frenetix_occlusion import synthetic as SY
+    sm, ob = _scene(sc, ego)
+    traj = SY.make_trajectories(M, seed=seed, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    rev, area = sm.future_visibility(traj["x"], traj["y"], t_stride=stride, n_rays=n_rays)
+    torch.cuda.synchronize()
+    rev, area = rev.cpu().numpy(), area.cpu().numpy()
+    corn, cen, flags = ob.arrays()
+    dirs = sm._fv_dirs.cpu().numpy()
+    w = sm.window
+    (x0, y0) = sm.raster_origin
+    occ = sm.occluded_cells().cpu().numpy()
+    ref_rev, ref_area = oracle.future_visibility(traj["x"], traj["y"], stride, dirs, sm.sensor_radius, sm.map_geometry.edges,
+                                                 corn, flags, occ, x0, y0, sm.cell_size, w.ix0, w.iy0, w.nx)
+    assert rev.shape == ref_rev.shape == (M, (traj["x"].shape[1] + stride - 1) // stride)
+    assert np.array_equal(rev, ref_rev)
+    np.testing.assert_allclose(area, ref_area, rtol=1e-12, atol=1e-9)
+    return rev, area, sm, traj
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_scenario_maps_match_the_restatement(torch_cuda, oracle, k):
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, f"scenario{k}_geometry.npz"))
+    rev, area, sm, traj = _check(torch_cuda, oracle, sc, sc.ego_initial, 48, 5, 192, seed=7)
+    assert rev.max() > 0 and area.min() > 0.0
+    # pose 0 of every trajectory is the ego pose: same count for all, and nothing of the occluded set is visible from
+    # where it was classified as occluded except through the coarser fan (192 instead of 720 rays)
+    assert (rev[:, 0] == rev[0, 0]).all() and rev[0, 0] <= 0.05 * len(sm.occluded_cells())
+    # area never exceeds the disc
+    assert area.max() <= math.pi * sm.sensor_radius ** 2 + 1e-6
+
+
+def test_city_grid_and_odd_sizes(torch_cuda, oracle):
+    from frenetix_occlusion import scenario as S
+    sc = S.synthetic_urban_grid()
+    _check(torch_cuda, oracle, sc, sc.ego_initial, 24, 7, 97, seed=11)      # K = 5, odd ray count
+    rev, area, sm, traj = _check(torch_cuda, oracle, sc, sc.ego_initial, 16, 31, 256, seed=12)   # K = 1, max rays
+    assert rev.shape[1] == 1
+
+
+def test_interface_entry_and_empty_batch(torch_cuda, tmp_path):
+    from types import SimpleNamespace
+
+    import yaml
+    from frenetix_occlusion import interface, scenario as S, synthetic as SY
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    p = tmp_path / "occ.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    ref_path = ego[None, :2] + np.linspace(0, 80, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+    veh = SimpleNamespace(**dict(zip(("length", "width", "wb_rear_axle", "mass", "a_max"), SY.VEHICLE_BMW320I)))
+    fo = interface.FOInterface(sc, ref_path, veh, 0.1, config_path=str(p))
+    with pytest.raises(RuntimeError):
+        fo.future_visibility_batch(SY.make_trajectories(2, seed=1))         # no evaluate_scenario yet
+    fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    traj = SY.make_trajectories(10, seed=2, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    objs = [SimpleNamespace(cartesian=SimpleNamespace(**{k: v[i] for k, v in traj.items()})) for i in range(10)]
+    rev, area = fo.future_visibility_batch(objs, t_stride=10, n_rays=128)
+    rev2, area2 = fo.future_visibility_batch(traj, t_stride=10, n_rays=128)
+    torch_cuda.cuda.synchronize()
+    assert rev.shape == (10, 4) and torch_cuda.equal(rev, rev2) and torch_cuda.equal(area, area2)
+    # a faster trajectory gets farther and sees at least as much new area at its last pose as a standing one sees
+    still = {k: np.repeat(v[:1, :1], 31, axis=1) for k, v in traj.items()}
+    r0, _ = fo.future_visibility_batch(still, t_stride=10)
+    assert (r0.cpu().numpy() == r0.cpu().numpy()[0, 0]).all()

@@ -311,3 +311,50 @@ def test_lanelet_index_raster_matches_the_lane_heading_raster():
     ras = S.lanelet_index_raster(sc.lanelets, -60.0, -60.0, 0.5, 400, 300)
     yaw = S.lane_yaw_raster(sc.lanelets, -60.0, -60.0, 0.5, 400, 300)
     assert np.array_equal(ras >= 0, ~np.isnan(yaw)) and (ras >= 0).sum() > 1000 and ras.max() < len(sc.lanelets)
+
+
+def test_future_visibility_extension_in_a_room_with_a_wall(oracle):
+    """extension: a corridor with a box in the middle; poses before, beside and past the box.  The
+    polygon of hit points fills the corridor minus the box shadow; the cells behind the box are revealed only from the
+    poses that have passed it."""
+    g = room(-30, 30, -5, 5)
+    box = S.Obstacle(1, "static", "car", 2.0, 6.0, 0, np.array([0.0, -2.0, 0.0, 0.0]), np.zeros((0, 4)))
+    corn = box.corners(box.initial)[None]
+    flags = np.array([3], np.uint8)
+    ego = np.array([-20.0, -2.0])
+    s = _grid_for(oracle, g, ego, 0.0, 60.0, ocorn=corn.reshape(-1, 8), oflags=flags)
+    occ = s["occ"]
+    assert len(occ) > 100                                            # the shadow of the box down the corridor
+    T = 5
+    x = np.array([np.linspace(-20.0, 20.0, T)])                      # one trajectory driving past the box at y = 3.5
+    y = np.full((1, T), 3.5)
+    dirs = oracle.ray_dirs(256)
+    rev, area = oracle.future_visibility(x, y, 1, dirs, 60.0, g.edges, corn.reshape(-1, 8), flags, occ, s["x0"], s["y0"],
+                                         s["cs"], 0, 0, s["nx"])
+    assert rev.shape == (1, T) and area.shape == (1, T)
+    assert rev[0, 0] < rev[0, 2] < rev[0, 4]                          # more of the shadow is seen the farther it gets
+    assert rev[0, 4] >= 0.9 * len(occ)                                # past the box (almost) everything behind it shows
+    # the visible polygon can never exceed the corridor minus the box, and from x = 20 it is most of it
+    assert (area <= 600.0 - 12.0 + 1e-9).all() and area[0, 2] > 0.95 * 588.0      # beside the box: almost no shadow
+    np.testing.assert_allclose(area[0, ::-1], area[0], rtol=1e-9)      # the scene is mirror-symmetric about x = 0
+    # stride: K = ceil(T / stride), pose k = sample k * stride
+    rev2, area2 = oracle.future_visibility(x, y, 2, dirs, 60.0, g.edges, corn.reshape(-1, 8), flags, occ, s["x0"], s["y0"],
+                                           s["cs"], 0, 0, s["nx"])
+    assert np.array_equal(rev2[0], rev[0, ::2]) and np.array_equal(area2[0], area[0, ::2])
+
+
+@pytest.mark.parametrize("n_rays", [97, 181, 720, 5, 4])
+def test_every_direction_of_a_full_fan_has_a_sector(oracle, n_rays):
+    """an empty hall much larger than the sensor range: every cell centre within the polygon of hit points is visible,
+    whatever the parity of the ray count (a full fan searched in halves loses a sliver next to ray n/2 when n is odd)"""
+    g = room(-40, 40, -40, 40)
+    ego = np.array([0.13, -0.21])
+    r = 20.0
+    s = _grid_for(oracle, g, ego, 0.4, r, n_rays=n_rays)
+    iy, ix = np.mgrid[0:s["ny"], 0:s["nx"]]
+    cx, cy = s["x0"] + (ix + 0.5) * s["cs"], s["y0"] + (iy + 0.5) * s["cs"]
+    d = np.hypot(cx - ego[0], cy - ego[1])
+    vis = (s["cls"] & 2) != 0
+    inner = d <= r * math.cos(math.pi / n_rays) - 1e-9           # inside the inscribed circle of the ray polygon
+    assert vis[inner].all()
+    assert not vis[d > r].any()
