@@ -751,20 +751,27 @@ __global__ __launch_bounds__(FV_THREADS) void fo_future_visibility_kernel(
   const int n_occ = *n_occ_ptr;
   const double r2 = r * r;
   int cnt = 0;
-  for (int ci = tid; ci < n_occ; ci += FV_THREADS) {
-    const int idx = occ_idx[ci];
+  auto inside_fan = [&](int idx) -> int {
     const int wx = ix0 + idx % nx, wy = iy0 + idx / nx;
     const double cx = rx0 + ((double)wx + 0.5) * cs, cy = ry0 + ((double)wy + 0.5) * cs;
     const double qx = cx - px, qy = cy - py;
-    if (qx * qx + qy * qy > r2) continue;
-    if (qx == 0.0 && qy == 0.0) { ++cnt; continue; }
+    if (qx * qx + qy * qy > r2) return 0;
+    if (qx == 0.0 && qy == 0.0) return 1;
     const int i = fan_sector_uniform(n_rays, s_dir, qx, qy);
-    if (i < 0) continue;
+    if (i < 0) return 0;
     const int j = (i + 1 == n_rays) ? 0 : i + 1;
     const double hix = s_rng[i] * s_dir[2 * i], hiy = s_rng[i] * s_dir[2 * i + 1];
     const double hjx = s_rng[j] * s_dir[2 * j], hjy = s_rng[j] * s_dir[2 * j + 1];
-    if ((hjx - hix) * (qy - hiy) - (hjy - hiy) * (qx - hix) >= 0.0) ++cnt;
+    return ((hjx - hix) * (qy - hiy) - (hjy - hiy) * (qx - hix) >= 0.0) ? 1 : 0;
+  };
+  // four cell indices per thread in flight (the list is read once per pose; the loads are what the loop waits for)
+  int ci = tid;
+  for (; ci + 3 * FV_THREADS < n_occ; ci += 4 * FV_THREADS) {
+    const int i0 = occ_idx[ci], i1 = occ_idx[ci + FV_THREADS], i2 = occ_idx[ci + 2 * FV_THREADS],
+              i3 = occ_idx[ci + 3 * FV_THREADS];
+    cnt += inside_fan(i0) + inside_fan(i1) + inside_fan(i2) + inside_fan(i3);
   }
+  for (; ci < n_occ; ci += FV_THREADS) cnt += inside_fan(occ_idx[ci]);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
   if (lane == 0) s_cnt[wave] = cnt;
