@@ -202,3 +202,25 @@ def classify(q, lanelet_polys, boundary_edges, ego, yaw, r, fov_deg=360.0, obsta
     half = sector_polygon(ego, 1.5 * r, yaw - math.radians(90), yaw + math.radians(90))
     occ = points_in_polygon(q, half) & road & ~vis
     return road, vis, occ
+
+
+def obstacles_visible(lanelet_polys, boundary_edges, ego, yaw, r, fov_deg, corners, is_bicycle, ds=0.02, off=0.0075):
+    """ref sensor_model.py:59-76: `obst.current_polygon.intersects(visible_area.buffer(0.01))`.  The visible area has the
+    obstacle grown by 5 mm removed (:183), so the polygon touches the 1 cm buffer iff a point just outside that skin is
+    visible: the obstacle's outline, pushed out by 7.5 mm and sampled every `ds`, is classified by `classify`."""
+    out = []
+    for c in corners:
+        c = np.asarray(c, float).reshape(4, 2)
+        pts = []
+        for sd in range(4):
+            a, b = c[sd], c[(sd + 1) % 4]
+            e = b - a
+            ln = np.linalg.norm(e)
+            nrm = np.array([e[1], -e[0]]) / ln
+            if np.dot(nrm, a - c.mean(0)) < 0:
+                nrm = -nrm
+            t = np.clip(np.arange(0.0, ln + ds, ds) / ln, 0.0, 1.0)
+            pts.append(a[None] + t[:, None] * e[None] + off * nrm[None])
+        _, vis, _ = classify(np.concatenate(pts), lanelet_polys, boundary_edges, ego, yaw, r, fov_deg, corners, is_bicycle)
+        out.append(bool(vis.any()))
+    return np.array(out)

@@ -180,3 +180,29 @@ def test_synthetic_urban_grid_matches_the_reference_set_algebra(oracle):
     assert int(s["vis"].sum()) > 5000 and int(s["occ"].sum()) > 9000
     assert np.array_equal(s["vis"], s["o_vis"]) and np.array_equal(s["occ"], s["o_occ"])
     assert len(np.unique(s["g"].edge_line)) < 0.2 * len(s["g"].edges)      # straight kerbs collapse into chains
+
+
+def test_visible_objects_agree_with_the_reference_predicate(oracle):
+    """visible_objects_timestep (ref sensor_model.py:59-76) on the three scenario maps while the ego and the obstacles
+    move: fan hits + probe points against "the obstacle's outline, pushed out past the 5 mm skin, has a visible point"."""
+    n = 0
+    for k in (1, 2, 3):
+        sc = S.load_geometry_npz(os.path.join(GOLDEN, f"scenario{k}_geometry.npz"))
+        g = S.MapGeometry.from_lanelets(sc.lanelets)
+        polys = [ll.polygon for ll in sc.lanelets]
+        e0 = sc.ego_initial
+        for ts in (0, 10, 25, 40, 60):
+            ego = e0[:2] + 0.7 * ts * np.array([math.cos(e0[2]), math.sin(e0[2])])
+            yaw, r, fov = float(e0[2]), 50.0, 360.0
+            corn, cen, flags, _ = sc.obstacle_arrays(ts)
+            dirs, rmax = ray_dirs(720, yaw, fov), footprint_ranges(720, yaw, fov, r)
+            hi = HoleIndex(g)
+            rings = hi.enclosed(ego, yaw, fov, r)
+            skip = hi.edge_skip(rings) if rings else None
+            _, hid, _ = oracle.raycast(g.edges, corn.reshape(-1, 8), flags, ego, dirs, r, rmax=rmax, edge_skip=skip)
+            ours = oracle.obstacle_visibility(g.edges, corn, cen, flags, ego, r, True, dirs, edge_skip=skip, hit_id=hid)
+            present = (flags & 1) != 0
+            ref = RP.obstacles_visible(polys, g.edges, ego, yaw, r, fov, corn[present], [(f & 2) == 0 for f in flags[present]])
+            assert np.array_equal(ours[present].astype(bool), ref), (k, ts)
+            n += int(present.sum())
+    assert n >= 30
