@@ -58,12 +58,17 @@ def trajectories_to_arrays(trajectories):
     if isinstance(trajectories, dict):
         return trajectories
     out = {}
+    M = len(trajectories)
+    if M == 0:
+        return {k: np.zeros((0, 0)) for k in ("x", "y", "theta", "v", "a")}
+    carts = [t.cartesian for t in trajectories]
+    T = len(carts[0].x)
     for k in ("x", "y", "theta", "v", "a"):
-        rows = [np.asarray(getattr(t.cartesian, k), dtype=np.float64) for t in trajectories]
-        T = len(rows[0])
+        rows = [getattr(c, k) for c in carts]
         if any(len(r) != T for r in rows):
             raise ValueError("all trajectories of a batch must have the same number of samples")
-        out[k] = np.stack(rows, axis=0) if rows else np.zeros((0, 0))
+        # one C-level concatenation instead of M small conversions (the planner hands over thousands of objects)
+        out[k] = np.concatenate(rows, axis=None).astype(np.float64, copy=False).reshape(M, T)
     return out
 
 
