@@ -49,6 +49,21 @@ def main():
         if it >= 5:
             stages["evaluate_scenario"].append(t1 - t0)
             stages["assessment_batch"].append(t2 - t1)
+    # the reference's own calling pattern: one call per candidate (interface.py:216-219), no batch beforehand
+    objs = [SimpleNamespace(cartesian=SimpleNamespace(**{k: v[i] for k, v in traj.items()})) for i in range(min(M, 200))]
+    fo.metrics.invalidate()
+    t0 = time.perf_counter()
+    for o in objs:
+        res, safe = fo.trajectory_safety_assessment(o)
+    per_call = (time.perf_counter() - t0) / len(objs)
+    # ... and the same objects served from one full-output batch
+    t0 = time.perf_counter()
+    fo.trajectory_safety_assessment_batch(objs, mode="full")
+    for o in objs:
+        res, safe = fo.trajectory_safety_assessment(o)
+    served = (time.perf_counter() - t0) / len(objs)
+    print(f"  per-trajectory call     {per_call * 1e3:8.3f} ms each (no batch);  {served * 1e3:8.3f} ms each when served "
+          f"from one full-output batch of {len(objs)}")
     print(f"mode={mode} M={M} agents={len(fo.agent_manager.phantom_agents)} spawn_points={len(fo.spawn_points)}")
     for k, v in stages.items():
         print(f"  {k:20s} median {np.median(v) * 1e3:8.3f} ms   max {np.max(v) * 1e3:8.3f} ms")
