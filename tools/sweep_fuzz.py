@@ -1,0 +1,53 @@
+"""One-off robustness run on the GPU box: the metric sweep (through the C ABI) against the oracle on random batch
+shapes -- M, A, T, ragged prediction lengths, agent types, metric subsets, thresholds, output modes.  Reuses the
+comparison of tests/test_sweep_gpu.py.  usage: python tools/sweep_fuzz.py [n] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "frenetix-occlusion_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from frenetix_occlusion import synthetic as SY  # noqa: E402
+from oracle import fo_oracle as oracle  # noqa: E402
+import test_sweep_gpu as TS  # noqa: E402
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    oracle.build()
+    worst = 0.0
+    for it in range(n):
+        M = int(rng.choice([1, 2, 63, 64, 65, 127, 200, 513, 1000]))
+        A = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 64]))
+        T = int(rng.choice([2, 3, 7, 16, 17, 30, 31]))
+        seed = int(rng.integers(1 << 30))
+        traj = SY.make_trajectories(M, T, 0.1, seed=seed)
+        agents = SY.make_agents(A, T, 0.1, seed=seed + 1, lateral=float(rng.choice([3.0, 14.0])))
+        agents["len"] = rng.integers(0 if rng.random() < 0.2 else 1, T + 1, A).astype(np.int32)
+        if rng.random() < 0.5:      # every ObstacleType code of the harm model's mass / protection tables
+            agents["type"] = rng.integers(0, 12, A).astype(np.int32)
+        allm = ["hr", "ttc", "ttce", "dce", "wttc", "cp"]
+        metrics = allm if rng.random() < 0.5 else list(rng.choice(allm, int(rng.integers(1, 6)), replace=False))
+        thr = {"harm": float(rng.uniform(0.05, 1)), "risk": float(rng.uniform(0.01, 1)), "ttc": float(rng.uniform(0, 3)),
+               "dce": float(rng.uniform(0, 1)), "cp": float(rng.uniform(0.1, 1))}
+        if rng.random() < 0.3:
+            thr = {k: v for k, v in thr.items() if rng.random() < 0.5}
+        ref = oracle.sweep(traj, agents, SY.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr, nthreads=8)
+        got = TS._hip_sweep(torch, traj, agents, SY.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr)
+        w = TS._compare(oracle, ref, got)
+        assert np.array_equal(ref["safe"], got["safe"])
+        worst = max(worst, w)
+        red = TS._hip_sweep(torch, traj, agents, SY.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr, mode="reduced")
+        assert np.array_equal(red["safe"], got["safe"])
+        c1, c2 = red["cost"], got["cost"]
+        assert np.array_equal(np.isfinite(c1), np.isfinite(c2)) and np.allclose(c1[np.isfinite(c1)], c2[np.isfinite(c2)], rtol=0, atol=1e-12)
+        print(it, "M", M, "A", A, "T", T, "metrics", ",".join(metrics), "worst", f"{w:.2e}", "safe", float(ref["safe"].mean()), flush=True)
+    print("all", n, "batches within 1e-9 of the oracle, integers exact; worst float deviation", f"{worst:.2e}")
+
+
+if __name__ == "__main__":
+    main()
