@@ -10,7 +10,6 @@ import json
 import os
 
 import numpy as np
-import torch
 
 from .. import _native as N
 from ..sweep import DEFAULT_HARM_COEFF, MetricSweep, SweepResult

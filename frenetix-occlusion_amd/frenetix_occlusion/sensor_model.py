@@ -228,7 +228,7 @@ class SensorModel:
 
     # ---- one-off: replaces _convert_lanelet_network (sensor_model.py:195-199)
     def _set_map(self, net):
-        from .scenario import Lanelet, lane_yaw_raster, lanelets_of
+        from .scenario import lane_yaw_raster, lanelets_of
         if isinstance(net, MapGeometry):
             geo, lanelets = net, None
         else:

@@ -15,7 +15,6 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import _native as N
 
 MIN_AHEAD = 3.0            # spawn_locator.py:234,381 "ahead by >= 3 m"
 S_THRESHOLD_TIME = 4.0     # spawn_locator.py:65-66,113: s_threshold = s_ego + max(4 v, 25)

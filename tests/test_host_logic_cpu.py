@@ -103,7 +103,6 @@ def test_cell_window_round_trip():
 
 
 def test_default_config_and_coefficients_load():
-    import yaml
     from frenetix_occlusion import interface
     from frenetix_occlusion.metrics.metric import load_harm_coeff
     from frenetix_occlusion.sweep import DEFAULT_HARM_COEFF

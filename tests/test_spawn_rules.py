@@ -1,7 +1,6 @@
 """The reference's spawn rules restated on the cell classes (spawn_rules.py): known-answer scenes evaluated with the
 oracle's ray fan / cell grid on the CPU.  PARITY UNPINNED vs the reference (GEOS absent): these tests are the pin."""
 import math
-from types import SimpleNamespace
 
 import numpy as np
 import pytest

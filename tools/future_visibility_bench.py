@@ -1,10 +1,8 @@
 """Throughput of the future-visibility extension at the BASELINE configs[2] size (10 000 trajectories, city grid):
 HIP-event time of fo_scene_future_visibility for a few (stride, rays) settings.  Run on the GPU box."""
-import math
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

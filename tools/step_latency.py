@@ -1,7 +1,6 @@
 """Wall-clock latency of one planning step through the drop-in boundary itself (FOInterface.evaluate_scenario +
 trajectory_safety_assessment_batch, synchronised each step) -- what a planner calling the Python interface sees, as
 opposed to bench.py's lean loop.  Run on the GPU box: python tools/step_latency.py [cells|rules|both] [M]."""
-import math
 import os
 import sys
 import tempfile
