@@ -695,7 +695,7 @@ __global__ __launch_bounds__(FV_THREADS) void fo_future_visibility_kernel(
     }
     __syncthreads();
   }
-  // obstacles within reach: corner rows staged in LDS (256 at a time)
+  // obstacles within reach: corner rows staged in LDS (64 at a time)
   for (int base = 0; base < O; base += 64) {
     __syncthreads();
     if (tid == 0) s_nob = 0;

@@ -201,9 +201,10 @@ def union_boundary_edges(polys, eps=1e-4, tol=1e-9):
         n = len(p)
         a, b = p, np.roll(p, -1, axis=0)
         ccw = _signed_area(p) > 0
-        near = [qi for qi in range(len(polys)) if qi != pi and not (
-            boxes[qi, 0] > boxes[pi, 2] + tol or boxes[qi, 2] < boxes[pi, 0] - tol or
-            boxes[qi, 1] > boxes[pi, 3] + tol or boxes[qi, 3] < boxes[pi, 1] - tol)]
+        apart = ((boxes[:, 0] > boxes[pi, 2] + tol) | (boxes[:, 2] < boxes[pi, 0] - tol) |
+                 (boxes[:, 1] > boxes[pi, 3] + tol) | (boxes[:, 3] < boxes[pi, 1] - tol))
+        apart[pi] = True
+        near = [int(qi) for qi in np.nonzero(~apart)[0]]
         splits = [[0.0, 1.0] for _ in range(n)]
         for qi in near:
             q = polys[qi]
