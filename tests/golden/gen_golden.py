@@ -121,7 +121,11 @@ class AgentManager:
 
 
 AGENT_TYPES = ["Car", "Truck", "Bicycle", "Pedestrian"]
-RAW_DIMS = {"Car": (4.8, 2.0), "Truck": (9.0, 2.5), "Bicycle": (2.0, 0.9), "Pedestrian": (0.3, 0.5)}
+RAW_DIMS = {"Car": (4.8, 2.0), "Truck": (9.0, 2.5), "Bicycle": (2.0, 0.9), "Pedestrian": (0.3, 0.5),
+            # types the phantom generator never produces but the harm model's tables know (harm_model.py:15-32,158-190)
+            "Bus": (12.0, 2.6), "Train": (20.0, 3.0), "Motorcycle": (2.2, 0.8), "Taxi": (4.6, 1.9), "Unknown": (1.0, 1.0)}
+SPEED = {"Car": 10.0, "Truck": 10.0, "Bicycle": 5.0, "Pedestrian": 1.4, "Bus": 8.0, "Train": 12.0, "Motorcycle": 11.0,
+         "Taxi": 9.0, "Unknown": 2.0}
 
 
 def make_traj(rng, T, dt, x0=0.0, y0=0.0, psi0=0.0):
@@ -142,12 +146,13 @@ def make_traj(rng, T, dt, x0=0.0, y0=0.0, psi0=0.0):
     return x, y, theta, v, a
 
 
-def make_prediction(rng, kind, L, dt, near_xy, var0=0.1, vf=1.05, zero_cov=False, curved=False):
+def make_prediction(rng, kind, L, dt, near_xy, var0=0.1, vf=1.05, zero_cov=False, curved=False, heading=None,
+                    offset=None):
     raw_l, raw_w = RAW_DIMS[kind]
     fl, fw = (1.4, 2.5) if kind == "Bicycle" else (1.2, 1.3)
-    speed = {"Car": 10.0, "Truck": 10.0, "Bicycle": 5.0, "Pedestrian": 1.4}[kind] * rng.uniform(0.6, 1.2)
-    psi = rng.uniform(-np.pi, np.pi)
-    p0 = np.asarray(near_xy) + rng.uniform(-6, 6, size=2)
+    speed = SPEED[kind] * rng.uniform(0.6, 1.2)
+    psi = rng.uniform(-np.pi, np.pi) if heading is None else heading
+    p0 = np.asarray(near_xy) + (rng.uniform(-6, 6, size=2) if offset is None else np.asarray(offset))
     t = np.arange(L) * dt
     if curved:
         om = rng.uniform(-0.4, 0.4)
@@ -302,6 +307,24 @@ def main():
     kinds = ["Car", "Pedestrian", "Bicycle"]
     preds = [make_prediction(rng, k, 31, dt, mid) for k in kinds]
     run_case("short_traj", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC)
+
+    # case 4: a ring of agents around the trajectories' mid-point -- every bearing x many headings, so that both
+    # impact angles visit all front / side / rear bins of logistic_regression.py:28-42 -- with every obstacle type whose
+    # enum value survives `.lower()` (harm_model.py:61,78): mass table and protection flags of :15-32,158-190
+    rng = np.random.default_rng(20240134)
+    trajs = [Traj(*make_traj(rng, 31, dt, psi0=0.7)) for _ in range(12)]
+    mid = np.array([trajs[0].cartesian.x[14], trajs[0].cartesian.y[14]])
+    ring_kinds = ["Car", "Truck", "Bus", "Taxi", "Train", "Motorcycle", "Unknown", "Bicycle", "Pedestrian"]
+    kinds, preds = [], []
+    for j in range(36):
+        kind = ring_kinds[j % len(ring_kinds)]
+        bearing = 2 * np.pi * j / 36
+        rad = 4.0 + 9.0 * ((j * 7) % 5) / 4.0
+        heading = bearing * 3.0 + 0.4 * j                      # decorrelated from the bearing, runs past 2 pi
+        kinds.append(kind)
+        preds.append(make_prediction(rng, kind, 31, dt, mid, heading=heading,
+                                     offset=rad * np.array([np.cos(bearing), np.sin(bearing)])))
+    run_case("ring_all_types", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC)
 
 
 if __name__ == "__main__":

@@ -56,3 +56,9 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(d, f)).read()
                 assert "fo_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_golden_fixture_type_codes_are_the_product_codes():
+    import golden_util
+    from frenetix_occlusion import _native as native
+    assert golden_util.TYPE_CODES == native.TYPE_CODES
