@@ -9,7 +9,7 @@
 // must be bit-identical to the CPU restatement, so only + - * / sqrt and comparisons on float64 are used and no
 // FMA is formed.
 //
-// Kernels (all latency-bound at one ego; launch count matters more than bandwidth here -- eleven launches per step):
+// Kernels (all latency-bound at one ego; launch count matters more than bandwidth here -- nine launches per step):
 //   fo_raster_kernel       one-off: world-aligned road raster (cell centre inside any lanelet polygon)
 //   fo_fan_kernel          ray directions, footprint range per ray, half fan of the occluded area
 //   fo_rays_kernel         ray fan + obstacle-visibility probes in one launch: a workgroup per ray / per probe; the
@@ -20,7 +20,8 @@
 //                          counts of the occluded-cell compaction
 //   fo_settle_kernel       a workgroup per undecided cell (does an occluder cross the segment ego -> centre) and a
 //                          workgroup per obstacle (5 mm skin)
-//   fo_flag_scan/scatter   deterministic stream compaction (ballot prefix inside a block, scanned block counts)
+//   fo_flag_compact_kernel deterministic stream compaction in one launch (ballot prefix inside a block, every block
+//                          sums the counts before it; fo_flag_scan/scatter for very large windows)
 //   fo_spawn_flag_kernel   candidate cells (+ block counts), fo_spawn_pick_kernel (evenly spaced pick + heading),
 //                          fo_spawn_predict_kernel (predictions in the sweep's agent layout)
 #include <hip/hip_runtime.h>
@@ -829,6 +830,29 @@ __global__ __launch_bounds__(256) void fo_flag_scatter_kernel(const uint8_t *__r
   if (f) out[off + before] = idx;
 }
 
+// One-launch variant for the usual window sizes (a few hundred blocks): every block sums the counts of the blocks
+// before it itself (a few hundred L2-resident ints) instead of waiting for a separate scan launch; same output.
+__global__ __launch_bounds__(256) void fo_flag_compact_kernel(const uint8_t *__restrict__ flags, int n,
+                                                              const int32_t *__restrict__ cnt,
+                                                              int32_t *__restrict__ out, int32_t *__restrict__ total) {
+  __shared__ int wsum[4], psum[4];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool f = idx < n && flags[idx];
+  const unsigned long long b = __ballot(f);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int before = __popcll(b & ((1ull << lane) - 1ull));
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += cnt[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+  if (lane == 0) { wsum[w] = __popcll(b); psum[w] = part; }
+  __syncthreads();
+  int off = psum[0] + psum[1] + psum[2] + psum[3];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = off + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  for (int k = 0; k < w; ++k) off += wsum[k];
+  if (f) out[off + before] = idx;
+}
+
 // ------------------------------------------------------------------------------------------------ spawn sampling
 __global__ void fo_spawn_flag_kernel(const uint8_t *__restrict__ cls, int nx, int ny, double rx0, double ry0, double cs,
                                      int ix0, int iy0, double ex, double ey, double hx, double hy, double min_ahead,
@@ -1050,8 +1074,12 @@ int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
 // flags -> ascending indices (out) + count (d_total)
 int compact(fo_ctx *ctx, Scene *sc, const uint8_t *flags, int n, int32_t *out, int32_t *d_total, hipStream_t s) {
   const int nb = (n + 255) / 256;  // block counts were written by the kernel that produced the flags
-  hipLaunchKernelGGL(fo_flag_scan_kernel, dim3(1), dim3(1024), 0, s, sc->d_blk, nb, d_total);
-  hipLaunchKernelGGL(fo_flag_scatter_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk, out);
+  if (nb <= 2048) {
+    hipLaunchKernelGGL(fo_flag_compact_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk, out, d_total);
+  } else {
+    hipLaunchKernelGGL(fo_flag_scan_kernel, dim3(1), dim3(1024), 0, s, sc->d_blk, nb, d_total);
+    hipLaunchKernelGGL(fo_flag_scatter_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk, out);
+  }
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
 }
