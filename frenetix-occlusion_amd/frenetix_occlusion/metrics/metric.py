@@ -91,61 +91,84 @@ class BatchAssessment:
     def column(self, name):
         return self.cost[:, N.COST[name]]
 
+    HOST_CACHE_BYTES = 256 << 20     # per-pair outputs up to this size are mirrored on the host in one copy
+
     def _to_host(self):
         if self._host is None:
             r = self.result
+            big = r.lists is not None and r.lists.numel() * 8 > self.HOST_CACHE_BYTES
             self._host = {"cost": r.cost.cpu().numpy(), "safe": r.safe.cpu().numpy(),
-                          "pair_f": None if r.pair_f is None else r.pair_f.cpu().numpy(),
-                          "pair_i": None if r.pair_i is None else r.pair_i.cpu().numpy(),
-                          "lists": None if r.lists is None else r.lists.cpu().numpy()}
+                          "pair_f": None if (r.pair_f is None or big) else r.pair_f.cpu().numpy(),
+                          "pair_i": None if (r.pair_i is None or big) else r.pair_i.cpu().numpy(),
+                          "lists": None if (r.lists is None or big) else r.lists.cpu().numpy()}
         return self._host
 
-    def result_dict(self, m):
-        """the reference's nested dict for trajectory m; needs mode 'full'"""
+    def _column(self, m):
+        """per-pair outputs of trajectory m as host arrays: pair_f [NPF, A], pair_i [NPI, A], lists [NL, A, T-1].
+        Small batches are mirrored on the host once; for large ones (10 000 x 256 full outputs are 3.4 GB) only the
+        trajectory's own column crosses PCIe, gathered on the device."""
         h = self._to_host()
-        if h["lists"] is None:
+        if h["lists"] is not None:
+            return h["pair_f"][:, :, m], h["pair_i"][:, :, m], np.ascontiguousarray(h["lists"][:, :, :, m])
+        r = self.result
+        return (r.pair_f[:, :, m].cpu().numpy(), r.pair_i[:, :, m].cpu().numpy(),
+                r.lists[:, :, :, m].contiguous().cpu().numpy())
+
+    def result_dict(self, m):
+        """the reference's nested dict for trajectory m; needs mode 'full'.
+
+        One strided gather per output array pulls trajectory m's column out of the batch; the per-prediction entries
+        are then cut from plain Python lists (``ndarray.tolist`` once per array), which is what keeps a planner that
+        still asks trajectory by trajectory (interface.py:216-219) at a fraction of a millisecond per call."""
+        if self.result.lists is None:
             raise RuntimeError("result_dict needs the batch to be evaluated with mode='full'")
-        pf, pi, ls, cost = h["pair_f"], h["pair_i"], h["lists"], h["cost"][m]
+        h = self._to_host()
+        cost = h["cost"][m]
+        pf, pi, ls = self._column(m)                # [NPF, A], [NPI, A], [NL, A, T-1]
+        # entries past a list's length are NaN (hr.py:87-98 stops at min(T-1, len(prediction))): lengths per slot
+        n_valid = (~np.isnan(ls)).sum(axis=2)       # [NL, A]
+        pf_l, pi_l = pf.tolist(), pi.tolist()
+        PF, PI, LST = N.PF, N.PI, N.LST
+        slots = self.prediction_slots
         out = {}
         for name in self.metric_order:
             if name == "cp":
-                out["cp"] = {}
-                for pid, k in self.prediction_slots:
-                    v = ls[N.LST["cp"], k, :, m]
-                    out["cp"][pid] = v[~np.isnan(v)]
+                row, nv = ls[LST["cp"]], n_valid[LST["cp"]]
+                out["cp"] = {pid: row[k, :nv[k]] for pid, k in slots}     # views of this call's own gather
             elif name == "dce":
-                out["dce"] = {pid: {"dce": float(pf[N.PF["dce"], k, m]), "time_dce": int(pi[N.PI["time_dce"], k, m])}
-                              for pid, k in self.prediction_slots}
+                d, t = pf_l[PF["dce"]], pi_l[PI["time_dce"]]
+                out["dce"] = {pid: {"dce": d[k], "time_dce": t[k]} for pid, k in slots}
             elif name == "ttc":
-                out["ttc"] = {pid: float(pf[N.PF["ttc"], k, m]) for pid, k in self.prediction_slots}
+                v = pf_l[PF["ttc"]]
+                out["ttc"] = {pid: v[k] for pid, k in slots}
             elif name == "ttce":
-                out["ttce"] = {pid: float(pf[N.PF["ttce"], k, m]) for pid, k in self.prediction_slots}
+                v = pf_l[PF["ttce"]]
+                out["ttce"] = {pid: v[k] for pid, k in slots}
             elif name == "wttc":
                 out["wttc"] = float(cost[N.COST["wttc"]])
             elif name == "be":
-                out["be"] = {pid: {"required_constant_deceleration": float(pf[N.PF["be_decel"], k, m]),
-                                   "break_threat_number": float(pf[N.PF["be_btn"], k, m])}
-                             for pid, k in self.prediction_slots}
+                d, b = pf_l[PF["be_decel"]], pf_l[PF["be_btn"]]
+                out["be"] = {pid: {"required_constant_deceleration": d[k], "break_threat_number": b[k]}
+                             for pid, k in slots}
             elif name == "hr":
                 hr = {}
-                for pid, k in self.prediction_slots:
-                    if not pi[N.PI["hr_valid"], k, m]:
+                valid = pi_l[PI["hr_valid"]]
+                mer, mor, mhc = pf_l[PF["max_ego_risk"]], pf_l[PF["max_obst_risk"]], pf_l[PF["max_obst_harm_with_cp"]]
+                meh, moh, mcp = pf_l[PF["max_ego_harm"]], pf_l[PF["max_obst_harm"]], pf_l[PF["max_collision_probability"]]
+                ridx = pi_l[PI["max_obst_risk_index"]]
+                i_er, i_or, i_eh, i_oh, i_cp = (LST[k_] for k_ in ("ego_risk", "obst_risk", "ego_harm", "obst_harm", "cp"))
+                er_l, or_l = ls[i_er].tolist(), ls[i_or].tolist()      # the two lists the reference returns as lists
+                for pid, k in slots:
+                    if not valid[k]:
                         continue
-
-                    def lst(key):
-                        v = ls[N.LST[key], k, :, m]
-                        return [float(q) for q in v[~np.isnan(v)]]
-                    cpv = ls[N.LST["cp"], k, :, m]
-                    hr[pid] = {"max_ego_risk": float(pf[N.PF["max_ego_risk"], k, m]),
-                               "max_obst_risk": float(pf[N.PF["max_obst_risk"], k, m]),
-                               "max_obst_harm_with_cp": float(pf[N.PF["max_obst_harm_with_cp"], k, m]),
-                               "max_obst_risk_index": int(pi[N.PI["max_obst_risk_index"], k, m]),
-                               "max_ego_harm": float(pf[N.PF["max_ego_harm"], k, m]),
-                               "max_obst_harm": float(pf[N.PF["max_obst_harm"], k, m]),
-                               "ego_risk_traj": lst("ego_risk"), "obst_risk_traj": lst("obst_risk"),
-                               "ego_harm_traj": np.array(lst("ego_harm")), "obst_harm_traj": np.array(lst("obst_harm")),
-                               "collision_probability": cpv[~np.isnan(cpv)],
-                               "max_collision_probability": float(pf[N.PF["max_collision_probability"], k, m])}
+                    hr[pid] = {"max_ego_risk": mer[k], "max_obst_risk": mor[k], "max_obst_harm_with_cp": mhc[k],
+                               "max_obst_risk_index": ridx[k], "max_ego_harm": meh[k], "max_obst_harm": moh[k],
+                               "ego_risk_traj": er_l[k][:n_valid[i_er, k]],
+                               "obst_risk_traj": or_l[k][:n_valid[i_or, k]],
+                               "ego_harm_traj": ls[i_eh, k, :n_valid[i_eh, k]],
+                               "obst_harm_traj": ls[i_oh, k, :n_valid[i_oh, k]],
+                               "collision_probability": ls[i_cp, k, :n_valid[i_cp, k]],
+                               "max_collision_probability": mcp[k]}
                 for key in ("max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
                             "max_collision_probability_all", "max_obst_harm_with_cp_all"):
                     hr[key] = float(cost[N.COST[key]])

@@ -196,3 +196,27 @@ def test_rule_based_spawn_points_through_the_interface(torch_cuda, oracle, tmp_p
         assert np.array_equal(np.isfinite(got), f)
         np.testing.assert_allclose(got[f], ref["cost"][f], rtol=0, atol=1e-9)
     assert found["rules"] == (1, 1) and found["both"][0] > 1 and found["both"][1] == 1
+
+
+def test_result_dict_column_gather_equals_host_mirror(torch_cuda, tmp_path):
+    """large batches do not mirror their per-pair outputs on the host: the trajectory's column is gathered on the
+    device instead -- same nested dict either way"""
+    fo, sc, ego, SY = _setup(tmp_path, max_agents=8)
+    fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    traj = SY.make_trajectories(12, seed=9, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    ba = fo.trajectory_safety_assessment_batch(traj, mode="full")
+    host = [ba.result_dict(m) for m in (0, 5, 11)]
+    ba2 = fo.trajectory_safety_assessment_batch(traj, mode="full")
+    ba2.HOST_CACHE_BYTES = 0
+    col = [ba2.result_dict(m) for m in (0, 5, 11)]
+    assert ba2._to_host()["lists"] is None
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, np.ndarray):
+            return np.array_equal(a, b, equal_nan=True)
+        if isinstance(a, (list, tuple)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return a == b or (isinstance(a, float) and math.isnan(a) and math.isnan(b))
+    assert all(same(h, c) for h, c in zip(host, col))
