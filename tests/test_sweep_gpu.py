@@ -354,3 +354,19 @@ def test_dce_ties_stationary_and_random_geometry(torch_cuda, oracle):
 
 VEH_TOUCH_X = 1.4227 + 4.508 / 2 + 2.4   # ego centre offset + half ego length + half agent length: faces touch
 import math  # noqa: E402
+
+
+def test_single_sample_trajectories(torch_cuda, oracle):
+    """T = 1: no collision-probability or harm sample exists (cp.py loops from 1, harm_model.py:66 takes T-1 = 0),
+    DCE sees the one sample; list outputs have length 0"""
+    from frenetix_occlusion import synthetic as S
+    for M, A in ((1, 1), (70, 5)):
+        traj = {k: v[:, :1].copy() for k, v in S.make_trajectories(M, 2, 0.1, seed=3).items()}
+        agents = S.make_agents(A, 2, 0.1, seed=4)
+        for k in ("pos", "yaw", "v", "cov"):
+            agents[k] = agents[k][:, :1].copy()
+        agents["len"] = np.minimum(agents["len"], 1).astype(np.int32)
+        ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1)
+        got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1)
+        _compare(oracle, ref, got)
+        assert got["lists"].shape[-1] == 0 and np.array_equal(ref["safe"], got["safe"])
