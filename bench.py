@@ -85,9 +85,10 @@ def main():
     ap.add_argument("--M", type=int, default=10000)
     ap.add_argument("--A", type=int, default=256)
     ap.add_argument("--T", type=int, default=31)
-    ap.add_argument("--scene", default="urban", choices=["urban", "synthetic"],
+    ap.add_argument("--scene", default="urban", choices=["urban", "scenario1", "synthetic"],
                     help="urban: full planning step on the synthetic urban grid; synthetic: sweep only, fixed agents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="skip the agents-per-wave selection pass of the set-up")
     ap.add_argument("--order", default="sampler", choices=["sampler", "random"],
                     help="row order of the synthetic trajectories (synthetic.make_trajectories)")
     args = ap.parse_args()
@@ -121,13 +122,16 @@ def main():
     d = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a)).to(dev, dt)
 
     scene = None
-    if args.scene == "urban":
+    if args.scene in ("urban", "scenario1"):
         import yaml
         from frenetix_occlusion import interface
         from frenetix_occlusion import scenario as SC
         from frenetix_occlusion.sensor_model import SensorModel
         from frenetix_occlusion.spawn_locator import SpawnLocator
-        sc = SC.synthetic_urban_grid()
+        if args.scene == "urban":
+            sc = SC.synthetic_urban_grid()
+        else:   # BASELINE configs[1]: scenario1.xml geometry (committed fixture), use with --M 2000 --A 32
+            sc = SC.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario1_geometry.npz"))
         ego = sc.ego_initial
         with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
             cfg = yaml.safe_load(f)
@@ -163,6 +167,22 @@ def main():
         if use_dist:
             dist.all_gather_into_tensor(gathered, out.cost)
 
+    # Set-up, before the W warm-up steps: pick the sweep kernel's agents-per-wave for this batch shape by timing the
+    # real step (4 candidates x (10 + 60) steps, ~0.25 s).  The same pass brings the GPU to its sustained clocks: a
+    # cold MI355X runs the first few dozen steps 10-15 % slower, so without it the result would depend on W.
+    tune = {}
+    if not os.environ.get("FO_SWEEP_APW") and not args.no_autotune:
+        for apw in (1, 2, 4, 8):
+            os.environ["FO_SWEEP_APW"] = str(apw)
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            for _ in range(60):
+                step()
+            torch.cuda.synchronize()
+            tune[apw] = (time.perf_counter() - t_a) / 60
+        os.environ["FO_SWEEP_APW"] = str(min(tune, key=tune.get))
     for _ in range(args.warmup):
         step()
     sw.ctx.call("fo_sweep_check", torch.cuda.current_stream().cuda_stream)
@@ -209,7 +229,10 @@ def main():
         # HBM traffic of the dominant kernel from the PMC passes of the same command (profiles/, see README there):
         # WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), KB -> bytes; null when no summary has been committed
         traffic = None
+        default_workload = (args.scene == "urban" and M == 10000 and A == 256 and T == 31 and args.mode == "full")
         try:
+            if not default_workload:
+                raise LookupError("the committed PMC summary belongs to the default workload")
             import csv
             tag = os.environ.get("FO_PROFILE_TAG", "r01_final")
             with open(os.path.join(ROOT, "profiles", f"{tag}_summary.csv")) as f:
@@ -222,13 +245,17 @@ def main():
             "metric": "trajectory_x_agent_metric_evals_per_sec", "value": pairs / elapsed, "unit": "pair-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: synthetic urban lanelet net, 10k trajectories x 256 phantoms, "
-                                   "360 deg ray-cast @ 0.5 deg, T=31 (full planning step; per-rank trajectory shard when "
-                                   "n_gpus>1)" if scene is not None else
+            "config": {"workload": ("BASELINE configs[2]: synthetic urban lanelet net, 10k trajectories x 256 phantoms, "
+                                    "360 deg ray-cast @ 0.5 deg, T=31 (full planning step; per-rank trajectory shard when "
+                                    "n_gpus>1)") if args.scene == "urban" else
+                                   (f"BASELINE configs[1]: scenario1 geometry, {M} trajectories x {A} phantom slots, full "
+                                    "metric set, T=31 (full planning step)") if args.scene == "scenario1" else
                                    "sweep only: 10k synthetic trajectories x 256 synthetic phantom predictions, T=31",
                        "M_per_gpu": M, "A": A, "A_active": n_active, "T": T, "output_mode": args.mode,
                        "traj_order": args.order, "metrics": ["hr", "ttc", "ttce", "dce", "wttc", "cp"],
                        "scene_stage_ms": scene_ms, "sweep_kernel_ms": kern_s * 1e3,
+                       "agents_per_wave": int(os.environ["FO_SWEEP_APW"]) if os.environ.get("FO_SWEEP_APW") else None,
+                       "setup_autotune_ms_per_step": {str(k): round(v * 1e3, 4) for k, v in tune.items()},
                        "boundary_edges": scene["edges"] if scene else None, "rays": 720 if scene else None,
                        "parallelism": f"traj-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "fo_sweep_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -1274,10 +1274,12 @@ uint32_t required_metrics(uint32_t m) {  // metric.py:125-147
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
-// agents per wave: enough workgroups to fill 256 CUs several times over, but no more partial rows than needed
+// agents per wave: enough workgroups to fill 256 CUs many times over (the tail of the last round of workgroups costs
+// less the shorter they are), but no more partial rows than needed.  Measured at steady clocks on 10 000 x 256:
+// 1 -> 0.764 ms, 2 -> 0.748, 3 -> 0.756, 4 -> 0.765, 8 -> 0.79 (bench.py re-checks this per batch shape at set-up).
 int pick_apw(int n_tiles, int A, int wpb) {
   int apw = 8;
-  while (apw > 1 && (long)n_tiles * ((A + wpb * apw - 1) / (wpb * apw)) * wpb < 8192) apw >>= 1;
+  while (apw > 1 && (long)n_tiles * ((A + wpb * apw - 1) / (wpb * apw)) * wpb < 16384) apw >>= 1;
   return apw;
 }
 
