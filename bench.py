@@ -13,6 +13,10 @@ N > 1: every rank holds its own 10 000-trajectory shard (weak scaling); the scen
 (SURVEY 8e), cost vectors are all-gathered.  `--scene synthetic` replaces the scene stage by a fixed synthetic agent
 set (the sweep-only workload of earlier profiles).
 
+Set-up (untimed, before the W warm-up steps): the real step is timed for four agents-per-wave settings of the sweep
+kernel and the best one kept -- which also brings the GPU to its sustained clocks, so that the timed K steps do not
+depend on W (`--no-autotune` skips it).  `--scene scenario1 --M 2000 --A 32` runs BASELINE configs[1] instead.
+
 Prints ONE JSON line on rank 0.  `value` = trajectory x agent metric evaluations per second over all ranks.
 """
 import argparse
