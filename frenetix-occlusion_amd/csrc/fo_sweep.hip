@@ -1188,10 +1188,10 @@ __global__ __launch_bounds__(256) void fo_be_kernel(int M, int Mp, int T, int A,
 }
 
 // fold the per-chunk partials into the cost vector + safety flag (metric.py:50-100, hr.py:101-114, wttc.py:32-42)
-// 64 trajectories per workgroup, four waves: wave w folds its quarter of the chunk rows (in chunk order), the four
+// 64 trajectories per workgroup, eight waves: wave w folds its eighth of the chunk rows (in chunk order), the eight
 // partial results meet in LDS and wave 0 folds them in the same order -- ties keep the earliest chunk, exactly like one
-// sequential pass, with a quarter of the dependent-load chain.
-constexpr int RED_WAVES = 4;
+// sequential pass, with an eighth of the dependent-load chain.
+constexpr int RED_WAVES = 8;
 __global__ __launch_bounds__(64 * RED_WAVES) void fo_reduce_kernel(int M, int Mp, int A, int n_chunks,
                                                                    const double *__restrict__ partial,
                                                                    fo_thresholds_t thr, uint32_t mask,
