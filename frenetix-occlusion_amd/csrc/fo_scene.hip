@@ -9,7 +9,7 @@
 // must be bit-identical to the CPU restatement, so only + - * / sqrt and comparisons on float64 are used and no
 // FMA is formed.
 //
-// Kernels (all latency-bound at one ego; launch count matters more than bandwidth here -- nine launches per step):
+// Kernels (all latency-bound at one ego; launch count matters more than bandwidth here -- eight launches per step):
 //   fo_raster_kernel       one-off: world-aligned road raster (cell centre inside any lanelet polygon)
 //   fo_fan_kernel          ray directions, footprint range per ray, half fan of the occluded area
 //   fo_rays_kernel         ray fan + obstacle-visibility probes in one launch: a workgroup per ray / per probe; the
@@ -22,8 +22,8 @@
 //                          workgroup per obstacle (5 mm skin)
 //   fo_flag_compact_kernel deterministic stream compaction in one launch (ballot prefix inside a block, every block
 //                          sums the counts before it; fo_flag_scan/scatter for very large windows)
-//   fo_spawn_flag_kernel   candidate cells (+ block counts), fo_spawn_pick_kernel (evenly spaced pick + heading),
-//                          fo_spawn_predict_kernel (predictions in the sweep's agent layout)
+//   fo_spawn_flag_kernel   candidate cells (+ block counts), fo_spawn_predict_kernel (evenly spaced pick + heading +
+//                          predictions in the sweep's agent layout)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "fo_ctx.hpp"
@@ -889,30 +889,25 @@ struct SpawnTypes {  // per pattern slot (j % 4): type code, speed, raw dims, in
 
 // evenly spaced pick of the candidates + heading per phantom: pedestrians -> unit vector to the closest point of the
 // ego reference path (agent.py:475-481 + helper_functions.py:38-76); vehicles -> lane heading raster at their cell
-__global__ __launch_bounds__(256) void fo_spawn_pick_kernel(const int32_t *__restrict__ cand,
-                                                            const int32_t *__restrict__ n_cand, int nx, double rx0,
-                                                            double ry0, double cs, int ix0, int iy0, int max_agents,
-                                                            SpawnTypes st, int N, const double *__restrict__ path,
-                                                            const double *__restrict__ lane_yaw, int rnx, int rny,
-                                                            int32_t *__restrict__ cell, double *__restrict__ pos,
-                                                            double *__restrict__ yaw, int32_t *__restrict__ n_out) {
-  // one wave per phantom slot; the lanes share the search for the closest reference-path segment
-  const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int n = *n_cand;
+// Phantom slot j of the step (the whole wave calls this; every result is wave-uniform): which candidate cell it takes
+// -- the candidates at ranks floor(j n / max_agents) when there are more than slots -- its centre and its heading:
+// vehicles on a lane follow the lane-heading raster, everything else heads for the closest point of the reference path
+// (agent.py:475-481), the lanes sharing the search for the closest path segment.  Returns false for an unused slot.
+__device__ __forceinline__ bool spawn_pick(int j, int lane, const int32_t *__restrict__ cand, int n, int nx, double rx0,
+                                           double ry0, double cs, int ix0, int iy0, int max_agents, const SpawnTypes &st,
+                                           int N, const double *__restrict__ path,
+                                           const double *__restrict__ lane_yaw, int rnx, int rny, int &ci, double &px,
+                                           double &py, double &a) {
   const int m = n < max_agents ? n : max_agents;
-  if (j == 0 && lane == 0) *n_out = m;
-  if (j >= max_agents) return;
-  if (j >= m) {
-    if (lane == 0) { cell[j] = -1; pos[2 * j] = 0.0; pos[2 * j + 1] = 0.0; yaw[j] = 0.0; }
-    return;
-  }
+  ci = -1; px = 0.0; py = 0.0; a = 0.0;
+  if (j >= m) return false;
   const int pick = (n <= max_agents) ? j : (int)(((long long)j * n) / max_agents);
-  const int ci = cand[pick];
+  ci = cand[pick];
   const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
-  const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
+  px = rx0 + ((double)wx + 0.5) * cs;
+  py = ry0 + ((double)wy + 0.5) * cs;
   const int type = st.type[j & 3];
-  double a = NAN;
+  a = NAN;
   if (type != FO_TYPE_PEDESTRIAN && lane_yaw && wx >= 0 && wx < rnx && wy >= 0 && wy < rny)
     a = lane_yaw[(size_t)wy * rnx + wx];
   if (isnan(a)) {  // wave-uniform
@@ -945,7 +940,7 @@ __global__ __launch_bounds__(256) void fo_spawn_pick_kernel(const int32_t *__res
     a = atan2(uy, ux);
     if (a < 0.0) a += 2.0 * M_PI;
   }
-  if (lane == 0) { cell[j] = ci; pos[2 * j] = px; pos[2 * j + 1] = py; yaw[j] = a; }
+  return true;
 }
 
 // Predictions in the layout fo_sweep_set_agents consumes, one wave per prediction slot (j, r), r < R:
@@ -954,24 +949,27 @@ __global__ __launch_bounds__(256) void fo_spawn_pick_kernel(const int32_t *__res
 //     route_planner.py:31-90 + frenetix_handler.py + agent.py:283-426); the prediction ends where the route ends;
 //   pedestrian / off-lane vehicle / no route table -> r = 0: straight constant velocity (agent.py:451-536), r > 0 empty.
 // Slots of agents j >= n are inactive (len = 0).
-__global__ __launch_bounds__(64) void fo_spawn_predict_kernel(int max_agents, int R, const int32_t *__restrict__ n_ptr,
-                                                              const int32_t *__restrict__ cell,
-                                                              const double *__restrict__ pos0,
-                                                              const double *__restrict__ yaw0, SpawnTypes st, int T,
-                                                              double dt, double var0, double factor, int nx, int ix0,
-                                                              int iy0, int rnx, int rny,
-                                                              const int32_t *__restrict__ lanelet_raster, int RT,
-                                                              const int32_t *__restrict__ route_first,
-                                                              const int32_t *__restrict__ route_count,
-                                                              const double *__restrict__ route_xy,
-                                                              const double *__restrict__ route_s,
-                                                              double *__restrict__ pos, double *__restrict__ yaw,
-                                                              double *__restrict__ v, double *__restrict__ cov,
-                                                              double *__restrict__ shape, double *__restrict__ raw,
-                                                              int32_t *__restrict__ type, int32_t *__restrict__ len) {
+__global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
+    int max_agents, int R, const int32_t *__restrict__ cand, const int32_t *__restrict__ n_cand, double rx0, double ry0,
+    double cs, int n_path, const double *__restrict__ path, const double *__restrict__ lane_yaw, SpawnTypes st, int T,
+    double dt, double var0, double factor, int nx, int ix0, int iy0, int rnx, int rny,
+    const int32_t *__restrict__ lanelet_raster, int RT, const int32_t *__restrict__ route_first,
+    const int32_t *__restrict__ route_count, const double *__restrict__ route_xy, const double *__restrict__ route_s,
+    int32_t *__restrict__ cell, double *__restrict__ pos0, double *__restrict__ yaw0, int32_t *__restrict__ n_out,
+    double *__restrict__ pos, double *__restrict__ yaw, double *__restrict__ v, double *__restrict__ cov,
+    double *__restrict__ shape, double *__restrict__ raw, int32_t *__restrict__ type, int32_t *__restrict__ len) {
   const int lane = threadIdx.x;
   const int slot = blockIdx.x, j = slot / R, r = slot % R;
-  const bool on = j < *n_ptr;
+  // the pick of agent j (repeated by each of its R route slots: a few dozen path segments; saves a launch)
+  const int n_c = *n_cand;
+  int ci;
+  double p0x, p0y, a0;
+  const bool on = spawn_pick(j, lane, cand, n_c, nx, rx0, ry0, cs, ix0, iy0, max_agents, st, n_path, path, lane_yaw, rnx,
+                             rny, ci, p0x, p0y, a0);
+  if (r == 0 && lane == 0) {
+    cell[j] = ci; pos0[2 * j] = p0x; pos0[2 * j + 1] = p0y; yaw0[j] = a0;
+    if (j == 0) *n_out = n_c < max_agents ? n_c : max_agents;
+  }
   const int sdx = j & 3;
   const double spd = st.speed[sdx];
   double *P = pos + (size_t)slot * T * 2, *Y = yaw + (size_t)slot * T, *V = v + (size_t)slot * T;
@@ -987,26 +985,25 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(int max_agents, in
   }
   int ll = -1;
   if (on && lanelet_raster && st.type[sdx] != FO_TYPE_PEDESTRIAN) {
-    const int ci = cell[j];
     const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
     if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny) ll = lanelet_raster[(size_t)wy * rnx + wx];
   }
   const bool routed = on && ll >= 0 && r < RT && route_count[(size_t)ll * RT] > 0;
   int L = 0;
   if (on && !routed && r == 0) {  // straight constant velocity
-    const double a = yaw0[j];
+    const double a = a0;
     const double vx = __builtin_rint(spd * cos(a) * 1000.0) / 1000.0;  // round(v cos psi, 3)  (agent.py:492, Q12)
     const double vy = __builtin_rint(spd * sin(a) * 1000.0) / 1000.0;
     for (int k = lane; k < T; k += 64) {
       const double t = (double)k * dt;
-      P[2 * k] = pos0[2 * j] + t * vx; P[2 * k + 1] = pos0[2 * j + 1] + t * vy; Y[k] = a; V[k] = spd;
+      P[2 * k] = p0x + t * vx; P[2 * k + 1] = p0y + t * vy; Y[k] = a; V[k] = spd;
     }
     L = T;
   } else if (routed && route_count[(size_t)ll * RT + r] >= 2) {
     const int nv = route_count[(size_t)ll * RT + r];
     const double *q = route_xy + 2 * (size_t)route_first[(size_t)ll * RT + r];
     const double *sq = route_s + route_first[(size_t)ll * RT + r];
-    const double px = pos0[2 * j], py = pos0[2 * j + 1];
+    const double px = p0x, py = p0y;
     double best = INFINITY, s0 = 0.0, d0 = 0.0;
     int bi = 0x7fffffff;
     for (int i = lane; i + 1 < nv; i += 64) {  // closest point of the route: per lane ascending i, first minimum
@@ -1378,14 +1375,12 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
     st.type[i] = type4[i]; st.speed[i] = speed4[i]; st.raw_l[i] = raw_l4[i]; st.raw_w[i] = raw_w4[i];
     st.infl_l[i] = infl_l4[i]; st.infl_w[i] = infl_w4[i];
   }
-  hipLaunchKernelGGL(fo_spawn_pick_kernel, dim3((max_agents + 3) / 4), dim3(256), 0, s, sc->d_cand, sc->d_ncand, win_nx,
-                     sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, max_agents, st, n_path, d_path, sc->d_lane_yaw, sc->rnx,
-                     sc->rny, d_cell, d_pos0, d_yaw0, d_n);
   const int R = routes > 0 ? routes : 1;
-  hipLaunchKernelGGL(fo_spawn_predict_kernel, dim3(max_agents * R), dim3(64), 0, s, max_agents, R, d_n, d_cell, d_pos0,
-                     d_yaw0, st, T, dt, var0, var_factor, win_nx, win_ix0, win_iy0, sc->rnx, sc->rny,
-                     routes > 0 ? sc->d_lanelet_raster : nullptr, sc->R, sc->d_route_first, sc->d_route_count,
-                     sc->d_route_xy, sc->d_route_s, d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len);
+  hipLaunchKernelGGL(fo_spawn_predict_kernel, dim3(max_agents * R), dim3(64), 0, s, max_agents, R, sc->d_cand, sc->d_ncand,
+                     sc->x0, sc->y0, sc->cs, n_path, d_path, sc->d_lane_yaw, st, T, dt, var0, var_factor, win_nx, win_ix0,
+                     win_iy0, sc->rnx, sc->rny, routes > 0 ? sc->d_lanelet_raster : nullptr, sc->R, sc->d_route_first,
+                     sc->d_route_count, sc->d_route_xy, sc->d_route_s, d_cell, d_pos0, d_yaw0, d_n, d_pos, d_yaw, d_v,
+                     d_cov, d_shape, d_raw_dims, d_type, d_len);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
 }
