@@ -248,6 +248,26 @@ __global__ void fo_fan_kernel(int n, double yaw, double fov, int full, double r,
   }
 }
 
+// Sector of a uniform full fan (ray i at angle yaw + 2 pi i / n, ray 0 = dirs[0]): a float atan2 of the direction
+// rotated back by ray 0 proposes the index, the exact predicate of fan_sector (ccw(i) and not ccw(i + 1)) confirms it
+// or moves it by a step -- same answer as the binary search, a fraction of its dependent loads.
+__device__ __forceinline__ int fan_sector_uniform(int n_rays, const double *__restrict__ dirs, double rx, double ry) {
+  const float c0 = (float)dirs[0], s0 = (float)dirs[1];
+  const float fx = (float)rx, fy = (float)ry;
+  const float ang = atan2f(fy * c0 - fx * s0, fx * c0 + fy * s0);
+  int i = (int)floorf(ang * ((float)n_rays * 0.15915494309189535f));
+  if (i < 0) i += n_rays;
+  if (i >= n_rays) i -= n_rays;
+#pragma unroll 1
+  for (int it = 0; it < 3; ++it) {
+    const int j = i + 1 == n_rays ? 0 : i + 1;
+    const bool a = fan_ccw(n_rays, dirs, i, rx, ry), b = fan_ccw(n_rays, dirs, j, rx, ry);
+    if (a && !b) return i;
+    if (!a) i = i == 0 ? n_rays - 1 : i - 1; else i = j;
+  }
+  return fan_sector(n_rays, dirs, 1, rx, ry);
+}
+
 // ------------------------------------------------------------------------------------------------ rays + probes
 // One launch for the ray fan and the obstacle-visibility probes.  Workgroups [0, n_rays): one ray each, its five
 // waves scan interleaved fifths of the soup and the (t, id) minima are combined through LDS.  Workgroups
@@ -402,7 +422,8 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
     ry = py - ey;
     d2 = rx * rx + ry * ry;
     if ((c & 1) && d2 <= r2) {
-      const int i = fan_sector(n_rays, dirs, full, rx, ry);
+      // (the zero vector never confirms a proposal and falls through to fan_sector's -1)
+      const int i = full ? fan_sector_uniform(n_rays, dirs, rx, ry) : fan_sector(n_rays, dirs, full, rx, ry);
       if (rx == 0.0 && ry == 0.0) {
         visible = 1;
       } else if (i >= 0) {
@@ -568,24 +589,6 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
       }
     }
   }
-}
-
-// Sector of a uniform full fan (ray i at angle 2 pi i / n): a float atan2 proposes the index, the exact predicate of
-// fan_sector (ccw(i) and not ccw(i + 1)) confirms it or moves it by a step -- same answer as the binary search, a
-// fifth of the instructions.
-__device__ __forceinline__ int fan_sector_uniform(int n_rays, const double *__restrict__ dirs, double rx, double ry) {
-  const float ang = atan2f((float)ry, (float)rx);
-  int i = (int)floorf(ang * ((float)n_rays * 0.15915494309189535f));
-  if (i < 0) i += n_rays;
-  if (i >= n_rays) i -= n_rays;
-#pragma unroll 1
-  for (int it = 0; it < 3; ++it) {
-    const int j = i + 1 == n_rays ? 0 : i + 1;
-    const bool a = fan_ccw(n_rays, dirs, i, rx, ry), b = fan_ccw(n_rays, dirs, j, rx, ry);
-    if (a && !b) return i;
-    if (!a) i = i == 0 ? n_rays - 1 : i - 1; else i = j;
-  }
-  return fan_sector(n_rays, dirs, 1, rx, ry);
 }
 
 // ------------------------------------------------------------------------------------------------ future visibility
