@@ -60,7 +60,7 @@ int fo_sweep_check(fo_ctx *ctx, void *stream) {
   FO_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
   int st = 0;
   FO_HIP_TRY(ctx, hipMemcpy(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
-  if (st & 1)
+  if (st != 0 && st == ctx->status_gen)  // recorded by the latest fo_sweep_set_agents
     return fo_fail(ctx, FO_E_UNSUPPORTED_COV,
                    "agent covariance with non-zero off-diagonal terms: only diagonal covariances (what "
                    "agent.py:260-280 produces) are implemented; affected collision probabilities are NaN");

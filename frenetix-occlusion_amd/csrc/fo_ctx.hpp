@@ -26,7 +26,9 @@ struct fo_ctx {
   void *d_exp_tab = nullptr;        // 2^(j/64) table
   int32_t *d_agent_int = nullptr;   // [A][2] protection class, valid length
   size_t cap_agent_int = 0;
-  int *d_status = nullptr;          // device status word (bit 0: off-diagonal covariance met)
+  int *d_status = nullptr;          // device status word: generation of the last fo_sweep_set_agents call that met an
+                                    // off-diagonal covariance (compared with status_gen; never cleared, so no per-step memset)
+  int status_gen = 0;
   size_t cap_agent_tab = 0, cap_agent_const = 0;
 
   // ---- trajectory tile buffer + partial reductions (HBM workspace)

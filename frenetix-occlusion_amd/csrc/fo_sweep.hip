@@ -197,7 +197,7 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
                                       const double *__restrict__ shape, const double *__restrict__ raw,
                                       const int32_t *__restrict__ type, const int32_t *__restrict__ len,
                                       double ego_mass, double *__restrict__ tab, double *__restrict__ cst,
-                                      int32_t *__restrict__ aint, int *__restrict__ status) {
+                                      int32_t *__restrict__ aint, int *__restrict__ status, int gen) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A * Ta) return;
   const int k = i / Ta, t = i % Ta;
@@ -207,7 +207,7 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
   if (sxx == 0.0 && sxy == 0.0 && syx == 0.0 && syy == 0.0) { sxx = 0.1; syy = 0.1; }  // collision_probability.py:84-86
   double isx = 1.0 / (sqrt(sxx) * M_SQRT2), isy = 1.0 / (sqrt(syy) * M_SQRT2);
   if ((sxy != 0.0 || syx != 0.0) && t < len[k]) {  // general BVN not implemented: poison + status word
-    atomicOr(status, 1);
+    atomicMax(status, gen);
     isx = NAN;
     isy = NAN;
   }
@@ -1338,12 +1338,16 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
   if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(A > 0 ? A : 1) * 2))) return rc;
   ctx->A = A;
   ctx->Ta = Ta;
-  FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), s));
+  if (ctx->status_gen >= (1 << 30)) {  // generations never run out in practice; start over cleanly if they do
+    FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), s));
+    ctx->status_gen = 0;
+  }
+  const int gen = ++ctx->status_gen;
   if (A > 0) {
     const int n = A * Ta;
     hipLaunchKernelGGL(fo_prep_agents_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, Ta, d_pos, d_yaw, d_v, d_cov,
                        d_shape, d_raw_dims, d_type, d_len, ctx->veh.mass, ctx->d_agent_tab, ctx->d_agent_const,
-                       ctx->d_agent_int, ctx->d_status);
+                       ctx->d_agent_int, ctx->d_status, gen);
     FO_HIP_TRY(ctx, hipGetLastError());
   }
   return FO_OK;

@@ -203,6 +203,16 @@ def test_off_diagonal_covariance_fails_loudly(torch_cuda):
         sw.set_agents(agents["pos"], agents["yaw"], agents["v"], agents["cov"], agents["shape"], agents["raw_dims"],
                       agents["type"], agents["len"])
     assert e.value.code == N.FO_E_UNSUPPORTED_COV
+    # the condition belongs to that agent set only: a clean set on the same context passes, a bad one fails again
+    good = S.make_batch(10, 2, config_id=10)[1]
+    sw.set_agents(good["pos"], good["yaw"], good["v"], good["cov"], good["shape"], good["raw_dims"], good["type"],
+                  good["len"])
+    sw.set_agents(good["pos"], good["yaw"], good["v"], good["cov"], good["shape"], good["raw_dims"], good["type"],
+                  good["len"], check=False)
+    sw.ctx.call("fo_sweep_check", torch_cuda.cuda.current_stream().cuda_stream)
+    with pytest.raises(N.NativeError):
+        sw.set_agents(agents["pos"], agents["yaw"], agents["v"], agents["cov"], agents["shape"], agents["raw_dims"],
+                      agents["type"], agents["len"])
 
 
 def test_full_size_properties_10k_x_256(torch_cuda):
