@@ -1,0 +1,70 @@
+"""Soak / determinism run on the GPU box: the bench's planning step repeated n times on identical inputs; every
+per-trajectory cost vector, safety flag, phantom set and occluded-cell list must be bit-identical from the first step to
+the last (no atomics-order or stale-workspace effects), and the step time must not drift.
+usage: python tools/soak.py [n]"""
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "frenetix-occlusion_amd"))
+from frenetix_occlusion import _native as N, interface, scenario as SC, synthetic as S  # noqa: E402
+from frenetix_occlusion.sensor_model import SensorModel  # noqa: E402
+from frenetix_occlusion.spawn_locator import SpawnLocator  # noqa: E402
+from frenetix_occlusion.sweep import MetricSweep  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    dev = torch.device("cuda", 0)
+    ctx = N.Context(0)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.3, "risk": 0.2}, device=0, ctx=ctx)
+    sc = SC.synthetic_urban_grid()
+    ego = sc.ego_initial
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"].update(max_agents=256, all_occluded=True, max_dist=45.0)
+    ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+    sm = SensorModel(sc.lanelets, ref_path, sensor_radius=50.0, sensor_angle=360.0, ctx=ctx)
+    sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
+    sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1, horizon=3.0)
+    traj = S.make_trajectories(10000, 31, 0.1, seed=7, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    t = {k: torch.as_tensor(v).to(dev) for k, v in traj.items()}
+    out = None
+
+    def step():
+        nonlocal out
+        sm.launch(ego[:2], float(ego[2]))
+        b = sl.sample(ego[:2], float(ego[2]), float(ego[3]))
+        sw.set_agents(*b.sweep_args(), check=False)
+        out = sw.run(t["x"], t["y"], t["theta"], t["v"], t["a"], mode="full", out=out)
+        return b
+
+    b = step()
+    torch.cuda.synchronize()
+    ref = dict(cost=out.cost.clone(), safe=out.safe.clone(), cls=sm.cell_class.clone(), occ=sm.occluded_cells().clone(),
+               pos=b.pos.clone(), lists_sum=out.lists.nan_to_num().sum().item(), pair_i=out.pair_i.clone())
+    times = []
+    for blk in range(n // 100):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            b = step()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / 100 * 1e3)
+        assert torch.equal(out.cost.nan_to_num(), ref["cost"].nan_to_num()) and torch.equal(out.safe, ref["safe"])
+        assert torch.equal(sm.cell_class, ref["cls"]) and torch.equal(sm.occluded_cells(), ref["occ"])
+        assert torch.equal(b.pos, ref["pos"]) and torch.equal(out.pair_i, ref["pair_i"])
+        assert out.lists.nan_to_num().sum().item() == ref["lists_sum"]
+    sw.ctx.call("fo_sweep_check", torch.cuda.current_stream().cuda_stream)
+    print(f"{n} steps bit-identical; ms per step by block of 100: first {times[0]:.4f}, min {min(times):.4f}, "
+          f"median {np.median(times):.4f}, last {times[-1]:.4f}")
+
+
+if __name__ == "__main__":
+    main()
