@@ -172,20 +172,20 @@ def main():
             dist.all_gather_into_tensor(gathered, out.cost)
 
     # Set-up, before the W warm-up steps: pick the sweep kernel's agents-per-wave for this batch shape by timing the
-    # real step (4 candidates x (10 + 60) steps, ~0.25 s).  The same pass brings the GPU to its sustained clocks: a
+    # real step (4 candidates x (20 + 100) steps, ~0.4 s).  The same pass brings the GPU to its sustained clocks: a
     # cold MI355X runs the first few dozen steps 10-15 % slower, so without it the result would depend on W.
     tune = {}
     if not os.environ.get("FO_SWEEP_APW") and not args.no_autotune:
         for apw in (1, 2, 4, 8):
             os.environ["FO_SWEEP_APW"] = str(apw)
-            for _ in range(10):
+            for _ in range(20):
                 step()
             torch.cuda.synchronize()
             t_a = time.perf_counter()
-            for _ in range(60):
+            for _ in range(100):
                 step()
             torch.cuda.synchronize()
-            tune[apw] = (time.perf_counter() - t_a) / 60
+            tune[apw] = (time.perf_counter() - t_a) / 100
         os.environ["FO_SWEEP_APW"] = str(min(tune, key=tune.get))
     for _ in range(args.warmup):
         step()
@@ -196,7 +196,8 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    sw.ctx.timing(True)
+    # HIP events around the sweep kernel of every timed step (FO_BENCH_TIME_EVERY=k: every k-th; measured: no gain)
+    sw.ctx.timing(True, every=int(os.environ.get("FO_BENCH_TIME_EVERY", "1")))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -43,6 +43,7 @@ struct fo_ctx {
   // ---- last launch (profiling aid) + optional HIP-event timing of the sweep kernel alone
   int last_grid = 0, last_block = 0, last_apw = 0;
   bool timing = false;
+  int timing_stride = 1, n_launch = 0;  // every timing_stride-th launch is timed
   static constexpr int kMaxTimed = 1024;
   hipEvent_t *ev_start = nullptr, *ev_stop = nullptr;
   int n_timed = 0;

@@ -1409,7 +1409,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     }
     const int grid = a.nt8 * 8 * n_chunks;
     ctx->last_grid = grid; ctx->last_block = TILE * wpb; ctx->last_apw = apw;
-    const bool timed = ctx->timing && ctx->n_timed < fo_ctx::kMaxTimed;
+    const bool timed = ctx->timing && ctx->n_timed < fo_ctx::kMaxTimed && (ctx->n_launch++ % ctx->timing_stride) == 0;
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[ctx->n_timed], s));
     const dim3 g(grid), b(TILE * wpb);
     if (use_queue) {
@@ -1460,6 +1460,8 @@ int fo_sweep_timing(fo_ctx *ctx, int enable) {
     }
   }
   ctx->timing = enable != 0;
+  ctx->timing_stride = enable > 1 ? enable : 1;  // enable = k > 1: every k-th launch carries the event pair
+  ctx->n_launch = 0;
   ctx->n_timed = 0;
   return FO_OK;
 }

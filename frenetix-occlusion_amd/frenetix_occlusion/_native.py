@@ -142,8 +142,9 @@ class Context:
     def call(self, name, *args):
         self._check(getattr(self._lib, name)(self._h, *args))
 
-    def timing(self, enable=True):
-        self.call("fo_sweep_timing", 1 if enable else 0)
+    def timing(self, enable=True, every=1):
+        """HIP-event timing of the sweep kernel; every = k > 1 times every k-th launch only"""
+        self.call("fo_sweep_timing", (max(int(every), 1) if enable else 0))
 
     def timing_read(self):
         ms, n = C.c_double(), C.c_int()

@@ -101,7 +101,9 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
 int fo_sweep_check(fo_ctx *ctx, void *stream);
 
 /* HIP-event timing of the sweep kernel alone (events recorded on the launch stream around that one kernel):
- * enable, run K times (K <= 1024), then read the summed duration.  fo_sweep_timing_read synchronises. */
+ * enable, run K times (at most 1024 timed launches), then read the summed duration and the number of timed launches.
+ * enable = k > 1 puts the event pair around every k-th launch only (the two event records cost a few microseconds of
+ * stream time each).  fo_sweep_timing_read synchronises. */
 int fo_sweep_timing(fo_ctx *ctx, int enable);
 int fo_sweep_timing_read(fo_ctx *ctx, double *total_ms, int *launches);
 
