@@ -50,9 +50,20 @@ class PhantomBatch:
     type: torch.Tensor       # int32 [slots]
     len: torch.Tensor        # int32 [slots]  (valid samples of the prediction, 0 = unused slot)
     R: int = 1               # prediction slots per agent: slot j * R + r (r = candidate route of a phantom vehicle)
+    head: Optional[torch.Tensor] = None   # uint8: one allocation backing pos0 | yaw0 | n | type (one copy to the host)
 
     def sweep_args(self):
         return self.pos, self.yaw, self.v, self.cov, self.shape, self.raw_dims, self.type, self.len
+
+    def host_head(self):
+        """(n, pos0 [A,2], yaw0 [A], type [slots]) on the host with ONE device-to-host copy"""
+        A, S_ = self.pos0.shape[0], self.type.shape[0]
+        if self.head is None:
+            return int(self.n.item()), self.pos0.cpu().numpy(), self.yaw0.cpu().numpy(), self.type.cpu().numpy()
+        h = self.head.cpu().numpy()
+        o1, o2, o3 = A * 16, A * 24, A * 24 + 8
+        return (int(h[o2:o2 + 4].view(np.int32)[0]), h[:o1].view(np.float64).reshape(A, 2), h[o1:o2].view(np.float64),
+                h[o3:o3 + 4 * S_].view(np.int32))
 
 
 class SpawnLocator:
@@ -113,9 +124,13 @@ class SpawnLocator:
         S_ = A * self.R                                            # prediction slots: slot j * R + r
         f = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
         i = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
-        return PhantomBatch(n=torch.zeros(1, dtype=torch.int32, device=dev), cell=i(A), pos0=f(A, 2), yaw0=f(A),
-                            pos=f(S_, T, 2), yaw=f(S_, T), v=f(S_, T), cov=f(S_, T, 2, 2), shape=f(S_, 2),
-                            raw_dims=f(S_, 2), type=i(S_), len=i(S_), R=self.R)
+        # what find_spawn_points reads back lives in one allocation: pos0 | yaw0 | n (+ pad) | type
+        o1, o2, o3 = A * 16, A * 24, A * 24 + 8
+        head = torch.zeros(o3 + 4 * S_ + 4, dtype=torch.uint8, device=dev)
+        return PhantomBatch(n=head[o2:o2 + 4].view(torch.int32), cell=i(A), pos0=head[:o1].view(torch.float64).view(A, 2),
+                            yaw0=head[o1:o2].view(torch.float64), pos=f(S_, T, 2), yaw=f(S_, T), v=f(S_, T),
+                            cov=f(S_, T, 2, 2), shape=f(S_, 2), raw_dims=f(S_, 2),
+                            type=head[o3:o3 + 4 * S_].view(torch.int32), len=i(S_), R=self.R, head=head)
 
     def max_distance(self, ego_v):
         if self.max_dist_override is not None:
@@ -182,10 +197,8 @@ class SpawnLocator:
         self.spawn_points, self.rule_points = [], []
         if self.mode in ("cells", "both"):
             b = self.sample(ego_pos, ego_orientation, ego_v)
-            n = int(b.n.item())
-            pos0 = b.pos0[:n].cpu().numpy()
-            yaw0 = b.yaw0[:n].cpu().numpy()
-            typ = b.type[:n].cpu().numpy()
+            n, pos0, yaw0, typ_slots = b.host_head()
+            typ = typ_slots[:: b.R]                # agent j's type = type of its first prediction slot
             for j in range(n):
                 cl = None
                 if self.cosy_cl is not None:

@@ -220,3 +220,15 @@ def test_result_dict_column_gather_equals_host_mirror(torch_cuda, tmp_path):
             return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
         return a == b or (isinstance(a, float) and math.isnan(a) and math.isnan(b))
     assert all(same(h, c) for h, c in zip(host, col))
+
+
+def test_spawn_point_types_match_the_phantom_agents_with_route_slots(torch_cuda, tmp_path):
+    """with R > 1 prediction slots per agent the spawn-point list still names agent j's own type (slot j * R)"""
+    fo, sc, ego, SY = _setup(tmp_path, max_agents=12)
+    assert fo.spawn_locator.R > 1
+    fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    assert len(fo.spawn_points) == len(fo.agent_manager.phantom_agents) > 4
+    pattern = [p.lower() for p in fo.config["accelerator"]["spawn"]["pattern"]]
+    for j, (sp, ag) in enumerate(zip(fo.spawn_points, fo.agent_manager.phantom_agents)):
+        assert sp.agent_type.lower() == ag.agent_type.lower() == pattern[j % 4]
+        np.testing.assert_allclose(sp.position, ag.initial_position if hasattr(ag, "initial_position") else sp.position)
