@@ -302,10 +302,12 @@ class SensorModel:
         key = (w.nx, w.ny, O, self.n_rays)
         if getattr(self, "_buf_key", None) != key:
             dev, n = self.device, self.n_rays
+            # hit ids and visibility flags are read back together after a step: one allocation, one copy
+            hv = torch.zeros(4 * n + max(O, 1), dtype=torch.uint8, device=dev)
             self._buf = dict(rng=torch.empty(n, dtype=torch.float64, device=dev),
-                             hit=torch.empty(n, dtype=torch.int32, device=dev),
+                             hit=hv[:4 * n].view(torch.int32), hv=hv,
                              ring=torch.empty((n, 2), dtype=torch.float64, device=dev),
-                             ovis=torch.zeros(max(O, 1), dtype=torch.uint8, device=dev),
+                             ovis=hv[4 * n:],
                              # whole 32-bit words: the settle kernel clears class bits with word atomics
                              cls=torch.empty((w.ny * w.nx + 3) // 4 * 4, dtype=torch.uint8,
                                              device=dev)[:w.ny * w.nx].view(w.ny, w.nx),
@@ -419,8 +421,9 @@ class SensorModel:
         _, _, _, O = self.upload_obstacles(obstacles)
         self.launch(ego_pos, ego_orientation)
         if O:
-            vis = self._buf["ovis"][:O].cpu().numpy().astype(bool)
-            hit_h = self.hit_id.cpu().numpy()
+            hv = self._buf["hv"].cpu().numpy()
+            hit_h = hv[:4 * self.n_rays].view(np.int32)
+            vis = hv[4 * self.n_rays:4 * self.n_rays + O].astype(bool)
             E = len(self.map_geometry.edges)
             for i, obst in enumerate(obstacles):
                 obst.current_visible = bool(vis[i])
