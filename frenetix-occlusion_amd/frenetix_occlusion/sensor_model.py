@@ -291,8 +291,15 @@ class SensorModel:
         dev = self.device
         if obstacles is not None and len(obstacles) > 0:
             corn, cen, flags = obstacles.arrays() if hasattr(obstacles, "arrays") else obstacles
-            self._obst = (torch.as_tensor(np.ascontiguousarray(corn)).to(dev), torch.as_tensor(np.ascontiguousarray(cen)).to(dev),
-                          torch.as_tensor(np.ascontiguousarray(flags)).to(dev), len(flags))
+            O = len(flags)
+            # one host buffer, one copy: corners [O,4,2] | centres [O,2] | flags [O]
+            host = np.empty(O * 81, dtype=np.uint8)
+            host[:O * 64].view(np.float64)[:] = np.asarray(corn, dtype=np.float64).reshape(-1)
+            host[O * 64:O * 80].view(np.float64)[:] = np.asarray(cen, dtype=np.float64).reshape(-1)
+            host[O * 80:] = np.asarray(flags, dtype=np.uint8)
+            d = torch.as_tensor(host).to(dev)
+            self._obst = (d[:O * 64].view(torch.float64).view(O, 4, 2), d[O * 64:O * 80].view(torch.float64).view(O, 2),
+                          d[O * 80:], O)
         else:
             self._obst = (None, None, None, 0)
         return self._obst
