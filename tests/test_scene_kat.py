@@ -358,3 +358,38 @@ def test_every_direction_of_a_full_fan_has_a_sector(oracle, n_rays):
     inner = d <= r * math.cos(math.pi / n_rays) - 1e-9           # inside the inscribed circle of the ray polygon
     assert vis[inner].all()
     assert not vis[d > r].any()
+
+
+def test_edge_lines_chain_collinear_pieces_and_stop_at_corners_and_junctions():
+    """an L-shaped kerb sampled every metre: two chains (one per leg); a third piece touching the corner makes the
+    corner a junction; a detached piece is its own chain"""
+    leg1 = np.array([[x, 0.0, x + 1.0, 0.0] for x in range(10)], float)            # (0,0) -> (10,0)
+    leg2 = np.array([[10.0, y, 10.0, y + 1.0] for y in range(5)], float)           # (10,0) -> (10,5)
+    far = np.array([[30.0, 30.0, 31.0, 30.0]])
+    e = np.concatenate((leg1, leg2, far))
+    lab = S.edge_lines(e)
+    assert len(set(lab[:10])) == 1 and len(set(lab[10:15])) == 1 and lab[0] != lab[10] and lab[15] not in (lab[0], lab[10])
+    # reversed piece orientation does not matter
+    e2 = e.copy()
+    e2[3] = e2[3][[2, 3, 0, 1]]
+    assert len(set(S.edge_lines(e2)[:10])) == 1
+    # a junction (three pieces meeting at (5,0)) stops the chain there
+    e3 = np.concatenate((e, np.array([[5.0, 0.0, 5.0, -3.0]])))
+    lab3 = S.edge_lines(e3)
+    assert len(set(lab3[:5])) == 1 and len(set(lab3[5:10])) == 1 and lab3[0] != lab3[5]
+    # a slight bend (1e-6 rad) is not a straight continuation at the default tolerance
+    bent = np.array([[0.0, 0.0, 1.0, 0.0], [1.0, 0.0, 2.0, 1e-6]])
+    assert len(set(S.edge_lines(bent))) == 2 and len(set(S.edge_lines(bent, sin_tol=1e-5))) == 1
+
+
+def test_spatial_order_is_a_permutation_that_groups_neighbours():
+    rng = np.random.default_rng(3)
+    p = rng.uniform(0, 500, (2000, 2))
+    e = np.concatenate((p, p + rng.normal(0, 1, (2000, 2))), axis=1)
+    o = S.spatial_order(e)
+    assert sorted(map(tuple, o)) == sorted(map(tuple, e))                   # same pieces
+    def mean_box(a):
+        a = a[: len(a) // 64 * 64].reshape(-1, 64, 4)
+        return float(np.mean((a[:, :, [0, 2]].max((1, 2)) - a[:, :, [0, 2]].min((1, 2))) *
+                             (a[:, :, [1, 3]].max((1, 2)) - a[:, :, [1, 3]].min((1, 2)))))
+    assert mean_box(o) < 0.1 * mean_box(e)                                  # 64 consecutive pieces cover a small patch
