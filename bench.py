@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--T", type=int, default=31)
     ap.add_argument("--scene", default="urban", choices=["urban", "scenario1", "synthetic"],
                     help="urban: full planning step on the synthetic urban grid; synthetic: sweep only, fixed agents")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --M trajectories per rank; strong: --M trajectories in total, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="skip the agents-per-wave selection pass of the set-up")
     ap.add_argument("--order", default="sampler", choices=["sampler", "random"],
@@ -119,6 +121,8 @@ def main():
     torch.cuda.set_device(dev)
 
     M, A, T = args.M, args.A, args.T
+    if args.scaling == "strong":      # BASELINE configs[3] read literally: ONE batch of --M trajectories split over the ranks
+        M = (M + world - 1) // world
     thr = {"harm": 0.1, "risk": 1}   # configurations/simulation/occlusion.yaml:20-28 of the reference's example
     ctx = N.Context(local_rank)
     sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds=thr, device=local_rank, ctx=ctx)
@@ -249,7 +253,7 @@ def main():
         res = {
             "metric": "trajectory_x_agent_metric_evals_per_sec", "value": pairs / elapsed, "unit": "pair-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: synthetic urban lanelet net, 10k trajectories x 256 phantoms, "
                                     "360 deg ray-cast @ 0.5 deg, T=31 (full planning step; per-rank trajectory shard when "
                                     "n_gpus>1)") if args.scene == "urban" else
