@@ -201,12 +201,15 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A * Ta) return;
   const int k = i / Ta, t = i % Ta;
+  // valid length clamped to the table: the sweep indexes rows with min(t, L-1) and assumes L <= Ta; a longer claim
+  // would read the next agent's rows
+  const int L = min(max(len[k], 0), Ta);
   double sn, cs;
   sincos(yaw[i], &sn, &cs);
   double sxx = cov[4 * (size_t)i], sxy = cov[4 * (size_t)i + 1], syx = cov[4 * (size_t)i + 2], syy = cov[4 * (size_t)i + 3];
   if (sxx == 0.0 && sxy == 0.0 && syx == 0.0 && syy == 0.0) { sxx = 0.1; syy = 0.1; }  // collision_probability.py:84-86
   double isx = 1.0 / (sqrt(sxx) * M_SQRT2), isy = 1.0 / (sqrt(syy) * M_SQRT2);
-  if ((sxy != 0.0 || syx != 0.0) && t < len[k]) {  // general BVN not implemented: poison + status word
+  if ((sxy != 0.0 || syx != 0.0) && t < L) {  // general BVN not implemented: poison + status word
     atomicMax(status, gen);
     isx = NAN;
     isy = NAN;
@@ -219,9 +222,9 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
     double *c = cst + (size_t)k * NAC;
     c[0] = 0.5 * raw[2 * k]; c[1] = 0.5 * raw[2 * k + 1]; c[2] = shape[2 * k] / 2.0;
     c[3] = m_obs / (ego_mass + m_obs); c[4] = ego_mass / (ego_mass + m_obs);
-    c[5] = (double)fo_obstacle_protection(type[k]); c[6] = (double)len[k]; c[7] = (double)type[k];
+    c[5] = (double)fo_obstacle_protection(type[k]); c[6] = (double)L; c[7] = (double)type[k];
     aint[2 * k] = fo_obstacle_protection(type[k]);
-    aint[2 * k + 1] = len[k];
+    aint[2 * k + 1] = L;
   }
 }
 
@@ -1197,7 +1200,8 @@ __global__ __launch_bounds__(64 * RED_WAVES) void fo_reduce_kernel(int M, int Mp
                                                                    fo_thresholds_t thr, uint32_t mask,
                                                                    const double *__restrict__ be_btn,
                                                                    double *__restrict__ cost,
-                                                                   uint8_t *__restrict__ safe) {
+                                                                   uint8_t *__restrict__ safe,
+                                                                   const int *__restrict__ status, int gen) {
   __shared__ double sh[RED_WAVES][NPS + 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 64 + lane;
@@ -1254,6 +1258,13 @@ __global__ __launch_bounds__(64 * RED_WAVES) void fo_reduce_kernel(int M, int Mp
     if ((mask & FO_M_TTC) && min_ttc < thr.ttc) ok = false;
     if ((mask & FO_M_DCE) && flag > 0.0) ok = false;
     if ((mask & FO_M_BE) && max_btn > thr.be) ok = false;  // metric.py:54-61
+    // The current agent set holds an off-diagonal covariance (fo_prep_agents_kernel poisoned those rows and tagged
+    // the status word with this generation): fmax() above drops the NaNs, so say it here -- nothing that depends
+    // on a collision probability may read as "safe", whether or not the caller runs fo_sweep_check.
+    if ((mask & (FO_M_CP | FO_M_HR)) && gen > 0 && *status == gen) {
+      ok = false;
+      max_cp = max_er = max_or = max_hwc = NAN;
+    }
   }
   double *c = cost + (size_t)m * FO_NC;
   c[FO_C_WTTC] = min_ttc; c[FO_C_MIN_DCE] = min_dce; c[FO_C_MAX_EGO_RISK] = max_er; c[FO_C_MAX_OBST_RISK] = max_or;
@@ -1443,7 +1454,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     be_btn = ctx->d_be_btn;
   }
   hipLaunchKernelGGL(fo_reduce_kernel, dim3((M + 63) / 64), dim3(64 * RED_WAVES), 0, s, M, Mp, A, n_chunks, ctx->d_partial,
-                     ctx->thr, ctx->mask, be_btn, d_cost, d_safe);
+                     ctx->thr, ctx->mask, be_btn, d_cost, d_safe, ctx->d_status, ctx->status_gen);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
 }

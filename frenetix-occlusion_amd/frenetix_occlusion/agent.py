@@ -42,20 +42,50 @@ class FOAgentManager:
         self._manual = []             # agents added through add_agent() (host-side predictions)
         self._pred_cache = None
         self.all_obstacle_id = [getattr(o, "obstacle_id", None) for o in getattr(scenario, "obstacles", [])]
+        self._step_ids = []           # ids minted for this step's phantoms; handed back by reset()
 
     # ---- reference API ------------------------------------------------------------------------------------
     def reset(self):
         self._batch, self._n_batch, self._batch_agents = None, 0, None
         self._manual = []
         self._pred_cache = None
+        self._release_step_ids()
+
+    def _release_step_ids(self):
+        """hand back the ids of phantoms that no longer exist; ids of the scenario's obstacles and of agents added
+        to the scenario (``real_agents``) stay taken.  The reference never releases (agent.py:189-199 only appends),
+        which is harmless at its ~5 phantoms per step but would drain the 1001-value range in 4 steps at 256."""
+        if self._step_ids:
+            keep = {a.agent_id for a in self.real_agents}
+            drop = {i for i in self._step_ids if i not in keep}
+            self.all_obstacle_id = [i for i in self.all_obstacle_id if i not in drop]
+            self._step_ids = []
+
+    ID_RANGE = (10000, 11000)        # agent.py:191
+    ID_RANGE_WIDE = (11001, 99999)   # still five digits, so agent_by_prediction_id's str(pid)[:5] keeps working
 
     def _create_id(self):
-        """agent.py:189-199: unique random id in [10000, 11000]"""
-        while True:
-            i = randint(10000, 11000)
-            if i not in self.all_obstacle_id:
-                self.all_obstacle_id.append(i)
-                return i
+        """agent.py:189-199: unique random id in [10000, 11000].  Bounded: a few random draws, then the first free
+        value of the range, then the wider five-digit range; raises when every five-digit id is taken instead of
+        spinning."""
+        taken = set(self.all_obstacle_id)
+        lo, hi = self.ID_RANGE
+        i = None
+        for _ in range(8):
+            c = randint(lo, hi)
+            if c not in taken:
+                i = c
+                break
+        if i is None:
+            for rng in (self.ID_RANGE, self.ID_RANGE_WIDE):
+                i = next((c for c in range(rng[0], rng[1] + 1) if c not in taken), None)
+                if i is not None:
+                    break
+        if i is None:
+            raise RuntimeError("FOAgentManager: no free five-digit agent id left")
+        self.all_obstacle_id.append(i)
+        self._step_ids.append(i)
+        return i
 
     def _velocity(self, velocity, conf, allow_lanelet):
         if velocity == "default":
@@ -224,6 +254,10 @@ class FOAgentManager:
     # ---- device side ------------------------------------------------------------------------------------------
     def attach_batch(self, batch: PhantomBatch, n_active: int):
         """take over the spawn kernel's output (n_active slots are live)"""
+        if self._batch_agents:                       # ids of the batch being replaced
+            gone = {a.agent_id for a in self._batch_agents}
+            self.all_obstacle_id = [i for i in self.all_obstacle_id if i not in gone]
+            self._step_ids = [i for i in self._step_ids if i not in gone]
         self._batch, self._n_batch, self._batch_agents = batch, int(n_active), None
         self._pred_cache = None
 

@@ -194,12 +194,14 @@ class Metric:
         self._agents_version = None
         self._batch = None
         self._batch_ids = {}
+        self._batch_objs = []
 
     def invalidate(self):
         """call when the phantom set changed (FOInterface.evaluate_scenario does)"""
         self._agents_version = None
         self._batch = None
         self._batch_ids = {}
+        self._batch_objs = []
 
     def _upload_agents(self):
         if self._agents_version is not None:
@@ -220,7 +222,10 @@ class Metric:
         ba = BatchAssessment(res, slots, self.metrics, mode)
         if remember is not None:
             self._batch = ba
-            self._batch_ids = {id(t): i for i, t in enumerate(remember)}
+            # strong references: id() is only unique among live objects, and the planner may drop its list and
+            # build new trajectory objects (re-sampling at a higher density) before asking for single results
+            self._batch_objs = list(remember)
+            self._batch_ids = {id(t): i for i, t in enumerate(self._batch_objs)}
         return ba
 
     def evaluate_metrics(self, trajectory):
@@ -228,6 +233,8 @@ class Metric:
         if not self.agent_manager.has_phantoms() or not self.metrics:
             return {}, True
         m = self._batch_ids.get(id(trajectory)) if self._batch is not None else None
+        if m is not None and self._batch_objs[m] is not trajectory:
+            m = None
         if m is not None and self._batch.mode == "full":
             return self._batch.result_dict(m)
         ba = self.evaluate_batch([trajectory], mode="full")

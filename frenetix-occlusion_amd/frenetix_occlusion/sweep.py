@@ -85,13 +85,33 @@ class MetricSweep:
         if check:
             self.ctx.call("fo_sweep_check", self._stream())
 
+    def _check_out(self, out, M, T, A, mode):
+        """a reused SweepResult must match the batch: the kernels write with the strides of the *current* M/A/T"""
+        want = {"cost": ((M, N.NC), torch.float64), "safe": ((M,), torch.uint8),
+                "pair_f": ((N.NPF, A, M), torch.float64) if mode in ("pair", "full") else None,
+                "pair_i": ((N.NPI, A, M), torch.int32) if mode in ("pair", "full") else None,
+                "lists": ((N.NL, A, max(T - 1, 0), M), torch.float64) if mode == "full" else None}
+        for name, w in want.items():
+            t = getattr(out, name)
+            if w is None:
+                if t is not None:
+                    raise ValueError(f"out.{name} is set but mode '{mode}' does not write it")
+                continue
+            if t is None or tuple(t.shape) != w[0] or t.dtype != w[1] or t.device != self.device or not t.is_contiguous():
+                got = None if t is None else (tuple(t.shape), t.dtype, str(t.device))
+                raise ValueError(f"out.{name}: need contiguous {w[0]} {w[1]} on {self.device}, got {got}")
+
     def run(self, x, y, theta, v, a=None, mode="reduced", out: Optional[SweepResult] = None) -> SweepResult:
         """x,y,theta,v[,a]: [M,T].  mode: 'reduced' (cost+safe), 'pair' (+ per-pair scalars), 'full' (+ lists)."""
         x, y, theta, v = self._dev(x), self._dev(y), self._dev(theta), self._dev(v)
         a = self._dev(a) if a is not None else None
         M, T = int(x.shape[0]), int(x.shape[1])
         A = self.A
-        if out is None:
+        if mode not in ("reduced", "pair", "full"):
+            raise ValueError(f"unknown output mode '{mode}'")
+        if out is not None:
+            self._check_out(out, M, T, A, mode)
+        else:
             out = SweepResult(cost=torch.empty((M, N.NC), dtype=torch.float64, device=self.device),
                               safe=torch.empty((M,), dtype=torch.uint8, device=self.device))
             if mode in ("pair", "full"):

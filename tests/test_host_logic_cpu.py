@@ -124,3 +124,64 @@ def test_no_gpu_interface_refuses_to_start():
     with pytest.raises(RuntimeError):
         interface.FOInterface(sc, np.zeros((2, 2)), SimpleNamespace(length=4.5, width=1.6, wb_rear_axle=1.4, mass=1000.0,
                                                                      a_max=11.5), 0.1)
+
+
+def _bare_agent_manager(ids=()):
+    """FOAgentManager without a GPU: only the id bookkeeping is exercised"""
+    from frenetix_occlusion.agent import FOAgentManager
+    sc = SimpleNamespace(obstacles=[SimpleNamespace(obstacle_id=i) for i in ids])
+    return FOAgentManager(sc, np.array([[0.0, 0.0], [10.0, 0.0]]), {}, 0, device="cpu")
+
+
+def test_agent_ids_are_released_every_step():
+    """agent.py:189-199 draws from 1001 values and never hands them back; 32 phantoms per step must not drain the
+    pool (it used to spin forever at step 31)"""
+    am = _bare_agent_manager(ids=(10005, 10500, 42))
+    for step in range(300):
+        ids = [am._create_id() for _ in range(32)]
+        assert len(set(ids)) == 32 and all(10000 <= i <= 11000 for i in ids)
+        assert 10005 not in ids and 10500 not in ids
+        assert len(am.all_obstacle_id) == 3 + 32
+        am.reset()
+        assert sorted(am.all_obstacle_id) == [42, 10005, 10500]
+
+
+def test_agent_ids_of_scenario_agents_stay_taken_and_pool_exhaustion_raises():
+    from frenetix_occlusion.agent import FOAgentManager, PhantomAgent
+    am = _bare_agent_manager()
+    keep = am._create_id()
+    am.real_agents.append(PhantomAgent(keep, "Pedestrian", np.zeros(2), 0.0, 1.4, 0.5, 0.5))   # add_to_scenario=True
+    am.reset()
+    assert am.all_obstacle_id == [keep]
+    # more agents than the reference's range holds: spills into the remaining five-digit ids, still unique
+    ids = [am._create_id() for _ in range(1200)]
+    assert len(set(ids)) == 1200 and keep not in ids and all(10000 <= i <= 99999 for i in ids)
+    am.reset()
+    am.ID_RANGE, am.ID_RANGE_WIDE = (10000, 10003), (10004, 10005)
+    got = [am._create_id() for _ in range(6 - (10000 <= keep <= 10005))]
+    assert len(set(got)) == len(got)
+    with pytest.raises(RuntimeError):
+        am._create_id()
+
+
+def test_served_from_batch_checks_object_identity():
+    """the per-trajectory cache is keyed by id(); a new object at a recycled address must not be served another
+    trajectory's result (metric.py of this package, evaluate_metrics)"""
+    from frenetix_occlusion.metrics.metric import Metric
+    m = Metric.__new__(Metric)
+    m.metrics = ["dce"]
+    m.agent_manager = SimpleNamespace(has_phantoms=lambda: True)
+    served = []
+    m._batch = SimpleNamespace(mode="full", result_dict=lambda i: served.append(i) or ({"i": i}, True))
+    objs = [SimpleNamespace(tag=i) for i in range(4)]
+    m._batch_objs = list(objs)
+    m._batch_ids = {id(t): i for i, t in enumerate(objs)}
+    assert m.evaluate_metrics(objs[2]) == ({"i": 2}, True)
+    stranger = SimpleNamespace(tag=99)
+    m._batch_ids[id(stranger)] = 1                     # what address reuse after the planner dropped its list looks like
+    fresh = []
+    m.evaluate_batch = lambda trajs, mode="full": fresh.append(trajs) or SimpleNamespace(result_dict=lambda i: ({"new": 1}, False))
+    assert m.evaluate_metrics(stranger) == ({"new": 1}, False)
+    assert fresh and fresh[0][0] is stranger and served == [2]
+    m.invalidate()
+    assert m._batch is None and m._batch_objs == [] and m._batch_ids == {}

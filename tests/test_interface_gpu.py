@@ -232,3 +232,27 @@ def test_spawn_point_types_match_the_phantom_agents_with_route_slots(torch_cuda,
     for j, (sp, ag) in enumerate(zip(fo.spawn_points, fo.agent_manager.phantom_agents)):
         assert sp.agent_type.lower() == ag.agent_type.lower() == pattern[j % 4]
         np.testing.assert_allclose(sp.position, ag.initial_position if hasattr(ag, "initial_position") else sp.position)
+
+
+def test_many_planning_steps_do_not_exhaust_the_agent_ids(torch_cuda, tmp_path):
+    """the reference API mints one id per phantom per step (agent.py:189-199, 1001 values); 250 steps at 32 phantoms
+    through phantom_agents / predictions / agent_by_prediction_id must neither hang nor collide"""
+    fo, sc, ego, SY = _setup(tmp_path, max_agents=32)
+    scenario_ids = {o.obstacle_id for o in sc.obstacles}
+    traj = SY.make_trajectories(8, seed=5, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    objs = _traj_objects(traj)
+    n_seen = 0
+    for step in range(250):
+        fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+        agents = fo.agent_manager.phantom_agents
+        ids = [a.agent_id for a in agents]
+        assert len(set(ids)) == len(ids) and not (set(ids) & scenario_ids)
+        assert all(10000 <= i <= 99999 for i in ids)
+        n_seen += len(ids)
+        if step % 50 == 0:
+            preds = fo.agent_manager.predictions
+            assert all(fo.agent_manager.agent_by_prediction_id(pid) is not None for pid in preds)
+            res, safe = fo.trajectory_safety_assessment(objs[0])
+            assert isinstance(safe, bool)
+        assert len(fo.agent_manager.all_obstacle_id) <= len(scenario_ids) + len(ids) + len(fo.agent_manager.real_agents)
+    assert n_seen >= 250 * 8

@@ -380,3 +380,79 @@ def test_single_sample_trajectories(torch_cuda, oracle):
         got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1)
         _compare(oracle, ref, got)
         assert got["lists"].shape[-1] == 0 and np.array_equal(ref["safe"], got["safe"])
+
+
+def test_off_diagonal_covariance_poisons_the_outputs_without_the_check(torch_cuda):
+    """set_agents(check=False) and a caller that never runs fo_sweep_check: the unsupported covariance must still
+    show in cost / safe (fmax would otherwise drop the poisoned probabilities and report 'safe')"""
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sweep import MetricSweep
+    traj, agents = S.make_batch(130, 3, config_id=10)
+    bad = {k: v.copy() for k, v in agents.items()}
+    bad["cov"][2, :, 0, 1] = 0.01
+    bad["cov"][2, :, 1, 0] = 0.01
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1)
+    args = lambda a: (a["pos"], a["yaw"], a["v"], a["cov"], a["shape"], a["raw_dims"], a["type"], a["len"])
+    sw.set_agents(*args(bad), check=False)
+    out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj["a"], mode="reduced")
+    torch_cuda.cuda.synchronize()
+    cost, safe = out.cost.cpu().numpy(), out.safe.cpu().numpy()
+    assert not safe.any() and (cost[:, N.COST["safe"]] == 0.0).all()
+    for name in ("max_collision_probability_all", "max_obst_risk_all", "max_ego_risk_all", "max_obst_harm_with_cp_all"):
+        assert np.isnan(cost[:, N.COST[name]]).all(), name
+    assert np.isfinite(cost[:, N.COST["min_dce"]]).all()        # geometry does not depend on the covariance
+    # a clean set on the same context is not affected by the earlier one
+    sw.set_agents(*args(agents), check=False)
+    out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj["a"], mode="reduced")
+    torch_cuda.cuda.synchronize()
+    assert np.isfinite(out.cost.cpu().numpy()[:, N.COST["max_collision_probability_all"]]).all()
+
+
+def test_prediction_length_is_clamped_to_the_table(torch_cuda, oracle):
+    """len[k] > Ta cannot be validated through the ABI (device array): the table build clamps it, so the result is
+    the one of len = Ta and no row of the next agent is read"""
+    from frenetix_occlusion import synthetic as S
+    traj, agents = S.make_batch(96, 5, config_id=12)
+    Ta = agents["pos"].shape[1]
+    over = {k: v.copy() for k, v in agents.items()}
+    over["len"][:] = Ta
+    ref = _hip_sweep(torch_cuda, traj, over, S.VEHICLE_BMW320I, 0.1)
+    over["len"][1], over["len"][4] = Ta + 7, 10 * Ta
+    neg = over["len"].copy()
+    got = _hip_sweep(torch_cuda, traj, over, S.VEHICLE_BMW320I, 0.1)
+    for k in ("cost", "safe", "pair_f", "pair_i", "lists"):
+        assert np.array_equal(ref[k], got[k], equal_nan=True), k
+    neg[2] = -3                                                    # negative = unused slot, like 0
+    over["len"] = neg
+    zero = {k: v.copy() for k, v in over.items()}
+    zero["len"][2] = 0
+    a, b = (_hip_sweep(torch_cuda, traj, d, S.VEHICLE_BMW320I, 0.1) for d in (over, zero))
+    for k in ("cost", "safe", "pair_f", "pair_i", "lists"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_reused_result_buffers_are_validated(torch_cuda):
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sweep import MetricSweep
+    traj, agents = S.make_batch(70, 4, config_id=13)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1)
+    args = lambda a: (a["pos"], a["yaw"], a["v"], a["cov"], a["shape"], a["raw_dims"], a["type"], a["len"])
+    sw.set_agents(*args(agents))
+    run = lambda t, **kw: sw.run(t["x"], t["y"], t["theta"], t["v"], t["a"], **kw)
+    out = run(traj, mode="full")
+    again = run(traj, mode="full", out=out)                         # same shapes: reused in place
+    assert again is out
+    with pytest.raises(ValueError):
+        run(traj, mode="reduced", out=out)                          # buffers the mode does not write
+    with pytest.raises(ValueError):
+        run({k: v[:50] for k, v in traj.items()}, mode="full", out=out)     # other M
+    with pytest.raises(ValueError):
+        run({k: v[:, :20] for k, v in traj.items()}, mode="full", out=out)  # other T
+    fewer = {k: v[:3] for k, v in agents.items()}
+    sw.set_agents(*args(fewer))
+    with pytest.raises(ValueError):
+        run(traj, mode="full", out=out)                             # other A
+    with pytest.raises(ValueError):
+        run(traj, mode="everything")
+    torch_cuda.cuda.synchronize()
