@@ -23,8 +23,9 @@ namespace {
 
 constexpr int TILE = 64;   // trajectories per wave
 constexpr int WAVES = 4;   // waves per workgroup
-constexpr int NEF = 6;     // ego fields per (t, trajectory): x, y, cos, sin, theta, v
-constexpr int NAF = 8;     // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2)
+constexpr int NEF = 8;     // ego fields per (t, trajectory): x, y, cos, sin, theta, v, v cos, v sin
+constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, -, -
+                           // (96-byte rows: the 32-byte and 16-byte groups the scalar loads fetch stay naturally aligned)
 constexpr int NAC = 8;     // per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type
 constexpr int NPS = 14;    // partial-reduction slots
 enum { PS_MIN_DCE = 0, PS_ARG_DCE, PS_MIN_TTC, PS_ARG_TTC, PS_MIN_TTCE, PS_MAX_ER, PS_MAX_OR, PS_ARG_OR, PS_MAX_EH,
@@ -100,8 +101,9 @@ __device__ __forceinline__ void fo_erf_fast4(const double2 *__restrict__ tab, do
   }
 }
 
+constexpr int EXP_N = 256;
 __global__ void fo_exp_table_kernel(double *tab) {
-  if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x / 64.0);
+  if (threadIdx.x < EXP_N) tab[threadIdx.x] = exp2((double)threadIdx.x / (double)EXP_N);
 }
 
 __device__ __forceinline__ double fo_erf_lds(const double2 *__restrict__ tab, double u) {
@@ -140,15 +142,20 @@ __global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int /*M
                                                            const double *__restrict__ y,
                                                            const double *__restrict__ th,
                                                            const double *__restrict__ v, double *__restrict__ tab) {
-  extern __shared__ double sh[];  // [T][TILE+1]
+  extern __shared__ double sh[];  // [2][T][TILE+1]
   const int m0 = blockIdx.x * TILE;
   const int n = min(TILE, M - m0);
   const int ld = TILE + 1;
-  const double *src[4] = {x, y, th, v};
+  const double *src[3] = {x, y, th};
   {
-    const int f = blockIdx.y;  // one input array per workgroup: 4 x n_tiles workgroups instead of n_tiles
+    const int f = blockIdx.y;  // one input array per workgroup (the heading's also reads the speed: velocity vector)
     const double *s = src[f] + (size_t)m0 * T;
     for (int i = threadIdx.x; i < n * T; i += blockDim.x) sh[(i % T) * ld + (i / T)] = s[i];
+    if (f == 2) {
+      const double *s2 = v + (size_t)m0 * T;
+      double *sh2 = sh + (size_t)T * ld;
+      for (int i = threadIdx.x; i < n * T; i += blockDim.x) sh2[(i % T) * ld + (i / T)] = s2[i];
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < T * TILE; i += blockDim.x) {
       const int t = i / TILE, ml = i % TILE;
@@ -156,13 +163,17 @@ __global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int /*M
       double *dst = tab + ((size_t)blockIdx.x * T + t) * NEF * TILE + ml;
       if (f == 0) dst[0 * TILE] = val;
       else if (f == 1) dst[1 * TILE] = val;
-      else if (f == 2) {
+      else {
+        const double spd = sh[(size_t)T * ld + t * ld + min(ml, n - 1)];
         double sn, cs;
         sincos(val, &sn, &cs);
         dst[2 * TILE] = cs;
         dst[3 * TILE] = sn;
         dst[4 * TILE] = val;
-      } else dst[5 * TILE] = val;
+        dst[5 * TILE] = spd;
+        dst[6 * TILE] = spd * cs;
+        dst[7 * TILE] = spd * sn;
+      }
     }
     __syncthreads();
   }
@@ -216,7 +227,7 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
   }
   double *o = tab + (size_t)i * NAF;
   o[0] = pos[2 * (size_t)i]; o[1] = pos[2 * (size_t)i + 1]; o[2] = cs; o[3] = sn; o[4] = yaw[i]; o[5] = v[i];
-  o[6] = isx; o[7] = isy;
+  o[6] = isx; o[7] = isy; o[8] = v[i] * cs; o[9] = v[i] * sn; o[10] = 0.0; o[11] = 0.0;
   if (t == 0) {
     const double m_obs = fo_obstacle_mass(type[k], shape[2 * k] * shape[2 * k + 1]);  // inflated footprint (Q8)
     double *c = cst + (size_t)k * NAC;
@@ -235,7 +246,7 @@ struct SweepArgs {
   const double *atab;    // [A][Ta][NAF]
   const double *acst;    // [A][NAC]
   const double2 *erf_tab;  // [ERF_N]
-  const double *exp_tab;   // [64]  2^(j/64)
+  const double *exp_tab;   // [EXP_N]  2^(j/EXP_N)
   const int32_t *aint;     // [A][2] protection class, valid length
   double *partial;       // [n_chunks][NPS][Mp]
   double *pair_f;        // [NPF][A][M] or null
@@ -284,6 +295,20 @@ __device__ __forceinline__ double fo_lr4s_coef_dir(double dx, double dy, double 
   if (unwrapped_far || -Cc >= aS) return rear;
   if (Cc > aS) return 0.0;
   return side;
+}
+
+// the same decision as an index (0 front, 1 side, 2 rear) -- the queue kernel takes it in pass 1, where the poses are
+// in registers anyway, and keeps two bits per sample until pass 2 looks the logistic offset up.  flip = obstacle side
+// (angle rel + pi: both S and C change sign).
+__device__ __forceinline__ unsigned fo_lr4s_class(double dx, double dy, double hc, double hs, float rel_crude, float turn,
+                                                  float heading, bool flip) {
+  double S = dy * hc - dx * hs, Cc = dx * hc + dy * hs;
+  if (flip) Cc = -Cc;  // |S| is all that is used of S
+  const double aS = fabs(S);
+  const bool unwrapped_far = fabsf(turn + rel_crude - heading) > 3.14159265f;
+  unsigned c = (Cc > aS) ? 0u : 1u;
+  if (unwrapped_far || -Cc >= aS) c = 2u;
+  return c;
 }
 
 // squared distance from point (px,py) to the axis-aligned box [-hl,hl]x[-hw,hw]
@@ -562,7 +587,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #define FO_ERF_GROUP 1  // table gathers of the CP boxes issued together (4) or one at a time (1: fewer live registers)
 #endif
 #ifndef FO_TC
-#define FO_TC 16     // timesteps per chunk of the two-pass scheme (rows of the per-wave cp buffer)
+#define FO_TC 8      // timesteps per chunk of the two-pass scheme (rows of the per-wave cp buffer)
 #endif
 #ifndef FO_QWAVES
 #define FO_QWAVES 4  // waves per workgroup of the queue kernel (45 KB of LDS -> three workgroups per CU)
@@ -570,9 +595,20 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #ifndef FO_MINW
 #define FO_MINW 3    // waves per SIMD the register allocation has to allow (<= 168 VGPRs)
 #endif
+#ifdef FO_PLAIN_STORE
+#define FO_LSTORE(v, p) (*(p) = (v))
+#else
+#define FO_LSTORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+#ifndef FO_X
+#define FO_X 0       // timing experiments only (tools/build_variant.sh x1 -DFO_X=1 ...): 1 no pass 2, 2 no probe, 4 no harm
+#endif               // geometry in pass 1, 8 pass 2 without its arithmetic, 32 no DCE in pass 1, 64 no gate -- WRONG results
 constexpr int TC = FO_TC;
+constexpr int DVR = TC + 1;          // rows of the per-wave ring of relative speeds: samples t0-1 .. t1-1 are live at once
+constexpr int WROWS = TC + DVR;      // LDS rows (64 doubles each) per wave
 constexpr int QWAVES = FO_QWAVES;
 constexpr int QCAP = 128;
+static_assert(TC <= 16, "two class bits per sample are kept in 32-bit lanes, 16 samples deep");
 
 // v_max_f64 / v_min_f64 without the canonicalisation fmax()/fmin() add for loop-carried operands (IEEE quieting of
 // signalling NaNs: two extra instructions per call); operands here are results of arithmetic, never signalling
@@ -582,24 +618,24 @@ __device__ __forceinline__ double fo_vmax(double a, double b) {
   return r;
 }
 
-// exp(z) = 2^(k/64) * e^r, k = rint(64 z / ln 2), |r| <= ln2/128: 64-entry table of 2^(j/64) in LDS and a degree-4
-// polynomial (remainder r^5/120 < 4e-14 relative).  Few distinct float64 constants on purpose: every one of them
-// occupies an SGPR pair for the whole loop, and the kernel is short of SGPRs, not of LDS bandwidth.
+// exp(z) = 2^(k/256) * e^r, k = rint(256 z / ln 2), |r| <= ln2/512: 256-entry table of 2^(j/256) in LDS (2 KB) and a
+// degree-3 polynomial (remainder r^4/24 < 1.5e-13 relative).  One-step argument reduction: ln2/256 cut to 43
+// significant bits, so k * hi is exact for |k| < 2^10 and the dropped tail costs |k| * 2.1e-16 (< 1e-12 relative over
+// the arguments the logistic models produce, z in [-5e3, 6]; a logistic value moves by a quarter of that).  Few distinct
+// float64 constants on purpose: every one of them occupies an SGPR pair for the whole loop.
 template <bool CLAMP = true>
 __device__ __forceinline__ double fo_exp_tab(const double *__restrict__ tab2, double z) {
   if (CLAMP) z = fmin(fmax(z, -700.0), 700.0);  // CLAMP = false: the caller bounds the argument
   const double MAGIC = 6755399441055744.0;                          // 1.5 * 2^52
-  const double tm = fma(z, 92.33248261689366, MAGIC);               // 64 / ln 2
+  const double tm = fma(z, 369.3299304675746, MAGIC);               // 256 / ln 2
   const double kf = tm - MAGIC;
   const int k = __double2loint(tm);
-  double r = fma(kf, -0.01083042469326756, z);                      // ln2/64 hi (32 significant bits)
-  r = fma(kf, -2.9815858269852933e-12, r);                          // ln2/64 lo
-  const double tv = tab2[k & 63];
-  double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
+  const double r = fma(kf, -0x1.62e42fefa3800p-9, z);               // ln2/256, 43 significant bits
+  const double tv = tab2[k & (EXP_N - 1)];
+  double p = fma(r, 1.0 / 6.0, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(tv * p, k >> 6);
+  return ldexp(tv * p, k >> 8);
 }
 
 // 1 / (1 + exp(nz)); v_rcp_f64 (measured ~3e-8 relative) + one Newton step (1.6e-14 against the oracle)
@@ -655,12 +691,17 @@ template <bool PAIR, bool LISTS, bool ALLM>
 __global__ __launch_bounds__(TILE *QWAVES) __attribute__((amdgpu_waves_per_eu(FO_MINW, FO_MINW)))
 void fo_sweep_queue_kernel(const SweepArgs a) {
   __shared__ double2 erf_tab[ERF_N];
-  __shared__ double exp_tab[64];
-  __shared__ double cpbuf_all[QWAVES * TC * TILE];  // also the cross-wave reduction scratch at the end
+  __shared__ double exp_tab[EXP_N];
+  __shared__ double zc_tab[4];                      // LR4S logistic offsets by impact class: front, side, rear
+  __shared__ double hk_all[QWAVES * 4];             // per wave: the current agent's logistic slopes and offsets
+  __shared__ double cpbuf_all[QWAVES * WROWS * TILE];  // per wave: TC rows of collision probabilities, DVR rows of
+                                                       // relative speeds; also the cross-wave reduction scratch
   __shared__ unsigned short queue_all[QWAVES * QCAP];
-  static_assert(QWAVES * TC >= (QWAVES - 1) * NPS, "reduction scratch must fit into the cp buffers");
+  static_assert(QWAVES * WROWS >= (QWAVES - 1) * NPS, "reduction scratch must fit into the per-wave buffers");
   for (int i = threadIdx.x; i < ERF_N; i += TILE * QWAVES) erf_tab[i] = a.erf_tab[i];
-  if (threadIdx.x < 64) exp_tab[threadIdx.x] = a.exp_tab[threadIdx.x];
+  for (int i = threadIdx.x; i < EXP_N; i += TILE * QWAVES) exp_tab[i] = a.exp_tab[i];
+  if (threadIdx.x < 4)
+    zc_tab[threadIdx.x] = -a.hc.lr4s_const - (threadIdx.x == 0 ? 0.0 : threadIdx.x == 1 ? a.hc.lr4s_side : a.hc.lr4s_rear);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -676,7 +717,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   const int T = a.T, Tm1 = a.T - 1, M = a.M, A = a.A;
   const double *tjb = a.traj + (size_t)tile * T * NEF * TILE;  // uniform tile base
   const double *tj = tjb + lane;
-  double *cpw = cpbuf_all + wave * (TC * TILE);
+  double *cpw = cpbuf_all + wave * (WROWS * TILE);
+  double *dvw = cpw + TC * TILE;
+  double *hk = hk_all + wave * 4;
   unsigned short *q = queue_all + wave * QCAP;
   const bool do_dce = ALLM || (a.mask & FO_M_DCE), do_cp = ALLM || (a.mask & FO_M_CP), do_hr = ALLM || (a.mask & FO_M_HR);
   const bool do_ttc = ALLM || (a.mask & FO_M_TTC), do_ttce = ALLM || (a.mask & FO_M_TTCE);
@@ -690,6 +733,12 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   int w_arg_dce = -1, w_arg_ttc = -1, w_arg_or = -1;  // agent indices as integers: three VGPRs less than as doubles
   bool w_dce_flag = false;
 
+#ifndef FO_STAGGER
+#define FO_STAGGER 0
+#endif
+  // Experiment (off: measured 0.745 vs 0.725 ms): an agent's first time chunk of a different length from wave to wave,
+  // so that the waves do not alternate in step between the store-free pass 1 and the store-only pass 2.
+  const int first_len = FO_STAGGER ? 1 + (wave * (TC / QWAVES > 0 ? TC / QWAVES : 1) + (blockIdx.x >> 3)) % TC : TC;
   const int k0 = (chunk * QWAVES + wave) * a.apw;
   for (int kk = 0; kk < a.apw; ++kk) {
     const int k = k0 + kk;
@@ -728,7 +777,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     double dce = INFINITY, thr2 = INFINITY, thrR2 = INFINITY;
     int tdce = 0;
     const double Rsum = sqrt(hlA * hlA + hwA * hwA) + sqrt(hlB * hlB + hwB * hwB);
-    if (do_dce && !(ablate & 1)) {
+    if (do_dce && !(ablate & 1) && !(FO_X & 2)) {
       const int Ld = min(L, T);
       double bestc = INFINITY;
       int tb = 0;
@@ -772,18 +821,30 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     double *lp = LISTS ? a.lists + (size_t)k * Tm1 * M + m : nullptr;
     // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
     // (harm_model.py:96-97: ego_dv = m_obs/(m_ego+m_obs) dv, obs_dv = m_ego/(m_ego+m_obs) dv)
-    const double c4 = -a.hc.lr4s_const, c1 = -a.hc.lr1s_const;
-    const double k4e = -a.hc.lr4s_speed * f_ego, k4o = -a.hc.lr4s_speed * f_obs;
-    const double k1e = -a.hc.lr1s_speed * f_ego, kpo = -a.hc.ped_speed * f_obs;
     const bool lr4s = prot == 1;
+    // They are wave-uniform, but the scalar registers are taken: parked in LDS, pass 2 reads them back into vector
+    // registers that are free by then (held across pass 1 they cost eight VGPRs at its register peak).
+    if (lane == 0) {
+      hk[0] = lr4s ? -a.hc.lr4s_speed * f_ego : -a.hc.lr1s_speed * f_ego;
+      hk[1] = lr4s ? -a.hc.lr4s_speed * f_obs : -a.hc.ped_speed * f_obs;
+      hk[2] = -a.hc.lr1s_const;
+      hk[3] = a.hc.ped_const;
+    }
     const double gate_far2 = (5.0 + hdev + 1e-6) * (5.0 + hdev + 1e-6);
+    // LR4S impact classes (0 front, 1 side, 2 rear) of the ego's and the obstacle's occupants: two bits per sample,
+    // slot t & 15 (a chunk and its predecessor's last sample are live at once: TC + 1 <= 16 slots)
+    unsigned cls_e = 0u, cls_o = 0u;
 
-    // The horizon is walked in chunks of TC iterations.  Iteration t evaluates DCE(t) and the gate of sample t-1
-    // (ego t, agent mean t-1, agent heading t: Q1), so chunk [t0, t1) owns the gate samples [t0-1, t1-1); their
-    // collision probabilities go to row (g - t0 + 1) of the wave's cp buffer, and pass 2 of the chunk (harm, risk,
-    // maxima, lists) consumes them before the next chunk overwrites the rows.
-    for (int t0 = 0; t0 < T; t0 += TC) {
-      const int t1 = min(t0 + TC, T);
+    // The horizon is walked in chunks of TC iterations, two passes per chunk.
+    //  pass 1, iteration t: everything that needs the poses -- DCE(t); the relative speed of sample t (harm_model.py:
+    //          92-94) into the wave's ring in LDS and, for LR4S agents, the impact classes of sample t; the gate of
+    //          sample t-1 (ego t, agent mean t-1, agent heading t: Q1), so chunk [t0, t1) owns the gate samples
+    //          [t0-1, t1-1), whose collision probabilities go to row (g - t0 + 1) of the wave's cp buffer.
+    //  pass 2, samples [t0-1, t1-1): logistic models, risk, maxima, lists -- from LDS and registers only: no vector
+    //          or scalar load shares a counter with the list stores (vmcnt retires loads and stores in issue order, so
+    //          a load behind five stores per iteration used to wait for their acknowledgement).
+    for (int t0 = 0, t1 = 0; t0 < T; t0 = t1) {
+      t1 = min(t0 + (t0 == 0 ? first_len : TC), T);
       const int gbase = t0 - 1;  // gate sample of buffer row 0
 
       // evaluates n (<= 64) queued in-gate samples, one per lane (collision_probability.py:77-122)
@@ -824,32 +885,39 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
 
-      // ---------------------------------------------------------------- pass 1: DCE + gate -> queue
+      // ---------------------------------------------------------------- pass 1: DCE + harm geometry + gate -> queue
       // Every operand of iteration t was requested one iteration earlier: the ego row t+1 (vector loads) and the
       // agent row t+1 (scalar loads) are issued at the top and first used at the top of the next iteration.
       unsigned gmask = 0u;  // bit row: gate sample gbase + row is inside the 5 m gate for this lane
+      unsigned wgate = 0u;  // the same for the whole wave (uniform): some lane is inside the gate
       int qn = 0;
+      int ring = t0 % DVR;  // row of sample t in the ring of relative speeds
+      const bool geo = do_hr && !(ablate & 4);
       const double *e0_ = tj + (size_t)t0 * NEF * TILE;
       double nx_ = e0_[0 * TILE], ny_ = e0_[1 * TILE], nc_ = e0_[2 * TILE], ns_ = e0_[3 * TILE];
+      double nvx_ = e0_[6 * TILE], nvy_ = e0_[7 * TILE], nth_ = 0.0;
+      if (lr4s) nth_ = e0_[4 * TILE];
       const cdp_t gr0 = G + (size_t)min(t0, L - 1) * NAF;
-      double npx = gr0[0], npy = gr0[1], npc = gr0[2], nps = gr0[3];
+      double npx = gr0[0], npy = gr0[1], npc = gr0[2], nps = gr0[3], nyaw = gr0[4], npvx = gr0[8], npvy = gr0[9];
       const cdp_t grp = G + (size_t)min(max(t0 - 1, 0), L - 1) * NAF;
       double ppx = grp[0], ppy = grp[1];  // agent mean of the previous sample
       // Scalar loads return out of order, so any use of an s_load result waits for lgkmcnt(0).  Pinning the per-agent
       // constants and the first rows here (an empty asm that names them as SGPR inputs) drains the counter before the
       // loop, which leaves the in-loop wait to cover only the row that was prefetched one iteration ago.
       asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(f_ego), "s"(f_obs), "s"(npx),
-                   "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy));
+                   "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy), "s"(npvx), "s"(npvy), "s"(nyaw));
       for (int t = t0; t < t1; ++t) {
-        const double ex = nx_, ey = ny_, ec = nc_, es = ns_;
-        const double px = npx, py = npy, pc = npc, ps = nps;
+        const double ex = nx_, ey = ny_, ec = nc_, es = ns_, evx = nvx_, evy = nvy_, eth = nth_;
+        const double px = npx, py = npy, pc = npc, ps = nps, pyaw = nyaw, pvx = npvx, pvy = npvy;
         {
           const double *e1 = tj + (size_t)min(t + 1, T - 1) * NEF * TILE;
           nx_ = e1[0 * TILE]; ny_ = e1[1 * TILE]; nc_ = e1[2 * TILE]; ns_ = e1[3 * TILE];
+          nvx_ = e1[6 * TILE]; nvy_ = e1[7 * TILE];
+          if (lr4s) nth_ = e1[4 * TILE];
           const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
-          npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3];
+          npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3]; nyaw = g1[4]; npvx = g1[8]; npvy = g1[9];
         }
-        if (do_dce && t < L && !(ablate & 1)) {
+        if (do_dce && t < L && !(ablate & 1) && !(FO_X & 32)) {
           const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
           const double dx = px - ccx, dy = py - ccy;
           // nothing to gain after the (earliest) zero; otherwise the centres must be close enough
@@ -889,7 +957,26 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             }
           }
         }
-        if (do_cp && t >= 1 && t < L && !(ablate & 2)) {
+        if (geo && t < Lh && !(FO_X & 4)) {
+          // relative speed of sample t (harm_model.py:92-94): sqrt(ve^2 + va^2 + 2 ve va cos(pdof)), pdof = yaw - theta
+          // + pi, is the length of the difference of the two velocity vectors; capped (1e4 m/s) so that the logistic
+          // arguments of pass 2 stay in the range of the table exp without a clamp of their own
+          const double dvx = evx - pvx, dvy = evy - pvy;
+          dvw[ring * TILE + lane] = fmin(fo_sqrt(fma(dvx, dvx, dvy * dvy)), 1.0e4);
+          if (lr4s) {
+            // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
+            double ddx = px - ex, ddy = py - ey;
+            if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;  // atan2(0, 0) = 0
+            const float relc = fo_atan2_crude((float)ddy, (float)ddx);
+            const unsigned ce = fo_lr4s_class(ddx, ddy, ec, es, relc, 0.0f, (float)eth, false);
+            const unsigned co = fo_lr4s_class(ddx, ddy, pc, ps, relc, 3.14159265f, (float)pyaw, true);
+            const int sh = (t & 15) * 2;
+            cls_e = (cls_e & ~(3u << sh)) | (ce << sh);
+            cls_o = (cls_o & ~(3u << sh)) | (co << sh);
+          }
+        }
+        ring = (ring + 1 == DVR) ? 0 : ring + 1;
+        if (do_cp && t >= 1 && t < L && !(ablate & 2) && !(FO_X & 64)) {
           // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
           const double rx = ex - ppx, ry = ey - ppy;
           const double d0 = rx * rx + ry * ry;
@@ -901,7 +988,10 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
             const double m2 = fmin(d0, fmin(dp, dm));
             ing = m2 <= 25.0;
-            if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);  // keep the reference's test on the rounded sqrt
+            // keep the reference's test on the rounded sqrt (a whole-wave branch: the band is 1e-9 wide)
+            if (__ballot(!ing && m2 < 25.0 + 1e-9)) {
+              if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);
+            }
           }
           const unsigned long long bal = __ballot(ing);
           if (bal) {
@@ -911,6 +1001,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
               q[pos] = (unsigned short)(lane | (row << 6));
               gmask |= 1u << row;
             }
+            wgate |= 1u << row;
             qn += __popcll(bal);
             if (qn >= 64) {
               process(64);
@@ -926,85 +1017,78 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
         ppx = px; ppy = py;
       }
       if (qn > 0) process(qn);
+      wgate = __builtin_amdgcn_readfirstlane(wgate);  // uniform by construction; says so to the register allocator
 
       // ---------------------------------------------------------------- pass 2: harm, risk, maxima, lists
       // of the gate samples g in [max(t0-1, 0), t1-1) -- harm index g, cp index g (Q6)
       const int g0s = max(gbase, 0), g1s = t1 - 1;
-      if ((do_cp || do_hr) && g0s < g1s) {
-        // one instantiation per harm model: the LR4S path (impact-angle classes, three more ego fields in flight)
-        // and the pedestrian / LR1S path keep separate register and constant sets
+      if ((do_cp || do_hr) && g0s < g1s && !(FO_X & 1)) {
+        // one instantiation per harm model: the LR4S path (impact classes -> logistic offsets) and the pedestrian /
+        // LR1S path keep separate register and constant sets
         auto pass2 = [&](auto lr4s_tag) {
           constexpr bool LR4S = decltype(lr4s_tag)::value;
-          // Ego samples are fetched two iterations ahead: vmcnt retires vector memory operations in issue order, loads
-          // and stores alike, so a load issued after the list stores of the previous iteration would not return
-          // before those stores are acknowledged.
-          const double *e_ = tj + (size_t)g0s * NEF * TILE;
-          double ec0 = e_[2 * TILE], es0 = e_[3 * TILE], ev0 = e_[5 * TILE];
-          double ex0 = 0.0, ey0 = 0.0, eth0 = 0.0, ex1 = 0.0, ey1 = 0.0, eth1 = 0.0;
-          if (LR4S) { ex0 = e_[0 * TILE]; ey0 = e_[1 * TILE]; eth0 = e_[4 * TILE]; }
-          e_ = tj + (size_t)min(g0s + 1, T - 1) * NEF * TILE;
-          double ec1 = e_[2 * TILE], es1 = e_[3 * TILE], ev1 = e_[5 * TILE];
-          if (LR4S) { ex1 = e_[0 * TILE]; ey1 = e_[1 * TILE]; eth1 = e_[4 * TILE]; }
-          const cdp_t gq = G + (size_t)min(g0s, L - 1) * NAF;
-          double gx1 = gq[0], gy1 = gq[1], gc1 = gq[2], gs1 = gq[3], gyaw1 = gq[4], gv1 = gq[5];  // agent row (one ahead)
-          double cpv = cpw[(g0s - gbase) * TILE + lane];
-          asm volatile("; scalar operands resident" ::"s"(gx1), "s"(gy1), "s"(gc1), "s"(gs1), "s"(gyaw1), "s"(gv1),
-                       "v"(cpv));
+          const double ke_ = hk[0], ko_ = hk[1], ce_ = hk[2], co_ = hk[3];
+          int rr = g0s % DVR;
+          // LDS reads of sample t+1 are issued while sample t is evaluated
+          double dvn = dvw[rr * TILE + lane];
+          double zen = 0.0, zon = 0.0;
+          if (LR4S) {
+            const int sh = (g0s & 15) * 2;
+            zen = zc_tab[(cls_e >> sh) & 3u];
+            zon = zc_tab[(cls_o >> sh) & 3u];
+          }
           for (int t = g0s; t < g1s; ++t) {
-            const double gx = gx1, gy = gy1, pc = gc1, ps = gs1, gyaw = gyaw1, pv = gv1;
             const int row = t - gbase;
-            const double cp = ((gmask >> row) & 1u) ? cpv : 0.0;
-            // the only LDS read of the iteration (next cp) goes out together with the scalar prefetch of the next agent
-            // row; both are first touched at the top of the next iteration (LDS and SMEM share lgkmcnt)
-            cpv = cpw[min(row + 1, TC - 1) * TILE + lane];
-            {
-              const cdp_t gn = G + (size_t)min(t + 1, L - 1) * NAF;
-              gx1 = gn[0]; gy1 = gn[1]; gc1 = gn[2]; gs1 = gn[3]; gyaw1 = gn[4]; gv1 = gn[5];
+            const double dv = dvn, ze = zen, zo = zon;
+            rr = (rr + 1 == DVR) ? 0 : rr + 1;
+            dvn = dvw[rr * TILE + lane];
+            if (LR4S) {
+              const int sh = ((t + 1) & 15) * 2;
+              zen = zc_tab[(cls_e >> sh) & 3u];
+              zon = zc_tab[(cls_o >> sh) & 3u];
             }
-            e_ = tj + (size_t)min(t + 2, T - 1) * NEF * TILE;
-            const double ec2 = e_[2 * TILE], es2 = e_[3 * TILE], ev2 = e_[5 * TILE];
-            double ex2 = 0.0, ey2 = 0.0, eth2 = 0.0;
-            if (LR4S) { ex2 = e_[0 * TILE]; ey2 = e_[1 * TILE]; eth2 = e_[4 * TILE]; }
-            double eh = NAN, oh = NAN, er = NAN, orr = NAN;
-            if (do_hr && t < Lh && !(ablate & 4)) {
-              const double cr = pc * ec0 + ps * es0;
-              // cos(pdof) = -cos(yaw - theta); dv is capped (1e4 m/s) so that the logistic arguments below stay in
-              // the range of the table exp without a clamp of their own
-              const double dv = fmin(fo_sqrt(fmax(ev0 * ev0 + pv * pv - 2.0 * ev0 * pv * cr, 0.0)), 1.0e4);
+            double eh = NAN, oh = NAN, er = NAN, orr = NAN, cp = 0.0;
+            const bool hv = geo && t < Lh;  // wave-uniform
+            if (hv && (FO_X & 8)) {
+              eh = dv; oh = ze + zo;
+            } else if (hv) {
               if (LR4S) {
-                // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
-                double ddx = gx - ex0, ddy = gy - ey0;
-                if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;  // atan2(0, 0) = 0
-                const float relc = fo_atan2_crude((float)ddy, (float)ddx);
-                const double ke = fo_lr4s_coef_dir(ddx, ddy, ec0, es0, relc, 0.0f, eth0, a.hc.lr4s_side, a.hc.lr4s_rear);
-                const double ko = fo_lr4s_coef_dir(ddx, ddy, pc, ps, relc, 3.14159265f, gyaw, a.hc.lr4s_side, a.hc.lr4s_rear);
-                eh = fo_logistic_neg<false>(exp_tab, fma(k4e, dv, c4) - ke);
-                oh = fo_logistic_neg<false>(exp_tab, fma(k4o, dv, c4) - ko);
+                eh = fo_logistic_neg<false>(exp_tab, fma(ke_, dv, ze));
+                oh = fo_logistic_neg<false>(exp_tab, fma(ko_, dv, zo));
               } else if (prot == 0) {
-                eh = fo_logistic_neg<false>(exp_tab, fma(k1e, dv, c1));
-                oh = fo_logistic_neg<false>(exp_tab, fma(kpo, dv, a.hc.ped_const));
+                eh = fo_logistic_neg<false>(exp_tab, fma(ke_, dv, ce_));
+                oh = fo_logistic_neg<false>(exp_tab, fma(ko_, dv, co_));
               } else {
                 eh = 1.0;
                 oh = 1.0;
               }
-              er = eh * cp;
-              orr = oh * cp;
-              max_er = fo_vmax(max_er, er);
-              if (orr > max_or) { max_or = orr; idx_or = t; }
               max_eh = fo_vmax(max_eh, eh);
               max_oh = fo_vmax(max_oh, oh);
             }
-            if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
+            // No lane of the wave is inside the gate at this sample (97 % of the samples of the bench workload): every
+            // probability is zero, so are the risks, and none of the running maxima or indices can move -- they were
+            // seeded by sample 0, which always takes the long way.
+            if (!hv || t == 0 || ((wgate >> row) & 1u)) {
+              if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
+              if (hv) {
+                er = eh * cp;
+                orr = oh * cp;
+                max_er = fo_vmax(max_er, er);
+                if (orr > max_or) { max_or = orr; idx_or = t; }
+              }
+              if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
+            } else {
+              er = 0.0;
+              orr = 0.0;
+            }
             if (LISTS) {
-              __builtin_nontemporal_store(cp, lp + FO_L_CP * ls);
-              __builtin_nontemporal_store(eh, lp + FO_L_EGO_HARM * ls);
-              __builtin_nontemporal_store(oh, lp + FO_L_OBST_HARM * ls);
-              __builtin_nontemporal_store(er, lp + FO_L_EGO_RISK * ls);
-              __builtin_nontemporal_store(orr, lp + FO_L_OBST_RISK * ls);
+              FO_LSTORE(cp, lp + FO_L_CP * ls);
+              FO_LSTORE(eh, lp + FO_L_EGO_HARM * ls);
+              FO_LSTORE(oh, lp + FO_L_OBST_HARM * ls);
+              FO_LSTORE(er, lp + FO_L_EGO_RISK * ls);
+              FO_LSTORE(orr, lp + FO_L_OBST_RISK * ls);
               lp += M;
             }
-            ec0 = ec1; es0 = es1; ev0 = ev1; ex0 = ex1; ey0 = ey1; eth0 = eth1;
-            ec1 = ec2; es1 = es2; ev1 = ev2; ex1 = ex2; ey1 = ey2; eth1 = eth2;
           }
         };
         if (lr4s) pass2(std::true_type{}); else pass2(std::false_type{});
@@ -1302,8 +1386,8 @@ extern "C" {
 int fo_sweep_init_(fo_ctx *ctx) {
   FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_erf_tab, sizeof(double2) * ERF_N));
   hipLaunchKernelGGL(fo_erf_table_kernel, dim3((ERF_N + 255) / 256), dim3(256), 0, 0, (double2 *)ctx->d_erf_tab);
-  FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_exp_tab, sizeof(double) * 64));
-  hipLaunchKernelGGL(fo_exp_table_kernel, dim3(1), dim3(64), 0, 0, (double *)ctx->d_exp_tab);
+  FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_exp_tab, sizeof(double) * EXP_N));
+  hipLaunchKernelGGL(fo_exp_table_kernel, dim3(1), dim3(EXP_N), 0, 0, (double *)ctx->d_exp_tab);
   FO_HIP_TRY(ctx, hipGetLastError());
   FO_HIP_TRY(ctx, hipDeviceSynchronize());
   return FO_OK;
@@ -1399,7 +1483,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   }
 
   if (A > 0) {
-    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 4), dim3(256), (size_t)T * (TILE + 1) * sizeof(double), s, M, T,
+    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 3), dim3(256), (size_t)2 * T * (TILE + 1) * sizeof(double), s, M, T,
                        Mp, d_x, d_y, d_theta, d_v, ctx->d_traj_tab);
     FO_HIP_TRY(ctx, hipGetLastError());
     SweepArgs a{};
