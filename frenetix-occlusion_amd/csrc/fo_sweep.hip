@@ -694,10 +694,10 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   __shared__ double exp_tab[EXP_N];
   __shared__ double zc_tab[4];                      // LR4S logistic offsets by impact class: front, side, rear
   __shared__ double hk_all[QWAVES * 4];             // per wave: the current agent's logistic slopes and offsets
-  __shared__ double cpbuf_all[QWAVES * WROWS * TILE];  // per wave: TC rows of collision probabilities, DVR rows of
+  constexpr int BUFROWS = QWAVES * WROWS > (QWAVES - 1) * NPS ? QWAVES * WROWS : (QWAVES - 1) * NPS;
+  __shared__ double cpbuf_all[BUFROWS * TILE];  // per wave: TC rows of collision probabilities, DVR rows of
                                                        // relative speeds; also the cross-wave reduction scratch
   __shared__ unsigned short queue_all[QWAVES * QCAP];
-  static_assert(QWAVES * WROWS >= (QWAVES - 1) * NPS, "reduction scratch must fit into the per-wave buffers");
   for (int i = threadIdx.x; i < ERF_N; i += TILE * QWAVES) erf_tab[i] = a.erf_tab[i];
   for (int i = threadIdx.x; i < EXP_N; i += TILE * QWAVES) exp_tab[i] = a.exp_tab[i];
   if (threadIdx.x < 4)
@@ -733,12 +733,6 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   int w_arg_dce = -1, w_arg_ttc = -1, w_arg_or = -1;  // agent indices as integers: three VGPRs less than as doubles
   bool w_dce_flag = false;
 
-#ifndef FO_STAGGER
-#define FO_STAGGER 0
-#endif
-  // Experiment (off: measured 0.745 vs 0.725 ms): an agent's first time chunk of a different length from wave to wave,
-  // so that the waves do not alternate in step between the store-free pass 1 and the store-only pass 2.
-  const int first_len = FO_STAGGER ? 1 + (wave * (TC / QWAVES > 0 ? TC / QWAVES : 1) + (blockIdx.x >> 3)) % TC : TC;
   const int k0 = (chunk * QWAVES + wave) * a.apw;
   for (int kk = 0; kk < a.apw; ++kk) {
     const int k = k0 + kk;
@@ -843,8 +837,8 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     //  pass 2, samples [t0-1, t1-1): logistic models, risk, maxima, lists -- from LDS and registers only: no vector
     //          or scalar load shares a counter with the list stores (vmcnt retires loads and stores in issue order, so
     //          a load behind five stores per iteration used to wait for their acknowledgement).
-    for (int t0 = 0, t1 = 0; t0 < T; t0 = t1) {
-      t1 = min(t0 + (t0 == 0 ? first_len : TC), T);
+    for (int t0 = 0; t0 < T; t0 += TC) {
+      const int t1 = min(t0 + TC, T);
       const int gbase = t0 - 1;  // gate sample of buffer row 0
 
       // evaluates n (<= 64) queued in-gate samples, one per lane (collision_probability.py:77-122)
