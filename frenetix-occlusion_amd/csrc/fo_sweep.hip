@@ -23,7 +23,9 @@ namespace {
 
 constexpr int TILE = 64;   // trajectories per wave
 constexpr int WAVES = 4;   // waves per workgroup
-constexpr int NEF = 8;     // ego fields per (t, trajectory): x, y, cos, sin, theta, v, v cos, v sin
+constexpr int NEF = 8;     // ego fields per (t, trajectory): x, y, cos, sin, theta, v, v cos, v sin -- stored as four
+                           // pairs per trajectory, [t][pair][trajectory][2]: one 16-byte load per lane fetches two
+                           // fields (a vector-memory instruction costs the CU ~10 cycles whatever its width)
 constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, -, -
                            // (96-byte rows: the 32-byte and 16-byte groups the scalar loads fetch stay naturally aligned)
 constexpr int NAC = 8;     // per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type
@@ -101,6 +103,11 @@ __device__ __forceinline__ void fo_erf_fast4(const double2 *__restrict__ tab, do
   }
 }
 
+// offset of ego field f from a row pointer that already points at the lane's first pair (row base + 2 lane)
+#define EF(f) ((((f) >> 1) * 2 * TILE) + ((f) & 1))
+typedef double fo_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fo_d2 fo_ld2(const double *p) { return *(const fo_d2 *)p; }
+
 constexpr int EXP_N = 256;
 __global__ void fo_exp_table_kernel(double *tab) {
   if (threadIdx.x < EXP_N) tab[threadIdx.x] = exp2((double)threadIdx.x / (double)EXP_N);
@@ -146,36 +153,28 @@ __global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int /*M
   const int m0 = blockIdx.x * TILE;
   const int n = min(TILE, M - m0);
   const int ld = TILE + 1;
-  const double *src[3] = {x, y, th};
-  {
-    const int f = blockIdx.y;  // one input array per workgroup (the heading's also reads the speed: velocity vector)
-    const double *s = src[f] + (size_t)m0 * T;
-    for (int i = threadIdx.x; i < n * T; i += blockDim.x) sh[(i % T) * ld + (i / T)] = s[i];
-    if (f == 2) {
-      const double *s2 = v + (size_t)m0 * T;
-      double *sh2 = sh + (size_t)T * ld;
-      for (int i = threadIdx.x; i < n * T; i += blockDim.x) sh2[(i % T) * ld + (i / T)] = s2[i];
+  const int f = blockIdx.y;  // 0: positions (x, y); 1: heading and speed -> (cos, sin), (theta, v), (v cos, v sin)
+  const double *s0 = (f == 0 ? x : th) + (size_t)m0 * T, *s1 = (f == 0 ? y : v) + (size_t)m0 * T;
+  double *sh1 = sh + (size_t)T * ld;
+  for (int i = threadIdx.x; i < n * T; i += blockDim.x) {
+    sh[(i % T) * ld + (i / T)] = s0[i];
+    sh1[(i % T) * ld + (i / T)] = s1[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * TILE; i += blockDim.x) {
+    const int t = i / TILE, ml = i % TILE;
+    const int src = t * ld + min(ml, n - 1);  // pad lanes replicate the last trajectory of the tile
+    const double a0 = sh[src], a1 = sh1[src];
+    fo_d2 *dst = (fo_d2 *)(tab + ((size_t)blockIdx.x * T + t) * NEF * TILE) + ml;  // pair p of lane ml: dst[p * TILE]
+    if (f == 0) {
+      dst[0 * TILE] = fo_d2{a0, a1};
+    } else {
+      double sn, cs;
+      sincos(a0, &sn, &cs);
+      dst[1 * TILE] = fo_d2{cs, sn};
+      dst[2 * TILE] = fo_d2{a0, a1};
+      dst[3 * TILE] = fo_d2{a1 * cs, a1 * sn};
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < T * TILE; i += blockDim.x) {
-      const int t = i / TILE, ml = i % TILE;
-      const double val = sh[t * ld + min(ml, n - 1)];  // pad lanes replicate the last trajectory of the tile
-      double *dst = tab + ((size_t)blockIdx.x * T + t) * NEF * TILE + ml;
-      if (f == 0) dst[0 * TILE] = val;
-      else if (f == 1) dst[1 * TILE] = val;
-      else {
-        const double spd = sh[(size_t)T * ld + t * ld + min(ml, n - 1)];
-        double sn, cs;
-        sincos(val, &sn, &cs);
-        dst[2 * TILE] = cs;
-        dst[3 * TILE] = sn;
-        dst[4 * TILE] = val;
-        dst[5 * TILE] = spd;
-        dst[6 * TILE] = spd * cs;
-        dst[7 * TILE] = spd * sn;
-      }
-    }
-    __syncthreads();
   }
 }
 
@@ -236,6 +235,24 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
     c[5] = (double)fo_obstacle_protection(type[k]); c[6] = (double)L; c[7] = (double)type[k];
     aint[2 * k] = fo_obstacle_protection(type[k]);
     aint[2 * k + 1] = L;
+  }
+}
+
+// The five per-timestep lists of hr.py:87-98 for sample index i = (k (T-1) + t) M + m, n = A (T-1) M entries per list
+// (layout of include/fo_hip.h): cp alone, the two harms and the two risks as interleaved pairs -- a lane writes 8 + 16 +
+// 16 bytes with three store instructions, each covering one contiguous run of the wave (512 B / 1 KB / 1 KB).
+template <bool NT = true>
+__device__ __forceinline__ void fo_store_lists(double *lists, size_t n, size_t i, double cp, double eh, double oh,
+                                               double er, double orr) {
+  fo_d2 *h = (fo_d2 *)(lists + n) + i, *r = (fo_d2 *)(lists + 3 * n) + i;
+  if (NT) {
+    __builtin_nontemporal_store(cp, lists + i);
+    __builtin_nontemporal_store(fo_d2{eh, oh}, h);
+    __builtin_nontemporal_store(fo_d2{er, orr}, r);
+  } else {
+    lists[i] = cp;
+    *h = fo_d2{eh, oh};
+    *r = fo_d2{er, orr};
   }
 }
 
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
   const bool valid = m < a.M;
   const int T = a.T, Tm1 = a.T - 1, M = a.M, A = a.A;
   const size_t Mp = TILE;  // field stride inside a tile
-  const double *tj = a.traj + (size_t)tile * T * NEF * TILE + lane;
+  const double *tj = a.traj + (size_t)tile * T * NEF * TILE + 2 * lane;
   const bool do_dce = a.mask & FO_M_DCE, do_cp = a.mask & FO_M_CP, do_hr = a.mask & FO_M_HR;
   const bool do_ttc = a.mask & FO_M_TTC, do_ttce = a.mask & FO_M_TTCE;
 
@@ -367,8 +384,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
       }
       if (LISTS && valid) {
         const size_t ls = (size_t)A * Tm1 * M;
-        for (int f = 0; f < FO_NL; ++f)
-          for (int t = 0; t < Tm1; ++t) a.lists[(size_t)f * ls + ((size_t)k * Tm1 + t) * M + m] = NAN;
+        for (int t = 0; t < Tm1; ++t) fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
       }
       continue;
     }
@@ -383,15 +399,15 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
     // Software pipeline.  Ego samples: E(t) and E(t+1) are in registers when iteration t starts (CP reads t+1 early),
     // the loads of E(t+2) are issued at the top of the iteration and first touched at its bottom.  Agent rows
     // (wave-uniform -> scalar loads): row t in SGPRs, row t+1 requested at the top and first read by the CP step.
-    double ex = tj[0 * Mp], ey = tj[1 * Mp], ec = tj[2 * Mp], es = tj[3 * Mp], eth = tj[4 * Mp], ev = tj[5 * Mp];
+    double ex = tj[EF(0)], ey = tj[EF(1)], ec = tj[EF(2)], es = tj[EF(3)], eth = tj[EF(4)], ev = tj[EF(5)];
     const double *tj1 = tj + (size_t)min(1, T - 1) * NEF * Mp;
-    double ex1 = tj1[0 * Mp], ey1 = tj1[1 * Mp], ec1 = tj1[2 * Mp], es1 = tj1[3 * Mp], eth1 = tj1[4 * Mp],
-           ev1 = tj1[5 * Mp];
+    double ex1 = tj1[EF(0)], ey1 = tj1[EF(1)], ec1 = tj1[EF(2)], es1 = tj1[EF(3)], eth1 = tj1[EF(4)],
+           ev1 = tj1[EF(5)];
     double px = G[0], py = G[1], pc = G[2], ps = G[3], pth = G[4], pv = G[5], isx = G[6], isy = G[7];
     for (int t = 0; t < T; ++t) {
       const double *tj2 = tj + (size_t)min(t + 2, T - 1) * NEF * Mp;
-      const double ex2 = tj2[0 * Mp], ey2 = tj2[1 * Mp], ec2 = tj2[2 * Mp], es2 = tj2[3 * Mp], eth2 = tj2[4 * Mp],
-                   ev2 = tj2[5 * Mp];
+      const double ex2 = tj2[EF(0)], ey2 = tj2[EF(1)], ec2 = tj2[EF(2)], es2 = tj2[EF(3)], eth2 = tj2[EF(4)],
+                   ev2 = tj2[EF(5)];
       const double *gn = G + (size_t)min(t + 1, L - 1) * NAF;
       const double npx = gn[0], npy = gn[1], pc1 = gn[2], ps1 = gn[3], npth = gn[4], npv = gn[5], nisx = gn[6],
                    nisy = gn[7];
@@ -480,15 +496,8 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
           max_oh = fmax(max_oh, oh);
         }
         if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
-        if (LISTS && valid) {
-          double *l = a.lists + ((size_t)k * Tm1 + t) * M + m;
-          const size_t ls = (size_t)A * Tm1 * M;
-          __builtin_nontemporal_store(cp, l + FO_L_CP * ls);
-          __builtin_nontemporal_store(eh, l + FO_L_EGO_HARM * ls);
-          __builtin_nontemporal_store(oh, l + FO_L_OBST_HARM * ls);
-          __builtin_nontemporal_store(er, l + FO_L_EGO_RISK * ls);
-          __builtin_nontemporal_store(orr, l + FO_L_OBST_RISK * ls);
-        }
+        if (LISTS && valid)
+          fo_store_lists(a.lists, (size_t)A * Tm1 * M, ((size_t)k * Tm1 + t) * M + m, cp, eh, oh, er, orr);
       }
       ex = ex1; ey = ey1; ec = ec1; es = es1; eth = eth1; ev = ev1;
       ex1 = ex2; ey1 = ey2; ec1 = ec2; es1 = es2; eth1 = eth2; ev1 = ev2;
@@ -594,11 +603,6 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #endif
 #ifndef FO_MINW
 #define FO_MINW 3    // waves per SIMD the register allocation has to allow (<= 168 VGPRs)
-#endif
-#ifdef FO_PLAIN_STORE
-#define FO_LSTORE(v, p) (*(p) = (v))
-#else
-#define FO_LSTORE(v, p) __builtin_nontemporal_store(v, p)
 #endif
 #ifndef FO_X
 #define FO_X 0       // timing experiments only (tools/build_variant.sh x1 -DFO_X=1 ...): 1 no pass 2, 2 no probe, 4 no harm
@@ -716,7 +720,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   const int m = min(tile * TILE + lane, a.M - 1);
   const int T = a.T, Tm1 = a.T - 1, M = a.M, A = a.A;
   const double *tjb = a.traj + (size_t)tile * T * NEF * TILE;  // uniform tile base
-  const double *tj = tjb + lane;
+  const double *tj = tjb + 2 * lane;
   double *cpw = cpbuf_all + wave * (WROWS * TILE);
   double *dvw = cpw + TC * TILE;
   double *hk = hk_all + wave * 4;
@@ -752,8 +756,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       }
       if (LISTS) {
         const size_t ls = (size_t)A * Tm1 * M;
-        for (int f = 0; f < FO_NL; ++f)
-          for (int t = 0; t < Tm1; ++t) a.lists[(size_t)f * ls + ((size_t)k * Tm1 + t) * M + m] = NAN;
+        for (int t = 0; t < Tm1; ++t) fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
       }
       continue;
     }
@@ -775,16 +778,19 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       const int Ld = min(L, T);
       double bestc = INFINITY;
       int tb = 0;
-      // latency-bound by construction (two loads, five operations per sample): eight samples in flight at a time
+      // latency-bound by construction (two loads, five operations per sample): eight samples in flight at a time.
+      // Every second sample is enough for a seed (on the bench workload the exact geometry runs as rarely as with all
+      // of them; stride 4 would cost a quarter more) -- and halves the loads of this phase.
+      constexpr int PS = 2;
 #pragma unroll 1
-      for (int t8 = 0; t8 < Ld; t8 += 8) {
+      for (int t8 = 0; t8 * PS < Ld; t8 += 8) {
         double vx[8], vy[8], gpx[8], gpy[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int t = min(t8 + u, Ld - 1);
-          const double *e = tj + (size_t)t * NEF * TILE;
-          vx[u] = e[0 * TILE];
-          vy[u] = e[1 * TILE];
+          const int t = min((t8 + u) * PS, Ld - 1);
+          const fo_d2 xy = fo_ld2(tj + (size_t)t * NEF * TILE);
+          vx[u] = xy.x;
+          vy[u] = xy.y;
           const cdp_t g = G + (size_t)t * NAF;   // eight scalar loads in flight as well (one lgkmcnt wait for all)
           gpx[u] = g[0];
           gpy[u] = g[1];
@@ -794,7 +800,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
                      "s"(gpx[6]), "s"(gpy[6]), "s"(gpx[7]), "s"(gpy[7]));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int t = min(t8 + u, Ld - 1);  // repeats of the last sample cannot win (strict <)
+          const int t = min((t8 + u) * PS, Ld - 1);  // repeats of the last sample cannot win (strict <)
           const double rx = gpx[u] - vx[u], ry = gpy[u] - vy[u];
           const double c2 = rx * rx + ry * ry;
           if (c2 < bestc) { bestc = c2; tb = t; }
@@ -802,7 +808,8 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       }
       const double *e = tj + (size_t)tb * NEF * TILE;                   // per-lane sample: gathers
       const double *g = a.atab + ((size_t)k * a.Ta + tb) * NAF;
-      dce = fo_rect_mm(e[0 * TILE], e[1 * TILE], e[2 * TILE], e[3 * TILE], g[0], g[1], g[2], g[3], hlA, hwA, a.wb, hlB, hwB);
+      const fo_d2 exy = fo_ld2(e), ecs = fo_ld2(e + EF(2));
+      dce = fo_rect_mm(exy.x, exy.y, ecs.x, ecs.y, g[0], g[1], g[2], g[3], hlA, hwA, a.wb, hlB, hwB);
       tdce = tb;
       const double thr = (dce + 0.51) * 1e-3;
       thr2 = thr * thr;
@@ -812,7 +819,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     double oh_at_cp = 0.0;
     int idx_or = 0, idx_cp = 0;
     const size_t ls = (size_t)A * Tm1 * M;
-    double *lp = LISTS ? a.lists + (size_t)k * Tm1 * M + m : nullptr;
+    size_t li = (size_t)k * Tm1 * M + m;  // index of the next sample in the list buffers
     // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
     // (harm_model.py:96-97: ego_dv = m_obs/(m_ego+m_obs) dv, obs_dv = m_ego/(m_ego+m_obs) dv)
     const bool lr4s = prot == 1;
@@ -847,8 +854,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
         if (lane < n) {
           const int item = q[lane];
           const int src = item & 63, row = item >> 6, ti = gbase + row;
-          const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + src;  // ego sample ti+1 of trajectory `src`
-          const double qex = e[0 * TILE], qey = e[1 * TILE], qec = e[2 * TILE], qes = e[3 * TILE];
+          const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + 2 * src;  // ego sample ti+1 of trajectory `src`
+          const fo_d2 qxy = fo_ld2(e), qcs = fo_ld2(e + EF(2));
+          const double qex = qxy.x, qey = qxy.y, qec = qcs.x, qes = qcs.y;
           const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti
           const double qpx = g0[0], qpy = g0[1], qisx = g0[6], qisy = g0[7];
           const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
@@ -888,9 +896,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       int ring = t0 % DVR;  // row of sample t in the ring of relative speeds
       const bool geo = do_hr && !(ablate & 4);
       const double *e0_ = tj + (size_t)t0 * NEF * TILE;
-      double nx_ = e0_[0 * TILE], ny_ = e0_[1 * TILE], nc_ = e0_[2 * TILE], ns_ = e0_[3 * TILE];
-      double nvx_ = e0_[6 * TILE], nvy_ = e0_[7 * TILE], nth_ = 0.0;
-      if (lr4s) nth_ = e0_[4 * TILE];
+      fo_d2 nxy = fo_ld2(e0_), ncs = fo_ld2(e0_ + EF(2)), nvv = fo_ld2(e0_ + EF(6));
+      double nth_ = 0.0;
+      if (lr4s) nth_ = e0_[EF(4)];
       const cdp_t gr0 = G + (size_t)min(t0, L - 1) * NAF;
       double npx = gr0[0], npy = gr0[1], npc = gr0[2], nps = gr0[3], nyaw = gr0[4], npvx = gr0[8], npvy = gr0[9];
       const cdp_t grp = G + (size_t)min(max(t0 - 1, 0), L - 1) * NAF;
@@ -901,13 +909,12 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(f_ego), "s"(f_obs), "s"(npx),
                    "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy), "s"(npvx), "s"(npvy), "s"(nyaw));
       for (int t = t0; t < t1; ++t) {
-        const double ex = nx_, ey = ny_, ec = nc_, es = ns_, evx = nvx_, evy = nvy_, eth = nth_;
+        const double ex = nxy.x, ey = nxy.y, ec = ncs.x, es = ncs.y, evx = nvv.x, evy = nvv.y, eth = nth_;
         const double px = npx, py = npy, pc = npc, ps = nps, pyaw = nyaw, pvx = npvx, pvy = npvy;
         {
           const double *e1 = tj + (size_t)min(t + 1, T - 1) * NEF * TILE;
-          nx_ = e1[0 * TILE]; ny_ = e1[1 * TILE]; nc_ = e1[2 * TILE]; ns_ = e1[3 * TILE];
-          nvx_ = e1[6 * TILE]; nvy_ = e1[7 * TILE];
-          if (lr4s) nth_ = e1[4 * TILE];
+          nxy = fo_ld2(e1); ncs = fo_ld2(e1 + EF(2)); nvv = fo_ld2(e1 + EF(6));
+          if (lr4s) nth_ = e1[EF(4)];
           const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
           npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3]; nyaw = g1[4]; npvx = g1[8]; npvy = g1[9];
         }
@@ -1076,12 +1083,8 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
               orr = 0.0;
             }
             if (LISTS) {
-              FO_LSTORE(cp, lp + FO_L_CP * ls);
-              FO_LSTORE(eh, lp + FO_L_EGO_HARM * ls);
-              FO_LSTORE(oh, lp + FO_L_OBST_HARM * ls);
-              FO_LSTORE(er, lp + FO_L_EGO_RISK * ls);
-              FO_LSTORE(orr, lp + FO_L_OBST_RISK * ls);
-              lp += M;
+              fo_store_lists(a.lists, ls, li, cp, eh, oh, er, orr);
+              li += M;
             }
           }
         };
@@ -1212,12 +1215,12 @@ __global__ __launch_bounds__(256) void fo_be_kernel(int M, int Mp, int T, int A,
   const int m = tile * TILE + lane;
   const int L = aint[2 * k + 1];
   const double hlB = acst[(size_t)k * NAC + 0], hwB = acst[(size_t)k * NAC + 1];
-  const double *tjl = traj + (size_t)tile * T * NEF * TILE + lane;  // this lane's column of the tile
+  const double *tjl = traj + (size_t)tile * T * NEF * TILE + 2 * lane;  // this lane's pairs of the tile
   const double *G = atab + (size_t)k * Ta * NAF;
   const bool active = m < M && L > 0 && T >= 2 && be_mask[(size_t)k * Mp + m];
   double decel = 0.0, btn = 0.0;
   if (active) {
-    const double v0 = tjl[5 * TILE], v1 = tjl[(size_t)(NEF + 5) * TILE];
+    const double v0 = tjl[EF(5)], v1 = tjl[(size_t)NEF * TILE + EF(5)];
     const double dend = dist[(size_t)(T - 1) * Mp + m];
     double min_d = __builtin_rint(fabs(mina[m]) * 100.0) / 100.0, max_d = 5.0;  // np.round(abs(min(min(a), 0)), 2)
     for (int it = 0; it < 10; ++it) {
@@ -1233,12 +1236,12 @@ __global__ __launch_bounds__(256) void fo_be_kernel(int M, int Mp, int T, int A,
           const int idx = min(max(j, 1), T - 1);
           const double xlo = dist[(size_t)(idx - 1) * Mp + m], xhi = dist[(size_t)idx * Mp + m];
           const double *r0 = tjl + (size_t)(idx - 1) * NEF * TILE, *r1 = tjl + (size_t)idx * NEF * TILE;
-          double xn = r0[0 * TILE], yn = r0[1 * TILE], tn = r0[4 * TILE];
+          double xn = r0[EF(0)], yn = r0[EF(1)], tn = r0[EF(4)];
           if (xhi != xlo) {
             const double w = sc - xlo, inv = xhi - xlo;
-            xn = (r1[0 * TILE] - xn) / inv * w + xn;
-            yn = (r1[1 * TILE] - yn) / inv * w + yn;
-            tn = (r1[4 * TILE] - tn) / inv * w + tn;
+            xn = (r1[EF(0)] - xn) / inv * w + xn;
+            yn = (r1[EF(1)] - yn) / inv * w + yn;
+            tn = (r1[EF(4)] - tn) / inv * w + tn;
           }
           double es, ec;
           sincos(tn, &es, &ec);
@@ -1477,7 +1480,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   }
 
   if (A > 0) {
-    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 3), dim3(256), (size_t)2 * T * (TILE + 1) * sizeof(double), s, M, T,
+    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 2), dim3(256), (size_t)2 * T * (TILE + 1) * sizeof(double), s, M, T,
                        Mp, d_x, d_y, d_theta, d_v, ctx->d_traj_tab);
     FO_HIP_TRY(ctx, hipGetLastError());
     SweepArgs a{};

@@ -10,9 +10,10 @@ import json
 import os
 
 import numpy as np
+import torch
 
 from .. import _native as N
-from ..sweep import DEFAULT_HARM_COEFF, MetricSweep, SweepResult
+from ..sweep import DEFAULT_HARM_COEFF, MetricSweep, SweepResult, list_views
 
 AVAILABLE = ("dce", "cp", "ttc", "ttce", "wttc", "be", "hr")   # metric.py:109-117
 
@@ -96,11 +97,13 @@ class BatchAssessment:
     def _to_host(self):
         if self._host is None:
             r = self.result
-            big = r.lists is not None and r.lists.numel() * 8 > self.HOST_CACHE_BYTES
+            big = r.lists_raw is not None and r.lists_raw.numel() * 8 > self.HOST_CACHE_BYTES
             self._host = {"cost": r.cost.cpu().numpy(), "safe": r.safe.cpu().numpy(),
                           "pair_f": None if (r.pair_f is None or big) else r.pair_f.cpu().numpy(),
                           "pair_i": None if (r.pair_i is None or big) else r.pair_i.cpu().numpy(),
-                          "lists": None if (r.lists is None or big) else r.lists.cpu().numpy()}
+                          # one copy of the raw buffer; the five lists are strided views of it
+                          "lists": None if (r.lists_raw is None or big) else
+                          list_views(r.lists_raw.cpu().numpy(), *r.lists_shape)}
         return self._host
 
     def _column(self, m):
@@ -109,10 +112,10 @@ class BatchAssessment:
         trajectory's own column crosses PCIe, gathered on the device."""
         h = self._to_host()
         if h["lists"] is not None:
-            return h["pair_f"][:, :, m], h["pair_i"][:, :, m], np.ascontiguousarray(h["lists"][:, :, :, m])
+            return h["pair_f"][:, :, m], h["pair_i"][:, :, m], np.stack([v[:, :, m] for v in h["lists"]])
         r = self.result
         return (r.pair_f[:, :, m].cpu().numpy(), r.pair_i[:, :, m].cpu().numpy(),
-                r.lists[:, :, :, m].contiguous().cpu().numpy())
+                torch.stack([v[:, :, m] for v in r.list_views()]).cpu().numpy())
 
     def result_dict(self, m):
         """the reference's nested dict for trajectory m; needs mode 'full'.
@@ -120,7 +123,7 @@ class BatchAssessment:
         One strided gather per output array pulls trajectory m's column out of the batch; the per-prediction entries
         are then cut from plain Python lists (``ndarray.tolist`` once per array), which is what keeps a planner that
         still asks trajectory by trajectory (interface.py:216-219) at a fraction of a millisecond per call."""
-        if self.result.lists is None:
+        if self.result.lists_raw is None:
             raise RuntimeError("result_dict needs the batch to be evaluated with mode='full'")
         h = self._to_host()
         cost = h["cost"][m]

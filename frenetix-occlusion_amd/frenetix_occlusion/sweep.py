@@ -18,13 +18,34 @@ DEFAULT_HARM_COEFF = dict(lr4s_const=-4.457, lr4s_speed=0.177, lr4s_side=0.244, 
 DEFAULT_METRICS = ("hr", "ttc", "ttce", "dce", "wttc", "cp")  # config/config.yaml:6-12
 
 
+def list_views(raw, A, Tm1, M):
+    """The five per-timestep lists (order of ``_native.LST``: cp, ego_harm, obst_harm, ego_risk, obst_risk) as strided
+    ``[A, T-1, M]`` views of the raw list buffer ``fo_sweep_run`` fills (layout: include/fo_hip.h -- cp dense, the
+    harms and the risks as interleaved pairs).  Works for torch tensors and numpy arrays alike."""
+    n = A * Tm1 * M
+    cp = raw[:n].reshape(A, Tm1, M)
+    harm = raw[n:3 * n].reshape(A, Tm1, M, 2)
+    risk = raw[3 * n:5 * n].reshape(A, Tm1, M, 2)
+    return [cp, harm[..., 0], harm[..., 1], risk[..., 0], risk[..., 1]]
+
+
 @dataclass
 class SweepResult:
     cost: torch.Tensor                    # [M, 16] float64
     safe: torch.Tensor                    # [M] uint8
     pair_f: Optional[torch.Tensor] = None  # [12, A, M] float64
     pair_i: Optional[torch.Tensor] = None  # [4, A, M] int32
-    lists: Optional[torch.Tensor] = None   # [5, A, T-1, M] float64
+    lists_raw: Optional[torch.Tensor] = None  # [5 A (T-1) M] float64, layout of include/fo_hip.h
+    lists_shape: tuple = (0, 0, 0)         # (A, T-1, M)
+
+    def list_views(self):
+        """five strided [A, T-1, M] views (no copy), order of ``_native.LST``"""
+        return None if self.lists_raw is None else list_views(self.lists_raw, *self.lists_shape)
+
+    @property
+    def lists(self):
+        """dense [5, A, T-1, M] copy (tests and small batches; large batches should use ``list_views``)"""
+        return None if self.lists_raw is None else torch.stack(self.list_views())
 
 
 def _vehicle_tuple(vp):
@@ -90,7 +111,7 @@ class MetricSweep:
         want = {"cost": ((M, N.NC), torch.float64), "safe": ((M,), torch.uint8),
                 "pair_f": ((N.NPF, A, M), torch.float64) if mode in ("pair", "full") else None,
                 "pair_i": ((N.NPI, A, M), torch.int32) if mode in ("pair", "full") else None,
-                "lists": ((N.NL, A, max(T - 1, 0), M), torch.float64) if mode == "full" else None}
+                "lists_raw": ((N.NL * A * max(T - 1, 0) * M,), torch.float64) if mode == "full" else None}
         for name, w in want.items():
             t = getattr(out, name)
             if w is None:
@@ -118,9 +139,10 @@ class MetricSweep:
                 out.pair_f = torch.empty((N.NPF, A, M), dtype=torch.float64, device=self.device)
                 out.pair_i = torch.empty((N.NPI, A, M), dtype=torch.int32, device=self.device)
             if mode == "full":
-                out.lists = torch.empty((N.NL, A, max(T - 1, 0), M), dtype=torch.float64, device=self.device)
+                out.lists_raw = torch.empty((N.NL * A * max(T - 1, 0) * M,), dtype=torch.float64, device=self.device)
         p = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
         self._last_inputs = (x, y, theta, v, a)
         self.ctx.call("fo_sweep_run", M, T, p(x), p(y), p(theta), p(v), p(a), p(out.cost), p(out.safe),
-                      p(out.pair_f), p(out.pair_i), p(out.lists), self._stream())
+                      p(out.pair_f), p(out.pair_i), p(out.lists_raw), self._stream())
+        out.lists_shape = (A, max(T - 1, 0), M)
         return out

@@ -20,7 +20,11 @@
  *     safe   uint8 [M]                  safety_assessment of metric.py:50-100
  *     pair_f [FO_NPF][A][M]             per (trajectory, agent) scalars
  *     pair_i int32 [FO_NPI][A][M]
- *     lists  [FO_NL][A][T-1][M]         per-timestep lists of hr.py:87-98 (NaN past the reference's list length)
+ *     lists  FO_NL A (T-1) M doubles    per-timestep lists of hr.py:87-98 (NaN past the reference's list length), n = A (T-1) M
+ *                                       entries each, in three blocks: collision probability [A][T-1][M] at offset 0;
+ *                                       (ego harm, obstacle harm) pairs [A][T-1][M][2] at offset n; (ego risk, obstacle risk)
+ *                                       pairs [A][T-1][M][2] at offset 3 n -- a GPU lane writes one sample with three
+ *                                       stores of 8 + 16 + 16 bytes, each contiguous across the trajectories of a wave
  */
 #ifndef FO_HIP_H
 #define FO_HIP_H

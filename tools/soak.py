@@ -48,7 +48,7 @@ def main():
     b = step()
     torch.cuda.synchronize()
     ref = dict(cost=out.cost.clone(), safe=out.safe.clone(), cls=sm.cell_class.clone(), occ=sm.occluded_cells().clone(),
-               pos=b.pos.clone(), lists_sum=out.lists.nan_to_num().sum().item(), pair_i=out.pair_i.clone())
+               pos=b.pos.clone(), lists_sum=out.lists_raw.nan_to_num().sum().item(), pair_i=out.pair_i.clone())
     times = []
     for blk in range(n // 100):
         torch.cuda.synchronize()
@@ -60,7 +60,7 @@ def main():
         assert torch.equal(out.cost.nan_to_num(), ref["cost"].nan_to_num()) and torch.equal(out.safe, ref["safe"])
         assert torch.equal(sm.cell_class, ref["cls"]) and torch.equal(sm.occluded_cells(), ref["occ"])
         assert torch.equal(b.pos, ref["pos"]) and torch.equal(out.pair_i, ref["pair_i"])
-        assert out.lists.nan_to_num().sum().item() == ref["lists_sum"]
+        assert out.lists_raw.nan_to_num().sum().item() == ref["lists_sum"]
     sw.ctx.call("fo_sweep_check", torch.cuda.current_stream().cuda_stream)
     print(f"{n} steps bit-identical; ms per step by block of 100: first {times[0]:.4f}, min {min(times):.4f}, "
           f"median {np.median(times):.4f}, last {times[-1]:.4f}")
