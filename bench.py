@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 def algorithmic_bytes(M, A, T, mode):
     """float64 storage.  Inputs read once, outputs written once (DESIGN.md 'Algorithmic bytes')."""
-    traj_in = M * T * 6 * 8              # tile table the sweep kernel reads: x, y, cos, sin, theta, v
-    agent_in = A * (T * 8 * 8 + 8 * 8)   # agent table rows + per-agent constants
+    traj_in = M * T * 8 * 8              # tile table the sweep kernel reads: x, y, cos, sin, theta, v, v cos, v sin
+    agent_in = A * (T * 12 * 8 + 8 * 8)  # agent table rows (96 B) + per-agent constants
     out = 0
     if mode in ("pair", "full"):
         out += M * A * (12 * 8 + 4 * 4)
@@ -243,7 +243,7 @@ def main():
             if not default_workload:
                 raise LookupError("the committed PMC summary belongs to the default workload")
             import csv
-            tag = os.environ.get("FO_PROFILE_TAG", "r01_final")
+            tag = os.environ.get("FO_PROFILE_TAG", "r02_final")
             with open(os.path.join(ROOT, "profiles", f"{tag}_summary.csv")) as f:
                 for row in csv.DictReader(f):
                     if row["kernel"].startswith("fo_sweep_queue_kernel") and row.get("WRITE_SIZE") and row.get("FETCH_SIZE"):
