@@ -28,7 +28,8 @@ constexpr int NEF = 8;     // ego fields per (t, trajectory): x, y, cos, sin, th
                            // fields (a vector-memory instruction costs the CU ~10 cycles whatever its width)
 constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, -, -
                            // (96-byte rows: the 32-byte and 16-byte groups the scalar loads fetch stay naturally aligned)
-constexpr int NAC = 8;     // per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type
+constexpr int NAC = 16;    // per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type, sum of the
+                           // circumradii, far-gate radius^2, logistic slopes (ego, obstacle) and offsets, -, -
 constexpr int NPS = 14;    // partial-reduction slots
 enum { PS_MIN_DCE = 0, PS_ARG_DCE, PS_MIN_TTC, PS_ARG_TTC, PS_MIN_TTCE, PS_MAX_ER, PS_MAX_OR, PS_ARG_OR, PS_MAX_EH,
        PS_MAX_OH, PS_MAX_CP, PS_MAX_HWC, PS_DCE_FLAG, PS_MAX_BTN };
@@ -70,6 +71,32 @@ __device__ __forceinline__ double fo_erf_fast(const double2 *__restrict__ tab, d
   p = fma(p, y, a1);
   p = fma(p, y, a0);
   return copysign(fma(e.y * d, p, e.x), u);
+}
+
+// The same with the argument already multiplied by 128 (the caller folds the factor into 1/(sigma sqrt 2), once per
+// sample): the node index is the low word of |v| + 1.5 * 2^52, d' = |v| - node is the offset in units of 1/128, and the
+// powers of two that turn d' and y' = node d' back into d and y = x0 d are folded into the coefficients (S = 2^-14 per
+// power of y or s, Q = 2^-7 for the leading d) -- 19 VALU operations instead of 24, no constant that has to be moved
+// into a vector register first.
+__device__ __forceinline__ double fo_erf_fast128(const double2 *__restrict__ tab, double v) {
+  constexpr double S = 0x1p-14, Q = 0x1p-7;
+  const double av = fmin(fabs(v), 768.0);
+  const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+  const double tm = av + MAGIC;
+  const double fi = tm - MAGIC;               // rint(|v|), exact
+  const int i = __double2loint(tm);
+  const double d = av - fi;
+  const double y = fi * d;
+  const double sq = d * d;
+  const double2 e = tab[i];
+  const double a0 = fma(sq, fma(sq, 0.1 * S * S * Q, -(1.0 / 3.0) * S * Q), Q);
+  const double a1 = fma(sq, 0.5 * S * S * Q, -S * Q);
+  const double a2 = fma(sq, -0.4 * S * S * S * Q, (2.0 / 3.0) * S * S * Q);
+  double p = fma(y, (2.0 / 15.0) * S * S * S * S * Q, -(1.0 / 3.0) * S * S * S * Q);
+  p = fma(p, y, a2);
+  p = fma(p, y, a1);
+  p = fma(p, y, a0);
+  return copysign(fma(e.y * d, p, e.x), v);
 }
 
 // four erf evaluations with the four LDS gathers issued back to back (one lgkmcnt wait instead of four)
@@ -139,6 +166,13 @@ __device__ __forceinline__ double fo_sqrt(double x) {
 }
 
 __device__ __forceinline__ double fo_round3(double v) { return __builtin_rint(v * 1000.0) / 1000.0; }  // np.round(v,3)
+// r / 1000.0, correctly rounded, for finite r: q = r RN(1/1000), one fma for the exact remainder, one for the correction
+// (three operations instead of the ~30 of a float64 division; checked against true division for every integer below 2e7)
+__device__ __forceinline__ double fo_div1000(double r) {
+  const double q = r * 0.001;
+  return fma(fma(-q, 1000.0, r), 0.001, q);
+}
+__device__ __forceinline__ double fo_round3_fast(double v) { return fo_div1000(__builtin_rint(v * 1000.0)); }
 
 // ------------------------------------------------------------------------------------------------ prep kernels
 // trajectories [M][T] (row per trajectory) -> tile table [tile][T][NEF][64], transposed through LDS so that both the
@@ -206,7 +240,8 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
                                       const double *__restrict__ v, const double *__restrict__ cov,
                                       const double *__restrict__ shape, const double *__restrict__ raw,
                                       const int32_t *__restrict__ type, const int32_t *__restrict__ len,
-                                      double ego_mass, double *__restrict__ tab, double *__restrict__ cst,
+                                      double ego_mass, double hlA, double hwA, fo_harm_coeff_t hc,
+                                      double *__restrict__ tab, double *__restrict__ cst,
                                       int32_t *__restrict__ aint, int *__restrict__ status, int gen) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A * Ta) return;
@@ -233,6 +268,17 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
     c[0] = 0.5 * raw[2 * k]; c[1] = 0.5 * raw[2 * k + 1]; c[2] = shape[2 * k] / 2.0;
     c[3] = m_obs / (ego_mass + m_obs); c[4] = ego_mass / (ego_mass + m_obs);
     c[5] = (double)fo_obstacle_protection(type[k]); c[6] = (double)L; c[7] = (double)type[k];
+    // what every wave that takes this agent would otherwise recompute
+    c[8] = sqrt(hlA * hlA + hwA * hwA) + sqrt(c[0] * c[0] + c[1] * c[1]);   // circumradii: centre distance - c[8] <= distance
+    c[9] = (5.0 + c[2] + 1e-6) * (5.0 + c[2] + 1e-6);   // beyond 5 m + half the inflated length no mean is in the gate
+    const bool lr4s = fo_obstacle_protection(type[k]) == 1;
+    // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
+    // (harm_model.py:96-97: ego_dv = m_obs/(m_ego+m_obs) dv, obs_dv = m_ego/(m_ego+m_obs) dv)
+    c[10] = lr4s ? -hc.lr4s_speed * c[3] : -hc.lr1s_speed * c[3];
+    c[11] = lr4s ? -hc.lr4s_speed * c[4] : -hc.ped_speed * c[4];
+    c[12] = -hc.lr1s_const;
+    c[13] = hc.ped_const;
+    c[14] = 0.0; c[15] = 0.0;
     aint[2 * k] = fo_obstacle_protection(type[k]);
     aint[2 * k + 1] = L;
   }
@@ -743,7 +789,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     if (k >= A) break;
     const cdp_t G = fo_const(a.atab) + (size_t)k * a.Ta * NAF;
     const cdp_t C = fo_const(a.acst) + (size_t)k * NAC;
-    const double hlB = C[0], hwB = C[1], hdev = C[2], f_ego = C[3], f_obs = C[4];
+    const double hlB = C[0], hwB = C[1], hdev = C[2], Rsum = C[8], gate_far2 = C[9];
     const int prot = fo_const(a.aint)[2 * k], L = fo_const(a.aint)[2 * k + 1];
     const int Lh = min(Tm1, L);
 
@@ -773,7 +819,6 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     // win the tie on t).
     double dce = INFINITY, thr2 = INFINITY, thrR2 = INFINITY;
     int tdce = 0;
-    const double Rsum = sqrt(hlA * hlA + hwA * hwA) + sqrt(hlB * hlB + hwB * hwB);
     if (do_dce && !(ablate & 1) && !(FO_X & 2)) {
       const int Ld = min(L, T);
       double bestc = INFINITY;
@@ -823,15 +868,10 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
     // (harm_model.py:96-97: ego_dv = m_obs/(m_ego+m_obs) dv, obs_dv = m_ego/(m_ego+m_obs) dv)
     const bool lr4s = prot == 1;
-    // They are wave-uniform, but the scalar registers are taken: parked in LDS, pass 2 reads them back into vector
-    // registers that are free by then (held across pass 1 they cost eight VGPRs at its register peak).
-    if (lane == 0) {
-      hk[0] = lr4s ? -a.hc.lr4s_speed * f_ego : -a.hc.lr1s_speed * f_ego;
-      hk[1] = lr4s ? -a.hc.lr4s_speed * f_obs : -a.hc.ped_speed * f_obs;
-      hk[2] = -a.hc.lr1s_const;
-      hk[3] = a.hc.ped_const;
-    }
-    const double gate_far2 = (5.0 + hdev + 1e-6) * (5.0 + hdev + 1e-6);
+    // The logistic slopes and offsets (fo_prep_agents_kernel) are wave-uniform, but the scalar registers are taken:
+    // parked in LDS, pass 2 reads them back into vector registers that are free by then (held across pass 1 they would
+    // cost eight VGPRs at its register peak).
+    if (lane < 4) hk[lane] = a.acst[(size_t)k * NAC + 10 + lane];
     // LR4S impact classes (0 front, 1 side, 2 rear) of the ego's and the obstacle's occupants: two bits per sample,
     // slot t & 15 (a chunk and its predecessor's last sample are live at once: TC + 1 <= 16 slots)
     unsigned cls_e = 0u, cls_o = 0u;
@@ -858,7 +898,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
           const fo_d2 qxy = fo_ld2(e), qcs = fo_ld2(e + EF(2));
           const double qex = qxy.x, qey = qxy.y, qec = qcs.x, qes = qcs.y;
           const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti
-          const double qpx = g0[0], qpy = g0[1], qisx = g0[6], qisy = g0[7];
+          const double qpx = g0[0], qpy = g0[1], qisx = g0[6] * ERF_SCALE, qisy = g0[7] * ERF_SCALE;
           const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
           const double devx = qc1 * hdev, devy = qs1 * hdev;
           const double rx = qex - qpx, ry = qey - qpy;
@@ -876,8 +916,8 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
                            (cy - a.off_y) * qisy, e4);
               acc = fma(e4[0] - e4[1], e4[2] - e4[3], acc);
 #else
-              const double fx = fo_erf_fast(erf_tab, (cx + a.off_x) * qisx) - fo_erf_fast(erf_tab, (cx - a.off_x) * qisx);
-              const double fy = fo_erf_fast(erf_tab, (cy + a.off_y) * qisy) - fo_erf_fast(erf_tab, (cy - a.off_y) * qisy);
+              const double fx = fo_erf_fast128(erf_tab, (cx + a.off_x) * qisx) - fo_erf_fast128(erf_tab, (cx - a.off_x) * qisx);
+              const double fy = fo_erf_fast128(erf_tab, (cy + a.off_y) * qisy) - fo_erf_fast128(erf_tab, (cy - a.off_y) * qisy);
               acc = fma(fx, fy, acc);
 #endif
             }
@@ -906,7 +946,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       // Scalar loads return out of order, so any use of an s_load result waits for lgkmcnt(0).  Pinning the per-agent
       // constants and the first rows here (an empty asm that names them as SGPR inputs) drains the counter before the
       // loop, which leaves the in-loop wait to cover only the row that was prefetched one iteration ago.
-      asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(f_ego), "s"(f_obs), "s"(npx),
+      asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(Rsum), "s"(gate_far2), "s"(npx),
                    "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy), "s"(npvx), "s"(npvy), "s"(nyaw));
       for (int t = t0; t < t1; ++t) {
         const double ex = nxy.x, ey = nxy.y, ec = ncs.x, es = ncs.y, evx = nvv.x, evy = nvv.y, eth = nth_;
@@ -1093,9 +1133,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     }
 
     // ------------------------------------------------------------------ per-pair scalars
-    const double dce_m = dce / 1000.0;                                                      // np.round(d, 3)
-    const double ttc = (dce == 0.0) ? fo_round3((double)tdce * a.dt) : INFINITY;            // ttc.py:43-46
-    const double ttce = fo_round3((double)tdce * a.dt);                                     // ttce.py:39
+    const double dce_m = (dce < INFINITY) ? fo_div1000(dce) : dce;                          // np.round(d, 3)
+    const double ttce = fo_round3_fast((double)tdce * a.dt);                                // ttce.py:39
+    const double ttc = (dce == 0.0) ? ttce : INFINITY;                                      // ttc.py:43-46
     if (a.be_mask) a.be_mask[(size_t)k * a.Mp + m] = (do_ttc && ttc < INFINITY && ttc > 0.0) ? 1 : 0;  // be.py:49-50
     const bool hr_valid = do_hr && Lh > 0;
     const double hwc = (max_cp > 0.01) ? oh_at_cp : 0.0;                                    // hr.py:81-84
@@ -1139,8 +1179,8 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   // ---------------- combine the waves of the workgroup (ascending agent order); scratch aliases the cp buffers
   __syncthreads();
   double *red = cpbuf_all;
-  double w_min_ttc = w_min_tttc == 0x7fffffff ? INFINITY : fo_round3((double)w_min_tttc * a.dt);
-  double w_min_ttce = w_min_tttce == 0x7fffffff ? INFINITY : fo_round3((double)w_min_tttce * a.dt);
+  double w_min_ttc = w_min_tttc == 0x7fffffff ? INFINITY : fo_round3_fast((double)w_min_tttc * a.dt);
+  double w_min_ttce = w_min_tttce == 0x7fffffff ? INFINITY : fo_round3_fast((double)w_min_tttce * a.dt);
   if (wave > 0) {
     double *rp = red + (size_t)(wave - 1) * NPS * TILE + lane;
     rp[PS_MIN_DCE * TILE] = w_min_dce; rp[PS_ARG_DCE * TILE] = (double)w_arg_dce; rp[PS_MIN_TTC * TILE] = w_min_ttc;
@@ -1438,7 +1478,8 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
   if (A > 0) {
     const int n = A * Ta;
     hipLaunchKernelGGL(fo_prep_agents_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, Ta, d_pos, d_yaw, d_v, d_cov,
-                       d_shape, d_raw_dims, d_type, d_len, ctx->veh.mass, ctx->d_agent_tab, ctx->d_agent_const,
+                       d_shape, d_raw_dims, d_type, d_len, ctx->veh.mass, 0.5 * ctx->veh.length, 0.5 * ctx->veh.width, ctx->hc,
+                       ctx->d_agent_tab, ctx->d_agent_const,
                        ctx->d_agent_int, ctx->d_status, gen);
     FO_HIP_TRY(ctx, hipGetLastError());
   }
