@@ -284,7 +284,10 @@ def main():
             res["cpu_baseline"] = cpu_baseline(S, traj, agents, thr, usable_cores())
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        if use_dist:   # RCCL's start-up banner sits in the C library's stdout buffer: let it out first, the JSON line last
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
