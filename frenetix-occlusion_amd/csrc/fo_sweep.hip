@@ -737,7 +737,10 @@ __device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(uns
 
 // ALLM: the default metric set (dce, cp, ttc, ttce, hr all active, no debug ablation) is compiled with the flags as
 // constants -- fewer wave-uniform masks to keep in SGPRs, fewer branches; any other selection takes the generic copy.
-template <bool PAIR, bool LISTS, bool ALLM>
+// SPLIT (small batches, where one agent per wave leaves most SIMDs with a single wave): the four waves of a workgroup
+// take the SAME agent and a quarter of the horizon each (time chunk `wave`); every per-pair result is a minimum or a
+// first maximum over time, so the segments are folded in time order through LDS at the end.  Needs T <= QWAVES * TC.
+template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT = false>
 __global__ __launch_bounds__(TILE *QWAVES) __attribute__((amdgpu_waves_per_eu(FO_MINW, FO_MINW)))
 void fo_sweep_queue_kernel(const SweepArgs a) {
   __shared__ double2 erf_tab[ERF_N];
@@ -783,8 +786,12 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   int w_arg_dce = -1, w_arg_ttc = -1, w_arg_or = -1;  // agent indices as integers: three VGPRs less than as doubles
   bool w_dce_flag = false;
 
-  const int k0 = (chunk * QWAVES + wave) * a.apw;
-  for (int kk = 0; kk < a.apw; ++kk) {
+  const int apw_ = SPLIT ? 1 : a.apw;
+  const int k0 = SPLIT ? chunk : (chunk * QWAVES + wave) * a.apw;
+  // the samples this wave owns: everything, or time chunk `wave` of the agent the workgroup shares
+  const int seg0 = SPLIT ? wave * TC : 0, seg1 = SPLIT ? min(seg0 + TC, a.T) : a.T;
+  const int gfirst_ = max(seg0 - 1, 0);  // first harm / cp sample this wave evaluates for an agent
+  for (int kk = 0; kk < apw_; ++kk) {
     const int k = k0 + kk;
     if (k >= A) break;
     const cdp_t G = fo_const(a.atab) + (size_t)k * a.Ta * NAF;
@@ -794,6 +801,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     const int Lh = min(Tm1, L);
 
     if (L <= 0) {  // inactive slot (a spawn buffer that is only partly filled): no outputs enter any reduction
+      if (SPLIT && wave > 0) continue;
       if (a.be_mask) a.be_mask[(size_t)k * a.Mp + m] = 0;
       if (PAIR) {
         const size_t ps_ = (size_t)A * M;
@@ -819,20 +827,20 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     // win the tie on t).
     double dce = INFINITY, thr2 = INFINITY, thrR2 = INFINITY;
     int tdce = 0;
-    if (do_dce && !(ablate & 1) && !(FO_X & 2)) {
-      const int Ld = min(L, T);
+    if (do_dce && !(ablate & 1) && !(FO_X & 2) && seg0 < min(L, seg1)) {
+      const int Ld = min(L, seg1);
       double bestc = INFINITY;
-      int tb = 0;
+      int tb = seg0;
       // latency-bound by construction (two loads, five operations per sample): eight samples in flight at a time.
       // Every second sample is enough for a seed (on the bench workload the exact geometry runs as rarely as with all
       // of them; stride 4 would cost a quarter more) -- and halves the loads of this phase.
       constexpr int PS = 2;
 #pragma unroll 1
-      for (int t8 = 0; t8 * PS < Ld; t8 += 8) {
+      for (int t8 = 0; seg0 + t8 * PS < Ld; t8 += 8) {
         double vx[8], vy[8], gpx[8], gpy[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int t = min((t8 + u) * PS, Ld - 1);
+          const int t = min(seg0 + (t8 + u) * PS, Ld - 1);
           const fo_d2 xy = fo_ld2(tj + (size_t)t * NEF * TILE);
           vx[u] = xy.x;
           vy[u] = xy.y;
@@ -845,7 +853,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
                      "s"(gpx[6]), "s"(gpy[6]), "s"(gpx[7]), "s"(gpy[7]));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int t = min((t8 + u) * PS, Ld - 1);  // repeats of the last sample cannot win (strict <)
+          const int t = min(seg0 + (t8 + u) * PS, Ld - 1);  // repeats of the last sample cannot win (strict <)
           const double rx = gpx[u] - vx[u], ry = gpy[u] - vy[u];
           const double c2 = rx * rx + ry * ry;
           if (c2 < bestc) { bestc = c2; tb = t; }
@@ -864,7 +872,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     double oh_at_cp = 0.0;
     int idx_or = 0, idx_cp = 0;
     const size_t ls = (size_t)A * Tm1 * M;
-    size_t li = (size_t)k * Tm1 * M + m;  // index of the next sample in the list buffers
+    size_t li = ((size_t)k * Tm1 + gfirst_) * M + m;  // index of the next sample in the list buffers
     // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
     // (harm_model.py:96-97: ego_dv = m_obs/(m_ego+m_obs) dv, obs_dv = m_ego/(m_ego+m_obs) dv)
     const bool lr4s = prot == 1;
@@ -884,8 +892,12 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     //  pass 2, samples [t0-1, t1-1): logistic models, risk, maxima, lists -- from LDS and registers only: no vector
     //          or scalar load shares a counter with the list stores (vmcnt retires loads and stores in issue order, so
     //          a load behind five stores per iteration used to wait for their acknowledgement).
-    for (int t0 = 0; t0 < T; t0 += TC) {
+    const int gfirst = gfirst_;
+    for (int t0 = seg0; t0 < seg1; t0 += TC) {
       const int t1 = min(t0 + TC, T);
+      // A segment other than the first also needs the relative speed and the impact classes of the sample before it
+      // (pass 2 covers the samples [t0-1, t1-1)): its pass 1 starts one sample early, for that part only.
+      const int tl = (SPLIT && t0 > 0) ? t0 - 1 : t0;
       const int gbase = t0 - 1;  // gate sample of buffer row 0
 
       // evaluates n (<= 64) queued in-gate samples, one per lane (collision_probability.py:77-122)
@@ -933,22 +945,23 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       unsigned gmask = 0u;  // bit row: gate sample gbase + row is inside the 5 m gate for this lane
       unsigned wgate = 0u;  // the same for the whole wave (uniform): some lane is inside the gate
       int qn = 0;
-      int ring = t0 % DVR;  // row of sample t in the ring of relative speeds
+      int ring = tl % DVR;  // row of sample t in the ring of relative speeds
       const bool geo = do_hr && !(ablate & 4);
-      const double *e0_ = tj + (size_t)t0 * NEF * TILE;
+      const double *e0_ = tj + (size_t)tl * NEF * TILE;
       fo_d2 nxy = fo_ld2(e0_), ncs = fo_ld2(e0_ + EF(2)), nvv = fo_ld2(e0_ + EF(6));
       double nth_ = 0.0;
       if (lr4s) nth_ = e0_[EF(4)];
-      const cdp_t gr0 = G + (size_t)min(t0, L - 1) * NAF;
+      const cdp_t gr0 = G + (size_t)min(tl, L - 1) * NAF;
       double npx = gr0[0], npy = gr0[1], npc = gr0[2], nps = gr0[3], nyaw = gr0[4], npvx = gr0[8], npvy = gr0[9];
-      const cdp_t grp = G + (size_t)min(max(t0 - 1, 0), L - 1) * NAF;
+      const cdp_t grp = G + (size_t)min(max(tl - 1, 0), L - 1) * NAF;
       double ppx = grp[0], ppy = grp[1];  // agent mean of the previous sample
       // Scalar loads return out of order, so any use of an s_load result waits for lgkmcnt(0).  Pinning the per-agent
       // constants and the first rows here (an empty asm that names them as SGPR inputs) drains the counter before the
       // loop, which leaves the in-loop wait to cover only the row that was prefetched one iteration ago.
       asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(Rsum), "s"(gate_far2), "s"(npx),
                    "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy), "s"(npvx), "s"(npvy), "s"(nyaw));
-      for (int t = t0; t < t1; ++t) {
+      for (int t = tl; t < t1; ++t) {
+        const bool own = !SPLIT || t >= t0;  // wave-uniform
         const double ex = nxy.x, ey = nxy.y, ec = ncs.x, es = ncs.y, evx = nvv.x, evy = nvv.y, eth = nth_;
         const double px = npx, py = npy, pc = npc, ps = nps, pyaw = nyaw, pvx = npvx, pvy = npvy;
         {
@@ -958,7 +971,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
           const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
           npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3]; nyaw = g1[4]; npvx = g1[8]; npvy = g1[9];
         }
-        if (do_dce && t < L && !(ablate & 1) && !(FO_X & 32)) {
+        if (do_dce && own && t < L && !(ablate & 1) && !(FO_X & 32)) {
           const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
           const double dx = px - ccx, dy = py - ccy;
           // nothing to gain after the (earliest) zero; otherwise the centres must be close enough
@@ -1017,7 +1030,7 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
           }
         }
         ring = (ring + 1 == DVR) ? 0 : ring + 1;
-        if (do_cp && t >= 1 && t < L && !(ablate & 2) && !(FO_X & 64)) {
+        if (do_cp && own && t >= 1 && t < L && !(ablate & 2) && !(FO_X & 64)) {
           // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
           const double rx = ex - ppx, ry = ey - ppy;
           const double d0 = rx * rx + ry * ry;
@@ -1108,8 +1121,8 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
             }
             // No lane of the wave is inside the gate at this sample (97 % of the samples of the bench workload): every
             // probability is zero, so are the risks, and none of the running maxima or indices can move -- they were
-            // seeded by sample 0, which always takes the long way.
-            if (!hv || t == 0 || ((wgate >> row) & 1u)) {
+            // seeded by the wave's first sample, which always takes the long way.
+            if (!hv || t == gfirst || ((wgate >> row) & 1u)) {
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
               if (hv) {
                 er = eh * cp;
@@ -1132,6 +1145,30 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
       }
     }
 
+    if (SPLIT) {
+      // ---------------------------------------------------------------- fold the four time segments, in time order
+      // (minimum with the earliest t for the DCE, first maximum for the risks and probabilities): each wave parks its
+      // values in its own LDS rows, wave 0 folds them and goes on to the outputs alone
+      if (wave > 0) {
+        double *sp = cpw + lane;
+        sp[0 * TILE] = dce; sp[1 * TILE] = (double)tdce; sp[2 * TILE] = max_er; sp[3 * TILE] = max_or;
+        sp[4 * TILE] = (double)idx_or; sp[5 * TILE] = max_eh; sp[6 * TILE] = max_oh; sp[7 * TILE] = max_cp;
+        sp[8 * TILE] = (double)idx_cp; sp[9 * TILE] = oh_at_cp;
+      }
+      __syncthreads();
+      if (wave > 0) continue;
+      for (int w = 1; w < QWAVES; ++w) {
+        const double *sp = cpbuf_all + w * (WROWS * TILE) + lane;
+        const double d_w = sp[0 * TILE];
+        const int t_w = (int)sp[1 * TILE];
+        if (d_w < dce || (d_w == dce && t_w < tdce)) { dce = d_w; tdce = t_w; }
+        max_er = fmax(max_er, sp[2 * TILE]);
+        if (sp[3 * TILE] > max_or) { max_or = sp[3 * TILE]; idx_or = (int)sp[4 * TILE]; }
+        max_eh = fmax(max_eh, sp[5 * TILE]);
+        max_oh = fmax(max_oh, sp[6 * TILE]);
+        if (sp[7 * TILE] > max_cp) { max_cp = sp[7 * TILE]; idx_cp = (int)sp[8 * TILE]; oh_at_cp = sp[9 * TILE]; }
+      }
+    }
     // ------------------------------------------------------------------ per-pair scalars
     const double dce_m = (dce < INFINITY) ? fo_div1000(dce) : dce;                          // np.round(d, 3)
     const double ttce = fo_round3_fast((double)tdce * a.dt);                                // ttce.py:39
@@ -1447,7 +1484,9 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
   int rc;
   if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)max_T * NEF * Mp))) return rc;
   // worst case number of chunks: one agent per wave
-  const size_t chunks = (size_t)(max_A + WAVES - 1) / WAVES + 1;  // WAVES <= QWAVES: the larger count
+  // one agent per wave, or (small batches) one workgroup per agent -- but then n_tiles * A < 3 072
+  const size_t chunks_split = (size_t)max_A + 1, tiles = (size_t)Mp / TILE;
+  const size_t chunks = tiles * max_A < 3072 ? chunks_split : (size_t)(max_A + WAVES - 1) / WAVES + 1;
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, chunks * NPS * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) * NAF))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(max_A > 0 ? max_A : 1) * NAC))) return rc;
@@ -1510,7 +1549,12 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   const int wpb = use_queue ? QWAVES : WAVES;  // waves per workgroup of the kernel that will run
   int apw = pick_apw(n_tiles, A, wpb);
   if (const char *e = getenv("FO_SWEEP_APW")) { const int v = atoi(e); if (v >= 1 && v <= 64) apw = v; }  // tuning aid
-  const int n_chunks = A > 0 ? (A + wpb * apw - 1) / (wpb * apw) : 0;
+  // Small batches: with one agent per wave the grid is n_tiles x A waves; below the 3 072 wave slots of the chip the
+  // horizon of every agent is split over the four waves of a workgroup instead (one workgroup per tile and agent).
+  bool split = use_queue && T <= QWAVES * TC && (long)n_tiles * A < 3072;
+  if (const char *e = getenv("FO_SWEEP_SPLIT")) split = use_queue && T <= QWAVES * TC && e[0] == '1';  // tests, A/B runs
+  if (split) apw = 1;
+  const int n_chunks = A > 0 ? (split ? A : (A + wpb * apw - 1) / (wpb * apw)) : 0;
   int rc;
   if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)T * NEF * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)(n_chunks + 1) * NPS * Mp))) return rc;
@@ -1548,7 +1592,15 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     if (use_queue) {
       const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
       const bool allm = (a.mask & all5) == all5 && a.ablate == 0;
-      if (allm) {
+      if (allm && split) {
+        if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, true, true>), g, b, 0, s, a);
+        else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, true, true>), g, b, 0, s, a);
+      } else if (split) {
+        if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, false, true>), g, b, 0, s, a);
+        else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, false, true>), g, b, 0, s, a);
+      } else if (allm) {
         if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, true>), g, b, 0, s, a);
         else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, true>), g, b, 0, s, a);

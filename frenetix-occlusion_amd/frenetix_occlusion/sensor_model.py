@@ -96,12 +96,22 @@ class HoleIndex:
             return ()
         from .scenario import points_in_polygon
         full = fov_deg >= 359.9
-        foot = footprint_polygon(ego, ego_yaw, fov_deg, r) if (footprint == "polygon" or not full) else None
+        foot = footprint_polygon(ego, ego_yaw, fov_deg, r) if not full else None
         out = []
         for i in cand:
             k, pts = self.holes[i]
-            inside = (np.hypot(pts[:, 0] - ego[0], pts[:, 1] - ego[1]) <= r).all()
-            if inside and foot is not None:
+            rho = np.hypot(pts[:, 0] - ego[0], pts[:, 1] - ego[1])
+            inside = (rho <= r).all()
+            if inside and full and footprint == "polygon":
+                # inside the regular 64-gon Point(ego).buffer(r) (a vertex at world angle 0): the distance along the
+                # normal of the sector's side stays below the apothem -- a handful of vector operations instead of a
+                # crossing-number pass over 64 edges
+                delta = 2.0 * np.pi / 64.0
+                phi = np.mod(np.arctan2(pts[:, 1] - ego[1], pts[:, 0] - ego[0]), delta)
+                near_side = rho * np.cos(phi - 0.5 * delta) > r * np.cos(0.5 * delta) * (1.0 - 1e-9)
+                if near_side.any():             # within a hair of the polygon's side: let the exact test decide
+                    inside = points_in_polygon(pts, footprint_polygon(ego, ego_yaw, fov_deg, r)).all()
+            elif inside and foot is not None:
                 inside = points_in_polygon(pts, foot).all()
             if inside:
                 out.append(k)
@@ -204,6 +214,7 @@ class SensorModel:
         if not torch.cuda.is_available():
             raise RuntimeError("SensorModel needs a ROCm GPU (no CPU fallback)")
         self.device = torch.device("cuda", int(device))
+        self._dev_index = int(device)
         self.ctx = ctx or N.Context(self.device.index)
         self.lanelet_network = lanelet_network
         self.ref_path = ref_path
@@ -336,7 +347,7 @@ class SensorModel:
         poly = self.footprint == "polygon"
         self.ctx.call("fo_scene_fan", self.n_rays, float(ego_orientation), self.sensor_angle, self.sensor_radius,
                       1 if poly else 0, dirs.data_ptr(), rmax.data_ptr() if poly else None,
-                      half.data_ptr() if poly else None, torch.cuda.current_stream().cuda_stream)
+                      half.data_ptr() if poly else None, N.current_stream(self._dev_index))
         return dirs, (rmax if poly else None), (half if poly else None)
 
     def enclosed_hole_rings(self, ego_pos, ego_orientation):
@@ -374,7 +385,7 @@ class SensorModel:
                       p(dirs), p(rmax), p(half), p(skip), O, p(d_corn),
                       p(d_cen), p(d_flags),
                       w.ix0, w.iy0, w.nx, w.ny, p(b["rng"]), p(b["hit"]), p(b["ring"]), p(b["ovis"]), p(b["cls"]),
-                      p(b["occ"]), p(b["n_occ"]), torch.cuda.current_stream().cuda_stream)
+                      p(b["occ"]), p(b["n_occ"]), N.current_stream(self._dev_index))
         self.window = w
         self.dirs, self.rmax, self.half_dirs, self.edge_skip = dirs, rmax, half, skip
         self.range, self.hit_id, self.cell_class = b["rng"], b["hit"], b["cls"]
@@ -407,7 +418,7 @@ class SensorModel:
         if getattr(self, "_fv_dirs_key", None) != key:
             self._fv_dirs = torch.empty((key, 2), dtype=torch.float64, device=dev)
             self.ctx.call("fo_scene_fan", key, 0.0, 360.0, r, 0, self._fv_dirs.data_ptr(), None, None,
-                          torch.cuda.current_stream().cuda_stream)
+                          N.current_stream(self._dev_index))
             self._fv_dirs_key = key
         revealed = torch.empty((M, K), dtype=torch.int32, device=dev)
         area = torch.empty((M, K), dtype=torch.float64, device=dev)
@@ -417,7 +428,7 @@ class SensorModel:
         self.ctx.call("fo_scene_future_visibility", M, T, tx.data_ptr(), ty.data_ptr(), int(t_stride), key,
                       self._fv_dirs.data_ptr(), r, O, p(d_corn), p(d_flags), self.occluded_idx_buffer.data_ptr(),
                       self.n_occluded.data_ptr(), w.ix0, w.iy0, w.nx, revealed.data_ptr(), area.data_ptr(),
-                      torch.cuda.current_stream().cuda_stream)
+                      N.current_stream(self._dev_index))
         return revealed, area
 
     def calc_visible_and_occluded_area(self, timestep, ego_pos, ego_orientation, obstacles):

@@ -15,6 +15,8 @@ from typing import Optional
 import numpy as np
 import torch
 
+from . import _native as N
+
 
 MIN_AHEAD = 3.0            # spawn_locator.py:234,381 "ahead by >= 3 m"
 S_THRESHOLD_TIME = 4.0     # spawn_locator.py:65-66,113: s_threshold = s_ego + max(4 v, 25)
@@ -79,6 +81,7 @@ class SpawnLocator:
         self.debug = debug
         self.ctx = sensor_model.ctx
         self.device = sensor_model.device
+        self._dev_index = self.device.index or 0
         acc = (config.get("accelerator") or {}).get("spawn", {}) if isinstance(config, dict) else {}
         self.max_agents = int(max_agents if max_agents is not None else acc.get("max_agents", 32))
         self.pattern = list(pattern if pattern is not None else acc.get("pattern",
@@ -153,7 +156,7 @@ class SpawnLocator:
                       self.var0, self.var_factor, b.cell.data_ptr(), b.pos0.data_ptr(), b.yaw0.data_ptr(),
                       b.n.data_ptr(), b.pos.data_ptr(), b.yaw.data_ptr(), b.v.data_ptr(), b.cov.data_ptr(),
                       b.shape.data_ptr(), b.raw_dims.data_ptr(), b.type.data_ptr(), b.len.data_ptr(),
-                      torch.cuda.current_stream().cuda_stream)
+                      N.current_stream(self._dev_index))
         return b
 
     def _rule_engine(self):

@@ -59,6 +59,7 @@ class MetricSweep:
         if not torch.cuda.is_available():
             raise RuntimeError("MetricSweep needs a ROCm GPU (no CPU fallback)")
         self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
+        self._dev_index = self.device.index
         self.ctx = ctx or N.Context(self.device.index)   # one fo_ctx per ego per GPU; shared with the scene stage
         self.dt = float(dt)
         self.metrics = tuple(metrics)
@@ -84,9 +85,8 @@ class MetricSweep:
             t = torch.as_tensor(np.ascontiguousarray(t))
         return t.to(device=self.device, dtype=dtype).contiguous()
 
-    @staticmethod
-    def _stream():
-        return torch.cuda.current_stream().cuda_stream
+    def _stream(self):
+        return N.current_stream(self._dev_index)
 
     def set_agents(self, pos, yaw, v, cov, shape, raw_dims, type, len, check=True):
         """pos [A,Ta,2], yaw/v [A,Ta], cov [A,Ta,2,2], shape/raw_dims [A,2], type/len [A] (numpy or torch)."""

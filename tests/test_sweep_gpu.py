@@ -20,6 +20,15 @@ def torch_cuda():
     return torch
 
 
+@pytest.fixture(autouse=True, params=["auto", "one-agent-per-wave"])
+def sweep_kernel_mode(request, monkeypatch):
+    """small batches take the kernel variant that splits an agent's horizon over the waves of a workgroup; every test of
+    this module also runs with that variant switched off, so that both code paths meet every case"""
+    if request.param != "auto":
+        monkeypatch.setenv("FO_SWEEP_SPLIT", "0")
+    return request.param
+
+
 def _hip_sweep(torch, traj, agents, veh, dt, metrics=None, thr=None, mode="full"):
     from frenetix_occlusion.sweep import DEFAULT_METRICS, MetricSweep
     sw = MetricSweep(veh, dt, metrics=metrics or DEFAULT_METRICS, thresholds=thr)
@@ -456,3 +465,24 @@ def test_reused_result_buffers_are_validated(torch_cuda):
     with pytest.raises(ValueError):
         run(traj, mode="everything")
     torch_cuda.cuda.synchronize()
+
+
+def test_horizon_split_variant_is_bit_identical(torch_cuda, monkeypatch):
+    """FO_SWEEP_SPLIT=1 (four waves share an agent, a quarter of the horizon each) against =0 (one agent per wave):
+    every output bit for bit, for full and short horizons, ragged predictions, every obstacle type"""
+    from frenetix_occlusion import synthetic as S
+    rng = np.random.default_rng(5)
+    for M, A, T in ((130, 7, 31), (64, 3, 32), (200, 12, 10), (65, 5, 2), (300, 9, 17), (1, 1, 31)):
+        traj = S.make_trajectories(M, T, 0.1, seed=100 + T)
+        agents = S.make_agents(A, T, 0.1, seed=200 + T, lateral=3.0)
+        agents["len"] = rng.integers(0, T + 1, A).astype(np.int32)
+        agents["type"] = rng.integers(0, 11, A).astype(np.int32)
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("FO_SWEEP_SPLIT", flag)
+            outs.append(_hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.2, "risk": 0.1, "ttc": 1.0}))
+            red = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.2, "risk": 0.1, "ttc": 1.0},
+                             mode="reduced")
+            assert np.array_equal(red["cost"], outs[-1]["cost"], equal_nan=True) and np.array_equal(red["safe"], outs[-1]["safe"])
+        for k in ("cost", "safe", "pair_f", "pair_i", "lists"):
+            assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (M, A, T, k)
