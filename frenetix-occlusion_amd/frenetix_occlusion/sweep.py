@@ -85,6 +85,27 @@ class MetricSweep:
             t = torch.as_tensor(np.ascontiguousarray(t))
         return t.to(device=self.device, dtype=dtype).contiguous()
 
+    def _upload_packed(self, arrays):
+        """host arrays [M,T] (x, y, theta, v[, a]) -> device tensors through ONE pinned staging buffer and ONE
+        host-to-device copy (five pageable copies of a 2 000 x 31 batch cost 0.1 ms more than the sweep itself)"""
+        n, (M, T) = len(arrays), arrays[0].shape
+        need = n * M * T
+        if getattr(self, "_pin", None) is None or self._pin.numel() < need:
+            self._pin = torch.empty(need, dtype=torch.float64).pin_memory()
+            self._stage = torch.empty(need, dtype=torch.float64, device=self.device)
+            self._pin_free = None
+        if self._pin_free is not None:
+            self._pin_free.synchronize()            # the previous copy out of the pinned buffer must have finished
+        host = self._pin[:need].view(n, M, T)
+        hv = host.numpy()
+        for i, arr in enumerate(arrays):
+            np.copyto(hv[i], arr, casting="unsafe")
+        dev = self._stage[:need].view(n, M, T)
+        dev.copy_(host, non_blocking=True)
+        self._pin_free = torch.cuda.Event()
+        self._pin_free.record()
+        return [dev[i] for i in range(n)]
+
     def _stream(self):
         return N.current_stream(self._dev_index)
 
@@ -124,8 +145,14 @@ class MetricSweep:
 
     def run(self, x, y, theta, v, a=None, mode="reduced", out: Optional[SweepResult] = None) -> SweepResult:
         """x,y,theta,v[,a]: [M,T].  mode: 'reduced' (cost+safe), 'pair' (+ per-pair scalars), 'full' (+ lists)."""
-        x, y, theta, v = self._dev(x), self._dev(y), self._dev(theta), self._dev(v)
-        a = self._dev(a) if a is not None else None
+        ins = [x, y, theta, v] + ([a] if a is not None else [])
+        if all(isinstance(q, np.ndarray) and q.ndim == 2 and q.shape == ins[0].shape for q in ins) and ins[0].size:
+            up = self._upload_packed(ins)
+            x, y, theta, v = up[:4]
+            a = up[4] if a is not None else None
+        else:
+            x, y, theta, v = self._dev(x), self._dev(y), self._dev(theta), self._dev(v)
+            a = self._dev(a) if a is not None else None
         M, T = int(x.shape[0]), int(x.shape[1])
         A = self.A
         if mode not in ("reduced", "pair", "full"):
