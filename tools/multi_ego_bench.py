@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: four egos x 2 000 candidate trajectories each, one fo_ctx / HIP stream per ego, egos dealt
+round-robin to the GPUs of the node (one process per GPU; launch with torch.distributed.run for N > 1, no collective:
+the egos are independent planners).  The scenario XMLs hold one planning problem each, so three more ego poses are
+placed along lanelet centre lines (scenario2 / scenario3 geometry fixtures, alternating).
+
+    python tools/multi_ego_bench.py [--egos 4] [--M 2000] [--A 32] [--steps 200] [--mode reduced]
+
+One "step" = one planning step of EVERY ego of this rank (scene stage + phantom sampling + sweep + reduction), all
+queued on the egos' own streams before one synchronisation.  Prints one JSON line per rank.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "frenetix-occlusion_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+from frenetix_occlusion import _native as N, interface, scenario as SC, synthetic as S  # noqa: E402
+from frenetix_occlusion.sensor_model import SensorModel  # noqa: E402
+from frenetix_occlusion.spawn_locator import SpawnLocator  # noqa: E402
+from frenetix_occlusion.sweep import MetricSweep  # noqa: E402
+
+
+def ego_poses(n):
+    sc0 = SC.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario2_geometry.npz"))
+    poses = [sc0.ego_initial.copy()]
+    for ll in sc0.lanelets:
+        c = ll.center
+        if len(c) >= 4 and len(poses) < n:
+            i = len(c) // 3
+            poses.append(np.array([c[i, 0], c[i, 1], math.atan2(c[i + 1, 1] - c[i, 1], c[i + 1, 0] - c[i, 0]), 6.0]))
+    return poses[:n]
+
+
+class Ego:
+    def __init__(self, idx, pose, dev, M, A, T):
+        self.pose = pose
+        self.stream = torch.cuda.Stream(device=dev)
+        ctx = N.Context(dev)
+        sc = SC.load_geometry_npz(os.path.join(ROOT, "tests", "golden", f"scenario{2 + idx % 2}_geometry.npz"))
+        with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+            cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=40.0)
+        yaw = float(pose[2])
+        ref = pose[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+        self.sm = SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx,
+                              device=dev)
+        self.sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
+        self.sl = SpawnLocator(None, ref, cfg, self.sm, dt=0.1, horizon=(T - 1) * 0.1)
+        self.sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, device=dev, ctx=ctx)
+        self.sw.reserve(M, T, A, T)
+        traj = S.make_trajectories(M, T, 0.1, seed=11 + idx, ego_pos=pose[:2], ego_yaw=yaw)
+        self.traj = [torch.as_tensor(traj[k]).to(f"cuda:{dev}") for k in ("x", "y", "theta", "v", "a")]
+        self.out = None
+
+    def step(self, mode):
+        with torch.cuda.stream(self.stream):
+            self.sm.launch(self.pose[:2], float(self.pose[2]))
+            args = self.sl.sample(self.pose[:2], float(self.pose[2]), float(self.pose[3])).sweep_args()
+            self.sw.set_agents(*args, check=False)
+            self.out = self.sw.run(*self.traj, mode=mode, out=self.out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--egos", type=int, default=4)
+    ap.add_argument("--M", type=int, default=2000)
+    ap.add_argument("--A", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--mode", default="reduced", choices=["reduced", "pair", "full"])
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(dev)
+    T = 31
+    mine = [(i, p) for i, p in enumerate(ego_poses(args.egos)) if i % world == rank]
+    egos = [Ego(i, p, dev, args.M, args.A, T) for i, p in mine]
+    torch.cuda.synchronize()
+
+    def step():
+        for e in egos:
+            e.step(args.mode)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # the same egos one after the other, each drained before the next starts (what sharing the GPU buys)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for e in egos:
+            e.step(args.mode)
+            e.stream.synchronize()
+    serial = (time.perf_counter() - t0) / args.steps
+    n_act = [int(e.sl.batch.n.item()) for e in egos]
+    print(json.dumps({"workload": "BASELINE configs[4]: multi-ego, one fo_ctx and stream per ego", "rank": rank, "n_gpus": world,
+                      "egos_on_this_gpu": len(egos), "M_per_ego": args.M, "phantoms_per_ego": n_act, "mode": args.mode,
+                      "ms_per_step_all_egos": dt * 1e3, "ms_per_step_egos_one_after_the_other": serial * 1e3,
+                      "pair_evals_per_sec": sum(args.M * a for a in n_act) / dt}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
