@@ -185,3 +185,27 @@ def test_served_from_batch_checks_object_identity():
     assert fresh and fresh[0][0] is stranger and served == [2]
     m.invalidate()
     assert m._batch is None and m._batch_objs == [] and m._batch_ids == {}
+
+
+def test_list_views_follow_the_documented_buffer_layout():
+    """include/fo_hip.h: cp [A][T-1][M] at offset 0, (ego harm, obstacle harm) pairs [A][T-1][M][2] at n, (ego risk,
+    obstacle risk) pairs at 3 n; sweep.list_views returns strided views in the order of _native.LST"""
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion.sweep import list_views
+    A, Tm1, M = 3, 4, 5
+    n = A * Tm1 * M
+    raw = np.arange(5 * n, dtype=np.float64)
+    views = list_views(raw, A, Tm1, M)
+    assert [v.shape for v in views] == [(A, Tm1, M)] * 5 and len(views) == N.NL
+    k, t, m = 2, 1, 3
+    i = (k * Tm1 + t) * M + m
+    assert views[N.LST["cp"]][k, t, m] == raw[i]
+    assert views[N.LST["ego_harm"]][k, t, m] == raw[n + 2 * i] and views[N.LST["obst_harm"]][k, t, m] == raw[n + 2 * i + 1]
+    assert views[N.LST["ego_risk"]][k, t, m] == raw[3 * n + 2 * i] and views[N.LST["obst_risk"]][k, t, m] == raw[3 * n + 2 * i + 1]
+    views[N.LST["obst_risk"]][k, t, m] = -1.0            # views, not copies
+    assert raw[3 * n + 2 * i + 1] == -1.0
+    torch = pytest.importorskip("torch")
+    tv = list_views(torch.arange(5 * n, dtype=torch.float64), A, Tm1, M)
+    assert float(tv[N.LST["ego_harm"]][k, t, m]) == n + 2 * i
+    empty = list_views(np.zeros(0), 0, Tm1, M)
+    assert all(v.shape == (0, Tm1, M) for v in empty)
