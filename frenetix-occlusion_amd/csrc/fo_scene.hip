@@ -31,8 +31,11 @@
 namespace {
 
 
-struct Scene {
-  // static map
+// the static map of a scenario: uploaded once (fo_scene_set_map / _set_routes / _set_edge_lines), read-only afterwards,
+// and shared by reference between the contexts of several egos on one GPU (fo_scene_share_map: BASELINE configs[4],
+// "shared occlusion map in HBM")
+struct StaticMap {
+  int refs = 1;
   int P = 0, E = 0;
   double cs = 0.5, x0 = 0, y0 = 0;
   int rnx = 0, rny = 0;
@@ -46,6 +49,19 @@ struct Scene {
   int R = 0, n_lanelets = 0;
   int32_t *d_route_first = nullptr, *d_route_count = nullptr, *d_lanelet_raster = nullptr;
   double *d_route_xy = nullptr, *d_route_s = nullptr;
+};
+
+void map_release(StaticMap *m) {
+  if (!m || --m->refs > 0) return;
+  void *ptrs[] = {m->d_edges, m->d_edge_line, m->d_chunk_box, m->d_sub_box, m->d_raster, m->d_lane_yaw, m->d_route_first,
+                  m->d_route_count, m->d_lanelet_raster, m->d_route_xy, m->d_route_s};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  delete m;
+}
+
+struct Scene {
+  StaticMap *map = new StaticMap();
   // per-step workspace
   size_t cap_cand = 0, cap_vis32 = 0;
   int32_t *d_vis32 = nullptr;     // [O] probe results (zero between steps)
@@ -1091,13 +1107,28 @@ extern "C" {
 void fo_scene_destroy_(fo_ctx *ctx) {
   if (!ctx || !ctx->scene) return;
   Scene *sc = (Scene *)ctx->scene;
-  void *ptrs[] = {sc->d_edges, sc->d_raster, sc->d_lane_yaw, sc->d_vis32, sc->d_route_first, sc->d_route_count, sc->d_lanelet_raster, sc->d_route_xy,
-                  sc->d_route_s, sc->d_flags, sc->d_blk,
-                  sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_edge_line, sc->d_chunk_box, sc->d_sub_box};
+  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  map_release(sc->map);
   delete sc;
   ctx->scene = nullptr;
+}
+
+// Let `ctx` read the static map another context of the same device has uploaded (edge soup, chunk boxes, road and
+// lane-heading rasters, route table) instead of holding a copy: several egos planning on one scenario on one GPU
+// (BASELINE configs[4]).  The per-step workspace stays per context.  The map is reference counted; a later
+// fo_scene_set_map on either context gives that context a map of its own again.
+int fo_scene_share_map(fo_ctx *ctx, fo_ctx *owner) {
+  if (!ctx || !owner || !owner->scene) return fo_fail(ctx, FO_E_ARG, "fo_scene_share_map: the owner has no map");
+  if (ctx->device != owner->device) return fo_fail(ctx, FO_E_ARG, "fo_scene_share_map: contexts live on different devices");
+  Scene *dst = scene_of(ctx), *src = (Scene *)owner->scene;
+  if (dst->map == src->map) return FO_OK;
+  if (src->map->P < 1) return fo_fail(ctx, FO_E_STATE, "fo_scene_share_map: the owner has not called fo_scene_set_map");
+  map_release(dst->map);
+  dst->map = src->map;
+  ++dst->map->refs;
+  return FO_OK;
 }
 
 int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double *h_poly_xy, int E,
@@ -1108,6 +1139,10 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
     return fo_fail(ctx, FO_E_ARG, "fo_scene_set_map: bad arguments (P=%d E=%d cs=%g)", P, E, cs);
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   Scene *sc = scene_of(ctx);
+  if (sc->map->refs > 1) {  // shared with other contexts: this one gets a map of its own
+    map_release(sc->map);
+    sc->map = new StaticMap();
+  }
   const int V = h_poly_off[P];
   double xmin = INFINITY, ymin = INFINITY, xmax = -INFINITY, ymax = -INFINITY;
   double *pbox = new double[4 * (size_t)P];
@@ -1121,38 +1156,38 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
     xmin = fmin(xmin, bx0); ymin = fmin(ymin, by0); xmax = fmax(xmax, bx1); ymax = fmax(ymax, by1);
   }
   if (h_raster_origin_or_null && h_raster_dims_or_null) {
-    sc->x0 = h_raster_origin_or_null[0]; sc->y0 = h_raster_origin_or_null[1];
-    sc->rnx = h_raster_dims_or_null[0]; sc->rny = h_raster_dims_or_null[1];
+    sc->map->x0 = h_raster_origin_or_null[0]; sc->map->y0 = h_raster_origin_or_null[1];
+    sc->map->rnx = h_raster_dims_or_null[0]; sc->map->rny = h_raster_dims_or_null[1];
   } else {  // origin snapped to whole cells so that windows of different steps share cell boundaries
-    sc->x0 = floor((xmin - margin) / cs) * cs;
-    sc->y0 = floor((ymin - margin) / cs) * cs;
-    sc->rnx = (int)ceil((xmax + margin - sc->x0) / cs);
-    sc->rny = (int)ceil((ymax + margin - sc->y0) / cs);
+    sc->map->x0 = floor((xmin - margin) / cs) * cs;
+    sc->map->y0 = floor((ymin - margin) / cs) * cs;
+    sc->map->rnx = (int)ceil((xmax + margin - sc->map->x0) / cs);
+    sc->map->rny = (int)ceil((ymax + margin - sc->map->y0) / cs);
   }
-  if (sc->rnx < 1 || sc->rny < 1 || (long)sc->rnx * sc->rny > (1L << 28)) {
+  if (sc->map->rnx < 1 || sc->map->rny < 1 || (long)sc->map->rnx * sc->map->rny > (1L << 28)) {
     delete[] pbox;
-    return fo_fail(ctx, FO_E_ARG, "fo_scene_set_map: raster %d x %d out of range", sc->rnx, sc->rny);
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_set_map: raster %d x %d out of range", sc->map->rnx, sc->map->rny);
   }
-  sc->P = P; sc->E = E; sc->cs = cs;
-  sc->R = 0;  // a new raster invalidates the route table
-  if (sc->d_lanelet_raster) { (void)hipFree(sc->d_lanelet_raster); sc->d_lanelet_raster = nullptr; }
-  for (void **p : {(void **)&sc->d_edges, (void **)&sc->d_raster, (void **)&sc->d_lane_yaw, (void **)&sc->d_chunk_box,
-                   (void **)&sc->d_edge_line, (void **)&sc->d_sub_box}) {
+  sc->map->P = P; sc->map->E = E; sc->map->cs = cs;
+  sc->map->R = 0;  // a new raster invalidates the route table
+  if (sc->map->d_lanelet_raster) { (void)hipFree(sc->map->d_lanelet_raster); sc->map->d_lanelet_raster = nullptr; }
+  for (void **p : {(void **)&sc->map->d_edges, (void **)&sc->map->d_raster, (void **)&sc->map->d_lane_yaw, (void **)&sc->map->d_chunk_box,
+                   (void **)&sc->map->d_edge_line, (void **)&sc->map->d_sub_box}) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   }
   int32_t *d_off = nullptr;
   double *d_xy = nullptr, *d_box = nullptr;
-  const size_t cells = (size_t)sc->rnx * sc->rny;
+  const size_t cells = (size_t)sc->map->rnx * sc->map->rny;
   FO_HIP_TRY(ctx, hipMalloc((void **)&d_off, sizeof(int32_t) * (P + 1)));
   FO_HIP_TRY(ctx, hipMalloc((void **)&d_xy, sizeof(double) * 2 * V));
   FO_HIP_TRY(ctx, hipMalloc((void **)&d_box, sizeof(double) * 4 * P));
-  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_raster, cells));
-  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_edges, sizeof(double) * 4 * (size_t)(E > 0 ? E : 1)));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_raster, cells));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_edges, sizeof(double) * 4 * (size_t)(E > 0 ? E : 1)));
   FO_HIP_TRY(ctx, hipMemcpy(d_off, h_poly_off, sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice));
   FO_HIP_TRY(ctx, hipMemcpy(d_xy, h_poly_xy, sizeof(double) * 2 * V, hipMemcpyHostToDevice));
   FO_HIP_TRY(ctx, hipMemcpy(d_box, pbox, sizeof(double) * 4 * P, hipMemcpyHostToDevice));
   delete[] pbox;
-  if (E > 0) FO_HIP_TRY(ctx, hipMemcpy(sc->d_edges, h_edges, sizeof(double) * 4 * (size_t)E, hipMemcpyHostToDevice));
+  if (E > 0) FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_edges, h_edges, sizeof(double) * 4 * (size_t)E, hipMemcpyHostToDevice));
   {  // bounding boxes of the 64-piece chunks the scans cull by (tight when the caller's order is spatially coherent)
     const int nc = (E + 63) / 64;
     double *cb = new double[4 * (size_t)(nc > 0 ? nc : 1)];
@@ -1165,9 +1200,9 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
       }
       cb[4 * c] = bx0; cb[4 * c + 1] = by0; cb[4 * c + 2] = bx1; cb[4 * c + 3] = by1;
     }
-    hipError_t e1 = hipMalloc((void **)&sc->d_chunk_box, sizeof(double) * 4 * (size_t)(nc > 0 ? nc : 1));
+    hipError_t e1 = hipMalloc((void **)&sc->map->d_chunk_box, sizeof(double) * 4 * (size_t)(nc > 0 ? nc : 1));
     if (e1 == hipSuccess && nc > 0)
-      e1 = hipMemcpy(sc->d_chunk_box, cb, sizeof(double) * 4 * (size_t)nc, hipMemcpyHostToDevice);
+      e1 = hipMemcpy(sc->map->d_chunk_box, cb, sizeof(double) * 4 * (size_t)nc, hipMemcpyHostToDevice);
     delete[] cb;
     FO_HIP_TRY(ctx, e1);
     double *sb = new double[16 * (size_t)(nc > 0 ? nc : 1)];
@@ -1180,20 +1215,20 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
       }
       sb[4 * c] = bx0; sb[4 * c + 1] = by0; sb[4 * c + 2] = bx1; sb[4 * c + 3] = by1;
     }
-    e1 = hipMalloc((void **)&sc->d_sub_box, sizeof(double) * 16 * (size_t)(nc > 0 ? nc : 1));
+    e1 = hipMalloc((void **)&sc->map->d_sub_box, sizeof(double) * 16 * (size_t)(nc > 0 ? nc : 1));
     if (e1 == hipSuccess && nc > 0)
-      e1 = hipMemcpy(sc->d_sub_box, sb, sizeof(double) * 16 * (size_t)nc, hipMemcpyHostToDevice);
+      e1 = hipMemcpy(sc->map->d_sub_box, sb, sizeof(double) * 16 * (size_t)nc, hipMemcpyHostToDevice);
     delete[] sb;
     FO_HIP_TRY(ctx, e1);
   }
   hipLaunchKernelGGL(fo_raster_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, P, d_off, d_xy, d_box,
-                     sc->x0, sc->y0, cs, sc->rnx, sc->rny, sc->d_raster);
+                     sc->map->x0, sc->map->y0, cs, sc->map->rnx, sc->map->rny, sc->map->d_raster);
   FO_HIP_TRY(ctx, hipGetLastError());
   FO_HIP_TRY(ctx, hipDeviceSynchronize());
   (void)hipFree(d_off); (void)hipFree(d_xy); (void)hipFree(d_box);
   if (h_lane_yaw_or_null) {
-    FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_lane_yaw, sizeof(double) * cells));
-    FO_HIP_TRY(ctx, hipMemcpy(sc->d_lane_yaw, h_lane_yaw_or_null, sizeof(double) * cells, hipMemcpyHostToDevice));
+    FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_lane_yaw, sizeof(double) * cells));
+    FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_lane_yaw, h_lane_yaw_or_null, sizeof(double) * cells, hipMemcpyHostToDevice));
   }
   return FO_OK;
 }
@@ -1208,37 +1243,37 @@ int fo_scene_set_routes(fo_ctx *ctx, int P, int R, const int32_t *h_first, const
     if (h_count[i] < 0 || h_first[i] < 0 || (long)h_first[i] + h_count[i] > NV)
       return fo_fail(ctx, FO_E_ARG, "fo_scene_set_routes: route %d leaves the vertex table", i);
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  for (void **p : {(void **)&sc->d_route_first, (void **)&sc->d_route_count, (void **)&sc->d_lanelet_raster,
-                   (void **)&sc->d_route_xy, (void **)&sc->d_route_s}) {
+  for (void **p : {(void **)&sc->map->d_route_first, (void **)&sc->map->d_route_count, (void **)&sc->map->d_lanelet_raster,
+                   (void **)&sc->map->d_route_xy, (void **)&sc->map->d_route_s}) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   }
-  const size_t cells = (size_t)sc->rnx * sc->rny, nvs = (size_t)(NV > 0 ? NV : 1);
-  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_route_first, sizeof(int32_t) * P * R));
-  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_route_count, sizeof(int32_t) * P * R));
-  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_lanelet_raster, sizeof(int32_t) * cells));
-  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_route_xy, sizeof(double) * 2 * nvs));
-  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_route_s, sizeof(double) * nvs));
-  FO_HIP_TRY(ctx, hipMemcpy(sc->d_route_first, h_first, sizeof(int32_t) * P * R, hipMemcpyHostToDevice));
-  FO_HIP_TRY(ctx, hipMemcpy(sc->d_route_count, h_count, sizeof(int32_t) * P * R, hipMemcpyHostToDevice));
-  FO_HIP_TRY(ctx, hipMemcpy(sc->d_lanelet_raster, h_lanelet_raster, sizeof(int32_t) * cells, hipMemcpyHostToDevice));
+  const size_t cells = (size_t)sc->map->rnx * sc->map->rny, nvs = (size_t)(NV > 0 ? NV : 1);
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_route_first, sizeof(int32_t) * P * R));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_route_count, sizeof(int32_t) * P * R));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_lanelet_raster, sizeof(int32_t) * cells));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_route_xy, sizeof(double) * 2 * nvs));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_route_s, sizeof(double) * nvs));
+  FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_route_first, h_first, sizeof(int32_t) * P * R, hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_route_count, h_count, sizeof(int32_t) * P * R, hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_lanelet_raster, h_lanelet_raster, sizeof(int32_t) * cells, hipMemcpyHostToDevice));
   if (NV > 0) {
-    FO_HIP_TRY(ctx, hipMemcpy(sc->d_route_xy, h_xy, sizeof(double) * 2 * NV, hipMemcpyHostToDevice));
-    FO_HIP_TRY(ctx, hipMemcpy(sc->d_route_s, h_s, sizeof(double) * NV, hipMemcpyHostToDevice));
+    FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_route_xy, h_xy, sizeof(double) * 2 * NV, hipMemcpyHostToDevice));
+    FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_route_s, h_s, sizeof(double) * NV, hipMemcpyHostToDevice));
   }
-  sc->R = R;
-  sc->n_lanelets = P;
+  sc->map->R = R;
+  sc->map->n_lanelets = P;
   return FO_OK;
 }
 
 int fo_scene_map_info(fo_ctx *ctx, double *x0, double *y0, double *cs, int *nx, int *ny, int *n_edges) {
   if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_map_info: no map set");
   Scene *sc = (Scene *)ctx->scene;
-  if (x0) *x0 = sc->x0;
-  if (y0) *y0 = sc->y0;
-  if (cs) *cs = sc->cs;
-  if (nx) *nx = sc->rnx;
-  if (ny) *ny = sc->rny;
-  if (n_edges) *n_edges = sc->E;
+  if (x0) *x0 = sc->map->x0;
+  if (y0) *y0 = sc->map->y0;
+  if (cs) *cs = sc->map->cs;
+  if (nx) *nx = sc->map->rnx;
+  if (ny) *ny = sc->map->rny;
+  if (n_edges) *n_edges = sc->map->E;
   return FO_OK;
 }
 
@@ -1246,21 +1281,21 @@ int fo_scene_copy_raster(fo_ctx *ctx, uint8_t *h_out) {
   if (!ctx || !ctx->scene || !h_out) return fo_fail(ctx, FO_E_STATE, "fo_scene_copy_raster: no map set");
   Scene *sc = (Scene *)ctx->scene;
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  FO_HIP_TRY(ctx, hipMemcpy(h_out, sc->d_raster, (size_t)sc->rnx * sc->rny, hipMemcpyDeviceToHost));
+  FO_HIP_TRY(ctx, hipMemcpy(h_out, sc->map->d_raster, (size_t)sc->map->rnx * sc->map->rny, hipMemcpyDeviceToHost));
   return FO_OK;
 }
 
 int fo_scene_set_edge_lines(fo_ctx *ctx, int E, const int32_t *h_line) {
   if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_set_edge_lines: call fo_scene_set_map first");
   Scene *sc = (Scene *)ctx->scene;
-  if (E != sc->E || (E > 0 && !h_line)) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_edge_lines: E must match the map");
+  if (E != sc->map->E || (E > 0 && !h_line)) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_edge_lines: E must match the map");
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (sc->d_edge_line) { (void)hipFree(sc->d_edge_line); sc->d_edge_line = nullptr; }
+  if (sc->map->d_edge_line) { (void)hipFree(sc->map->d_edge_line); sc->map->d_edge_line = nullptr; }
   if (E == 0) return FO_OK;
   for (int e = 0; e < E; ++e)
     if (h_line[e] < 0 || h_line[e] >= E) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_edge_lines: label out of [0, E)");
-  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->d_edge_line, sizeof(int32_t) * (size_t)E));
-  FO_HIP_TRY(ctx, hipMemcpy(sc->d_edge_line, h_line, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_edge_line, sizeof(int32_t) * (size_t)E));
+  FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_edge_line, h_line, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice));
   return FO_OK;
 }
 
@@ -1301,28 +1336,28 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
   const dim3 rgrid(n_rays + (probes ? 5 * O : 0)), rblock(64 * RAY_WAVES);
   if (d_edge_skip)
-    hipLaunchKernelGGL(fo_rays_kernel<true>, rgrid, rblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O, d_ocorn,
+    hipLaunchKernelGGL(fo_rays_kernel<true>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
                        probes ? sc->d_vis32 : nullptr, sc->d_namb);
   else
-    hipLaunchKernelGGL(fo_rays_kernel<false>, rgrid, rblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O, d_ocorn,
+    hipLaunchKernelGGL(fo_rays_kernel<false>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
                        probes ? sc->d_vis32 : nullptr, sc->d_namb);
-  hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->d_raster, sc->rnx, sc->rny, sc->x0,
-                     sc->y0, sc->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
+  hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->map->d_raster, sc->map->rnx, sc->map->rny, sc->map->x0,
+                     sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
                      n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk, probes ? O : 0, sc->d_vis32,
-                     probes ? d_obst_vis : nullptr, exact_cells ? 1 : 0, sc->E, d_hit_id, d_rmax, sc->d_amb,
-                     sc->d_namb, d_half, sc->d_edge_line);
+                     probes ? d_obst_vis : nullptr, exact_cells ? 1 : 0, sc->map->E, d_hit_id, d_rmax, sc->d_amb,
+                     sc->d_namb, d_half, sc->map->d_edge_line);
   if (exact_cells) {
     if ((uintptr_t)d_cls & 3) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: d_cls must be 4-byte aligned");
     const dim3 sgrid(SETTLE_BLOCKS + O), sblock(64 * RAY_WAVES);
     if (d_edge_skip)
-      hipLaunchKernelGGL(fo_settle_kernel<true>, sgrid, sblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O,
-                         d_ocorn, d_oflags, sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
+      hipLaunchKernelGGL(fo_settle_kernel<true>, sgrid, sblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O,
+                         d_ocorn, d_oflags, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
                          d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny);
     else
-      hipLaunchKernelGGL(fo_settle_kernel<false>, sgrid, sblock, 0, s, sc->E, sc->d_edges, sc->d_chunk_box, d_edge_skip, O,
-                         d_ocorn, d_oflags, sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
+      hipLaunchKernelGGL(fo_settle_kernel<false>, sgrid, sblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O,
+                         d_ocorn, d_oflags, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
                          d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny);
   }
   FO_HIP_TRY(ctx, hipGetLastError());
@@ -1342,8 +1377,8 @@ int fo_scene_future_visibility(fo_ctx *ctx, int M, int T, const double *d_x, con
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int K = (T + t_stride - 1) / t_stride;
   hipLaunchKernelGGL(fo_future_visibility_kernel, dim3((unsigned)((size_t)M * K)), dim3(FV_THREADS), 0, (hipStream_t)stream,
-                     T, d_x, d_y, t_stride, K, n_rays, d_dirs, r, sc->E, sc->d_edges, sc->d_sub_box, O, d_ocorn,
-                     d_oflags, d_occ_idx, d_n_occ, sc->x0, sc->y0, sc->cs, win_ix0, win_iy0, win_nx, d_revealed, d_area);
+                     T, d_x, d_y, t_stride, K, n_rays, d_dirs, r, sc->map->E, sc->map->d_edges, sc->map->d_sub_box, O, d_ocorn,
+                     d_oflags, d_occ_idx, d_n_occ, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, d_revealed, d_area);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
 }
@@ -1361,7 +1396,7 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
       !d_path || T < 1 || !d_cell || !d_pos0 || !d_yaw0 || !d_n || !d_pos || !d_yaw || !d_v || !d_cov || !d_shape ||
       !d_raw_dims || !d_type || !d_len)
     return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn: bad arguments");
-  if (routes < 0 || (routes > 0 && !sc->d_lanelet_raster))
+  if (routes < 0 || (routes > 0 && !sc->map->d_lanelet_raster))
     return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn: routes = %d needs fo_scene_set_routes first", routes);
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1369,8 +1404,8 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
   int rc;
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
   if ((rc = fo_reserve(ctx, &sc->d_cand, &sc->cap_cand, (size_t)cells))) return rc;
-  hipLaunchKernelGGL(fo_spawn_flag_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, d_cls, win_nx, win_ny, sc->x0,
-                     sc->y0, sc->cs, win_ix0, win_iy0, ego_x, ego_y, head_x, head_y, min_ahead, max_dist, all_occluded ? 1 : 0,
+  hipLaunchKernelGGL(fo_spawn_flag_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, d_cls, win_nx, win_ny, sc->map->x0,
+                     sc->map->y0, sc->map->cs, win_ix0, win_iy0, ego_x, ego_y, head_x, head_y, min_ahead, max_dist, all_occluded ? 1 : 0,
                      sc->d_flags, sc->d_blk);
   if ((rc = compact(ctx, sc, sc->d_flags, cells, sc->d_cand, sc->d_ncand, s))) return rc;
   SpawnTypes st;
@@ -1380,9 +1415,9 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
   }
   const int R = routes > 0 ? routes : 1;
   hipLaunchKernelGGL(fo_spawn_predict_kernel, dim3(max_agents * R), dim3(64), 0, s, max_agents, R, sc->d_cand, sc->d_ncand,
-                     sc->x0, sc->y0, sc->cs, n_path, d_path, sc->d_lane_yaw, st, T, dt, var0, var_factor, win_nx, win_ix0,
-                     win_iy0, sc->rnx, sc->rny, routes > 0 ? sc->d_lanelet_raster : nullptr, sc->R, sc->d_route_first,
-                     sc->d_route_count, sc->d_route_xy, sc->d_route_s, d_cell, d_pos0, d_yaw0, d_n, d_pos, d_yaw, d_v,
+                     sc->map->x0, sc->map->y0, sc->map->cs, n_path, d_path, sc->map->d_lane_yaw, st, T, dt, var0, var_factor, win_nx, win_ix0,
+                     win_iy0, sc->map->rnx, sc->map->rny, routes > 0 ? sc->map->d_lanelet_raster : nullptr, sc->map->R, sc->map->d_route_first,
+                     sc->map->d_route_count, sc->map->d_route_xy, sc->map->d_route_s, d_cell, d_pos0, d_yaw0, d_n, d_pos, d_yaw, d_v,
                      d_cov, d_shape, d_raw_dims, d_type, d_len);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;

@@ -28,7 +28,7 @@ EXPORTS = [
     "fo_abi_version", "fo_create", "fo_destroy", "fo_last_error",
     "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read",
-    "fo_scene_set_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
+    "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
     "fo_scene_candidate_count",
 ]
 
@@ -82,6 +82,7 @@ def load():
     lib.fo_sweep_last_launch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     D = C.c_double
     lib.fo_scene_set_map.argtypes = [vp, C.c_int, ip, dp, C.c_int, dp, D, D, dp, dp, ip]
+    lib.fo_scene_share_map.argtypes = [vp, vp]
     lib.fo_scene_set_routes.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.c_int, dp, dp, ip]
     lib.fo_scene_map_info.argtypes = [vp] + [C.POINTER(D)] * 3 + [C.POINTER(C.c_int)] * 3
     lib.fo_scene_copy_raster.argtypes = [vp, vp]

@@ -197,7 +197,7 @@ class VisibleArea:
 class SensorModel:
     def __init__(self, lanelet_network, ref_path, sensor_radius=30, sensor_angle=90, debug=True, visualization=None,
                  ctx: Optional[N.Context] = None, n_rays=720, cell_size=0.5, device=0, routes=0,
-                 footprint="polygon", enclosed_holes="transparent", cell_visibility="exact"):
+                 footprint="polygon", enclosed_holes="transparent", cell_visibility="exact", share_map_with=None):
         """lanelet_network: a :class:`~frenetix_occlusion.scenario.MapGeometry`, a list of
         :class:`~frenetix_occlusion.scenario.Lanelet`, or an object with ``.lanelets`` (duck-typed CommonRoad).
 
@@ -205,7 +205,10 @@ class SensorModel:
         radius.  enclosed_holes: "transparent" = an interior ring of the road union that the footprint encloses casts
         no shadow (the reference walks exterior rings only, sensor_model.py:126-131), "occlude" = every boundary piece
         occludes.  cell_visibility: "exact" = cells the ray fan cannot decide (their two enclosing rays stop at
-        different occluders) are settled by the reference's set algebra at the cell centre, "fan" = chord rule only."""
+        different occluders) are settled by the reference's set algebra at the cell centre, "fan" = chord rule only.
+        share_map_with: another SensorModel of the same scenario on the same GPU (an ego of a multi-ego run): the static
+        map is neither recomputed on the host nor uploaded again, both contexts read one copy in HBM
+        (``fo_scene_share_map``); ``lanelet_network`` is then ignored."""
         if (footprint not in ("polygon", "circle") or enclosed_holes not in ("transparent", "occlude")
                 or cell_visibility not in ("exact", "fan")):
             raise ValueError("footprint: 'polygon' | 'circle'; enclosed_holes: 'transparent' | 'occlude'; "
@@ -235,7 +238,22 @@ class SensorModel:
         self.ego_orientation = None
         self.window = None
         self.cell_class = None
-        self._set_map(lanelet_network)
+        if share_map_with is not None:
+            self._share_map(share_map_with)
+        else:
+            self._set_map(lanelet_network)
+
+    def _share_map(self, other):
+        """take over another SensorModel's static map: host-side geometry by reference, device-side by fo_scene_share_map"""
+        if other.device != self.device or other.cell_size != self.cell_size or (self.routes > 0 and other.routes != self.routes):
+            raise ValueError("share_map_with: the other SensorModel must live on the same GPU with the same cell size "
+                             "(and route count)")
+        self.lanelet_network = other.lanelet_network
+        self.map_geometry, self.hole_index = other.map_geometry, other.hole_index
+        self._skip_key, self._edge_skip = (), None
+        self.raster_origin, self.raster_dims, self.lane_yaw = other.raster_origin, other.raster_dims, other.lane_yaw
+        self.route_table, self.lanelet_raster = other.route_table, other.lanelet_raster
+        self.ctx.call("fo_scene_share_map", other.ctx._h)
 
     # ---- one-off: replaces _convert_lanelet_network (sensor_model.py:195-199)
     def _set_map(self, net):

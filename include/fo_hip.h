@@ -128,6 +128,13 @@ int fo_sweep_last_launch(const fo_ctx *ctx, int *grid, int *block, int *agents_p
 int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double *h_poly_xy, int E,
                      const double *h_edges, double cs, double margin, const double *h_lane_yaw_or_null,
                      const double *h_raster_origin_or_null, const int32_t *h_raster_dims_or_null);
+/* Instead of fo_scene_set_map: let `ctx` read the static map (boundary pieces and their chunk boxes, road and
+ * lane-heading rasters, chain labels, route table) that `owner` -- another context on the same device -- has uploaded,
+ * by reference.  Several egos planning on one scenario on one GPU (BASELINE configs[4]: "shared occlusion map in HBM")
+ * then hold the map once; every per-step buffer stays per context.  Reference counted: destroying the owner does not
+ * pull the map away, and a later fo_scene_set_map gives the calling context a map of its own again.  (No counterpart in
+ * the reference, which builds one shapely road polygon per SensorModel, sensor_model.py:195-199.) */
+int fo_scene_share_map(fo_ctx *ctx, fo_ctx *owner);
 /* One-off, after fo_scene_set_map (replaces FORoutePlanner, route_planner.py:15-90, evaluated for every lanelet up
  * front): HOST arrays.  Lanelet index p (order of the polygons given to fo_scene_set_map) has up to R candidate routes;
  * route r occupies vertices [first[p*R+r], first[p*R+r] + count[p*R+r]) of xy [NV][2] / s [NV] (arc length from the

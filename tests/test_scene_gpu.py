@@ -296,3 +296,53 @@ def test_phantom_vehicle_predictions_follow_lanelet_routes(torch_cuda, oracle):
         veh_routes = ln.reshape(n, R)[types != 4]
         assert (veh_routes[:, 0] > 0).all() and (veh_routes > 0).sum() > len(veh_routes)    # some vehicle has 2 routes
         assert (ln.reshape(n, R)[types == 4][:, 1:] == 0).all()
+
+
+def test_static_map_shared_between_contexts(torch_cuda):
+    """BASELINE configs[4] ('shared occlusion map in HBM'): a second ego's SensorModel reads the first one's static map
+    by reference (fo_scene_share_map).  Same outputs as with a map of its own, at its own pose, also after the owner
+    is gone; a context on which fo_scene_set_map is called again detaches without disturbing the other."""
+    import gc
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    torch = torch_cuda
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    poses = [(ego[0], ego[1], float(ego[2])), (ego[0] + 6.0, ego[1] - 0.3, float(ego[2]) + 0.2)]
+    ref = ego[None, :2] + np.linspace(0.0, 60.0, 61)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+    cfg = _default_config()
+    cfg["accelerator"]["spawn"].update(max_agents=16, routes=3)
+
+    def outputs(sm, pose):
+        ob = FOObstacles(sc.obstacles)
+        ob.update(0)
+        sm.calc_visible_and_occluded_area(0, np.array(pose[:2]), pose[2], ob)
+        b = SpawnLocator(None, ref, cfg, sm, dt=0.1, horizon=3.0).sample(np.array(pose[:2]), pose[2], 7.0)
+        torch.cuda.synchronize()
+        return [t.cpu().numpy().copy() for t in (sm.range, sm.hit_id, sm.cell_class, sm.occluded_cells(), b.pos, b.yaw, b.len,
+                                                  b.type, b.n)] + [sm.road_raster()]
+
+    mk = lambda **kw: SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, routes=3, **kw)
+    own = [outputs(mk(), p) for p in poses]                       # every ego with a map of its own
+    first = mk()
+    second = mk(share_map_with=first)
+    assert second.map_geometry is first.map_geometry
+    got = [outputs(first, poses[0]), outputs(second, poses[1])]
+    for a, b in zip(own, got):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+    del first                                                     # the map is reference counted
+    gc.collect()
+    again = outputs(second, poses[1])
+    for x, y in zip(own[1], again):
+        assert np.array_equal(x, y, equal_nan=True)
+    third = mk(share_map_with=second)
+    third._set_map(S.load_geometry_npz(os.path.join(GOLDEN, "scenario2_geometry.npz")).lanelets)   # detaches
+    for x, y in zip(own[1], outputs(second, poses[1])):
+        assert np.array_equal(x, y, equal_nan=True)
+    other_dev_free = N.Context(0)
+    with pytest.raises(N.NativeError):
+        other_dev_free.call("fo_scene_share_map", N.Context(0)._h)    # the owner has no map

@@ -40,7 +40,7 @@ def ego_poses(n):
 
 
 class Ego:
-    def __init__(self, idx, pose, dev, M, A, T):
+    def __init__(self, idx, pose, dev, M, A, T, share_with=None):
         self.pose = pose
         self.stream = torch.cuda.Stream(device=dev)
         ctx = N.Context(dev)
@@ -50,8 +50,9 @@ class Ego:
         cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=40.0)
         yaw = float(pose[2])
         ref = pose[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+        # egos on the same scenario and GPU read one copy of the static map (fo_scene_share_map)
         self.sm = SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx,
-                              device=dev)
+                              device=dev, share_map_with=share_with.sm if share_with is not None else None)
         self.sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
         self.sl = SpawnLocator(None, ref, cfg, self.sm, dt=0.1, horizon=(T - 1) * 0.1)
         self.sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, device=dev, ctx=ctx)
@@ -82,7 +83,11 @@ def main():
     torch.cuda.set_device(dev)
     T = 31
     mine = [(i, p) for i, p in enumerate(ego_poses(args.egos)) if i % world == rank]
-    egos = [Ego(i, p, dev, args.M, args.A, T) for i, p in mine]
+    egos = []
+    for i, p in mine:
+        same = next((e for e in egos if e.scenario == 2 + i % 2), None)
+        egos.append(Ego(i, p, dev, args.M, args.A, T, share_with=same))
+        egos[-1].scenario = 2 + i % 2
     torch.cuda.synchronize()
 
     def step():
