@@ -29,7 +29,10 @@ from .utils.fo_obstacle import FOObstacles
 
 
 class FOInterface:
-    def __init__(self, scenario, reference_path, vehicle_params, dt, config_path=None, cosy_cl=None):
+    def __init__(self, scenario, reference_path, vehicle_params, dt, config_path=None, cosy_cl=None, share_map_with=None):
+        """Signature of the reference (interface.py:69) plus ``share_map_with``: another FOInterface of the same scenario
+        on the same GPU (the planner of another ego) whose static map this one reads instead of building and uploading
+        its own (BASELINE configs[4])."""
         self.config = self._load_config(config_path)
         acc = self.config.get("accelerator") or {}
         if not torch.cuda.is_available():
@@ -67,7 +70,8 @@ class FOInterface:
                                         device=self.device.index, routes=int((acc.get("spawn") or {}).get("routes", 0)),
                                         footprint=str(acc.get("footprint", "polygon")),
                                         enclosed_holes=str(acc.get("enclosed_holes", "transparent")),
-                                        cell_visibility=str(acc.get("cell_visibility", "exact")))
+                                        cell_visibility=str(acc.get("cell_visibility", "exact")),
+                                        share_map_with=share_map_with.sensor_model if share_map_with is not None else None)
         self.agent_manager = FOAgentManager(scenario=self.cr_scenario, reference_path=self.ego_reference_path,
                                             config=self.config["agent_manager"], visualization=None,
                                             timestep=self.timestep, dt=self.dt, debug=self.debug,

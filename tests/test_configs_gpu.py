@@ -22,7 +22,7 @@ def torch_cuda():
     return torch
 
 
-def _interface(tmp_path, scenario_file, ego, metrics=None, thresholds=None, spawn=None, name="occ.yaml"):
+def _interface(tmp_path, scenario_file, ego, metrics=None, thresholds=None, spawn=None, name="occ.yaml", share=None):
     import yaml
     from frenetix_occlusion import interface
     from frenetix_occlusion import scenario as S
@@ -42,7 +42,7 @@ def _interface(tmp_path, scenario_file, ego, metrics=None, thresholds=None, spaw
     ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
     v = SY.VEHICLE_BMW320I
     veh = SimpleNamespace(length=v[0], width=v[1], wb_rear_axle=v[2], mass=v[3], a_max=v[4])
-    return interface.FOInterface(sc, ref_path, veh, 0.1, config_path=str(p)), sc, ego, SY
+    return interface.FOInterface(sc, ref_path, veh, 0.1, config_path=str(p), share_map_with=share), sc, ego, SY
 
 
 def _agents_of(fo):
@@ -116,9 +116,13 @@ def test_config5_multi_ego_four_interfaces_share_the_gpu(torch_cuda, oracle, tmp
             poses.append(np.array([c[i, 0], c[i, 1], yaw, 6.0]))
     assert len(poses) == 4
     thr = {"harm": 0.1, "risk": 1}
-    egos = [_interface(tmp_path, "scenario2_geometry.npz" if i % 2 == 0 else "scenario3_geometry.npz", p, thresholds=thr,
-                       spawn=dict(max_agents=16, all_occluded=True, max_dist=40.0), name=f"occ{i}.yaml")
-            for i, p in enumerate(poses)]
+    egos = []
+    for i, p in enumerate(poses):    # egos 0/2 plan on scenario 2, egos 1/3 on scenario 3: the second of each pair reads
+        share = egos[i - 2][0] if i >= 2 else None      # the first one's static map (one copy in HBM)
+        egos.append(_interface(tmp_path, "scenario2_geometry.npz" if i % 2 == 0 else "scenario3_geometry.npz", p,
+                               thresholds=thr, spawn=dict(max_agents=16, all_occluded=True, max_dist=40.0),
+                               name=f"occ{i}.yaml", share=share))
+    assert egos[2][0].sensor_model.map_geometry is egos[0][0].sensor_model.map_geometry
     results = []
     for fo, sc, ego, SY in egos:          # all four steps are queued before anything is read back
         fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
