@@ -18,6 +18,9 @@ kernel and the best one kept -- which also brings the GPU to its sustained clock
 depend on W (`--no-autotune` skips it).  `--scene scenario1 --M 2000 --A 32` runs BASELINE configs[1] instead.
 
 Prints ONE JSON line on rank 0.  `value` = trajectory x agent metric evaluations per second over all ranks.
+With the default workload on one GPU the line also carries `config.small_batch`: the same planning step at BASELINE
+configs[1] (scenario1 geometry, 2 000 candidates x 32 phantom slots), i.e. ms per planning step at the reference's own
+problem size (a few hundred steps of ~0.1 ms after the timed region).
 """
 import argparse
 import json
@@ -78,6 +81,61 @@ def cpu_baseline(S, traj, agents, thr, threads):
             "sample": f"first {Ms} trajectories x {A} agents of the same batch (same phantom set the GPU step produced), "
                       f"full outputs, oracle/fo_oracle.c, OpenMP over trajectories on {threads} threads, best of 3 "
                       f"passes ({best:.2f} s each)"}
+
+
+def small_batch_step(local_rank, steps=300):
+    """BASELINE configs[1] beside the headline: scenario1 geometry, 2 000 candidates x 32 phantom slots, the same planning
+    step (scene stage + sampling + sweep + reduction, reduced outputs as a planner consumes them), own context; a few
+    hundred steps of ~0.1 ms.  Reported under config.small_batch -- ms per planning step at the reference's own size."""
+    import math
+    import numpy as np
+    import torch
+    import yaml
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as SC
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.sweep import MetricSweep
+    M, A, T = 2000, 32, 31
+    ctx = N.Context(local_rank)
+    sc = SC.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=45.0)
+    yaw = float(ego[2])
+    ref = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    sm = SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx, device=local_rank)
+    sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
+    sl = SpawnLocator(None, ref, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, device=local_rank, ctx=ctx)
+    sw.reserve(M, T, A, T)
+    traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 2, ego_pos=ego[:2], ego_yaw=yaw)
+    tr = [torch.as_tensor(traj[k]).to(f"cuda:{local_rank}") for k in ("x", "y", "theta", "v", "a")]
+    out = None
+
+    def step():
+        nonlocal out
+        sm.launch(ego[:2], yaw)
+        sw.set_agents(*sl.sample(ego[:2], yaw, float(ego[3])).sweep_args(), check=False)
+        out = sw.run(*tr, mode="reduced", out=out)
+
+    for _ in range(100):
+        step()
+    torch.cuda.synchronize()
+    sw.ctx.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kms, kn = sw.ctx.timing_read()
+    sw.ctx.timing(False)
+    return {"workload": "BASELINE configs[1]: scenario1 geometry, 2000 trajectories x 32 phantom slots, T=31, reduced outputs",
+            "ms_per_step": dt * 1e3, "sweep_kernel_ms": kms / max(kn, 1), "A_active": int(sl.batch.n.item()), "steps": steps,
+            "sweep_grid": sw.ctx.last_launch()["grid"]}
 
 
 def main():
@@ -277,6 +335,8 @@ def main():
             res["config"]["gate_pair_frac"] = float((out.pair_f[N.PF["max_collision_probability"]] > 0).double().mean())
             res["config"]["collision_pair_frac"] = float((out.pair_f[N.PF["dce"]] == 0).double().mean())
             res["config"]["safe_traj_frac"] = float(out.safe.double().mean())
+        if world == 1 and default_workload:
+            res["config"]["small_batch"] = small_batch_step(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             if scene is not None:
                 b = scene["sl"].batch
