@@ -36,6 +36,9 @@ def main():
                "dce": float(rng.uniform(0, 1)), "cp": float(rng.uniform(0.1, 1))}
         if rng.random() < 0.3:
             thr = {k: v for k, v in thr.items() if rng.random() < 0.5}
+        # both sweep variants: horizon split over the waves of a workgroup (what batches this small take by default)
+        # and one agent per wave
+        os.environ["FO_SWEEP_SPLIT"] = "1" if it % 2 == 0 else "0"
         ref = oracle.sweep(traj, agents, SY.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr, nthreads=8)
         got = TS._hip_sweep(torch, traj, agents, SY.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr)
         w = TS._compare(oracle, ref, got)
