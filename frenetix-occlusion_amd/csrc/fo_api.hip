@@ -21,8 +21,8 @@ int fo_create(fo_ctx **out, int device) {
   fo_ctx *ctx = new (std::nothrow) fo_ctx();
   if (!ctx) return FO_E_NOMEM;
   ctx->device = device;
-  if (hipMalloc((void **)&ctx->d_status, sizeof(int)) != hipSuccess) { delete ctx; return FO_E_NOMEM; }
-  if (hipMemset(ctx->d_status, 0, sizeof(int)) != hipSuccess) { (void)hipFree(ctx->d_status); delete ctx; return FO_E_HIP; }
+  if (hipMalloc((void **)&ctx->d_status, 2 * sizeof(int)) != hipSuccess) { delete ctx; return FO_E_NOMEM; }
+  if (hipMemset(ctx->d_status, 0, 2 * sizeof(int)) != hipSuccess) { (void)hipFree(ctx->d_status); delete ctx; return FO_E_HIP; }
   if (fo_sweep_init_(ctx) != FO_OK) { fo_destroy(ctx); return FO_E_HIP; }
   *out = ctx;
   return FO_OK;
@@ -42,6 +42,7 @@ void fo_destroy(fo_ctx *ctx) {
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->d_erf_tab) (void)hipFree(ctx->d_erf_tab);
   if (ctx->d_exp_tab) (void)hipFree(ctx->d_exp_tab);
+  if (ctx->d_gl_tab) (void)hipFree(ctx->d_gl_tab);
   if (ctx->d_agent_int) (void)hipFree(ctx->d_agent_int);
   if (ctx->ev_start) {
     for (int i = 0; i < fo_ctx::kMaxTimed; ++i) { (void)hipEventDestroy(ctx->ev_start[i]); (void)hipEventDestroy(ctx->ev_stop[i]); }
@@ -62,8 +63,8 @@ int fo_sweep_check(fo_ctx *ctx, void *stream) {
   FO_HIP_TRY(ctx, hipMemcpy(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
   if (st != 0 && st == ctx->status_gen)  // recorded by the latest fo_sweep_set_agents
     return fo_fail(ctx, FO_E_UNSUPPORTED_COV,
-                   "agent covariance with non-zero off-diagonal terms: only diagonal covariances (what "
-                   "agent.py:260-280 produces) are implemented; affected collision probabilities are NaN");
+                   "an agent's covariance is no usable matrix (asymmetric, not positive, or |correlation| > 0.99): "
+                   "the affected collision probabilities are NaN");
   return FO_OK;
 }
 

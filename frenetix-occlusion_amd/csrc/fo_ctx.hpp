@@ -23,11 +23,13 @@ struct fo_ctx {
   double *d_agent_tab = nullptr;    // [A][Ta][NAF]
   double *d_agent_const = nullptr;  // [A][NAC]
   void *d_erf_tab = nullptr;        // erf lookup table (fo_sweep.hip)
-  void *d_exp_tab = nullptr;        // 2^(j/64) table
+  void *d_exp_tab = nullptr;        // 2^(j/256) table
+  void *d_gl_tab = nullptr;         // Gauss-Legendre nodes / weights (box probabilities under correlated covariances)
   int32_t *d_agent_int = nullptr;   // [A][2] protection class, valid length
   size_t cap_agent_int = 0;
-  int *d_status = nullptr;          // device status word: generation of the last fo_sweep_set_agents call that met an
-                                    // off-diagonal covariance (compared with status_gen; never cleared, so no per-step memset)
+  int *d_status = nullptr;          // [2] device status words: generation of the last fo_sweep_set_agents call that met
+                                    // [0] an unusable covariance, [1] a correlated one (compared with status_gen;
+                                    // never cleared, so no per-step memset)
   int status_gen = 0;
   size_t cap_agent_tab = 0, cap_agent_const = 0;
 

@@ -26,7 +26,9 @@ constexpr int WAVES = 4;   // waves per workgroup
 constexpr int NEF = 8;     // ego fields per (t, trajectory): x, y, cos, sin, theta, v, v cos, v sin -- stored as four
                            // pairs per trajectory, [t][pair][trajectory][2]: one 16-byte load per lane fetches two
                            // fields (a vector-memory instruction costs the CU ~10 cycles whatever its width)
-constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, -, -
+constexpr int GL_A = 48, GL_B = 96;   // node counts of the two Gauss-Legendre rules (fo_box_corr)
+typedef const double __attribute__((address_space(4))) *cdp_gl_t;
+constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, rho, -
                            // (96-byte rows: the 32-byte and 16-byte groups the scalar loads fetch stay naturally aligned)
 constexpr int NAC = 16;    // per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type, sum of the
                            // circumradii, far-gate radius^2, logistic slopes (ego, obstacle) and offsets, -, -
@@ -254,14 +256,24 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
   double sxx = cov[4 * (size_t)i], sxy = cov[4 * (size_t)i + 1], syx = cov[4 * (size_t)i + 2], syy = cov[4 * (size_t)i + 3];
   if (sxx == 0.0 && sxy == 0.0 && syx == 0.0 && syy == 0.0) { sxx = 0.1; syy = 0.1; }  // collision_probability.py:84-86
   double isx = 1.0 / (sqrt(sxx) * M_SQRT2), isy = 1.0 / (sqrt(syy) * M_SQRT2);
-  if ((sxy != 0.0 || syx != 0.0) && t < L) {  // general BVN not implemented: poison + status word
-    atomicMax(status, gen);
-    isx = NAN;
-    isy = NAN;
+  double rho = 0.0;
+  if (sxy != 0.0 || syx != 0.0) {  // a covariance with correlation (real agents from a prediction module): the sweep
+    // integrates the bivariate normal over every box (fo_box_corr; status[1] tells the sweep kernel which of its two
+    // bodies to run); a matrix that is no usable covariance -- asymmetric, not positive, |rho| > 0.99 -- poisons the
+    // row and raises status[0] (fo_sweep_check)
+    rho = 0.5 * (sxy + syx) / sqrt(sxx * syy);
+    if (!(sxx > 0.0) || !(syy > 0.0) || fabs(sxy - syx) > 1e-12 * sqrt(sxx * syy) || !(fabs(rho) <= 0.99)) {
+      if (t < L) atomicMax(status, gen);
+      isx = NAN;
+      isy = NAN;
+      rho = 0.0;
+    } else if (t < L) {
+      atomicMax(status + 1, gen);
+    }
   }
   double *o = tab + (size_t)i * NAF;
   o[0] = pos[2 * (size_t)i]; o[1] = pos[2 * (size_t)i + 1]; o[2] = cs; o[3] = sn; o[4] = yaw[i]; o[5] = v[i];
-  o[6] = isx; o[7] = isy; o[8] = v[i] * cs; o[9] = v[i] * sn; o[10] = 0.0; o[11] = 0.0;
+  o[6] = isx; o[7] = isy; o[8] = v[i] * cs; o[9] = v[i] * sn; o[10] = rho; o[11] = 0.0;
   if (t == 0) {
     const double m_obs = fo_obstacle_mass(type[k], shape[2 * k] * shape[2 * k + 1]);  // inflated footprint (Q8)
     double *c = cst + (size_t)k * NAC;
@@ -310,6 +322,9 @@ struct SweepArgs {
   const double *acst;    // [A][NAC]
   const double2 *erf_tab;  // [ERF_N]
   const double *exp_tab;   // [EXP_N]  2^(j/EXP_N)
+  const double *gl;        // [GL_A + GL_B][2] Gauss-Legendre nodes and weights (correlated covariances)
+  const int *status;       // [2] generation tags of fo_prep_agents_kernel: [0] unusable covariance, [1] correlated one
+  int gen;                 // generation of the current agent set
   const int32_t *aint;     // [A][2] protection class, valid length
   double *partial;       // [n_chunks][NPS][Mp]
   double *pair_f;        // [NPF][A][M] or null
@@ -385,6 +400,23 @@ __device__ __forceinline__ double fo_phi_diff(const double2 *__restrict__ tab, d
   return 0.5 * (fo_erf_lds(tab, hi) - fo_erf_lds(tab, lo));
 }
 
+// fo_box_corr for the generic kernel: libm erf / exp, always the 96-node rule
+__device__ __forceinline__ double fo_box_corr_plain(const double *__restrict__ gl, double A, double B, double Cc, double D,
+                                                    double rho) {
+  A = fmax(A, -6.0);
+  B = fmin(B, 6.0);
+  if (!(B > A)) return 0.0;
+  const double mid = 0.5 * (A + B), half = 0.5 * (B - A), q = 1.0 / sqrt(1.0 - rho * rho);
+  gl += 2 * GL_A;
+  double acc = 0.0;
+#pragma unroll 1
+  for (int i = 0; i < GL_B; ++i) {
+    const double X = fma(half, gl[2 * i], mid);
+    acc = fma(gl[2 * i + 1] * exp(-X * X), erf((D - rho * X) * q) - erf((Cc - rho * X) * q), acc);
+  }
+  return acc * half * 0.28209479177387814;
+}
+
 template <bool PAIR, bool LISTS>
 __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const SweepArgs a) {
   __shared__ double red[(WAVES - 1) * NPS * TILE];
@@ -450,13 +482,14 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
     double ex1 = tj1[EF(0)], ey1 = tj1[EF(1)], ec1 = tj1[EF(2)], es1 = tj1[EF(3)], eth1 = tj1[EF(4)],
            ev1 = tj1[EF(5)];
     double px = G[0], py = G[1], pc = G[2], ps = G[3], pth = G[4], pv = G[5], isx = G[6], isy = G[7];
+    double rho = G[10];
     for (int t = 0; t < T; ++t) {
       const double *tj2 = tj + (size_t)min(t + 2, T - 1) * NEF * Mp;
       const double ex2 = tj2[EF(0)], ey2 = tj2[EF(1)], ec2 = tj2[EF(2)], es2 = tj2[EF(3)], eth2 = tj2[EF(4)],
                    ev2 = tj2[EF(5)];
       const double *gn = G + (size_t)min(t + 1, L - 1) * NAF;
       const double npx = gn[0], npy = gn[1], pc1 = gn[2], ps1 = gn[3], npth = gn[4], npv = gn[5], nisx = gn[6],
-                   nisy = gn[7];
+                   nisy = gn[7], nrho = gn[10];
       const double cr = pc * ec + ps * es;  // cos(yaw - theta)
       const double sr = ps * ec - pc * es;  // sin(yaw - theta)
 
@@ -506,6 +539,11 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #pragma unroll
               for (int b = -1; b <= 1; ++b) {     // three boxes
                 const double cx = qx + b * bxs, cy = qy + b * bys;
+                if (rho != 0.0) {   // correlated covariance (wave-uniform: one agent per wave)
+                  acc += fo_box_corr_plain(a.gl, (cx - a.off_x) * isx, (cx + a.off_x) * isx, (cy - a.off_y) * isy,
+                                           (cy + a.off_y) * isy, rho);
+                  continue;
+                }
                 const double fx = fo_phi_diff(erf_tab, (cx - a.off_x) * isx, (cx + a.off_x) * isx);
                 const double fy = fo_phi_diff(erf_tab, (cy - a.off_y) * isy, (cy + a.off_y) * isy);
                 acc += fx * fy;
@@ -547,7 +585,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
       }
       ex = ex1; ey = ey1; ec = ec1; es = es1; eth = eth1; ev = ev1;
       ex1 = ex2; ey1 = ey2; ec1 = ec2; es1 = es2; eth1 = eth2; ev1 = ev2;
-      px = npx; py = npy; pc = pc1; ps = ps1; pth = npth; pv = npv; isx = nisx; isy = nisy;
+      px = npx; py = npy; pc = pc1; ps = ps1; pth = npth; pv = npv; isx = nisx; isy = nisy; rho = nrho;
     }
 
     // ---------------- per-pair scalars
@@ -701,6 +739,33 @@ __device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab
   return y;
 }
 
+// Gauss-Legendre nodes for the box probability under a CORRELATED covariance: two rules in one table, [x, w] pairs,
+// 48 nodes then 96 (computed on the host at context creation, fo_sweep_init_).
+
+// P(box) for a bivariate normal with correlation rho (collision_probability.py:117 hands any covariance to mvnun, which
+// integrates the bivariate normal exactly).  One-dimensional integral over x in units X = (x - mu_x)/(s_x sqrt 2):
+//   P = 1/sqrt(pi) Int_A^B exp(-X^2) 1/2 [erf((D - rho X) q) - erf((C - rho X) q)] dX,  q = 1/sqrt(1 - rho^2),
+// A, B / C, D the box edges in those units along x / y; Gauss-Legendre on [A, B] clipped to +-6 with n nodes (48 up to
+// |rho| = 0.9, 96 up to 0.99: 1e-12 against mvnun on boxes of this size).  Rare path (real agents with a full
+// covariance inside the 5 m gate): ~70 operations per node.
+__device__ __forceinline__ double fo_box_corr(const double2 *__restrict__ erf_tab, const double *__restrict__ exp_tab,
+                                              cdp_gl_t gl, int n, double A, double B, double Cc, double D, double rho,
+                                              double q) {
+  A = fmax(A, -6.0);
+  B = fmin(B, 6.0);
+  if (!(B > A)) return 0.0;
+  const double mid = 0.5 * (A + B), half = 0.5 * (B - A);
+  double acc = 0.0;
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) {
+    const double X = fma(half, gl[2 * i], mid);   // node and weight are wave-uniform: scalar loads
+    const double rq = rho * X;
+    const double f = fo_erf_fast128(erf_tab, (D - rq) * (q * ERF_SCALE)) - fo_erf_fast128(erf_tab, (Cc - rq) * (q * ERF_SCALE));
+    acc = fma(gl[2 * i + 1] * fo_exp_tab<false>(exp_tab, -X * X), f, acc);
+  }
+  return acc * half * 0.28209479177387814;  // 1 / (2 sqrt(pi))
+}
+
 // Rounded distance (whole millimetres, rint(1000 d) = 1000 np.round(d, 3), dce.py:79) between the ego rectangle at
 // rear-axle pose (ex, ey, heading (ec, es)) and the agent rectangle at (px, py, heading (pc, ps)): four-axis SAT
 // (overlap -> 0), otherwise the minimum over the eight corner-to-box distances.
@@ -740,22 +805,14 @@ __device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(uns
 // SPLIT (small batches, where one agent per wave leaves most SIMDs with a single wave): the four waves of a workgroup
 // take the SAME agent and a quarter of the horizon each (time chunk `wave`); every per-pair result is a minimum or a
 // first maximum over time, so the segments are folded in time order through LDS at the end.  Needs T <= QWAVES * TC.
-template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT = false>
-__global__ __launch_bounds__(TILE *QWAVES) __attribute__((amdgpu_waves_per_eu(FO_MINW, FO_MINW)))
-void fo_sweep_queue_kernel(const SweepArgs a) {
-  __shared__ double2 erf_tab[ERF_N];
-  __shared__ double exp_tab[EXP_N];
-  __shared__ double zc_tab[4];                      // LR4S logistic offsets by impact class: front, side, rear
-  __shared__ double hk_all[QWAVES * 4];             // per wave: the current agent's logistic slopes and offsets
-  constexpr int BUFROWS = QWAVES * WROWS > (QWAVES - 1) * NPS ? QWAVES * WROWS : (QWAVES - 1) * NPS;
-  __shared__ double cpbuf_all[BUFROWS * TILE];  // per wave: TC rows of collision probabilities, DVR rows of
-                                                       // relative speeds; also the cross-wave reduction scratch
-  __shared__ unsigned short queue_all[QWAVES * QCAP];
-  for (int i = threadIdx.x; i < ERF_N; i += TILE * QWAVES) erf_tab[i] = a.erf_tab[i];
-  for (int i = threadIdx.x; i < EXP_N; i += TILE * QWAVES) exp_tab[i] = a.exp_tab[i];
-  if (threadIdx.x < 4)
-    zc_tab[threadIdx.x] = -a.hc.lr4s_const - (threadIdx.x == 0 ? 0.0 : threadIdx.x == 1 ? a.hc.lr4s_side : a.hc.lr4s_rear);
-  __syncthreads();
+// CORR: the agent set holds a covariance with correlation (status[1] of fo_prep_agents_kernel): in-gate samples then
+// integrate their box probabilities numerically (fo_box_corr).  The kernel below carries both bodies and picks one at
+// its start, so that the usual diagonal case keeps the registers and the code it had.
+template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT, bool CORR>
+__device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const double2 *__restrict__ erf_tab,
+                                                    const double *__restrict__ exp_tab, const double *__restrict__ zc_tab,
+                                                    double *__restrict__ hk_all, double *__restrict__ cpbuf_all,
+                                                    unsigned short *__restrict__ queue_all) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -911,11 +968,29 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
           const double qex = qxy.x, qey = qxy.y, qec = qcs.x, qes = qcs.y;
           const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti
           const double qpx = g0[0], qpy = g0[1], qisx = g0[6] * ERF_SCALE, qisy = g0[7] * ERF_SCALE;
+          const double qrho = CORR ? g0[10] : 0.0;
           const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
           const double devx = qc1 * hdev, devy = qs1 * hdev;
           const double rx = qex - qpx, ry = qey - qpy;
           const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
           double acc = 0.0;
+          if (CORR && __ballot(qrho != 0.0)) {
+            // some queued sample belongs to a covariance with correlation: every lane of the batch integrates its
+            // nine boxes numerically (valid for rho = 0 as well); 96 nodes when any |rho| exceeds 0.9
+            const bool fine = __ballot(fabs(qrho) > 0.9) != 0ull;
+            const cdp_gl_t gl = (cdp_gl_t)(unsigned long long)(a.gl + (fine ? 2 * GL_A : 0));
+            const double qq = 1.0 / sqrt(1.0 - qrho * qrho), ix0 = g0[6], iy0 = g0[7];
+#pragma unroll 1
+            for (int jm = -1; jm <= 1; ++jm) {
+              const double qx = rx - jm * devx, qy = ry - jm * devy;
+#pragma unroll 1
+              for (int b = -1; b <= 1; ++b) {
+                const double cx = qx + b * bxs, cy = qy + b * bys;
+                acc += 4.0 * fo_box_corr(erf_tab, exp_tab, gl, fine ? GL_B : GL_A, (cx - a.off_x) * ix0, (cx + a.off_x) * ix0,
+                                         (cy - a.off_y) * iy0, (cy + a.off_y) * iy0, qrho, qq);
+              }
+            }
+          } else
 #pragma unroll 1
           for (int jm = -1; jm <= 1; ++jm) {
             const double qx = rx - jm * devx, qy = ry - jm * devy;
@@ -1259,6 +1334,29 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   }
 }
 
+template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT = false>
+__global__ __launch_bounds__(TILE *QWAVES) __attribute__((amdgpu_waves_per_eu(FO_MINW, FO_MINW)))
+void fo_sweep_queue_kernel(const SweepArgs a) {
+  __shared__ double2 erf_tab[ERF_N];
+  __shared__ double exp_tab[EXP_N];
+  __shared__ double zc_tab[4];                      // LR4S logistic offsets by impact class: front, side, rear
+  __shared__ double hk_all[QWAVES * 4];             // per wave: the current agent's logistic slopes and offsets
+  constexpr int BUFROWS = QWAVES * WROWS > (QWAVES - 1) * NPS ? QWAVES * WROWS : (QWAVES - 1) * NPS;
+  __shared__ double cpbuf_all[BUFROWS * TILE];  // per wave: TC rows of collision probabilities, DVR rows of
+                                                       // relative speeds; also the cross-wave reduction scratch
+  __shared__ unsigned short queue_all[QWAVES * QCAP];
+  for (int i = threadIdx.x; i < ERF_N; i += TILE * QWAVES) erf_tab[i] = a.erf_tab[i];
+  for (int i = threadIdx.x; i < EXP_N; i += TILE * QWAVES) exp_tab[i] = a.exp_tab[i];
+  if (threadIdx.x < 4)
+    zc_tab[threadIdx.x] = -a.hc.lr4s_const - (threadIdx.x == 0 ? 0.0 : threadIdx.x == 1 ? a.hc.lr4s_side : a.hc.lr4s_rear);
+  const bool corr = a.status[1] == a.gen;   // scalar load; written by fo_prep_agents_kernel earlier on this stream
+  __syncthreads();
+  if (__builtin_expect(!corr, 1))
+    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
+  else
+    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, true>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
+}
+
 
 // ================================================================================================ BE (optional)
 // Brake evaluation (metrics/be.py:31-193), active only with FO_M_BE: for every pair that collides at ttc > 0 the minimum
@@ -1471,6 +1569,29 @@ int fo_sweep_init_(fo_ctx *ctx) {
   FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_exp_tab, sizeof(double) * EXP_N));
   hipLaunchKernelGGL(fo_exp_table_kernel, dim3(1), dim3(EXP_N), 0, 0, (double *)ctx->d_exp_tab);
   FO_HIP_TRY(ctx, hipGetLastError());
+  {  // Gauss-Legendre rules (fo_box_corr): Newton on the Legendre recurrence, nodes in ascending order
+    static double gl[2 * (GL_A + GL_B)];
+    const int ns[2] = {GL_A, GL_B};
+    double *o = gl;
+    for (int r = 0; r < 2; ++r) {
+      const int n = ns[r];
+      for (int i = 0; i < n; ++i) {
+        double x = -cos(M_PI * (i + 0.75) / (n + 0.5)), dp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+          double p0 = 1.0, p1 = x;
+          for (int k = 2; k <= n; ++k) { const double p2 = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k; p0 = p1; p1 = p2; }
+          dp = n * (x * p1 - p0) / (x * x - 1.0);
+          const double dx = p1 / dp;
+          x -= dx;
+          if (fabs(dx) < 1e-16) break;
+        }
+        *o++ = x;
+        *o++ = 2.0 / ((1.0 - x * x) * dp * dp);
+      }
+    }
+    FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gl_tab, sizeof gl));
+    FO_HIP_TRY(ctx, hipMemcpy(ctx->d_gl_tab, gl, sizeof gl, hipMemcpyHostToDevice));
+  }
   FO_HIP_TRY(ctx, hipDeviceSynchronize());
   return FO_OK;
 }
@@ -1518,7 +1639,7 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
   ctx->A = A;
   ctx->Ta = Ta;
   if (ctx->status_gen >= (1 << 30)) {  // generations never run out in practice; start over cleanly if they do
-    FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), s));
+    FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, 2 * sizeof(int), s));
     ctx->status_gen = 0;
   }
   const int gen = ++ctx->status_gen;
@@ -1580,6 +1701,9 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     a.M = M; a.Mp = Mp; a.T = T; a.A = A; a.Ta = Ta; a.n_tiles = n_tiles; a.nt8 = (n_tiles + 7) / 8; a.apw = apw;
     a.erf_tab = (const double2 *)ctx->d_erf_tab;
     a.exp_tab = (const double *)ctx->d_exp_tab;
+    a.gl = (const double *)ctx->d_gl_tab;
+    a.status = ctx->d_status;
+    a.gen = ctx->status_gen;
     a.aint = ctx->d_agent_int;
     a.traj = ctx->d_traj_tab; a.atab = ctx->d_agent_tab; a.acst = ctx->d_agent_const; a.partial = ctx->d_partial;
     a.pair_f = d_pair_f; a.pair_i = d_pair_i; a.lists = d_lists;

@@ -99,9 +99,11 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
                  const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
                  int32_t *d_pair_i, double *d_lists, void *stream);
 
-/* Blocks until `stream` has drained, then returns FO_E_UNSUPPORTED_COV if the last fo_sweep_set_agents met a
- * covariance with non-zero off-diagonal terms (those agents' collision probabilities are NaN), else FO_OK.
- * Replaces: the exception scipy's mvnun would raise / the silent wrong answer.  Not capturable in a hipGraph. */
+/* Blocks until `stream` has drained, then returns FO_E_UNSUPPORTED_COV if the last fo_sweep_set_agents met a matrix
+ * that is no usable covariance -- asymmetric, not positive, or |correlation| > 0.99 (those agents' collision
+ * probabilities are NaN and no trajectory reads as safe) -- else FO_OK.  Diagonal covariances take the closed form,
+ * symmetric ones with correlation are integrated numerically (the reference hands any matrix to scipy's mvnun,
+ * collision_probability.py:117).  Not capturable in a hipGraph. */
 int fo_sweep_check(fo_ctx *ctx, void *stream);
 
 /* HIP-event timing of the sweep kernel alone (events recorded on the launch stream around that one kernel):

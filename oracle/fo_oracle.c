@@ -155,8 +155,57 @@ double fo_oracle_box_prob(const double lo[2], const double hi[2], const double m
   return ql0 * ql1 - qu0 * ql1 - ql0 * qu1 + qu0 * qu1;
 }
 
-/* probs[T-1]; returns -2 when a covariance with non-zero off-diagonal is met (not produced by the reference's
- * phantom agents, agent.py:260-280; general BVN is not restated). */
+/* Correlated covariance (what a prediction module hands over for real agents; the reference passes any matrix to
+ * mvnun, which for d = 2 integrates the bivariate normal exactly: MVNDST -> BVNMVN -> BVU).  Restated as a one-
+ * dimensional Gauss-Legendre integral instead of Genz's BVU (not a line-by-line restatement; pinned to the reference's
+ * own outputs by tests/golden/correlated_cov.npz):  with X = (x - mu_x)/(s_x sqrt 2),
+ *   P = 1/sqrt(pi) * Int_A^B exp(-X^2) * 1/2 [ erf((D - rho X) q) - erf((C - rho X) q) ] dX,   q = 1/sqrt(1 - rho^2),
+ * A, B (C, D) the box edges in those units along x (y).  96 nodes on [A, B] clipped to +-6: 1e-15 against mvnun for
+ * |rho| <= 0.99 on boxes of this size; beyond that the integrand is too sharp and the matrix counts as degenerate. */
+#define FO_GL_N 96
+static double gl_x[FO_GL_N], gl_w[FO_GL_N];
+static int gl_ready = 0;
+static void gl_init(void) {
+  const int n = FO_GL_N;
+  for (int i = 0; i < (n + 1) / 2; ++i) {
+    double z = cos(M_PI * (i + 0.75) / (n + 0.5)), pp = 1.0;
+    for (int it = 0; it < 100; ++it) {
+      double p1 = 1.0, p2 = 0.0;
+      for (int j = 0; j < n; ++j) { double p3 = p2; p2 = p1; p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0); }
+      pp = n * (z * p1 - p2) / (z * z - 1.0);
+      double dz = p1 / pp;
+      z -= dz;
+      if (fabs(dz) < 1e-16) break;
+    }
+    gl_x[i] = -z; gl_x[n - 1 - i] = z;
+    gl_w[i] = gl_w[n - 1 - i] = 2.0 / ((1.0 - z * z) * pp * pp);
+  }
+  gl_ready = 1;
+}
+
+/* returns NaN for a matrix that is not a usable covariance (asymmetric, not positive, |rho| > 0.99) */
+double fo_oracle_box_prob_corr(const double lo[2], const double hi[2], const double mu[2], double sxx, double sxy,
+                               double syx, double syy) {
+  if (!(sxx > 0.0) || !(syy > 0.0) || fabs(sxy - syx) > 1e-12 * sqrt(sxx * syy)) return NAN;
+  const double rho = 0.5 * (sxy + syx) / sqrt(sxx * syy);
+  if (!(fabs(rho) <= 0.99)) return NAN;
+  if (!gl_ready) gl_init();
+  const double ix = 1.0 / (sqrt(sxx) * M_SQRT2), iy = 1.0 / (sqrt(syy) * M_SQRT2), q = 1.0 / sqrt(1.0 - rho * rho);
+  double A = (lo[0] - mu[0]) * ix, B = (hi[0] - mu[0]) * ix;
+  const double Cc = (lo[1] - mu[1]) * iy, D = (hi[1] - mu[1]) * iy;
+  if (A < -6.0) A = -6.0;
+  if (B > 6.0) B = 6.0;
+  if (!(B > A)) return 0.0;
+  const double mid = 0.5 * (A + B), half = 0.5 * (B - A);
+  double acc = 0.0;
+  for (int i = 0; i < FO_GL_N; ++i) {
+    const double X = mid + half * gl_x[i];
+    acc += gl_w[i] * exp(-X * X) * (erf((D - rho * X) * q) - erf((Cc - rho * X) * q));
+  }
+  return acc * half * 0.5 / sqrt(M_PI);
+}
+
+/* probs[T-1]; returns -2 when a matrix is met that is not a usable covariance (see fo_oracle_box_prob_corr). */
 static int cp_pair(int T, const double *x, const double *y, const double *th, const fo_vehicle_t *veh, int L,
                    const double *pos, const double *yaw, const double *cov, double len_infl, double *probs) {
   const double off0 = veh->length / 6.0, off1 = veh->width / 2.0; /* :35 */
@@ -177,7 +226,7 @@ static int cp_pair(int T, const double *x, const double *y, const double *th, co
         const double *c4 = cov + 4 * (i - 1);
         double sxx = c4[0], sxy = c4[1], syx = c4[2], syy = c4[3];
         if (sxx == 0.0 && sxy == 0.0 && syx == 0.0 && syy == 0.0) { sxx = 0.1; syy = 0.1; } /* :84-86 */
-        if (sxy != 0.0 || syx != 0.0) return -2;
+        const int corr = sxy != 0.0 || syx != 0.0;
         /* three axis-aligned boxes around the REAR-AXLE point (Q2; :94-107,129-164) */
         double r_x = veh->length / 2.0;
         double ax = cos(th[i]), ay = sin(th[i]);
@@ -187,7 +236,13 @@ static int cp_pair(int T, const double *x, const double *y, const double *th, co
           for (int b = 0; b < 3; ++b) {
             double lo[2] = {ccx[b] - off0, ccy[b] - off1}, hi[2] = {ccx[b] + off0, ccy[b] + off1};
             double mu[2] = {mx[j], my[j]};
-            prob += fo_oracle_box_prob(lo, hi, mu, sxx, syy);
+            if (corr) {
+              const double pb = fo_oracle_box_prob_corr(lo, hi, mu, sxx, sxy, syx, syy);
+              if (pb != pb) return -2;
+              prob += pb;
+            } else {
+              prob += fo_oracle_box_prob(lo, hi, mu, sxx, syy);
+            }
           }
         }
       }

@@ -65,6 +65,9 @@ double fo_oracle_round3(double v); /* np.round(v, 3) */
 
 /* P(lower <= X <= upper), X ~ N(mu, diag(sxx, syy)) -- closed form equal to scipy mvnun for diagonal cov */
 double fo_oracle_box_prob(const double lo[2], const double hi[2], const double mu[2], double sxx, double syy);
+/* the same for a covariance with correlation (NaN when the matrix is not a usable covariance) */
+double fo_oracle_box_prob_corr(const double lo[2], const double hi[2], const double mu[2], double sxx, double sxy,
+                               double syx, double syy);
 
 /* The sweep.  Inputs: trajectories [M][T]; agent predictions [A][Ta](...) with per-agent valid length alen[k]
  * (1..Ta).  acov = [A][Ta][4] (xx,xy,yx,yy); ashape = inflated (prediction dict 'shape'), araw = agent.shape.

@@ -205,8 +205,8 @@ def test_off_diagonal_covariance_fails_loudly(torch_cuda):
     from frenetix_occlusion import synthetic as S
     from frenetix_occlusion.sweep import MetricSweep
     traj, agents = S.make_batch(10, 2, config_id=10)
-    agents["cov"][1, :, 0, 1] = 0.01
-    agents["cov"][1, :, 1, 0] = 0.01
+    agents["cov"][1, :, 0, 1] = 0.01          # asymmetric: no covariance matrix (a symmetric one with |rho| <= 0.99
+    agents["cov"][1, :, 1, 0] = 0.02          # is integrated numerically, test_correlated_covariances_*)
     sw = MetricSweep(S.VEHICLE_BMW320I, 0.1)
     with pytest.raises(N.NativeError) as e:
         sw.set_agents(agents["pos"], agents["yaw"], agents["v"], agents["cov"], agents["shape"], agents["raw_dims"],
@@ -399,8 +399,8 @@ def test_off_diagonal_covariance_poisons_the_outputs_without_the_check(torch_cud
     from frenetix_occlusion.sweep import MetricSweep
     traj, agents = S.make_batch(130, 3, config_id=10)
     bad = {k: v.copy() for k, v in agents.items()}
-    bad["cov"][2, :, 0, 1] = 0.01
-    bad["cov"][2, :, 1, 0] = 0.01
+    bad["cov"][2, :, 0, 1] = 0.9999 * bad["cov"][2, :, 0, 0]      # |rho| > 0.99: degenerate
+    bad["cov"][2, :, 1, 0] = 0.9999 * bad["cov"][2, :, 0, 0]
     sw = MetricSweep(S.VEHICLE_BMW320I, 0.1)
     args = lambda a: (a["pos"], a["yaw"], a["v"], a["cov"], a["shape"], a["raw_dims"], a["type"], a["len"])
     sw.set_agents(*args(bad), check=False)
@@ -486,3 +486,33 @@ def test_horizon_split_variant_is_bit_identical(torch_cuda, monkeypatch):
             assert np.array_equal(red["cost"], outs[-1]["cost"], equal_nan=True) and np.array_equal(red["safe"], outs[-1]["safe"])
         for k in ("cost", "safe", "pair_f", "pair_i", "lists"):
             assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (M, A, T, k)
+
+
+def test_correlated_covariances_against_the_oracle_and_the_diagonal_limit(torch_cuda, oracle):
+    """full covariance matrices (real agents from a prediction module; the reference hands any matrix to mvnun,
+    collision_probability.py:117): the numerical box integral of the kernel against the oracle's (itself pinned to the
+    reference by tests/golden/correlated_cov.npz), mixed with diagonal agents in one batch, high correlations (96-node
+    rule), and the limit rho -> 0 against the closed form"""
+    from frenetix_occlusion import synthetic as S
+    rng = np.random.default_rng(4)
+    traj, agents = S.make_batch(150, 6, config_id=31)
+    T = agents["pos"].shape[1]
+    for k, rho in enumerate((0.5, -0.97, 0.0, 0.85, -0.2, 0.985)):
+        sx = np.sqrt(0.08 * 1.05 ** np.arange(T)) * (1.0 + 0.4 * k)
+        sy = np.sqrt(0.15 * 1.03 ** np.arange(T))
+        agents["cov"][k, :, 0, 0], agents["cov"][k, :, 1, 1] = sx * sx, sy * sy
+        agents["cov"][k, :, 0, 1] = agents["cov"][k, :, 1, 0] = rho * sx * sy
+    agents["pos"][:, :, :] = traj["x"][0, 12], traj["y"][0, 12]              # park them on the candidates' way
+    agents["pos"] += rng.uniform(-2.0, 2.0, size=(6, 1, 2))
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1)
+    got = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1)
+    assert ref["lists"][:, :, oracle.LST["cp"], :].max() > 0.1               # the gate is really entered
+    _compare(oracle, ref, got)
+    # rho -> 0: the numerical integral meets the closed form of the diagonal case
+    tiny = {k: v.copy() for k, v in agents.items()}
+    diag = {k: v.copy() for k, v in agents.items()}
+    tiny["cov"][:, :, 0, 1] = tiny["cov"][:, :, 1, 0] = 1e-13
+    diag["cov"][:, :, 0, 1] = diag["cov"][:, :, 1, 0] = 0.0
+    a, b = (_hip_sweep(torch_cuda, traj, d, S.VEHICLE_BMW320I, 0.1) for d in (tiny, diag))
+    cpa, cpb = a["lists"][:, :, oracle.LST["cp"], :], b["lists"][:, :, oracle.LST["cp"], :]
+    assert np.nanmax(np.abs(cpa - cpb)) < 1e-11
