@@ -26,9 +26,15 @@ constexpr int WAVES = 4;   // waves per workgroup
 constexpr int NEF = 8;     // ego fields per (t, trajectory): x, y, cos, sin, theta, v, v cos, v sin -- stored as four
                            // pairs per trajectory, [t][pair][trajectory][2]: one 16-byte load per lane fetches two
                            // fields (a vector-memory instruction costs the CU ~10 cycles whatever its width)
-constexpr int GL_A = 48, GL_B = 96;   // node counts of the two Gauss-Legendre rules (fo_box_corr)
+// Gauss-Legendre rules of the correlation integral (fo_corr_term): node counts by the largest |rho| they serve, and where
+// each rule starts in the table ([t, w] pairs, t = (x + 1)/2, w = weight/(4 pi); host, fo_sweep_init_)
+constexpr int GL_NR = 4;
+__host__ __device__ constexpr int gl_nodes(int r) { return r == 0 ? 8 : r == 1 ? 12 : r == 2 ? 20 : 48; }
+__host__ __device__ constexpr int gl_first(int r) { return r == 0 ? 0 : r == 1 ? 8 : r == 2 ? 20 : 40; }
+constexpr int GL_TOTAL = 88;
+constexpr double GL_RHO0 = 0.5, GL_RHO1 = 0.8, GL_RHO2 = 0.95;   // rule r serves |rho| <= GL_RHOr, the last one <= 0.99
 typedef const double __attribute__((address_space(4))) *cdp_gl_t;
-constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, rho, -
+constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, rho, asin rho
                            // (96-byte rows: the 32-byte and 16-byte groups the scalar loads fetch stay naturally aligned)
 constexpr int NAC = 16;    // per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type, sum of the
                            // circumradii, far-gate radius^2, logistic slopes (ego, obstacle) and offsets, -, -
@@ -258,7 +264,7 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
   double isx = 1.0 / (sqrt(sxx) * M_SQRT2), isy = 1.0 / (sqrt(syy) * M_SQRT2);
   double rho = 0.0;
   if (sxy != 0.0 || syx != 0.0) {  // a covariance with correlation (real agents from a prediction module): the sweep
-    // integrates the bivariate normal over every box (fo_box_corr; status[1] tells the sweep kernel which of its two
+    // integrates the bivariate normal over every box (fo_corr_corners; status[1] tells the sweep kernel which of its two
     // bodies to run); a matrix that is no usable covariance -- asymmetric, not positive, |rho| > 0.99 -- poisons the
     // row and raises status[0] (fo_sweep_check)
     rho = 0.5 * (sxy + syx) / sqrt(sxx * syy);
@@ -273,7 +279,7 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
   }
   double *o = tab + (size_t)i * NAF;
   o[0] = pos[2 * (size_t)i]; o[1] = pos[2 * (size_t)i + 1]; o[2] = cs; o[3] = sn; o[4] = yaw[i]; o[5] = v[i];
-  o[6] = isx; o[7] = isy; o[8] = v[i] * cs; o[9] = v[i] * sn; o[10] = rho; o[11] = 0.0;
+  o[6] = isx; o[7] = isy; o[8] = v[i] * cs; o[9] = v[i] * sn; o[10] = rho; o[11] = asin(rho);
   if (t == 0) {
     const double m_obs = fo_obstacle_mass(type[k], shape[2 * k] * shape[2 * k + 1]);  // inflated footprint (Q8)
     double *c = cst + (size_t)k * NAC;
@@ -322,7 +328,7 @@ struct SweepArgs {
   const double *acst;    // [A][NAC]
   const double2 *erf_tab;  // [ERF_N]
   const double *exp_tab;   // [EXP_N]  2^(j/EXP_N)
-  const double *gl;        // [GL_A + GL_B][2] Gauss-Legendre nodes and weights (correlated covariances)
+  const double *gl;        // [GL_TOTAL][2] Gauss-Legendre nodes and weights (correlated covariances)
   const int *status;       // [2] generation tags of fo_prep_agents_kernel: [0] unusable covariance, [1] correlated one
   int gen;                 // generation of the current agent set
   const int32_t *aint;     // [A][2] protection class, valid length
@@ -400,21 +406,19 @@ __device__ __forceinline__ double fo_phi_diff(const double2 *__restrict__ tab, d
   return 0.5 * (fo_erf_lds(tab, hi) - fo_erf_lds(tab, lo));
 }
 
-// fo_box_corr for the generic kernel: libm erf / exp, always the 96-node rule
-__device__ __forceinline__ double fo_box_corr_plain(const double *__restrict__ gl, double A, double B, double Cc, double D,
-                                                    double rho) {
-  A = fmax(A, -6.0);
-  B = fmin(B, 6.0);
-  if (!(B > A)) return 0.0;
-  const double mid = 0.5 * (A + B), half = 0.5 * (B - A), q = 1.0 / sqrt(1.0 - rho * rho);
-  gl += 2 * GL_A;
+// the correlation integral of one box (see fo_corr_corners) for the generic kernel: libm, always the 48-node rule
+__device__ __forceinline__ double fo_corr_term_plain(const double *__restrict__ gl, double A, double B, double Cc, double D,
+                                                     double asr) {
+  gl += 2 * gl_first(GL_NR - 1);
   double acc = 0.0;
 #pragma unroll 1
-  for (int i = 0; i < GL_B; ++i) {
-    const double X = fma(half, gl[2 * i], mid);
-    acc = fma(gl[2 * i + 1] * exp(-X * X), erf((D - rho * X) * q) - erf((Cc - rho * X) * q), acc);
+  for (int i = 0; i < gl_nodes(GL_NR - 1); ++i) {
+    const double sn = sin(asr * gl[2 * i]), c2 = 1.0 / (1.0 - sn * sn);
+    const double f = exp(-c2 * (A * A + Cc * Cc - 2.0 * sn * A * Cc)) - exp(-c2 * (B * B + Cc * Cc - 2.0 * sn * B * Cc)) -
+                     exp(-c2 * (A * A + D * D - 2.0 * sn * A * D)) + exp(-c2 * (B * B + D * D - 2.0 * sn * B * D));
+    acc = fma(gl[2 * i + 1], f, acc);
   }
-  return acc * half * 0.28209479177387814;
+  return acc * asr;
 }
 
 template <bool PAIR, bool LISTS>
@@ -482,14 +486,14 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
     double ex1 = tj1[EF(0)], ey1 = tj1[EF(1)], ec1 = tj1[EF(2)], es1 = tj1[EF(3)], eth1 = tj1[EF(4)],
            ev1 = tj1[EF(5)];
     double px = G[0], py = G[1], pc = G[2], ps = G[3], pth = G[4], pv = G[5], isx = G[6], isy = G[7];
-    double rho = G[10];
+    double asr = G[11];   // asin of the covariance's correlation (0: the box probabilities factorise)
     for (int t = 0; t < T; ++t) {
       const double *tj2 = tj + (size_t)min(t + 2, T - 1) * NEF * Mp;
       const double ex2 = tj2[EF(0)], ey2 = tj2[EF(1)], ec2 = tj2[EF(2)], es2 = tj2[EF(3)], eth2 = tj2[EF(4)],
                    ev2 = tj2[EF(5)];
       const double *gn = G + (size_t)min(t + 1, L - 1) * NAF;
       const double npx = gn[0], npy = gn[1], pc1 = gn[2], ps1 = gn[3], npth = gn[4], npv = gn[5], nisx = gn[6],
-                   nisy = gn[7], nrho = gn[10];
+                   nisy = gn[7], nasr = gn[11];
       const double cr = pc * ec + ps * es;  // cos(yaw - theta)
       const double sr = ps * ec - pc * es;  // sin(yaw - theta)
 
@@ -539,11 +543,9 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #pragma unroll
               for (int b = -1; b <= 1; ++b) {     // three boxes
                 const double cx = qx + b * bxs, cy = qy + b * bys;
-                if (rho != 0.0) {   // correlated covariance (wave-uniform: one agent per wave)
-                  acc += fo_box_corr_plain(a.gl, (cx - a.off_x) * isx, (cx + a.off_x) * isx, (cy - a.off_y) * isy,
-                                           (cy + a.off_y) * isy, rho);
-                  continue;
-                }
+                if (asr != 0.0)   // correlated covariance (wave-uniform: one agent per wave)
+                  acc += fo_corr_term_plain(a.gl, (cx - a.off_x) * isx, (cx + a.off_x) * isx, (cy - a.off_y) * isy,
+                                            (cy + a.off_y) * isy, asr);
                 const double fx = fo_phi_diff(erf_tab, (cx - a.off_x) * isx, (cx + a.off_x) * isx);
                 const double fy = fo_phi_diff(erf_tab, (cy - a.off_y) * isy, (cy + a.off_y) * isy);
                 acc += fx * fy;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
       }
       ex = ex1; ey = ey1; ec = ec1; es = es1; eth = eth1; ev = ev1;
       ex1 = ex2; ey1 = ey2; ec1 = ec2; es1 = es2; eth1 = eth2; ev1 = ev2;
-      px = npx; py = npy; pc = pc1; ps = ps1; pth = npth; pv = npv; isx = nisx; isy = nisy; rho = nrho;
+      px = npx; py = npy; pc = pc1; ps = ps1; pth = npth; pv = npv; isx = nisx; isy = nisy; asr = nasr;
     }
 
     // ---------------- per-pair scalars
@@ -739,31 +741,38 @@ __device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab
   return y;
 }
 
-// Gauss-Legendre nodes for the box probability under a CORRELATED covariance: two rules in one table, [x, w] pairs,
-// 48 nodes then 96 (computed on the host at context creation, fo_sweep_init_).
-
-// P(box) for a bivariate normal with correlation rho (collision_probability.py:117 hands any covariance to mvnun, which
-// integrates the bivariate normal exactly).  One-dimensional integral over x in units X = (x - mu_x)/(s_x sqrt 2):
-//   P = 1/sqrt(pi) Int_A^B exp(-X^2) 1/2 [erf((D - rho X) q) - erf((C - rho X) q)] dX,  q = 1/sqrt(1 - rho^2),
-// A, B / C, D the box edges in those units along x / y; Gauss-Legendre on [A, B] clipped to +-6 with n nodes (48 up to
-// |rho| = 0.9, 96 up to 0.99: 1e-12 against mvnun on boxes of this size).  Rare path (real agents with a full
-// covariance inside the 5 m gate): ~70 operations per node.
-__device__ __forceinline__ double fo_box_corr(const double2 *__restrict__ erf_tab, const double *__restrict__ exp_tab,
-                                              cdp_gl_t gl, int n, double A, double B, double Cc, double D, double rho,
-                                              double q) {
-  A = fmax(A, -6.0);
-  B = fmin(B, 6.0);
-  if (!(B > A)) return 0.0;
-  const double mid = 0.5 * (A + B), half = 0.5 * (B - A);
-  double acc = 0.0;
-#pragma unroll 1
-  for (int i = 0; i < n; ++i) {
-    const double X = fma(half, gl[2 * i], mid);   // node and weight are wave-uniform: scalar loads
-    const double rq = rho * X;
-    const double f = fo_erf_fast128(erf_tab, (D - rq) * (q * ERF_SCALE)) - fo_erf_fast128(erf_tab, (Cc - rq) * (q * ERF_SCALE));
-    acc = fma(gl[2 * i + 1] * fo_exp_tab<false>(exp_tab, -X * X), f, acc);
-  }
-  return acc * half * 0.28209479177387814;  // 1 / (2 sqrt(pi))
+// Box probabilities under a CORRELATED covariance (collision_probability.py:117 hands any 2x2 matrix to mvnun).  With
+// L(h, k) = P(X > h, Y > k) for the standardised pair, Drezner & Wesolowsky / Genz write
+//   L(h, k; rho) = Phi(-h) Phi(-k) + 1/(2 pi) Int_0^asin(rho) exp(-(h^2 + k^2 - 2 h k sin th) / (2 cos^2 th)) dth,
+// and P(box) = L(a1,a2) - L(b1,a2) - L(a1,b2) + L(b1,b2): the Phi products add up to the diagonal box probability the
+// kernel computes anyway, the integrals to a correction that vanishes with rho.  The integrand is smooth in th whatever
+// the box and the variances are: Gauss-Legendre with 8 / 12 / 20 / 48 nodes for |rho| <= 0.5 / 0.8 / 0.95 / 0.99 is
+// exact to 1e-14 (tools/corr_nodes.py).  Arguments here are in units of 1/(sigma sqrt 2), which cancels the 2 of the
+// denominator.  sin over |th| <= asin(0.99) = 1.43: Taylor through th^21 (remainder 1e-18).
+__device__ __forceinline__ double fo_sin_halfpi(double x) {
+  const double z = x * x;
+  double p = -1.0 / 51090942171709440000.0;            // 1/21!
+  p = fma(p, z, 1.0 / 121645100408832000.0);           // 19!
+  p = fma(p, z, -1.0 / 355687428096000.0);             // 17!
+  p = fma(p, z, 1.0 / 1307674368000.0);                // 15!
+  p = fma(p, z, -1.0 / 6227020800.0);                  // 13!
+  p = fma(p, z, 1.0 / 39916800.0);                     // 11!
+  p = fma(p, z, -1.0 / 362880.0);                      // 9!
+  p = fma(p, z, 1.0 / 5040.0);                         // 7!
+  p = fma(p, z, -1.0 / 120.0);                         // 5!
+  p = fma(p, z, 1.0 / 6.0);                            // 3!  (sign below)
+  return fma(-x * z, p, x);
+}
+// the four corner terms of one box at one node: s2 = 2 sin th, c2 = 1/cos^2 th  (four table exponentials in flight:
+// serialising them to save registers was measured 40 % slower)
+__device__ __forceinline__ double fo_corr_corners(const double *__restrict__ exp_tab, double A, double B, double Cc, double D,
+                                                  double s2, double c2) {
+  const double a2 = A * A, b2 = B * B;
+  const double eAC = fo_exp_tab(exp_tab, -c2 * fma(-s2 * A, Cc, fma(Cc, Cc, a2)));
+  const double eBC = fo_exp_tab(exp_tab, -c2 * fma(-s2 * B, Cc, fma(Cc, Cc, b2)));
+  const double eAD = fo_exp_tab(exp_tab, -c2 * fma(-s2 * A, D, fma(D, D, a2)));
+  const double eBD = fo_exp_tab(exp_tab, -c2 * fma(-s2 * B, D, fma(D, D, b2)));
+  return (eAC - eBC) - (eAD - eBD);
 }
 
 // Rounded distance (whole millimetres, rint(1000 d) = 1000 np.round(d, 3), dce.py:79) between the ego rectangle at
@@ -806,7 +815,7 @@ __device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(uns
 // take the SAME agent and a quarter of the horizon each (time chunk `wave`); every per-pair result is a minimum or a
 // first maximum over time, so the segments are folded in time order through LDS at the end.  Needs T <= QWAVES * TC.
 // CORR: the agent set holds a covariance with correlation (status[1] of fo_prep_agents_kernel): in-gate samples then
-// integrate their box probabilities numerically (fo_box_corr).  The kernel below carries both bodies and picks one at
+// add the correlation integral to their box probabilities (fo_corr_corners).  The kernel below carries both bodies and picks one at
 // its start, so that the usual diagonal case keeps the registers and the code it had.
 template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT, bool CORR>
 __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const double2 *__restrict__ erf_tab,
@@ -968,29 +977,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           const double qex = qxy.x, qey = qxy.y, qec = qcs.x, qes = qcs.y;
           const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti
           const double qpx = g0[0], qpy = g0[1], qisx = g0[6] * ERF_SCALE, qisy = g0[7] * ERF_SCALE;
-          const double qrho = CORR ? g0[10] : 0.0;
           const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
           const double devx = qc1 * hdev, devy = qs1 * hdev;
           const double rx = qex - qpx, ry = qey - qpy;
           const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
           double acc = 0.0;
-          if (CORR && __ballot(qrho != 0.0)) {
-            // some queued sample belongs to a covariance with correlation: every lane of the batch integrates its
-            // nine boxes numerically (valid for rho = 0 as well); 96 nodes when any |rho| exceeds 0.9
-            const bool fine = __ballot(fabs(qrho) > 0.9) != 0ull;
-            const cdp_gl_t gl = (cdp_gl_t)(unsigned long long)(a.gl + (fine ? 2 * GL_A : 0));
-            const double qq = 1.0 / sqrt(1.0 - qrho * qrho), ix0 = g0[6], iy0 = g0[7];
-#pragma unroll 1
-            for (int jm = -1; jm <= 1; ++jm) {
-              const double qx = rx - jm * devx, qy = ry - jm * devy;
-#pragma unroll 1
-              for (int b = -1; b <= 1; ++b) {
-                const double cx = qx + b * bxs, cy = qy + b * bys;
-                acc += 4.0 * fo_box_corr(erf_tab, exp_tab, gl, fine ? GL_B : GL_A, (cx - a.off_x) * ix0, (cx + a.off_x) * ix0,
-                                         (cy - a.off_y) * iy0, (cy + a.off_y) * iy0, qrho, qq);
-              }
-            }
-          } else
 #pragma unroll 1
           for (int jm = -1; jm <= 1; ++jm) {
             const double qx = rx - jm * devx, qy = ry - jm * devy;
@@ -1010,6 +1001,52 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             }
           }
           cpw[row * TILE + src] = acc * (0.25 / 3.0);  // (1/2)(1/2) of the two Phi differences, /3 (:122)
+        }
+        if (CORR) {
+          // Covariances with correlation: a second walk over the same queued samples adds the correlation integral of
+          // the nine boxes to the value stored above.  It re-reads its operands (nothing of the evaluation above stays
+          // live: this body shares the kernel's register budget with the usual one); whole batches without a
+          // correlated sample skip it, and asin(rho) = 0 makes it vanish lane by lane.
+          __asm__ volatile("" ::: "memory");
+          const double asr = lane < n ? a.atab[((size_t)k * a.Ta + gbase + (q[lane] >> 6)) * NAF + 11] : 0.0;
+          if (__ballot(asr != 0.0)) {
+            const double ar = fabs(asr);   // asin is monotonic: the rule thresholds are compared as angles
+            const int rule = __ballot(ar > 1.2532358975033751) ? 3 : __ballot(ar > 0.9272952180016123) ? 2
+                             : __ballot(ar > 0.5235987755982989) ? 1 : 0;   // asin(GL_RHO2), asin(GL_RHO1), asin(GL_RHO0)
+            const cdp_gl_t gl = (cdp_gl_t)(unsigned long long)(a.gl + 2 * gl_first(rule));
+            const int nn = gl_nodes(rule);
+            if (lane < n) {
+              const int item = q[lane];
+              const int src = item & 63, row = item >> 6, ti = gbase + row;
+              const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + 2 * src;
+              const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;
+              const fo_d2 qxy = fo_ld2(e), qcs = fo_ld2(e + EF(2));
+              // everything in units of the standard deviations (times sqrt 2) along x and y
+              const double ix0 = g0[6], iy0 = g0[7];
+              const double rx = (qxy.x - g0[0]) * ix0, ry = (qxy.y - g0[1]) * iy0;
+              const double devx = g0[NAF + 2] * hdev * ix0, devy = g0[NAF + 3] * hdev * iy0;
+              const double bxs = a.len3 * qcs.x * ix0, bys = a.len3 * qcs.y * iy0;
+              const double ox = a.off_x * ix0, oy = a.off_y * iy0;
+              double csum = 0.0;
+#pragma unroll 1
+              for (int i = 0; i < nn; ++i) {
+                const double sn = fo_sin_halfpi(asr * gl[2 * i]);   // node and weight are wave-uniform: scalar loads
+                const double c2 = 1.0 / fma(-sn, sn, 1.0);
+                double S = 0.0;
+#pragma unroll 1
+                for (int jm = -1; jm <= 1; ++jm) {
+                  const double qx = rx - jm * devx, qy = ry - jm * devy;
+#pragma unroll 1
+                  for (int b = -1; b <= 1; ++b) {
+                    const double cx = qx + b * bxs, cy = qy + b * bys;
+                    S += fo_corr_corners(exp_tab, cx - ox, cx + ox, cy - oy, cy + oy, 2.0 * sn, c2);
+                  }
+                }
+                csum = fma(gl[2 * i + 1], S, csum);
+              }
+              cpw[row * TILE + src] = fma(asr * (1.0 / 3.0), csum, cpw[row * TILE + src]);
+            }
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
@@ -1569,12 +1606,12 @@ int fo_sweep_init_(fo_ctx *ctx) {
   FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_exp_tab, sizeof(double) * EXP_N));
   hipLaunchKernelGGL(fo_exp_table_kernel, dim3(1), dim3(EXP_N), 0, 0, (double *)ctx->d_exp_tab);
   FO_HIP_TRY(ctx, hipGetLastError());
-  {  // Gauss-Legendre rules (fo_box_corr): Newton on the Legendre recurrence, nodes in ascending order
-    static double gl[2 * (GL_A + GL_B)];
-    const int ns[2] = {GL_A, GL_B};
+  {  // Gauss-Legendre rules of the correlation integral: Newton on the Legendre recurrence; stored as
+     // t = (x + 1)/2 and w/(4 pi)  (Int_0^asr f = asr/2 Sum w f(asr t), times the 1/(2 pi) of the formula)
+    static double gl[2 * GL_TOTAL];
     double *o = gl;
-    for (int r = 0; r < 2; ++r) {
-      const int n = ns[r];
+    for (int r = 0; r < GL_NR; ++r) {
+      const int n = gl_nodes(r);
       for (int i = 0; i < n; ++i) {
         double x = -cos(M_PI * (i + 0.75) / (n + 0.5)), dp = 1.0;
         for (int it = 0; it < 100; ++it) {
@@ -1585,8 +1622,8 @@ int fo_sweep_init_(fo_ctx *ctx) {
           x -= dx;
           if (fabs(dx) < 1e-16) break;
         }
-        *o++ = x;
-        *o++ = 2.0 / ((1.0 - x * x) * dp * dp);
+        *o++ = 0.5 * (x + 1.0);
+        *o++ = 2.0 / ((1.0 - x * x) * dp * dp) / (4.0 * M_PI);
       }
     }
     FO_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gl_tab, sizeof gl));

@@ -155,14 +155,18 @@ double fo_oracle_box_prob(const double lo[2], const double hi[2], const double m
   return ql0 * ql1 - qu0 * ql1 - ql0 * qu1 + qu0 * qu1;
 }
 
-/* Correlated covariance (what a prediction module hands over for real agents; the reference passes any matrix to
- * mvnun, which for d = 2 integrates the bivariate normal exactly: MVNDST -> BVNMVN -> BVU).  Restated as a one-
- * dimensional Gauss-Legendre integral instead of Genz's BVU (not a line-by-line restatement; pinned to the reference's
- * own outputs by tests/golden/correlated_cov.npz):  with X = (x - mu_x)/(s_x sqrt 2),
+/* Box probability under a covariance WITH correlation (collision_probability.py:117: mvnun -> MVNDST, which for two
+ * dimensions evaluates Genz's BVU).  Restated here as a one-dimensional integral over x instead (not a line-by-line
+ * restatement; pinned to the reference's own outputs by tests/golden/correlated_cov.npz):  with
+ * X = (x - mu_x)/(s_x sqrt 2),
  *   P = 1/sqrt(pi) * Int_A^B exp(-X^2) * 1/2 [ erf((D - rho X) q) - erf((C - rho X) q) ] dX,   q = 1/sqrt(1 - rho^2),
- * A, B (C, D) the box edges in those units along x (y).  96 nodes on [A, B] clipped to +-6: 1e-15 against mvnun for
- * |rho| <= 0.99 on boxes of this size; beyond that the integrand is too sharp and the matrix counts as degenerate. */
-#define FO_GL_N 96
+ * A, B (C, D) the box edges in those units along x (y).  Composite Gauss-Legendre: the range is cut to where the
+ * integrand is not below 1e-30 (|X| < 8.5 and the erf difference alive), then split into panels of half the width of
+ * the integrand's narrowest feature, min(1, sqrt(1 - rho^2)/|rho|), 16 nodes each: 1e-15 against mvnun whatever the
+ * variances are (tight covariances make boxes dozens of standard deviations wide).  |rho| > 0.99 counts as degenerate.
+ * The HIP side integrates a different formula (over the correlation angle, fo_sweep.hip fo_corr_corners): the two
+ * check each other. */
+#define FO_GL_N 16
 static double gl_x[FO_GL_N], gl_w[FO_GL_N];
 static int gl_ready = 0;
 static void gl_init(void) {
@@ -193,14 +197,27 @@ double fo_oracle_box_prob_corr(const double lo[2], const double hi[2], const dou
   const double ix = 1.0 / (sqrt(sxx) * M_SQRT2), iy = 1.0 / (sqrt(syy) * M_SQRT2), q = 1.0 / sqrt(1.0 - rho * rho);
   double A = (lo[0] - mu[0]) * ix, B = (hi[0] - mu[0]) * ix;
   const double Cc = (lo[1] - mu[1]) * iy, D = (hi[1] - mu[1]) * iy;
-  if (A < -6.0) A = -6.0;
-  if (B > 6.0) B = 6.0;
+  if (A < -8.5) A = -8.5;
+  if (B > 8.5) B = 8.5;
+  double feat = 1.0;
+  if (rho != 0.0) { /* the erf difference is below 1e-19 unless (C - rho X) q < 6.5 and (D - rho X) q > -6.5 */
+    double u1 = (Cc - 6.5 / q) / rho, u2 = (D + 6.5 / q) / rho;
+    if (u1 > u2) { const double t = u1; u1 = u2; u2 = t; }
+    if (A < u1) A = u1;
+    if (B > u2) B = u2;
+    const double f = sqrt(1.0 - rho * rho) / fabs(rho);
+    if (f < feat) feat = f;
+  }
   if (!(B > A)) return 0.0;
-  const double mid = 0.5 * (A + B), half = 0.5 * (B - A);
+  const int panels = (int)ceil((B - A) / (0.5 * feat));
+  const double half = 0.5 * (B - A) / panels;
   double acc = 0.0;
-  for (int i = 0; i < FO_GL_N; ++i) {
-    const double X = mid + half * gl_x[i];
-    acc += gl_w[i] * exp(-X * X) * (erf((D - rho * X) * q) - erf((Cc - rho * X) * q));
+  for (int p = 0; p < panels; ++p) {
+    const double mid = A + (2 * p + 1) * half;
+    for (int i = 0; i < FO_GL_N; ++i) {
+      const double X = mid + half * gl_x[i];
+      acc += gl_w[i] * exp(-X * X) * (erf((D - rho * X) * q) - erf((Cc - rho * X) * q));
+    }
   }
   return acc * half * 0.5 / sqrt(M_PI);
 }

@@ -327,18 +327,21 @@ def main():
     run_case("ring_all_types", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC)
 
     # case 5: full covariance matrices (what a prediction module hands over for real agents): correlation from -0.95 to
-    # 0.95, unequal and growing variances -- scipy's mvnun integrates the bivariate normal exactly (MVNDST -> BVNMVN)
+    # 0.985, unequal and growing variances -- scipy's mvnun integrates the bivariate normal exactly (MVNDST -> BVNMVN)
     rng = np.random.default_rng(20240135)
     trajs = [Traj(*make_traj(rng, 31, dt, psi0=-0.4)) for _ in range(10)]
     mid = np.array([trajs[0].cartesian.x[13], trajs[0].cartesian.y[13]])
-    kinds = ["Car", "Pedestrian", "Bicycle", "Truck", "Pedestrian", "Car", "Bicycle", "Pedestrian"]
-    rhos = [0.6, -0.8, 0.95, -0.95, 0.3, -0.15, 0.9, 0.0]
+    kinds = ["Car", "Pedestrian", "Bicycle", "Truck", "Pedestrian", "Car", "Bicycle", "Pedestrian", "Car", "Pedestrian"]
+    rhos = [0.6, -0.8, 0.95, -0.95, 0.3, -0.15, 0.9, 0.0, 0.985, -0.9]
     preds = []
     for i, (k, rho) in enumerate(zip(kinds, rhos)):
-        p = make_prediction(rng, k, 31, dt, mid, offset=rng.uniform(-2.5, 2.5, size=2))
+        off = rng.uniform(-2.5, 2.5, size=2)
+        p = make_prediction(rng, k, 31, dt, mid, offset=off if i < 8 else 0.15 * off)
         L = len(p["pos_list"])
         sx = np.sqrt(0.08 * 1.05 ** np.arange(L)) * (1.0 + 0.5 * (i % 3))
         sy = np.sqrt(0.12 * 1.04 ** np.arange(L))
+        if i >= 8:                             # tight, strongly correlated: standard deviations of 4 to 9 cm, so the
+            sx, sy = 0.15 * sx, 0.2 * sy       # boxes span dozens of them (hard for a quadrature in x)
         r = rho * np.cos(0.05 * np.arange(L)) if i % 2 else np.full(L, rho)      # some correlations change over time
         cov = np.zeros((L, 2, 2))
         cov[:, 0, 0], cov[:, 1, 1] = sx * sx, sy * sy
