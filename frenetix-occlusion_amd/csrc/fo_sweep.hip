@@ -187,27 +187,30 @@ __device__ __forceinline__ double fo_round3_fast(double v) { return fo_div1000(_
 // HBM read (along T) and the HBM write (along trajectories) are contiguous; sincos(theta) is taken once here.
 // Within a tile every (t, field) row is 512 contiguous bytes = one wave-wide load, and field / timestep strides
 // are compile-time constants (immediate offsets in the sweep's loads).
-__global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int /*Mp*/, const double *__restrict__ x,
+__global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int tz, const double *__restrict__ x,
                                                            const double *__restrict__ y,
                                                            const double *__restrict__ th,
                                                            const double *__restrict__ v, double *__restrict__ tab) {
-  extern __shared__ double sh[];  // [2][T][TILE+1]
+  extern __shared__ double sh[];  // [2][tz][TILE+1]
   const int m0 = blockIdx.x * TILE;
   const int n = min(TILE, M - m0);
   const int ld = TILE + 1;
   const int f = blockIdx.y;  // 0: positions (x, y); 1: heading and speed -> (cos, sin), (theta, v), (v cos, v sin)
-  const double *s0 = (f == 0 ? x : th) + (size_t)m0 * T, *s1 = (f == 0 ? y : v) + (size_t)m0 * T;
-  double *sh1 = sh + (size_t)T * ld;
-  for (int i = threadIdx.x; i < n * T; i += blockDim.x) {
-    sh[(i % T) * ld + (i / T)] = s0[i];
-    sh1[(i % T) * ld + (i / T)] = s1[i];
+  const int t0 = blockIdx.z * tz, nt = min(tz, T - t0);   // this block's slice of the horizon (latency: short blocks)
+  if (nt <= 0) return;
+  const double *s0 = (f == 0 ? x : th) + (size_t)m0 * T + t0, *s1 = (f == 0 ? y : v) + (size_t)m0 * T + t0;
+  double *sh1 = sh + (size_t)tz * ld;
+  for (int i = threadIdx.x; i < n * nt; i += blockDim.x) {
+    const int ml = i / nt, tl = i - ml * nt;
+    sh[tl * ld + ml] = s0[(size_t)ml * T + tl];
+    sh1[tl * ld + ml] = s1[(size_t)ml * T + tl];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < T * TILE; i += blockDim.x) {
-    const int t = i / TILE, ml = i % TILE;
-    const int src = t * ld + min(ml, n - 1);  // pad lanes replicate the last trajectory of the tile
+  for (int i = threadIdx.x; i < nt * TILE; i += blockDim.x) {
+    const int tl = i / TILE, ml = i % TILE;
+    const int src = tl * ld + min(ml, n - 1);  // pad lanes replicate the last trajectory of the tile
     const double a0 = sh[src], a1 = sh1[src];
-    fo_d2 *dst = (fo_d2 *)(tab + ((size_t)blockIdx.x * T + t) * NEF * TILE) + ml;  // pair p of lane ml: dst[p * TILE]
+    fo_d2 *dst = (fo_d2 *)(tab + ((size_t)blockIdx.x * T + t0 + tl) * NEF * TILE) + ml;  // pair p of lane ml: dst[p * TILE]
     if (f == 0) {
       dst[0 * TILE] = fo_d2{a0, a1};
     } else {
@@ -1731,8 +1734,9 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   }
 
   if (A > 0) {
-    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 2), dim3(256), (size_t)2 * T * (TILE + 1) * sizeof(double), s, M, T,
-                       Mp, d_x, d_y, d_theta, d_v, ctx->d_traj_tab);
+    const int tz = T > 8 ? 8 : T;   // horizon slice per block
+    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 2, (T + tz - 1) / tz), dim3(256),
+                       (size_t)2 * tz * (TILE + 1) * sizeof(double), s, M, T, tz, d_x, d_y, d_theta, d_v, ctx->d_traj_tab);
     FO_HIP_TRY(ctx, hipGetLastError());
     SweepArgs a{};
     a.M = M; a.Mp = Mp; a.T = T; a.A = A; a.Ta = Ta; a.n_tiles = n_tiles; a.nt8 = (n_tiles + 7) / 8; a.apw = apw;
