@@ -233,6 +233,18 @@ def main():
         if use_dist:
             dist.all_gather_into_tensor(gathered, out.cost)
 
+    # Everything slow on the host side happens first (the first timing() call creates the event pool; the check and the
+    # agent count synchronise), so that from here to the timed region the GPU is never idle for longer than a
+    # synchronize takes (microseconds): after an idle of milliseconds the MI355X runs two sweeps fast and the next ~15
+    # 6-8 % slow, decaying over ~40 steps (power management; per-launch series in DESIGN §7) -- a 20-step window right
+    # behind such an idle would consist of that dip.
+    sw.ctx.timing(True)
+    step()
+    sw.ctx.call("fo_sweep_check", torch.cuda.current_stream().cuda_stream)
+    n_active = A
+    if scene is not None:
+        n_active = int(scene["sl"].batch.n.item())
+    sw.ctx.timing(False)
     # Set-up, before the W warm-up steps: pick the sweep kernel's agents-per-wave for this batch shape by timing the
     # real step (4 candidates x (20 + 100) steps, ~0.4 s).  The same pass brings the GPU to its sustained clocks: a
     # cold MI355X runs the first few dozen steps 10-15 % slower, so without it the result would depend on W.
@@ -251,10 +263,6 @@ def main():
         os.environ["FO_SWEEP_APW"] = str(min(tune, key=tune.get))
     for _ in range(args.warmup):
         step()
-    sw.ctx.call("fo_sweep_check", torch.cuda.current_stream().cuda_stream)
-    n_active = A
-    if scene is not None:
-        n_active = int(scene["sl"].batch.n.item())
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -268,7 +276,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = sw.ctx.timing_read()
+    kern_each = sw.ctx.timing_read_each()
+    kern_ms, kern_n = float(sum(kern_each)), len(kern_each)
+    if os.environ.get("FO_BENCH_DUMP_SERIES"):
+        with open(os.environ["FO_BENCH_DUMP_SERIES"], "w") as f:
+            f.write(" ".join(f"{v:.4f}" for v in kern_each) + "\n")
     sw.ctx.timing(False)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -328,6 +340,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fo_sweep_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_s * 1e3, "launches_timed": kern_n,
+                         "kernel_ms_p50": float(np.percentile(kern_each, 50)) if kern_each else None,
+                         "kernel_ms_p95": float(np.percentile(kern_each, 95)) if kern_each else None,
                          "grid": launch["grid"], "block": launch["block"],
                          "kernel_pair_evals_per_sec": M * n_active / kern_s},
         }

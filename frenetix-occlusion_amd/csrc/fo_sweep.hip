@@ -1840,6 +1840,20 @@ int fo_sweep_timing_read(fo_ctx *ctx, double *total_ms, int *launches) {
   return FO_OK;
 }
 
+int fo_sweep_timing_read_each(fo_ctx *ctx, double *each_ms, int cap, int *launches) {
+  if (!ctx || !each_ms || !launches || cap < 0) return FO_E_ARG;
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < ctx->n_timed && i < cap; ++i) {
+    float ms = 0.f;
+    FO_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop[i]));
+    FO_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
+    each_ms[i] = ms;
+  }
+  *launches = ctx->n_timed;
+  ctx->n_timed = 0;
+  return FO_OK;
+}
+
 int fo_sweep_last_launch(const fo_ctx *ctx, int *grid, int *block, int *agents_per_wave) {
   if (!ctx) return FO_E_ARG;
   if (grid) *grid = ctx->last_grid;

@@ -27,7 +27,7 @@ TYPE_CODES = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4, "pr
 EXPORTS = [
     "fo_abi_version", "fo_create", "fo_destroy", "fo_last_error",
     "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
-    "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read",
+    "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read", "fo_sweep_timing_read_each",
     "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
     "fo_scene_candidate_count",
 ]
@@ -79,6 +79,7 @@ def load():
     lib.fo_sweep_check.argtypes = [vp, vp]
     lib.fo_sweep_timing.argtypes = [vp, C.c_int]
     lib.fo_sweep_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.fo_sweep_timing_read_each.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
     lib.fo_sweep_last_launch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     D = C.c_double
     lib.fo_scene_set_map.argtypes = [vp, C.c_int, ip, dp, C.c_int, dp, D, D, dp, dp, ip]
@@ -164,6 +165,12 @@ class Context:
         ms, n = C.c_double(), C.c_int()
         self._check(self._lib.fo_sweep_timing_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def timing_read_each(self, cap=1024):
+        """durations (ms) of the timed launches, one by one"""
+        buf, n = (C.c_double * cap)(), C.c_int()
+        self._check(self._lib.fo_sweep_timing_read_each(self._h, buf, cap, C.byref(n)))
+        return list(buf[:min(n.value, cap)])
 
     def last_launch(self):
         g, b, a = C.c_int(), C.c_int(), C.c_int()

@@ -112,6 +112,8 @@ int fo_sweep_check(fo_ctx *ctx, void *stream);
  * stream time each).  fo_sweep_timing_read synchronises. */
 int fo_sweep_timing(fo_ctx *ctx, int enable);
 int fo_sweep_timing_read(fo_ctx *ctx, double *total_ms, int *launches);
+/* the same read-out launch by launch: each_ms[i] = duration of the i-th timed launch, i < min(*launches, cap) */
+int fo_sweep_timing_read_each(fo_ctx *ctx, double *each_ms, int cap, int *launches);
 
 /* launch geometry of the last sweep launch (for profiling scripts) */
 int fo_sweep_last_launch(const fo_ctx *ctx, int *grid, int *block, int *agents_per_wave);
