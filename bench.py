@@ -316,7 +316,10 @@ def main():
             tag = os.environ.get("FO_PROFILE_TAG", "r02_final")
             with open(os.path.join(ROOT, "profiles", f"{tag}_summary.csv")) as f:
                 for row in csv.DictReader(f):
-                    if row["kernel"].startswith("fo_sweep_queue_kernel") and row.get("WRITE_SIZE") and row.get("FETCH_SIZE"):
+                    # the full-output instantiation (PAIR, LISTS = true, true); the small-batch step of the same
+                    # command runs another one
+                    if row["kernel"].startswith("fo_sweep_queue_kernel<true, true") and row.get("WRITE_SIZE") \
+                            and row.get("FETCH_SIZE") and traffic is None:
                         traffic = (float(row["WRITE_SIZE"]) + 2.0 * float(row["FETCH_SIZE"])) * 1024.0
         except Exception:
             traffic = None
