@@ -40,6 +40,7 @@ class FOAgentManager:
         self._n_batch = 0             # active slots in it
         self._batch_agents = None     # PhantomAgent objects of those slots (built on first access)
         self._manual = []             # agents added through add_agent() (host-side predictions)
+        self._external = []           # (obstacle id, prediction dict, type name) of REAL agents (extension, see below)
         self._pred_cache = None
         self.all_obstacle_id = [getattr(o, "obstacle_id", None) for o in getattr(scenario, "obstacles", [])]
         self._step_ids = []           # ids minted for this step's phantoms; handed back by reset()
@@ -48,6 +49,7 @@ class FOAgentManager:
     def reset(self):
         self._batch, self._n_batch, self._batch_agents = None, 0, None
         self._manual = []
+        self._external = []
         self._pred_cache = None
         self._release_step_ids()
 
@@ -251,6 +253,21 @@ class FOAgentManager:
             if a.agent_type.lower() == "pedestrian" and a.agent_id in cr_scenario_predictions:
                 cr_scenario_predictions[a.agent_id] = a.predictions[0]
 
+    def set_external_predictions(self, predictions, types=None):
+        """EXTENSION, not in the reference (whose metrics see the phantom agents only, interface.py:216-219): the
+        predictions of REAL agents as the planner's prediction module delivers them -- ``{obstacle_id: {'pos_list'
+        [L,2], 'v_list' [L], 'orientation_list' [L], 'cov_list' [L,2,2], 'shape': {'length', 'width'}}}`` -- take part
+        in the sweep as further agents, keyed by their obstacle id in the results.  Their covariances may carry
+        correlation.  ``types``: ``{obstacle_id: type name}``, default 'car'.  Call after reset()."""
+        self._external = []
+        for oid in sorted(predictions or {}):
+            p = predictions[oid]
+            L = min(len(p["pos_list"]), len(p["v_list"]), len(p["orientation_list"]), len(p["cov_list"]))
+            if L > 0:
+                name = str((types or {}).get(oid, "car")).lower()
+                self._external.append((int(oid), p, name if name in TYPE_CODE else "unknown"))
+        self._pred_cache = None
+
     # ---- device side ------------------------------------------------------------------------------------------
     def attach_batch(self, batch: PhantomBatch, n_active: int):
         """take over the spawn kernel's output (n_active slots are live)"""
@@ -262,11 +279,12 @@ class FOAgentManager:
         self._pred_cache = None
 
     def has_phantoms(self):
-        return self._n_batch > 0 or bool(self._manual)
+        return self._n_batch > 0 or bool(self._manual) or bool(self._external)
 
     def n_slots(self):
         """length of the agent axis of the sweep outputs"""
-        return (self._batch.pos.shape[0] if self._batch is not None else 0) + sum(len(a.predictions) for a in self._manual)
+        return (self._batch.pos.shape[0] if self._batch is not None else 0) + \
+            sum(len(a.predictions) for a in self._manual) + len(self._external)
 
     @property
     def phantom_agents(self):
@@ -288,24 +306,28 @@ class FOAgentManager:
         return self._batch_agents + self._manual
 
     def sweep_arrays(self):
-        """tensors for MetricSweep.set_agents: spawn-kernel slots first, then manually added agents"""
+        """tensors for MetricSweep.set_agents: spawn-kernel slots first, then manually added agents, then the real
+        agents' predictions (set_external_predictions)"""
         parts = []
         if self._batch is not None:
             parts.append(self._batch.sweep_args())
-        if self._manual:
+        if self._manual or self._external:
             dev = self.device
-            preds = [(a, p) for a in self._manual for p in a.predictions]     # one sweep slot per prediction
-            T = max(len(p["pos_list"]) for _, p in preds)
+            # one sweep slot per prediction: (type name, un-inflated length, width, prediction)
+            preds = [(a.agent_type, a.length, a.width, p) for a in self._manual for p in a.predictions]
+            preds += [(t, p["shape"]["length"], p["shape"]["width"], p) for _, p, t in self._external]
+            T = max(len(p["pos_list"]) for *_, p in preds)
             n = len(preds)
             pos, yaw, v = np.zeros((n, T, 2)), np.zeros((n, T)), np.zeros((n, T))
             cov, shape, raw = np.zeros((n, T, 2, 2)), np.zeros((n, 2)), np.zeros((n, 2))
             typ, ln = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
-            for i, (a, p) in enumerate(preds):
-                L = len(p["pos_list"])
-                pos[i, :L], yaw[i, :L], v[i, :L], cov[i, :L] = p["pos_list"], p["orientation_list"], p["v_list"], p["cov_list"]
+            for i, (tname, rl, rw, p) in enumerate(preds):
+                L = min(len(p["pos_list"]), len(p["v_list"]), len(p["orientation_list"]), len(p["cov_list"]))
+                pos[i, :L], yaw[i, :L], v[i, :L] = p["pos_list"][:L], p["orientation_list"][:L], p["v_list"][:L]
+                cov[i, :L] = p["cov_list"][:L]
                 shape[i] = (p["shape"]["length"], p["shape"]["width"])
-                raw[i] = (a.length, a.width)
-                typ[i], ln[i] = TYPE_CODE[a.agent_type.lower()], L
+                raw[i] = (rl, rw)
+                typ[i], ln[i] = TYPE_CODE[tname.lower()], L
             d = lambda x, dt=torch.float64: torch.as_tensor(x).to(dev, dt)
             parts.append((d(pos), d(yaw), d(v), d(cov), d(shape), d(raw), d(typ, torch.int32), d(ln, torch.int32)))
         if not parts:
@@ -363,6 +385,10 @@ class FOAgentManager:
                 out[pid] = p
                 order.append((pid, slot))
                 slot += 1
+        for oid, p, _ in self._external:                             # real agents: keyed by their obstacle id
+            out[oid] = p
+            order.append((oid, slot))
+            slot += 1
         self._pred_cache = out
         self.prediction_slots = order
         return out

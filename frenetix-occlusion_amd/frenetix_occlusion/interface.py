@@ -60,6 +60,7 @@ class FOInterface:
         self.sensor_radius = self.config["sensor_model"]["sensor_radius"]
         self.sensor_angle = self.config["sensor_model"]["sensor_angle"]
         self.visualization = None   # debug drawing is out of scope (forces TkAgg upstream)
+        self.include_real_agents = bool(acc.get("include_real_agents", False))
 
         self.ctx = N.Context(self.device.index)
         self.fo_obstacles = FOObstacles(self.cr_scenario.obstacles)
@@ -127,6 +128,14 @@ class FOInterface:
             for sp in self.spawn_points:
                 print("Phantom agent of type {} added to scenario at position {}".format(sp.agent_type, sp.position))
         self.agent_manager.update_real_agents(self.predictions)
+        if self.include_real_agents and self.predictions:
+            # EXTENSION (accelerator.include_real_agents, off by default): the real agents' predictions join the sweep
+            types = {}
+            for oid in self.predictions:
+                ob = self.cr_scenario.obstacle_by_id(oid) if hasattr(self.cr_scenario, "obstacle_by_id") else None
+                t = getattr(ob, "obstacle_type", None)
+                types[oid] = getattr(t, "value", t) or "car"
+            self.agent_manager.set_external_predictions(self.predictions, types)
         return self.sensor_model.visible_area
 
     def trajectory_safety_assessment(self, trajectory):

@@ -82,6 +82,13 @@ class Scenario:
                 return ll
         raise KeyError(lid)
 
+    def obstacle_by_id(self, oid) -> Optional["Obstacle"]:
+        """commonroad's Scenario.obstacle_by_id: None when there is no such obstacle"""
+        for ob in self.obstacles:
+            if ob.obstacle_id == oid:
+                return ob
+        return None
+
     def obstacle_arrays(self, timestep):
         """corner points [O,4,2], centres [O,2], flags [O] (bit0 present, bit1 occludes: not a bicycle, Q10)"""
         O = len(self.obstacles)

@@ -146,6 +146,29 @@ def test_agent_ids_are_released_every_step():
         assert sorted(am.all_obstacle_id) == [42, 10005, 10500]
 
 
+def test_external_predictions_become_sweep_slots_keyed_by_obstacle_id():
+    """EXTENSION (FOAgentManager.set_external_predictions): real agents' predictions join the agent axis after the
+    phantoms, in ascending obstacle id; ragged list lengths are cut to the shortest; reset() drops them"""
+    am = _bare_agent_manager(ids=(7, 3))
+    L = 12
+    cov = np.tile(np.array([[0.2, 0.05], [0.05, 0.3]]), (L, 1, 1))
+    mk = lambda x0, n: {"pos_list": np.c_[x0 + np.arange(n), np.zeros(n)], "v_list": np.ones(n), "orientation_list": np.zeros(n),
+                        "cov_list": cov[:n], "shape": {"length": 4.5, "width": 1.8}}
+    p7, p3 = mk(10.0, L), mk(20.0, L - 2)
+    p3["v_list"] = np.ones(L - 4)                          # a list that ends early
+    am.set_external_predictions({7: p7, 3: p3, 9: mk(0.0, 0)}, types={7: "truck", 3: "Bicycle", 9: "car"})
+    assert am.has_phantoms() and am.n_slots() == 2         # the empty prediction is dropped
+    pos, yaw, v, c, shape, raw, typ, ln = am.sweep_arrays()
+    from frenetix_occlusion._native import TYPE_CODES
+    assert typ.tolist() == [TYPE_CODES["bicycle"], TYPE_CODES["truck"]] and ln.tolist() == [L - 4, L]
+    assert pos.shape == (2, L, 2) and float(pos[0, 0, 0]) == 20.0 and float(pos[1, L - 1, 0]) == 10.0 + L - 1
+    assert float(c[1, 3, 0, 1]) == 0.05 and shape.tolist() == raw.tolist() == [[4.5, 1.8], [4.5, 1.8]]
+    preds = am.predictions
+    assert list(preds) == [3, 7] and am.prediction_slots == [(3, 0), (7, 1)]
+    am.reset()
+    assert not am.has_phantoms() and am.sweep_arrays() is None
+
+
 def test_agent_ids_of_scenario_agents_stay_taken_and_pool_exhaustion_raises():
     from frenetix_occlusion.agent import FOAgentManager, PhantomAgent
     am = _bare_agent_manager()

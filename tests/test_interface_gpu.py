@@ -23,7 +23,7 @@ def _traj_objects(traj):
     return [SimpleNamespace(cartesian=SimpleNamespace(**{k: v[i] for k, v in traj.items()})) for i in range(len(traj["x"]))]
 
 
-def _setup(tmp_path, thresholds=None, max_agents=16, metrics=None):
+def _setup(tmp_path, thresholds=None, max_agents=16, metrics=None, include_real_agents=False):
     import yaml
     from frenetix_occlusion import interface
     from frenetix_occlusion import scenario as S
@@ -31,6 +31,7 @@ def _setup(tmp_path, thresholds=None, max_agents=16, metrics=None):
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
     cfg["accelerator"]["spawn"]["max_agents"] = max_agents
+    cfg["accelerator"]["include_real_agents"] = include_real_agents
     if thresholds:
         cfg["metrics"]["metric_thresholds"].update(thresholds)
     if metrics:
@@ -256,3 +257,57 @@ def test_many_planning_steps_do_not_exhaust_the_agent_ids(torch_cuda, tmp_path):
             assert isinstance(safe, bool)
         assert len(fo.agent_manager.all_obstacle_id) <= len(scenario_ids) + len(ids) + len(fo.agent_manager.real_agents)
     assert n_seen >= 250 * 8
+
+
+def _real_predictions(sc, ego, L=31, dt=0.1):
+    """what a prediction module hands the planner for two real obstacles: constant velocity towards the ego's lane,
+    covariances that grow and carry correlation"""
+    preds = {}
+    for j, ob in enumerate(sc.obstacles[:2]):
+        yaw = float(ego[2]) + (2.2 if j == 0 else -1.9)
+        p0 = ego[:2] + np.array([14.0 + 6.0 * j, 2.5 if j == 0 else -2.0])
+        t = np.arange(L) * dt
+        v = 1.5 + 2.0 * j
+        pos = p0[None, :] + (v * t)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+        sx, sy = np.sqrt(0.05 * 1.06 ** np.arange(L)), np.sqrt(0.09 * 1.04 ** np.arange(L))
+        rho = 0.7 if j == 0 else -0.93
+        cov = np.zeros((L, 2, 2))
+        cov[:, 0, 0], cov[:, 1, 1] = sx * sx, sy * sy
+        cov[:, 0, 1] = cov[:, 1, 0] = rho * sx * sy
+        preds[ob.obstacle_id] = {"pos_list": pos, "v_list": np.full(L, v), "orientation_list": np.full(L, yaw),
+                                 "cov_list": cov, "shape": {"length": ob.length, "width": ob.width}}
+    return preds
+
+
+def test_real_agent_predictions_join_the_sweep_when_enabled(torch_cuda, oracle, tmp_path):
+    """EXTENSION (accelerator.include_real_agents): the predictions handed to evaluate_scenario are evaluated next to
+    the phantoms, keyed by obstacle id; off by default, like the reference (interface.py:216-219: phantoms only)."""
+    fo, sc, ego, SY = _setup(tmp_path, max_agents=4, include_real_agents=True)
+    preds = _real_predictions(sc, ego)
+    fo.evaluate_scenario(dict(preds), ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    am = fo.agent_manager
+    n_ph = 4 * fo.spawn_locator.R
+    assert am.n_slots() == n_ph + 2
+    traj = SY.make_trajectories(24, seed=9, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    objs = _traj_objects(traj)
+    ba = fo.trajectory_safety_assessment_batch(objs, mode="full")
+    torch_cuda.cuda.synchronize()
+    agents = dict(zip(("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len"),
+                      [t.cpu().numpy() for t in am.sweep_arrays()]))
+    assert np.all(agents["cov"][n_ph:, :, 0, 1] != 0.0)                   # the real agents' slots carry correlation
+    ref = oracle.sweep(traj, agents, SY.VEHICLE_BMW320I, 0.1, thr={"harm": 1, "risk": 1})
+    got = ba.result.pair_f.permute(2, 1, 0).cpu().numpy()
+    f = np.isfinite(ref["pair_f"])
+    assert np.array_equal(np.isnan(got), np.isnan(ref["pair_f"]))
+    np.testing.assert_allclose(got[f], ref["pair_f"][f], rtol=0, atol=1e-9)
+    assert ref["pair_f"][:, n_ph:, oracle.PF["max_collision_probability"]].max() > 1e-3   # and they matter
+    res, safe = fo.trajectory_safety_assessment(objs[0])                  # served from the batch, reference's schema
+    for oid in preds:
+        assert oid in res["hr"] and oid in res["dce"]
+        k = [s for pid, s in am.prediction_slots if pid == oid][0]
+        np.testing.assert_allclose(res["hr"][oid]["max_collision_probability"],
+                                   ref["pair_f"][0, k, oracle.PF["max_collision_probability"]], rtol=0, atol=1e-9)
+
+    fo2, sc2, ego2, _ = _setup(tmp_path, max_agents=4)                    # default: the predictions are not evaluated
+    fo2.evaluate_scenario(dict(preds), ego2[:2], float(ego2[2]), (0.0, 0.0), float(ego2[3]), 0, None)
+    assert fo2.agent_manager.n_slots() == 4 * fo2.spawn_locator.R
