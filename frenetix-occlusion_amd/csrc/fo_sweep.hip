@@ -28,11 +28,13 @@ constexpr int NEF = 8;     // ego fields per (t, trajectory): x, y, cos, sin, th
                            // fields (a vector-memory instruction costs the CU ~10 cycles whatever its width)
 // Gauss-Legendre rules of the correlation integral (fo_corr_term): node counts by the largest |rho| they serve, and where
 // each rule starts in the table ([t, w] pairs, t = (x + 1)/2, w = weight/(4 pi); host, fo_sweep_init_)
-constexpr int GL_NR = 4;
-__host__ __device__ constexpr int gl_nodes(int r) { return r == 0 ? 8 : r == 1 ? 12 : r == 2 ? 20 : 48; }
-__host__ __device__ constexpr int gl_first(int r) { return r == 0 ? 0 : r == 1 ? 8 : r == 2 ? 20 : 40; }
-constexpr int GL_TOTAL = 88;
-constexpr double GL_RHO0 = 0.5, GL_RHO1 = 0.8, GL_RHO2 = 0.95;   // rule r serves |rho| <= GL_RHOr, the last one <= 0.99
+constexpr int GL_NR = 5;
+__host__ __device__ constexpr int gl_nodes(int r) { return r == 0 ? 6 : r == 1 ? 8 : r == 2 ? 12 : r == 3 ? 20 : 24; }
+__host__ __device__ constexpr int gl_first(int r) { return r == 0 ? 0 : r == 1 ? 6 : r == 2 ? 14 : r == 3 ? 26 : 46; }
+constexpr int GL_TOTAL = 70;
+// rule r serves asin|rho| up to GL_ASR[r] = asin(0.5, 0.7, 0.9, 0.97); the last rule the rest, |rho| <= 0.99
+constexpr double GL_ASR0 = 0.5235987755982989, GL_ASR1 = 0.775397496610753, GL_ASR2 = 1.1197695149986342,
+                 GL_ASR3 = 1.3252308092796046;
 typedef const double __attribute__((address_space(4))) *cdp_gl_t;
 constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, rho, asin rho
                            // (96-byte rows: the 32-byte and 16-byte groups the scalar loads fetch stay naturally aligned)
@@ -409,7 +411,7 @@ __device__ __forceinline__ double fo_phi_diff(const double2 *__restrict__ tab, d
   return 0.5 * (fo_erf_lds(tab, hi) - fo_erf_lds(tab, lo));
 }
 
-// the correlation integral of one box (see fo_corr_corners) for the generic kernel: libm, always the 48-node rule
+// the correlation integral of one box (see fo_corr_corners) for the generic kernel: libm, always the 24-node rule
 __device__ __forceinline__ double fo_corr_term_plain(const double *__restrict__ gl, double A, double B, double Cc, double D,
                                                      double asr) {
   gl += 2 * gl_first(GL_NR - 1);
@@ -749,8 +751,8 @@ __device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab
 //   L(h, k; rho) = Phi(-h) Phi(-k) + 1/(2 pi) Int_0^asin(rho) exp(-(h^2 + k^2 - 2 h k sin th) / (2 cos^2 th)) dth,
 // and P(box) = L(a1,a2) - L(b1,a2) - L(a1,b2) + L(b1,b2): the Phi products add up to the diagonal box probability the
 // kernel computes anyway, the integrals to a correction that vanishes with rho.  The integrand is smooth in th whatever
-// the box and the variances are: Gauss-Legendre with 8 / 12 / 20 / 48 nodes for |rho| <= 0.5 / 0.8 / 0.95 / 0.99 is
-// exact to 1e-14 (tools/corr_nodes.py).  Arguments here are in units of 1/(sigma sqrt 2), which cancels the 2 of the
+// the box and the variances are: Gauss-Legendre with 6 / 8 / 12 / 20 / 24 nodes for |rho| <= 0.5 / 0.7 / 0.9 / 0.97 /
+// 0.99 is exact to 1e-11 (tools/corr_nodes.py), a tenth of what the erf table leaves.  Arguments here are in units of 1/(sigma sqrt 2), which cancels the 2 of the
 // denominator.  sin over |th| <= asin(0.99) = 1.43: Taylor through th^21 (remainder 1e-18).
 __device__ __forceinline__ double fo_sin_halfpi(double x) {
   const double z = x * x;
@@ -1014,8 +1016,8 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           const double asr = lane < n ? a.atab[((size_t)k * a.Ta + gbase + (q[lane] >> 6)) * NAF + 11] : 0.0;
           if (__ballot(asr != 0.0)) {
             const double ar = fabs(asr);   // asin is monotonic: the rule thresholds are compared as angles
-            const int rule = __ballot(ar > 1.2532358975033751) ? 3 : __ballot(ar > 0.9272952180016123) ? 2
-                             : __ballot(ar > 0.5235987755982989) ? 1 : 0;   // asin(GL_RHO2), asin(GL_RHO1), asin(GL_RHO0)
+            const int rule = __ballot(ar > GL_ASR3) ? 4 : __ballot(ar > GL_ASR2) ? 3 : __ballot(ar > GL_ASR1) ? 2
+                             : __ballot(ar > GL_ASR0) ? 1 : 0;
             const cdp_gl_t gl = (cdp_gl_t)(unsigned long long)(a.gl + 2 * gl_first(rule));
             const int nn = gl_nodes(rule);
             if (lane < n) {

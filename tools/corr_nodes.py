@@ -19,9 +19,9 @@ def box(n, A, B, C, D, rho):
 
 def main():
     rng = np.random.default_rng(4)
-    ns = (6, 8, 12, 16, 20, 32, 48)
+    ns = (6, 8, 12, 16, 20, 24, 32)
     print("rho    " + "".join(f"{n:>10d}" for n in ns))
-    for rho in (0.3, 0.5, 0.8, 0.9, 0.95, 0.99):
+    for rho in (0.3, 0.5, 0.7, 0.9, 0.95, 0.97, 0.99):
         err = {n: 0.0 for n in ns}
         for _ in range(4000):
             h = rng.uniform(-3, 3)
