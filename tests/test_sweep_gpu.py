@@ -49,10 +49,26 @@ def _compare(oracle, ref, got, atol=ATOL):
     """ref = oracle output dict, got = HIP output dict (both in oracle layout)."""
     PF, PI, C = oracle.PF, oracle.PI, oracle.COST
     worst = 0.0
+    # Plateaus of the collision probability: several samples within 2 atol of the pair's maximum (a tight covariance
+    # whose box probabilities saturate; float noise of the two implementations then decides np.argmax's "first
+    # maximum", hr.py:81).  harm_with_cp = obst_harm[argmax cp] is discontinuous there: on such pairs it is checked
+    # against the oracle's harm at the index the HIP side picked instead.
+    have_lists = "lists" in ref and ref["lists"] is not None and ref["lists"].shape[-1] > 0
+    plateau = np.zeros(ref["pair_f"].shape[:2], dtype=bool)
+    if have_lists:
+        cpv, mxc = ref["lists"][:, :, oracle.LST["cp"], :], ref["pair_f"][..., PF["max_collision_probability"]]
+        plateau = (np.nan_to_num(mxc) > 0.01 + atol) & ((np.abs(cpv - mxc[..., None]) <= 2 * atol).sum(axis=-1) > 1)
+        if plateau.any():
+            gi = got["pair_i"][..., PI["cp_argmax"]].astype(np.int64)
+            oh = np.take_along_axis(ref["lists"][:, :, oracle.LST["obst_harm"], :], gi[..., None], axis=-1)[..., 0]
+            hw = got["pair_f"][..., PF["max_obst_harm_with_cp"]]
+            assert np.all(np.abs(hw - oh)[plateau] <= atol), "max_obst_harm_with_cp on a cp plateau"
     # float pair scalars
     for name in ("dce", "ttc", "ttce", "max_ego_risk", "max_obst_risk", "max_obst_harm_with_cp", "max_ego_harm",
                  "max_obst_harm", "max_collision_probability"):
         a, b = ref["pair_f"][..., PF[name]], got["pair_f"][..., PF[name]]
+        if name == "max_obst_harm_with_cp" and plateau.any():
+            a, b = np.where(plateau, 0.0, a), np.where(plateau, 0.0, b)
         assert np.array_equal(np.isnan(a), np.isnan(b)), name
         assert np.array_equal(np.isinf(a), np.isinf(b)), name
         fin = np.isfinite(a)
@@ -73,7 +89,9 @@ def _compare(oracle, ref, got, atol=ATOL):
             mxv = ref["pair_f"][..., PF[mx]]
             ok = np.isnan(mxv) | (np.abs(picked - mxv) <= atol)
             assert ok.all(), idx_name
-            sig = np.nan_to_num(mxv) > 1e-9
+            # ... and unique: on a plateau (several samples within 2 atol of the maximum -- e.g. a tight covariance
+            # whose box probabilities saturate) the first-maximum rule may pick another sample of the plateau
+            sig = (np.nan_to_num(mxv) > 1e-9) & ((np.abs(vals - mxv[..., None]) <= 2 * atol).sum(axis=-1) == 1)
             assert np.array_equal(ri[sig], gi[sig]), idx_name
         a, b = ref["lists"], got["lists"]
         assert np.array_equal(np.isnan(a), np.isnan(b))
@@ -87,6 +105,8 @@ def _compare(oracle, ref, got, atol=ATOL):
         a, b = ref["cost"][:, C[name]], got["cost"][:, C[name]]
         assert np.array_equal(np.isinf(a), np.isinf(b)), name
         fin = np.isfinite(a)
+        if name == "max_obst_harm_with_cp_all":
+            fin &= ~plateau.any(axis=1)
         np.testing.assert_allclose(b[fin], a[fin], rtol=0, atol=atol, err_msg=name)
     for name in ("argmin_dce", "argmin_ttc"):
         assert np.array_equal(ref["cost"][:, C[name]], got["cost"][:, C[name]]), name

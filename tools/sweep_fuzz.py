@@ -30,6 +30,14 @@ def main():
         agents["len"] = rng.integers(0 if rng.random() < 0.2 else 1, T + 1, A).astype(np.int32)
         if rng.random() < 0.5:      # every ObstacleType code of the harm model's mass / protection tables
             agents["type"] = rng.integers(0, 12, A).astype(np.int32)
+        if rng.random() < 0.35:     # full covariances on some agents: any correlation the sweep accepts, loose to tight
+            cov = agents["cov"]
+            for k in np.nonzero(rng.random(A) < 0.5)[0]:
+                scale = float(rng.choice([0.05, 0.3, 1.0, 2.5]))
+                rho = float(rng.uniform(-0.99, 0.99)) * (np.cos(0.04 * np.arange(T)) if rng.random() < 0.5 else np.ones(T))
+                sx, sy = np.sqrt(cov[k, :, 0, 0]) * scale, np.sqrt(cov[k, :, 1, 1]) * scale * float(rng.uniform(0.5, 2.0))
+                cov[k, :, 0, 0], cov[k, :, 1, 1] = sx * sx, sy * sy
+                cov[k, :, 0, 1] = cov[k, :, 1, 0] = rho * sx * sy
         allm = ["hr", "ttc", "ttce", "dce", "wttc", "cp"]
         metrics = allm if rng.random() < 0.5 else list(rng.choice(allm, int(rng.integers(1, 6)), replace=False))
         thr = {"harm": float(rng.uniform(0.05, 1)), "risk": float(rng.uniform(0.01, 1)), "ttc": float(rng.uniform(0, 3)),
