@@ -63,6 +63,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # PyTorch ships its own libamdhip64; the process must end up with ONE HIP runtime, the one torch allocates with.
+    # Loaded after torch, libfo_hip.so binds to that copy (same soname); loaded first it would pull in /opt/rocm's, torch
+    # would then bring a second runtime, and fo_create would fail on a device the other runtime owns.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
     lib.fo_abi_version.restype = C.c_int

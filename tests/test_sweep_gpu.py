@@ -536,3 +536,15 @@ def test_correlated_covariances_against_the_oracle_and_the_diagonal_limit(torch_
     a, b = (_hip_sweep(torch_cuda, traj, d, S.VEHICLE_BMW320I, 0.1) for d in (tiny, diag))
     cpa, cpb = a["lists"][:, :, oracle.LST["cp"], :], b["lists"][:, :, oracle.LST["cp"], :]
     assert np.nanmax(np.abs(cpa - cpb)) < 1e-11
+
+
+def test_library_loaded_before_torch_still_gets_the_device():
+    """__graft_entry__.build() loads libfo_hip.so before anything imports torch; torch ships its own HIP runtime, and
+    with two of them in one process fo_create used to fail (-3).  _native.load() therefore imports torch first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from frenetix_occlusion import _native as N; N.load(); import torch; "
+            "c = N.Context(0); print('ctx ok', N.load().fo_abi_version())" % os.path.join(root, "frenetix-occlusion_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ctx ok" in r.stdout, r.stderr[-2000:]
