@@ -541,6 +541,7 @@ def test_correlated_covariances_against_the_oracle_and_the_diagonal_limit(torch_
 def test_library_loaded_before_torch_still_gets_the_device():
     """__graft_entry__.build() loads libfo_hip.so before anything imports torch; torch ships its own HIP runtime, and
     with two of them in one process fo_create used to fail (-3).  _native.load() therefore imports torch first."""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
