@@ -942,6 +942,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     double max_er = -INFINITY, max_or = -INFINITY, max_eh = -INFINITY, max_oh = -INFINITY, max_cp = -INFINITY;
     double oh_at_cp = 0.0;
     int idx_or = 0, idx_cp = 0;
+    // Without the per-sample lists the harm values are needed at the gate samples only (risk = harm x cp); their maxima
+    // are the logistic of the smallest argument -- 1/(1 + exp(nz)) falls with nz -- so the other samples keep a running
+    // minimum of the two arguments and the logistic is taken once per pair.
+    double nze_min = INFINITY, nzo_min = INFINITY;
     const size_t ls = (size_t)A * Tm1 * M;
     size_t li = ((size_t)k * Tm1 + gfirst_) * M + m;  // index of the next sample in the list buffers
     // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
@@ -1231,24 +1235,27 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             if (hv && (FO_X & 8)) {
               eh = dv; oh = ze + zo;
             } else if (hv) {
-              if (LR4S) {
-                eh = fo_logistic_neg<false>(exp_tab, fma(ke_, dv, ze));
-                oh = fo_logistic_neg<false>(exp_tab, fma(ko_, dv, zo));
-              } else if (prot == 0) {
-                eh = fo_logistic_neg<false>(exp_tab, fma(ke_, dv, ce_));
-                oh = fo_logistic_neg<false>(exp_tab, fma(ko_, dv, co_));
+              const bool model = LR4S || prot == 0;   // wave-uniform; otherwise harm is 1 on both sides
+              const double nze = LR4S ? fma(ke_, dv, ze) : fma(ke_, dv, ce_), nzo = LR4S ? fma(ko_, dv, zo) : fma(ko_, dv, co_);
+              if (LISTS || !model) {
+                eh = model ? fo_logistic_neg<false>(exp_tab, nze) : 1.0;
+                oh = model ? fo_logistic_neg<false>(exp_tab, nzo) : 1.0;
+                max_eh = fo_vmax(max_eh, eh);
+                max_oh = fo_vmax(max_oh, oh);
               } else {
-                eh = 1.0;
-                oh = 1.0;
+                nze_min = fmin(nze_min, nze);
+                nzo_min = fmin(nzo_min, nzo);
               }
-              max_eh = fo_vmax(max_eh, eh);
-              max_oh = fo_vmax(max_oh, oh);
             }
             // No lane of the wave is inside the gate at this sample (97 % of the samples of the bench workload): every
             // probability is zero, so are the risks, and none of the running maxima or indices can move -- they were
             // seeded by the wave's first sample, which always takes the long way.
             if (!hv || t == gfirst || ((wgate >> row) & 1u)) {
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
+              if (!LISTS && hv && (LR4S || prot == 0)) {   // the harm values themselves, where a risk may need them
+                eh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ke_, dv, ze) : fma(ke_, dv, ce_));
+                oh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ko_, dv, zo) : fma(ko_, dv, co_));
+              }
               if (hv) {
                 er = eh * cp;
                 orr = oh * cp;
@@ -1268,6 +1275,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         };
         if (lr4s) pass2(std::true_type{}); else pass2(std::false_type{});
       }
+    }
+    if (!LISTS && nze_min < INFINITY) {   // (a wave whose samples carry no harm keeps -inf, as the lists path does)
+      max_eh = fo_vmax(max_eh, fo_logistic_neg<false>(exp_tab, nze_min));
+      max_oh = fo_vmax(max_oh, fo_logistic_neg<false>(exp_tab, nzo_min));
     }
 
     if (SPLIT) {
