@@ -62,3 +62,18 @@ def test_golden_fixture_type_codes_are_the_product_codes():
     import golden_util
     from frenetix_occlusion import _native as native
     assert golden_util.TYPE_CODES == native.TYPE_CODES
+
+
+def test_c_example_compiles_as_plain_c(tmp_path):
+    """examples/sweep_from_c.c (a host with nothing but a C compiler and the HIP runtime's C API) builds and links
+    against the header and the library; without a GPU it must stop at fo_create with its message (no CPU path)."""
+    import subprocess
+    lib = os.path.join(ROOT, "frenetix-occlusion_amd", "lib")
+    exe = str(tmp_path / "sweep_from_c")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-O2", os.path.join(ROOT, "examples", "sweep_from_c.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-L" + lib, "-lfo_hip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "fo_create failed" in r.stderr
