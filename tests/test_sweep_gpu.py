@@ -538,6 +538,37 @@ def test_correlated_covariances_against_the_oracle_and_the_diagonal_limit(torch_
     assert np.nanmax(np.abs(cpa - cpb)) < 1e-11
 
 
+def test_correlated_and_diagonal_agent_sets_alternate_on_one_context(torch_cuda, oracle):
+    """the sweep kernel picks its body from a generation-tagged device flag written by the agent preparation: a
+    context that saw correlated agents must go back to the closed form -- bit for bit what a fresh context computes --
+    when the next agent set is diagonal, and forth again"""
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sweep import MetricSweep
+    traj, diag = S.make_batch(130, 5, config_id=33)
+    T = diag["pos"].shape[1]
+    diag["pos"][:, :, :] = traj["x"][0, 10], traj["y"][0, 10]
+    diag["pos"] += np.random.default_rng(8).uniform(-2.0, 2.0, size=(5, 1, 2))
+    corr = {k: v.copy() for k, v in diag.items()}
+    s = np.sqrt(corr["cov"][:, :, 0, 0] * corr["cov"][:, :, 1, 1])
+    corr["cov"][:, :, 0, 1] = corr["cov"][:, :, 1, 0] = np.array([0.6, -0.8, 0.3, 0.95, -0.4])[:, None] * s
+    keys = ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")
+    fresh = _hip_sweep(torch_cuda, traj, diag, S.VEHICLE_BMW320I, 0.1)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1)
+    outs = []
+    for agents in (corr, diag, corr, diag, diag):
+        sw.set_agents(*[agents[k] for k in keys])
+        o = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj["a"], mode="full")
+        torch_cuda.cuda.synchronize()
+        outs.append((o.cost.cpu().numpy().copy(), o.lists.permute(3, 1, 0, 2).cpu().numpy().copy()))
+    for i in (1, 3, 4):
+        assert np.array_equal(outs[i][0], fresh["cost"]) and np.array_equal(outs[i][1], fresh["lists"], equal_nan=True)
+    assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1], equal_nan=True)
+    ref = oracle.sweep(traj, corr, S.VEHICLE_BMW320I, 0.1)
+    f = np.isfinite(ref["lists"])
+    np.testing.assert_allclose(outs[0][1][f], ref["lists"][f], rtol=0, atol=ATOL)
+    assert np.abs(outs[0][1][f] - fresh["lists"][f]).max() > 1e-3        # and the correlation does change the numbers
+
+
 def test_library_loaded_before_torch_still_gets_the_device():
     """__graft_entry__.build() loads libfo_hip.so before anything imports torch; torch ships its own HIP runtime, and
     with two of them in one process fo_create used to fail (-3).  _native.load() therefore imports torch first."""
