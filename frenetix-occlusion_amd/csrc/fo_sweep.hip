@@ -822,11 +822,13 @@ __device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(uns
 // CORR: the agent set holds a covariance with correlation (status[1] of fo_prep_agents_kernel): in-gate samples then
 // add the correlation integral to their box probabilities (fo_corr_corners).  The kernel below carries both bodies and picks one at
 // its start, so that the usual diagonal case keeps the registers and the code it had.
-template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT, bool CORR>
+template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT, bool CORR, int TC_>
 __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const double2 *__restrict__ erf_tab,
                                                     const double *__restrict__ exp_tab, const double *__restrict__ zc_tab,
                                                     double *__restrict__ hk_all, double *__restrict__ cpbuf_all,
                                                     unsigned short *__restrict__ queue_all) {
+  constexpr int TC = TC_, DVR = TC + 1, WROWS = TC + DVR;   // this instantiation's chunk length (see fo_sweep_queue_kernel)
+  static_assert(!SPLIT || WROWS >= 10, "the horizon-split fold parks ten values per lane in the wave's rows");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -1387,9 +1389,19 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
   }
 }
 
+// Chunk length and occupancy by output mode: with the per-sample lists the hot loops need 164 VGPRs (three waves per
+// SIMD, chunks of eight); without them -- and not in the horizon-split form, whose four waves must cover T <= 32 with
+// one chunk each -- chunks of four fit 128 VGPRs and 37 KB of LDS: four waves per SIMD (measured -5 % on those modes).
+template <bool LISTS, bool SPLIT>
+struct SweepShape {
+  static constexpr bool wide = !LISTS && !SPLIT && FO_MINW == 3 && FO_TC == 8;   // tuning builds override both macros
+  static constexpr int tc = wide ? 4 : FO_TC, minw = wide ? 4 : FO_MINW;
+};
 template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT = false>
-__global__ __launch_bounds__(TILE *QWAVES) __attribute__((amdgpu_waves_per_eu(FO_MINW, FO_MINW)))
+__global__ __launch_bounds__(TILE *QWAVES)
+__attribute__((amdgpu_waves_per_eu(SweepShape<LISTS, SPLIT>::minw, SweepShape<LISTS, SPLIT>::minw)))
 void fo_sweep_queue_kernel(const SweepArgs a) {
+  constexpr int TCK = SweepShape<LISTS, SPLIT>::tc, WROWS = TCK + TCK + 1;
   __shared__ double2 erf_tab[ERF_N];
   __shared__ double exp_tab[EXP_N];
   __shared__ double zc_tab[4];                      // LR4S logistic offsets by impact class: front, side, rear
@@ -1405,9 +1417,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   const bool corr = a.status[1] == a.gen;   // scalar load; written by fo_prep_agents_kernel earlier on this stream
   __syncthreads();
   if (__builtin_expect(!corr, 1))
-    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
+    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
   else
-    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, true>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
+    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, true, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
 }
 
 
