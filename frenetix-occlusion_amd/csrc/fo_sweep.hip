@@ -697,7 +697,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #endif
 #ifndef FO_X
 #define FO_X 0       // timing experiments only (tools/build_variant.sh x1 -DFO_X=1 ...): 1 no pass 2, 2 no probe, 4 no harm
-#endif               // geometry in pass 1, 8 pass 2 without its arithmetic, 32 no DCE in pass 1, 64 no gate -- WRONG results
+#endif               // geometry in pass 1, 8 pass 2 without its arithmetic, 32 no DCE in pass 1, 64 no gate, 128 no second (correlated) body -- WRONG results
 constexpr int TC = FO_TC;
 constexpr int DVR = TC + 1;          // rows of the per-wave ring of relative speeds: samples t0-1 .. t1-1 are live at once
 constexpr int WROWS = TC + DVR;      // LDS rows (64 doubles each) per wave
@@ -1414,7 +1414,8 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   for (int i = threadIdx.x; i < EXP_N; i += TILE * QWAVES) exp_tab[i] = a.exp_tab[i];
   if (threadIdx.x < 4)
     zc_tab[threadIdx.x] = -a.hc.lr4s_const - (threadIdx.x == 0 ? 0.0 : threadIdx.x == 1 ? a.hc.lr4s_side : a.hc.lr4s_rear);
-  const bool corr = a.status[1] == a.gen;   // scalar load; written by fo_prep_agents_kernel earlier on this stream
+  // (FO_X & 128: register / timing experiments without the second body -- WRONG results for correlated covariances)
+  const bool corr = !(FO_X & 128) && a.status[1] == a.gen;   // scalar load; written by fo_prep_agents_kernel on this stream
   __syncthreads();
   if (__builtin_expect(!corr, 1))
     fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
