@@ -1392,9 +1392,12 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
 // Chunk length and occupancy by output mode: with the per-sample lists the hot loops need 164 VGPRs (three waves per
 // SIMD, chunks of eight); without them -- and not in the horizon-split form, whose four waves must cover T <= 32 with
 // one chunk each -- chunks of four fit 128 VGPRs and 37 KB of LDS: four waves per SIMD (measured -5 % on those modes).
+#ifndef FO_WIDE_LISTS
+#define FO_WIDE_LISTS 0   // 1: tuning builds -- the full-output instantiation in the four-wave shape as well
+#endif
 template <bool LISTS, bool SPLIT>
 struct SweepShape {
-  static constexpr bool wide = !LISTS && !SPLIT && FO_MINW == 3 && FO_TC == 8;   // tuning builds override both macros
+  static constexpr bool wide = (!LISTS || FO_WIDE_LISTS) && !SPLIT && FO_MINW == 3 && FO_TC == 8;   // tuning builds override both macros
   static constexpr int tc = wide ? 4 : FO_TC, minw = wide ? 4 : FO_MINW;
 };
 template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT = false>
