@@ -389,15 +389,33 @@ __device__ __forceinline__ double fo_lr4s_coef_dir(double dx, double dy, double 
 // the same decision as an index (0 front, 1 side, 2 rear) -- the queue kernel takes it in pass 1, where the poses are
 // in registers anyway, and keeps two bits per sample until pass 2 looks the logistic offset up.  flip = obstacle side
 // (angle rel + pi: both S and C change sign).
+// `band` is raised where the sample sits on a class boundary to within rounding (|C| = |S| up to 1e-13 relative): there
+// the reference's own floating-point route -- atan2, the subtraction, the comparison with 45/180 pi -- decides, and may
+// decide either way (a heading of exactly -pi/4 with the other party exactly on the x axis gives ang == t_a: "side",
+// although cos of that heading is one ulp above |sin|); the caller re-rates those samples with fo_lr4s_class_ref.
 __device__ __forceinline__ unsigned fo_lr4s_class(double dx, double dy, double hc, double hs, float rel_crude, float turn,
-                                                  float heading, bool flip) {
+                                                  float heading, bool flip, bool &band) {
   double S = dy * hc - dx * hs, Cc = dx * hc + dy * hs;
   if (flip) Cc = -Cc;  // |S| is all that is used of S
-  const double aS = fabs(S);
+  const double aS = fabs(S), aC = fabs(Cc);
+  band = fabs(aC - aS) <= 1e-13 * (aC + aS);
   const bool unwrapped_far = fabsf(turn + rel_crude - heading) > 3.14159265f;
   unsigned c = (Cc > aS) ? 0u : 1u;
   if (unwrapped_far || -Cc >= aS) c = 2u;
   return c;
+}
+// the reference's binning of the un-wrapped angle itself (logistic_regression.py:28-42) as a class index
+__device__ __forceinline__ unsigned fo_lr4s_class_ref(double ang) {
+  const double t_a = 45.0 / 180.0 * M_PI, t_b = 3.0 * t_a;
+  if (-t_a < ang && ang < t_a) return 0u;
+  if ((t_a <= ang && ang < t_b) || (-t_a >= ang && ang > -t_b)) return 1u;
+  return 2u;
+}
+// both classes of one sample by the reference's route (harm_model.py:86-90): ego class | obstacle class << 2.  A real
+// call on purpose: inlined, the float64 atan2 raises the register demand of the whole kernel (measured +7 % / +34 %).
+__device__ __attribute__((noinline)) unsigned fo_lr4s_classes_ref(double ddx, double ddy, double theta, double yaw) {
+  const double rel = atan2(ddy, ddx);
+  return fo_lr4s_class_ref(rel - theta) | (fo_lr4s_class_ref(M_PI + rel - yaw) << 2);
 }
 
 // squared distance from point (px,py) to the axis-aligned box [-hl,hl]x[-hw,hw]
@@ -1067,6 +1085,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       // agent row t+1 (scalar loads) are issued at the top and first used at the top of the next iteration.
       unsigned gmask = 0u;  // bit row: gate sample gbase + row is inside the 5 m gate for this lane
       unsigned wgate = 0u;  // the same for the whole wave (uniform): some lane is inside the gate
+      unsigned wband = 0u;  // (uniform) bit t & 15: some lane's impact angle of sample t sits on a class boundary
       int qn = 0;
       int ring = tl % DVR;  // row of sample t in the ring of relative speeds
       const bool geo = do_hr && !(ablate & 4);
@@ -1153,8 +1172,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             double ddx = px - ex, ddy = py - ey;
             if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;  // atan2(0, 0) = 0
             const float relc = fo_atan2_crude((float)ddy, (float)ddx);
-            const unsigned ce = fo_lr4s_class(ddx, ddy, ec, es, relc, 0.0f, (float)eth, false);
-            const unsigned co = fo_lr4s_class(ddx, ddy, pc, ps, relc, 3.14159265f, (float)pyaw, true);
+            bool be_, bo_;
+            const unsigned ce = fo_lr4s_class(ddx, ddy, ec, es, relc, 0.0f, (float)eth, false, be_);
+            const unsigned co = fo_lr4s_class(ddx, ddy, pc, ps, relc, 3.14159265f, (float)pyaw, true, bo_);
+            if (__ballot(be_ || bo_)) wband |= 1u << (t & 15);   // re-rated after the loop (rare; see there)
             const int sh = (t & 15) * 2;
             cls_e = (cls_e & ~(3u << sh)) | (ce << sh);
             cls_o = (cls_o & ~(3u << sh)) | (co << sh);
@@ -1203,6 +1224,30 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       }
       if (qn > 0) process(qn);
       wgate = __builtin_amdgcn_readfirstlane(wgate);  // uniform by construction; says so to the register allocator
+      wband = __builtin_amdgcn_readfirstlane(wband);
+      if (lr4s && wband) {
+        // Impact angles on a class boundary to within rounding: the reference's own floating-point route (float64 atan2,
+        // the subtraction, the comparison with 45/180 pi; harm_model.py:86-90, logistic_regression.py:28-42) decides
+        // those samples -- here, outside the loop whose registers a float64 atan2 does not fit into.
+        for (unsigned wb = wband; wb; wb &= wb - 1u) {
+          const int slot = __builtin_ctz(wb), t = tl + ((slot - tl) & 15);
+          const double *e0 = tj + (size_t)t * NEF * TILE;
+          const fo_d2 xy = fo_ld2(e0), cs = fo_ld2(e0 + EF(2));
+          const double th0 = e0[EF(4)];
+          const cdp_t g0 = G + (size_t)min(t, L - 1) * NAF;
+          double ddx = g0[0] - xy.x, ddy = g0[1] - xy.y;
+          if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;
+          bool be_, bo_;
+          (void)fo_lr4s_class(ddx, ddy, cs.x, cs.y, 0.0f, 0.0f, 0.0f, false, be_);
+          (void)fo_lr4s_class(ddx, ddy, g0[2], g0[3], 0.0f, 0.0f, 0.0f, true, bo_);
+          if (be_ || bo_) {
+            const unsigned both = fo_lr4s_classes_ref(ddx, ddy, th0, g0[4]);
+            const int sh = slot * 2;
+            if (be_) cls_e = (cls_e & ~(3u << sh)) | ((both & 3u) << sh);
+            if (bo_) cls_o = (cls_o & ~(3u << sh)) | ((both >> 2) << sh);
+          }
+        }
+      }
 
       // ---------------------------------------------------------------- pass 2: harm, risk, maxima, lists
       // of the gate samples g in [max(t0-1, 0), t1-1) -- harm index g, cp index g (Q6)

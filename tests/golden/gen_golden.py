@@ -352,6 +352,29 @@ def main():
         preds.append(p)
     run_case("correlated_cov", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC)
 
+    # case 6: the impact-angle bins of the LR4S model (logistic_regression.py:28-42) and their boundaries.  The ego
+    # stands at the origin with seven headings (one trajectory each); 240 cars sit on a circle of 12 m at 1.5 deg steps,
+    # once with yaw 0 and once with yaw pi/2.  The positions at multiples of 45 deg are exact ((12, 0), (8.5, 8.5), ...),
+    # so for the headings that are multiples of 45 deg the un-wrapped angle lands ON a boundary as a float (atan2(1, 1)
+    # is the float pi/4 = 45/180*pi): what the reference's comparisons make of those is part of the contract, and
+    # differs from what exact geometry says (cos of the float -pi/4 is one ulp above |sin|: "front", the reference:
+    # "side").  Elsewhere the neighbouring floats of the boundaries are visited.
+    T = 2
+    heads = [0.0, np.pi / 2, -np.pi / 4, 0.7, 5.5, -3.0 * np.pi / 4, np.pi]
+    trajs = [Traj(np.zeros(T), np.zeros(T), np.full(T, h), np.full(T, 0.5), np.zeros(T)) for h in heads]
+    nb = 240
+    exact = [(12.0, 0.0), (8.5, 8.5), (0.0, 12.0), (-8.5, 8.5), (-12.0, 0.0), (-8.5, -8.5), (0.0, -12.0), (8.5, -8.5)]
+    kinds, preds = [], []
+    for psi in (0.0, np.pi / 2):
+        for i in range(nb):
+            beta = 2.0 * np.pi * i / nb
+            p0 = np.array(exact[i // 30]) if i % 30 == 0 else 12.0 * np.array([np.cos(beta), np.sin(beta)])
+            kinds.append("Car")
+            preds.append({"pos_list": np.tile(p0, (T, 1)), "v_list": np.full(T, 2.0), "orientation_list": np.full(T, psi),
+                          "cov_list": np.tile(0.1 * np.eye(2), (T, 1, 1)),
+                          "shape": {"length": RAW_DIMS["Car"][0] * 1.2, "width": RAW_DIMS["Car"][1] * 1.3}})
+    run_case("angle_bins", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC)
+
 
 if __name__ == "__main__":
     main()

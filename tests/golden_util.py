@@ -6,7 +6,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TYPE_CODES = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4, "priorityvehicle": 5, "parkedvehicle": 6,
               "train": 7, "motorcycle": 8, "taxi": 9, "unknown": 10}      # = frenetix_occlusion._native.TYPE_CODES
-CASES = ["probe_ped_crossing", "random_equal_len", "random_ragged", "short_traj", "ring_all_types", "correlated_cov"]
+CASES = ["probe_ped_crossing", "random_equal_len", "random_ragged", "short_traj", "ring_all_types", "correlated_cov", "angle_bins"]
 
 
 def load_case(name):

@@ -33,7 +33,7 @@ def test_hr_scalars_match_reference(oracle, name):
     # e.g. 3.7e-51 where the true box probability is 1e-102 -- see DESIGN.md "CP tails").
     sig = g["ref_max_obst_risk"] > 1e-12
     assert np.array_equal(pi[:, :, oracle.PI["max_obst_risk_index"]][sig], g["ref_max_obst_risk_index"][sig])
-    assert sig.sum() > 0 or name == "short_traj"
+    assert sig.sum() > 0 or name in ("short_traj", "angle_bins")   # (cases whose agents never enter the gate)
     for key in ("max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
                 "max_collision_probability_all", "max_obst_harm_with_cp_all"):
         np.testing.assert_allclose(cost[:, oracle.COST[key]], g["ref_" + key], rtol=0, atol=TOL, err_msg=key)
