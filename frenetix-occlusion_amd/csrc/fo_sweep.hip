@@ -389,7 +389,7 @@ __device__ __forceinline__ double fo_lr4s_coef_dir(double dx, double dy, double 
 // the same decision as an index (0 front, 1 side, 2 rear) -- the queue kernel takes it in pass 1, where the poses are
 // in registers anyway, and keeps two bits per sample until pass 2 looks the logistic offset up.  flip = obstacle side
 // (angle rel + pi: both S and C change sign).
-// `band` is raised where the sample sits on a class boundary to within rounding (|C| = |S| up to 1e-13 relative): there
+// `band` is raised where the sample may sit on a class boundary to within rounding (|C| = |S| up to 1e-13 relative): there
 // the reference's own floating-point route -- atan2, the subtraction, the comparison with 45/180 pi -- decides, and may
 // decide either way (a heading of exactly -pi/4 with the other party exactly on the x axis gives ang == t_a: "side",
 // although cos of that heading is one ulp above |sin|); the caller re-rates those samples with fo_lr4s_class_ref.
@@ -398,11 +398,17 @@ __device__ __forceinline__ unsigned fo_lr4s_class(double dx, double dy, double h
   double S = dy * hc - dx * hs, Cc = dx * hc + dy * hs;
   if (flip) Cc = -Cc;  // |S| is all that is used of S
   const double aS = fabs(S), aC = fabs(Cc);
-  band = fabs(aC - aS) <= 1e-13 * (aC + aS);
+  // coarse and cheap here (high words within one of each other: |C| = |S| to ~1e-6); the exact 1e-13 test is taken
+  // by fo_lr4s_on_boundary where the flagged samples are re-rated
+  band = (unsigned)(__double2hiint(aC) - __double2hiint(aS) + 1) <= 2u;
   const bool unwrapped_far = fabsf(turn + rel_crude - heading) > 3.14159265f;
   unsigned c = (Cc > aS) ? 0u : 1u;
   if (unwrapped_far || -Cc >= aS) c = 2u;
   return c;
+}
+__device__ __forceinline__ bool fo_lr4s_on_boundary(double dx, double dy, double hc, double hs) {
+  const double aS = fabs(dy * hc - dx * hs), aC = fabs(dx * hc + dy * hs);
+  return fabs(aC - aS) <= 1e-13 * (aC + aS);
 }
 // the reference's binning of the un-wrapped angle itself (logistic_regression.py:28-42) as a class index
 __device__ __forceinline__ unsigned fo_lr4s_class_ref(double ang) {
@@ -1084,8 +1090,8 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       // Every operand of iteration t was requested one iteration earlier: the ego row t+1 (vector loads) and the
       // agent row t+1 (scalar loads) are issued at the top and first used at the top of the next iteration.
       unsigned gmask = 0u;  // bit row: gate sample gbase + row is inside the 5 m gate for this lane
-      unsigned wgate = 0u;  // the same for the whole wave (uniform): some lane is inside the gate
-      unsigned wband = 0u;  // (uniform) bit t & 15: some lane's impact angle of sample t sits on a class boundary
+      unsigned wgate = 0u;  // the same for the whole wave (uniform): some lane is inside the gate.  Bits 16 + (t & 15)
+                            // of the same scalar: some lane's impact angle of sample t may sit on a class boundary
       int qn = 0;
       int ring = tl % DVR;  // row of sample t in the ring of relative speeds
       const bool geo = do_hr && !(ablate & 4);
@@ -1175,7 +1181,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             bool be_, bo_;
             const unsigned ce = fo_lr4s_class(ddx, ddy, ec, es, relc, 0.0f, (float)eth, false, be_);
             const unsigned co = fo_lr4s_class(ddx, ddy, pc, ps, relc, 3.14159265f, (float)pyaw, true, bo_);
-            if (__ballot(be_ || bo_)) wband |= 1u << (t & 15);   // re-rated after the loop (rare; see there)
+            if (__ballot(be_ || bo_)) wgate |= 0x10000u << (t & 15);   // re-rated after the loop (rare; see there)
             const int sh = (t & 15) * 2;
             cls_e = (cls_e & ~(3u << sh)) | (ce << sh);
             cls_o = (cls_o & ~(3u << sh)) | (co << sh);
@@ -1224,7 +1230,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       }
       if (qn > 0) process(qn);
       wgate = __builtin_amdgcn_readfirstlane(wgate);  // uniform by construction; says so to the register allocator
-      wband = __builtin_amdgcn_readfirstlane(wband);
+      const unsigned wband = wgate >> 16;
       if (lr4s && wband) {
         // Impact angles on a class boundary to within rounding: the reference's own floating-point route (float64 atan2,
         // the subtraction, the comparison with 45/180 pi; harm_model.py:86-90, logistic_regression.py:28-42) decides
@@ -1237,9 +1243,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           const cdp_t g0 = G + (size_t)min(t, L - 1) * NAF;
           double ddx = g0[0] - xy.x, ddy = g0[1] - xy.y;
           if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;
-          bool be_, bo_;
-          (void)fo_lr4s_class(ddx, ddy, cs.x, cs.y, 0.0f, 0.0f, 0.0f, false, be_);
-          (void)fo_lr4s_class(ddx, ddy, g0[2], g0[3], 0.0f, 0.0f, 0.0f, true, bo_);
+          const bool be_ = fo_lr4s_on_boundary(ddx, ddy, cs.x, cs.y), bo_ = fo_lr4s_on_boundary(ddx, ddy, g0[2], g0[3]);
           if (be_ || bo_) {
             const unsigned both = fo_lr4s_classes_ref(ddx, ddy, th0, g0[4]);
             const int sh = slot * 2;
