@@ -18,7 +18,8 @@ kernel and the best one kept -- which also brings the GPU to its sustained clock
 depend on W (`--no-autotune` skips it).  `--scene scenario1 --M 2000 --A 32` runs BASELINE configs[1] instead.
 
 Prints ONE JSON line on rank 0.  `value` = trajectory x agent metric evaluations per second over all ranks.
-With the default workload on one GPU the line also carries `config.small_batch`: the same planning step at BASELINE
+With the default workload on one GPU the line also carries `config.reduced_outputs` (the same step with the cost vectors and
+flags only, no per-pair data) and `config.small_batch`: the same planning step at BASELINE
 configs[1] (scenario1 geometry, 2 000 candidates x 32 phantom slots), i.e. ms per planning step at the reference's own
 problem size (a few hundred steps of ~0.1 ms after the timed region).
 """
@@ -353,6 +354,25 @@ def main():
             res["config"]["collision_pair_frac"] = float((out.pair_f[N.PF["dce"]] == 0).double().mean())
             res["config"]["safe_traj_frac"] = float(out.safe.double().mean())
         if world == 1 and default_workload:
+            # the same step with reduced outputs (cost vectors + flags: what a planner loop consumes), beside the headline
+            red = None
+            for _ in range(60):
+                a_args = scene_stage()
+                sw.set_agents(*a_args, check=False)
+                red = sw.run(tx, ty, tth, tv, ta, mode="reduced", out=red)
+            torch.cuda.synchronize()
+            sw.ctx.timing(True)
+            t_r = time.perf_counter()
+            for _ in range(100):
+                a_args = scene_stage()
+                sw.set_agents(*a_args, check=False)
+                red = sw.run(tx, ty, tth, tv, ta, mode="reduced", out=red)
+            torch.cuda.synchronize()
+            dt_r = (time.perf_counter() - t_r) / 100
+            kms_r, kn_r = sw.ctx.timing_read()
+            sw.ctx.timing(False)
+            res["config"]["reduced_outputs"] = {"ms_per_step": dt_r * 1e3, "pair_evals_per_sec": M * n_active / dt_r,
+                                                "sweep_kernel_ms": kms_r / max(kn_r, 1), "steps": 100}
             res["config"]["small_batch"] = small_batch_step(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             if scene is not None:
