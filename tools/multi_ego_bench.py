@@ -28,15 +28,32 @@ from frenetix_occlusion.spawn_locator import SpawnLocator  # noqa: E402
 from frenetix_occlusion.sweep import MetricSweep  # noqa: E402
 
 
-def ego_poses(n):
+def candidate_poses():
+    """the scenario's own planning problem first, then poses along the lanelet centre lines (three per lanelet)"""
     sc0 = SC.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario2_geometry.npz"))
     poses = [sc0.ego_initial.copy()]
     for ll in sc0.lanelets:
         c = ll.center
-        if len(c) >= 4 and len(poses) < n:
-            i = len(c) // 3
-            poses.append(np.array([c[i, 0], c[i, 1], math.atan2(c[i + 1, 1] - c[i, 1], c[i + 1, 0] - c[i, 0]), 6.0]))
-    return poses[:n]
+        if len(c) >= 4:
+            for frac in (0.25, 0.5, 0.75):
+                i = min(int(frac * (len(c) - 1)), len(c) - 2)
+                poses.append(np.array([c[i, 0], c[i, 1], math.atan2(c[i + 1, 1] - c[i, 1], c[i + 1, 0] - c[i, 0]), 6.0]))
+    return poses
+
+
+def ego_poses(n, dev, A, T):
+    """n poses whose surroundings hide something: a candidate is kept if its first planning step yields phantoms (an
+    ego with an empty occluded area would make its share of the batch a no-op)"""
+    keep = []
+    for p in candidate_poses():
+        if len(keep) == n:
+            break
+        e = Ego(len(keep), p, dev, 64, A, T)
+        e.step("reduced")
+        e.stream.synchronize()
+        if int(e.sl.batch.n.item()) > 0 or not keep:
+            keep.append(p)
+    return keep
 
 
 class Ego:
@@ -82,7 +99,7 @@ def main():
     dev = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(dev)
     T = 31
-    mine = [(i, p) for i, p in enumerate(ego_poses(args.egos)) if i % world == rank]
+    mine = [(i, p) for i, p in enumerate(ego_poses(args.egos, dev, args.A, T)) if i % world == rank]
     egos = []
     for i, p in mine:
         same = next((e for e in egos if e.scenario == 2 + i % 2), None)
