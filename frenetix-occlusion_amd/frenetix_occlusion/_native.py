@@ -151,9 +151,10 @@ class Context:
         self.device = int(device)
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.fo_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.fo_destroy(h)
+            h.value = None        # (no module globals here: __del__ may run while the interpreter shuts down)
 
     __del__ = close
 
