@@ -254,9 +254,95 @@ def run_case(name, trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC, dce_inputs=
     print("wrote", path, "M", M, "A", A, "T", T, "max cp", cp.max())
 
 
+class _OracleDCE:
+    """stands in for metrics/dce.py (shapely + commonroad_dc are not installable here): the reference's Metric class gets
+    its 'dce' results from this repository's oracle, so that its OWN threshold logic (metric.py:50-100) and dependency
+    closure (:125-147) can be run unmodified on top of its own CP / HR / TTC / TTCE / WTTC results."""
+    table = {}          # id(trajectory) -> {prediction key: {"dce": float, "time_dce": int}}
+
+    def __init__(self, vehicle_params, agent_manager):
+        pass
+
+    def evaluate(self, trajectory, results):
+        return _OracleDCE.table[id(trajectory)]
+
+
+class _NoBE:
+    def __init__(self, vehicle_params, agent_manager):
+        pass
+
+
+def run_threshold_case(name, trajs, kinds, preds, dt, Metric, configs):
+    """(results, safe) of the reference's Metric.evaluate_metrics for several metric / threshold configurations"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import fo_oracle as O
+    O.build()
+    am = AgentManager(dt)
+    keys = []
+    for i, (kind, pred) in enumerate(zip(kinds, preds)):
+        am.phantom_agents.append(Agent(10000 + i, kind))
+        key = int(str(10000 + i) + "0")
+        am.predictions[key] = pred
+        keys.append(key)
+    vp = VehicleParams()
+    M, A, T = len(trajs), len(keys), len(trajs[0].cartesian.x)
+    Lmax = max(len(p["pos_list"]) for p in preds)
+    codes = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4}
+    traj = {k: np.stack([getattr(t.cartesian, k) for t in trajs]) for k in ("x", "y", "theta", "v", "a")}
+    agents = {
+        "pos": np.stack([np.pad(p["pos_list"], ((0, Lmax - len(p["pos_list"])), (0, 0))) for p in preds]),
+        "yaw": pad([p["orientation_list"] for p in preds], Lmax, 0.0), "v": pad([p["v_list"] for p in preds], Lmax, 0.0),
+        "cov": np.stack([np.pad(p["cov_list"], ((0, Lmax - len(p["cov_list"])), (0, 0), (0, 0))) for p in preds]),
+        "shape": np.array([[p["shape"]["length"], p["shape"]["width"]] for p in preds]),
+        "raw_dims": np.array([RAW_DIMS[k] for k in kinds]), "type": np.array([codes[k.lower()] for k in kinds], dtype=np.int32),
+        "len": np.array([len(p["pos_list"]) for p in preds], dtype=np.int32)}
+    orc = O.sweep(traj, agents, (vp.length, vp.width, vp.wb_rear_axle, vp.mass, vp.a_max), dt)
+    for m, tr in enumerate(trajs):
+        _OracleDCE.table[id(tr)] = {key: {"dce": float(orc["pair_f"][m, j, O.PF["dce"]]),
+                                           "time_dce": int(orc["pair_i"][m, j, O.PI["time_dce"]])} for j, key in enumerate(keys)}
+    out = {"dt": dt, "vehicle": np.array([vp.length, vp.width, vp.wb_rear_axle, vp.mass, vp.a_max]),
+           **{"traj_" + k: v for k, v in traj.items()},
+           "agent_type": np.array(kinds), "agent_len": agents["len"], "agent_pos": agents["pos"], "agent_yaw": agents["yaw"],
+           "agent_v": agents["v"], "agent_cov": agents["cov"], "agent_shape": agents["shape"], "agent_raw_dims": agents["raw_dims"],
+           "n_configs": len(configs)}
+    names = ("harm", "risk", "be", "cp", "ttc", "wttc", "ttce", "dce")
+    # a threshold given as ("q", f) is put at the f-quantile of the batch's own values (finite ones), so that the
+    # configuration has candidates on both sides of it
+    per_traj = {"harm": orc["cost"][:, O.COST["max_obst_harm_with_cp_all"]], "risk": orc["cost"][:, O.COST["max_obst_risk_all"]],
+                "cp": orc["cost"][:, O.COST["max_collision_probability_all"]], "ttc": orc["cost"][:, O.COST["wttc"]],
+                "dce": orc["cost"][:, O.COST["min_dce"]]}
+    for c, (activated, thr) in enumerate(configs):
+        thr = dict(thr)
+        for k, v in list(thr.items()):
+            if isinstance(v, tuple):
+                vals = per_traj[k][np.isfinite(per_traj[k])]
+                thr[k] = float(np.round(np.quantile(vals, v[1]), 4))
+        full = {k: thr.get(k) for k in names}
+        met = Metric({"activated_metrics": list(activated), "metric_thresholds": full}, vp, am)
+        safe = np.zeros(M, dtype=np.uint8)
+        present = set()
+        for m, tr in enumerate(trajs):
+            res, ok = met.evaluate_metrics(tr)
+            safe[m] = 1 if ok else 0
+            present |= set(res)
+        out[f"cfg{c}_activated"] = np.array(list(activated))
+        out[f"cfg{c}_thr"] = np.array([np.nan if full[k] is None else float(full[k]) for k in names])
+        out[f"cfg{c}_evaluated"] = np.array(sorted(present))         # metric names after the dependency closure
+        out[f"cfg{c}_safe"] = safe
+    out["thr_names"] = np.array(names)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "M", M, "A", A, "configs", len(configs), "safe fractions",
+          [float(out[f"cfg{c}_safe"].mean()) for c in range(len(configs))])
+
+
 def main():
     _install_aliases()
     sys.path.insert(0, REF)
+    for modname, cls_name, cls in (("frenetix_occlusion.metrics.dce", "DCE", _OracleDCE), ("frenetix_occlusion.metrics.be", "BE", _NoBE)):
+        mod = types.ModuleType(modname)
+        setattr(mod, cls_name, cls)
+        sys.modules[modname] = mod
     from frenetix_occlusion.metrics.cp import CP
     from frenetix_occlusion.metrics.hr import HR
     from frenetix_occlusion.metrics.ttc import TTC
@@ -374,6 +460,34 @@ def main():
                           "cov_list": np.tile(0.1 * np.eye(2), (T, 1, 1)),
                           "shape": {"length": RAW_DIMS["Car"][0] * 1.2, "width": RAW_DIMS["Car"][1] * 1.3}})
     run_case("angle_bins", trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC)
+
+    # case 7: the safety decision itself -- the reference's Metric.evaluate_metrics (metric.py:35-100) with its own
+    # threshold logic and dependency closure, for several activated-metric lists and threshold sets, on a batch that
+    # has safe and unsafe candidates under each of them.  'dce' results are fed from this repository's oracle
+    # (_OracleDCE above); everything else is the reference's own arithmetic.
+    from frenetix_occlusion.metrics.metric import Metric
+    rng = np.random.default_rng(20240137)
+    trajs = [Traj(*make_traj(rng, 31, dt, psi0=0.2)) for _ in range(40)]
+    mid = np.array([trajs[0].cartesian.x[12], trajs[0].cartesian.y[12]])
+    kinds = ["Pedestrian", "Car", "Bicycle", "Pedestrian", "Truck", "Car"]
+    # agents ahead of the slower candidates and to the side of the lane: part of the batch reaches them, part does not
+    offs = [(6.0, 3.5), (14.0, -6.5), (9.0, -4.5), (3.0, -3.5), (25.0, 8.0), (11.0, 6.0)]
+    preds = [make_prediction(rng, k, 31 if i != 4 else 19, dt, mid, offset=np.array(offs[i]),
+                             heading=[-1.4, 0.2, 1.8, 1.5, 3.3, -2.0][i]) for i, k in enumerate(kinds)]
+    allm = ("hr", "ttc", "ttce", "dce", "wttc", "cp")
+    configs = [
+        (allm, {"harm": 0.1, "risk": 1}),                                  # occlusion.yaml of the reference's example
+        (allm, {"harm": 1, "risk": 1}),                                    # config.yaml defaults: nothing trips
+        (("hr", "ttc"), {"harm": 0.3, "risk": 0.05}),                     # BASELINE configs[0]: closure adds cp, dce
+        (allm, {"cp": ("q", 0.5)}),
+        (allm, {"ttc": ("q", 0.5)}),
+        (allm, {"dce": 1.0}),
+        (("ttc",), {"ttc": ("q", 0.3), "harm": 0.0}),                      # harm threshold without 'hr': not checked
+        (("wttc",), {"wttc": 9.0, "ttce": 9.0}),                           # thresholds the reference never checks
+        (("cp",), {"cp": 0.0001}),                                         # cp threshold needs 'hr' (metric.py:79)
+        (allm, {"harm": ("q", 0.8), "risk": ("q", 0.8), "cp": ("q", 0.8), "ttc": ("q", 0.2), "dce": 0.05}),
+    ]
+    run_threshold_case("thresholds", trajs, kinds, preds, dt, Metric, configs)
 
 
 if __name__ == "__main__":

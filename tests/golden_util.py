@@ -17,3 +17,21 @@ def load_case(name):
               "type": np.array([TYPE_CODES[str(t).lower()] for t in g["agent_type"]], dtype=np.int32),
               "len": g["agent_len"].astype(np.int32)}
     return g, traj, agents, tuple(g["vehicle"]), float(g["dt"])
+
+
+def load_threshold_case():
+    """tests/golden/thresholds.npz: (inputs, [(activated metrics, thresholds dict, evaluated metric names, safe[M])...])
+    produced by the reference's own Metric.evaluate_metrics (gen_golden.py case 7)"""
+    g = dict(np.load(os.path.join(GOLDEN, "thresholds.npz"), allow_pickle=False))
+    traj = {k: g["traj_" + k] for k in ("x", "y", "theta", "v", "a")}
+    agents = {"pos": g["agent_pos"], "yaw": g["agent_yaw"], "v": g["agent_v"], "cov": g["agent_cov"],
+              "shape": g["agent_shape"], "raw_dims": g["agent_raw_dims"],
+              "type": np.array([TYPE_CODES[str(t).lower()] for t in g["agent_type"]], dtype=np.int32),
+              "len": g["agent_len"].astype(np.int32)}
+    names = [str(n) for n in g["thr_names"]]
+    configs = []
+    for c in range(int(g["n_configs"])):
+        thr = {n: (None if np.isnan(v) else float(v)) for n, v in zip(names, g[f"cfg{c}_thr"])}
+        configs.append(([str(m) for m in g[f"cfg{c}_activated"]], thr, sorted(str(m) for m in g[f"cfg{c}_evaluated"]),
+                        g[f"cfg{c}_safe"].astype(bool)))
+    return traj, agents, tuple(g["vehicle"]), float(g["dt"]), configs

@@ -232,3 +232,12 @@ def test_list_views_follow_the_documented_buffer_layout():
     assert float(tv[N.LST["ego_harm"]][k, t, m]) == n + 2 * i
     empty = list_views(np.zeros(0), 0, Tm1, M)
     assert all(v.shape == (0, Tm1, M) for v in empty)
+
+
+def test_dependency_closure_equals_the_references():
+    """which metrics get evaluated for a list of activated ones (metric.py:125-147), as the reference's own class
+    reported them for the configurations of tests/golden/thresholds.npz"""
+    from golden_util import load_threshold_case
+    from frenetix_occlusion.metrics.metric import check_required_metrics
+    for activated, _, evaluated, _ in load_threshold_case()[4]:
+        assert sorted(check_required_metrics(list(activated))) == evaluated, activated

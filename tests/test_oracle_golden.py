@@ -60,3 +60,19 @@ def test_probe_headline_numbers(oracle):
     assert cp.shape == (30,)
     assert abs(cp.max() - float(g["ref_cp"].max())) < TOL
     assert int(np.argmax(cp)) == int(np.argmax(g["ref_cp"][0, 0]))
+
+
+def test_safety_decision_matches_the_references_metric_class(oracle):
+    """Metric.evaluate_metrics of the reference itself (metric.py:35-100: threshold logic; :125-147: which metrics get
+    evaluated) decided `safe` for ten metric / threshold configurations -- thresholds without their metric, thresholds
+    the reference never checks (wttc, ttce), the cp threshold that needs 'hr'.  Only its 'dce' inputs came from this
+    oracle (GEOS is not installable here)."""
+    from golden_util import load_threshold_case
+    traj, agents, veh, dt, configs = load_threshold_case()
+    mixed = 0
+    for activated, thr, evaluated, safe_ref in configs:
+        t = {k: v for k, v in thr.items() if k in ("harm", "risk", "be", "cp", "ttc", "dce") and v is not None}
+        out = oracle.sweep(traj, agents, veh, dt, metrics=tuple(activated), thr=t)
+        assert np.array_equal(out["safe"].astype(bool), safe_ref), (activated, thr)
+        mixed += 0 < safe_ref.mean() < 1
+    assert mixed >= 6

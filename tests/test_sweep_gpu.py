@@ -569,6 +569,18 @@ def test_correlated_and_diagonal_agent_sets_alternate_on_one_context(torch_cuda,
     assert np.abs(outs[0][1][f] - fresh["lists"][f]).max() > 1e-3        # and the correlation does change the numbers
 
 
+def test_safety_decision_matches_the_references_metric_class(torch_cuda):
+    """the `safe` flags of the sweep against what the reference's own Metric.evaluate_metrics decided (tests/golden/
+    thresholds.npz; see tests/test_oracle_golden.py), in full and in reduced output mode"""
+    from golden_util import load_threshold_case
+    traj, agents, veh, dt, configs = load_threshold_case()
+    for activated, thr, _, safe_ref in configs:
+        t = {k: v for k, v in thr.items() if k in ("harm", "risk", "be", "cp", "ttc", "dce") and v is not None}
+        for mode in ("full", "reduced"):
+            got = _hip_sweep(torch_cuda, traj, agents, veh, dt, metrics=tuple(activated), thr=t, mode=mode)
+            assert np.array_equal(got["safe"].astype(bool), safe_ref), (activated, thr, mode)
+
+
 def test_library_loaded_before_torch_still_gets_the_device():
     """__graft_entry__.build() loads libfo_hip.so before anything imports torch; torch ships its own HIP runtime, and
     with two of them in one process fo_create used to fail (-3).  _native.load() therefore imports torch first."""
