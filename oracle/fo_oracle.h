@@ -6,11 +6,14 @@
  * Everything is float64 like the reference (numpy).  Citations are relative to /root/reference/.
  *
  * Pinning status:
- *   CP, harm, HR, TTC, TTCE, WTTC  -- pinned against golden vectors produced by the reference's own code
+ *   CP (diagonal and full covariances), harm incl. the impact-angle bins on their boundaries, HR, TTC, TTCE, WTTC,
+ *   the safety decision (Metric thresholds + dependency closure), pedestrian predictions
+ *                                  -- pinned against golden vectors produced by the reference's own code
  *                                     (tests/golden/gen_golden.py).
- *   DCE, thresholds (Metric), sensor model, spawn, pedestrian prediction -- PARITY UNPINNED: the reference
- *                                     delegates to shapely/GEOS + commonroad, absent here; pinned only by
- *                                     analytic known-answer tests (tests/test_oracle_kat.py).
+ *   DCE, sensor model, spawn       -- PARITY UNPINNED: the reference delegates to shapely/GEOS + commonroad, absent
+ *                                     here; pinned by analytic known-answer tests (tests/test_oracle_kat.py,
+ *                                     test_scene_kat.py) and to sympy's exact rational geometry (test_dce_sympy.py,
+ *                                     test_scene_sympy.py).
  */
 #ifndef FO_ORACLE_H
 #define FO_ORACLE_H

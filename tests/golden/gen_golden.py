@@ -254,6 +254,69 @@ def run_case(name, trajs, kinds, preds, dt, CP, HR, TTC, TTCE, WTTC, dce_inputs=
     print("wrote", path, "M", M, "A", A, "T", T, "max cp", cp.max())
 
 
+def _install_agent_stubs():
+    """enough of commonroad / shapely / the reference's own frenetix- and route-planner wrappers for agent.py to import;
+    none of it computes anything the pedestrian prediction uses when the spawn point brings its orientation"""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class Rectangle:
+        def __init__(self, length, width, center=None, orientation=0.0):
+            self.length, self.width, self.center, self.orientation = length, width, center, orientation
+
+    class State:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class Dummy:
+        def __init__(self, *a, **kw):
+            pass
+
+    mod("commonroad.geometry", shape=mod("commonroad.geometry.shape", Rectangle=Rectangle))
+    mod("commonroad.scenario.state", InitialState=State, CustomState=State)
+    sys.modules["commonroad.scenario.obstacle"].DynamicObstacle = Dummy
+    mod("commonroad.prediction", prediction=mod("commonroad.prediction.prediction", TrajectoryPrediction=Dummy))
+    mod("commonroad.scenario.trajectory", Trajectory=Dummy)
+    mod("shapely", geometry=mod("shapely.geometry", Polygon=Dummy, Point=Dummy, MultiPolygon=Dummy, LineString=Dummy),
+        affinity=mod("shapely.affinity", rotate=Dummy, translate=Dummy))
+    mod("frenetix_occlusion.route_planner", FORoutePlanner=Dummy)
+    mod("frenetix_occlusion.utils.frenetix_handler", FrenetixHandler=Dummy)
+
+
+def run_pedestrian_predictions(name, dt):
+    """predictions of the reference's own OAPPedestrianAgent (agent.py:429-536) for spawn points that bring their
+    orientation (interface.py:192-198): rounding of the velocity components (Q12), horizon -> sample count, covariance
+    growth (agent.py:260-280), shape inflation"""
+    _install_agent_stubs()
+    from frenetix_occlusion.agent import OAPPedestrianAgent
+    rng = np.random.default_rng(20240138)
+    n = 24
+    cfg = {"prediction": {"size_factor_length_s": 1.2, "size_factor_width_s": 1.3, "variance_factor": 1.05}}
+    pos0 = rng.uniform(-40.0, 40.0, size=(n, 2))
+    yaw = np.concatenate(([0.0, np.pi / 2, np.pi, -np.pi / 2, np.pi / 3, 2.0943951023931953], rng.uniform(-np.pi, 2 * np.pi, n - 6)))
+    speed = np.concatenate(([1.4, 1.4, 1.4, 1.4, 1.001, 0.9995], rng.uniform(0.3, 3.0, n - 6)))
+    horizon = np.where(np.arange(n) % 5 == 4, 2.05, 3.0)
+    out = {"dt": dt, "pos0": pos0, "yaw": yaw, "speed": speed, "horizon": horizon, "raw_length": 0.3, "raw_width": 0.5,
+           **{"cfg_" + k: v for k, v in cfg["prediction"].items()}}
+    Tmax = int(3.0 / dt) + 1
+    P, V, Y, Cv = (np.full((n, Tmax) + sh, np.nan) for sh in ((2,), (), (), (2, 2)))
+    L, shape = np.zeros(n, dtype=np.int64), np.zeros((n, 2))
+    for i in range(n):
+        a = OAPPedestrianAgent(pos0[i].copy(), float(speed[i]), "Pedestrian", {"agent_id": 10000 + i, "length": 0.3, "width": 0.5},
+                               None, cfg, dt=dt, horizon=float(horizon[i]), ref_path=None, mode="ref_path", orientation=float(yaw[i]))
+        p = a.predictions[0]
+        L[i] = len(p["pos_list"])
+        P[i, :L[i]], V[i, :L[i]], Y[i, :L[i]], Cv[i, :L[i]] = p["pos_list"], p["v_list"], p["orientation_list"], p["cov_list"]
+        shape[i] = (p["shape"]["length"], p["shape"]["width"])
+    out.update({"ref_pos": P, "ref_v": V, "ref_yaw": Y, "ref_cov": Cv, "ref_len": L, "ref_shape": shape})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "n", n, "lengths", sorted(set(L.tolist())))
+
+
 class _OracleDCE:
     """stands in for metrics/dce.py (shapely + commonroad_dc are not installable here): the reference's Metric class gets
     its 'dce' results from this repository's oracle, so that its OWN threshold logic (metric.py:50-100) and dependency
@@ -488,6 +551,9 @@ def main():
         (allm, {"harm": ("q", 0.8), "risk": ("q", 0.8), "cp": ("q", 0.8), "ttc": ("q", 0.2), "dce": 0.05}),
     ]
     run_threshold_case("thresholds", trajs, kinds, preds, dt, Metric, configs)
+
+    # case 8: pedestrian predictions of the reference's own agent class
+    run_pedestrian_predictions("ped_predictions", dt)
 
 
 if __name__ == "__main__":

@@ -76,3 +76,40 @@ def test_safety_decision_matches_the_references_metric_class(oracle):
         assert np.array_equal(out["safe"].astype(bool), safe_ref), (activated, thr)
         mixed += 0 < safe_ref.mean() < 1
     assert mixed >= 6
+
+
+def test_pedestrian_predictions_match_the_references_agent_class(oracle):
+    """OAPPedestrianAgent of the reference (agent.py:429-536, imported unmodified under stub modules) produced
+    tests/golden/ped_predictions.npz for 24 spawn points that bring their orientation: velocity components rounded to
+    1e-3 (Q12), int(horizon/dt)+1 samples (21 for a horizon of 2.05 s), covariance growth, shape inflation.  Pinned here:
+    the oracle's fo_oracle_cv_predictions (what the GPU spawn kernel is compared with bit for bit) and the host's
+    FOAgentManager.add_agent path."""
+    import os
+    from types import SimpleNamespace
+    from golden_util import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "ped_predictions.npz")))
+    dt, n = float(g["dt"]), len(g["speed"])
+    for T in sorted(set(g["ref_len"].tolist())):
+        sel = np.nonzero(g["ref_len"] == T)[0]
+        pos, yaw, v, cov = oracle.cv_predictions(g["pos0"][sel], g["yaw"][sel], g["speed"][sel], int(T), dt, 0.1,
+                                                 float(g["cfg_variance_factor"]))
+        assert np.array_equal(pos, g["ref_pos"][sel, :T]) and np.array_equal(yaw, g["ref_yaw"][sel, :T])
+        assert np.array_equal(v, g["ref_v"][sel, :T])
+        np.testing.assert_allclose(cov, g["ref_cov"][sel, :T], rtol=1e-15, atol=0)
+    # the host path of manually added agents
+    from frenetix_occlusion.agent import FOAgentManager
+    cfg = {"pedestrian": {"default_velocity": 1.4, "length": float(g["raw_length"]), "width": float(g["raw_width"])},
+           "prediction": {"size_factor_length_s": float(g["cfg_size_factor_length_s"]),
+                          "size_factor_width_s": float(g["cfg_size_factor_width_s"]),
+                          "size_factor_length_l": 1.4, "size_factor_width_l": 2.5,
+                          "variance_factor": float(g["cfg_variance_factor"])}}
+    am = FOAgentManager(SimpleNamespace(obstacles=[]), np.array([[0.0, 0.0], [10.0, 0.0]]), cfg, 0, dt=dt, device="cpu")
+    for i in range(n):
+        a = am.add_agent(g["pos0"][i], velocity=float(g["speed"][i]), agent_type="Pedestrian", timestep=0,
+                         horizon=float(g["horizon"][i]), orientation=float(g["yaw"][i]))
+        p, L = a.predictions[0], int(g["ref_len"][i])
+        assert len(p["pos_list"]) == L
+        assert np.array_equal(p["pos_list"], g["ref_pos"][i, :L]) and np.array_equal(p["v_list"], g["ref_v"][i, :L])
+        assert np.array_equal(p["orientation_list"], g["ref_yaw"][i, :L])
+        assert np.array_equal(p["cov_list"], g["ref_cov"][i, :L])
+        assert (p["shape"]["length"], p["shape"]["width"]) == tuple(g["ref_shape"][i])
