@@ -317,6 +317,56 @@ def run_pedestrian_predictions(name, dt):
     print("wrote", name, "n", n, "lengths", sorted(set(L.tolist())))
 
 
+def run_obstacle_states(name):
+    """FOObstacles of the reference (utils/fo_obstacle.py:14-116 + helper_functions.calc_corner_points :99-112, imported
+    unmodified; shapely's Point / Polygon are inert stubs, they only wrap what this fixture records): which state an
+    obstacle has at a global time step -- initial state at its own first step, state_list[rel - 1] afterwards, nothing
+    before it appears and after its trajectory ends, static obstacles always their initial state -- and its corner
+    points.  The obstacle shape's vertices follow commonroad's Rectangle (the closed ring (-l/2,-w/2), (-l/2,w/2),
+    (l/2,w/2), (l/2,-w/2), (-l/2,-w/2)): an assumption of this fixture, commonroad is not installable here."""
+    _install_agent_stubs()
+    mp = types.ModuleType("shapely.geometry.multipolygon")
+    mp.MultiPolygon = lambda polys: list(polys)
+    sys.modules["shapely.geometry.multipolygon"] = mp
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    rng = np.random.default_rng(20240139)
+    NS = types.SimpleNamespace
+
+    def ring(l, w):
+        return np.array([[-l / 2, -w / 2], [-l / 2, w / 2], [l / 2, w / 2], [l / 2, -w / 2], [-l / 2, -w / 2]])
+
+    spec = [("STATIC", 0, 0), ("DYNAMIC", 0, 10), ("DYNAMIC", 3, 6), ("STATIC", 2, 0), ("DYNAMIC", 5, 20), ("DYNAMIC", 1, 1)]
+    obs, rec = [], []
+    for i, (role, t0, n) in enumerate(spec):
+        l, w = float(rng.uniform(1.5, 9.0)), float(rng.uniform(0.6, 2.6))
+        init = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-4, 7), rng.uniform(0, 12)])
+        states = np.column_stack((rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), rng.uniform(-4, 7, n), rng.uniform(0, 12, n)))
+        o = NS(obstacle_id=100 + i, obstacle_role=NS(name=role), obstacle_shape=NS(vertices=ring(l, w), length=l, width=w),
+               initial_state=NS(time_step=t0, position=init[:2].copy(), orientation=float(init[2])),
+               prediction=NS(trajectory=NS(state_list=[NS(position=st[:2].copy(), orientation=float(st[2])) for st in states])))
+        obs.append(o)
+        rec.append((role, t0, l, w, init, states))
+    fo = FOObstacles(obs)
+    steps = 16
+    present = np.zeros((len(obs), steps), dtype=np.uint8)
+    pos, yaw, corn = np.full((len(obs), steps, 2), np.nan), np.full((len(obs), steps), np.nan), np.full((len(obs), steps, 4, 2), np.nan)
+    for t in range(steps):
+        fo.update(t)
+        for i, o in enumerate(fo):
+            if o.current_pos is not None:
+                present[i, t] = 1
+                pos[i, t], yaw[i, t], corn[i, t] = o.current_pos, o.current_orientation, o.current_corner_points
+    nmax = max(len(r[5]) for r in rec)
+    st = np.full((len(obs), nmax, 4), np.nan)
+    for i, r in enumerate(rec):
+        st[i, :len(r[5])] = r[5]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), role=np.array([r[0] for r in rec]), t0=np.array([r[1] for r in rec]),
+                        length=np.array([r[2] for r in rec]), width=np.array([r[3] for r in rec]),
+                        initial=np.stack([r[4] for r in rec]), states=st, n_states=np.array([len(r[5]) for r in rec]),
+                        ref_present=present, ref_pos=pos, ref_yaw=yaw, ref_corners=corn)
+    print("wrote", name, "present per obstacle", present.sum(axis=1).tolist())
+
+
 class _OracleDCE:
     """stands in for metrics/dce.py (shapely + commonroad_dc are not installable here): the reference's Metric class gets
     its 'dce' results from this repository's oracle, so that its OWN threshold logic (metric.py:50-100) and dependency
@@ -554,6 +604,9 @@ def main():
 
     # case 8: pedestrian predictions of the reference's own agent class
     run_pedestrian_predictions("ped_predictions", dt)
+
+    # case 9: obstacle state cache of the reference
+    run_obstacle_states("obstacle_states")
 
 
 if __name__ == "__main__":

@@ -113,3 +113,28 @@ def test_pedestrian_predictions_match_the_references_agent_class(oracle):
         assert np.array_equal(p["orientation_list"], g["ref_yaw"][i, :L])
         assert np.array_equal(p["cov_list"], g["ref_cov"][i, :L])
         assert (p["shape"]["length"], p["shape"]["width"]) == tuple(g["ref_shape"][i])
+
+
+def test_obstacle_state_cache_matches_the_references():
+    """FOObstacles of the reference (utils/fo_obstacle.py + helper_functions.calc_corner_points, imported unmodified
+    under inert shapely stubs) recorded presence, pose and corner points of six obstacles over sixteen time steps:
+    tests/golden/obstacle_states.npz.  Pinned: this package's FOObstacles / Obstacle.pose_at / Obstacle.corners, i.e.
+    what is uploaded to the ray-cast kernels."""
+    import os
+    from golden_util import GOLDEN
+    from frenetix_occlusion.scenario import Obstacle
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    g = dict(np.load(os.path.join(GOLDEN, "obstacle_states.npz")))
+    obs = [Obstacle(100 + i, str(g["role"][i]).lower(), "car", float(g["length"][i]), float(g["width"][i]), int(g["t0"][i]),
+                    g["initial"][i], g["states"][i, :int(g["n_states"][i])]) for i in range(len(g["t0"]))]
+    fo = FOObstacles(obs)
+    for t in range(g["ref_present"].shape[1]):
+        fo.update(t)
+        corn, cen, flags = fo.arrays()
+        for i, o in enumerate(fo):
+            assert (o.current_pos is not None) == bool(g["ref_present"][i, t]), (i, t)
+            assert bool(flags[i] & 1) == bool(g["ref_present"][i, t])
+            if o.current_pos is not None:
+                assert np.array_equal(o.current_pos, g["ref_pos"][i, t]) and o.current_orientation == g["ref_yaw"][i, t]
+                np.testing.assert_allclose(o.current_corner_points, g["ref_corners"][i, t], rtol=0, atol=1e-13)
+                np.testing.assert_allclose(corn[i], g["ref_corners"][i, t], rtol=0, atol=1e-13)
