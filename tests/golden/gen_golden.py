@@ -367,6 +367,73 @@ def run_obstacle_states(name):
     print("wrote", name, "present per obstacle", present.sum(axis=1).tolist())
 
 
+def run_route_enumeration(name):
+    """FORoutePlanner._find_all_routes of the reference (route_planner.py:54-90, imported unmodified; the three
+    commonroad_route_planner imports at its top are inert stubs): candidate lanelet-id routes from every start lanelet,
+    depth 2, over successors and same-direction neighbours that have successors -- on the topology of the three example
+    scenarios (read from their XML by this repository's loader; only ids and adjacency are stored) and on two random
+    networks."""
+    for modname, names in (("commonroad_route_planner", ()), ("commonroad_route_planner.route_planner", ("Route",)),
+                           ("commonroad_route_planner.utility", ()), ("commonroad_route_planner.utility.route", ("lanelet_orientation_at_position",)),
+                           ("commonroad_route_planner.route", ("RouteType",))):
+        m = types.ModuleType(modname)
+        for n in names:
+            setattr(m, n, object)
+        sys.modules[modname] = m
+    sys.modules.pop("frenetix_occlusion.route_planner", None)      # (a stub of it may be installed by the agent case)
+    from frenetix_occlusion.route_planner import FORoutePlanner
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(OUT)), "frenetix-occlusion_amd"))
+    nets = []
+    # the example scenarios' topology through this repository's loader (its own package shadows the reference's name:
+    # load it from its file)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fo_amd_scenario", os.path.join(os.path.dirname(os.path.dirname(OUT)),
+                                                  "frenetix-occlusion_amd", "frenetix_occlusion", "scenario.py"))
+    SC = importlib.util.module_from_spec(spec)
+    sys.modules["fo_amd_scenario"] = SC
+    spec.loader.exec_module(SC)
+    for k in (1, 2, 3):
+        sc = SC.load_commonroad_xml(os.path.join(REF, "example_scenarios", f"scenario{k}.xml"))
+        nets.append([(ll.lanelet_id, list(ll.successors), ll.adj_left, bool(ll.adj_left_same_direction), ll.adj_right,
+                      bool(ll.adj_right_same_direction)) for ll in sc.lanelets])
+    rng = np.random.default_rng(20240140)
+    for n in (30, 45):
+        ids = list(range(100, 100 + n))
+        net = []
+        for i in ids:
+            succ = [int(x) for x in rng.choice(ids, size=int(rng.integers(0, 4)), replace=False) if x != i]
+            al = int(rng.choice(ids)) if rng.random() < 0.4 else None
+            ar = int(rng.choice(ids)) if rng.random() < 0.4 else None
+            net.append((i, succ, al, bool(rng.random() < 0.6), ar, bool(rng.random() < 0.6)))
+        nets.append(net)
+    NS = types.SimpleNamespace
+    out = {"n_nets": len(nets)}
+    for q, net in enumerate(nets):
+        by = {i: NS(lanelet_id=i, successor=list(su), adj_left=al, adj_left_same_direction=als, adj_right=ar,
+                    adj_right_same_direction=ars) for i, su, al, als, ar, ars in net}
+        rp = FORoutePlanner(None, NS(find_lanelet_by_id=lambda i, by=by: by[i]), None, False)
+        flat, off = [], [0]
+        starts = []
+        for i in by:
+            for route in rp._find_all_routes(i, max_depth=2):
+                flat.extend(route)
+                off.append(len(flat))
+                starts.append(i)
+        succ_flat, succ_off = [], [0]
+        for _, su, *_ in net:
+            succ_flat.extend(su)
+            succ_off.append(len(succ_flat))
+        out.update({f"net{q}_id": np.array([t[0] for t in net]), f"net{q}_succ": np.array(succ_flat, dtype=np.int64),
+                    f"net{q}_succ_off": np.array(succ_off), f"net{q}_adj_left": np.array([-1 if t[2] is None else t[2] for t in net]),
+                    f"net{q}_adj_left_same": np.array([t[3] for t in net]),
+                    f"net{q}_adj_right": np.array([-1 if t[4] is None else t[4] for t in net]),
+                    f"net{q}_adj_right_same": np.array([t[5] for t in net]),
+                    f"net{q}_route_start": np.array(starts), f"net{q}_route_flat": np.array(flat, dtype=np.int64),
+                    f"net{q}_route_off": np.array(off)})
+        print("net", q, "lanelets", len(net), "routes", len(starts))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 class _OracleDCE:
     """stands in for metrics/dce.py (shapely + commonroad_dc are not installable here): the reference's Metric class gets
     its 'dce' results from this repository's oracle, so that its OWN threshold logic (metric.py:50-100) and dependency
@@ -607,6 +674,9 @@ def main():
 
     # case 9: obstacle state cache of the reference
     run_obstacle_states("obstacle_states")
+
+    # case 10: route enumeration of the reference's route planner
+    run_route_enumeration("routes")
 
 
 if __name__ == "__main__":

@@ -138,3 +138,34 @@ def test_obstacle_state_cache_matches_the_references():
                 assert np.array_equal(o.current_pos, g["ref_pos"][i, t]) and o.current_orientation == g["ref_yaw"][i, t]
                 np.testing.assert_allclose(o.current_corner_points, g["ref_corners"][i, t], rtol=0, atol=1e-13)
                 np.testing.assert_allclose(corn[i], g["ref_corners"][i, t], rtol=0, atol=1e-13)
+
+
+def test_route_enumeration_matches_the_references_route_planner():
+    """FORoutePlanner._find_all_routes of the reference (route_planner.py:54-90, imported unmodified) listed the candidate
+    routes from every start lanelet of the three example scenarios' networks and of two random ones:
+    tests/golden/routes.npz.  Pinned: scenario.enumerate_routes (same routes, same order), which feeds the route table
+    of the phantom-vehicle predictions."""
+    import os
+    from golden_util import GOLDEN
+    from frenetix_occlusion.scenario import Lanelet, enumerate_routes
+    g = dict(np.load(os.path.join(GOLDEN, "routes.npz")))
+    z = np.zeros((2, 2))
+    total = 0
+    for q in range(int(g["n_nets"])):
+        ids, so, sf = g[f"net{q}_id"], g[f"net{q}_succ_off"], g[f"net{q}_succ"]
+        lls = []
+        for i, lid in enumerate(ids):
+            al, ar = int(g[f"net{q}_adj_left"][i]), int(g[f"net{q}_adj_right"][i])
+            lls.append(Lanelet(int(lid), z, z, successors=[int(s) for s in sf[so[i]:so[i + 1]]],
+                               adj_left=None if al < 0 else al, adj_left_same_direction=bool(g[f"net{q}_adj_left_same"][i]),
+                               adj_right=None if ar < 0 else ar, adj_right_same_direction=bool(g[f"net{q}_adj_right_same"][i])))
+        mine = enumerate_routes(lls, max_depth=2)
+        ref = {}
+        off, flat = g[f"net{q}_route_off"], g[f"net{q}_route_flat"]
+        for r, start in enumerate(g[f"net{q}_route_start"]):
+            ref.setdefault(int(start), []).append([int(x) for x in flat[off[r]:off[r + 1]]])
+        assert set(mine) == set(ref)
+        for lid in ref:
+            assert mine[lid] == ref[lid], (q, lid)
+            total += len(ref[lid])
+    assert total > 300
