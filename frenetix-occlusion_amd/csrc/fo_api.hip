@@ -10,6 +10,11 @@ extern "C" {
 
 int fo_abi_version(void) { return FO_ABI_VERSION; }
 
+#ifndef FO_BUILD_ID
+#define FO_BUILD_ID "unstamped"
+#endif
+const char *fo_build_id(void) { return FO_BUILD_ID; }
+
 void fo_destroy(fo_ctx *ctx);
 
 int fo_create(fo_ctx **out, int device) {

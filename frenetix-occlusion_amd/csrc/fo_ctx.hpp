@@ -17,6 +17,7 @@ struct fo_ctx {
   uint32_t mask = 0;   // after dependency closure
   double dt = 0.1;
   bool configured = false;
+  int list_format = FO_LISTS_F64;   // element type of the per-timestep lists fo_sweep_run writes
 
   // ---- agents (prepared form, HBM)
   int A = 0, Ta = 0;

@@ -325,7 +325,26 @@ __device__ __forceinline__ void fo_store_lists(double *lists, size_t n, size_t i
   }
 }
 
+// The same three blocks with float32 elements (fo_sweep_set_list_format(FO_LISTS_F32): the storage SURVEY 8d prices,
+// 648 B per pair): cp float [n], (ego harm, obstacle harm) float2 [n], (ego risk, obstacle risk) float2 [n] -- a lane
+// writes 4 + 8 + 8 bytes, each store one contiguous run of the wave (256 B / 512 B / 512 B).
+typedef float fo_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fo_store_lists_f32(float *lists, size_t n, size_t i, float cp, float eh, float oh, float er,
+                                                   float orr) {
+  __builtin_nontemporal_store(cp, lists + i);
+  __builtin_nontemporal_store(fo_f2{eh, oh}, (fo_f2 *)(lists + n) + i);
+  __builtin_nontemporal_store(fo_f2{er, orr}, (fo_f2 *)(lists + 3 * n) + i);
+}
+// 1 / (1 + exp(nz)) in float32 on the hardware transcendentals (v_exp_f32, v_rcp_f32: 8 cycles each against ~70 for the
+// float64 table route): for the float32 list entries only -- every maximum, risk and cost entry stays float64.  |error|
+// < 4e-7 absolute (argument rounding 6e-8 |nz| times the slope <= 1/4, one ulp each for exp2 and rcp).
+__device__ __forceinline__ float fo_logistic_neg_f32(double nz) {
+  const float e = __builtin_amdgcn_exp2f((float)nz * 1.44269504f);   // +inf for large nz -> rcp gives 0; 0 for very negative nz -> 1
+  return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 // ------------------------------------------------------------------------------------------------ the sweep
+enum { LST_NONE = 0, LST_F64 = 1, LST_F32 = 2 };   // per-timestep list output of a sweep instantiation
 struct SweepArgs {
   int M, Mp, T, A, Ta, n_tiles, nt8, apw;  // apw = agents per wave
   const double *traj;    // [n_tiles][T][NEF][64]
@@ -450,7 +469,7 @@ __device__ __forceinline__ double fo_corr_term_plain(const double *__restrict__ 
   return acc * asr;
 }
 
-template <bool PAIR, bool LISTS>
+template <bool PAIR, int LISTS>
 __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const SweepArgs a) {
   __shared__ double red[(WAVES - 1) * NPS * TILE];
   __shared__ double2 erf_tab[ERF_N];
@@ -495,7 +514,10 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
       }
       if (LISTS && valid) {
         const size_t ls = (size_t)A * Tm1 * M;
-        for (int t = 0; t < Tm1; ++t) fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
+        for (int t = 0; t < Tm1; ++t) {
+          if (LISTS == LST_F32) fo_store_lists_f32((float *)a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
+          else fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
+        }
       }
       continue;
     }
@@ -611,7 +633,10 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
           max_oh = fmax(max_oh, oh);
         }
         if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
-        if (LISTS && valid)
+        if (LISTS == LST_F32 && valid)   // (this kernel converts at the store; the queue kernel has a float32 harm path)
+          fo_store_lists_f32((float *)a.lists, (size_t)A * Tm1 * M, ((size_t)k * Tm1 + t) * M + m, (float)cp, (float)eh,
+                             (float)oh, (float)er, (float)orr);
+        else if (LISTS && valid)
           fo_store_lists(a.lists, (size_t)A * Tm1 * M, ((size_t)k * Tm1 + t) * M + m, cp, eh, oh, er, orr);
       }
       ex = ex1; ey = ey1; ec = ec1; es = es1; eth = eth1; ev = ev1;
@@ -846,7 +871,7 @@ __device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(uns
 // CORR: the agent set holds a covariance with correlation (status[1] of fo_prep_agents_kernel): in-gate samples then
 // add the correlation integral to their box probabilities (fo_corr_corners).  The kernel below carries both bodies and picks one at
 // its start, so that the usual diagonal case keeps the registers and the code it had.
-template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT, bool CORR, int TC_>
+template <bool PAIR, int LISTS, bool ALLM, bool SPLIT, bool CORR, int TC_>
 __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const double2 *__restrict__ erf_tab,
                                                     const double *__restrict__ exp_tab, const double *__restrict__ zc_tab,
                                                     double *__restrict__ hk_all, double *__restrict__ cpbuf_all,
@@ -907,7 +932,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       }
       if (LISTS) {
         const size_t ls = (size_t)A * Tm1 * M;
-        for (int t = 0; t < Tm1; ++t) fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
+        for (int t = 0; t < Tm1; ++t) {
+          if (LISTS == LST_F32) fo_store_lists_f32((float *)a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
+          else fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
+        }
       }
       continue;
     }
@@ -1282,20 +1310,26 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               zon = zc_tab[(cls_o >> sh) & 3u];
             }
             double eh = NAN, oh = NAN, er = NAN, orr = NAN, cp = 0.0;
+            float ehf = NAN, ohf = NAN;   // LST_F32: the harm entries of the lists
             const bool hv = geo && t < Lh;  // wave-uniform
             if (hv && (FO_X & 8)) {
               eh = dv; oh = ze + zo;
             } else if (hv) {
               const bool model = LR4S || prot == 0;   // wave-uniform; otherwise harm is 1 on both sides
               const double nze = LR4S ? fma(ke_, dv, ze) : fma(ke_, dv, ce_), nzo = LR4S ? fma(ko_, dv, zo) : fma(ko_, dv, co_);
-              if (LISTS || !model) {
+              if (LISTS == LST_F64 || !model) {
                 eh = model ? fo_logistic_neg<false>(exp_tab, nze) : 1.0;
                 oh = model ? fo_logistic_neg<false>(exp_tab, nzo) : 1.0;
                 max_eh = fo_vmax(max_eh, eh);
                 max_oh = fo_vmax(max_oh, oh);
+                if (LISTS == LST_F32) { ehf = 1.0f; ohf = 1.0f; }
               } else {
                 nze_min = fmin(nze_min, nze);
                 nzo_min = fmin(nzo_min, nzo);
+                if (LISTS == LST_F32) {   // float32 list entries: hardware exp / rcp (the maxima above stay float64)
+                  ehf = fo_logistic_neg_f32(nze);
+                  ohf = fo_logistic_neg_f32(nzo);
+                }
               }
             }
             // No lane of the wave is inside the gate at this sample (97 % of the samples of the bench workload): every
@@ -1303,9 +1337,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             // seeded by the wave's first sample, which always takes the long way.
             if (!hv || t == gfirst || ((wgate >> row) & 1u)) {
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
-              if (!LISTS && hv && (LR4S || prot == 0)) {   // the harm values themselves, where a risk may need them
+              if (LISTS != LST_F64 && hv && (LR4S || prot == 0)) {   // the harm values themselves, where a risk may need them
                 eh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ke_, dv, ze) : fma(ke_, dv, ce_));
                 oh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ko_, dv, zo) : fma(ko_, dv, co_));
+                if (LISTS == LST_F32) { ehf = (float)eh; ohf = (float)oh; }   // so that risk = harm x cp holds in the lists too
               }
               if (hv) {
                 er = eh * cp;
@@ -1318,8 +1353,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               er = 0.0;
               orr = 0.0;
             }
-            if (LISTS) {
+            if (LISTS == LST_F64) {
               fo_store_lists(a.lists, ls, li, cp, eh, oh, er, orr);
+              li += M;
+            } else if (LISTS == LST_F32) {
+              fo_store_lists_f32((float *)a.lists, ls, li, (float)cp, ehf, ohf, (float)er, (float)orr);
               li += M;
             }
           }
@@ -1327,7 +1365,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         if (lr4s) pass2(std::true_type{}); else pass2(std::false_type{});
       }
     }
-    if (!LISTS && nze_min < INFINITY) {   // (a wave whose samples carry no harm keeps -inf, as the lists path does)
+    if (LISTS != LST_F64 && nze_min < INFINITY) {   // (a wave whose samples carry no harm keeps -inf, as the lists path does)
       max_eh = fo_vmax(max_eh, fo_logistic_neg<false>(exp_tab, nze_min));
       max_oh = fo_vmax(max_oh, fo_logistic_neg<false>(exp_tab, nzo_min));
     }
@@ -1444,12 +1482,16 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
 #ifndef FO_WIDE_LISTS
 #define FO_WIDE_LISTS 0   // 1: tuning builds -- the full-output instantiation in the four-wave shape as well
 #endif
-template <bool LISTS, bool SPLIT>
+#ifndef FO_WIDE_F32
+#define FO_WIDE_F32 0     // 1: the float32-list instantiation in the four-wave shape
+#endif
+template <int LISTS, bool SPLIT>
 struct SweepShape {
-  static constexpr bool wide = (!LISTS || FO_WIDE_LISTS) && !SPLIT && FO_MINW == 3 && FO_TC == 8;   // tuning builds override both macros
+  static constexpr bool wide = (LISTS == LST_NONE || FO_WIDE_LISTS || (LISTS == LST_F32 && FO_WIDE_F32)) && !SPLIT &&
+                               FO_MINW == 3 && FO_TC == 8;   // tuning builds override both macros
   static constexpr int tc = wide ? 4 : FO_TC, minw = wide ? 4 : FO_MINW;
 };
-template <bool PAIR, bool LISTS, bool ALLM, bool SPLIT = false>
+template <bool PAIR, int LISTS, bool ALLM, bool SPLIT = false>
 __global__ __launch_bounds__(TILE *QWAVES)
 __attribute__((amdgpu_waves_per_eu(SweepShape<LISTS, SPLIT>::minw, SweepShape<LISTS, SPLIT>::minw)))
 void fo_sweep_queue_kernel(const SweepArgs a) {
@@ -1667,6 +1709,15 @@ uint32_t required_metrics(uint32_t m) {  // metric.py:125-147
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
+// one instantiation of the queue kernel per output mode: cost vectors only / + pair scalars / + float64 or float32 lists
+template <bool ALLM, bool SPLIT>
+void launch_queue(int lst, bool pair, dim3 g, dim3 b, hipStream_t s, const SweepArgs &a) {
+  if (lst == LST_F64) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F64, ALLM, SPLIT>), g, b, 0, s, a);
+  else if (lst == LST_F32) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F32, ALLM, SPLIT>), g, b, 0, s, a);
+  else if (pair) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
+}
+
 // agents per wave: enough workgroups to fill 256 CUs many times over (the tail of the last round of workgroups costs
 // less the shorter they are), but no more partial rows than needed.  Measured at steady clocks on 10 000 x 256:
 // 1 -> 0.764 ms, 2 -> 0.748, 3 -> 0.756, 4 -> 0.765, 8 -> 0.79 (bench.py re-checks this per batch shape at set-up).
@@ -1741,6 +1792,13 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
   return FO_OK;
 }
 
+int fo_sweep_set_list_format(fo_ctx *ctx, int format) {
+  if (!ctx) return FO_E_ARG;
+  if (format != FO_LISTS_F64 && format != FO_LISTS_F32) return fo_fail(ctx, FO_E_ARG, "fo_sweep_set_list_format: unknown format %d", format);
+  ctx->list_format = format;
+  return FO_OK;
+}
+
 int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const double *d_yaw, const double *d_v,
                         const double *d_cov, const double *d_shape, const double *d_raw_dims, const int32_t *d_type,
                         const int32_t *d_len, void *stream) {
@@ -1788,7 +1846,8 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   hipStream_t s = (hipStream_t)stream;
   const int A = ctx->A, Ta = ctx->Ta;
   if (d_lists && A > 0 && T > 1 && !(ctx->mask & (FO_M_CP | FO_M_HR)))  // nothing will write them: all-ones = NaN
-    FO_HIP_TRY(ctx, hipMemsetAsync(d_lists, 0xFF, sizeof(double) * FO_NL * (size_t)A * (T - 1) * M, s));
+    FO_HIP_TRY(ctx, hipMemsetAsync(d_lists, 0xFF, (ctx->list_format == FO_LISTS_F32 ? sizeof(float) : sizeof(double)) *
+                                                     FO_NL * (size_t)A * (T - 1) * M, s));
   const int Mp = round_up(M, TILE);
   const int n_tiles = Mp / TILE;
   const char *force_generic = getenv("FO_SWEEP_GENERIC");  // debug / A-B aid
@@ -1840,30 +1899,19 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     const bool timed = ctx->timing && ctx->n_timed < fo_ctx::kMaxTimed && (ctx->n_launch++ % ctx->timing_stride) == 0;
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[ctx->n_timed], s));
     const dim3 g(grid), b(TILE * wpb);
+    const int lst = !d_lists ? LST_NONE : ctx->list_format == FO_LISTS_F32 ? LST_F32 : LST_F64;
     if (use_queue) {
       const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
       const bool allm = (a.mask & all5) == all5 && a.ablate == 0;
-      if (allm && split) {
-        if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, true, true>), g, b, 0, s, a);
-        else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, true, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, true, true>), g, b, 0, s, a);
-      } else if (split) {
-        if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, false, true>), g, b, 0, s, a);
-        else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, false, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, false, true>), g, b, 0, s, a);
-      } else if (allm) {
-        if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, true>), g, b, 0, s, a);
-        else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, true>), g, b, 0, s, a);
-      } else {
-        if (d_lists) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, true, false>), g, b, 0, s, a);
-        else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, false, false>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, false, false>), g, b, 0, s, a);
-      }
+      if (allm && split) launch_queue<true, true>(lst, d_pair_f != nullptr, g, b, s, a);
+      else if (split) launch_queue<false, true>(lst, d_pair_f != nullptr, g, b, s, a);
+      else if (allm) launch_queue<true, false>(lst, d_pair_f != nullptr, g, b, s, a);
+      else launch_queue<false, false>(lst, d_pair_f != nullptr, g, b, s, a);
     } else {
-      if (d_lists) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, true>), g, b, 0, s, a);
-      else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, false>), g, b, 0, s, a);
-      else hipLaunchKernelGGL((fo_sweep_generic_kernel<false, false>), g, b, 0, s, a);
+      if (lst == LST_F64) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_F64>), g, b, 0, s, a);
+      else if (lst == LST_F32) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_F32>), g, b, 0, s, a);
+      else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_NONE>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((fo_sweep_generic_kernel<false, LST_NONE>), g, b, 0, s, a);
     }
     FO_HIP_TRY(ctx, hipGetLastError());
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop[ctx->n_timed++], s));

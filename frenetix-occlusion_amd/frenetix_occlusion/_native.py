@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("FO_HIP_LIB") or os.path.join(os.path.dirname(_HERE), 
 
 FO_OK, FO_E_ARG, FO_E_UNSUPPORTED_COV, FO_E_HIP, FO_E_NOMEM, FO_E_STATE = 0, -1, -2, -3, -4, -5
 NPF, NPI, NL, NC = 12, 4, 5, 16
+LISTS_F64, LISTS_F32 = 0, 1
 
 PF = {"dce": 0, "ttc": 1, "ttce": 2, "max_ego_risk": 3, "max_obst_risk": 4, "max_obst_harm_with_cp": 5,
       "max_ego_harm": 6, "max_obst_harm": 7, "max_collision_probability": 8, "be_decel": 9, "be_btn": 10}
@@ -25,8 +26,8 @@ TYPE_CODES = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4, "pr
 
 # every symbol include/fo_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "fo_abi_version", "fo_create", "fo_destroy", "fo_last_error",
-    "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
+    "fo_abi_version", "fo_build_id", "fo_create", "fo_destroy", "fo_last_error",
+    "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_list_format", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read", "fo_sweep_timing_read_each",
     "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
     "fo_scene_candidate_count",
@@ -73,6 +74,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
     lib.fo_abi_version.restype = C.c_int
+    lib.fo_build_id.restype = C.c_char_p
     lib.fo_create.argtypes = [C.POINTER(vp), C.c_int]
     lib.fo_destroy.argtypes = [vp]
     lib.fo_destroy.restype = None
@@ -81,6 +83,7 @@ def load():
     lib.fo_sweep_configure.argtypes = [vp, C.POINTER(Vehicle), C.POINTER(HarmCoeff), C.POINTER(Thresholds),
                                        C.c_uint32, C.c_double]
     lib.fo_sweep_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.fo_sweep_set_list_format.argtypes = [vp, C.c_int]
     lib.fo_sweep_set_agents.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, vp]
     lib.fo_sweep_run.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, vp]
     lib.fo_sweep_check.argtypes = [vp, vp]
@@ -105,10 +108,15 @@ def load():
     lib.fo_scene_candidate_count.argtypes = [vp, ip, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("fo_destroy", "fo_last_error"):
+        if name not in ("fo_destroy", "fo_last_error", "fo_build_id"):
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def build_id():
+    """hash of the sources the loaded library was built from (fo_build_id)"""
+    return load().fo_build_id().decode()
 
 
 def current_stream(device_index=None):

@@ -82,7 +82,7 @@ class FOInterface:
                                           fo_obstacles=self.fo_obstacles, visualization=None, debug=self.debug,
                                           dt=self.dt)
         self.metrics = Metric(self.config["metrics"], self.vehicle_params, self.agent_manager, dt=self.dt,
-                              device=self.device.index, ctx=self.ctx)
+                              device=self.device.index, ctx=self.ctx, list_storage=str(acc.get("list_storage", "f64")))
 
     # ---------------------------------------------------------------------------------------- reference API
     def set_coordinate_system(self, cosy_cl):

@@ -97,7 +97,7 @@ class BatchAssessment:
     def _to_host(self):
         if self._host is None:
             r = self.result
-            big = r.lists_raw is not None and r.lists_raw.numel() * 8 > self.HOST_CACHE_BYTES
+            big = r.lists_raw is not None and r.lists_raw.numel() * r.lists_raw.element_size() > self.HOST_CACHE_BYTES
             self._host = {"cost": r.cost.cpu().numpy(), "safe": r.safe.cpu().numpy(),
                           "pair_f": None if (r.pair_f is None or big) else r.pair_f.cpu().numpy(),
                           "pair_i": None if (r.pair_i is None or big) else r.pair_i.cpu().numpy(),
@@ -180,8 +180,10 @@ class BatchAssessment:
 
 
 class Metric:
-    def __init__(self, config, vehicle_params, agent_manager, dt=None, harm_coeff=None, device=0, ctx=None):
+    def __init__(self, config, vehicle_params, agent_manager, dt=None, harm_coeff=None, device=0, ctx=None,
+                 list_storage="f64"):
         self.config = config
+        self.list_storage = list_storage     # accelerator.list_storage: element type of the per-timestep lists
         self.metric_thresholds = config["metric_thresholds"]
         self.vehicle_params = vehicle_params
         self.agent_manager = agent_manager
@@ -219,7 +221,7 @@ class Metric:
             return None                                          # metric.py:44-45: ({}, True) for every trajectory
         arr = trajectories_to_arrays(trajectories)
         self._upload_agents()
-        res = self.sweep.run(arr["x"], arr["y"], arr["theta"], arr["v"], arr.get("a"), mode=mode)
+        res = self.sweep.run(arr["x"], arr["y"], arr["theta"], arr["v"], arr.get("a"), mode=mode, lists=self.list_storage)
         _ = self.agent_manager.predictions if mode == "full" else None
         slots = getattr(self.agent_manager, "prediction_slots", None) if mode == "full" else None
         ba = BatchAssessment(res, slots, self.metrics, mode)

@@ -35,7 +35,7 @@ class SweepResult:
     safe: torch.Tensor                    # [M] uint8
     pair_f: Optional[torch.Tensor] = None  # [12, A, M] float64
     pair_i: Optional[torch.Tensor] = None  # [4, A, M] int32
-    lists_raw: Optional[torch.Tensor] = None  # [5 A (T-1) M] float64, layout of include/fo_hip.h
+    lists_raw: Optional[torch.Tensor] = None  # [5 A (T-1) M] float64 (or float32, lists="f32"), layout of include/fo_hip.h
     lists_shape: tuple = (0, 0, 0)         # (A, T-1, M)
 
     def list_views(self):
@@ -127,12 +127,12 @@ class MetricSweep:
         if check:
             self.ctx.call("fo_sweep_check", self._stream())
 
-    def _check_out(self, out, M, T, A, mode):
+    def _check_out(self, out, M, T, A, mode, ldt=torch.float64):
         """a reused SweepResult must match the batch: the kernels write with the strides of the *current* M/A/T"""
         want = {"cost": ((M, N.NC), torch.float64), "safe": ((M,), torch.uint8),
                 "pair_f": ((N.NPF, A, M), torch.float64) if mode in ("pair", "full") else None,
                 "pair_i": ((N.NPI, A, M), torch.int32) if mode in ("pair", "full") else None,
-                "lists_raw": ((N.NL * A * max(T - 1, 0) * M,), torch.float64) if mode == "full" else None}
+                "lists_raw": ((N.NL * A * max(T - 1, 0) * M,), ldt) if mode == "full" else None}
         for name, w in want.items():
             t = getattr(out, name)
             if w is None:
@@ -143,8 +143,16 @@ class MetricSweep:
                 got = None if t is None else (tuple(t.shape), t.dtype, str(t.device))
                 raise ValueError(f"out.{name}: need contiguous {w[0]} {w[1]} on {self.device}, got {got}")
 
-    def run(self, x, y, theta, v, a=None, mode="reduced", out: Optional[SweepResult] = None) -> SweepResult:
-        """x,y,theta,v[,a]: [M,T].  mode: 'reduced' (cost+safe), 'pair' (+ per-pair scalars), 'full' (+ lists)."""
+    def run(self, x, y, theta, v, a=None, mode="reduced", out: Optional[SweepResult] = None, lists="f64") -> SweepResult:
+        """x,y,theta,v[,a]: [M,T].  mode: 'reduced' (cost+safe), 'pair' (+ per-pair scalars), 'full' (+ lists).
+        lists: element type of the per-timestep lists of mode 'full' -- 'f64' (the reference's numpy dtype) or 'f32'
+        (half the bytes; cost / safe / pair outputs are identical, see fo_sweep_set_list_format in include/fo_hip.h)."""
+        if lists not in ("f64", "f32"):
+            raise ValueError(f"unknown list format '{lists}'")
+        ldt = torch.float32 if lists == "f32" else torch.float64
+        if lists != getattr(self, "_list_format", "f64"):
+            self.ctx.call("fo_sweep_set_list_format", N.LISTS_F32 if lists == "f32" else N.LISTS_F64)
+            self._list_format = lists
         ins = [x, y, theta, v] + ([a] if a is not None else [])
         if all(isinstance(q, np.ndarray) and q.ndim == 2 and q.shape == ins[0].shape for q in ins) and ins[0].size:
             up = self._upload_packed(ins)
@@ -158,7 +166,7 @@ class MetricSweep:
         if mode not in ("reduced", "pair", "full"):
             raise ValueError(f"unknown output mode '{mode}'")
         if out is not None:
-            self._check_out(out, M, T, A, mode)
+            self._check_out(out, M, T, A, mode, ldt)
         else:
             out = SweepResult(cost=torch.empty((M, N.NC), dtype=torch.float64, device=self.device),
                               safe=torch.empty((M,), dtype=torch.uint8, device=self.device))
@@ -166,7 +174,7 @@ class MetricSweep:
                 out.pair_f = torch.empty((N.NPF, A, M), dtype=torch.float64, device=self.device)
                 out.pair_i = torch.empty((N.NPI, A, M), dtype=torch.int32, device=self.device)
             if mode == "full":
-                out.lists_raw = torch.empty((N.NL * A * max(T - 1, 0) * M,), dtype=torch.float64, device=self.device)
+                out.lists_raw = torch.empty((N.NL * A * max(T - 1, 0) * M,), dtype=ldt, device=self.device)
         p = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
         self._last_inputs = (x, y, theta, v, a)
         self.ctx.call("fo_sweep_run", M, T, p(x), p(y), p(theta), p(v), p(a), p(out.cost), p(out.safe),

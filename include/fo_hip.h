@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 4
+#define FO_ABI_VERSION 5
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -76,6 +76,9 @@ int fo_create(fo_ctx **out, int device);            /* replaces: FOInterface.__i
 void fo_destroy(fo_ctx *ctx);
 const char *fo_last_error(const fo_ctx *ctx);       /* replaces: Python exceptions (SURVEY 8b "error conventions") */
 int fo_abi_version(void);
+/* SHA-256 (hex) of the sources and flags this library was built from (__graft_entry__.source_id()): build(), smoke()
+ * and bench.py compare it with the tree they run in, so a stale prebuilt library cannot pass for the current one */
+const char *fo_build_id(void);
 
 /* ---- metric sweep: replaces M calls of FOInterface.trajectory_safety_assessment (interface.py:216-219 ->
  *      metrics/metric.py:35-100 -> dce.py, ttc.py, ttce.py, wttc.py, cp.py, hr.py) ------------------------ */
@@ -84,6 +87,15 @@ int fo_sweep_configure(fo_ctx *ctx, const fo_vehicle_t *veh, const fo_harm_coeff
 
 /* pre-size the context's HBM workspace so that fo_sweep_run never allocates (needed before hipGraph capture) */
 int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta);
+
+/* Element type of the per-timestep lists (d_lists of fo_sweep_run).  FO_LISTS_F64 (default): float64, the reference's
+ * own numpy dtype (hr.py:87-98) -- what the parity tests hold to 1e-9.  FO_LISTS_F32: the same three blocks with float32
+ * elements (cp float [n], harm float2 [n], risk float2 [n]; n = A (T-1) M), the storage SURVEY 8d prices at 648 B per
+ * pair.  Collision probabilities and risks are the float64 results rounded at the store; harm entries away from the 5 m
+ * gate are evaluated in float32 (hardware exp / rcp, |error| < 4e-7 -- north_star's tolerance is 1e-5).  cost, safe,
+ * pair_f and pair_i are float64 / exact and bit-identical in both formats. */
+enum { FO_LISTS_F64 = 0, FO_LISTS_F32 = 1 };
+int fo_sweep_set_list_format(fo_ctx *ctx, int format);
 
 /* replaces: agent_manager.predictions (agent.py:179-183) as read by every metric */
 int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const double *d_yaw, const double *d_v,

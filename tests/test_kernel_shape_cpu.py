@@ -23,10 +23,11 @@ def test_sweep_kernel_register_and_lds_budgets(tmp_path):
     for m in re.finditer(r"\.group_segment_fixed_size: (\d+).*?\.name:\s+(\S+).*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count: (\d+)",
                          txt, re.S):
         if "fo_sweep_queue_kernel" in m.group(2):
-            flags = re.search(r"queue_kernelI(Lb\dELb\dELb\dELb\dE)", m.group(2)).group(1)
-            pair, lists, allm, split = [c == "1" for c in re.findall(r"Lb(\d)E", flags)]
+            f = re.search(r"queue_kernelILb(\d)ELi(\d)ELb(\d)ELb(\d)E", m.group(2))
+            pair, lists, allm, split = f.group(1) == "1", int(f.group(2)), f.group(3) == "1", f.group(4) == "1"
             seen[(pair, lists, allm, split)] = (int(m.group(1)), int(m.group(3)))
-    assert len(seen) == 12                                   # (full, pair, reduced) x (all metrics, subset) x (split, not)
+    # (float64 lists, float32 lists, pair scalars, reduced) x (all metrics, subset) x (split, not)
+    assert len(seen) == 16
     for (pair, lists, allm, split), (lds, vgpr) in seen.items():
         if lists or split:
             assert vgpr <= 168 and 3 * lds <= 160 * 1024, (pair, lists, allm, split, lds, vgpr)

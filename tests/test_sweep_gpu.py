@@ -29,12 +29,12 @@ def sweep_kernel_mode(request, monkeypatch):
     return request.param
 
 
-def _hip_sweep(torch, traj, agents, veh, dt, metrics=None, thr=None, mode="full"):
+def _hip_sweep(torch, traj, agents, veh, dt, metrics=None, thr=None, mode="full", lists="f64"):
     from frenetix_occlusion.sweep import DEFAULT_METRICS, MetricSweep
     sw = MetricSweep(veh, dt, metrics=metrics or DEFAULT_METRICS, thresholds=thr)
     sw.set_agents(agents["pos"], agents["yaw"], agents["v"], agents["cov"], agents["shape"], agents["raw_dims"],
                   agents["type"], agents["len"])
-    out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj.get("a"), mode=mode)
+    out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj.get("a"), mode=mode, lists=lists)
     torch.cuda.synchronize()
     res = {"cost": out.cost.cpu().numpy(), "safe": out.safe.cpu().numpy()}
     if out.pair_f is not None:
@@ -184,6 +184,66 @@ def test_output_modes_agree(torch_cuda):
     assert np.array_equal(full["cost"], pair["cost"]) and np.array_equal(full["cost"], red["cost"])
     assert np.array_equal(full["pair_f"], pair["pair_f"], equal_nan=True)
     assert np.array_equal(full["safe"], red["safe"])
+
+
+# float32 list storage (fo_sweep_set_list_format(FO_LISTS_F32), SURVEY 8d's 648 B per pair): the lists are held to
+# LIST32_ATOL against the float64 oracle and the reference's goldens; everything else must not move by a bit
+LIST32_ATOL = 1e-6
+
+
+def _compare_f32_lists(ref_lists, got32, got64):
+    assert got32["lists"].dtype == np.float32
+    for k in ("cost", "safe", "pair_i"):
+        assert np.array_equal(got32[k], got64[k]), k
+    assert np.array_equal(got32["pair_f"], got64["pair_f"], equal_nan=True)
+    assert np.array_equal(np.isnan(ref_lists), np.isnan(got32["lists"]))
+    fin = np.isfinite(ref_lists)
+    worst = float(np.abs(ref_lists[fin] - got32["lists"][fin].astype(np.float64)).max()) if fin.any() else 0.0
+    assert worst < LIST32_ATOL, worst
+    # consistent among themselves: risk = harm x cp holds in the stored lists up to float32 rounding
+    cp, eh, oh, er, orr = (got32["lists"][:, :, i, :].astype(np.float64) for i in range(5))
+    f = np.isfinite(er)
+    assert np.abs(er[f] - (eh * cp)[f]).max() < 3e-7 and np.abs(orr[f] - (oh * cp)[f]).max() < 3e-7
+    return worst
+
+
+@pytest.mark.parametrize("M,A,cfg", [(300, 16, 1), (2000, 32, 2), (130, 5, 3), (70, 9, 8)])
+def test_float32_lists_match_oracle(torch_cuda, oracle, M, A, cfg):
+    from frenetix_occlusion import synthetic as S
+    traj, agents = S.make_batch(M, A, config_id=cfg)
+    if cfg == 8:
+        agents["len"] = np.array([31, 1, 2, 30, 17, 31, 5, 29, 0], dtype=np.int32)   # ragged + an inactive slot
+    thr = {"harm": 0.3, "risk": 0.2, "ttc": 1.0, "dce": 0.05, "cp": 0.8}
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, nthreads=8)
+    g64 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr)
+    g32 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, lists="f32")
+    _compare_f32_lists(ref["lists"], g32, g64)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_float32_lists_match_reference_goldens(torch_cuda, name):
+    """the float32 lists directly against what the reference's own CP / HR code produced"""
+    g, traj, agents, veh, dt = load_case(name)
+    g64 = _hip_sweep(torch_cuda, traj, agents, veh, dt)
+    g32 = _hip_sweep(torch_cuda, traj, agents, veh, dt, lists="f32")
+    ref = np.stack([g["ref_" + k] for k in ("cp", "ego_harm", "obst_harm", "ego_risk", "obst_risk")], axis=2)
+    _compare_f32_lists(ref, g32, g64)
+
+
+def test_float32_lists_generic_kernel_and_metric_subset(torch_cuda, oracle, monkeypatch):
+    from frenetix_occlusion import synthetic as S
+    traj, agents = S.make_batch(200, 12, config_id=11)
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
+    g64 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
+    g32 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32")
+    _compare_f32_lists(ref["lists"], g32, g64)
+    monkeypatch.setenv("FO_SWEEP_GENERIC", "1")
+    g32 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32")
+    _compare_f32_lists(ref["lists"], g32, g64)
+    # a metric set that writes no lists at all: NaN-filled in either format
+    monkeypatch.delenv("FO_SWEEP_GENERIC")
+    g32 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("dce",), lists="f32")
+    assert g32["lists"].dtype == np.float32 and np.isnan(g32["lists"]).all()
 
 
 def test_metric_subset_config1(torch_cuda, oracle):
