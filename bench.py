@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the Frenetix-Occlusion per-planning-step hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode full|pair|reduced] [--M 10000] [--A 256]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode full|pair|reduced] [--lists f32|f64] [--M 10000] [--A 256]
 
 One "step" = one planning step of BASELINE.json configs[2] with every input already resident in HBM:
     visibility ray fan (720 rays @ 0.5 deg, r = 50 m) over the synthetic urban lanelet net (~9.4e3 boundary edges,
@@ -9,24 +9,34 @@ One "step" = one planning step of BASELINE.json configs[2] with every input alre
     occluded cells + their predictions  ->  agent table  ->  trajectory x agent metric sweep (DCE / TTC / TTCE / WTTC /
     CP / harm / risk over T = 31) for 10 000 candidate trajectories  ->  threshold reduction
     (+ one RCCL all-gather of the per-trajectory cost vectors when N > 1).
-N > 1: every rank holds its own 10 000-trajectory shard (weak scaling); the scene stage and the agents are replicated
-(SURVEY 8e), cost vectors are all-gathered.  `--scene synthetic` replaces the scene stage by a fixed synthetic agent
-set (the sweep-only workload of earlier profiles).
+
+N > 1 (BASELINE configs[3]): ONE batch of --M trajectories is block-partitioned over the ranks (`--scaling strong`, the
+default; M/N per rank, scene stage and agents replicated, `cost [M][16]` all-gathered) -- `--scaling weak` gives every
+rank its own --M trajectories instead.  `bench.py --gpus N` without a launcher starts its own N worker processes (one
+per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) before anything touches a GPU and
+exits with their status; under `torch.distributed.run` it uses the environment it is given.
+
+Output lists: `--lists f32` (default) stores the five per-timestep lists as float32 -- the storage SURVEY 8d prices
+(648 B per pair); `--lists f64` stores them as float64 like the reference's numpy arrays.  All arithmetic that reaches
+a cost vector, a flag or a per-pair scalar is float64 in both.
 
 Set-up (untimed, before the W warm-up steps): the real step is timed for four agents-per-wave settings of the sweep
 kernel and the best one kept -- which also brings the GPU to its sustained clocks, so that the timed K steps do not
 depend on W (`--no-autotune` skips it).  `--scene scenario1 --M 2000 --A 32` runs BASELINE configs[1] instead.
 
 Prints ONE JSON line on rank 0.  `value` = trajectory x agent metric evaluations per second over all ranks.
-With the default workload on one GPU the line also carries `config.reduced_outputs` (the same step with the cost vectors and
-flags only, no per-pair data) and `config.small_batch`: the same planning step at BASELINE
-configs[1] (scenario1 geometry, 2 000 candidates x 32 phantom slots), i.e. ms per planning step at the reference's own
-problem size (a few hundred steps of ~0.1 ms after the timed region).
+`roofline` follows SURVEY 8d: algorithmic bytes = 620 B per trajectory + 636 B per agent + 648 B per pair (full
+outputs, fp32 storage) over the HIP-event duration of the sweep kernel; `frac_stored_bytes` is the same on the bytes
+this build really moves (float64 inputs and pair scalars).  `parity` compares the GPU buffers of the last timed step
+with the CPU oracle on EVERY pair of the batch; `cpu_baseline` holds the three CPU figures of SURVEY 8d (NumPy in the
+reference's loop structure on one thread, the C port on one thread and on all cores).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,19 +45,33 @@ sys.path.insert(0, os.path.join(ROOT, "frenetix-occlusion_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+THR = {"harm": 0.1, "risk": 1}   # configurations/simulation/occlusion.yaml:20-28 of the reference's example
 
 
-def algorithmic_bytes(M, A, T, mode):
-    """float64 storage.  Inputs read once, outputs written once (DESIGN.md 'Algorithmic bytes')."""
-    traj_in = M * T * 8 * 8              # tile table the sweep kernel reads: x, y, cos, sin, theta, v, v cos, v sin
-    agent_in = A * (T * 12 * 8 + 8 * 8)  # agent table rows (96 B) + per-agent constants
-    out = 0
+def bytes_8d(M, A, T, mode):
+    """SURVEY 8d, fp32 storage: trajectory 5 arrays x T x 4 B, agent prediction (x, y, psi, v, var) x T x 4 B + 16 B,
+    outputs 64 B per trajectory (reduced) / 48 B per pair (pair scalars) / 48 + 5 (T-1) 4 B per pair (full)."""
+    b = M * 5 * T * 4 + A * (5 * T * 4 + 16)
+    if mode == "reduced":
+        b += M * 64
     if mode in ("pair", "full"):
-        out += M * A * (12 * 8 + 4 * 4)
+        b += M * A * 48
     if mode == "full":
-        out += M * A * 5 * (T - 1) * 8
-    # per-chunk partial maxima the sweep kernel writes for the reduce kernel are workspace, not counted
-    return traj_in + agent_in + out
+        b += M * A * 5 * (T - 1) * 4
+    return b
+
+
+def bytes_stored(M, A, T, mode, lists):
+    """what this build moves: the float64 tile table the sweep kernel reads (x, y, cos, sin, theta, v, v cos, v sin per
+    sample), the prepared agent rows (96 B) + constants, float64 pair scalars + int32 indices, lists in `lists`"""
+    b = M * T * 8 * 8 + A * (T * 12 * 8 + 8 * 8)
+    if mode == "reduced":
+        b += M * 16 * 8
+    if mode in ("pair", "full"):
+        b += M * A * (12 * 8 + 4 * 4)
+    if mode == "full":
+        b += M * A * 5 * (T - 1) * (4 if lists == "f32" else 8)
+    return b
 
 
 def usable_cores():
@@ -62,33 +86,199 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(S, traj, agents, thr, threads):
-    """oracle/fo_oracle.c (a C port of the reference's per-trajectory loops) on the host cores: bounded sample"""
-    from oracle import fo_oracle as O  # checker / baseline only
-    O.build()
-    A = agents["pos"].shape[0]
-    probe = {k: v[: 4 * threads] for k, v in traj.items()}
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 without a launcher
+def launch_workers(n, argv):
+    """`bench.py --gpus N` called directly: start N copies of this script, one per GPU, and exit with their status.
+    The parent never imports torch and never touches a GPU (a process that has must not be replaced or forked)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc, deadline = 0, time.time() + float(os.environ.get("FO_BENCH_LAUNCH_TIMEOUT", "1500"))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            c = p.poll()
+            if c is not None:
+                alive.remove(p)
+                rc = rc or c
+        if (rc or time.time() > deadline) and alive:      # one worker failed (or the job hangs): end exactly our children
+            for p in alive:
+                p.terminate()
+            for p in alive:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def launcher_selftest(args):
+    """CPU check of the N > 1 plumbing (tests/test_bench_launcher_cpu.py): the workers rendezvous over gloo on
+    127.0.0.1, take their block of ONE --M batch (strong scaling), all-gather a cost matrix whose rows are a function of
+    the global trajectory index, and rank 0 prints a bench-shaped JSON line.  No GPU, no kernel, no oracle."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from frenetix_occlusion.distributed import shard_bounds
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    M, NC = args.M, 16
+    lo, hi = shard_bounds(M, world, rank)
+    per = -(-M // world)
+    mine = torch.full((per, NC), float("nan"), dtype=torch.float64)
+    rows = torch.arange(lo, hi, dtype=torch.float64)
+    mine[: hi - lo] = rows[:, None] * 16.0 + torch.arange(NC, dtype=torch.float64)[None, :]
+    gathered = torch.empty((world * per, NC), dtype=torch.float64)
+    dist.barrier()
     t0 = time.perf_counter()
-    O.sweep(probe, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, nthreads=threads)
-    rate = 4 * threads * A / max(time.perf_counter() - t0, 1e-6)           # first guess (includes page faults)
-    Ms = int(min(len(traj["x"]), max(8 * threads, rate * 6.0 / A)))         # ~6 s per pass, 3 passes
-    sub = {k: v[:Ms] for k, v in traj.items()}
-    best, bufs = float("inf"), None
-    for _ in range(3):  # first pass page-faults the output buffers; they are reused afterwards
+    for _ in range(args.steps):
+        dist.all_gather_into_tensor(gathered, mine)
+    dist.barrier()
+    el = time.perf_counter() - t0
+    # rank r's block sits at rows [r per, r per + its length): put the blocks back to back
+    parts = [gathered[r * per: r * per + (shard_bounds(M, world, r)[1] - shard_bounds(M, world, r)[0])] for r in range(world)]
+    full = torch.cat(parts)
+    want = torch.arange(M, dtype=torch.float64)[:, None] * 16.0 + torch.arange(NC, dtype=torch.float64)[None, :]
+    ok = full.shape == want.shape and bool((full == want).all())
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher_selftest", "n_gpus": world, "ranks_seen": dist.get_world_size(),
+                          "scaling": args.scaling or "strong", "M_total": M, "M_per_rank": per, "steps": args.steps,
+                          "gather_ok": bool(flag.item() == 1.0), "ms_per_step": el / max(args.steps, 1) * 1e3}), flush=True)
+    dist.destroy_process_group()
+    return 0 if flag.item() == 1.0 else 1
+
+
+# ------------------------------------------------------------------------------------------------ CPU figures + parity
+def cpu_and_parity(S, N, traj, agents, out, lists_fmt, want_parity=True):
+    """Runs the oracle (oracle/fo_oracle.c, a C port of the reference's per-trajectory loops) over the WHOLE batch in
+    chunks on every usable core -- timing only the oracle calls (CPU baseline B2) and comparing every chunk with the
+    GPU buffers of the last timed step (parity) -- then the same port on one thread (B1) and the NumPy restatement in
+    the reference's loop structure on one thread (B0) on bounded samples."""
+    import numpy as np
+    import torch
+    from oracle import fo_compare as CMP   # checker / baseline only
+    from oracle import fo_numpy_ref as R
+    from oracle import fo_oracle as O
+    O.build()
+    threads = usable_cores()
+    M, A = traj["x"].shape[0], agents["pos"].shape[0]
+    A_act = int((agents["len"] > 0).sum())
+    full = out is not None and out.lists_raw is not None and want_parity
+    views = out.list_views() if full else None
+    chunk = 500
+    t_or, n_or, par, bufs = 0.0, 0, None, None
+    for lo in range(0, M, chunk):
+        hi = min(lo + chunk, M)
+        sub = {k: v[lo:hi] for k, v in traj.items()}
+        same = bufs is not None and bufs["cost"].shape[0] == hi - lo
         t0 = time.perf_counter()
-        bufs = O.sweep(sub, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, want_lists=True, nthreads=threads, out=bufs)
-        best = min(best, time.perf_counter() - t0)
-    return {"value": Ms * A / best, "unit": "pair-evals/s", "cores": threads, "kind": "port",
-            "sample": f"first {Ms} trajectories x {A} agents of the same batch (same phantom set the GPU step produced), "
-                      f"full outputs, oracle/fo_oracle.c, OpenMP over trajectories on {threads} threads, best of 3 "
-                      f"passes ({best:.2f} s each)"}
+        ref = O.sweep(sub, agents, S.VEHICLE_BMW320I, 0.1, thr=THR, want_lists=True, nthreads=threads, out=bufs if same else None)
+        dt = time.perf_counter() - t0
+        if same or M <= chunk:          # the first pass over fresh buffers is page faults, not arithmetic
+            t_or, n_or = t_or + dt, n_or + (hi - lo)
+        bufs = ref
+        if full:
+            got = {"cost": out.cost[lo:hi].cpu().numpy(), "safe": out.safe[lo:hi].cpu().numpy(),
+                   "pair_f": out.pair_f[:, :, lo:hi].permute(2, 1, 0).cpu().numpy(),
+                   "pair_i": out.pair_i[:, :, lo:hi].permute(2, 1, 0).cpu().numpy(),
+                   "lists": torch.stack([v[:, :, lo:hi] for v in views]).permute(3, 1, 0, 2).cpu().numpy()}
+            par = CMP.merge(par, CMP.compare(ref, got))
+    if n_or == 0:
+        t_or, n_or = dt, hi - lo
+    b2 = n_or * A_act / t_or
+    # B1: the same C port, one thread, ~5 s
+    m1 = int(min(M, max(8, b2 / threads * 5.0 / max(A_act, 1))))
+    sub = {k: v[:m1] for k, v in traj.items()}
+    O.sweep(sub, agents, S.VEHICLE_BMW320I, 0.1, thr=THR, want_lists=True, nthreads=1)
+    t0 = time.perf_counter()
+    O.sweep(sub, agents, S.VEHICLE_BMW320I, 0.1, thr=THR, want_lists=True, nthreads=1)
+    b1 = m1 * A_act / (time.perf_counter() - t0)
+    # B0: NumPy in the reference's loop structure, one thread, trajectories spread over the batch x the first 32 active
+    # agents, sized for ~10 s by a short probe
+    act = np.flatnonzero(agents["len"] > 0)[:32]
+    ag0 = {k: v[act] for k, v in agents.items()}
+    pick = lambda n: {k: v[np.linspace(0, M - 1, n).astype(np.int64)] for k, v in traj.items()}
+    t0 = time.perf_counter()
+    R.sweep(pick(2), ag0, S.VEHICLE_BMW320I, 0.1, thr=THR)
+    probe = 2 * len(act) / max(time.perf_counter() - t0, 1e-6)
+    m0 = int(min(M, 200, max(4, probe * 10.0 / max(len(act), 1))))
+    t0 = time.perf_counter()
+    R.sweep(pick(m0), ag0, S.VEHICLE_BMW320I, 0.1, thr=THR)
+    b0 = m0 * len(act) / (time.perf_counter() - t0)
+    cpu = {"value": b2, "unit": "pair-evals/s", "cores": threads, "kind": "port",
+           "sample": f"{n_or} trajectories x {A_act} active agents of the same batch (the phantom set the GPU step produced), "
+                     f"full outputs, oracle/fo_oracle.c, OpenMP over trajectories on {threads} threads, {t_or:.2f} s",
+           "b0_numpy_1t": {"value": b0, "sample": f"{m0} trajectories spread over the batch x {len(act)} agents, "
+                                                  "oracle/fo_numpy_ref.py (the reference's loop structure: per trajectory "
+                                                  "-> per metric -> per agent -> per timestep), one thread; extrapolates "
+                                                  "linearly in the pair count"},
+           "b1_c_1t": {"value": b1, "sample": f"first {m1} trajectories x {A_act} agents, oracle/fo_oracle.c, one thread"},
+           "b2_c_allcores": {"value": b2, "cores": threads}, "cpu_model": cpu_model(),
+           "reference_python_indicative": "~1e3 pair-evals/s per core (SURVEY section 6; the reference itself cannot run "
+                                          "here: shapely / commonroad / frenetix are not installable)"}
+    parity = None
+    if par is not None:
+        ltol = 1e-6 if lists_fmt == "f32" else 1e-9
+        parity = dict(par, checked_against="oracle/fo_oracle.c on every pair of the batch (full outputs)", tol_float=1e-9,
+                      tol_lists=ltol, lists=lists_fmt,
+                      ok=bool(par["float_max_abs_err"] <= 1e-9 and par["list_max_abs_err"] <= ltol and
+                              par["int_mismatches"] == 0 and par["pattern_mismatches"] == 0))
+    return cpu, parity
+
+
+def committed_traffic(N, lists_fmt):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary -- WRITE_SIZE + 2 x FETCH_SIZE (gfx950
+    correction), KB -> bytes -- but only when that profile was taken with THIS library: profiles/<tag>_build.json holds
+    the fo_build_id() of the run; anything else prints null."""
+    import csv
+    tag = os.environ.get("FO_PROFILE_TAG", "r03_final")
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{tag}_build.json")) as f:
+            meta = json.load(f)
+        if meta.get("build_id") != N.build_id() or meta.get("lists", "f64") != lists_fmt:
+            return None, tag
+        want = "fo_sweep_queue_kernel<true, 2" if lists_fmt == "f32" else "fo_sweep_queue_kernel<true, 1"
+        with open(os.path.join(ROOT, "profiles", f"{tag}_summary.csv")) as f:
+            for row in csv.DictReader(f):
+                if row["kernel"].startswith(want) and row.get("WRITE_SIZE") and row.get("FETCH_SIZE"):
+                    return (float(row["WRITE_SIZE"]) + 2.0 * float(row["FETCH_SIZE"])) * 1024.0, tag
+    except Exception:
+        pass
+    return None, tag
 
 
 def small_batch_step(local_rank, steps=300):
     """BASELINE configs[1] beside the headline: scenario1 geometry, 2 000 candidates x 32 phantom slots, the same planning
     step (scene stage + sampling + sweep + reduction, reduced outputs as a planner consumes them), own context; a few
     hundred steps of ~0.1 ms.  Reported under config.small_batch -- ms per planning step at the reference's own size."""
-    import math
     import numpy as np
     import torch
     import yaml
@@ -111,7 +301,7 @@ def small_batch_step(local_rank, steps=300):
     sm = SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx, device=local_rank)
     sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
     sl = SpawnLocator(None, ref, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
-    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, device=local_rank, ctx=ctx)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds=THR, device=local_rank, ctx=ctx)
     sw.reserve(M, T, A, T)
     traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 2, ego_pos=ego[:2], ego_yaw=yaw)
     tr = [torch.as_tensor(traj[k]).to(f"cuda:{local_rank}") for k in ("x", "y", "theta", "v", "a")]
@@ -145,30 +335,41 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="full", choices=["full", "pair", "reduced"])
+    ap.add_argument("--lists", default="f32", choices=["f32", "f64"],
+                    help="element type of the per-timestep lists of --mode full (f32: SURVEY 8d's storage; f64: the reference's)")
     ap.add_argument("--M", type=int, default=10000)
     ap.add_argument("--A", type=int, default=256)
     ap.add_argument("--T", type=int, default=31)
     ap.add_argument("--scene", default="urban", choices=["urban", "scenario1", "synthetic"],
                     help="urban: full planning step on the synthetic urban grid; synthetic: sweep only, fixed agents")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): --M trajectories per rank; strong: --M trajectories in total, split over the ranks")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default): --M trajectories in total, split over the ranks (BASELINE configs[3]); "
+                         "weak: --M trajectories per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the oracle parity check")
     ap.add_argument("--no-autotune", action="store_true", help="skip the agents-per-wave selection pass of the set-up")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other output modes, configs[1])")
     ap.add_argument("--order", default="sampler", choices=["sampler", "random"],
                     help="row order of the synthetic trajectories (synthetic.make_trajectories)")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher above us: become one -- before torch is imported or a GPU is touched
+        sys.exit(launch_workers(args.gpus, sys.argv[1:]))
+    if args.launcher_selftest:
+        sys.exit(launcher_selftest(args))
 
     import numpy as np
     import torch
     from frenetix_occlusion import _native as N
     from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.distributed import shard_bounds
     from frenetix_occlusion.sweep import MetricSweep
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    scaling = args.scaling or "strong"
     dist = None
     use_dist = world > 1 or os.environ.get("FO_BENCH_FORCE_DIST") == "1"   # env: exercise the RCCL path on one rank
     if use_dist:
@@ -179,16 +380,19 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    M, A, T = args.M, args.A, args.T
-    if args.scaling == "strong":      # BASELINE configs[3] read literally: ONE batch of --M trajectories split over the ranks
-        M = (M + world - 1) // world
-    thr = {"harm": 0.1, "risk": 1}   # configurations/simulation/occlusion.yaml:20-28 of the reference's example
+    M_total, A, T = args.M, args.A, args.T
+    if scaling == "strong":      # BASELINE configs[3]: ONE batch of --M trajectories, block-partitioned over the ranks
+        lo, hi = shard_bounds(M_total, world, rank)
+        M, per = hi - lo, -(-M_total // world)
+    else:
+        lo, M, per = 0, M_total, M_total
     ctx = N.Context(local_rank)
-    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds=thr, device=local_rank, ctx=ctx)
-    sw.reserve(M, T, A, T)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds=THR, device=local_rank, ctx=ctx)
+    sw.reserve(max(M, 1), T, A, T)
     d = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a)).to(dev, dt)
 
     scene = None
+    seed = 20240131 + 3 + (1000 * rank if scaling == "weak" else 0)
     if args.scene in ("urban", "scenario1"):
         import yaml
         from frenetix_occlusion import interface
@@ -209,30 +413,38 @@ def main():
         sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
         sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
         scene = dict(sm=sm, sl=sl, ego=ego, edges=len(sm.map_geometry.edges), obstacles=len(sc.obstacles))
-        traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3 + 1000 * rank, ego_pos=ego[:2], ego_yaw=float(ego[2]),
-                                   order=args.order)
+        traj_all = S.make_trajectories(M_total, T, 0.1, seed=seed, ego_pos=ego[:2], ego_yaw=float(ego[2]), order=args.order)
         agents = None
     else:
-        traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3 + 1000 * rank, order=args.order)
+        traj_all = S.make_trajectories(M_total, T, 0.1, seed=seed, order=args.order)
         agents = S.make_agents(A, T, 0.1, seed=20240131 + 3)
         ag = [d(agents[k]) for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims")] + \
              [d(agents["type"], torch.int32), d(agents["len"], torch.int32)]
+    traj = {k: v[lo:lo + M] for k, v in traj_all.items()} if scaling == "strong" else traj_all
     tx, ty, tth, tv, ta = (d(traj[k]) for k in ("x", "y", "theta", "v", "a"))
     out = None
-    gathered = torch.empty((world * M, N.NC), dtype=torch.float64, device=dev) if use_dist else None
+    # every rank contributes a block of `per` rows (the last one padded) -- all_gather_into_tensor wants equal blocks
+    mine = torch.full((per, N.NC), float("nan"), dtype=torch.float64, device=dev) if use_dist else None
+    gathered = torch.empty((world * per, N.NC), dtype=torch.float64, device=dev) if use_dist else None
 
     def scene_stage():
         sm, sl, ego = scene["sm"], scene["sl"], scene["ego"]
         sm.launch(ego[:2], float(ego[2]))
         return sl.sample(ego[:2], float(ego[2]), float(ego[3])).sweep_args()
 
-    def step():
-        nonlocal out
+    def step(mode=args.mode, lists=args.lists, res=None, gather=True):
         a_args = scene_stage() if scene is not None else ag
         sw.set_agents(*a_args, check=False)
-        out = sw.run(tx, ty, tth, tv, ta, mode=args.mode, out=out)
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, out.cost)
+        if M > 0:
+            res = sw.run(tx, ty, tth, tv, ta, mode=mode, out=res, lists=lists)
+        if use_dist and gather:
+            if M == per and M > 0:
+                dist.all_gather_into_tensor(gathered, res.cost)
+            else:
+                if M > 0:
+                    mine[:M].copy_(res.cost)
+                dist.all_gather_into_tensor(gathered, mine)
+        return res
 
     # Everything slow on the host side happens first (the first timing() call creates the event pool; the check and the
     # agent count synchronise), so that from here to the timed region the GPU is never idle for longer than a
@@ -240,7 +452,7 @@ def main():
     # 6-8 % slow, decaying over ~40 steps (power management; per-launch series in DESIGN §7) -- a 20-step window right
     # behind such an idle would consist of that dip.
     sw.ctx.timing(True)
-    step()
+    out = step(res=out)
     sw.ctx.call("fo_sweep_check", torch.cuda.current_stream().cuda_stream)
     n_active = A
     if scene is not None:
@@ -254,16 +466,21 @@ def main():
         for apw in (1, 2, 4, 8):
             os.environ["FO_SWEEP_APW"] = str(apw)
             for _ in range(20):
-                step()
+                out = step(res=out, gather=False)
             torch.cuda.synchronize()
             t_a = time.perf_counter()
             for _ in range(100):
-                step()
+                out = step(res=out, gather=False)
             torch.cuda.synchronize()
             tune[apw] = (time.perf_counter() - t_a) / 100
-        os.environ["FO_SWEEP_APW"] = str(min(tune, key=tune.get))
+        best = min(tune, key=tune.get)
+        if use_dist:      # one setting for the whole job
+            b = torch.tensor([best], device=dev)
+            dist.broadcast(b, 0)
+            best = int(b.item())
+        os.environ["FO_SWEEP_APW"] = str(best)
     for _ in range(args.warmup):
-        step()
+        out = step(res=out)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -271,7 +488,7 @@ def main():
     sw.ctx.timing(True, every=int(os.environ.get("FO_BENCH_TIME_EVERY", "1")))
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        out = step(res=out)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -283,10 +500,21 @@ def main():
         with open(os.environ["FO_BENCH_DUMP_SERIES"], "w") as f:
             f.write(" ".join(f"{v:.4f}" for v in kern_each) + "\n")
     sw.ctx.timing(False)
+    ag_ms = None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # the collective alone: 100 all-gathers of the cost blocks back to back
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(100):
+            dist.all_gather_into_tensor(gathered, mine if (M != per or M == 0) else out.cost)
+        e1.record()
+        torch.cuda.synchronize()
+        ag_ms = e0.elapsed_time(e1) / 100
 
     # stage breakdown (outside the timed region): the scene stage alone, HIP events on the launch stream
     scene_ms = None
@@ -301,86 +529,94 @@ def main():
         scene_ms = e0.elapsed_time(e1) / 20
 
     if rank == 0:
-        pairs = world * M * n_active * args.steps
+        M_job = M_total if scaling == "strong" else world * M
+        pairs = M_job * n_active * args.steps
         kern_s = kern_ms / 1e3 / max(kern_n, 1)
-        abytes = algorithmic_bytes(M, n_active, T, args.mode)
-        achieved = abytes / kern_s / 1e9
+        a8d, ast = bytes_8d(M, n_active, T, args.mode), bytes_stored(M, n_active, T, args.mode, args.lists)
+        achieved = a8d / kern_s / 1e9
         launch = sw.ctx.last_launch()
-        # HBM traffic of the dominant kernel from the PMC passes of the same command (profiles/, see README there):
-        # WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), KB -> bytes; null when no summary has been committed
-        traffic = None
-        default_workload = (args.scene == "urban" and M == 10000 and A == 256 and T == 31 and args.mode == "full")
-        try:
-            if not default_workload:
-                raise LookupError("the committed PMC summary belongs to the default workload")
-            import csv
-            tag = os.environ.get("FO_PROFILE_TAG", "r02_final")
-            with open(os.path.join(ROOT, "profiles", f"{tag}_summary.csv")) as f:
-                for row in csv.DictReader(f):
-                    # the full-output instantiation (PAIR, LISTS = true, true); the small-batch step of the same
-                    # command runs another one
-                    if row["kernel"].startswith("fo_sweep_queue_kernel<true, true") and row.get("WRITE_SIZE") \
-                            and row.get("FETCH_SIZE") and traffic is None:
-                        traffic = (float(row["WRITE_SIZE"]) + 2.0 * float(row["FETCH_SIZE"])) * 1024.0
-        except Exception:
-            traffic = None
+        default_workload = (args.scene == "urban" and M_total == 10000 and A == 256 and T == 31 and args.mode == "full")
+        traffic, ptag = (None, None)
+        if default_workload and world == 1:
+            traffic, ptag = committed_traffic(N, args.lists)
         res = {
             "metric": "trajectory_x_agent_metric_evals_per_sec", "value": pairs / elapsed, "unit": "pair-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: synthetic urban lanelet net, 10k trajectories x 256 phantoms, "
-                                    "360 deg ray-cast @ 0.5 deg, T=31 (full planning step; per-rank trajectory shard when "
-                                    "n_gpus>1)") if args.scene == "urban" else
-                                   (f"BASELINE configs[1]: scenario1 geometry, {M} trajectories x {A} phantom slots, full "
+                                    "360 deg ray-cast @ 0.5 deg, T=31 (full planning step)" if world == 1 else
+                                    "BASELINE configs[3]: the synthetic 10k x 256 batch of configs[2] block-partitioned "
+                                    f"over {world} GPUs, one RCCL all-gather of the cost vectors per step"
+                                    if scaling == "strong" else
+                                    f"weak scaling: every one of {world} ranks evaluates its own {M} trajectories x 256 phantoms "
+                                    "(NOT configs[3]), cost vectors all-gathered") if args.scene == "urban" else
+                                   (f"BASELINE configs[1]: scenario1 geometry, {M_total} trajectories x {A} phantom slots, full "
                                     "metric set, T=31 (full planning step)") if args.scene == "scenario1" else
                                    "sweep only: 10k synthetic trajectories x 256 synthetic phantom predictions, T=31",
-                       "M_per_gpu": M, "A": A, "A_active": n_active, "T": T, "output_mode": args.mode,
+                       "M_total": M_job, "M_per_gpu": M, "A": A, "A_active": n_active, "T": T, "output_mode": args.mode,
+                       "list_storage": (args.lists + (" (harm entries away from the 5 m gate evaluated in float32; every cost, "
+                                                     "flag and pair scalar float64)" if args.lists == "f32" else ""))
+                       if args.mode == "full" else None,
                        "traj_order": args.order, "metrics": ["hr", "ttc", "ttce", "dce", "wttc", "cp"],
                        "scene_stage_ms": scene_ms, "sweep_kernel_ms": kern_s * 1e3,
                        "agents_per_wave": int(os.environ["FO_SWEEP_APW"]) if os.environ.get("FO_SWEEP_APW") else None,
                        "setup_autotune_ms_per_step": {str(k): round(v * 1e3, 4) for k, v in tune.items()},
                        "boundary_edges": scene["edges"] if scene else None, "rays": 720 if scene else None,
-                       "parallelism": f"traj-shard x{world}"},
+                       "parallelism": f"traj-shard x{world}", "ranks_seen": dist.get_world_size() if use_dist else 1,
+                       "allgather_ms": ag_ms, "allgather_bytes_per_rank": per * N.NC * 8 if use_dist else None,
+                       "build_id": N.build_id()},
             "roofline": {"bound": "hbm", "kernel": "fo_sweep_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_s * 1e3, "launches_timed": kern_n,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_profile": ptag,
+                         "bytes_definition": "SURVEY 8d, fp32 storage: 620 B/trajectory + 636 B/agent + per pair 48 B "
+                                             "scalars (+ 600 B lists in full mode); 64 B/trajectory in reduced mode",
+                         "algorithmic_bytes_per_launch": a8d, "stored_bytes_per_launch": ast,
+                         "achieved_stored": ast / kern_s / 1e9, "frac_stored_bytes": ast / kern_s / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms": kern_s * 1e3, "launches_timed": kern_n,
                          "kernel_ms_p50": float(np.percentile(kern_each, 50)) if kern_each else None,
                          "kernel_ms_p95": float(np.percentile(kern_each, 95)) if kern_each else None,
                          "grid": launch["grid"], "block": launch["block"],
                          "kernel_pair_evals_per_sec": M * n_active / kern_s},
         }
-        if out.pair_f is not None:
+        if out is not None and out.pair_f is not None:
             res["config"]["gate_pair_frac"] = float((out.pair_f[N.PF["max_collision_probability"]] > 0).double().mean())
             res["config"]["collision_pair_frac"] = float((out.pair_f[N.PF["dce"]] == 0).double().mean())
             res["config"]["safe_traj_frac"] = float(out.safe.double().mean())
-        if world == 1 and default_workload:
-            # the same step with reduced outputs (cost vectors + flags: what a planner loop consumes), beside the headline
-            red = None
-            for _ in range(60):
-                a_args = scene_stage()
-                sw.set_agents(*a_args, check=False)
-                red = sw.run(tx, ty, tth, tv, ta, mode="reduced", out=red)
-            torch.cuda.synchronize()
-            sw.ctx.timing(True)
-            t_r = time.perf_counter()
-            for _ in range(100):
-                a_args = scene_stage()
-                sw.set_agents(*a_args, check=False)
-                red = sw.run(tx, ty, tth, tv, ta, mode="reduced", out=red)
-            torch.cuda.synchronize()
-            dt_r = (time.perf_counter() - t_r) / 100
-            kms_r, kn_r = sw.ctx.timing_read()
-            sw.ctx.timing(False)
-            res["config"]["reduced_outputs"] = {"ms_per_step": dt_r * 1e3, "pair_evals_per_sec": M * n_active / dt_r,
-                                                "sweep_kernel_ms": kms_r / max(kn_r, 1), "steps": 100}
-            res["config"]["small_batch"] = small_batch_step(local_rank)
         if world == 1 and not args.no_cpu_baseline:
+            # oracle on EVERY pair: parity of the last timed step's buffers + the CPU baselines (before the extras below
+            # reuse the context)
             if scene is not None:
                 b = scene["sl"].batch
                 agents = {k: getattr(b, k).cpu().numpy() for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")}
-            res["cpu_baseline"] = cpu_baseline(S, traj, agents, thr, usable_cores())
+            res["cpu_baseline"], res["parity"] = cpu_and_parity(S, N, traj, agents, out, args.lists)
         else:
-            res["cpu_baseline"] = None
+            res["cpu_baseline"], res["parity"] = None, None
+        if world == 1 and default_workload and not args.no_extras:
+            def side(mode, lists, n=100):
+                r = None
+                for _ in range(60):
+                    r = step(mode, lists, r)
+                torch.cuda.synchronize()
+                sw.ctx.timing(True)
+                t_r = time.perf_counter()
+                for _ in range(n):
+                    r = step(mode, lists, r)
+                torch.cuda.synchronize()
+                dt_r = (time.perf_counter() - t_r) / n
+                kms_r, kn_r = sw.ctx.timing_read()
+                sw.ctx.timing(False)
+                ks = kms_r / max(kn_r, 1) / 1e3
+                b8, bs = bytes_8d(M, n_active, T, mode), bytes_stored(M, n_active, T, mode, lists)
+                del r
+                return {"ms_per_step": dt_r * 1e3, "pair_evals_per_sec": M * n_active / dt_r, "sweep_kernel_ms": ks * 1e3,
+                        "frac": b8 / ks / 1e9 / HBM_PEAK_GBS, "frac_stored_bytes": bs / ks / 1e9 / HBM_PEAK_GBS, "steps": n}
+            del out
+            torch.cuda.empty_cache()
+            # the same step with the lists in the other element type, and with reduced outputs (cost vectors + flags:
+            # what a planner loop consumes), beside the headline
+            other = "f64" if args.lists == "f32" else "f32"
+            res["config"][f"{other}_lists"] = side("full", other)
+            res["config"]["reduced_outputs"] = side("reduced", args.lists)
+            res["config"]["small_batch"] = small_batch_step(local_rank)
         if use_dist:   # RCCL's start-up banner sits in the C library's stdout buffer: let it out first, the JSON line last
             import ctypes
             ctypes.CDLL(None).fflush(None)

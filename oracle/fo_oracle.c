@@ -527,6 +527,7 @@ int fo_oracle_sweep(int M, int T, const double *x, const double *y, const double
   uint32_t mask = fo_oracle_required_metrics(metric_mask);
   const int Tm1 = T - 1;
   int err = 0;
+  if (!gl_ready) gl_init(); /* once, before the worker threads exist (they only read the table) */
 #ifdef _OPENMP
   if (nthreads > 1) omp_set_num_threads(nthreads);
 #pragma omp parallel if (nthreads > 1)

@@ -1,0 +1,53 @@
+"""`python bench.py --gpus N` must be runnable as the driver runs it -- with and without a launcher above it.  On CPU
+(gloo) this drives exactly that plumbing: the self-launcher (N worker processes, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT), the rendezvous on 127.0.0.1, the block partition of ONE batch (strong scaling = BASELINE
+configs[3]) and the all-gather of the per-trajectory cost rows in rank order.  The GPU work itself is not part of it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=300)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, lines
+
+
+@pytest.mark.parametrize("n,M", [(2, 101), (3, 10)])
+def test_bench_launches_its_own_workers(n, M):
+    p, lines = _run({}, ["--gpus", str(n), "--launcher-selftest", "--M", str(M), "--steps", "3"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1                                   # rank 0 prints the one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["ranks_seen"] == n and d["gather_ok"] and d["scaling"] == "strong"
+    assert d["M_total"] == M and d["M_per_rank"] == -(-M // n)
+
+
+def test_bench_under_an_external_launcher():
+    """what `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` amounts to"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "0", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest", "--M", "64", "--steps", "2"]
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    cmd[cmd.index("--master-port") + 1] = str(s.getsockname()[1])
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    q = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stderr[-2000:]
+    d = json.loads([ln for ln in q.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["ranks_seen"] == 2 and d["gather_ok"]
+
+
+def test_a_failing_worker_fails_the_launcher():
+    p, _ = _run({"FO_BENCH_LAUNCH_TIMEOUT": "120"}, ["--gpus", "2", "--launcher-selftest", "--M", "8", "--steps", "1",
+                                                     "--mode", "nonsense"])
+    assert p.returncode != 0

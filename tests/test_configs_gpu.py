@@ -139,3 +139,61 @@ def test_config5_multi_ego_four_interfaces_share_the_gpu(torch_cuda, oracle, tmp
         ref = oracle.sweep(sub, _agents_of(fo), SY.VEHICLE_BMW320I, 0.1, thr=thr, want_lists=False, nthreads=8)
         _compare_cost(oracle, ba.cost.cpu().numpy()[:300], ref["cost"])
     assert n_with_agents >= 2
+
+
+@pytest.mark.parametrize("lists", ["f64", "f32"])
+def test_config3_headline_step_full_outputs_vs_oracle_on_every_pair(torch_cuda, oracle, lists):
+    """configs[2] exactly as bench.py times it -- urban grid, 720 rays, fo_scene_spawn of 256 phantoms (all_occluded,
+    max_dist 45), fo_sweep_run with full outputs on 10 000 candidates -- against the oracle on ALL 10 000 x 256 pairs
+    (chunked: the oracle's lists for the whole batch would be 3 GB of host memory).  Float outputs <= 1e-9 (float32
+    lists <= 1e-6), time_dce / argmin / argmax indices / safe exact (plateau rule of oracle/fo_compare.py)."""
+    import yaml
+    torch = torch_cuda
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as SC
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.sweep import MetricSweep
+    from oracle import fo_compare as CMP
+    M, A, T = 10000, 256, 31
+    thr = {"harm": 0.1, "risk": 1}
+    ctx = N.Context(0)
+    sc = SC.synthetic_urban_grid()
+    ego = sc.ego_initial
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=45.0)
+    ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+    sm = SensorModel(sc.lanelets, ref_path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx)
+    sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
+    sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds=thr, ctx=ctx)
+    traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+    sm.launch(ego[:2], float(ego[2]))
+    batch = sl.sample(ego[:2], float(ego[2]), float(ego[3]))
+    sw.set_agents(*batch.sweep_args())
+    out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj["a"], mode="full", lists=lists)
+    torch.cuda.synchronize()
+    agents = {k: getattr(batch, k).cpu().numpy() for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")}
+    assert int((agents["len"] > 0).sum()) == A
+    views, acc, bufs = out.list_views(), None, None
+    for lo in range(0, M, 500):
+        hi = lo + 500
+        ref = oracle.sweep({k: v[lo:hi] for k, v in traj.items()}, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, nthreads=8, out=bufs)
+        bufs = ref
+        got = {"cost": out.cost[lo:hi].cpu().numpy(), "safe": out.safe[lo:hi].cpu().numpy(),
+               "pair_f": out.pair_f[:, :, lo:hi].permute(2, 1, 0).cpu().numpy(),
+               "pair_i": out.pair_i[:, :, lo:hi].permute(2, 1, 0).cpu().numpy(),
+               "lists": torch.stack([v[:, :, lo:hi] for v in views]).permute(3, 1, 0, 2).cpu().numpy()}
+        acc = CMP.merge(acc, CMP.compare(ref, got))
+    assert acc["pairs"] == M * A
+    assert acc["int_mismatches"] == 0 and acc["pattern_mismatches"] == 0, acc
+    assert acc["float_max_abs_err"] <= 1e-9, acc
+    assert acc["list_max_abs_err"] <= (1e-6 if lists == "f32" else 1e-9), acc
+    # the batch exercises every branch: pairs inside the 5 m gate, colliding pairs, both verdicts
+    pf = out.pair_f
+    assert float((pf[N.PF["max_collision_probability"]] > 0).double().mean()) > 0.02
+    assert float((pf[N.PF["dce"]] == 0).double().mean()) > 0.001
+    assert 0.0 < float(out.safe.double().mean()) < 1.0

@@ -237,7 +237,8 @@ def test_float32_lists_generic_kernel_and_metric_subset(torch_cuda, oracle, monk
     g64 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
     g32 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32")
     _compare_f32_lists(ref["lists"], g32, g64)
-    monkeypatch.setenv("FO_SWEEP_GENERIC", "1")
+    monkeypatch.setenv("FO_SWEEP_GENERIC", "1")    # (the generic kernel's libm route differs from the queue kernel's in the last bits)
+    g64 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
     g32 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32")
     _compare_f32_lists(ref["lists"], g32, g64)
     # a metric set that writes no lists at all: NaN-filled in either format

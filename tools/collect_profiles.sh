@@ -18,4 +18,12 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/${TAG}_pmc$i -o run -- python3 bench.py $ARGS > $OUT/${TAG}_pmc$i.log 2>&1
 done
+# which library these numbers belong to (bench.py prints roofline.traffic only when this id equals the loaded library's)
+LISTS=f32; case " $* " in *" --lists f64 "*) LISTS=f64;; esac
+python3 - > $OUT/${TAG}_build.json <<PY
+import json, sys
+sys.path.insert(0, "frenetix-occlusion_amd")
+from frenetix_occlusion import _native as N
+print(json.dumps({"build_id": N.build_id(), "lists": "$LISTS", "bench_args": "$*"}))
+PY
 ls -R $OUT | grep -c csv

@@ -40,4 +40,7 @@ with open(os.path.join(dst, f"{tag}_summary.csv"), "w", newline="") as f:
         d = dur[k]
         w.writerow([k, len(d), round(sum(d) / len(d)), min(d), max(d)] + list(meta.get(k, [""] * 5)) +
                    [("%.6g" % (sum(ctr[k][c]) / len(ctr[k][c])) if ctr[k].get(c) else "") for c in counters])
+if os.path.exists(os.path.join(src, f"{tag}_build.json")):     # the library the profile belongs to (bench.py checks it)
+    import shutil
+    shutil.copy(os.path.join(src, f"{tag}_build.json"), os.path.join(dst, f"{tag}_build.json"))
 print(open(os.path.join(dst, f"{tag}_summary.csv")).read())
