@@ -41,6 +41,7 @@ void fo_destroy(fo_ctx *ctx) {
   if (ctx->d_agent_const) (void)hipFree(ctx->d_agent_const);
   if (ctx->d_traj_tab) (void)hipFree(ctx->d_traj_tab);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  if (ctx->d_chunk_tab) (void)hipFree(ctx->d_chunk_tab);
   if (ctx->d_be_dist) (void)hipFree(ctx->d_be_dist);
   if (ctx->d_be_btn) (void)hipFree(ctx->d_be_btn);
   if (ctx->d_be_mask) (void)hipFree(ctx->d_be_mask);

@@ -38,6 +38,8 @@ struct fo_ctx {
   double *d_traj_tab = nullptr;     // [T][NEF][Mp]
   double *d_partial = nullptr;      // [n_chunks][NPS][Mp]
   size_t cap_traj_tab = 0, cap_partial = 0;
+  int *d_chunk_tab = nullptr;       // [n_chunks][2] first agent / agents per wave of every chunk (tapered grid)
+  size_t cap_chunk_tab = 0;
   // ---- BE metric workspace (only allocated when FO_M_BE is active)
   double *d_be_dist = nullptr, *d_be_btn = nullptr;
   signed char *d_be_mask = nullptr;

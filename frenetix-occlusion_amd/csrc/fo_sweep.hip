@@ -192,8 +192,22 @@ __device__ __forceinline__ double fo_round3_fast(double v) { return fo_div1000(_
 __global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int tz, const double *__restrict__ x,
                                                            const double *__restrict__ y,
                                                            const double *__restrict__ th,
-                                                           const double *__restrict__ v, double *__restrict__ tab) {
+                                                           const double *__restrict__ v, double *__restrict__ tab,
+                                                           int *__restrict__ chunk_tab, int n_chunks, int wpb, int n0, int n1,
+                                                           int n2, int a0, int a1, int a2, int a3) {
   extern __shared__ double sh[];  // [2][tz][TILE+1]
+  // the chunk table of the sweep launch that follows on this stream (SweepArgs::chunk_tab): phases of n0 / n1 / n2 / the
+  // remaining chunks with a0 / a1 / a2 / a3 agents per wave
+  if (chunk_tab && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) {
+      int k0, ap;
+      if (c < n0) { ap = a0; k0 = c * a0; }
+      else if (c < n0 + n1) { ap = a1; k0 = n0 * a0 + (c - n0) * a1; }
+      else if (c < n0 + n1 + n2) { ap = a2; k0 = n0 * a0 + n1 * a1 + (c - n0 - n1) * a2; }
+      else { ap = a3; k0 = n0 * a0 + n1 * a1 + n2 * a2 + (c - n0 - n1 - n2) * a3; }
+      chunk_tab[2 * c] = k0 * wpb;
+      chunk_tab[2 * c + 1] = ap;
+    }
   const int m0 = blockIdx.x * TILE;
   const int n = min(TILE, M - m0);
   const int ld = TILE + 1;
@@ -366,6 +380,19 @@ struct SweepArgs {
   double dt, thr_dce;
   uint32_t mask;
   uint32_t ablate;  // debug only (env FO_SWEEP_ABLATE): 1 skip DCE, 2 skip CP box sums, 4 skip harm -- wrong results, timing aid
+  // Tapered grid: the chunks of a tile shrink towards the end of the launch (workgroups are dispatched in blockIdx order,
+  // chunk-major): ph_n[0] chunks of 4 x ph_a[0] agents, then ph_n[1] of 4 x ph_a[1], ..., the rest of 4 x ph_a[3].
+  // A workgroup lives ~40 us per agent of its waves; at the end of a launch the chip drains for about half a workgroup
+  // life (tools/wg_trace.py: with 16 agents per workgroup throughout, the last fifth of the launch runs half empty) --
+  // short workgroups there cut the drain, long ones before keep the per-workgroup start-up (table fill, cross-wave
+  // fold) off most of the work.
+  // The decode sits in a table, [chunk] -> (first agent of wave 0, agents per wave), which fo_prep_traj_kernel writes
+  // before every sweep: two scalar loads here (a decode loop over the phases in this kernel tipped its register
+  // allocation over: SGPR spills through scratch memory, twice the run time).
+  const int *chunk_tab;
+#if FO_TRACE
+  long long *trace;  // tuning builds (-DFO_TRACE=1): per workgroup start / end wall clock (100 MHz) + hardware id
+#endif
 };
 
 __device__ __forceinline__ double fo_lr4s_coef(double ang, double side, double rear) {
@@ -744,6 +771,9 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #ifndef FO_MINW
 #define FO_MINW 3    // waves per SIMD the register allocation has to allow (<= 168 VGPRs)
 #endif
+#ifndef FO_TRACE
+#define FO_TRACE 0
+#endif
 #ifndef FO_X
 #define FO_X 0       // timing experiments only (tools/build_variant.sh x1 -DFO_X=1 ...): 1 no pass 2, 2 no probe, 4 no harm
 #endif               // geometry in pass 1, 8 pass 2 without its arithmetic, 32 no DCE in pass 1, 64 no gate, 128 no second (correlated) body -- WRONG results
@@ -908,8 +938,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
   int w_arg_dce = -1, w_arg_ttc = -1, w_arg_or = -1;  // agent indices as integers: three VGPRs less than as doubles
   bool w_dce_flag = false;
 
-  const int apw_ = SPLIT ? 1 : a.apw;
-  const int k0 = SPLIT ? chunk : (chunk * QWAVES + wave) * a.apw;
+  // agents of this wave: chunk -> (first agent, agents per wave), see SweepArgs::chunk_tab
+  const int apw_ = SPLIT ? 1 : fo_const(a.chunk_tab)[2 * chunk + 1];
+  const int k0 = SPLIT ? chunk : fo_const(a.chunk_tab)[2 * chunk] + wave * apw_;
   // the samples this wave owns: everything, or time chunk `wave` of the agent the workgroup shares
   const int seg0 = SPLIT ? wave * TC : 0, seg1 = SPLIT ? min(seg0 + TC, a.T) : a.T;
   const int gfirst_ = max(seg0 - 1, 0);  // first harm / cp sample this wave evaluates for an agent
@@ -1227,11 +1258,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
             const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
             const double m2 = fmin(d0, fmin(dp, dm));
-            ing = m2 <= 25.0;
-            // keep the reference's test on the rounded sqrt (a whole-wave branch: the band is 1e-9 wide)
-            if (__ballot(!ing && m2 < 25.0 + 1e-9)) {
-              if (!ing && m2 < 25.0 + 1e-9) ing = !(sqrt(m2) > 5.0);
-            }
+            // the reference tests the ROUNDED distance, !(sqrt(m2) > 5.0) (collision_probability.py:67,75).  The
+            // correctly rounded square root of m2 is 5.0 up to and including m2 = 25 + one ulp (sqrt(25 (1 + d)) = 5 (1 + d/2),
+            // half an ulp of 5.0 is 4.4e-16, one ulp of 25 is 3.6e-15): no square root needed
+            ing = m2 <= 25.000000000000004;
           }
           const unsigned long long bal = __ballot(ing);
           if (bal) {
@@ -1510,11 +1540,23 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     zc_tab[threadIdx.x] = -a.hc.lr4s_const - (threadIdx.x == 0 ? 0.0 : threadIdx.x == 1 ? a.hc.lr4s_side : a.hc.lr4s_rear);
   // (FO_X & 128: register / timing experiments without the second body -- WRONG results for correlated covariances)
   const bool corr = !(FO_X & 128) && a.status[1] == a.gen;   // scalar load; written by fo_prep_agents_kernel on this stream
+#if FO_TRACE
+  if (a.trace && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.trace[4 * (size_t)blockIdx.x + 0] = wall_clock64();
+    a.trace[4 * (size_t)blockIdx.x + 2] = (long long)hw | ((long long)xcc << 32);
+  }
+#endif
   __syncthreads();
   if (__builtin_expect(!corr, 1))
     fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
   else
     fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, true, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
+#if FO_TRACE
+  if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 
@@ -1786,6 +1828,7 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
   const size_t chunks_split = (size_t)max_A + 1, tiles = (size_t)Mp / TILE;
   const size_t chunks = tiles * max_A < 3072 ? chunks_split : (size_t)(max_A + WAVES - 1) / WAVES + 1;
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, chunks * NPS * Mp))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_chunk_tab, &ctx->cap_chunk_tab, 2 * (chunks + 1)))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) * NAF))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(max_A > 0 ? max_A : 1) * NAC))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(max_A > 0 ? max_A : 1) * 2))) return rc;
@@ -1860,10 +1903,39 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   bool split = use_queue && T <= QWAVES * TC && (long)n_tiles * A < 3072;
   if (const char *e = getenv("FO_SWEEP_SPLIT")) split = use_queue && T <= QWAVES * TC && e[0] == '1';  // tests, A/B runs
   if (split) apw = 1;
-  const int n_chunks = A > 0 ? (split ? A : (A + wpb * apw - 1) / (wpb * apw)) : 0;
+  // Tapered grid (queue kernel, grids beyond one round of the chip): agents per wave halve from phase to phase down to
+  // one -- see SweepArgs::ph_n.  f[]: fraction of the agents per phase; FO_SWEEP_TAPER="f0,f1,f2" overrides them
+  // ("0" = no taper), a tuning aid.
+  int ph_n[3] = {0, 0, 0}, ph_a[4] = {apw, apw, apw, apw};
+  int n_chunks = A > 0 ? (split ? A : (A + wpb * apw - 1) / (wpb * apw)) : 0;
+  ph_n[0] = n_chunks;   // one phase unless tapered below
+  if (use_queue && !split && apw >= 2 && A > 0) {
+    double f[3] = {0.85, 0.10, 0.0};
+    if (apw >= 8) { f[0] = 0.55; f[1] = 0.25; f[2] = 0.12; }
+    if (const char *e = getenv("FO_SWEEP_TAPER")) {
+      f[0] = 1.0; f[1] = f[2] = 0.0;
+      sscanf(e, "%lf,%lf,%lf", &f[0], &f[1], &f[2]);
+      if (f[0] <= 0.0) f[0] = 1.0;
+    }
+    if ((long)n_tiles * n_chunks >= 768 && f[0] < 1.0) {
+      int left = A, ap = apw;
+      n_chunks = 0;
+      for (int ph = 0; ph < 3; ++ph) {
+        ph_a[ph] = ap;
+        ph_n[ph] = (int)(f[ph] * A) / (wpb * ap);
+        if (ph_n[ph] * wpb * ap > left) ph_n[ph] = left / (wpb * ap);
+        left -= ph_n[ph] * wpb * ap;
+        n_chunks += ph_n[ph];
+        ap = ap >= 2 ? ap / 2 : 1;
+      }
+      ph_a[3] = 1;
+      n_chunks += (left + wpb - 1) / wpb;
+    }
+  }
   int rc;
   if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)T * NEF * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)(n_chunks + 1) * NPS * Mp))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_chunk_tab, &ctx->cap_chunk_tab, (size_t)2 * (n_chunks + 1)))) return rc;
   if (do_be && A > 0) {
     if ((rc = fo_reserve(ctx, &ctx->d_be_dist, &ctx->cap_be_dist, (size_t)(T + 1) * Mp))) return rc;  // [T][Mp] + min(a) [Mp]
     if ((rc = fo_reserve(ctx, &ctx->d_be_btn, &ctx->cap_be_btn, (size_t)A * Mp))) return rc;
@@ -1873,10 +1945,12 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   if (A > 0) {
     const int tz = T > 8 ? 8 : T;   // horizon slice per block
     hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 2, (T + tz - 1) / tz), dim3(256),
-                       (size_t)2 * tz * (TILE + 1) * sizeof(double), s, M, T, tz, d_x, d_y, d_theta, d_v, ctx->d_traj_tab);
+                       (size_t)2 * tz * (TILE + 1) * sizeof(double), s, M, T, tz, d_x, d_y, d_theta, d_v, ctx->d_traj_tab,
+                       ctx->d_chunk_tab, n_chunks, wpb, ph_n[0], ph_n[1], ph_n[2], ph_a[0], ph_a[1], ph_a[2], ph_a[3]);
     FO_HIP_TRY(ctx, hipGetLastError());
     SweepArgs a{};
     a.M = M; a.Mp = Mp; a.T = T; a.A = A; a.Ta = Ta; a.n_tiles = n_tiles; a.nt8 = (n_tiles + 7) / 8; a.apw = apw;
+    a.chunk_tab = ctx->d_chunk_tab;
     a.erf_tab = (const double2 *)ctx->d_erf_tab;
     a.exp_tab = (const double *)ctx->d_exp_tab;
     a.gl = (const double *)ctx->d_gl_tab;
@@ -1899,6 +1973,12 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     const bool timed = ctx->timing && ctx->n_timed < fo_ctx::kMaxTimed && (ctx->n_launch++ % ctx->timing_stride) == 0;
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[ctx->n_timed], s));
     const dim3 g(grid), b(TILE * wpb);
+#if FO_TRACE
+    static long long *d_trace = nullptr;
+    const char *trace_path = getenv("FO_SWEEP_TRACE");
+    if (trace_path && !d_trace) (void)hipMalloc((void **)&d_trace, sizeof(long long) * 4 * 65536);
+    a.trace = trace_path ? d_trace : nullptr;
+#endif
     const int lst = !d_lists ? LST_NONE : ctx->list_format == FO_LISTS_F32 ? LST_F32 : LST_F64;
     if (use_queue) {
       const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
@@ -1915,6 +1995,15 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     }
     FO_HIP_TRY(ctx, hipGetLastError());
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop[ctx->n_timed++], s));
+#if FO_TRACE
+    if (a.trace && getenv("FO_SWEEP_TRACE_DUMP")) {   // (set for the one launch that is to be dumped)
+      (void)hipStreamSynchronize(s);
+      long long *h = (long long *)malloc(sizeof(long long) * 4 * grid);
+      (void)hipMemcpy(h, d_trace, sizeof(long long) * 4 * grid, hipMemcpyDeviceToHost);
+      if (FILE *f = fopen(trace_path, "wb")) { fwrite(h, sizeof(long long), 4 * (size_t)grid, f); fclose(f); }
+      free(h);
+    }
+#endif
   }
   const double *be_btn = nullptr;
   if (do_be && A > 0 && T >= 1) {
