@@ -25,6 +25,7 @@
 //   fo_spawn_flag_kernel   candidate cells (+ block counts), fo_spawn_predict_kernel (evenly spaced pick + heading +
 //                          predictions in the sweep's agent layout)
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include "fo_ctx.hpp"
 
@@ -35,7 +36,7 @@ namespace {
 // and shared by reference between the contexts of several egos on one GPU (fo_scene_share_map: BASELINE configs[4],
 // "shared occlusion map in HBM")
 struct StaticMap {
-  int refs = 1;
+  std::atomic<int> refs{1};        // contexts reading this map (fo_scene_share_map / fo_destroy may run on other host threads)
   int P = 0, E = 0;
   double cs = 0.5, x0 = 0, y0 = 0;
   int rnx = 0, rny = 0;
@@ -49,12 +50,23 @@ struct StaticMap {
   int R = 0, n_lanelets = 0;
   int32_t *d_route_first = nullptr, *d_route_count = nullptr, *d_lanelet_raster = nullptr;
   double *d_route_xy = nullptr, *d_route_s = nullptr;
+  // lanelet polygons as uploaded (exact point-in-lanelet tests of the spawn rule families, fo_spawn_rules.hpp)
+  int32_t *d_poly_off = nullptr;  // [P + 1]
+  double *d_poly_xy = nullptr;    // [V][2]
+  double *d_poly_box = nullptr;   // [P][4] xmin, ymin, xmax, ymax
+  // lanelet topology the rule families read (fo_scene_set_topology; optional)
+  double *d_left0 = nullptr;      // [P][2] first vertex of the left bound
+  int32_t *d_pred0 = nullptr, *d_adj_left = nullptr;   // [P] index of predecessors[0] / adj_left, -1 = none
+  int n_inter = 0;
+  int32_t *d_inter_off = nullptr, *d_inter_lanelet = nullptr;   // intersection i: entries [off[i], off[i+1]) of
+  uint8_t *d_inter_kind = nullptr;                              // (lanelet index, kind: 0 incoming, 1 inner)
 };
 
 void map_release(StaticMap *m) {
-  if (!m || --m->refs > 0) return;
+  if (!m || m->refs.fetch_sub(1) > 1) return;
   void *ptrs[] = {m->d_edges, m->d_edge_line, m->d_chunk_box, m->d_sub_box, m->d_raster, m->d_lane_yaw, m->d_route_first,
-                  m->d_route_count, m->d_lanelet_raster, m->d_route_xy, m->d_route_s};
+                  m->d_route_count, m->d_lanelet_raster, m->d_route_xy, m->d_route_s, m->d_poly_off, m->d_poly_xy,
+                  m->d_poly_box, m->d_left0, m->d_pred0, m->d_adj_left, m->d_inter_off, m->d_inter_lanelet, m->d_inter_kind};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete m;
@@ -73,6 +85,8 @@ struct Scene {
   int32_t *d_amb = nullptr;       // [cells] window indices of the cells the fan cannot decide
   int32_t *d_namb = nullptr;      // [1]; zeroed by the ray kernel of the step
   size_t cap_amb = 0;
+  double *d_rule_rec = nullptr;   // [1 + O][24] per-workgroup records of the spawn rule families (fo_spawn_rules.hpp)
+  size_t cap_rule_rec = 0;
 };
 
 Scene *scene_of(fo_ctx *ctx) {
@@ -1107,7 +1121,7 @@ extern "C" {
 void fo_scene_destroy_(fo_ctx *ctx) {
   if (!ctx || !ctx->scene) return;
   Scene *sc = (Scene *)ctx->scene;
-  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb};
+  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_rule_rec};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   map_release(sc->map);
@@ -1127,7 +1141,7 @@ int fo_scene_share_map(fo_ctx *ctx, fo_ctx *owner) {
   if (src->map->P < 1) return fo_fail(ctx, FO_E_STATE, "fo_scene_share_map: the owner has not called fo_scene_set_map");
   map_release(dst->map);
   dst->map = src->map;
-  ++dst->map->refs;
+  dst->map->refs.fetch_add(1);
   return FO_OK;
 }
 
@@ -1172,7 +1186,10 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
   sc->map->R = 0;  // a new raster invalidates the route table
   if (sc->map->d_lanelet_raster) { (void)hipFree(sc->map->d_lanelet_raster); sc->map->d_lanelet_raster = nullptr; }
   for (void **p : {(void **)&sc->map->d_edges, (void **)&sc->map->d_raster, (void **)&sc->map->d_lane_yaw, (void **)&sc->map->d_chunk_box,
-                   (void **)&sc->map->d_edge_line, (void **)&sc->map->d_sub_box}) {
+                   (void **)&sc->map->d_edge_line, (void **)&sc->map->d_sub_box, (void **)&sc->map->d_poly_off,
+                   (void **)&sc->map->d_poly_xy, (void **)&sc->map->d_poly_box, (void **)&sc->map->d_left0, (void **)&sc->map->d_pred0,
+                   (void **)&sc->map->d_adj_left, (void **)&sc->map->d_inter_off, (void **)&sc->map->d_inter_lanelet,
+                   (void **)&sc->map->d_inter_kind}) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   }
   int32_t *d_off = nullptr;
@@ -1225,7 +1242,8 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
                      sc->map->x0, sc->map->y0, cs, sc->map->rnx, sc->map->rny, sc->map->d_raster);
   FO_HIP_TRY(ctx, hipGetLastError());
   FO_HIP_TRY(ctx, hipDeviceSynchronize());
-  (void)hipFree(d_off); (void)hipFree(d_xy); (void)hipFree(d_box);
+  sc->map->d_poly_off = d_off; sc->map->d_poly_xy = d_xy; sc->map->d_poly_box = d_box;   // kept: the rule families test points against them
+  sc->map->n_inter = 0;
   if (h_lane_yaw_or_null) {
     FO_HIP_TRY(ctx, hipMalloc((void **)&sc->map->d_lane_yaw, sizeof(double) * cells));
     FO_HIP_TRY(ctx, hipMemcpy(sc->map->d_lane_yaw, h_lane_yaw_or_null, sizeof(double) * cells, hipMemcpyHostToDevice));
@@ -1242,6 +1260,11 @@ int fo_scene_set_routes(fo_ctx *ctx, int P, int R, const int32_t *h_first, const
   for (int i = 0; i < P * R; ++i)
     if (h_count[i] < 0 || h_first[i] < 0 || (long)h_first[i] + h_count[i] > NV)
       return fo_fail(ctx, FO_E_ARG, "fo_scene_set_routes: route %d leaves the vertex table", i);
+  // the tables belong to the map: while other contexts read it, freeing them here would pull them away under their
+  // kernels (and change the route count R for every ego)
+  if (sc->map->refs.load() > 1)
+    return fo_fail(ctx, FO_E_STATE, "fo_scene_set_routes: the static map is shared (fo_scene_share_map); set the routes on "
+                                    "the owner before sharing, or give this context its own map with fo_scene_set_map");
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (void **p : {(void **)&sc->map->d_route_first, (void **)&sc->map->d_route_count, (void **)&sc->map->d_lanelet_raster,
                    (void **)&sc->map->d_route_xy, (void **)&sc->map->d_route_s}) {
@@ -1289,6 +1312,9 @@ int fo_scene_set_edge_lines(fo_ctx *ctx, int E, const int32_t *h_line) {
   if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_set_edge_lines: call fo_scene_set_map first");
   Scene *sc = (Scene *)ctx->scene;
   if (E != sc->map->E || (E > 0 && !h_line)) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_edge_lines: E must match the map");
+  if (sc->map->refs.load() > 1)
+    return fo_fail(ctx, FO_E_STATE, "fo_scene_set_edge_lines: the static map is shared (fo_scene_share_map); set the labels "
+                                    "on the owner before sharing, or give this context its own map with fo_scene_set_map");
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (sc->map->d_edge_line) { (void)hipFree(sc->map->d_edge_line); sc->map->d_edge_line = nullptr; }
   if (E == 0) return FO_OK;
@@ -1432,3 +1458,5 @@ int fo_scene_candidate_count(fo_ctx *ctx, int32_t *h_n, void *stream) {
 }
 
 }  // extern "C"
+
+#include "fo_spawn_rules.hpp"   // the reference's three spawn rule families on the cell classes (same translation unit: they read the map)

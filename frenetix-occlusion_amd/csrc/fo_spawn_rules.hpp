@@ -1,0 +1,849 @@
+// fo_spawn_rules.hpp -- the reference's three spawn rule families on the per-step cell classes, on the device.
+// Included at the end of fo_scene.hip (one translation unit: the kernels read the static map), compiled with
+// -ffp-contract=off like the rest of the scene stage.
+//
+// Replaces SpawnLocator.find_spawn_points' rule functions (ref: spawn_locator.py:80-139):
+//   pedestrian behind a visible static obstacle   spawn_locator.py:323-476
+//   pedestrian behind a turn                       spawn_locator.py:481-578
+//   Car / Bicycle behind a visible dynamic obstacle  spawn_locator.py:145-317, rectangle fit :695-726
+// The reference asks shapely for intersections of lines, buffers and polygons with the visible / occluded AREAS; here
+// the same predicates are asked of the cell classes of fo_scene_visibility ("Rule families on cells"):
+//   line.intersects(area)             -> a sample of the line (every cs/8) lies in a cell of that class
+//   point.buffer(r).intersects(area)  -> the disc touches a cell square of that class
+//   point.buffer(r).within(road)      -> every cell square the disc touches is road
+//   area.buffer(b).exterior & line    -> samples where "disc of radius b touches the area" flips along the line
+// The curvilinear frame is the polyline frame of the ego's reference path (utils/curvilinear.PolylineCS; the table
+// [n][6] = x, y, s, segment length, unit tangent is built on the host once per reference path).
+// Checked against oracle/fo_spawn_rules_ref.py (an independent NumPy restatement of the same definitions).
+//
+// Launch shape: one workgroup for the turn rule + one per obstacle (static rule: a wave; dynamic rule: 256 threads and
+// 76 KB of LDS for the 97 x 97 candidate lattice), then one small workgroup that applies what depends on the order of
+// the obstacles (sorted by distance, the maxima of the YAML, 5 m between pedestrians) and writes the spawn points.
+
+namespace {
+
+constexpr double RL_MAX_DIST_OBST = 30.0;          // spawn_locator.py:69
+constexpr double RL_MIN_DIST_PED = 5.0;            // :73
+constexpr double RL_TOL_SAME_DIR = 20.0 / 180.0 * 3.14159265358979323846;   // :68
+constexpr double RL_BUFFER_SIDE = 12.0;            // :70
+constexpr double RL_MIN_AREA = 10.0;               // :71
+constexpr double RL_AREA_CAR = 9.0, RL_AREA_BIKE = 1.7;   // :72
+constexpr int RL_LAT = 97;                         // nodes per side of the 0.25 m candidate lattice (2 x 12 m + 1)
+constexpr int RL_MAXSAMP = 1024;                   // samples of a rule polyline (cs/8 steps; 40 m at cs = 0.5 -> 641)
+constexpr int RL_REC = 24;                         // doubles per per-workgroup record
+
+enum { RL_TYPE_CAR = 0, RL_TYPE_BICYCLE = 3, RL_TYPE_PED = 4 };
+enum { RL_SRC_DYNAMIC = 1, RL_SRC_STATIC = 2, RL_SRC_LEFT = 3, RL_SRC_RIGHT = 4 };
+
+struct RuleView {
+  const uint8_t *cls;       // [ny][nx] class bits of the step (1 road, 2 visible, 4 occluded)
+  int ix0, iy0, nx, ny;     // window inside the raster
+  double x0, y0, cs;        // raster origin, cell size
+  const double *lane_yaw;   // [rny][rnx] or null
+  int rnx, rny;
+  int P;
+  const int32_t *poly_off;
+  const double *poly_xy, *poly_box;
+  const double *left0;      // [P][2] or null
+  const int32_t *pred0, *adj_left;
+  int n_inter;
+  const int32_t *inter_off, *inter_lanelet;
+  const uint8_t *inter_kind;
+  const double *path;       // [n_path][6] x, y, s, segment length, tangent x, tangent y
+  int n_path;
+};
+
+__device__ inline int rl_class_at(const RuleView &v, double x, double y) {
+  const int ix = (int)floor((x - v.x0) / v.cs) - v.ix0, iy = (int)floor((y - v.y0) / v.cs) - v.iy0;
+  return (ix >= 0 && ix < v.nx && iy >= 0 && iy < v.ny) ? (int)v.cls[(size_t)iy * v.nx + ix] : 0;
+}
+
+// classes of the cell squares a disc touches: any has `bit` / all have `bit` (cells outside the window count as class 0)
+__device__ inline void rl_disc(const RuleView &v, double x, double y, double rad, int bit, bool &any, bool &all) {
+  const int ix0 = (int)floor((x - rad - v.x0) / v.cs) - v.ix0, iy0 = (int)floor((y - rad - v.y0) / v.cs) - v.iy0;
+  const int ix1 = (int)floor((x + rad - v.x0) / v.cs) - v.ix0, iy1 = (int)floor((y + rad - v.y0) / v.cs) - v.iy0;
+  any = false;
+  all = true;
+  for (int iy = iy0; iy <= iy1; ++iy)
+    for (int ix = ix0; ix <= ix1; ++ix) {
+      const double xl = v.x0 + (double)(v.ix0 + ix) * v.cs, yl = v.y0 + (double)(v.iy0 + iy) * v.cs;
+      const double qx = fmin(fmax(x, xl), xl + v.cs), qy = fmin(fmax(y, yl), yl + v.cs);
+      if ((qx - x) * (qx - x) + (qy - y) * (qy - y) <= rad * rad) {
+        const int c = (ix >= 0 && ix < v.nx && iy >= 0 && iy < v.ny) ? (int)v.cls[(size_t)iy * v.nx + ix] : 0;
+        if (c & bit) any = true; else all = false;
+      }
+    }
+}
+__device__ inline bool rl_disc_touches(const RuleView &v, double x, double y, double rad, int bit) {
+  bool any, all;
+  rl_disc(v, x, y, rad, bit, any, all);
+  return any;
+}
+
+__device__ inline bool rl_lane_yaw_at(const RuleView &v, double x, double y, double &yaw) {
+  if (!v.lane_yaw) return false;
+  const int ix = (int)floor((x - v.x0) / v.cs), iy = (int)floor((y - v.y0) / v.cs);
+  if (ix < 0 || ix >= v.rnx || iy < 0 || iy >= v.rny) return false;
+  yaw = v.lane_yaw[(size_t)iy * v.rnx + ix];
+  return yaw == yaw;
+}
+
+// crossing-number test, the rule of the road raster (half-open in y)
+__device__ inline bool rl_in_polygon(const RuleView &v, int p, double x, double y) {
+  const double *bb = v.poly_box + 4 * (size_t)p;
+  if (x < bb[0] || x > bb[2] || y < bb[1] || y > bb[3]) return false;
+  const int b = v.poly_off[p], e = v.poly_off[p + 1];
+  int c = 0;
+  for (int i = b, j = e - 1; i < e; j = i++) {
+    const double xi = v.poly_xy[2 * i], yi = v.poly_xy[2 * i + 1], xj = v.poly_xy[2 * j], yj = v.poly_xy[2 * j + 1];
+    if ((yi > y) != (yj > y)) {
+      const double xc = xi + (y - yi) * (xj - xi) / (yj - yi);
+      if (x < xc) c ^= 1;
+    }
+  }
+  return c != 0;
+}
+__device__ inline int rl_lanelet_of(const RuleView &v, double x, double y) {   // first lanelet (list order) holding the point
+  for (int p = 0; p < v.P; ++p)
+    if (rl_in_polygon(v, p, x, y)) return p;
+  return -1;
+}
+
+// ---- polyline frame (utils/curvilinear.PolylineCS): d positive to the left; false outside the projection domain
+__device__ inline bool rl_to_curv(const RuleView &v, double x, double y, double &s, double &d) {
+  const int ns = v.n_path - 1;
+  double best = INFINITY, bt = 0.0, btc = 0.0;
+  int k = 0;
+  for (int i = 0; i < ns; ++i) {
+    const double *q = v.path + 6 * (size_t)i;
+    const double t = (x - q[0]) * q[4] + (y - q[1]) * q[5];
+    const double tc = fmin(fmax(t, 0.0), q[3]);
+    const double fx = q[0] + tc * q[4], fy = q[1] + tc * q[5];
+    const double d2 = (x - fx) * (x - fx) + (y - fy) * (y - fy);
+    if (d2 < best) { best = d2; k = i; bt = t; btc = tc; }
+  }
+  const double *q = v.path + 6 * (size_t)k;
+  if ((k == 0 && bt < 0.0) || (k == ns - 1 && bt > q[3])) return false;
+  const double fx = q[0] + btc * q[4], fy = q[1] + btc * q[5];
+  s = q[2] + btc;
+  d = (x - fx) * (-q[5]) + (y - fy) * q[4];
+  return true;
+}
+__device__ inline bool rl_to_cart(const RuleView &v, double s, double d, double &x, double &y) {
+  const int n = v.n_path;
+  if (s < v.path[2] || s > v.path[6 * (size_t)(n - 1) + 2]) return false;
+  int lo = 0, hi = n;   // searchsorted(s_table, s, side = 'right'): first index with table > s
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (v.path[6 * (size_t)mid + 2] <= s) lo = mid + 1; else hi = mid;
+  }
+  const int k = min(lo - 1, n - 2);
+  const double *q = v.path + 6 * (size_t)k;
+  x = q[0] + (s - q[2]) * q[4] + d * (-q[5]);
+  y = q[1] + (s - q[2]) * q[5] + d * q[4];
+  return true;
+}
+
+// distance between segment ab and a convex quadrilateral c [4][2] (0 if they touch or the segment starts / ends inside)
+__device__ inline double rl_pt_seg(double px, double py, double ax, double ay, double bx, double by) {
+  const double dx = bx - ax, dy = by - ay, l2 = dx * dx + dy * dy;
+  double t = 0.0;
+  if (l2 != 0.0) t = fmin(1.0, fmax(0.0, ((px - ax) * dx + (py - ay) * dy) / l2));
+  const double qx = px - (ax + t * dx), qy = py - (ay + t * dy);
+  return sqrt(qx * qx + qy * qy);
+}
+__device__ inline bool rl_inside_quad(double px, double py, const double *c) {
+  int sgn = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int j = (i + 1) & 3;
+    const double cr = (c[2 * j] - c[2 * i]) * (py - c[2 * i + 1]) - (c[2 * j + 1] - c[2 * i + 1]) * (px - c[2 * i]);
+    if (fabs(cr) > 1e-12) {
+      if (sgn == 0) sgn = cr > 0 ? 1 : -1;
+      else if ((cr > 0) != (sgn > 0)) return false;
+    }
+  }
+  return true;
+}
+__device__ inline double rl_seg_rect_distance(double ax, double ay, double bx, double by, const double *c) {
+  if (rl_inside_quad(ax, ay, c) || rl_inside_quad(bx, by, c)) return 0.0;
+  double best = INFINITY;
+  for (int i = 0; i < 4; ++i) {
+    const int j = (i + 1) & 3;
+    const double p3x = c[2 * i], p3y = c[2 * i + 1], p4x = c[2 * j], p4y = c[2 * j + 1];
+    const double d1x = bx - ax, d1y = by - ay, d2x = p4x - p3x, d2y = p4y - p3y;
+    const double den = d1x * d2y - d1y * d2x;
+    if (fabs(den) > 1e-14) {
+      const double wx = p3x - ax, wy = p3y - ay;
+      const double t = (wx * d2y - wy * d2x) / den, u = (wx * d1y - wy * d1x) / den;
+      if (t >= 0.0 && t <= 1.0 && u >= 0.0 && u <= 1.0) return 0.0;
+    }
+    best = fmin(best, fmin(fmin(rl_pt_seg(ax, ay, p3x, p3y, p4x, p4y), rl_pt_seg(bx, by, p3x, p3y, p4x, p4y)),
+                           fmin(rl_pt_seg(p3x, p3y, ax, ay, bx, by), rl_pt_seg(p4x, p4y, ax, ay, bx, by))));
+  }
+  return best;
+}
+
+struct RuleParams {
+  double ego_x, ego_y, ego_yaw, ego_s, ego_d, s_threshold;
+  double ped_width, ped_length;
+  int intention;                 // 0 straight ahead, 1 left turn, 2 right turn
+  int win_i0, win_i1;            // reference window = path vertices [i0, i1)
+  int behind_static, behind_turn, behind_dynamic, max_static, max_dynamic;
+};
+
+// sample i of a polyline with cumulative lengths cum[] (np.interp on both coordinates); n_s samples, step apart, the
+// last one clamped to the end
+__device__ inline void rl_sample(const double *px, const double *py, const double *cum, int n, double q, double &x, double &y) {
+  if (q >= cum[n - 1]) { x = px[n - 1]; y = py[n - 1]; return; }
+  int lo = 0, hi = n - 1;   // largest j with cum[j] <= q
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cum[mid] <= q) lo = mid; else hi = mid - 1;
+  }
+  const double w = cum[lo + 1] - cum[lo];
+  x = (px[lo + 1] - px[lo]) / w * (q - cum[lo]) + px[lo];
+  y = (py[lo + 1] - py[lo]) / w * (q - cum[lo]) + py[lo];
+}
+
+// ---------------------------------------------------------------- pedestrian behind a turn (one wave)
+// rec: [0] valid, [1] x, [2] y, [3] s_ph, [4] d (the lateral phantom offset), [5] source
+__device__ void rl_turn_rule(const RuleView &v, const RuleParams &pr, double *rec, double *lx, double *ly, double *cum,
+                             unsigned char *inside) {
+  const int lane = threadIdx.x & 63;
+  if (lane == 0) rec[0] = 0.0;
+  const int nw = pr.win_i1 - pr.win_i0;
+  if (nw < 2 || nw > 256) return;
+  const bool left = pr.intention == 1;
+  // the line: the reference window, for a left turn shifted 3 m to the left (spawn_locator.py:510-518)
+  bool ok = true;
+  for (int i = lane; i < nw; i += 64) {
+    const double *q = v.path + 6 * (size_t)(pr.win_i0 + i);
+    double x = q[0], y = q[1];
+    if (left) ok = rl_to_cart(v, q[2], 3.0, x, y) && ok;
+    lx[i] = x;
+    ly[i] = y;
+  }
+  if (__ballot(!ok)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane == 0) {
+    cum[0] = 0.0;
+    for (int i = 1; i < nw; ++i) cum[i] = cum[i - 1] + sqrt((lx[i] - lx[i - 1]) * (lx[i] - lx[i - 1]) + (ly[i] - ly[i - 1]) * (ly[i] - ly[i - 1]));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const double total = cum[nw - 1], step = v.cs / 8.0;
+  if (!(total > 0.0)) return;
+  int ns = (int)ceil((total + 0.5 * step) / step);
+  if (ns > RL_MAXSAMP) ns = RL_MAXSAMP;
+  for (int i = lane; i < ns; i += 64) {
+    double x, y;
+    rl_sample(lx, ly, cum, nw, fmin((double)i * step, total), x, y);
+    inside[i] = (rl_class_at(v, x, y) & 4) ? 1 : 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane != 0) return;
+  // runs of consecutive samples in occluded cells: the first point of the only run, of the LAST run when there are several (:528)
+  int n_runs = 0, first_of_last = -1;
+  for (int i = 0; i < ns; ++i)
+    if (inside[i] && (i == 0 || !inside[i - 1])) { ++n_runs; first_of_last = i; }
+  if (n_runs == 0) return;
+  double fx, fy;
+  rl_sample(lx, ly, cum, nw, fmin((double)first_of_last * step, total), fx, fy);
+  double s_int, d_int;
+  if (!rl_to_curv(v, fx, fy, s_int, d_int)) return;
+  double s_ph = s_int + (left ? -0.5 : 0.0);
+  if (s_ph > pr.s_threshold || s_ph < pr.ego_s + 3.0) return;                    // :542
+  const double d_ph = left ? 1.0 : -1.0, d_off = d_ph + (left ? 3.0 : 0.0);     // :546
+  double x, y;
+  if (!rl_to_cart(v, s_ph, d_off, x, y)) return;
+  while (rl_disc_touches(v, x, y, 0.5, 2)) {                                     // :552-554
+    s_ph += 0.5;
+    if (!rl_to_cart(v, s_ph, d_off, x, y)) return;
+  }
+  rec[1] = x; rec[2] = y; rec[3] = s_ph; rec[4] = d_ph; rec[5] = left ? RL_SRC_LEFT : RL_SRC_RIGHT;
+  rec[0] = 1.0;   // (the obstacle and heading conditions, :557-572, are applied by the selection workgroup)
+}
+
+// ---------------------------------------------------------------- pedestrian behind a static obstacle (one wave)
+// rec: [0] distance to the ego, [1] role (1 static candidate, 2 dynamic candidate, 0 nothing), per line li = 0, 1:
+// [2 + 6 li] valid, x, y, s, d, yaw
+__device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, int O, const double *ocorn, const double *ocen,
+                               const uint8_t *oflags, const uint8_t *ovis, double *rec, double *sx, double *sy,
+                               unsigned char *near) {
+  const int lane = threadIdx.x & 63;
+  const double cx = ocen[2 * o], cy = ocen[2 * o + 1];
+  const double *oc = ocorn + 8 * (size_t)o;
+  if (lane == 0) { rec[2] = 0.0; rec[8] = 0.0; }
+  if (sqrt((pr.ego_x - cx) * (pr.ego_x - cx) + (pr.ego_y - cy) * (pr.ego_y - cy)) > RL_MAX_DIST_OBST) return;   // :369
+  double ob_s, ob_d;
+  if (!rl_to_curv(v, cx, cy, ob_s, ob_d)) return;
+  // :380 compares with ego s + s_threshold although s_threshold already contains ego s (kept as in the reference)
+  if (pr.ego_s + pr.s_threshold < ob_s || ob_s < pr.ego_s + 3.0) return;
+  double s_min = INFINITY, s_max = -INFINITY, d_min = INFINITY, d_max = -INFINITY;
+  for (int i = 0; i < 4; ++i) {
+    double s, d;
+    if (!rl_to_curv(v, oc[2 * i], oc[2 * i + 1], s, d)) return;
+    s_min = fmin(s_min, s); s_max = fmax(s_max, s); d_min = fmin(d_min, d); d_max = fmax(d_max, d);
+  }
+  s_min -= 0.8; s_max += 0.8; d_min -= 0.8; d_max += 0.8;                          // :384-390
+  double yaw_l = 0.0;
+  const bool have_yaw = rl_lane_yaw_at(v, cx, cy, yaw_l);
+  for (int li = 0; li < 2; ++li) {
+    const double s_line = li == 0 ? s_min : s_max;
+    double ax, ay, bx, by;
+    if (!rl_to_cart(v, s_line, d_min, ax, ay) || !rl_to_cart(v, s_line, d_max, bx, by)) continue;
+    const double total = sqrt((bx - ax) * (bx - ax) + (by - ay) * (by - ay)), step = v.cs / 8.0;
+    if (!(total > 0.0)) continue;
+    int ns = (int)ceil((total + 0.5 * step) / step);
+    if (ns > RL_MAXSAMP) ns = RL_MAXSAMP;
+    const double b = pr.ped_length / 2.0 * 1.3;                                    // :414
+    bool t_occ = false, t_vis = false;
+    for (int i = lane; i < ns; i += 64) {
+      const double q = fmin((double)i * step, total);
+      double x = bx, y = by;
+      if (q < total) { x = (bx - ax) / total * q + ax; y = (by - ay) / total * q + ay; }
+      sx[i] = x; sy[i] = y;
+      const int c = rl_class_at(v, x, y);
+      t_occ = t_occ || (c & 4);
+      t_vis = t_vis || (c & 2);
+      near[i] = rl_disc_touches(v, x, y, b, 2) ? 1 : 0;
+    }
+    if (!__ballot(t_occ) || !__ballot(t_vis)) continue;                           // :406-408
+    bool blocked = false;                                                         // :409-411: any VISIBLE obstacle within half a pedestrian width
+    for (int j = lane; j < O; j += 64)
+      if ((oflags[j] & 1) && ovis[j] && rl_seg_rect_distance(ax, ay, bx, by, ocorn + 8 * (size_t)j) <= pr.ped_width / 2.0) blocked = true;
+    if (__ballot(blocked)) continue;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) {
+      // candidates: where "the disc touches the visible area" flips, the sample just outside (:414-415)
+      int n_c = 0;
+      double spx = 0.0, spy = 0.0;
+      bool found = false;
+      int only = -1;
+      for (int i = 0; i + 1 < ns; ++i)
+        if (near[i] != near[i + 1]) { ++n_c; only = near[i] ? i + 1 : i; }
+      if (n_c == 1) {
+        spx = sx[only]; spy = sy[only]; found = true;
+      } else if (n_c > 1) {                                                       // MultiPoint (:419-433): nearest to the lanelet's first left vertex, inside the occluded area
+        const int ll = rl_lanelet_of(v, cx, cy);
+        const double anx = (ll >= 0 && v.left0) ? v.left0[2 * ll] : cx, any_ = (ll >= 0 && v.left0) ? v.left0[2 * ll + 1] : cy;
+        double bestd = INFINITY;
+        for (int i = 0; i + 1 < ns; ++i)
+          if (near[i] != near[i + 1]) {
+            const int c = near[i] ? i + 1 : i;
+            const double dd = sqrt((anx - sx[c]) * (anx - sx[c]) + (any_ - sy[c]) * (any_ - sy[c]));
+            if ((rl_class_at(v, sx[c], sy[c]) & 4) && dd < bestd) { bestd = dd; spx = sx[c]; spy = sy[c]; found = true; }
+          }
+      }
+      bool okp = found;
+      if (okp) {
+        bool any, all;
+        rl_disc(v, spx, spy, 0.15, 2, any, all);
+        if (any) okp = false;                                                     // :440
+        rl_disc(v, spx, spy, 0.15, 1, any, all);
+        if (!all) okp = false;                                                    // :444
+      }
+      double ss = 0.0, sd = 0.0;
+      if (okp && !rl_to_curv(v, spx, spy, ss, sd)) okp = false;
+      if (okp && !have_yaw) okp = false;
+      double *r = rec + 2 + 6 * li;
+      r[0] = okp ? 1.0 : 0.0; r[1] = spx; r[2] = spy; r[3] = ss; r[4] = sd; r[5] = yaw_l + 1.5707963267948966;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+// ---------------------------------------------------------------- Car / Bicycle behind a dynamic obstacle (a workgroup)
+struct RlFit { double area, cx, cy, jac; bool any; };
+
+// rec: [0] distance, [1] role = 2, [2] car valid, [3] car x, [4] car y, [5] bicycle valid, [6] x, [7] y
+__device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, const double *ocorn, const double *ocen,
+                                const double *oyaw, const double *odims, double *rec, int *lab, double *red, int *ired,
+                                unsigned char *fitok) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const double cx = ocen[2 * o], cy = ocen[2 * o + 1], oy = oyaw[o], olen = odims[2 * o], owid = odims[2 * o + 1];
+  const double *oc = ocorn + 8 * (size_t)o;
+  __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn;
+  __shared__ double s_c[2], s_yaw;
+  if (tid == 0) {
+    rec[2] = 0.0; rec[5] = 0.0;
+    s_go = 0;
+    s_npol = 0;
+    do {
+      if (sqrt((pr.ego_x - cx) * (pr.ego_x - cx) + (pr.ego_y - cy) * (pr.ego_y - cy)) > RL_MAX_DIST_OBST) break;   // :215
+      // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
+      // oncoming neighbours (adj_left) of the lanelets under every fifth vertex of the reference window
+      const int ego_ll = rl_lanelet_of(v, pr.ego_x, pr.ego_y);
+      if (ego_ll < 0) break;
+      int inter = -1;
+      for (int it = 0; it < v.n_inter && inter < 0; ++it)
+        for (int e = v.inter_off[it]; e < v.inter_off[it + 1]; ++e)
+          if (v.inter_lanelet[e] == ego_ll) { inter = it; break; }
+      auto relevant = [&](int p) {
+        if (inter >= 0) {
+          if (p == ego_ll) return false;
+          for (int e = v.inter_off[inter]; e < v.inter_off[inter + 1]; ++e)
+            if (v.inter_lanelet[e] == p) return true;
+          return false;
+        }
+        for (int i = pr.win_i0; i < pr.win_i1; i += 5) {
+          const double *q = v.path + 6 * (size_t)i;
+          const int ll = rl_lanelet_of(v, q[0], q[1]);
+          if (ll >= 0 && v.adj_left && v.adj_left[ll] == p) return true;
+        }
+        return false;
+      };
+      auto inner = [&](int p) {
+        if (inter < 0) return false;
+        for (int e = v.inter_off[inter]; e < v.inter_off[inter + 1]; ++e)
+          if (v.inter_lanelet[e] == p && v.inter_kind[e] == 1) return true;
+        return false;
+      };
+      // the obstacle's lanelets (all that hold its centre, list order)
+      int n_ob = 0, first_rel = -1;
+      bool any_rel = false, all_inner = true;
+      for (int p = 0; p < v.P; ++p)
+        if (rl_in_polygon(v, p, cx, cy)) {
+          ++n_ob;
+          const bool rel = relevant(p);
+          if (rel) { any_rel = true; if (first_rel < 0) first_rel = p; if (s_npol < 7) s_pol[s_npol++] = p; }
+          if (!inner(p)) all_inner = false;
+        }
+      if (!any_rel) break;                                                        // :222
+      double ob_s, ob_d;
+      if (!rl_to_curv(v, cx, cy, ob_s, ob_d)) break;
+      if (ob_s < pr.ego_s + 3.0 || fabs(ob_d) > 15.0) break;                      // :234
+      if (inter >= 0 && n_ob > 0 && all_inner && v.pred0 && v.pred0[first_rel] >= 0 && s_npol < 8) s_pol[s_npol++] = v.pred0[first_rel];   // :249-252
+      s_go = 1;
+    } while (false);
+  }
+  __syncthreads();
+  if (!s_go) return;
+  const int npol = s_npol;
+  // membership of a point in the candidate region's defining sets (:254-277)
+  const double diff = fmod(fabs(oy - pr.ego_yaw), 6.283185307179586);
+  const bool wedge = 3.141592653589793 - RL_TOL_SAME_DIR <= diff && diff <= 3.141592653589793 + RL_TOL_SAME_DIR;
+  const double oc_c = cos(oy), oc_s = sin(oy);
+  auto member = [&](double x, double y) {
+    bool ok = false;
+    for (int i = 0; i < npol && !ok; ++i) ok = rl_in_polygon(v, s_pol[i], x, y);
+    if (!ok) return false;
+    if (wedge) {   // the obstacle's own shadow: the sight line ego -> point crosses the rectangle (:264)
+      bool hit = false;
+      const double dx = x - pr.ego_x, dy = y - pr.ego_y;
+      for (int i = 0; i < 4 && !hit; ++i) {
+        const int j = (i + 1) & 3;
+        const double ex = oc[2 * j] - oc[2 * i], ey = oc[2 * j + 1] - oc[2 * i + 1];
+        const double den = dx * ey - dy * ex, wx = oc[2 * i] - pr.ego_x, wy = oc[2 * i + 1] - pr.ego_y;
+        if (fabs(den) > 1e-14) {
+          const double t = (wx * ey - wy * ex) / den, u = (wx * dy - wy * dx) / den;
+          hit = t >= 0.0 && t <= 1.0 && u >= 0.0 && u <= 1.0;
+        }
+      }
+      if (!hit) return false;
+    } else if (!(rl_class_at(v, x, y) & 4)) {   // the global occluded area (:272)
+      return false;
+    }
+    const double rx = x - cx, ry = y - cy;
+    if (!(sqrt(rx * rx + ry * ry) <= RL_BUFFER_SIDE)) return false;
+    const double lx_ = oc_c * rx + oc_s * ry, ly_ = -oc_s * rx + oc_c * ry;
+    const double ex = fmax(fabs(lx_) - olen / 2.0, 0.0), ey = fmax(fabs(ly_) - owid / 2.0, 0.0);
+    return sqrt(ex * ex + ey * ey) > 1.0;                                         // minus the obstacle grown by 1 m
+  };
+  // the 0.25 m lattice around the obstacle; label = linear index where the node is a member, INT_MAX elsewhere
+  const double h = 0.25;
+  constexpr int NL = RL_LAT * RL_LAT;
+  for (int i = tid; i < NL; i += nth) {
+    const int ix = i % RL_LAT, iy = i / RL_LAT;
+    lab[i] = member(cx + (-RL_BUFFER_SIDE + (double)ix * h), cy + (-RL_BUFFER_SIDE + (double)iy * h)) ? i : 0x7fffffff;
+  }
+  __syncthreads();
+  // connected parts (4-neighbourhood, scipy.ndimage.label's default): minimum-label propagation, whole rows then whole
+  // columns per round; every part ends up carrying its smallest linear index (= scipy's numbering order)
+  for (int round = 0; round < 64; ++round) {
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    bool ch = false;
+    if (tid < RL_LAT) {
+      int *row = lab + tid * RL_LAT;
+      for (int c = 1; c < RL_LAT; ++c)
+        if (row[c] != 0x7fffffff && row[c - 1] != 0x7fffffff && row[c - 1] < row[c]) { row[c] = row[c - 1]; ch = true; }
+      for (int c = RL_LAT - 2; c >= 0; --c)
+        if (row[c] != 0x7fffffff && row[c + 1] != 0x7fffffff && row[c + 1] < row[c]) { row[c] = row[c + 1]; ch = true; }
+    }
+    __syncthreads();
+    if (tid < RL_LAT) {
+      int *col = lab + tid;
+      for (int r = 1; r < RL_LAT; ++r)
+        if (col[r * RL_LAT] != 0x7fffffff && col[(r - 1) * RL_LAT] != 0x7fffffff && col[(r - 1) * RL_LAT] < col[r * RL_LAT]) { col[r * RL_LAT] = col[(r - 1) * RL_LAT]; ch = true; }
+      for (int r = RL_LAT - 2; r >= 0; --r)
+        if (col[r * RL_LAT] != 0x7fffffff && col[(r + 1) * RL_LAT] != 0x7fffffff && col[(r + 1) * RL_LAT] < col[r * RL_LAT]) { col[r * RL_LAT] = col[(r + 1) * RL_LAT]; ch = true; }
+    }
+    if (ch) s_changed = 1;
+    __syncthreads();
+    if (!s_changed) break;
+    __syncthreads();
+  }
+  // the largest part (first maximum in label order, :279-281): sizes by the roots' labels
+  if (tid == 0) { s_best = -1; s_bestn = 0; }
+  for (int i = tid; i < NL; i += nth) ired[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < NL; i += nth)
+    if (lab[i] != 0x7fffffff) atomicAdd(&ired[lab[i]], 1);
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 0; i < NL; ++i)
+      if (ired[i] > s_bestn) { s_bestn = ired[i]; s_best = i; }
+  }
+  __syncthreads();
+  const int best = s_best;
+  if (best < 0 || (double)s_bestn * h * h < RL_MIN_AREA) return;                  // :282-284
+  // centroid of the part (mean of its nodes; fixed summation order: per-thread partials, then thread 0)
+  double ax = 0.0, ay = 0.0;
+  for (int i = tid; i < NL; i += nth)
+    if (lab[i] == best) { ax += cx + (-RL_BUFFER_SIDE + (double)(i % RL_LAT) * h); ay += cy + (-RL_BUFFER_SIDE + (double)(i / RL_LAT) * h); }
+  red[2 * tid] = ax; red[2 * tid + 1] = ay;
+  __syncthreads();
+  if (tid == 0) {
+    double sx_ = 0.0, sy_ = 0.0;
+    for (int i = 0; i < nth; ++i) { sx_ += red[2 * i]; sy_ += red[2 * i + 1]; }
+    s_c[0] = sx_ / (double)s_bestn; s_c[1] = sy_ / (double)s_bestn;
+  }
+  __syncthreads();
+  // membership of arbitrary points in the chosen part: the defining sets hold and the nearest lattice node belongs to it
+  auto in_region = [&](double x, double y) {
+    const int ix = (int)rint((x - (cx - RL_BUFFER_SIDE)) / h), iy = (int)rint((y - (cy - RL_BUFFER_SIDE)) / h);
+    if (ix < 0 || ix >= RL_LAT || iy < 0 || iy >= RL_LAT) return false;
+    return lab[iy * RL_LAT + ix] == best && member(x, y);
+  };
+  if (tid == 0) {
+    s_go = 0;
+    do {
+      // the centroid must lie on a relevant lanelet (:287-291); relevant = the polygons collected above minus a
+      // predecessor that was only added for the region -- so test the original relevant set again
+      const int ego_ll = rl_lanelet_of(v, pr.ego_x, pr.ego_y);
+      int inter = -1;
+      for (int it = 0; it < v.n_inter && inter < 0; ++it)
+        for (int e = v.inter_off[it]; e < v.inter_off[it + 1]; ++e)
+          if (v.inter_lanelet[e] == ego_ll) { inter = it; break; }
+      bool rel_c = false;
+      for (int p = 0; p < v.P && !rel_c; ++p)
+        if (rl_in_polygon(v, p, s_c[0], s_c[1])) {
+          if (inter >= 0) {
+            if (p != ego_ll)
+              for (int e = v.inter_off[inter]; e < v.inter_off[inter + 1]; ++e)
+                if (v.inter_lanelet[e] == p) rel_c = true;
+          } else {
+            for (int i = pr.win_i0; i < pr.win_i1 && !rel_c; i += 5) {
+              const double *q = v.path + 6 * (size_t)i;
+              const int ll = rl_lanelet_of(v, q[0], q[1]);
+              if (ll >= 0 && v.adj_left && v.adj_left[ll] == p) rel_c = true;
+            }
+          }
+        }
+      if (!rel_c) break;
+      if (in_region(cx + 4.0 * oc_c, cy + 4.0 * oc_s)) break;                      // the region in front of the obstacle (:297)
+      double yw;
+      if (!rl_lane_yaw_at(v, s_c[0], s_c[1], yw)) break;
+      s_yaw = yw;
+      s_go = 1;
+    } while (false);
+  }
+  __syncthreads();
+  if (!s_go) return;
+  // rectangle fits on a 0.1 m lattice (:695-726): lane-aligned rectangle clipped to the region -> area, centroid, Jaccard
+  // similarity with the minimum rotated rectangle of the clipped part
+  const double fc = cos(s_yaw), fs = sin(s_yaw);
+  __shared__ double s_fit[4];   // area, cx, cy, jaccard
+  __shared__ int s_fitany;
+  auto fit = [&](double ccx, double ccy, double length, double width) {
+    const double fh = 0.1;
+    const int nx_ = (int)rint(length / fh), ny_ = (int)rint(width / fh), np_ = nx_ * ny_;
+    int cnt = 0;
+    double fx = 0.0, fy = 0.0;
+    for (int i = tid; i < np_; i += nth) {
+      const double u = ((double)(i % nx_) + 0.5) * fh - length / 2.0, w_ = ((double)(i / nx_) + 0.5) * fh - width / 2.0;
+      const double x = ccx + fc * u - fs * w_, y = ccy + fs * u + fc * w_;
+      const bool ok = in_region(x, y);
+      fitok[i] = ok ? 1 : 0;
+      if (ok) { ++cnt; fx += x; fy += y; }
+    }
+    red[3 * tid] = fx; red[3 * tid + 1] = fy; red[3 * tid + 2] = (double)cnt;
+    __syncthreads();
+    if (tid == 0) {
+      double sx_ = 0.0, sy_ = 0.0, n = 0.0;
+      for (int i = 0; i < nth; ++i) { sx_ += red[3 * i]; sy_ += red[3 * i + 1]; n += red[3 * i + 2]; }
+      s_fitany = n > 0.0;
+      if (n > 0.0) {
+        s_fit[0] = n * fh * fh; s_fit[1] = sx_ / n; s_fit[2] = sy_ / n;
+        if ((int)n == np_) {
+          s_fit[3] = 1.0;
+        } else {
+          // convex hull of the clipped lattice points: the extreme points of every lattice row suffice (the rest of a
+          // row is collinear between them); monotone chain, then the smallest rectangle over the hull's edge directions
+          double hx[128], hy[128];
+          int nh = 0;
+          for (int r = 0; r < ny_; ++r) {
+            int a0 = -1, a1 = -1;
+            for (int c = 0; c < nx_; ++c)
+              if (fitok[r * nx_ + c]) { if (a0 < 0) a0 = c; a1 = c; }
+            for (int t = 0; t < 2 && a0 >= 0; ++t) {
+              const int c = t == 0 ? a0 : a1;
+              if (t == 1 && a1 == a0) break;
+              const double u = ((double)c + 0.5) * fh - length / 2.0, w_ = ((double)r + 0.5) * fh - width / 2.0;
+              hx[nh] = ccx + fc * u - fs * w_; hy[nh] = ccy + fs * u + fc * w_; ++nh;
+            }
+          }
+          for (int i = 1; i < nh; ++i) {   // sort by (x, y)
+            const double px = hx[i], py = hy[i];
+            int j = i - 1;
+            while (j >= 0 && (hx[j] > px || (hx[j] == px && hy[j] > py))) { hx[j + 1] = hx[j]; hy[j + 1] = hy[j]; --j; }
+            hx[j + 1] = px; hy[j + 1] = py;
+          }
+          double kx[130], ky[130];
+          int k = 0;
+          for (int i = 0; i < nh; ++i) {
+            while (k >= 2 && (kx[k - 1] - kx[k - 2]) * (hy[i] - ky[k - 2]) - (ky[k - 1] - ky[k - 2]) * (hx[i] - kx[k - 2]) <= 1e-12) --k;
+            kx[k] = hx[i]; ky[k] = hy[i]; ++k;
+          }
+          const int lower = k + 1;
+          for (int i = nh - 2; i >= 0; --i) {
+            while (k >= lower && (kx[k - 1] - kx[k - 2]) * (hy[i] - ky[k - 2]) - (ky[k - 1] - ky[k - 2]) * (hx[i] - kx[k - 2]) <= 1e-12) --k;
+            kx[k] = hx[i]; ky[k] = hy[i]; ++k;
+          }
+          const int nv = k - 1;   // the last point repeats the first
+          double bestA = INFINITY;
+          if (nv >= 3)
+            for (int i = 0; i < nv; ++i) {
+              double ex = kx[(i + 1) % nv] - kx[i], ey = ky[(i + 1) % nv] - ky[i];
+              const double nn = sqrt(ex * ex + ey * ey);
+              if (nn == 0.0) continue;
+              ex /= nn; ey /= nn;
+              double a1n = INFINITY, a1x = -INFINITY, a2n = INFINITY, a2x = -INFINITY;
+              for (int q = 0; q < nv; ++q) {
+                const double p1 = kx[q] * ex + ky[q] * ey, p2 = kx[q] * (-ey) + ky[q] * ex;
+                a1n = fmin(a1n, p1); a1x = fmax(a1x, p1); a2n = fmin(a2n, p2); a2x = fmax(a2x, p2);
+              }
+              bestA = fmin(bestA, (a1x - a1n + fh) * (a2x - a2n + fh));
+            }
+          s_fit[3] = nv >= 3 ? fmin(1.0, s_fit[0] / bestA) : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+  };
+  fit(s_c[0], s_c[1], 5.5, 2.5);
+  if (!s_fitany) return;
+  const double car_a = s_fit[0], car_x = s_fit[1], car_y = s_fit[2], car_j = s_fit[3];
+  __syncthreads();
+  fit(car_x, car_y, 2.0, 1.0);
+  if (tid == 0) {
+    if (car_a >= RL_AREA_CAR && car_j > 0.98) { rec[2] = 1.0; rec[3] = car_x; rec[4] = car_y; }
+    if (s_fitany && s_fit[0] >= RL_AREA_BIKE && s_fit[3] > 0.98) { rec[5] = 1.0; rec[6] = s_fit[1]; rec[7] = s_fit[2]; }
+  }
+}
+
+// flags of an obstacle at this step: bit0 present, bit1 occludes (not a bicycle), bit2 dynamic role, bit3 type bicycle or
+// pedestrian (never triggers the dynamic rule, :209-210)
+__global__ __launch_bounds__(256) void fo_spawn_rules_kernel(RuleView v, RuleParams pr, int O, const double *__restrict__ ocorn,
+                                                             const double *__restrict__ ocen, const double *__restrict__ oyaw,
+                                                             const double *__restrict__ odims, const uint8_t *__restrict__ oflags,
+                                                             const uint8_t *__restrict__ ovis, double *__restrict__ recs) {
+  // one LDS arena, carved per rule (the dynamic rule needs the two lattice arrays: 2 x 37.6 KB)
+  __shared__ int lab[RL_LAT * RL_LAT];
+  __shared__ int ired[RL_LAT * RL_LAT];
+  __shared__ double red[3 * 256];
+  __shared__ unsigned char bytes[2048];
+  double *rec = recs + (size_t)blockIdx.x * RL_REC;
+  if (threadIdx.x < RL_REC) rec[threadIdx.x] = 0.0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64 && pr.behind_turn && pr.intention != 0) {
+      double *lx = (double *)lab, *ly = lx + 256, *cum = ly + 256;
+      rl_turn_rule(v, pr, rec, lx, ly, cum, bytes);
+    }
+    return;
+  }
+  const int o = blockIdx.x - 1;
+  const bool vis = (oflags[o] & 1) && ovis[o];
+  const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
+  if (threadIdx.x == 0) rec[0] = sqrt(dx * dx + dy * dy);
+  if (!vis) return;
+  const bool dynamic = oflags[o] & 4;
+  if (!dynamic) {
+    if (threadIdx.x == 0) rec[1] = 1.0;
+    if (threadIdx.x < 64 && pr.behind_static)
+      rl_static_rule(v, pr, o, O, ocorn, ocen, oflags, ovis, rec, (double *)lab, (double *)lab + RL_MAXSAMP, bytes);
+    return;
+  }
+  if (oflags[o] & 8) return;                                   // bicycles and pedestrians (:209-210)
+  if (threadIdx.x == 0) rec[1] = 2.0;
+  if (pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1))   // straight ahead or left turn (:124-126)
+    rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes);
+}
+
+// what depends on the order of the obstacles: both lists sorted by distance (stable), the maxima of the YAML compared
+// with '>' BEFORE appending (Q11), 5 m in s between pedestrians; output order = the reference's (dynamic, static, turn).
+// out [max_out][8]: type code, x, y, yaw (NaN = none), s, d (NaN = none), source code, obstacle index (-1 = none)
+__global__ void fo_spawn_rules_select_kernel(RuleView v, RuleParams pr, int O, const double *__restrict__ ocorn,
+                                             const uint8_t *__restrict__ oflags, const uint8_t *__restrict__ ovis,
+                                             const double *__restrict__ recs, int max_out, double *__restrict__ out,
+                                             int32_t *__restrict__ n_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n = 0;
+  auto put = [&](double type, double x, double y, double yaw, double s, double d, double src, double ob) {
+    if (n < max_out) {
+      double *q = out + 8 * (size_t)n;
+      q[0] = type; q[1] = x; q[2] = y; q[3] = yaw; q[4] = s; q[5] = d; q[6] = src; q[7] = ob;
+    }
+    ++n;
+  };
+  // visit the obstacles of one role in ascending distance, ties in list order (a stable sort)
+  auto next_by_distance = [&](double role, double last_d, int last_o) {
+    int best = -1;
+    double bd = INFINITY;
+    for (int o = 0; o < O; ++o) {
+      const double *r = recs + (size_t)(1 + o) * RL_REC;
+      if (r[1] != role) continue;
+      const bool after = r[0] > last_d || (r[0] == last_d && o > last_o);
+      if (after && (r[0] < bd)) { bd = r[0]; best = o; }
+    }
+    return best;
+  };
+  if (pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1)) {
+    int n_dyn = 0, last_o = -1;
+    double last_d = -1.0;
+    for (;;) {
+      const int o = next_by_distance(2.0, last_d, last_o);
+      if (o < 0) break;
+      const double *r = recs + (size_t)(1 + o) * RL_REC;
+      last_d = r[0]; last_o = o;
+      if (n_dyn > pr.max_dynamic) break;                                           // :212
+      if (r[2] != 0.0) { put(RL_TYPE_CAR, r[3], r[4], NAN, NAN, NAN, RL_SRC_DYNAMIC, o); ++n_dyn; }
+      if (r[5] != 0.0) { put(RL_TYPE_BICYCLE, r[6], r[7], NAN, NAN, NAN, RL_SRC_DYNAMIC, o); ++n_dyn; }
+    }
+  }
+  if (pr.behind_static) {
+    double s_pos[16];
+    int n_st = 0, last_o = -1;
+    double last_d = -1.0;
+    for (;;) {
+      const int o = next_by_distance(1.0, last_d, last_o);
+      if (o < 0) break;
+      const double *r = recs + (size_t)(1 + o) * RL_REC;
+      last_d = r[0]; last_o = o;
+      if (n_st > pr.max_static) break;                                             // :365
+      for (int li = 0; li < 2; ++li) {
+        const double *q = r + 2 + 6 * li;
+        if (q[0] == 0.0) continue;
+        bool close = false;
+        for (int i = 0; i < n_st && i < 16; ++i) close = close || fabs(s_pos[i] - q[3]) <= RL_MIN_DIST_PED;   // :453
+        if (close) continue;
+        put(RL_TYPE_PED, q[1], q[2], q[5], q[3], q[4], RL_SRC_STATIC, o);
+        if (n_st < 16) s_pos[n_st] = q[3];
+        ++n_st;
+        break;                                                                     // one per obstacle
+      }
+    }
+  }
+  if (pr.behind_turn && pr.intention != 0) {
+    const double *r = recs;
+    if (r[0] != 0.0) {
+      bool ok = true;
+      for (int o = 0; o < O && ok; ++o)                                            // :557: no visible obstacle within the 0.5 m disc
+        if ((oflags[o] & 1) && ovis[o] && rl_seg_rect_distance(r[1], r[2], r[1], r[2], ocorn + 8 * (size_t)o) <= 0.5) ok = false;
+      double ye, yp;
+      if (ok && (!rl_lane_yaw_at(v, pr.ego_x, pr.ego_y, ye) || !rl_lane_yaw_at(v, r[1], r[2], yp))) ok = false;
+      if (ok) {                                                                    // :561-572: the lanelet there must head elsewhere (>= 45 deg)
+        double m = fmod(fabs(yp - ye), 6.283185307179586);
+        if (m < 45.0 / 180.0 * 3.141592653589793) ok = false;
+      }
+      if (ok) put(RL_TYPE_PED, r[1], r[2], NAN, r[3], r[4], r[5], -1.0);
+    }
+  }
+  *n_out = n < max_out ? n : max_out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fo_scene_set_topology(fo_ctx *ctx, int P, const double *h_left0, const int32_t *h_pred0, const int32_t *h_adj_left,
+                          int n_inter, const int32_t *h_inter_off, const int32_t *h_inter_lanelet,
+                          const uint8_t *h_inter_kind) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_set_topology: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  if (P != sc->map->P || !h_left0 || !h_pred0 || !h_adj_left || n_inter < 0 || (n_inter > 0 && (!h_inter_off || !h_inter_lanelet || !h_inter_kind)))
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_set_topology: bad arguments (P=%d, the map has %d lanelets)", P, sc->map->P);
+  if (sc->map->refs.load() > 1)
+    return fo_fail(ctx, FO_E_STATE, "fo_scene_set_topology: the static map is shared (fo_scene_share_map); set the topology on the owner before sharing");
+  for (int p = 0; p < P; ++p)
+    if (h_pred0[p] < -1 || h_pred0[p] >= P || h_adj_left[p] < -1 || h_adj_left[p] >= P)
+      return fo_fail(ctx, FO_E_ARG, "fo_scene_set_topology: lanelet index out of range at %d", p);
+  const int n_e = n_inter > 0 ? h_inter_off[n_inter] : 0;
+  for (int e = 0; e < n_e; ++e)
+    if (h_inter_lanelet[e] < 0 || h_inter_lanelet[e] >= P) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_topology: intersection entry %d out of range", e);
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  StaticMap *m = sc->map;
+  for (void **p : {(void **)&m->d_left0, (void **)&m->d_pred0, (void **)&m->d_adj_left, (void **)&m->d_inter_off,
+                   (void **)&m->d_inter_lanelet, (void **)&m->d_inter_kind}) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  }
+  FO_HIP_TRY(ctx, hipMalloc((void **)&m->d_left0, sizeof(double) * 2 * P));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&m->d_pred0, sizeof(int32_t) * P));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&m->d_adj_left, sizeof(int32_t) * P));
+  FO_HIP_TRY(ctx, hipMemcpy(m->d_left0, h_left0, sizeof(double) * 2 * P, hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMemcpy(m->d_pred0, h_pred0, sizeof(int32_t) * P, hipMemcpyHostToDevice));
+  FO_HIP_TRY(ctx, hipMemcpy(m->d_adj_left, h_adj_left, sizeof(int32_t) * P, hipMemcpyHostToDevice));
+  m->n_inter = n_inter;
+  if (n_inter > 0) {
+    FO_HIP_TRY(ctx, hipMalloc((void **)&m->d_inter_off, sizeof(int32_t) * (n_inter + 1)));
+    FO_HIP_TRY(ctx, hipMalloc((void **)&m->d_inter_lanelet, sizeof(int32_t) * (n_e > 0 ? n_e : 1)));
+    FO_HIP_TRY(ctx, hipMalloc((void **)&m->d_inter_kind, (size_t)(n_e > 0 ? n_e : 1)));
+    FO_HIP_TRY(ctx, hipMemcpy(m->d_inter_off, h_inter_off, sizeof(int32_t) * (n_inter + 1), hipMemcpyHostToDevice));
+    if (n_e > 0) {
+      FO_HIP_TRY(ctx, hipMemcpy(m->d_inter_lanelet, h_inter_lanelet, sizeof(int32_t) * n_e, hipMemcpyHostToDevice));
+      FO_HIP_TRY(ctx, hipMemcpy(m->d_inter_kind, h_inter_kind, (size_t)n_e, hipMemcpyHostToDevice));
+    }
+  }
+  return FO_OK;
+}
+
+int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, int n_path,
+                         const double *d_path6, int O, const double *d_ocorn, const double *d_ocen, const double *d_oyaw,
+                         const double *d_odims, const uint8_t *d_oflags, const uint8_t *d_obst_vis,
+                         const fo_spawn_rule_params_t *params, int max_out, double *d_out, int32_t *d_n_out, void *stream) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn_rules: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  StaticMap *m = sc->map;
+  if (!d_cls || !params || !d_out || !d_n_out || max_out < 1 || win_nx < 1 || win_ny < 1 || n_path < 2 || !d_path6 || O < 0 ||
+      (O > 0 && (!d_ocorn || !d_ocen || !d_oyaw || !d_odims || !d_oflags || !d_obst_vis)))
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: bad arguments (n_path=%d O=%d max_out=%d)", n_path, O, max_out);
+  if (!m->d_poly_off) return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn_rules: the map holds no lanelet polygons");
+  if (params->win_i0 < 0 || params->win_i1 > n_path || params->win_i1 < params->win_i0)
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: reference window [%d, %d) outside the path", params->win_i0, params->win_i1);
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = fo_reserve(ctx, &sc->d_rule_rec, &sc->cap_rule_rec, (size_t)(O + 1) * RL_REC))) return rc;
+  RuleView v{};
+  v.cls = d_cls; v.ix0 = win_ix0; v.iy0 = win_iy0; v.nx = win_nx; v.ny = win_ny;
+  v.x0 = m->x0; v.y0 = m->y0; v.cs = m->cs; v.lane_yaw = m->d_lane_yaw; v.rnx = m->rnx; v.rny = m->rny;
+  v.P = m->P; v.poly_off = m->d_poly_off; v.poly_xy = m->d_poly_xy; v.poly_box = m->d_poly_box;
+  v.left0 = m->d_left0; v.pred0 = m->d_pred0; v.adj_left = m->d_adj_left;
+  v.n_inter = m->n_inter; v.inter_off = m->d_inter_off; v.inter_lanelet = m->d_inter_lanelet; v.inter_kind = m->d_inter_kind;
+  v.path = d_path6; v.n_path = n_path;
+  RuleParams pr{};
+  pr.ego_x = params->ego_x; pr.ego_y = params->ego_y; pr.ego_yaw = params->ego_yaw; pr.ego_s = params->ego_s; pr.ego_d = params->ego_d;
+  pr.s_threshold = params->s_threshold; pr.ped_width = params->ped_width; pr.ped_length = params->ped_length;
+  pr.intention = params->intention; pr.win_i0 = params->win_i0; pr.win_i1 = params->win_i1;
+  pr.behind_static = params->behind_static; pr.behind_turn = params->behind_turn; pr.behind_dynamic = params->behind_dynamic;
+  pr.max_static = params->max_static; pr.max_dynamic = params->max_dynamic;
+  hipLaunchKernelGGL(fo_spawn_rules_kernel, dim3(1 + O), dim3(256), 0, s, v, pr, O, d_ocorn, d_ocen, d_oyaw, d_odims, d_oflags,
+                     d_obst_vis, sc->d_rule_rec);
+  hipLaunchKernelGGL(fo_spawn_rules_select_kernel, dim3(1), dim3(64), 0, s, v, pr, O, d_ocorn, d_oflags, d_obst_vis,
+                     sc->d_rule_rec, max_out, d_out, d_n_out);
+  FO_HIP_TRY(ctx, hipGetLastError());
+  return FO_OK;
+}
+
+}  // extern "C"

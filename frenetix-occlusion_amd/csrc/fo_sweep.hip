@@ -1094,7 +1094,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
 #endif
             }
           }
-          cpw[row * TILE + src] = acc * (0.25 / 3.0);  // (1/2)(1/2) of the two Phi differences, /3 (:122)
+          // (1/2)(1/2) of the two Phi differences, /3 (:122).  A row poisoned by fo_prep_agents_kernel (no usable
+          // covariance: 1/sigma = NaN) must read NaN: the table erf clamps its argument, which would turn the NaN into
+          // erf(+-6) and the probability into 0
+          cpw[row * TILE + src] = (qisx != qisx || qisy != qisy) ? NAN : acc * (0.25 / 3.0);
         }
         if (CORR) {
           // Covariances with correlation: a second walk over the same queued samples adds the correlation integral of
@@ -1375,7 +1378,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               if (hv) {
                 er = eh * cp;
                 orr = oh * cp;
-                max_er = fo_vmax(max_er, er);
+                // (a NaN probability -- an agent row without a usable covariance -- sticks in max_er, from where the
+                // pair outputs below pick it up; v_max would drop it)
+                if (er > max_er || er != er) max_er = er;
                 if (orr > max_or) { max_or = orr; idx_or = t; }
               }
               if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
@@ -1417,7 +1422,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         const double d_w = sp[0 * TILE];
         const int t_w = (int)sp[1 * TILE];
         if (d_w < dce || (d_w == dce && t_w < tdce)) { dce = d_w; tdce = t_w; }
-        max_er = fmax(max_er, sp[2 * TILE]);
+        { const double e_ = sp[2 * TILE]; if (e_ > max_er || e_ != e_) max_er = e_; }
         if (sp[3 * TILE] > max_or) { max_or = sp[3 * TILE]; idx_or = (int)sp[4 * TILE]; }
         max_eh = fmax(max_eh, sp[5 * TILE]);
         max_oh = fmax(max_oh, sp[6 * TILE]);
@@ -1434,15 +1439,16 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     if (PAIR) {
       const size_t ps_ = (size_t)A * M;
       double *pf = a.pair_f + (size_t)k * M + m;
+      const bool cp_ok = hr_valid && max_er == max_er;   // false: a collision probability of this pair was NaN (see pass 2)
       pf[FO_PF_DCE * ps_] = do_dce ? dce_m : NAN;
       pf[FO_PF_TTC * ps_] = do_ttc ? ttc : NAN;
       pf[FO_PF_TTCE * ps_] = do_ttce ? ttce : NAN;
       pf[FO_PF_MAX_EGO_RISK * ps_] = hr_valid ? max_er : NAN;
-      pf[FO_PF_MAX_OBST_RISK * ps_] = hr_valid ? max_or : NAN;
-      pf[FO_PF_HARM_WITH_CP * ps_] = hr_valid ? hwc : NAN;
+      pf[FO_PF_MAX_OBST_RISK * ps_] = cp_ok ? max_or : NAN;
+      pf[FO_PF_HARM_WITH_CP * ps_] = cp_ok ? hwc : NAN;
       pf[FO_PF_MAX_EGO_HARM * ps_] = hr_valid ? max_eh : NAN;
       pf[FO_PF_MAX_OBST_HARM * ps_] = hr_valid ? max_oh : NAN;
-      pf[FO_PF_MAX_CP * ps_] = hr_valid ? max_cp : NAN;
+      pf[FO_PF_MAX_CP * ps_] = cp_ok ? max_cp : NAN;
       pf[FO_PF_BE_DECEL * ps_] = NAN;
       pf[FO_PF_BE_BTN * ps_] = NAN;
       pf[FO_PF_SPARE * ps_] = NAN;

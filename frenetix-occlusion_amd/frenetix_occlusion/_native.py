@@ -30,7 +30,7 @@ EXPORTS = [
     "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_list_format", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read", "fo_sweep_timing_read_each",
     "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
-    "fo_scene_candidate_count",
+    "fo_scene_candidate_count", "fo_scene_set_topology", "fo_scene_spawn_rules",
 ]
 
 
@@ -45,6 +45,12 @@ class HarmCoeff(C.Structure):
 
 class Thresholds(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("harm", "risk", "be", "cp", "ttc", "dce")]
+
+
+class SpawnRuleParams(C.Structure):       # fo_spawn_rule_params_t
+    _fields_ = ([(n, C.c_double) for n in ("ego_x", "ego_y", "ego_yaw", "ego_s", "ego_d", "s_threshold", "ped_width", "ped_length")] +
+                [(n, C.c_int32) for n in ("intention", "win_i0", "win_i1", "behind_static", "behind_turn", "behind_dynamic",
+                                          "max_static", "max_dynamic")])
 
 
 class NativeError(RuntimeError):
@@ -106,6 +112,9 @@ def load():
     lib.fo_scene_spawn.argtypes = ([vp, dp] + [C.c_int] * 4 + [D] * 6 + [C.c_int] * 3 + [ip] + [dp] * 5 + [C.c_int, dp, C.c_int]
                                    + [D] * 3 + [dp] * 12 + [vp])
     lib.fo_scene_candidate_count.argtypes = [vp, ip, vp]
+    lib.fo_scene_set_topology.argtypes = [vp, C.c_int, dp, ip, ip, C.c_int, ip, ip, dp]
+    lib.fo_scene_spawn_rules.argtypes = ([vp, dp] + [C.c_int] * 5 + [dp, C.c_int] + [dp] * 6 + [C.POINTER(SpawnRuleParams), C.c_int,
+                                                                                          dp, ip, vp])
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("fo_destroy", "fo_last_error", "fo_build_id"):

@@ -72,7 +72,9 @@ class FOInterface:
                                         footprint=str(acc.get("footprint", "polygon")),
                                         enclosed_holes=str(acc.get("enclosed_holes", "transparent")),
                                         cell_visibility=str(acc.get("cell_visibility", "exact")),
-                                        share_map_with=share_map_with.sensor_model if share_map_with is not None else None)
+                                        share_map_with=share_map_with.sensor_model if share_map_with is not None else None,
+                                        intersections=getattr(self.cr_scenario, "intersections", None) or
+                                        getattr(self.lanelet_network, "intersections", None))
         self.agent_manager = FOAgentManager(scenario=self.cr_scenario, reference_path=self.ego_reference_path,
                                             config=self.config["agent_manager"], visualization=None,
                                             timestep=self.timestep, dt=self.dt, debug=self.debug,

@@ -549,6 +549,26 @@ def obstacle_from_commonroad(ob) -> Obstacle:
                     np.array(states, dtype=np.float64).reshape(-1, 4))
 
 
+def normalize_intersections(inters) -> List[dict]:
+    """intersections as the rule families read them (spawn_locator.py:171-195): a list of
+    ``{'incomings': [{'incoming': ids, 'right': ids, 'straight': ids, 'left': ids}, ...]}`` -- from this package's own
+    dicts or from duck-typed CommonRoad ``Intersection`` objects (``incomings`` with ``incoming_lanelets`` /
+    ``successors_right`` / ``successors_straight`` / ``successors_left`` [ext])"""
+    out = []
+    for it in inters or []:
+        if isinstance(it, dict):
+            out.append(it)
+            continue
+        inc = []
+        for e in getattr(it, "incomings", []):
+            inc.append({"incoming": list(getattr(e, "incoming_lanelets", []) or []),
+                        "right": list(getattr(e, "successors_right", []) or []),
+                        "straight": list(getattr(e, "successors_straight", []) or []),
+                        "left": list(getattr(e, "successors_left", []) or [])})
+        out.append({"incomings": inc})
+    return out
+
+
 def lanelets_of(net) -> List[Lanelet]:
     """list[Lanelet] | Scenario | duck-typed CommonRoad LaneletNetwork (.lanelets with .left_vertices/.right_vertices)"""
     if isinstance(net, Scenario):

@@ -197,7 +197,8 @@ class VisibleArea:
 class SensorModel:
     def __init__(self, lanelet_network, ref_path, sensor_radius=30, sensor_angle=90, debug=True, visualization=None,
                  ctx: Optional[N.Context] = None, n_rays=720, cell_size=0.5, device=0, routes=0,
-                 footprint="polygon", enclosed_holes="transparent", cell_visibility="exact", share_map_with=None):
+                 footprint="polygon", enclosed_holes="transparent", cell_visibility="exact", share_map_with=None,
+                 intersections=None):
         """lanelet_network: a :class:`~frenetix_occlusion.scenario.MapGeometry`, a list of
         :class:`~frenetix_occlusion.scenario.Lanelet`, or an object with ``.lanelets`` (duck-typed CommonRoad).
 
@@ -228,6 +229,8 @@ class SensorModel:
         self.n_rays = int(n_rays)
         self.cell_size = float(cell_size)
         self.routes = int(routes)   # candidate routes per lanelet uploaded for phantom vehicle predictions (0 = none)
+        # intersections of the scenario (spawn rule "behind a dynamic obstacle"); default: the network's own, if it has any
+        self.intersections = intersections if intersections is not None else getattr(lanelet_network, "intersections", None)
         # state of the last step (names of sensor_model.py:26-35)
         self.visible_area = None
         self.occluded_area = None
@@ -288,6 +291,8 @@ class SensorModel:
         if len(edges):
             line = np.ascontiguousarray(geo.edge_line, dtype=np.int32)
             self.ctx.call("fo_scene_set_edge_lines", len(edges), line.ctypes.data)
+        if lanelets:
+            self._set_topology(lanelets)
         self.route_table = self.lanelet_raster = None
         if self.routes > 0 and lanelets is not None:
             from .scenario import RouteTable, lanelet_index_raster
@@ -298,6 +303,33 @@ class SensorModel:
             self.ctx.call("fo_scene_set_routes", len(lanelets), tab.R, first.ctypes.data, count.ctypes.data, len(rs),
                           rxy.ctypes.data if len(rs) else None, rs.ctypes.data if len(rs) else None, ras.ctypes.data)
             self.route_table, self.lanelet_raster = tab, ras
+
+    def _set_topology(self, lanelets):
+        """lanelet topology the spawn rule families read on the device (fo_scene_set_topology): first vertex of the left
+        bounds, first predecessor, left neighbour, the intersections' incoming / inner lanelets (spawn_locator.py:171-202,
+        249-252, 424).  Part of the static map: uploaded by its owner, shared with it."""
+        from .scenario import normalize_intersections
+        index = {ll.lanelet_id: i for i, ll in enumerate(lanelets)}
+        P = len(lanelets)
+        left0 = np.ascontiguousarray([ll.left[0] for ll in lanelets], dtype=np.float64)
+        pred0 = np.array([index.get(ll.predecessors[0], -1) if ll.predecessors else -1 for ll in lanelets], dtype=np.int32)
+        adjl = np.array([index.get(ll.adj_left, -1) if ll.adj_left is not None else -1 for ll in lanelets], dtype=np.int32)
+        inters = normalize_intersections(self.intersections)
+        off, lan, kind = [0], [], []
+        for it in inters:
+            for e in it["incomings"]:
+                for lid in e["incoming"]:
+                    if lid in index:
+                        lan.append(index[lid]); kind.append(0)
+                for key in ("left", "right", "straight"):
+                    for lid in e[key]:
+                        if lid in index:
+                            lan.append(index[lid]); kind.append(1)
+            off.append(len(lan))
+        off = np.array(off, dtype=np.int32)
+        lan, kind = np.array(lan or [0], dtype=np.int32), np.array(kind or [0], dtype=np.uint8)
+        self.ctx.call("fo_scene_set_topology", P, left0.ctypes.data, pred0.ctypes.data, adjl.ctypes.data, len(inters),
+                      off.ctypes.data, lan.ctypes.data, kind.ctypes.data)
 
     def road_raster(self):
         nx, ny = self.raster_dims

@@ -91,7 +91,7 @@ class SpawnLocator:
         self.dt = float(dt)
         self.T = int(horizon / self.dt) + 1                      # agent.py:496
         self.min_ahead = float(acc.get("min_ahead", MIN_AHEAD))
-        self.mode = str(acc.get("mode", "cells"))                  # "cells" | "rules" | "both" (spawn_rules.py)
+        self.mode = str(acc.get("mode", "cells"))                  # "cells" | "rules" | "both" (fo_scene_spawn_rules)
         if self.mode not in ("cells", "rules", "both"):
             raise ValueError("accelerator.spawn.mode must be 'cells', 'rules' or 'both'")
         self.rule_points = []
@@ -159,44 +159,114 @@ class SpawnLocator:
                       N.current_stream(self._dev_index))
         return b
 
-    def _rule_engine(self):
-        if self._rules is None:
-            from .scenario import lanelets_of, points_in_polygon
-            from .spawn_rules import SpawnRules
-            from .utils.curvilinear import PolylineCS
-            sm = self.sensor_model
-            if self.cosy_cl is None:
-                self.cosy_cl = PolylineCS(self.ref_path)     # interface.py docstring: "initialized if not provided"
-            try:
-                lanelets = lanelets_of(sm.lanelet_network)
-            except Exception:
-                lanelets = []
+    # ---------------------------------------------------------------- the reference's rule families, on the device
+    SOURCE_NAME = {1: "behind_dynamic_obstacle", 2: "behind static obstacle", 3: "left turn", 4: "right turn"}
+    MAX_RULE_POINTS = 16
 
-            def lane_yaw_at(xy):
-                if sm.lane_yaw is None:
-                    return None
-                (x0, y0), (nx, ny) = sm.raster_origin, sm.raster_dims
-                ix, iy = int(math.floor((xy[0] - x0) / sm.cell_size)), int(math.floor((xy[1] - y0) / sm.cell_size))
-                if not (0 <= ix < nx and 0 <= iy < ny) or np.isnan(sm.lane_yaw[iy, ix]):
-                    return None
-                return float(sm.lane_yaw[iy, ix])
+    def _rule_setup(self):
+        """one-off: the polyline frame of the reference path as the table fo_scene_spawn_rules reads, the output buffers
+        (the lanelet topology belongs to the static map: SensorModel._set_topology)"""
+        from .scenario import lanelets_of
+        from .utils.curvilinear import PolylineCS
+        sm = self.sensor_model
+        self._cs = PolylineCS(self.ref_path)
+        n = len(self.ref_path)
+        tab = np.zeros((n, 6))
+        tab[:, :2], tab[:, 2] = self._cs.path, self._cs.s
+        tab[:-1, 3], tab[:-1, 4:6] = self._cs.seg_len, self._cs.tangent
+        self._d_path6 = torch.as_tensor(tab).to(self.device)
+        try:
+            lanelets = lanelets_of(sm.lanelet_network)
+        except Exception:
+            lanelets = []
+        self._rule_lanelets = lanelets
+        P = len(lanelets)
+        self._rule_out = torch.zeros(self.MAX_RULE_POINTS * 8 + 1, dtype=torch.float64, device=self.device)
+        self._rule_n = self._rule_out[-1:].view(torch.int32)[:1]
+        sl = self.config["spawn_locator"]
+        ped = self.config["agent_manager"]["pedestrian"]
+        self._rule_cfg = dict(behind_static=int(bool(sl.get("spawn_point_behind_static_obstacle", True))),
+                              behind_turn=int(bool(sl.get("spawn_points_behind_turn", True))),
+                              behind_dynamic=int(bool(sl.get("spawn_point_behind_dynamic_obstacle", True)) and P > 0),
+                              max_static=int(sl.get("max_static_spawn_points", 1)),
+                              max_dynamic=int(sl.get("max_dynamic_spawn_points", 1)),
+                              ped_width=float(ped["width"]), ped_length=float(ped["length"]))
+        self._rules_ready = True
 
-            def lanelet_of(xy):
-                q = np.asarray(xy, dtype=np.float64).reshape(1, 2)
-                for ll in lanelets:
-                    if points_in_polygon(q, ll.polygon)[0]:
-                        return ll
-                return None
-            inters = getattr(getattr(self.agent_manager, "scenario", None), "intersections", None) or []
-            self._rules = SpawnRules(self.config, self.ref_path, self.cosy_cl, lane_yaw_at, lanelet_of, self.fo_obstacles,
-                                     self.debug, lanelets=lanelets, intersections=inters)
-        self._rules.cosy_cl = self.cosy_cl or self._rules.cosy_cl
-        return self._rules
+    def _rule_points_device(self, ego_pos, ego_orientation, ego_pos_cl, ego_v):
+        """``spawn.mode: rules``: the three rule families of the reference evaluated by fo_scene_spawn_rules on the cell
+        classes of this step, in HBM; the host supplies the step's scalars (curvilinear ego position, s_threshold,
+        the ego's intention from the curvature of the next 40 m of the reference path, spawn_locator.py:113,678-741)
+        and reads the handful of spawn points back."""
+        import ctypes as C
+        from .utils.curvilinear import curvature
+        if not getattr(self, "_rules_ready", False):
+            self._rule_setup()
+        sm = self.sensor_model
+        if ego_pos_cl is None:
+            ego_pos_cl = self._cs.convert_to_curvilinear_coords(float(ego_pos[0]), float(ego_pos[1]))
+        s_ego = float(ego_pos_cl[0])
+        ref_s = self._cs.s
+        i0 = int(np.argmin(np.abs(ref_s - s_ego)))                       # :678-693
+        i1 = int(np.argmin(np.abs(ref_s - (s_ego + 40.0))))
+        intention = 0
+        if i1 - i0 >= 3:                                                  # :729-741
+            key = (i0, i1)
+            if getattr(self, "_intent_key", None) != key:
+                k = curvature(self.ref_path[i0:i1])
+                self._intent = 1 if k.max() > 0.10 else 2 if k.min() < -0.10 else 0
+                self._intent_key = key
+            intention = self._intent
+        self.last_intention = ("straight ahead", "left turn", "right turn")[intention]
+        # obstacle attributes the rules read beyond the corner points (one small upload per step)
+        obst = list(self.fo_obstacles) if self.fo_obstacles is not None else []
+        O = len(obst)
+        d_corn, d_cen, d_flags, O_dev = getattr(sm, "_obst", (None, None, None, 0))
+        if O != O_dev:
+            raise RuntimeError("SpawnLocator: the obstacles of this step have not been uploaded (SensorModel.upload_obstacles)")
+        p = lambda t: t.data_ptr() if t is not None else None
+        if O:
+            host = np.zeros(O * 25, dtype=np.uint8)
+            yd = host[:O * 24].view(np.float64).reshape(O, 3)
+            fl = host[O * 24:]
+            for i, o in enumerate(obst):
+                if o.current_pos is None:
+                    continue
+                yd[i] = (o.current_orientation, o.length, o.width)
+                t = str(o.obstacle_type).lower()
+                fl[i] = 1 | (2 if o.occludes else 0) | (4 if o.obstacle_role == "dynamic" else 0) | (8 if t in ("bicycle", "pedestrian") else 0)
+            d = torch.as_tensor(host).to(self.device)
+            ydev = d[:O * 24].view(torch.float64).view(O, 3)
+            d_yaw, d_dims, d_fl = ydev[:, 0].contiguous(), ydev[:, 1:3].contiguous(), d[O * 24:]
+            d_vis = sm._buf["ovis"]
+        else:
+            d_yaw = d_dims = d_fl = d_vis = None
+        pr = N.SpawnRuleParams(float(ego_pos[0]), float(ego_pos[1]), float(ego_orientation), s_ego, float(ego_pos_cl[1]),
+                               s_ego + max(float(ego_v) * S_THRESHOLD_TIME, S_THRESHOLD_MIN),
+                               self._rule_cfg["ped_width"], self._rule_cfg["ped_length"], intention, i0, i1,
+                               self._rule_cfg["behind_static"], self._rule_cfg["behind_turn"], self._rule_cfg["behind_dynamic"],
+                               self._rule_cfg["max_static"], self._rule_cfg["max_dynamic"])
+        w = sm.window
+        self.ctx.call("fo_scene_spawn_rules", sm.cell_class.data_ptr(), w.ix0, w.iy0, w.nx, w.ny, int(self._d_path6.shape[0]),
+                      self._d_path6.data_ptr(), O, p(d_corn), p(d_cen), p(d_yaw), p(d_dims), p(d_fl), p(d_vis),
+                      C.byref(pr), self.MAX_RULE_POINTS, self._rule_out.data_ptr(), self._rule_n.data_ptr(),
+                      N.current_stream(self._dev_index))
+        h = self._rule_out.cpu().numpy()                                  # the one read-back of the rule path
+        n = int(h[-1:].view(np.int32)[0])
+        pts = []
+        for q in h[:n * 8].reshape(n, 8):
+            src = self.SOURCE_NAME[int(q[6])]
+            if int(q[6]) == 2:
+                src += " " + str(obst[int(q[7])].obstacle_id)             # spawn_locator.py:462
+            cl = None if np.isnan(q[4]) else np.array([q[4], q[5]])
+            pts.append(SpawnPoint(np.array([q[1], q[2]]), TYPE_NAME[int(q[0])], cl, src, None if np.isnan(q[3]) else float(q[3])))
+        return pts
 
     def find_spawn_points(self, ego_pos, ego_orientation, ego_pos_cl, ego_v):
         """reference signature (spawn_locator.py:80): returns list[SpawnPoint].  Cell-sampled points come from the
-        device (one small D2H copy); rule-based points (mode 'rules' / 'both') are evaluated on a host copy of the
-        cell classes and are turned into agents by the caller through ``FOAgentManager.add_agent``."""
+        device (one small D2H copy); rule-based points (mode 'rules' / 'both') come from ``fo_scene_spawn_rules`` -- the
+        reference's three rule families on the device -- and are turned into agents by the caller through
+        ``FOAgentManager.add_agent``."""
         self.spawn_points, self.rule_points = [], []
         if self.mode in ("cells", "both"):
             b = self.sample(ego_pos, ego_orientation, ego_v)
@@ -215,12 +285,6 @@ class SpawnLocator:
             self.batch = None
         self.n_cell_points = len(self.spawn_points)
         if self.mode in ("rules", "both"):
-            from .spawn_rules import CellView
-            rules = self._rule_engine()
-            sm = self.sensor_model
-            view = CellView(sm.cell_class.cpu().numpy(), sm.window)
-            if ego_pos_cl is None:
-                ego_pos_cl = rules.cosy_cl.convert_to_curvilinear_coords(float(ego_pos[0]), float(ego_pos[1]))
-            self.rule_points = rules.find(view, ego_pos, ego_pos_cl, ego_v, ego_orientation)
+            self.rule_points = self._rule_points_device(ego_pos, ego_orientation, ego_pos_cl, ego_v)
             self.spawn_points = self.spawn_points + self.rule_points
         return self.spawn_points

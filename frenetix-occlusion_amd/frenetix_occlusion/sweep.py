@@ -96,6 +96,10 @@ class MetricSweep:
             self._pin_free = None
         if self._pin_free is not None:
             self._pin_free.synchronize()            # the previous copy out of the pinned buffer must have finished
+        if getattr(self, "_stage_busy", None) is not None:
+            # the device staging buffer is still being read by the kernels of the previous run(); if the caller has
+            # switched streams in between, the new copy must wait for them (same stream: a no-op in stream order)
+            torch.cuda.current_stream(self.device).wait_event(self._stage_busy)
         host = self._pin[:need].view(n, M, T)
         hv = host.numpy()
         for i, arr in enumerate(arrays):
@@ -179,5 +183,8 @@ class MetricSweep:
         self._last_inputs = (x, y, theta, v, a)
         self.ctx.call("fo_sweep_run", M, T, p(x), p(y), p(theta), p(v), p(a), p(out.cost), p(out.safe),
                       p(out.pair_f), p(out.pair_i), p(out.lists_raw), self._stream())
+        if getattr(self, "_stage", None) is not None:
+            self._stage_busy = torch.cuda.Event()   # last consumer of the staging buffer (see _upload_packed)
+            self._stage_busy.record()
         out.lists_shape = (A, max(T - 1, 0), M)
         return out

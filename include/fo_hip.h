@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 5
+#define FO_ABI_VERSION 6
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -149,7 +149,11 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
  * by reference.  Several egos planning on one scenario on one GPU (BASELINE configs[4]: "shared occlusion map in HBM")
  * then hold the map once; every per-step buffer stays per context.  Reference counted: destroying the owner does not
  * pull the map away, and a later fo_scene_set_map gives the calling context a map of its own again.  (No counterpart in
- * the reference, which builds one shapely road polygon per SensorModel, sensor_model.py:195-199.) */
+ * the reference, which builds one shapely road polygon per SensorModel, sensor_model.py:195-199.)
+ * The route table and the edge-line labels are part of the map: upload them through the owner BEFORE sharing.  While a
+ * map has more than one reader, fo_scene_set_routes / fo_scene_set_edge_lines on any of them return FO_E_STATE (they
+ * would free tables other contexts' kernels are reading); fo_scene_set_map detaches the caller first and is always
+ * allowed.  The reference count is atomic: sharing and destroying from different host threads is safe. */
 int fo_scene_share_map(fo_ctx *ctx, fo_ctx *owner);
 /* One-off, after fo_scene_set_map (replaces FORoutePlanner, route_planner.py:15-90, evaluated for every lanelet up
  * front): HOST arrays.  Lanelet index p (order of the polygons given to fo_scene_set_map) has up to R candidate routes;
@@ -233,6 +237,43 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
                    double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,
                    int32_t *d_type, int32_t *d_len, void *stream);
 int fo_scene_candidate_count(fo_ctx *ctx, int32_t *h_n, void *stream);
+
+/* ---- the reference's three spawn rule families on the cell classes (replaces SpawnLocator.find_spawn_points' rule
+ *      functions: pedestrian behind a visible static obstacle, spawn_locator.py:323-476; pedestrian behind a turn,
+ *      :481-578; Car / Bicycle behind a visible dynamic obstacle, :145-317 with the rectangle fit of :695-726).  The
+ *      reference asks shapely for intersections with the visible / occluded polygons; here the same predicates are asked
+ *      of the cell classes.  The curvilinear frame is the polyline frame of the ego's reference path. */
+
+/* One-off, after fo_scene_set_map (HOST arrays, lanelet index = order of the polygons): first vertex of every lanelet's
+ * left bound [P][2] (spawn_locator.py:424), index of predecessors[0] and of adj_left per lanelet (-1 = none; :249-252,
+ * :196-202), and the intersections: entries [off[i], off[i+1]) of (lanelet index, kind: 0 incoming, 1 inner = the left /
+ * right / straight successors of an incoming element) for intersection i (:171-195). */
+int fo_scene_set_topology(fo_ctx *ctx, int P, const double *h_left0, const int32_t *h_pred0, const int32_t *h_adj_left,
+                          int n_inter, const int32_t *h_inter_off, const int32_t *h_inter_lanelet,
+                          const uint8_t *h_inter_kind);
+
+/* per-step scalars of the rules: ego pose, its curvilinear position, s_threshold = s_ego + max(4 v_ego, 25)
+ * (spawn_locator.py:65-66,113), the ego's intention (0 straight ahead, 1 left turn, 2 right turn: curvature of the next
+ * 40 m of the reference path, :678-693,729-741) and that window as vertex range [win_i0, win_i1) of the path table, the
+ * switches and maxima of the YAML (spawn_locator section), the pedestrian's width / length (agent_manager section) */
+typedef struct {
+  double ego_x, ego_y, ego_yaw, ego_s, ego_d, s_threshold;
+  double ped_width, ped_length;
+  int32_t intention, win_i0, win_i1;
+  int32_t behind_static, behind_turn, behind_dynamic, max_static, max_dynamic;
+} fo_spawn_rule_params_t;
+
+/* Per step, after fo_scene_visibility on the same stream.  d_cls + window: that call's cell classes.  d_path6 [n_path][6]:
+ * reference path table x, y, arc length, segment length, unit tangent (last row: tangent unused).  Obstacles at this
+ * step: d_ocorn [O][4][2], d_ocen [O][2], d_oyaw [O], d_odims [O][2] (length, width), d_oflags [O] (bit0 present, bit1
+ * occludes, bit2 dynamic role, bit3 type bicycle or pedestrian), d_obst_vis [O] = visible_objects_timestep of
+ * fo_scene_visibility.  Output d_out [max_out][8]: type (FO_TYPE_*), x, y, orientation (NaN = to be derived,
+ * agent.py:475-481), curvilinear s, d (NaN = none), source (1 behind dynamic obstacle, 2 behind static obstacle, 3 left
+ * turn, 4 right turn), obstacle index (-1 = none), in the reference's order (dynamic, static, turn); d_n_out [1]. */
+int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, int n_path,
+                         const double *d_path6, int O, const double *d_ocorn, const double *d_ocen, const double *d_oyaw,
+                         const double *d_odims, const uint8_t *d_oflags, const uint8_t *d_obst_vis,
+                         const fo_spawn_rule_params_t *params, int max_out, double *d_out, int32_t *d_n_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,10 @@
-"""The reference's spawn rule families restated on the ray/cell discretisation (host side, a handful of queries per
-step; ref: spawn_locator.py:80-139, 323-476, 481-578, 678-741).
+"""The reference's spawn rule families restated on the ray/cell discretisation in NumPy / Python
+(ref: spawn_locator.py:80-139, 323-476, 481-578, 678-741).
+
+TEST INFRASTRUCTURE ONLY: this is the checker of the device implementation (csrc/fo_spawn_rules.hpp,
+fo_scene_spawn_rules) -- an independent statement of the same definitions, with plain loops, scipy's connected
+components and convex hull.  tests/ import it; the product package never does (it was the product's host path for
+`spawn.mode: rules` until round 3: 0.9 ms per step in the interpreter).
 
 The reference evaluates these rules with shapely/GEOS on the visible / occluded polygons; here the same predicates are
 asked of the per-step cell classes (fo_scene_visibility):
@@ -18,9 +23,10 @@ from typing import List, Optional
 
 import numpy as np
 
-from .sensor_model import OCCLUDED, ROAD, VISIBLE
-from .spawn_locator import SpawnPoint
-from .utils.curvilinear import curvature, pathlength
+from frenetix_occlusion.spawn_locator import SpawnPoint
+from frenetix_occlusion.utils.curvilinear import curvature, pathlength
+
+ROAD, VISIBLE, OCCLUDED = 1, 2, 4      # class bits of fo_scene_visibility (include/fo_hip.h)
 
 S_THRESHOLD_TIME, MIN_S_THRESHOLD = 4.0, 25.0              # spawn_locator.py:65-66
 MAX_DISTANCE_TO_OTHER_OBSTACLE = 30.0                      # :69
@@ -312,7 +318,7 @@ class SpawnRules:
 
     # ---- spawn_locator.py:145-317
     def _lanelets_at(self, xy):
-        from .scenario import points_in_polygon
+        from frenetix_occlusion.scenario import points_in_polygon
         q = np.asarray(xy, dtype=np.float64).reshape(1, 2)
         return [ll for ll in self.lanelets if points_in_polygon(q, ll.polygon)[0]]
 
@@ -339,7 +345,7 @@ class SpawnRules:
 
     def behind_dynamic_obstacle(self, view: CellView) -> List[SpawnPoint]:
         from scipy import ndimage
-        from .scenario import points_in_polygon
+        from frenetix_occlusion.scenario import points_in_polygon
         pts: List[SpawnPoint] = []
         vis = [o for o in self.fo_obstacles if o.current_visible and o.obstacle_role == "dynamic"]
         vis.sort(key=lambda o: float(np.linalg.norm(self.ego_pos - o.current_pos)))

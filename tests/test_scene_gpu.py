@@ -346,3 +346,41 @@ def test_static_map_shared_between_contexts(torch_cuda):
     other_dev_free = N.Context(0)
     with pytest.raises(N.NativeError):
         other_dev_free.call("fo_scene_share_map", N.Context(0)._h)    # the owner has no map
+
+
+def test_tables_of_a_shared_map_cannot_be_replaced(torch_cuda):
+    """fo_scene_share_map: the route table and the edge-line labels belong to the map.  While two contexts read one map,
+    fo_scene_set_routes / fo_scene_set_edge_lines on either fail with FO_E_STATE instead of freeing tables under the
+    other's kernels; fo_scene_set_map detaches the caller and is always allowed."""
+    import ctypes as C
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import scenario as SC
+    from frenetix_occlusion.sensor_model import SensorModel
+    sc = SC.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    owner = SensorModel(sc.lanelets, None, sensor_radius=50.0, sensor_angle=360.0, n_rays=360)
+    owner.upload_obstacles(sc.obstacle_arrays(0)[:3])
+    owner.launch(ego[:2], float(ego[2]))
+    torch_cuda.cuda.synchronize()
+    before = (owner.range.cpu().numpy().copy(), owner.cell_class.cpu().numpy().copy())
+    sharer = SensorModel(sc.lanelets, None, sensor_radius=50.0, sensor_angle=360.0, n_rays=360, share_map_with=owner)
+    E = len(owner.map_geometry.edges)
+    line = np.zeros(E, dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(C.c_void_p)
+    for ctx in (sharer.ctx, owner.ctx):
+        with pytest.raises(N.NativeError) as e:
+            ctx.call("fo_scene_set_edge_lines", E, ip(line))
+        assert e.value.code == N.FO_E_STATE
+        first, count = np.zeros(len(sc.lanelets), dtype=np.int32), np.zeros(len(sc.lanelets), dtype=np.int32)
+        xy, s_ = np.zeros((1, 2)), np.zeros(1)
+        rast = np.full(int(np.prod(owner.raster_dims)), -1, dtype=np.int32)
+        with pytest.raises(N.NativeError) as e:
+            ctx.call("fo_scene_set_routes", len(sc.lanelets), 1, ip(first), ip(count), 1, ip(xy), ip(s_), ip(rast))
+        assert e.value.code == N.FO_E_STATE
+    owner.launch(ego[:2], float(ego[2]))                     # the owner's map is what it was
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(owner.range.cpu().numpy(), before[0]) and np.array_equal(owner.cell_class.cpu().numpy(), before[1])
+    del sharer                                               # one reader again: the labels may be replaced
+    import gc
+    gc.collect()
+    owner.ctx.call("fo_scene_set_edge_lines", E, ip(np.arange(E, dtype=np.int32)))

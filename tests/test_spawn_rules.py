@@ -1,5 +1,5 @@
-"""The reference's spawn rules restated on the cell classes (spawn_rules.py): known-answer scenes evaluated with the
-oracle's ray fan / cell grid on the CPU.  PARITY UNPINNED vs the reference (GEOS absent): these tests are the pin."""
+"""The reference's spawn rules restated on the cell classes (oracle/fo_spawn_rules_ref.py, the checker of the device
+implementation): known-answer scenes evaluated with the oracle's ray fan / cell grid on the CPU.  PARITY UNPINNED vs the reference (GEOS absent): these tests are the pin."""
 import math
 
 import numpy as np
@@ -7,7 +7,7 @@ import pytest
 
 from frenetix_occlusion import scenario as S
 from frenetix_occlusion.sensor_model import CellWindow
-from frenetix_occlusion.spawn_rules import CellView, SpawnRules, segment_rect_distance
+from oracle.fo_spawn_rules_ref import CellView, SpawnRules, segment_rect_distance
 from frenetix_occlusion.utils.curvilinear import PolylineCS, curvature
 from frenetix_occlusion.utils.fo_obstacle import FOObstacles
 

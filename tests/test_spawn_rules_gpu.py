@@ -1,0 +1,162 @@
+"""The reference's spawn rule families on the device (fo_scene_spawn_rules, csrc/fo_spawn_rules.hpp) against their
+independent NumPy restatement (oracle/fo_spawn_rules_ref.py) -- the three known-answer scenes of tests/test_spawn_rules.py
+and the scenario-1 fixture at several time steps: same spawn points (type, source, cell, orientation), positions to 1e-9."""
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CFG = {"spawn_locator": {"spawn_points_behind_turn": True, "spawn_point_behind_static_obstacle": True,
+                         "spawn_point_behind_dynamic_obstacle": True, "max_static_spawn_points": 1,
+                         "max_dynamic_spawn_points": 1},
+       "agent_manager": {"pedestrian": {"width": 0.5, "length": 0.3, "default_velocity": 1.4},
+                         "bicycle": {"width": 0.9, "length": 2.0, "default_velocity": 5.0},
+                         "car": {"width": 2.0, "length": 4.8, "default_velocity": 10.0},
+                         "prediction": {"variance_factor": 1.05, "size_factor_length_s": 1.2, "size_factor_width_s": 1.3,
+                                        "size_factor_length_l": 1.4, "size_factor_width_l": 2.5}},
+       "accelerator": {"spawn": {"mode": "rules"}}}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _both(torch, lanelets, obstacles, path, ego, yaw, v, intersections=None, timestep=0, n_rays=720):
+    """device rule points and checker rule points for one scene"""
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.utils.curvilinear import PolylineCS
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    from oracle.fo_spawn_rules_ref import CellView, SpawnRules
+    obs = FOObstacles(obstacles)
+    obs.update(timestep)
+    sm = SensorModel(lanelets, path, sensor_radius=50.0, sensor_angle=360.0, n_rays=n_rays, intersections=intersections)
+    sm.calc_visible_and_occluded_area(timestep, ego, yaw, obs)
+    am = SimpleNamespace(scenario=SimpleNamespace(intersections=intersections or []))
+    sl = SpawnLocator(am, path, CFG, sm, fo_obstacles=obs)
+    cs = PolylineCS(path)
+    ego_cl = cs.convert_to_curvilinear_coords(ego[0], ego[1])
+    dev = [p for p in sl.find_spawn_points(ego, yaw, ego_cl, v)]
+    torch.cuda.synchronize()
+    view = CellView(sm.cell_class.cpu().numpy(), sm.window)
+
+    def lane_yaw_at(xy):
+        (x0, y0), (nx, ny) = sm.raster_origin, sm.raster_dims
+        ix, iy = int(math.floor((xy[0] - x0) / sm.cell_size)), int(math.floor((xy[1] - y0) / sm.cell_size))
+        if not (0 <= ix < nx and 0 <= iy < ny) or np.isnan(sm.lane_yaw[iy, ix]):
+            return None
+        return float(sm.lane_yaw[iy, ix])
+
+    def lanelet_of(xy):
+        for ll in lanelets:
+            if S.points_in_polygon(np.asarray(xy, float).reshape(1, 2), ll.polygon)[0]:
+                return ll
+        return None
+    rules = SpawnRules(CFG, path, cs, lane_yaw_at, lanelet_of, obs, lanelets=lanelets, intersections=intersections or [])
+    ref = rules.find(view, ego, ego_cl, v, yaw)
+    assert sl.last_intention == rules.last_intention
+    return dev, ref, view
+
+
+def _same(dev, ref, view):
+    assert [(p.agent_type, p.source) for p in dev] == [(p.agent_type, p.source) for p in ref]
+    for a, b in zip(dev, ref):
+        assert view._cell(a.position) == view._cell(b.position)
+        np.testing.assert_allclose(a.position, b.position, rtol=0, atol=1e-9)
+        assert (a.orientation is None) == (b.orientation is None)
+        if a.orientation is not None:
+            assert a.orientation == pytest.approx(b.orientation, abs=1e-12)
+        assert (a.cl_pos is None) == (b.cl_pos is None)
+        if a.cl_pos is not None:
+            np.testing.assert_allclose(a.cl_pos, b.cl_pos, rtol=0, atol=1e-9)
+
+
+def _straight(S, lid, x0, x1, y_lo, y_hi, n=41):
+    xs = np.linspace(x0, x1, n)
+    return S.Lanelet(lid, np.stack((xs, np.full(n, y_hi)), -1), np.stack((xs, np.full(n, y_lo)), -1))
+
+
+def test_pedestrian_behind_a_parked_car(torch_cuda):
+    from frenetix_occlusion import scenario as S
+    lanes = [_straight(S, 1, -10, 70, -3.5, 0.0), _straight(S, 2, -10, 70, 0.0, 3.5)]
+    path = np.stack((np.linspace(-5, 65, 141), np.full(141, -1.0)), -1)
+    ego = np.array([0.0, -1.0])
+    for x, want in ((17.0, 1), (45.0, 0), (-6.0, 0)):
+        car = S.Obstacle(77, "static", "parkedVehicle", 4.5, 1.8, 0, np.array([x, -2.4, 0.0, 0.0]), np.zeros((0, 4)))
+        dev, ref, view = _both(torch_cuda, lanes, [car], path, ego, 0.0, 8.0)
+        assert len(ref) == want
+        _same(dev, ref, view)
+    # two parked cars 4 m apart in s: the 5 m rule between pedestrians drops the second one's point
+    cars = [S.Obstacle(70 + i, "static", "parkedVehicle", 4.5, 1.8, 0, np.array([14.0 + 6.5 * i, -2.4, 0.0, 0.0]), np.zeros((0, 4)))
+            for i in range(2)]
+    dev, ref, view = _both(torch_cuda, lanes, cars, path, ego, 0.0, 8.0)
+    _same(dev, ref, view)
+
+
+def test_pedestrian_behind_a_right_and_a_left_turn(torch_cuda):
+    from frenetix_occlusion import scenario as S
+    main = [_straight(S, 1, -40, 40, -3.5, 0.0), _straight(S, 2, -40, 40, 0.0, 3.5)]
+    ys = np.linspace(-3.5, -43.5, 41)
+    side = [S.Lanelet(3, np.stack((np.full(41, 13.5), ys), -1), np.stack((np.full(41, 10.0), ys), -1)),
+            S.Lanelet(4, np.stack((np.full(41, 17.0), ys), -1), np.stack((np.full(41, 13.5), ys), -1))]
+    ego = np.array([-5.0, -1.75])
+    ang = np.linspace(0, math.pi / 2, 30)
+    path = np.concatenate((np.stack((np.linspace(-30, 7.75, 76), np.full(76, -1.75)), -1),
+                           np.stack((7.75 + 4.0 * np.sin(ang), -5.75 + 4.0 * np.cos(ang)), -1)[1:],
+                           np.stack((np.full(60, 11.75), np.linspace(-6.25, -36.0, 60)), -1)))
+    dev, ref, view = _both(torch_cuda, main + side, [], path, ego, 0.0, 6.0)
+    assert len(ref) == 1 and ref[0].source == "right turn"
+    _same(dev, ref, view)
+    # mirrored: a left turn into a side street on the other side
+    mirror = lambda a: a * np.array([1.0, -1.0])
+    lanes_l = [S.Lanelet(ll.lanelet_id, mirror(ll.right), mirror(ll.left)) for ll in main + side]
+    dev, ref, view = _both(torch_cuda, lanes_l, [], mirror(path), mirror(ego), 0.0, 6.0)
+    assert all(p.source == "left turn" for p in ref)
+    _same(dev, ref, view)
+    # straight on: no turn rule
+    straight = np.stack((np.linspace(-30, 40, 141), np.full(141, -1.75)), -1)
+    dev, ref, view = _both(torch_cuda, main + side, [], straight, ego, 0.0, 6.0)
+    assert dev == [] and ref == []
+
+
+def test_car_and_bicycle_behind_an_oncoming_truck(torch_cuda):
+    from frenetix_occlusion import scenario as S
+    xs = np.linspace(-10, 70, 41)
+    lane1 = S.Lanelet(1, np.stack((xs, np.zeros(41)), -1), np.stack((xs, np.full(41, -3.5)), -1))
+    lane2 = S.Lanelet(2, np.stack((xs[::-1], np.zeros(41)), -1), np.stack((xs[::-1], np.full(41, 3.5)), -1))
+    lane1.adj_left, lane1.adj_left_same_direction = 2, False
+    lane2.adj_left, lane2.adj_left_same_direction = 1, False
+    path = np.stack((np.linspace(-5, 65, 141), np.full(141, -1.75)), -1)
+    ego = np.array([0.0, -1.75])
+    for typ, yaw in (("truck", math.pi), ("bicycle", math.pi), ("truck", 0.0), ("car", math.pi + 0.2)):
+        ob = S.Obstacle(31, "dynamic", typ, 9.0, 3.2 if typ == "truck" else 2.0, 0, np.array([20.0, 1.75, yaw, 8.0]), np.zeros((0, 4)))
+        dev, ref, view = _both(torch_cuda, [lane1, lane2], [ob], path, ego, 0.0, 8.0)
+        if typ == "truck" and yaw == math.pi:
+            assert [p.agent_type for p in ref] == ["Car", "Bicycle"]
+        _same(dev, ref, view)
+
+
+def test_scenario1_steps(torch_cuda):
+    """the scenario-1 fixture (12 lanelets, an intersection, parked and moving obstacles) at time steps 0 / 8 / 25 / 60"""
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    yaw = float(ego0[2])
+    path = ego0[None, :2] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    n_pts = 0
+    for step in (0, 8, 25, 60):
+        ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
+        dev, ref, view = _both(torch_cuda, sc.lanelets, sc.obstacles, path, ego, yaw, float(ego0[3]),
+                               intersections=sc.intersections, timestep=step)
+        _same(dev, ref, view)
+        n_pts += len(ref)
+    assert n_pts > 0

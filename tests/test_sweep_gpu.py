@@ -305,6 +305,35 @@ def test_off_diagonal_covariance_fails_loudly(torch_cuda):
                       agents["type"], agents["len"])
 
 
+def test_unusable_covariance_reads_nan_per_pair(torch_cuda):
+    """an agent whose covariance is no covariance: its collision probabilities -- pair scalar, list, risks -- are NaN (not
+    0 = "no risk"), the other agents' are untouched, and no trajectory reads as safe (include/fo_hip.h, fo_sweep_check)"""
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sweep import MetricSweep
+    traj, agents = S.make_batch(128, 3, config_id=10)
+    agents["pos"][1, :, :] = np.stack((traj["x"][5], traj["y"][5]), -1)     # agent 1 sits on trajectory 5: inside the gate
+    good = {k: v.copy() for k, v in agents.items()}
+    agents["cov"][1, :, 0, 1] = 0.01
+    agents["cov"][1, :, 1, 0] = 0.02
+    res = {}
+    for name, ag in (("bad", agents), ("good", good)):
+        sw = MetricSweep(S.VEHICLE_BMW320I, 0.1)
+        sw.set_agents(*[ag[k] for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")], check=False)
+        out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], mode="full")
+        torch_cuda.cuda.synchronize()
+        res[name] = (out.pair_f.cpu().numpy(), out.lists.cpu().numpy(), out.safe.cpu().numpy())
+    pf, ls, safe = res["bad"]
+    gpf, gls, _ = res["good"]
+    assert gpf[N.PF["max_collision_probability"], 1, 5] > 0.01              # the clean run does see a probability there
+    assert np.isnan(pf[N.PF["max_collision_probability"], 1, 5]) and np.isnan(pf[N.PF["max_obst_risk"], 1, 5])
+    ingate = gls[N.LST["cp"], 1, :, 5] > 0
+    assert ingate.any() and np.isnan(ls[N.LST["cp"], 1, :, 5][ingate]).all()
+    for k in (0, 2):                                                         # the other agents: bit-identical
+        assert np.array_equal(pf[:, k], gpf[:, k], equal_nan=True) and np.array_equal(ls[:, k], gls[:, k], equal_nan=True)
+    assert not safe.any()
+
+
 def test_full_size_properties_10k_x_256(torch_cuda):
     """BASELINE full size (10 000 x 256): size-independent properties instead of an oracle run.
     (1) permuting the agents permutes pair outputs and leaves the per-trajectory maxima unchanged;
@@ -572,8 +601,8 @@ def test_horizon_split_variant_is_bit_identical(torch_cuda, monkeypatch):
 def test_correlated_covariances_against_the_oracle_and_the_diagonal_limit(torch_cuda, oracle):
     """full covariance matrices (real agents from a prediction module; the reference hands any matrix to mvnun,
     collision_probability.py:117): the numerical box integral of the kernel against the oracle's (itself pinned to the
-    reference by tests/golden/correlated_cov.npz), mixed with diagonal agents in one batch, high correlations (96-node
-    rule), and the limit rho -> 0 against the closed form"""
+    reference by tests/golden/correlated_cov.npz), mixed with diagonal agents in one batch, high correlations (the
+    20- and 24-node rules of the correlation-angle integral), and the limit rho -> 0 against the closed form"""
     from frenetix_occlusion import synthetic as S
     rng = np.random.default_rng(4)
     traj, agents = S.make_batch(150, 6, config_id=31)
