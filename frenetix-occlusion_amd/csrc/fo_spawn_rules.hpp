@@ -22,6 +22,15 @@
 
 namespace {
 
+#ifndef FO_RULE_TRACE
+#define FO_RULE_TRACE 0
+#endif
+#if FO_RULE_TRACE
+#define RL_TICK(i) do { __syncthreads(); if (threadIdx.x == 0) rec[16 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define RL_TICK(i) do { } while (0)
+#endif
+
 constexpr double RL_MAX_DIST_OBST = 30.0;          // spawn_locator.py:69
 constexpr double RL_MIN_DIST_PED = 5.0;            // :73
 constexpr double RL_TOL_SAME_DIR = 20.0 / 180.0 * 3.14159265358979323846;   // :68
@@ -362,71 +371,80 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
   const int tid = threadIdx.x, nth = blockDim.x;
   const double cx = ocen[2 * o], cy = ocen[2 * o + 1], oy = oyaw[o], olen = odims[2 * o], owid = odims[2 * o + 1];
   const double *oc = ocorn + 8 * (size_t)o;
-  __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn;
+  __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn, s_ego_ll, s_inter;
   __shared__ double s_c[2], s_yaw;
+  // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
+  // oncoming neighbours (adj_left) of the lanelets under every fifth vertex of the reference window.  Flags per lanelet
+  // in ired[0, P): bit0 relevant, bit1 inner -- computed once, in parallel (P <= 97 x 97)
+  if (v.P > RL_LAT * RL_LAT) return;
+  for (int p = tid; p < v.P; p += nth) ired[p] = 0;
   if (tid == 0) {
     rec[2] = 0.0; rec[5] = 0.0;
     s_go = 0;
     s_npol = 0;
+    s_inter = -1;
+    s_ego_ll = rl_lanelet_of(v, pr.ego_x, pr.ego_y);
+    for (int it = 0; it < v.n_inter && s_inter < 0 && s_ego_ll >= 0; ++it)
+      for (int e = v.inter_off[it]; e < v.inter_off[it + 1]; ++e)
+        if (v.inter_lanelet[e] == s_ego_ll) { s_inter = it; break; }
+  }
+  __syncthreads();
+  if (s_ego_ll < 0) return;
+  if (s_inter >= 0) {
+    for (int e = v.inter_off[s_inter] + tid; e < v.inter_off[s_inter + 1]; e += nth) {
+      const int p = v.inter_lanelet[e];
+      atomicOr(&ired[p], (p != s_ego_ll ? 1 : 0) | (v.inter_kind[e] == 1 ? 2 : 0));
+    }
+  } else if (v.adj_left) {
+    for (int i = pr.win_i0 + 5 * tid; i < pr.win_i1; i += 5 * nth) {
+      const double *q = v.path + 6 * (size_t)i;
+      const int ll = rl_lanelet_of(v, q[0], q[1]);
+      if (ll >= 0 && v.adj_left[ll] >= 0) atomicOr(&ired[v.adj_left[ll]], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
     do {
       if (sqrt((pr.ego_x - cx) * (pr.ego_x - cx) + (pr.ego_y - cy) * (pr.ego_y - cy)) > RL_MAX_DIST_OBST) break;   // :215
-      // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
-      // oncoming neighbours (adj_left) of the lanelets under every fifth vertex of the reference window
-      const int ego_ll = rl_lanelet_of(v, pr.ego_x, pr.ego_y);
-      if (ego_ll < 0) break;
-      int inter = -1;
-      for (int it = 0; it < v.n_inter && inter < 0; ++it)
-        for (int e = v.inter_off[it]; e < v.inter_off[it + 1]; ++e)
-          if (v.inter_lanelet[e] == ego_ll) { inter = it; break; }
-      auto relevant = [&](int p) {
-        if (inter >= 0) {
-          if (p == ego_ll) return false;
-          for (int e = v.inter_off[inter]; e < v.inter_off[inter + 1]; ++e)
-            if (v.inter_lanelet[e] == p) return true;
-          return false;
-        }
-        for (int i = pr.win_i0; i < pr.win_i1; i += 5) {
-          const double *q = v.path + 6 * (size_t)i;
-          const int ll = rl_lanelet_of(v, q[0], q[1]);
-          if (ll >= 0 && v.adj_left && v.adj_left[ll] == p) return true;
-        }
-        return false;
-      };
-      auto inner = [&](int p) {
-        if (inter < 0) return false;
-        for (int e = v.inter_off[inter]; e < v.inter_off[inter + 1]; ++e)
-          if (v.inter_lanelet[e] == p && v.inter_kind[e] == 1) return true;
-        return false;
-      };
       // the obstacle's lanelets (all that hold its centre, list order)
       int n_ob = 0, first_rel = -1;
       bool any_rel = false, all_inner = true;
       for (int p = 0; p < v.P; ++p)
         if (rl_in_polygon(v, p, cx, cy)) {
           ++n_ob;
-          const bool rel = relevant(p);
-          if (rel) { any_rel = true; if (first_rel < 0) first_rel = p; if (s_npol < 7) s_pol[s_npol++] = p; }
-          if (!inner(p)) all_inner = false;
+          if (ired[p] & 1) { any_rel = true; if (first_rel < 0) first_rel = p; if (s_npol < 7) s_pol[s_npol++] = p; }
+          if (!(ired[p] & 2)) all_inner = false;
         }
       if (!any_rel) break;                                                        // :222
       double ob_s, ob_d;
       if (!rl_to_curv(v, cx, cy, ob_s, ob_d)) break;
       if (ob_s < pr.ego_s + 3.0 || fabs(ob_d) > 15.0) break;                      // :234
-      if (inter >= 0 && n_ob > 0 && all_inner && v.pred0 && v.pred0[first_rel] >= 0 && s_npol < 8) s_pol[s_npol++] = v.pred0[first_rel];   // :249-252
+      if (s_inter >= 0 && n_ob > 0 && all_inner && v.pred0 && v.pred0[first_rel] >= 0 && s_npol < 8) s_pol[s_npol++] = v.pred0[first_rel];   // :249-252
       s_go = 1;
     } while (false);
   }
   __syncthreads();
   if (!s_go) return;
+  RL_TICK(0);
   const int npol = s_npol;
+  // (the relevance flags move to the end of `lab`'s companion array later; keep a compact copy for the centroid test)
+  unsigned char *relflag = fitok + 1536;   // [P] bit0: relevant -- only consulted for the few lanelets holding the centroid
+  const bool rel_fits = v.P <= 512;
+  if (rel_fits)
+    for (int p = tid; p < v.P; p += nth) relflag[p] = (unsigned char)(ired[p] & 1);
+  __syncthreads();
   // membership of a point in the candidate region's defining sets (:254-277)
   const double diff = fmod(fabs(oy - pr.ego_yaw), 6.283185307179586);
   const bool wedge = 3.141592653589793 - RL_TOL_SAME_DIR <= diff && diff <= 3.141592653589793 + RL_TOL_SAME_DIR;
   const double oc_c = cos(oy), oc_s = sin(oy);
+  // (the tests are a conjunction: cheapest first -- distance, the obstacle grown by 1 m, shadow / occluded class -- and
+  // the lanelet polygons, the dear ones, last)
   auto member = [&](double x, double y) {
-    bool ok = false;
-    for (int i = 0; i < npol && !ok; ++i) ok = rl_in_polygon(v, s_pol[i], x, y);
-    if (!ok) return false;
+    const double rx = x - cx, ry = y - cy;
+    if (!(sqrt(rx * rx + ry * ry) <= RL_BUFFER_SIDE)) return false;
+    const double lx_ = oc_c * rx + oc_s * ry, ly_ = -oc_s * rx + oc_c * ry;
+    const double ex_ = fmax(fabs(lx_) - olen / 2.0, 0.0), ey_ = fmax(fabs(ly_) - owid / 2.0, 0.0);
+    if (!(sqrt(ex_ * ex_ + ey_ * ey_) > 1.0)) return false;                       // minus the obstacle grown by 1 m
     if (wedge) {   // the obstacle's own shadow: the sight line ego -> point crosses the rectangle (:264)
       bool hit = false;
       const double dx = x - pr.ego_x, dy = y - pr.ego_y;
@@ -443,11 +461,9 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     } else if (!(rl_class_at(v, x, y) & 4)) {   // the global occluded area (:272)
       return false;
     }
-    const double rx = x - cx, ry = y - cy;
-    if (!(sqrt(rx * rx + ry * ry) <= RL_BUFFER_SIDE)) return false;
-    const double lx_ = oc_c * rx + oc_s * ry, ly_ = -oc_s * rx + oc_c * ry;
-    const double ex = fmax(fabs(lx_) - olen / 2.0, 0.0), ey = fmax(fabs(ly_) - owid / 2.0, 0.0);
-    return sqrt(ex * ex + ey * ey) > 1.0;                                         // minus the obstacle grown by 1 m
+    bool ok = false;                                                                // possible_polygon (:255)
+    for (int i = 0; i < npol && !ok; ++i) ok = rl_in_polygon(v, s_pol[i], x, y);
+    return ok;
   };
   // the 0.25 m lattice around the obstacle; label = linear index where the node is a member, INT_MAX elsewhere
   const double h = 0.25;
@@ -457,32 +473,48 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     lab[i] = member(cx + (-RL_BUFFER_SIDE + (double)ix * h), cy + (-RL_BUFFER_SIDE + (double)iy * h)) ? i : 0x7fffffff;
   }
   __syncthreads();
+  RL_TICK(1);
   // connected parts (4-neighbourhood, scipy.ndimage.label's default): minimum-label propagation, whole rows then whole
   // columns per round; every part ends up carrying its smallest linear index (= scipy's numbering order)
   for (int round = 0; round < 64; ++round) {
     if (tid == 0) s_changed = 0;
     __syncthreads();
+    // a thread per row, then per column: the whole line is loaded into registers (independent LDS loads, one wait), swept
+    // both ways there, and written back -- a sweep over LDS itself is a chain of ~200 dependent round trips
     bool ch = false;
     if (tid < RL_LAT) {
-      int *row = lab + tid * RL_LAT;
+      int line[RL_LAT];
+#pragma unroll
+      for (int c = 0; c < RL_LAT; ++c) line[c] = lab[tid * RL_LAT + c];
+#pragma unroll
       for (int c = 1; c < RL_LAT; ++c)
-        if (row[c] != 0x7fffffff && row[c - 1] != 0x7fffffff && row[c - 1] < row[c]) { row[c] = row[c - 1]; ch = true; }
+        if (line[c] != 0x7fffffff && line[c - 1] < line[c]) { line[c] = line[c - 1]; ch = true; }
+#pragma unroll
       for (int c = RL_LAT - 2; c >= 0; --c)
-        if (row[c] != 0x7fffffff && row[c + 1] != 0x7fffffff && row[c + 1] < row[c]) { row[c] = row[c + 1]; ch = true; }
+        if (line[c] != 0x7fffffff && line[c + 1] < line[c]) { line[c] = line[c + 1]; ch = true; }
+#pragma unroll
+      for (int c = 0; c < RL_LAT; ++c) lab[tid * RL_LAT + c] = line[c];
     }
     __syncthreads();
     if (tid < RL_LAT) {
-      int *col = lab + tid;
+      int line[RL_LAT];
+#pragma unroll
+      for (int r = 0; r < RL_LAT; ++r) line[r] = lab[r * RL_LAT + tid];
+#pragma unroll
       for (int r = 1; r < RL_LAT; ++r)
-        if (col[r * RL_LAT] != 0x7fffffff && col[(r - 1) * RL_LAT] != 0x7fffffff && col[(r - 1) * RL_LAT] < col[r * RL_LAT]) { col[r * RL_LAT] = col[(r - 1) * RL_LAT]; ch = true; }
+        if (line[r] != 0x7fffffff && line[r - 1] < line[r]) { line[r] = line[r - 1]; ch = true; }
+#pragma unroll
       for (int r = RL_LAT - 2; r >= 0; --r)
-        if (col[r * RL_LAT] != 0x7fffffff && col[(r + 1) * RL_LAT] != 0x7fffffff && col[(r + 1) * RL_LAT] < col[r * RL_LAT]) { col[r * RL_LAT] = col[(r + 1) * RL_LAT]; ch = true; }
+        if (line[r] != 0x7fffffff && line[r + 1] < line[r]) { line[r] = line[r + 1]; ch = true; }
+#pragma unroll
+      for (int r = 0; r < RL_LAT; ++r) lab[r * RL_LAT + tid] = line[r];
     }
     if (ch) s_changed = 1;
     __syncthreads();
     if (!s_changed) break;
     __syncthreads();
   }
+  RL_TICK(2);
   // the largest part (first maximum in label order, :279-281): sizes by the roots' labels
   if (tid == 0) { s_best = -1; s_bestn = 0; }
   for (int i = tid; i < NL; i += nth) ired[i] = 0;
@@ -490,13 +522,22 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
   for (int i = tid; i < NL; i += nth)
     if (lab[i] != 0x7fffffff) atomicAdd(&ired[lab[i]], 1);
   __syncthreads();
-  if (tid == 0) {
-    for (int i = 0; i < NL; ++i)
-      if (ired[i] > s_bestn) { s_bestn = ired[i]; s_best = i; }
+  {   // first maximum in label order: per-thread (count, smallest label), then thread 0 over the 256 partials
+    int bn = 0, bi = -1;
+    for (int i = tid; i < NL; i += nth)
+      if (ired[i] > bn || (ired[i] == bn && bn > 0 && i < bi)) { bn = ired[i]; bi = i; }
+    red[2 * tid] = (double)bn; red[2 * tid + 1] = (double)bi;
+    __syncthreads();
+    if (tid == 0)
+      for (int i = 0; i < nth; ++i) {
+        const int n_ = (int)red[2 * i], l_ = (int)red[2 * i + 1];
+        if (n_ > s_bestn || (n_ == s_bestn && n_ > 0 && l_ < s_best)) { s_bestn = n_; s_best = l_; }
+      }
+    __syncthreads();
   }
-  __syncthreads();
   const int best = s_best;
   if (best < 0 || (double)s_bestn * h * h < RL_MIN_AREA) return;                  // :282-284
+  RL_TICK(3);
   // centroid of the part (mean of its nodes; fixed summation order: per-thread partials, then thread 0)
   double ax = 0.0, ay = 0.0;
   for (int i = tid; i < NL; i += nth)
@@ -518,19 +559,15 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
   if (tid == 0) {
     s_go = 0;
     do {
-      // the centroid must lie on a relevant lanelet (:287-291); relevant = the polygons collected above minus a
-      // predecessor that was only added for the region -- so test the original relevant set again
-      const int ego_ll = rl_lanelet_of(v, pr.ego_x, pr.ego_y);
-      int inter = -1;
-      for (int it = 0; it < v.n_inter && inter < 0; ++it)
-        for (int e = v.inter_off[it]; e < v.inter_off[it + 1]; ++e)
-          if (v.inter_lanelet[e] == ego_ll) { inter = it; break; }
+      // the centroid must lie on a relevant lanelet (:287-291)
       bool rel_c = false;
       for (int p = 0; p < v.P && !rel_c; ++p)
         if (rl_in_polygon(v, p, s_c[0], s_c[1])) {
-          if (inter >= 0) {
-            if (p != ego_ll)
-              for (int e = v.inter_off[inter]; e < v.inter_off[inter + 1]; ++e)
+          if (rel_fits) {
+            rel_c = relflag[p] & 1;
+          } else if (s_inter >= 0) {
+            if (p != s_ego_ll)
+              for (int e = v.inter_off[s_inter]; e < v.inter_off[s_inter + 1]; ++e)
                 if (v.inter_lanelet[e] == p) rel_c = true;
           } else {
             for (int i = pr.win_i0; i < pr.win_i1 && !rel_c; i += 5) {
@@ -550,14 +587,16 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
   }
   __syncthreads();
   if (!s_go) return;
+  RL_TICK(4);
   // rectangle fits on a 0.1 m lattice (:695-726): lane-aligned rectangle clipped to the region -> area, centroid, Jaccard
   // similarity with the minimum rotated rectangle of the clipped part
   const double fc = cos(s_yaw), fs = sin(s_yaw);
   __shared__ double s_fit[4];   // area, cx, cy, jaccard
   __shared__ int s_fitany;
+  __shared__ int s_a0[32], s_a1[32], s_hr[72], s_hc[72], s_nv;
   auto fit = [&](double ccx, double ccy, double length, double width) {
     const double fh = 0.1;
-    const int nx_ = (int)rint(length / fh), ny_ = (int)rint(width / fh), np_ = nx_ * ny_;
+    const int nx_ = (int)rint(length / fh), ny_ = (int)rint(width / fh), np_ = nx_ * ny_;   // (ny_ <= 32)
     int cnt = 0;
     double fx = 0.0, fy = 0.0;
     for (int i = tid; i < np_; i += nth) {
@@ -569,73 +608,79 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     }
     red[3 * tid] = fx; red[3 * tid + 1] = fy; red[3 * tid + 2] = (double)cnt;
     __syncthreads();
+    // the clipped part's convex hull needs only the first and last clipped point of every lattice row (the rest of a row
+    // lies between them): a thread per row finds them while thread 0 adds up the partial sums
+    if (tid >= 64 && tid < 64 + ny_) {
+      const int r = tid - 64;
+      int a0 = -1, a1 = -1;
+      for (int c = 0; c < nx_; ++c)
+        if (fitok[r * nx_ + c]) { if (a0 < 0) a0 = c; a1 = c; }
+      s_a0[r] = a0; s_a1[r] = a1;
+    }
     if (tid == 0) {
       double sx_ = 0.0, sy_ = 0.0, n = 0.0;
       for (int i = 0; i < nth; ++i) { sx_ += red[3 * i]; sy_ += red[3 * i + 1]; n += red[3 * i + 2]; }
       s_fitany = n > 0.0;
-      if (n > 0.0) {
-        s_fit[0] = n * fh * fh; s_fit[1] = sx_ / n; s_fit[2] = sy_ / n;
-        if ((int)n == np_) {
-          s_fit[3] = 1.0;
-        } else {
-          // convex hull of the clipped lattice points: the extreme points of every lattice row suffice (the rest of a
-          // row is collinear between them); monotone chain, then the smallest rectangle over the hull's edge directions
-          double hx[128], hy[128];
-          int nh = 0;
-          for (int r = 0; r < ny_; ++r) {
-            int a0 = -1, a1 = -1;
-            for (int c = 0; c < nx_; ++c)
-              if (fitok[r * nx_ + c]) { if (a0 < 0) a0 = c; a1 = c; }
-            for (int t = 0; t < 2 && a0 >= 0; ++t) {
-              const int c = t == 0 ? a0 : a1;
-              if (t == 1 && a1 == a0) break;
-              const double u = ((double)c + 0.5) * fh - length / 2.0, w_ = ((double)r + 0.5) * fh - width / 2.0;
-              hx[nh] = ccx + fc * u - fs * w_; hy[nh] = ccy + fs * u + fc * w_; ++nh;
-            }
-          }
-          for (int i = 1; i < nh; ++i) {   // sort by (x, y)
-            const double px = hx[i], py = hy[i];
-            int j = i - 1;
-            while (j >= 0 && (hx[j] > px || (hx[j] == px && hy[j] > py))) { hx[j + 1] = hx[j]; hy[j + 1] = hy[j]; --j; }
-            hx[j + 1] = px; hy[j + 1] = py;
-          }
-          double kx[130], ky[130];
-          int k = 0;
-          for (int i = 0; i < nh; ++i) {
-            while (k >= 2 && (kx[k - 1] - kx[k - 2]) * (hy[i] - ky[k - 2]) - (ky[k - 1] - ky[k - 2]) * (hx[i] - kx[k - 2]) <= 1e-12) --k;
-            kx[k] = hx[i]; ky[k] = hy[i]; ++k;
-          }
-          const int lower = k + 1;
-          for (int i = nh - 2; i >= 0; --i) {
-            while (k >= lower && (kx[k - 1] - kx[k - 2]) * (hy[i] - ky[k - 2]) - (ky[k - 1] - ky[k - 2]) * (hx[i] - kx[k - 2]) <= 1e-12) --k;
-            kx[k] = hx[i]; ky[k] = hy[i]; ++k;
-          }
-          const int nv = k - 1;   // the last point repeats the first
-          double bestA = INFINITY;
-          if (nv >= 3)
-            for (int i = 0; i < nv; ++i) {
-              double ex = kx[(i + 1) % nv] - kx[i], ey = ky[(i + 1) % nv] - ky[i];
-              const double nn = sqrt(ex * ex + ey * ey);
-              if (nn == 0.0) continue;
-              ex /= nn; ey /= nn;
-              double a1n = INFINITY, a1x = -INFINITY, a2n = INFINITY, a2x = -INFINITY;
-              for (int q = 0; q < nv; ++q) {
-                const double p1 = kx[q] * ex + ky[q] * ey, p2 = kx[q] * (-ey) + ky[q] * ex;
-                a1n = fmin(a1n, p1); a1x = fmax(a1x, p1); a2n = fmin(a2n, p2); a2x = fmax(a2x, p2);
-              }
-              bestA = fmin(bestA, (a1x - a1n + fh) * (a2x - a2n + fh));
-            }
-          s_fit[3] = nv >= 3 ? fmin(1.0, s_fit[0] / bestA) : 0.0;
-        }
+      s_fit[0] = n * fh * fh; s_fit[1] = n > 0.0 ? sx_ / n : 0.0; s_fit[2] = n > 0.0 ? sy_ / n : 0.0;
+      s_fit[3] = ((int)n == np_) ? 1.0 : 0.0;
+      s_nv = 0;
+    }
+    __syncthreads();
+    if (!s_fitany || s_fit[3] == 1.0) return;   // nothing clipped in, or nothing clipped off (Jaccard 1)
+    if (tid == 0) {
+      // monotone chain in LATTICE coordinates (row, column) -- integers, so the turn tests are exact; the points come
+      // sorted (rows ascending, first before last); collinear points are dropped like QHull drops them
+      int pr_[64], pc_[64], np2 = 0;
+      for (int r = 0; r < ny_; ++r) {
+        if (s_a0[r] < 0) continue;
+        pr_[np2] = r; pc_[np2] = s_a0[r]; ++np2;
+        if (s_a1[r] != s_a0[r]) { pr_[np2] = r; pc_[np2] = s_a1[r]; ++np2; }
       }
+      int k = 0;
+      auto turn = [&](int i) {   // cross product (hull[k-2] -> hull[k-1]) x (hull[k-2] -> point i)
+        return (s_hr[k - 1] - s_hr[k - 2]) * (pc_[i] - s_hc[k - 2]) - (s_hc[k - 1] - s_hc[k - 2]) * (pr_[i] - s_hr[k - 2]);
+      };
+      for (int i = 0; i < np2; ++i) {
+        while (k >= 2 && turn(i) <= 0) --k;
+        s_hr[k] = pr_[i]; s_hc[k] = pc_[i]; ++k;
+      }
+      const int lower = k + 1;
+      for (int i = np2 - 2; i >= 0; --i) {
+        while (k >= lower && turn(i) <= 0) --k;
+        s_hr[k] = pr_[i]; s_hc[k] = pc_[i]; ++k;
+      }
+      s_nv = k - 1;   // the last point repeats the first
+    }
+    __syncthreads();
+    const int nv = s_nv;
+    if (nv < 3) return;   // degenerate (QHull raises): Jaccard 0
+    // the smallest rectangle over the hull's edge directions (:716-724), a thread per edge; lengths in lattice units
+    if (tid < nv) {
+      double ex = (double)(s_hc[(tid + 1) % nv] - s_hc[tid]), ey = (double)(s_hr[(tid + 1) % nv] - s_hr[tid]);
+      const double nn = sqrt(ex * ex + ey * ey);
+      ex /= nn; ey /= nn;
+      double a1n = INFINITY, a1x = -INFINITY, a2n = INFINITY, a2x = -INFINITY;
+      for (int q = 0; q < nv; ++q) {
+        const double p1 = (double)s_hc[q] * ex + (double)s_hr[q] * ey, p2 = (double)s_hc[q] * (-ey) + (double)s_hr[q] * ex;
+        a1n = fmin(a1n, p1); a1x = fmax(a1x, p1); a2n = fmin(a2n, p2); a2x = fmax(a2x, p2);
+      }
+      red[tid] = ((a1x - a1n) * fh + fh) * ((a2x - a2n) * fh + fh);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double bestA = INFINITY;
+      for (int i = 0; i < nv; ++i) bestA = fmin(bestA, red[i]);
+      s_fit[3] = fmin(1.0, s_fit[0] / bestA);
     }
     __syncthreads();
   };
   fit(s_c[0], s_c[1], 5.5, 2.5);
+  RL_TICK(5);
   if (!s_fitany) return;
   const double car_a = s_fit[0], car_x = s_fit[1], car_y = s_fit[2], car_j = s_fit[3];
   __syncthreads();
   fit(car_x, car_y, 2.0, 1.0);
+  RL_TICK(6);
   if (tid == 0) {
     if (car_a >= RL_AREA_CAR && car_j > 0.98) { rec[2] = 1.0; rec[3] = car_x; rec[4] = car_y; }
     if (s_fitany && s_fit[0] >= RL_AREA_BIKE && s_fit[3] > 0.98) { rec[5] = 1.0; rec[6] = s_fit[1]; rec[7] = s_fit[2]; }
@@ -760,6 +805,11 @@ __global__ void fo_spawn_rules_select_kernel(RuleView v, RuleParams pr, int O, c
       if (ok) put(RL_TYPE_PED, r[1], r[2], NAN, r[3], r[4], r[5], -1.0);
     }
   }
+#if FO_RULE_TRACE
+  for (int o = 0; o < O; ++o)
+    if (recs[(size_t)(1 + o) * RL_REC + 1] == 2.0 && recs[(size_t)(1 + o) * RL_REC + 16] != 0.0)
+      for (int i = 0; i < 8; ++i) out[8 * (size_t)(max_out - 1) + i] = recs[(size_t)(1 + o) * RL_REC + 16 + i];
+#endif
   *n_out = n < max_out ? n : max_out;
 }
 

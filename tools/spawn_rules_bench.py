@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""ms per step of `spawn.mode: rules` (the reference's rule families on the device) on the scenario-1 fixture: scene stage
++ fo_scene_spawn_rules + the read-back of the spawn points, as SpawnLocator.find_spawn_points issues them."""
+import math
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "frenetix-occlusion_amd"))
+import numpy as np
+import torch
+import yaml
+from frenetix_occlusion import interface
+from frenetix_occlusion import scenario as S
+from frenetix_occlusion.sensor_model import SensorModel
+from frenetix_occlusion.spawn_locator import SpawnLocator
+from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+
+sc = S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario1_geometry.npz"))
+with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+    cfg = yaml.safe_load(f)
+cfg["accelerator"]["spawn"]["mode"] = "rules"
+ego0 = sc.ego_initial
+yaw = float(ego0[2])
+path = ego0[None, :2] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+obs = FOObstacles(sc.obstacles)
+sm = SensorModel(sc.lanelets, path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, intersections=sc.intersections)
+sl = SpawnLocator(SimpleNamespace(scenario=sc), path, cfg, sm, fo_obstacles=obs)
+for step in (0, 8, 25, 60):
+    ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
+    obs.update(step)
+    sm.calc_visible_and_occluded_area(step, ego, yaw, obs)
+    pts = sl.find_spawn_points(ego, yaw, None, float(ego0[3]))
+    torch.cuda.synchronize()
+    n = 300
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pts = sl.find_spawn_points(ego, yaw, None, float(ego0[3]))
+    dt_rules = (time.perf_counter() - t0) / n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sl._rule_out.zero_()
+    torch.cuda.synchronize()
+    # device time of the two rule kernels alone (events around the launches, no read-back)
+    import frenetix_occlusion.spawn_locator as SLM
+    cpu = torch.Tensor.cpu
+    e0.record()
+    for _ in range(50):
+        sl._rule_points_device(ego, yaw, None, float(ego0[3]))
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"step {step}: {len(pts)} rule points ({[p.agent_type for p in pts]}), find_spawn_points {dt_rules * 1e3:.3f} ms "
+          f"(host + device + read-back), per call by events {e0.elapsed_time(e1) / 50:.3f} ms")
+    if os.environ.get("FO_RULE_TRACE"):
+        h = sl._rule_out.cpu().numpy()[120:128]
+        if h[0] != 0:
+            print("   dynamic-rule phases (us): ", np.round(np.diff(h[:7]) * 0.01, 1).tolist(), "(membership, labelling, sizes, centroid+checks, car fit, bicycle fit)")
