@@ -977,7 +977,8 @@ __device__ __forceinline__ bool spawn_pick(int j, int lane, const int32_t *__res
 }
 
 // Predictions in the layout fo_sweep_set_agents consumes, one wave per prediction slot (j, r), r < R:
-//   vehicle whose cell lies on a lanelet with routes -> route r of that lanelet: constant speed along the route's
+//   vehicle whose cell lies on a lanelet with routes -> route r of that lanelet: the reference's min-var(v) Frenet sample
+//     (speed held along the route, quintic lateral move to the nearest of d1 in {-0.5, 0, 0.5}); constant speed along the route's
 //     centre line, initial lateral offset kept (what the reference's min-var(v) Frenet sample amounts to; replaces
 //     route_planner.py:31-90 + frenetix_handler.py + agent.py:283-426); the prediction ends where the route ends;
 //   pedestrian / off-lane vehicle / no route table -> r = 0: straight constant velocity (agent.py:451-536), r > 0 empty.
@@ -1060,9 +1061,15 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
       const int i2 = __shfl_xor(bi, off);
       if (b2 < best || (b2 == best && i2 < bi)) { best = b2; bi = i2; s0 = s2; d0 = dd2; }
     }
+    // the Frenet sample the reference keeps (agent.py:349-379 on the nine samples of frenetix_handler.py:82-105): end speed
+    // v0, lateral target d1 = the one of {-0.5, 0, 0.5} nearest to d0 (first of equally near ones), quintic d(t) over 3 s
+    double d1 = -0.5;
+    if (fabs(0.0 - d0) < fabs(d1 - d0)) d1 = 0.0;
+    if (fabs(0.5 - d0) < fabs(d1 - d0)) d1 = 0.5;
+    const double t1 = 3.0;
     const double s_end = sq[nv - 1];
     for (int k = lane; k < T; k += 64) {
-      const double sk = s0 + spd * ((double)k * dt);
+      const double tk = (double)k * dt, sk = s0 + spd * tk;
       if (sk > s_end) continue;
       int lo = 0, hi = nv - 2;  // largest m <= nv-2 with sq[m] <= sk
       while (lo < hi) {
@@ -1072,10 +1079,13 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
       const int m = lo;
       const double ex = q[2 * m + 2] - q[2 * m], ey = q[2 * m + 3] - q[2 * m + 1];
       const double l = sqrt(ex * ex + ey * ey), ux = ex / l, uy = ey / l, loc = sk - sq[m];
-      P[2 * k] = q[2 * m] + loc * ux + d0 * (-uy);
-      P[2 * k + 1] = q[2 * m + 1] + loc * uy + d0 * ux;
-      Y[k] = atan2(uy, ux);
-      V[k] = spd;
+      const double tau = tk < t1 ? tk / t1 : 1.0;
+      const double dk = d0 + (d1 - d0) * (tau * tau * tau * (10.0 + tau * (-15.0 + 6.0 * tau)));
+      const double dd = (d1 - d0) * (30.0 * tau * tau * (1.0 + tau * (-2.0 + tau))) / t1;
+      P[2 * k] = q[2 * m] + loc * ux + dk * (-uy);
+      P[2 * k + 1] = q[2 * m + 1] + loc * uy + dk * ux;
+      Y[k] = atan2(uy, ux) + atan2(dd, spd);
+      V[k] = sqrt(spd * spd + dd * dd);
     }
     // number of samples on the route: sk is non-decreasing in k, so the valid samples are a prefix
     int cnt = 0;

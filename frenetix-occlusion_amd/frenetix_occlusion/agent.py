@@ -164,8 +164,9 @@ class FOAgentManager:
         return []
 
     def _route_prediction(self, agent, horizon, poly):
-        """constant speed along a route polyline, initial lateral offset kept (same construction as
-        fo_spawn_predict_kernel; replaces the frenetix sampler of agent.py:283-426)"""
+        """the reference's min-var(v) Frenet sample along a route polyline: speed held, quintic lateral move to the nearest
+        of d1 in {-0.5, 0, 0.5} (same construction as fo_spawn_predict_kernel; replaces the frenetix sampler of
+        agent.py:283-426, frenetix_handler.py:82-105)"""
         pr = self.config["prediction"]
         big = agent.agent_type.lower() == "bicycle"
         fl = pr["size_factor_length_l"] if big else pr["size_factor_length_s"]
@@ -186,13 +187,18 @@ class FOAgentManager:
             return None
         m = np.clip(np.searchsorted(sarr, sk, side="right") - 1, 0, len(l) - 1)
         u = e[m] / l[m][:, None]
-        pos = a[m] + (sk - sarr[m])[:, None] * u + d0 * np.stack((-u[:, 1], u[:, 0]), -1)
+        # the Frenet sample the reference keeps (agent.py:349-379; utils/frenet_sampling.py): speed held, quintic to d1
+        from .utils.frenet_sampling import lateral_profile, nearest_lateral_target
+        tk = np.arange(len(sk)) * self.dt
+        dk, dd = lateral_profile(d0, nearest_lateral_target(d0), tk)
+        pos = a[m] + (sk - sarr[m])[:, None] * u + dk[:, None] * np.stack((-u[:, 1], u[:, 0]), -1)
         L = len(sk)
         var = 0.1 * np.power(pr["variance_factor"], np.arange(L))
         cov = np.zeros((L, 2, 2))
         cov[:, 0, 0] = var
         cov[:, 1, 1] = var
-        return {"orientation_list": np.arctan2(u[:, 1], u[:, 0]), "v_list": np.full(L, agent.initial_velocity),
+        v0 = agent.initial_velocity
+        return {"orientation_list": np.arctan2(u[:, 1], u[:, 0]) + np.arctan2(dd, v0), "v_list": np.sqrt(v0 * v0 + dd * dd),
                 "pos_list": pos, "shape": {"length": agent.length * fl, "width": agent.width * fw}, "cov_list": cov}
 
     def _lane_center_at(self, pos):

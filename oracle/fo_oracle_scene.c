@@ -452,7 +452,8 @@ int fo_oracle_cv_predictions(int n, const double *pos0, const double *yaw, const
  * to the route's centre line -- what the reference's min-var(v) Frenet sample (d1 = d0, ss1 = v0) amounts to.
  * Slot (j, r), r < R:  vehicle on a lanelet with routes -> route r of that lanelet (len 0 if it has fewer);
  * pedestrian, or vehicle off-lane / without routes -> r = 0 is the straight constant-velocity prediction with
- * yaw_fallback[j], r > 0 empty.  A prediction ends (len < T) where the route polyline ends.  PARITY UNPINNED. */
+ * yaw_fallback[j], r > 0 empty.  A prediction ends (len < T) where the route polyline ends.  PARITY UNPINNED for the
+ * trajectory itself (frenetix is absent); the sample SET is pinned (tests/golden/sampling_matrix.npz). */
 int fo_oracle_route_predictions(int n, const double *pos0, const int32_t *type, const double *speed,
                                 const int32_t *lanelet, int R, const int32_t *first, const int32_t *count,
                                 const double *xy, const double *sarr, const double *yaw_fallback, int T, double dt,
@@ -501,18 +502,31 @@ int fo_oracle_route_predictions(int n, const double *pos0, const int32_t *type, 
           d0 = ((px - cx) * (-ey) + (py - cy) * ex) / l; /* offset along the left normal */
         }
       }
+      /* The Frenet sample the reference keeps (agent.py:349-379: smallest variance of the speed among the nine samples
+       * of frenetix_handler.py:82-105, d1 in {-0.5, 0, 0.5} x end speed in {0.8, 1, 1.2} v0, t1 = 3 s): the one that holds
+       * the speed (end speed v0: s' = v0 throughout) and moves least sideways -- d1 = the lateral target nearest to d0
+       * (the first of equally near ones, in sampling order).  d(t) is the quintic with zero lateral velocity and
+       * acceleration at both ends; on a straight piece of the route the Cartesian speed is sqrt(s'^2 + d'^2) and the
+       * heading leaves the route's by atan(d'/s'). */
+      double d1 = -0.5;
+      if (fabs(0.0 - d0) < fabs(d1 - d0)) d1 = 0.0;
+      if (fabs(0.5 - d0) < fabs(d1 - d0)) d1 = 0.5;
+      const double t1 = 3.0; /* frenetix_handler.py:84 */
       const double s_end = sq[nv - 1];
       int m = 0, k = 0;
       for (; k < T; ++k) {
-        const double sk = s0 + speed[j] * ((double)k * dt);
+        const double tk = (double)k * dt, sk = s0 + speed[j] * tk;
         if (sk > s_end) break;
         while (m + 2 < nv && sq[m + 1] <= sk) ++m; /* segment with s[m] <= sk (last segment at the very end) */
         const double ex = q[2 * m + 2] - q[2 * m], ey = q[2 * m + 3] - q[2 * m + 1];
         const double l = sqrt(ex * ex + ey * ey), ux = ex / l, uy = ey / l, loc = sk - sq[m];
-        P[2 * k] = q[2 * m] + loc * ux + d0 * (-uy);
-        P[2 * k + 1] = q[2 * m + 1] + loc * uy + d0 * ux;
-        Y[k] = atan2(uy, ux);
-        V[k] = speed[j];
+        const double tau = tk < t1 ? tk / t1 : 1.0;
+        const double dk = d0 + (d1 - d0) * (tau * tau * tau * (10.0 + tau * (-15.0 + 6.0 * tau)));
+        const double dd = (d1 - d0) * (30.0 * tau * tau * (1.0 + tau * (-2.0 + tau))) / t1; /* d'(t) */
+        P[2 * k] = q[2 * m] + loc * ux + dk * (-uy);
+        P[2 * k + 1] = q[2 * m + 1] + loc * uy + dk * ux;
+        Y[k] = atan2(uy, ux) + atan2(dd, speed[j]);
+        V[k] = sqrt(speed[j] * speed[j] + dd * dd);
       }
       len[slot] = k;
     }

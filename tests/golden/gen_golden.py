@@ -679,5 +679,28 @@ def main():
     run_route_enumeration("routes")
 
 
+def gen_sampling_matrix():
+    """the matrix the reference hands to the frenetix sampler for a phantom vehicle (utils/frenetix_handler.py:82-105),
+    from its own, natively importable utils/sampling.py -- inputs and outputs only"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_sampling", os.path.join(REF, "frenetix_occlusion", "utils", "sampling.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    sh = m.SamplingHandler(dt=0.1, max_sampling_number=1, t_min=2.0, horizon=3.0, delta_d_max=0.5, delta_d_min=-0.5)
+    d1_range = np.array(list(sh.d_sampling.to_range(0)))
+    cases = np.array([[12.5, 1.2, 8.33], [0.0, 0.0, 30 / 3.6], [40.0, -0.3, 5.0], [7.0, 0.25, 13.9], [3.0, -2.0, 10.0]])
+    mats = []
+    for s0, d0, v0 in cases:
+        mats.append(m.generate_sampling_matrix(t0_range=0.0, t1_range=3.0, s0_range=s0, ss0_range=v0, sss0_range=0,
+                                               ss1_range=np.array([v0 * 0.8, v0, v0 * 1.2]), sss1_range=0, d0_range=d0,
+                                               dd0_range=0, ddd0_range=0, d1_range=d1_range, dd1_range=0.0, ddd1_range=0.0))
+    np.savez(os.path.join(OUT, "sampling_matrix.npz"), cases=cases, d1_range=d1_range, matrices=np.array(mats))
+    print("sampling_matrix.npz", np.array(mats).shape)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "sampling":     # only the sampling-matrix fixture
+        gen_sampling_matrix()
+    else:
+        main()
+        gen_sampling_matrix()

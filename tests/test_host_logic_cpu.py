@@ -241,3 +241,42 @@ def test_dependency_closure_equals_the_references():
     from frenetix_occlusion.metrics.metric import check_required_metrics
     for activated, _, evaluated, _ in load_threshold_case()[4]:
         assert sorted(check_required_metrics(list(activated))) == evaluated, activated
+
+
+def test_pedestrian_heading_without_a_given_orientation_known_answers():
+    """agent.py:475-481 + helper_functions.py:38-76: a pedestrian whose spawn point brings no orientation heads for the
+    closest point of its curve -- the ego's reference path (mode 'ref_path') or the centre line of the lanelet it stands
+    on (mode 'lane_center', agent.py:459-467; off-lanelet falls back to the reference path, Q12) -- as an angle in
+    [0, 2 pi) (angle_between_positive).  Closed-form cases; the shapely projection itself is not available here."""
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.agent import FOAgentManager
+    xs = np.linspace(0.0, 40.0, 21)
+    lane = S.Lanelet(1, np.stack((xs, np.full(21, 6.0)), -1), np.stack((xs, np.full(21, 2.0)), -1))     # centre line y = 4
+    sc = S.Scenario(0.1, [lane], [])
+    path = np.array([[0.0, 0.0], [10.0, 0.0], [10.0, 10.0]])                                           # an L: +x, then +y
+    cfg = {"pedestrian": {"length": 0.3, "width": 0.5, "default_velocity": 1.4},
+           "prediction": {"variance_factor": 1.05, "size_factor_length_s": 1.2, "size_factor_width_s": 1.3,
+                          "size_factor_length_l": 1.4, "size_factor_width_l": 2.5}}
+    am = FOAgentManager(sc, path, cfg, 0, device="cpu")
+    h = am._heading_towards_path
+    assert h(np.array([4.0, 3.0])) == pytest.approx(1.5 * math.pi)          # left of the first leg: straight down to it
+    assert h(np.array([4.0, -2.0])) == pytest.approx(0.5 * math.pi)         # right of it: straight up
+    assert h(np.array([13.0, 5.0])) == pytest.approx(math.pi)               # right of the second leg: towards -x
+    assert h(np.array([12.0, -2.0])) == pytest.approx(0.75 * math.pi)       # outside the corner: towards the corner vertex
+    assert h(np.array([-3.0, 4.0])) == pytest.approx(2.0 * math.pi - math.atan2(4.0, 3.0))   # before the start: towards the first vertex
+    assert h(np.array([10.0, 14.0])) == pytest.approx(1.5 * math.pi)        # beyond the end: back towards the last vertex
+    assert h(np.array([4.0, 0.0])) == 0.0                                   # on the curve: no direction -> 0
+    # through add_agent: ref_path mode heads for the reference path, lane_center mode for the lanelet's centre line ...
+    a = am.add_agent(np.array([20.0, 5.5]), agent_type="Pedestrian", mode="ref_path")
+    assert a.initial_orientation == pytest.approx(math.pi)                 # closest point (10, 5.5) on the second leg
+    b = am.add_agent(np.array([20.0, 5.5]), agent_type="Pedestrian", mode="lane_center")
+    assert b.initial_orientation == pytest.approx(1.5 * math.pi)           # centre line y = 4 lies below
+    # ... off-lanelet the lane_center mode falls back to the reference path instead of returning no trajectory (Q12)
+    c = am.add_agent(np.array([4.0, -2.0]), agent_type="Pedestrian", mode="lane_center")
+    assert c.initial_orientation == pytest.approx(0.5 * math.pi) and len(c.predictions) == 1
+    # a given orientation is taken as is (interface.py:192-198 passes the spawn point's)
+    d = am.add_agent(np.array([4.0, -2.0]), agent_type="Pedestrian", orientation=0.3)
+    assert d.initial_orientation == 0.3
+    # the velocity components are rounded to 3 decimals (agent.py:492-493, Q12)
+    p = c.predictions[0]["pos_list"]
+    np.testing.assert_allclose(p[10] - p[0], [round(1.4 * math.cos(c.initial_orientation), 3), round(1.4 * math.sin(c.initial_orientation), 3)], atol=1e-12)

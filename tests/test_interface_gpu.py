@@ -195,6 +195,12 @@ def test_rule_based_spawn_points_through_the_interface(torch_cuda, oracle, tmp_p
         got = ba.cost.cpu().numpy()
         f = np.isfinite(ref["cost"])
         assert np.array_equal(np.isfinite(got), f)
+        # the agent index of the largest risk only means something where that risk is numerically there (risks of 1e-19
+        # are the erf table's noise: either side may name any agent)
+        ia, ir = oracle.COST["argmax_risk"], oracle.COST["max_obst_risk_all"]
+        sig = ref["cost"][:, ir] > 1e-9
+        assert np.array_equal(got[sig, ia], ref["cost"][sig, ia])
+        got[:, ia] = ref["cost"][:, ia]
         np.testing.assert_allclose(got[f], ref["cost"][f], rtol=0, atol=1e-9)
     assert found["rules"] == (1, 1) and found["both"][0] > 1 and found["both"][1] == 1
 

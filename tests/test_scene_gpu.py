@@ -290,7 +290,7 @@ def test_phantom_vehicle_predictions_follow_lanelet_routes(torch_cuda, oracle):
         assert np.array_equal(got_len[:n * R], ln) and (got_len[n * R:] == 0).all()
         np.testing.assert_allclose(b.pos.cpu().numpy()[:n * R], pos, rtol=0, atol=1e-9)
         np.testing.assert_allclose(b.yaw.cpu().numpy()[:n * R], yl, rtol=0, atol=1e-12)
-        np.testing.assert_allclose(b.v.cpu().numpy()[:n * R], vl, rtol=0, atol=0)
+        np.testing.assert_allclose(b.v.cpu().numpy()[:n * R], vl, rtol=0, atol=1e-12)
         np.testing.assert_allclose(b.cov.cpu().numpy()[:n * R], cov, rtol=1e-13, atol=0)
         assert np.array_equal(b.type.cpu().numpy()[:n * R], np.repeat(types, R))
         veh_routes = ln.reshape(n, R)[types != 4]
