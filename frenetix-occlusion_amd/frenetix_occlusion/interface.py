@@ -15,6 +15,7 @@ occluded-cell frontier instead of the three GEOS rule families; no matplotlib (`
 metric ``'be'`` implies ``'ttc'`` (the reference raises KeyError when ``'be'`` is activated without it).
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -61,6 +62,8 @@ class FOInterface:
         self.sensor_angle = self.config["sensor_model"]["sensor_angle"]
         self.visualization = None   # debug drawing is out of scope (forces TkAgg upstream)
         self.include_real_agents = bool(acc.get("include_real_agents", False))
+        self._timing_sync = str(acc.get("timing", "issue")) == "device"
+        self.step_timing = {}
 
         self.ctx = N.Context(self.device.index)
         self.fo_obstacles = FOObstacles(self.cr_scenario.obstacles)
@@ -99,7 +102,25 @@ class FOInterface:
                                          agent_type=agent["agent_type"], add_to_scenario=True,
                                          timestep=agent["timestep"], horizon=agent["horizon"])
 
+    def _tick(self, name, t0):
+        """stage timer of ``step_timing``: host wall time since t0; with ``accelerator.timing: device`` the stream is
+        drained first, so the figure is the stage's own GPU + host time instead of the time to issue it"""
+        if self._timing_sync:
+            torch.cuda.current_stream(self.device).synchronize()
+        t1 = time.perf_counter()
+        self.step_timing[name] = (t1 - t0) * 1e3
+        return t1
+
     def evaluate_scenario(self, predictions, ego_pos, ego_orientation, ego_pos_cl, ego_v, timestep, cosy_cl=None):
+        """ref: interface.py:148-214.  Besides the visible area (the return value) the call leaves
+        ``self.step_timing``: milliseconds per stage of this planning step -- ``obstacles_ms`` (state cache),
+        ``visibility_ms`` (ray fan, cell classes), ``spawn_ms`` (phantom sampling / rule families + predictions),
+        ``agents_ms`` (registry), ``evaluate_scenario_ms`` (all of it), later ``assessment_batch_ms`` /
+        ``assessment_single_ms`` (metric sweep calls; the latter accumulates over the per-trajectory calls of the step
+        and counts them in ``assessment_single_calls``).  Host wall times of asynchronous work = the time to ISSUE it,
+        unless ``accelerator.timing: device`` (see :meth:`_tick`)."""
+        t_all = t0 = time.perf_counter()
+        self.step_timing = {"timestep": int(timestep), "mode": "device" if self._timing_sync else "issue"}
         self.set_coordinate_system(cosy_cl)
         self._update_time_step(timestep)
         self._add_real_agents()
@@ -112,14 +133,17 @@ class FOInterface:
         self.spawn_points = []
 
         self.fo_obstacles.update(self.timestep)
+        t0 = self._tick("obstacles_ms", t0)
         self.sensor_model.calc_visible_and_occluded_area(timestep=self.timestep, ego_pos=self.ego_pos,
                                                          ego_orientation=self.ego_orientation,
                                                          obstacles=self.fo_obstacles)
         self.fo_obstacles.update_multipolygon()
+        t0 = self._tick("visibility_ms", t0)
 
         # phantom sampling + predictions stay on the device; the spawn-point list is the reference's host view
         self.spawn_points = self.spawn_locator.find_spawn_points(self.ego_pos, self.ego_orientation, self.ego_pos_cl,
                                                                  ego_v)
+        t0 = self._tick("spawn_ms", t0)
         if self.spawn_locator.batch is not None:
             self.agent_manager.attach_batch(self.spawn_locator.batch, self.spawn_locator.n_cell_points)
         for sp in self.spawn_locator.rule_points:       # rule-based points become agents the reference's way (:192-198)
@@ -138,10 +162,17 @@ class FOInterface:
                 t = getattr(ob, "obstacle_type", None)
                 types[oid] = getattr(t, "value", t) or "car"
             self.agent_manager.set_external_predictions(self.predictions, types)
+        self._tick("agents_ms", t0)
+        self.step_timing["n_spawn_points"] = len(self.spawn_points)
+        self._tick("evaluate_scenario_ms", t_all)
         return self.sensor_model.visible_area
 
     def trajectory_safety_assessment(self, trajectory):
+        t0 = time.perf_counter()
         metrics, safety_assessment = self.metrics.evaluate_metrics(trajectory)
+        st = self.step_timing
+        st["assessment_single_ms"] = st.get("assessment_single_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+        st["assessment_single_calls"] = st.get("assessment_single_calls", 0) + 1
         return metrics, safety_assessment
 
     # ---------------------------------------------------------------------------------------- batched entry (new)
@@ -153,7 +184,11 @@ class FOInterface:
         ``mode='full'`` and a list input, later ``trajectory_safety_assessment(t)`` calls for the same objects are
         served from this batch."""
         remember = trajectories if (mode == "full" and not isinstance(trajectories, dict)) else None
-        return self.metrics.evaluate_batch(trajectories, mode=mode, remember=remember)
+        t0 = time.perf_counter()
+        ba = self.metrics.evaluate_batch(trajectories, mode=mode, remember=remember)
+        self._tick("assessment_batch_ms", t0)
+        self.step_timing["assessment_batch_size"] = 0 if ba is None else len(ba)
+        return ba
 
     def future_visibility_batch(self, trajectories, t_stride=5, n_rays=192):
         """EXTENSION, not part of the reference: per candidate trajectory and every ``t_stride``-th sample, the number

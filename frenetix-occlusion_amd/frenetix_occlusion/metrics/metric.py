@@ -118,65 +118,141 @@ class BatchAssessment:
                 torch.stack([v[:, :, m] for v in r.list_views()]).cpu().numpy())
 
     def result_dict(self, m):
-        """the reference's nested dict for trajectory m; needs mode 'full'.
+        """the reference's nested dict for trajectory m and its safety flag; needs mode 'full'.
 
-        One strided gather per output array pulls trajectory m's column out of the batch; the per-prediction entries
-        are then cut from plain Python lists (``ndarray.tolist`` once per array), which is what keeps a planner that
-        still asks trajectory by trajectory (interface.py:216-219) at a fraction of a millisecond per call."""
+        The dict is LAZY (:class:`LazyMetrics`): it has the reference's keys in the reference's order from the start, but
+        a metric's sub-dict is cut from the batch only when it is first read -- a planner that asks trajectory by
+        trajectory (interface.py:216-219) and looks at ``['hr']['max_obst_risk_all']`` or the flag pays microseconds per
+        call instead of building thirty per-prediction entries it never opens."""
         if self.result.lists_raw is None:
             raise RuntimeError("result_dict needs the batch to be evaluated with mode='full'")
         h = self._to_host()
+        return LazyMetrics(self, m), bool(h["safe"][m])
+
+    def _build_metric(self, m, name, col):
+        """sub-dict of metric `name` for trajectory m; col = that trajectory's column (see _column), shared by the metrics
+        of one LazyMetrics"""
+        h = self._to_host()
         cost = h["cost"][m]
-        pf, pi, ls = self._column(m)                # [NPF, A], [NPI, A], [NL, A, T-1]
-        # entries past a list's length are NaN (hr.py:87-98 stops at min(T-1, len(prediction))): lengths per slot
-        n_valid = (~np.isnan(ls)).sum(axis=2)       # [NL, A]
-        pf_l, pi_l = pf.tolist(), pi.tolist()
+        pf, pi, ls, n_valid, pf_l, pi_l = col
         PF, PI, LST = N.PF, N.PI, N.LST
         slots = self.prediction_slots
-        out = {}
-        for name in self.metric_order:
-            if name == "cp":
-                row, nv = ls[LST["cp"]], n_valid[LST["cp"]]
-                out["cp"] = {pid: row[k, :nv[k]] for pid, k in slots}     # views of this call's own gather
-            elif name == "dce":
-                d, t = pf_l[PF["dce"]], pi_l[PI["time_dce"]]
-                out["dce"] = {pid: {"dce": d[k], "time_dce": t[k]} for pid, k in slots}
-            elif name == "ttc":
-                v = pf_l[PF["ttc"]]
-                out["ttc"] = {pid: v[k] for pid, k in slots}
-            elif name == "ttce":
-                v = pf_l[PF["ttce"]]
-                out["ttce"] = {pid: v[k] for pid, k in slots}
-            elif name == "wttc":
-                out["wttc"] = float(cost[N.COST["wttc"]])
-            elif name == "be":
-                d, b = pf_l[PF["be_decel"]], pf_l[PF["be_btn"]]
-                out["be"] = {pid: {"required_constant_deceleration": d[k], "break_threat_number": b[k]}
-                             for pid, k in slots}
-            elif name == "hr":
-                hr = {}
-                valid = pi_l[PI["hr_valid"]]
-                mer, mor, mhc = pf_l[PF["max_ego_risk"]], pf_l[PF["max_obst_risk"]], pf_l[PF["max_obst_harm_with_cp"]]
-                meh, moh, mcp = pf_l[PF["max_ego_harm"]], pf_l[PF["max_obst_harm"]], pf_l[PF["max_collision_probability"]]
-                ridx = pi_l[PI["max_obst_risk_index"]]
-                i_er, i_or, i_eh, i_oh, i_cp = (LST[k_] for k_ in ("ego_risk", "obst_risk", "ego_harm", "obst_harm", "cp"))
-                er_l, or_l = ls[i_er].tolist(), ls[i_or].tolist()      # the two lists the reference returns as lists
-                for pid, k in slots:
-                    if not valid[k]:
-                        continue
-                    hr[pid] = {"max_ego_risk": mer[k], "max_obst_risk": mor[k], "max_obst_harm_with_cp": mhc[k],
-                               "max_obst_risk_index": ridx[k], "max_ego_harm": meh[k], "max_obst_harm": moh[k],
-                               "ego_risk_traj": er_l[k][:n_valid[i_er, k]],
-                               "obst_risk_traj": or_l[k][:n_valid[i_or, k]],
-                               "ego_harm_traj": ls[i_eh, k, :n_valid[i_eh, k]],
-                               "obst_harm_traj": ls[i_oh, k, :n_valid[i_oh, k]],
-                               "collision_probability": ls[i_cp, k, :n_valid[i_cp, k]],
-                               "max_collision_probability": mcp[k]}
-                for key in ("max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
-                            "max_collision_probability_all", "max_obst_harm_with_cp_all"):
-                    hr[key] = float(cost[N.COST[key]])
-                out["hr"] = hr
-        return out, bool(h["safe"][m])
+        if name == "cp":
+            row, nv = ls[LST["cp"]], n_valid[LST["cp"]]
+            return {pid: row[k, :nv[k]] for pid, k in slots}          # views of this trajectory's own gather
+        if name == "dce":
+            d, t = pf_l[PF["dce"]], pi_l[PI["time_dce"]]
+            return {pid: {"dce": d[k], "time_dce": t[k]} for pid, k in slots}
+        if name == "ttc":
+            v = pf_l[PF["ttc"]]
+            return {pid: v[k] for pid, k in slots}
+        if name == "ttce":
+            v = pf_l[PF["ttce"]]
+            return {pid: v[k] for pid, k in slots}
+        if name == "wttc":
+            return float(cost[N.COST["wttc"]])
+        if name == "be":
+            d, b = pf_l[PF["be_decel"]], pf_l[PF["be_btn"]]
+            return {pid: {"required_constant_deceleration": d[k], "break_threat_number": b[k]} for pid, k in slots}
+        if name == "hr":
+            return LazyHR(self, cost, col)
+        raise KeyError(name)
+
+    def _hr_entry(self, k, col):
+        pf, pi, ls, n_valid, pf_l, pi_l = col
+        PF, PI, LST = N.PF, N.PI, N.LST
+        i_er, i_or, i_eh, i_oh, i_cp = (LST[k_] for k_ in ("ego_risk", "obst_risk", "ego_harm", "obst_harm", "cp"))
+        return {"max_ego_risk": pf_l[PF["max_ego_risk"]][k], "max_obst_risk": pf_l[PF["max_obst_risk"]][k],
+                "max_obst_harm_with_cp": pf_l[PF["max_obst_harm_with_cp"]][k],
+                "max_obst_risk_index": pi_l[PI["max_obst_risk_index"]][k], "max_ego_harm": pf_l[PF["max_ego_harm"]][k],
+                "max_obst_harm": pf_l[PF["max_obst_harm"]][k],
+                "ego_risk_traj": ls[i_er, k, :n_valid[i_er, k]].tolist(),      # the two lists the reference returns as lists
+                "obst_risk_traj": ls[i_or, k, :n_valid[i_or, k]].tolist(),
+                "ego_harm_traj": ls[i_eh, k, :n_valid[i_eh, k]], "obst_harm_traj": ls[i_oh, k, :n_valid[i_oh, k]],
+                "collision_probability": ls[i_cp, k, :n_valid[i_cp, k]],
+                "max_collision_probability": pf_l[PF["max_collision_probability"]][k]}
+
+
+_UNBUILT = object()
+
+
+class _LazyDict(dict):
+    """a dict whose values are produced on first access: every key is there from the start (order, ``in``, ``len`` and
+    iteration are a plain dict's), unbuilt values are placeholders that ``[]``, ``get``, ``items``, ``values``, ``==`` and
+    ``materialize`` replace by the real thing"""
+
+    def _build(self, key):
+        raise NotImplementedError
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is _UNBUILT:
+            v = self._build(key)
+            dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def materialize(self):
+        for k in list(dict.keys(self)):
+            v = self[k]
+            if isinstance(v, _LazyDict):
+                v.materialize()
+        return self
+
+    def values(self):
+        return dict.values(self.materialize())
+
+    def items(self):
+        return dict.items(self.materialize())
+
+    def __eq__(self, other):
+        return dict.__eq__(self.materialize(), other.materialize() if isinstance(other, _LazyDict) else other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return dict.__repr__(self.materialize())
+
+    def copy(self):
+        return dict(self.materialize())
+
+    def __reduce__(self):
+        return (dict, (dict(self.materialize()),))
+
+
+class LazyMetrics(_LazyDict):
+    """result dict of one trajectory (keys = the activated metrics in the reference's order, metric.py:125-147)"""
+
+    def __init__(self, batch, m):
+        super().__init__((name, _UNBUILT) for name in batch.metric_order)
+        self._batch, self._m, self._col = batch, m, None
+
+    def _column(self):
+        if self._col is None:
+            pf, pi, ls = self._batch._column(self._m)        # [NPF, A], [NPI, A], [NL, A, T-1]
+            # entries past a list's length are NaN (hr.py:87-98 stops at min(T-1, len(prediction))): lengths per slot
+            self._col = (pf, pi, ls, (~np.isnan(ls)).sum(axis=2), pf.tolist(), pi.tolist())
+        return self._col
+
+    def _build(self, key):
+        return self._batch._build_metric(self._m, key, self._column())
+
+
+class LazyHR(_LazyDict):
+    """the 'hr' sub-dict: one entry per prediction with a harm model + the six maxima over all of them (hr.py:87-114)"""
+    ALL = ("max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
+           "max_collision_probability_all", "max_obst_harm_with_cp_all")
+
+    def __init__(self, batch, cost, col):
+        valid = col[5][N.PI["hr_valid"]]
+        self._slot = {pid: k for pid, k in batch.prediction_slots if valid[k]}
+        super().__init__([(pid, _UNBUILT) for pid in self._slot] + [(key, float(cost[N.COST[key]])) for key in self.ALL])
+        self._batch, self._col = batch, col
+
+    def _build(self, key):
+        return self._batch._hr_entry(self._slot[key], self._col)
 
 
 class Metric:

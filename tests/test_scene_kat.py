@@ -273,8 +273,9 @@ def test_scenario1_visibility_sanity(oracle):
 
 
 def test_route_enumeration_and_vehicle_predictions_along_routes(oracle):
-    """route_planner.py:54-90 restated (depth-2 DFS over successors / same-direction neighbours) + one constant-speed
-    prediction per candidate route that keeps the initial lateral offset"""
+    """route_planner.py:54-90 restated (depth-2 DFS over successors / same-direction neighbours) + one prediction per
+    candidate route: the reference's min-var(v) Frenet sample -- speed held along the route, quintic lateral move over 3 s
+    to the nearest of d1 in {-0.5, 0, 0.5} (agent.py:349-379, frenetix_handler.py:82-105)"""
     sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario3_geometry.npz"))
     routes = S.enumerate_routes(sc.lanelets)
     assert routes[1] == [[1, 3, 5], [1, 12, 9]]                    # incoming lanelet: left-ish and right turn
@@ -288,13 +289,16 @@ def test_route_enumeration_and_vehicle_predictions_along_routes(oracle):
     pos, yaw, v, cov, ln = oracle.route_predictions(pos0, types, speed, lan, 3, tab.first, tab.count, tab.xy, tab.s,
                                                     np.array([0.0, 0.0, 1.0, 0.5]), 31, 0.1)
     assert ln.reshape(4, 3).tolist() == [[31, 31, 0], [31, 31, 0], [31, 0, 0], [31, 0, 0]]
-    # car 0, route 0: straight part keeps y = 0.3 (offset to the centre line y = 0), x advances 1 m per step
-    np.testing.assert_allclose(pos[0, :15, 1], 0.3, atol=1e-12)
+    # car 0, route 0: on the straight part the offset to the centre line y = 0 moves from 0.3 towards the nearest lateral
+    # target, 0.5, along the quintic; x advances 1 m per step (s' = v0)
+    tau = np.arange(15) * 0.1 / 3.0
+    np.testing.assert_allclose(pos[0, :15, 1], 0.3 + 0.2 * (10 * tau ** 3 - 15 * tau ** 4 + 6 * tau ** 5), atol=1e-12)
     np.testing.assert_allclose(pos[0, :15, 0], 10.0 + np.arange(15), atol=1e-9)
+    assert yaw[0, 0] == 0.0 and 0.0 < yaw[0, 10] < 0.02 and v[0, 0] == 10.0 and 10.0 < v[0, 10] < 10.01
     # the two routes of car 0 part ways at the intersection: left (y grows) and right (y falls), heading follows
     assert pos[0, 30, 1] > 3.0 and pos[1, 30, 1] < -3.0 and yaw[0, 30] > 1.0 and yaw[1, 30] < -1.0
     step = np.hypot(np.diff(pos[1, :, 0]), np.diff(pos[1, :, 1]))
-    assert np.all(np.abs(step - 1.0) < 0.12)                        # constant speed along the centre line (offset 0.3 m)
+    assert np.all(np.abs(step - 1.0) < 0.2)                         # speed held along the centre line; the lateral offset (0.3 -> 0.5 m, outside of the bend) stretches the steps in the turn
     # pedestrian / off-lane vehicle: one straight prediction with the fallback heading, velocity components rounded
     np.testing.assert_allclose(pos[6, 10], pos0[2] + 1.0 * np.round(1.4 * np.array([math.cos(1.0), math.sin(1.0)]), 3))
     np.testing.assert_allclose(pos[9, 10], pos0[3] + 1.0 * np.round(10.0 * np.array([math.cos(0.5), math.sin(0.5)]), 3))
