@@ -129,12 +129,16 @@ class BatchAssessment:
         h = self._to_host()
         return LazyMetrics(self, m), bool(h["safe"][m])
 
-    def _build_metric(self, m, name, col):
-        """sub-dict of metric `name` for trajectory m; col = that trajectory's column (see _column), shared by the metrics
-        of one LazyMetrics"""
+    def _build_metric(self, m, name, lazy):
+        """sub-dict of metric `name` for trajectory m; ``lazy._column()`` = that trajectory's column (see _column), gathered
+        on first need and shared by the metrics of one LazyMetrics ('wttc' and the six maxima of 'hr' do not need it)"""
         h = self._to_host()
         cost = h["cost"][m]
-        pf, pi, ls, n_valid, pf_l, pi_l = col
+        if name == "wttc":
+            return float(cost[N.COST["wttc"]])
+        if name == "hr":
+            return LazyHR(self, m, cost, lazy)
+        pf, pi, ls, n_valid, pf_l, pi_l = lazy._column()
         PF, PI, LST = N.PF, N.PI, N.LST
         slots = self.prediction_slots
         if name == "cp":
@@ -149,13 +153,9 @@ class BatchAssessment:
         if name == "ttce":
             v = pf_l[PF["ttce"]]
             return {pid: v[k] for pid, k in slots}
-        if name == "wttc":
-            return float(cost[N.COST["wttc"]])
         if name == "be":
             d, b = pf_l[PF["be_decel"]], pf_l[PF["be_btn"]]
             return {pid: {"required_constant_deceleration": d[k], "break_threat_number": b[k]} for pid, k in slots}
-        if name == "hr":
-            return LazyHR(self, cost, col)
         raise KeyError(name)
 
     def _hr_entry(self, k, col):
@@ -237,7 +237,7 @@ class LazyMetrics(_LazyDict):
         return self._col
 
     def _build(self, key):
-        return self._batch._build_metric(self._m, key, self._column())
+        return self._batch._build_metric(self._m, key, self)
 
 
 class LazyHR(_LazyDict):
@@ -245,14 +245,17 @@ class LazyHR(_LazyDict):
     ALL = ("max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
            "max_collision_probability_all", "max_obst_harm_with_cp_all")
 
-    def __init__(self, batch, cost, col):
-        valid = col[5][N.PI["hr_valid"]]
+    def __init__(self, batch, m, cost, lazy):
+        hi = batch._to_host()["pair_i"]
+        # which predictions carry an 'hr' entry (harm_model.py:65-66: none for an empty horizon): from the host mirror of
+        # the batch when there is one, else from the trajectory's gathered column
+        valid = hi[N.PI["hr_valid"], :, m] if hi is not None else lazy._column()[1][N.PI["hr_valid"]]
         self._slot = {pid: k for pid, k in batch.prediction_slots if valid[k]}
         super().__init__([(pid, _UNBUILT) for pid in self._slot] + [(key, float(cost[N.COST[key]])) for key in self.ALL])
-        self._batch, self._col = batch, col
+        self._batch, self._lazy = batch, lazy
 
     def _build(self, key):
-        return self._batch._hr_entry(self._slot[key], self._col)
+        return self._batch._hr_entry(self._slot[key], self._lazy._column())
 
 
 class Metric:

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""What an UNMODIFIED planner pays through the drop-in: one evaluate_scenario, then M calls of
+trajectory_safety_assessment(t) (interface.py:216-219), each reading the safety flag and one entry of the result dict.
+With a cached full batch (trajectory_safety_assessment_batch(list, mode='full') first) the calls are served from it."""
+import math
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "frenetix-occlusion_amd"))
+import numpy as np
+import torch
+from frenetix_occlusion import interface
+from frenetix_occlusion import scenario as S
+from frenetix_occlusion import synthetic as SY
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+sc = S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario1_geometry.npz"))
+ego = sc.ego_initial
+ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+v = SY.VEHICLE_BMW320I
+veh = SimpleNamespace(length=v[0], width=v[1], wb_rear_axle=v[2], mass=v[3], a_max=v[4])
+fo = interface.FOInterface(sc, ref_path, veh, 0.1)
+traj = SY.make_trajectories(M, seed=1, ego_pos=ego[:2], ego_yaw=float(ego[2]))
+objs = [SimpleNamespace(cartesian=SimpleNamespace(**{k: a[i] for k, a in traj.items()})) for i in range(M)]
+for rep in range(3):
+    t0 = time.perf_counter()
+    fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
+    t1 = time.perf_counter()
+    fo.trajectory_safety_assessment_batch(objs, mode="full")
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    acc = 0.0
+    for o in objs:
+        res, safe = fo.trajectory_safety_assessment(o)
+        acc += res["hr"]["max_obst_risk_all"] + safe
+    t3 = time.perf_counter()
+    for o in objs[:50]:
+        res, safe = fo.trajectory_safety_assessment(o)
+        res.materialize()
+    t4 = time.perf_counter()
+print(f"M = {M}, {len(fo.agent_manager.predictions)} predictions: evaluate_scenario {1e3 * (t1 - t0):.3f} ms, batch (pack {M} objects + "
+      f"sweep + sync) {1e3 * (t2 - t1):.3f} ms, then {M} per-trajectory calls reading the flag and hr.max_obst_risk_all: "
+      f"{1e6 * (t3 - t2) / M:.1f} us each ({1e3 * (t3 - t2):.2f} ms in all); with every sub-dict opened: {1e6 * (t4 - t3) / 50:.1f} us each")
+print("step_timing:", {k: (round(x, 3) if isinstance(x, float) else x) for k, x in fo.step_timing.items()})
