@@ -774,6 +774,9 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #ifndef FO_TRACE
 #define FO_TRACE 0
 #endif
+#ifndef FO_DYN
+#define FO_DYN 0     // 1: the waves of a workgroup draw the chunk's agents one by one from an LDS counter (tuning builds)
+#endif
 #ifndef FO_X
 #define FO_X 0       // timing experiments only (tools/build_variant.sh x1 -DFO_X=1 ...): 1 no pass 2, 2 no probe, 4 no harm
 #endif               // geometry in pass 1, 8 pass 2 without its arithmetic, 32 no DCE in pass 1, 64 no gate, 128 no second (correlated) body -- WRONG results
@@ -905,7 +908,7 @@ template <bool PAIR, int LISTS, bool ALLM, bool SPLIT, bool CORR, int TC_>
 __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const double2 *__restrict__ erf_tab,
                                                     const double *__restrict__ exp_tab, const double *__restrict__ zc_tab,
                                                     double *__restrict__ hk_all, double *__restrict__ cpbuf_all,
-                                                    unsigned short *__restrict__ queue_all) {
+                                                    unsigned short *__restrict__ queue_all, int *__restrict__ next_agent) {
   constexpr int TC = TC_, DVR = TC + 1, WROWS = TC + DVR;   // this instantiation's chunk length (see fo_sweep_queue_kernel)
   static_assert(!SPLIT || WROWS >= 10, "the horizon-split fold parks ten values per lane in the wave's rows");
   const int lane = threadIdx.x & 63;
@@ -944,8 +947,20 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
   // the samples this wave owns: everything, or time chunk `wave` of the agent the workgroup shares
   const int seg0 = SPLIT ? wave * TC : 0, seg1 = SPLIT ? min(seg0 + TC, a.T) : a.T;
   const int gfirst_ = max(seg0 - 1, 0);  // first harm / cp sample this wave evaluates for an agent
-  for (int kk = 0; kk < apw_; ++kk) {
-    const int k = k0 + kk;
+  constexpr bool DYN = FO_DYN && !SPLIT;
+  const int kbase = k0 - wave * apw_, kcount = apw_ * QWAVES;   // the chunk's agents [kbase, kbase + kcount)
+  for (int kk = 0;; ++kk) {
+    int k;
+    if (DYN) {   // whichever wave is free takes the chunk's next agent (ascending within a wave)
+      int t_ = 0;
+      if (lane == 0) t_ = atomicAdd(next_agent, 1);
+      t_ = __builtin_amdgcn_readfirstlane(t_);
+      if (t_ >= kcount) break;
+      k = kbase + t_;
+    } else {
+      if (kk >= apw_) break;
+      k = k0 + kk;
+    }
     if (k >= A) break;
     const cdp_t G = fo_const(a.atab) + (size_t)k * a.Ta * NAF;
     const cdp_t C = fo_const(a.acst) + (size_t)k * NAC;
@@ -1491,11 +1506,14 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
   if (wave == 0) {
     for (int w = 0; w < QWAVES - 1; ++w) {
       const double *rp = red + (size_t)w * NPS * TILE + lane;
-      if (rp[PS_MIN_DCE * TILE] < w_min_dce) { w_min_dce = rp[PS_MIN_DCE * TILE]; w_arg_dce = (int)rp[PS_ARG_DCE * TILE]; }
-      if (rp[PS_MIN_TTC * TILE] < w_min_ttc) { w_min_ttc = rp[PS_MIN_TTC * TILE]; w_arg_ttc = (int)rp[PS_ARG_TTC * TILE]; }
+      // (ties keep the smaller agent index: with FO_DYN the waves' agents interleave, without it wave order = agent order
+      // and the index test never fires)
+      const int ad_ = (int)rp[PS_ARG_DCE * TILE], at_ = (int)rp[PS_ARG_TTC * TILE], ao_ = (int)rp[PS_ARG_OR * TILE];
+      if (rp[PS_MIN_DCE * TILE] < w_min_dce || (DYN && rp[PS_MIN_DCE * TILE] == w_min_dce && ad_ >= 0 && (w_arg_dce < 0 || ad_ < w_arg_dce))) { w_min_dce = rp[PS_MIN_DCE * TILE]; w_arg_dce = ad_; }
+      if (rp[PS_MIN_TTC * TILE] < w_min_ttc || (DYN && rp[PS_MIN_TTC * TILE] == w_min_ttc && at_ >= 0 && (w_arg_ttc < 0 || at_ < w_arg_ttc))) { w_min_ttc = rp[PS_MIN_TTC * TILE]; w_arg_ttc = at_; }
       w_min_ttce = fmin(w_min_ttce, rp[PS_MIN_TTCE * TILE]);
       w_max_er = fmax(w_max_er, rp[PS_MAX_ER * TILE]);
-      if (rp[PS_MAX_OR * TILE] > w_max_or) { w_max_or = rp[PS_MAX_OR * TILE]; w_arg_or = (int)rp[PS_ARG_OR * TILE]; }
+      if (rp[PS_MAX_OR * TILE] > w_max_or || (DYN && rp[PS_MAX_OR * TILE] == w_max_or && ao_ >= 0 && (w_arg_or < 0 || ao_ < w_arg_or))) { w_max_or = rp[PS_MAX_OR * TILE]; w_arg_or = ao_; }
       w_max_eh = fmax(w_max_eh, rp[PS_MAX_EH * TILE]);
       w_max_oh = fmax(w_max_oh, rp[PS_MAX_OH * TILE]);
       w_max_cp = fmax(w_max_cp, rp[PS_MAX_CP * TILE]);
@@ -1540,6 +1558,8 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   __shared__ double cpbuf_all[BUFROWS * TILE];  // per wave: TC rows of collision probabilities, DVR rows of
                                                        // relative speeds; also the cross-wave reduction scratch
   __shared__ unsigned short queue_all[QWAVES * QCAP];
+  __shared__ int next_agent;   // FO_DYN: agents of the chunk handed out so far
+  if (threadIdx.x == 0) next_agent = 0;
   for (int i = threadIdx.x; i < ERF_N; i += TILE * QWAVES) erf_tab[i] = a.erf_tab[i];
   for (int i = threadIdx.x; i < EXP_N; i += TILE * QWAVES) exp_tab[i] = a.exp_tab[i];
   if (threadIdx.x < 4)
@@ -1557,9 +1577,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
 #endif
   __syncthreads();
   if (__builtin_expect(!corr, 1))
-    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
+    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all, &next_agent);
   else
-    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, true, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all);
+    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, true, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all, &next_agent);
 #if FO_TRACE
   if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 1] = wall_clock64();
 #endif
