@@ -305,14 +305,27 @@ def small_batch_step(local_rank, steps=300):
     sw.reserve(M, T, A, T)
     traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 2, ego_pos=ego[:2], ego_yaw=yaw)
     tr = [torch.as_tensor(traj[k]).to(f"cuda:{local_rank}") for k in ("x", "y", "theta", "v", "a")]
+    from frenetix_occlusion.step import PlanningStep
+    ps = PlanningStep(sm, sl, sw, *tr, mode="reduced")      # the whole step through ONE native call (fo_step_run)
     out = None
 
-    def step():
+    def step_stages():      # the same step as five stage calls from Python (what round 2 measured)
         nonlocal out
         sm.launch(ego[:2], yaw)
         sw.set_agents(*sl.sample(ego[:2], yaw, float(ego[3])).sweep_args(), check=False)
         out = sw.run(*tr, mode="reduced", out=out)
 
+    def step():
+        ps.run(ego[:2], yaw, float(ego[3]))
+
+    for _ in range(100):
+        step_stages()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_stages()
+    torch.cuda.synchronize()
+    dt_stages = (time.perf_counter() - t0) / steps
     for _ in range(100):
         step()
     torch.cuda.synchronize()
@@ -320,12 +333,16 @@ def small_batch_step(local_rank, steps=300):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    t_issue = (time.perf_counter() - t0) / steps
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     kms, kn = sw.ctx.timing_read()
     sw.ctx.timing(False)
     return {"workload": "BASELINE configs[1]: scenario1 geometry, 2000 trajectories x 32 phantom slots, T=31, reduced outputs",
-            "ms_per_step": dt * 1e3, "sweep_kernel_ms": kms / max(kn, 1), "A_active": int(sl.batch.n.item()), "steps": steps,
+            "ms_per_step": dt * 1e3, "host_issue_ms_per_step": t_issue * 1e3, "ms_per_step_stage_calls": dt_stages * 1e3,
+            "entry": "fo_step_run (one native call per planning step); ms_per_step_stage_calls = the same step as five "
+                     "stage calls from Python",
+            "sweep_kernel_ms": kms / max(kn, 1), "A_active": int(sl.batch.n.item()), "steps": steps,
             "sweep_grid": sw.ctx.last_launch()["grid"]}
 
 

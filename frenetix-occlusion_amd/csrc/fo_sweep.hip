@@ -1786,12 +1786,13 @@ void launch_queue(int lst, bool pair, dim3 g, dim3 b, hipStream_t s, const Sweep
   else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
 }
 
-// agents per wave: enough workgroups to fill 256 CUs many times over (the tail of the last round of workgroups costs
-// less the shorter they are), but no more partial rows than needed.  Measured at steady clocks on 10 000 x 256:
-// 1 -> 0.764 ms, 2 -> 0.748, 3 -> 0.756, 4 -> 0.765, 8 -> 0.79 (bench.py re-checks this per batch shape at set-up).
+// agents per wave in the first phase of the (tapered) grid: long workgroups keep the per-workgroup start-up (table fill,
+// cross-wave fold) small, the taper takes care of the end of the launch.  Measured at steady clocks on 10 000 x 256 with
+// float32 lists and the default taper: 2 -> 0.585 ms, 3 -> 0.556, 4 -> 0.546, 6 -> 0.552, 8 -> 0.550 (bench.py re-checks
+// 1 / 2 / 4 / 8 per batch shape at set-up).
 int pick_apw(int n_tiles, int A, int wpb) {
   int apw = 8;
-  while (apw > 1 && (long)n_tiles * ((A + wpb * apw - 1) / (wpb * apw)) * wpb < 16384) apw >>= 1;
+  while (apw > 1 && (long)n_tiles * ((A + wpb * apw - 1) / (wpb * apw)) * wpb < 8192) apw >>= 1;
   return apw;
 }
 

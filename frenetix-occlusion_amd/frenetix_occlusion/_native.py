@@ -30,7 +30,7 @@ EXPORTS = [
     "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_list_format", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read", "fo_sweep_timing_read_each",
     "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
-    "fo_scene_candidate_count", "fo_scene_set_topology", "fo_scene_spawn_rules",
+    "fo_scene_candidate_count", "fo_scene_set_topology", "fo_scene_spawn_rules", "fo_step_run",
 ]
 
 
@@ -51,6 +51,27 @@ class SpawnRuleParams(C.Structure):       # fo_spawn_rule_params_t
     _fields_ = ([(n, C.c_double) for n in ("ego_x", "ego_y", "ego_yaw", "ego_s", "ego_d", "s_threshold", "ped_width", "ped_length")] +
                 [(n, C.c_int32) for n in ("intention", "win_i0", "win_i1", "behind_static", "behind_turn", "behind_dynamic",
                                           "max_static", "max_dynamic")])
+
+
+class Step(C.Structure):       # fo_step_t (include/fo_hip.h): the arguments of one planning step's five stage calls
+    _fields_ = [("n_rays", C.c_int32), ("polygon_footprint", C.c_int32), ("ego_yaw", C.c_double), ("fov_deg", C.c_double),
+                ("r", C.c_double), ("d_dirs", C.c_void_p), ("d_rmax", C.c_void_p), ("d_half", C.c_void_p),
+                ("ego_x", C.c_double), ("ego_y", C.c_double), ("head_x", C.c_double), ("head_y", C.c_double),
+                ("full_circle", C.c_int32), ("exact_cells", C.c_int32), ("O", C.c_int32), ("d_edge_skip", C.c_void_p),
+                ("d_ocorn", C.c_void_p), ("d_ocen", C.c_void_p), ("d_oflags", C.c_void_p),
+                ("win_ix0", C.c_int32), ("win_iy0", C.c_int32), ("win_nx", C.c_int32), ("win_ny", C.c_int32),
+                ("d_range", C.c_void_p), ("d_hit_id", C.c_void_p), ("d_ring", C.c_void_p), ("d_obst_vis", C.c_void_p),
+                ("d_cls", C.c_void_p), ("d_occ_idx", C.c_void_p), ("d_n_occ", C.c_void_p),
+                ("min_ahead", C.c_double), ("max_dist", C.c_double), ("all_occluded", C.c_int32), ("max_agents", C.c_int32),
+                ("routes", C.c_int32), ("n_path", C.c_int32), ("T_agents", C.c_int32), ("type4", C.c_int32 * 4),
+                ("speed4", C.c_double * 4), ("raw_l4", C.c_double * 4), ("raw_w4", C.c_double * 4),
+                ("infl_l4", C.c_double * 4), ("infl_w4", C.c_double * 4), ("d_path", C.c_void_p), ("dt", C.c_double),
+                ("var0", C.c_double), ("var_factor", C.c_double), ("d_cell", C.c_void_p), ("d_pos0", C.c_void_p),
+                ("d_yaw0", C.c_void_p), ("d_n", C.c_void_p), ("d_pos", C.c_void_p), ("d_yaw", C.c_void_p), ("d_v", C.c_void_p),
+                ("d_cov", C.c_void_p), ("d_shape", C.c_void_p), ("d_raw_dims", C.c_void_p), ("d_type", C.c_void_p),
+                ("d_len", C.c_void_p), ("M", C.c_int32), ("T", C.c_int32), ("d_x", C.c_void_p), ("d_y", C.c_void_p),
+                ("d_theta", C.c_void_p), ("d_vel", C.c_void_p), ("d_acc", C.c_void_p), ("d_cost", C.c_void_p),
+                ("d_safe", C.c_void_p), ("d_pair_f", C.c_void_p), ("d_pair_i", C.c_void_p), ("d_lists", C.c_void_p)]
 
 
 class NativeError(RuntimeError):
@@ -112,6 +133,7 @@ def load():
     lib.fo_scene_spawn.argtypes = ([vp, dp] + [C.c_int] * 4 + [D] * 6 + [C.c_int] * 3 + [ip] + [dp] * 5 + [C.c_int, dp, C.c_int]
                                    + [D] * 3 + [dp] * 12 + [vp])
     lib.fo_scene_candidate_count.argtypes = [vp, ip, vp]
+    lib.fo_step_run.argtypes = [vp, C.POINTER(Step), vp]
     lib.fo_scene_set_topology.argtypes = [vp, C.c_int, dp, ip, ip, C.c_int, ip, ip, dp]
     lib.fo_scene_spawn_rules.argtypes = ([vp, dp] + [C.c_int] * 5 + [dp, C.c_int] + [dp] * 6 + [C.POINTER(SpawnRuleParams), C.c_int,
                                                                                           dp, ip, vp])

@@ -389,16 +389,19 @@ class SensorModel:
         footprint range along each ray and the half fan that bounds the occluded area, written by the device
         (``fo_scene_fan``) into buffers owned by this object -- valid until the next call.  :func:`ray_dirs`,
         :func:`footprint_ranges` and :func:`half_fan_dirs` are the host statement of the same definitions."""
-        if getattr(self, "_fan_buf", None) is None:
-            self._fan_buf = (torch.empty((self.n_rays, 2), dtype=torch.float64, device=self.device),
-                             torch.empty(self.n_rays, dtype=torch.float64, device=self.device),
-                             torch.empty((100, 2), dtype=torch.float64, device=self.device))
-        dirs, rmax, half = self._fan_buf
+        dirs, rmax, half = self._fan_buffers()
         poly = self.footprint == "polygon"
         self.ctx.call("fo_scene_fan", self.n_rays, float(ego_orientation), self.sensor_angle, self.sensor_radius,
                       1 if poly else 0, dirs.data_ptr(), rmax.data_ptr() if poly else None,
                       half.data_ptr() if poly else None, N.current_stream(self._dev_index))
         return dirs, (rmax if poly else None), (half if poly else None)
+
+    def _fan_buffers(self):
+        if getattr(self, "_fan_buf", None) is None:
+            self._fan_buf = (torch.empty((self.n_rays, 2), dtype=torch.float64, device=self.device),
+                             torch.empty(self.n_rays, dtype=torch.float64, device=self.device),
+                             torch.empty((100, 2), dtype=torch.float64, device=self.device))
+        return self._fan_buf
 
     def enclosed_hole_rings(self, ego_pos, ego_orientation):
         if self.enclosed_holes != "transparent":

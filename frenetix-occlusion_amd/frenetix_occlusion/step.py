@@ -1,0 +1,105 @@
+"""One planning step in one native call (``fo_step_run``, include/fo_hip.h): ray fan -> cell classes -> phantom sampling
++ predictions -> agent table -> metric sweep -> threshold reduction.
+
+``PlanningStep`` binds a :class:`SensorModel`, a :class:`SpawnLocator`, a :class:`MetricSweep` (one ego, one context) and
+the candidate-trajectory tensors of a planning loop; :meth:`run` updates the handful of per-step scalars in a
+structure that was filled once and crosses the FFI once -- the same twelve kernel launches the stage-by-stage calls
+queue, without their five ctypes crossings (~90 converted arguments, ~90 us of host time per step; a step of the
+reference's own size needs ~60 us of GPU time).  Nothing is read back: the cost vectors and flags stay in HBM.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+from .sweep import SweepResult
+
+
+class PlanningStep:
+    def __init__(self, sensor_model, spawn_locator, sweep, x, y, theta, v, a=None, mode="reduced", lists="f64"):
+        if not (sensor_model.ctx is spawn_locator.ctx is sweep.ctx):
+            raise ValueError("PlanningStep: the three stages must share one context (one ego, one GPU)")
+        if mode not in ("reduced", "pair", "full"):
+            raise ValueError(f"unknown output mode '{mode}'")
+        self.sm, self.sl, self.sw = sensor_model, spawn_locator, sweep
+        self.ctx = sweep.ctx
+        self.mode, self.lists = mode, lists
+        dev = sweep.device
+        t = lambda q: None if q is None else torch.as_tensor(q).to(device=dev, dtype=torch.float64).contiguous()
+        self.traj = [t(x), t(y), t(theta), t(v), t(a)]
+        self.M, self.T = int(self.traj[0].shape[0]), int(self.traj[0].shape[1])
+        if spawn_locator.batch is None:
+            spawn_locator.batch = spawn_locator._alloc()
+        self.batch = spawn_locator.batch
+        A = int(self.batch.pos.shape[0])
+        ldt = torch.float32 if lists == "f32" else torch.float64
+        self.out = SweepResult(cost=torch.empty((self.M, N.NC), dtype=torch.float64, device=dev),
+                               safe=torch.empty((self.M,), dtype=torch.uint8, device=dev))
+        if mode in ("pair", "full"):
+            self.out.pair_f = torch.empty((N.NPF, A, self.M), dtype=torch.float64, device=dev)
+            self.out.pair_i = torch.empty((N.NPI, A, self.M), dtype=torch.int32, device=dev)
+        if mode == "full":
+            self.out.lists_raw = torch.empty((N.NL * A * max(self.T - 1, 0) * self.M,), dtype=ldt, device=dev)
+        self.out.lists_shape = (A, max(self.T - 1, 0), self.M)
+        self.ctx.call("fo_sweep_set_list_format", N.LISTS_F32 if lists == "f32" else N.LISTS_F64)
+        sweep._list_format = lists
+        sweep.reserve(self.M, self.T, A, spawn_locator.T)
+        self._s = None
+        self._key = None
+
+    def _fill(self, w, O):
+        """everything that does not change from step to step"""
+        sm, sl, b = self.sm, self.sl, self.batch
+        s = N.Step()
+        p = lambda q: None if q is None else q.data_ptr()
+        dirs, rmax, half = sm._fan_buffers()
+        poly = sm.footprint == "polygon"
+        s.n_rays, s.polygon_footprint, s.fov_deg, s.r = sm.n_rays, 1 if poly else 0, sm.sensor_angle, sm.sensor_radius
+        s.d_dirs, s.d_rmax, s.d_half = p(dirs), p(rmax) if poly else None, p(half) if poly else None
+        s.full_circle = 1 if sm.sensor_angle >= 359.9 else 0
+        s.exact_cells = 1 if sm.cell_visibility == "exact" else 0
+        d_corn, d_cen, d_flags, _ = getattr(sm, "_obst", (None, None, None, 0))
+        s.O, s.d_ocorn, s.d_ocen, s.d_oflags = O, p(d_corn), p(d_cen), p(d_flags)
+        buf = sm._buffers(w, O)
+        s.win_nx, s.win_ny = w.nx, w.ny
+        s.d_range, s.d_hit_id, s.d_ring, s.d_obst_vis = p(buf["rng"]), p(buf["hit"]), p(buf["ring"]), p(buf["ovis"])
+        s.d_cls, s.d_occ_idx, s.d_n_occ = p(buf["cls"]), p(buf["occ"]), p(buf["n_occ"])
+        s.min_ahead, s.all_occluded, s.max_agents, s.routes = sl.min_ahead, 1 if sl.all_occluded else 0, sl.max_agents, sl.routes
+        s.n_path, s.d_path, s.T_agents, s.dt, s.var0, s.var_factor = int(sl.ref_path.shape[0]), p(sl._d_path), sl.T, sl.dt, sl.var0, sl.var_factor
+        for i in range(4):
+            s.type4[i], s.speed4[i], s.raw_l4[i], s.raw_w4[i] = int(sl._t4[i]), sl._s4[i], sl._rl[i], sl._rw[i]
+            s.infl_l4[i], s.infl_w4[i] = sl._il[i], sl._iw[i]
+        s.d_cell, s.d_pos0, s.d_yaw0, s.d_n = p(b.cell), p(b.pos0), p(b.yaw0), p(b.n)
+        s.d_pos, s.d_yaw, s.d_v, s.d_cov, s.d_shape, s.d_raw_dims = p(b.pos), p(b.yaw), p(b.v), p(b.cov), p(b.shape), p(b.raw_dims)
+        s.d_type, s.d_len = p(b.type), p(b.len)
+        s.M, s.T = self.M, self.T
+        s.d_x, s.d_y, s.d_theta, s.d_vel, s.d_acc = (p(q) for q in self.traj)
+        o = self.out
+        s.d_cost, s.d_safe, s.d_pair_f, s.d_pair_i, s.d_lists = p(o.cost), p(o.safe), p(o.pair_f), p(o.pair_i), p(o.lists_raw)
+        self._buf = buf
+        return s
+
+    def run(self, ego_pos, ego_orientation, ego_v) -> SweepResult:
+        """queue one planning step on the current stream; returns the (reused) device outputs"""
+        sm, sl = self.sm, self.sl
+        yaw = float(ego_orientation)
+        w = sm._window_for(ego_pos)
+        O = getattr(sm, "_obst", (None, None, None, 0))[3]
+        key = (w.nx, w.ny, O, id(getattr(sm, "_obst", (None,))[0]))
+        if self._s is None or key != self._key:
+            self._s, self._key = self._fill(w, O), key
+        s = self._s
+        skip = sm._edge_skip_for(sm.enclosed_hole_rings(ego_pos, yaw))
+        s.d_edge_skip = None if skip is None else skip.data_ptr()
+        s.ego_yaw, s.ego_x, s.ego_y, s.head_x, s.head_y = yaw, float(ego_pos[0]), float(ego_pos[1]), math.cos(yaw), math.sin(yaw)
+        s.win_ix0, s.win_iy0 = w.ix0, w.iy0
+        s.max_dist = sl.max_distance(ego_v)
+        self.ctx._check(self.ctx._lib.fo_step_run(self.ctx._h, C.byref(s), N.current_stream(sm._dev_index)))
+        # the stage objects see the step as if they had queued it themselves
+        sm.window, sm.ego_pos, sm.ego_orientation = w, ego_pos, yaw
+        b = self._buf
+        sm.range, sm.hit_id, sm.cell_class = b["rng"], b["hit"], b["cls"]
+        sm.occluded_idx_buffer, sm.n_occluded = b["occ"], b["n_occ"]
+        self.sw.A, self.sw.Ta = int(self.batch.pos.shape[0]), sl.T
+        return self.out

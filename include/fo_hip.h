@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 6
+#define FO_ABI_VERSION 7
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -274,6 +274,55 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
                          const double *d_path6, int O, const double *d_ocorn, const double *d_ocen, const double *d_oyaw,
                          const double *d_odims, const uint8_t *d_oflags, const uint8_t *d_obst_vis,
                          const fo_spawn_rule_params_t *params, int max_out, double *d_out, int32_t *d_n_out, void *stream);
+
+/* ---- one planning step in one call: fo_scene_fan -> fo_scene_visibility -> fo_scene_spawn -> fo_sweep_set_agents ->
+ *      fo_sweep_run on one stream, with the arguments of those five entry points (same names, same meaning) in one
+ *      structure.  What it replaces is the reference's FOInterface.evaluate_scenario + M x trajectory_safety_assessment
+ *      (interface.py:148-219) for a host that calls through an FFI: a planning step of the reference's own size (2 000
+ *      candidates x 32 phantoms) is twelve kernel launches of a few microseconds each, and five FFI crossings with
+ *      ~90 arguments cost the host more than the GPU needs for the step.  The structure is filled once (every pointer
+ *      and size of a planning loop is stable); per step the caller updates the ego pose, the window origin and the
+ *      spawn range.  NULL-able members are the NULL-able arguments of the single calls.  Stops at the first failing
+ *      stage and returns its code. */
+typedef struct {
+  /* fo_scene_fan */
+  int32_t n_rays, polygon_footprint;
+  double ego_yaw, fov_deg, r;
+  double *d_dirs, *d_rmax, *d_half;
+  /* fo_scene_visibility (d_dirs / d_rmax / d_half as above) */
+  double ego_x, ego_y, head_x, head_y;
+  int32_t full_circle, exact_cells, O;
+  const uint8_t *d_edge_skip;
+  const double *d_ocorn, *d_ocen;
+  const uint8_t *d_oflags;
+  int32_t win_ix0, win_iy0, win_nx, win_ny;
+  double *d_range;
+  int32_t *d_hit_id;
+  double *d_ring;
+  uint8_t *d_obst_vis, *d_cls;
+  int32_t *d_occ_idx, *d_n_occ;
+  /* fo_scene_spawn (d_cls + window as above; its per-prediction outputs are the agent arrays of the sweep) */
+  double min_ahead, max_dist;
+  int32_t all_occluded, max_agents, routes, n_path, T_agents;
+  int32_t type4[4];
+  double speed4[4], raw_l4[4], raw_w4[4], infl_l4[4], infl_w4[4];
+  const double *d_path;
+  double dt, var0, var_factor;
+  int32_t *d_cell;
+  double *d_pos0, *d_yaw0;
+  int32_t *d_n;
+  double *d_pos, *d_yaw, *d_v, *d_cov, *d_shape, *d_raw_dims;
+  int32_t *d_type, *d_len;
+  /* fo_sweep_set_agents takes max_agents * max(routes, 1) prediction slots from the arrays above; fo_sweep_run: */
+  int32_t M, T;
+  const double *d_x, *d_y, *d_theta, *d_vel, *d_acc;
+  double *d_cost;
+  uint8_t *d_safe;
+  double *d_pair_f;
+  int32_t *d_pair_i;
+  double *d_lists;
+} fo_step_t;
+int fo_step_run(fo_ctx *ctx, const fo_step_t *step, void *stream);
 
 #ifdef __cplusplus
 }

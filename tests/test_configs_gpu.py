@@ -197,3 +197,56 @@ def test_config3_headline_step_full_outputs_vs_oracle_on_every_pair(torch_cuda, 
     assert float((pf[N.PF["max_collision_probability"]] > 0).double().mean()) > 0.02
     assert float((pf[N.PF["dce"]] == 0).double().mean()) > 0.001
     assert 0.0 < float(out.safe.double().mean()) < 1.0
+
+
+def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda):
+    """fo_step_run / PlanningStep (one FFI crossing per planning step) queues the same kernels as the five stage calls:
+    cost vectors, flags, phantom set and cell classes bit-identical, over several ego poses (window origin, spawn range and
+    heading change from step to step)"""
+    import yaml
+    torch = torch_cuda
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as SC
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.step import PlanningStep
+    from frenetix_occlusion.sweep import MetricSweep
+    M, A, T = 2000, 32, 31
+    sc = SC.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True)
+    yaw0 = float(ego0[2])
+    ref = ego0[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw0), math.sin(yaw0)]])
+    traj = S.make_trajectories(M, T, 0.1, seed=5, ego_pos=ego0[:2], ego_yaw=yaw0)
+    results = {}
+    for how in ("stages", "one-call"):
+        ctx = N.Context(0)
+        sm = SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx)
+        sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
+        sl = SpawnLocator(None, ref, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
+        sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, ctx=ctx)
+        tr = [torch.as_tensor(traj[k]).cuda() for k in ("x", "y", "theta", "v", "a")]
+        ps = PlanningStep(sm, sl, sw, *tr, mode="pair") if how == "one-call" else None
+        got = []
+        for i in range(4):
+            ego = ego0[:2] + 1.3 * i * np.array([math.cos(yaw0), math.sin(yaw0)])
+            yaw, v = yaw0 + 0.02 * i, 5.0 + 2.0 * i
+            if ps is not None:
+                out = ps.run(ego, yaw, v)
+            else:
+                sm.launch(ego, yaw)
+                sw.set_agents(*sl.sample(ego, yaw, v).sweep_args(), check=False)
+                out = sw.run(*tr, mode="pair")
+            torch.cuda.synchronize()
+            got.append((out.cost.cpu().numpy().copy(), out.safe.cpu().numpy().copy(), out.pair_f.cpu().numpy().copy(),
+                        sm.cell_class.cpu().numpy().copy(), sl.batch.pos.cpu().numpy().copy(), int(sl.batch.n.item())))
+        results[how] = got
+    for a, b in zip(results["stages"], results["one-call"]):
+        assert a[5] == b[5] and a[5] > 0
+        for x, y in zip(a[:5], b[:5]):
+            assert np.array_equal(x, y, equal_nan=True)
+    assert not np.array_equal(results["stages"][0][3], results["stages"][3][3])      # the steps did differ

@@ -77,9 +77,16 @@ class Ego:
         traj = S.make_trajectories(M, T, 0.1, seed=11 + idx, ego_pos=pose[:2], ego_yaw=yaw)
         self.traj = [torch.as_tensor(traj[k]).to(f"cuda:{dev}") for k in ("x", "y", "theta", "v", "a")]
         self.out = None
+        self.ps = None
 
-    def step(self, mode):
+    def step(self, mode, one_call=True):
         with torch.cuda.stream(self.stream):
+            if one_call:      # the whole step through fo_step_run: one FFI crossing per ego and step
+                if self.ps is None:
+                    from frenetix_occlusion.step import PlanningStep
+                    self.ps = PlanningStep(self.sm, self.sl, self.sw, *self.traj, mode=mode)
+                self.out = self.ps.run(self.pose[:2], float(self.pose[2]), float(self.pose[3]))
+                return
             self.sm.launch(self.pose[:2], float(self.pose[2]))
             args = self.sl.sample(self.pose[:2], float(self.pose[2]), float(self.pose[3])).sweep_args()
             self.sw.set_agents(*args, check=False)
@@ -126,10 +133,22 @@ def main():
             e.step(args.mode)
             e.stream.synchronize()
     serial = (time.perf_counter() - t0) / args.steps
+    # and queued through the five stage calls from Python instead of fo_step_run (round 2's way: host-bound)
+    for _ in range(20):
+        for e in egos:
+            e.step(args.mode, one_call=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for e in egos:
+            e.step(args.mode, one_call=False)
+    torch.cuda.synchronize()
+    stage_calls = (time.perf_counter() - t0) / args.steps
     n_act = [int(e.sl.batch.n.item()) for e in egos]
     print(json.dumps({"workload": "BASELINE configs[4]: multi-ego, one fo_ctx and stream per ego", "rank": rank, "n_gpus": world,
                       "egos_on_this_gpu": len(egos), "M_per_ego": args.M, "phantoms_per_ego": n_act, "mode": args.mode,
                       "ms_per_step_all_egos": dt * 1e3, "ms_per_step_egos_one_after_the_other": serial * 1e3,
+                      "ms_per_step_all_egos_stage_calls": stage_calls * 1e3,
                       "pair_evals_per_sec": sum(args.M * a for a in n_act) / dt}), flush=True)
 
 
