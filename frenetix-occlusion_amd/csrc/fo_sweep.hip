@@ -1068,6 +1068,14 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     //          or scalar load shares a counter with the list stores (vmcnt retires loads and stores in issue order, so
     //          a load behind five stores per iteration used to wait for their acknowledgement).
     const int gfirst = gfirst_;
+#ifndef FO_CARRY
+#define FO_CARRY 0   // 1: tuning builds -- the first ego row of a chunk is carried over pass 2 instead of re-loaded (measured: float32 lists 0.562 against 0.552, float64 lists 0.637 against 0.650: the 14 live registers cost more than the wait)
+#endif
+    // the ego row a chunk starts with: pass 1 of the chunk before has already fetched it (its last iteration prefetches
+    // row t1); carried over pass 2 in registers, the chunk's first loads do not queue behind that pass's list stores
+    // (vmcnt retires in issue order: a load issued after 24 stores waits for their acknowledgement)
+    fo_d2 nxy, ncs, nvv;
+    double nth_ = 0.0;
     for (int t0 = seg0; t0 < seg1; t0 += TC) {
       const int t1 = min(t0 + TC, T);
       // A segment other than the first also needs the relative speed and the impact classes of the sample before it
@@ -1172,10 +1180,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       int qn = 0;
       int ring = tl % DVR;  // row of sample t in the ring of relative speeds
       const bool geo = do_hr && !(ablate & 4);
-      const double *e0_ = tj + (size_t)tl * NEF * TILE;
-      fo_d2 nxy = fo_ld2(e0_), ncs = fo_ld2(e0_ + EF(2)), nvv = fo_ld2(e0_ + EF(6));
-      double nth_ = 0.0;
-      if (lr4s) nth_ = e0_[EF(4)];
+      if (!FO_CARRY || SPLIT || t0 == seg0) {
+        const double *e0_ = tj + (size_t)tl * NEF * TILE;
+        nxy = fo_ld2(e0_); ncs = fo_ld2(e0_ + EF(2)); nvv = fo_ld2(e0_ + EF(6));
+        if (lr4s) nth_ = e0_[EF(4)];
+      }
       const cdp_t gr0 = G + (size_t)min(tl, L - 1) * NAF;
       double npx = gr0[0], npy = gr0[1], npc = gr0[2], nps = gr0[3], nyaw = gr0[4], npvx = gr0[8], npvy = gr0[9];
       const cdp_t grp = G + (size_t)min(max(tl - 1, 0), L - 1) * NAF;

@@ -1,0 +1,64 @@
+"""One-off robustness run on the GPU box: the spawn rule families on the device (fo_scene_spawn_rules) against their NumPy
+checker (oracle/fo_spawn_rules_ref.py) on random ego poses, reference paths (straight ahead / along the lanelet's centre
+line and its successors) and time steps of the three scenario fixtures.  usage: python tools/spawn_rules_fuzz.py [n] [seed]"""
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "frenetix-occlusion_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from frenetix_occlusion import scenario as S  # noqa: E402
+import test_spawn_rules_gpu as TG  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+    scs = [S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", f"scenario{i}_geometry.npz")) for i in (1, 2, 3)]
+    kinds, n_pts = {}, 0
+    for it in range(n):
+        sc = scs[int(rng.integers(3))]
+        by = {l.lanelet_id: l for l in sc.lanelets}
+        ll = sc.lanelets[int(rng.integers(len(sc.lanelets)))]
+        c = ll.center
+        i = int(rng.integers(0, max(len(c) - 2, 1)))
+        ego = c[i] + rng.normal(0.0, 0.3, 2)
+        yaw = math.atan2(c[i + 1, 1] - c[i, 1], c[i + 1, 0] - c[i, 0]) + float(rng.normal(0.0, 0.05))
+        if rng.random() < 0.5:      # straight ahead
+            path = ego[None] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+        else:                        # along the centre lines: this lanelet, then successors (a turn where the map has one)
+            parts, cur = [c[max(i - 3, 0):]], ll
+            for _ in range(3):
+                if not cur.successors:
+                    break
+                cur = by.get(cur.successors[int(rng.integers(len(cur.successors)))])
+                if cur is None:
+                    break
+                parts.append(cur.center[1:])
+            path = np.concatenate(parts)
+            keep = np.concatenate(([True], np.hypot(np.diff(path[:, 0]), np.diff(path[:, 1])) > 1e-6))
+            path = path[keep]
+            if len(path) < 4:
+                continue
+        step = int(rng.integers(0, 80))
+        v = float(rng.uniform(2.0, 12.0))
+        try:
+            dev, ref, view = TG._both(torch, sc.lanelets, sc.obstacles, path, ego, yaw, v, intersections=sc.intersections,
+                                      timestep=step, n_rays=360)
+        except ValueError:          # ego outside the path's projection domain: nothing to compare
+            continue
+        TG._same(dev, ref, view)
+        n_pts += len(ref)
+        for p in ref:
+            kinds[p.source.split(" ")[0] + ":" + p.agent_type] = kinds.get(p.source.split(" ")[0] + ":" + p.agent_type, 0) + 1
+        print(it, "scenario", scs.index(sc) + 1, "step", step, "points", [(p.agent_type, p.source) for p in ref], flush=True)
+    print("all", n, "cases: device == checker;", n_pts, "spawn points:", kinds)
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     oracle.build()
-    worst = 0.0
+    worst, worst32 = 0.0, 0.0
     for it in range(n):
         M = int(rng.choice([1, 2, 63, 64, 65, 127, 200, 513, 1000]))
         A = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 64]))
@@ -52,12 +52,25 @@ def main():
         w = TS._compare(oracle, ref, got)
         assert np.array_equal(ref["safe"], got["safe"])
         worst = max(worst, w)
+        if "lists" in got and ("cp" in metrics or "hr" in metrics) and T > 1:
+            # float32 list storage: every other output bit-identical, the lists within 1e-6 of the oracle
+            g32 = TS._hip_sweep(torch, traj, agents, SY.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr, lists="f32")
+            for key in ("cost", "safe", "pair_i"):
+                assert np.array_equal(g32[key], got[key]), key
+            assert np.array_equal(g32["pair_f"], got["pair_f"], equal_nan=True)
+            fin = np.isfinite(ref["lists"])
+            assert np.array_equal(np.isnan(ref["lists"]), np.isnan(g32["lists"]))
+            if fin.any():
+                w32 = float(np.abs(ref["lists"][fin] - g32["lists"][fin].astype(np.float64)).max())
+                assert w32 < 1e-6, w32
+                worst32 = max(worst32, w32)
         red = TS._hip_sweep(torch, traj, agents, SY.VEHICLE_BMW320I, 0.1, metrics=metrics, thr=thr, mode="reduced")
         assert np.array_equal(red["safe"], got["safe"])
         c1, c2 = red["cost"], got["cost"]
         assert np.array_equal(np.isfinite(c1), np.isfinite(c2)) and np.allclose(c1[np.isfinite(c1)], c2[np.isfinite(c2)], rtol=0, atol=1e-12)
         print(it, "M", M, "A", A, "T", T, "metrics", ",".join(metrics), "worst", f"{w:.2e}", "safe", float(ref["safe"].mean()), flush=True)
-    print("all", n, "batches within 1e-9 of the oracle, integers exact; worst float deviation", f"{worst:.2e}")
+    print("all", n, "batches within 1e-9 of the oracle, integers exact; worst float deviation", f"{worst:.2e}",
+          "; float32 lists: worst deviation", f"{worst32:.2e}")
 
 
 if __name__ == "__main__":
