@@ -166,13 +166,29 @@ __device__ __forceinline__ double fo_erf_lds(const double2 *__restrict__ tab, do
 
 // sqrt by one Goldschmidt step on v_rsq_f64 (relative error ~1e-14 instead of the correctly rounded ~25-instruction
 // expansion of sqrt()); x >= 0, x = 0 -> 0.  Consumers are rounded to 1e-3 / compared at 1e-9.
+#ifndef FO_DIET
+#define FO_DIET 1   // 0: tuning builds -- the scalar-instruction diet of round 3 switched off (clamped row addresses, literals)
+#endif
 __device__ __forceinline__ double fo_sqrt(double x) {
+#if FO_DIET
+  // x = 0: rsq gives +inf, the Goldschmidt step NaN, and v_max_f64(NaN, 0) = 0 -- a guard that needs no float64 literal
+  // (1e-300 costs two s_mov per use: a scalar instruction is as dear to its wave as a vector one)
+  const double g = __builtin_amdgcn_rsq(x);
+  double y = x * g;
+  const double h = 0.5 * g;
+  const double r = fma(-h, y, 0.5);
+  y = fma(y, r, y);
+  double z;
+  asm("v_max_f64 %0, %1, 0" : "=v"(z) : "v"(y));
+  return z;
+#else
   const double g = __builtin_amdgcn_rsq(fmax(x, 1e-300));
   double y = x * g;
   const double h = 0.5 * g;
   const double r = fma(-h, y, 0.5);
   y = fma(y, r, y);
   return y;
+#endif
 }
 
 __device__ __forceinline__ double fo_round3(double v) { return __builtin_rint(v * 1000.0) / 1000.0; }  // np.round(v,3)
@@ -232,9 +248,12 @@ __global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int tz,
     } else {
       double sn, cs;
       sincos(a0, &sn, &cs);
+      // (speeds beyond 5 km/s are capped in the velocity components the harm model reads: the relative speed then stays
+      // below 1e4 m/s, inside the range of the sweep's table exp, without a clamp per sample)
+      const double vc = fmin(fmax(a1, -5.0e3), 5.0e3);
       dst[1 * TILE] = fo_d2{cs, sn};
       dst[2 * TILE] = fo_d2{a0, a1};
-      dst[3 * TILE] = fo_d2{a1 * cs, a1 * sn};
+      dst[3 * TILE] = fo_d2{vc * cs, vc * sn};
     }
   }
 }
@@ -298,7 +317,8 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
   }
   double *o = tab + (size_t)i * NAF;
   o[0] = pos[2 * (size_t)i]; o[1] = pos[2 * (size_t)i + 1]; o[2] = cs; o[3] = sn; o[4] = yaw[i]; o[5] = v[i];
-  o[6] = isx; o[7] = isy; o[8] = v[i] * cs; o[9] = v[i] * sn; o[10] = rho; o[11] = asin(rho);
+  const double vc = fmin(fmax(v[i], -5.0e3), 5.0e3);   // (see fo_prep_traj_kernel)
+  o[6] = isx; o[7] = isy; o[8] = vc * cs; o[9] = vc * sn; o[10] = rho; o[11] = asin(rho);
   if (t == 0) {
     const double m_obs = fo_obstacle_mass(type[k], shape[2 * k] * shape[2 * k + 1]);  // inflated footprint (Q8)
     double *c = cst + (size_t)k * NAC;
@@ -1185,9 +1205,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         nxy = fo_ld2(e0_); ncs = fo_ld2(e0_ + EF(2)); nvv = fo_ld2(e0_ + EF(6));
         if (lr4s) nth_ = e0_[EF(4)];
       }
-      const cdp_t gr0 = G + (size_t)min(tl, L - 1) * NAF;
+      // (FO_DIET: rows are addressed without clamping -- rows past an agent's length are read but never used, every use sits
+      // behind t < L; the tables end in spare rows, fo_sweep_set_agents / fo_sweep_run)
+      const cdp_t gr0 = G + (size_t)(FO_DIET ? tl : min(tl, L - 1)) * NAF;
       double npx = gr0[0], npy = gr0[1], npc = gr0[2], nps = gr0[3], nyaw = gr0[4], npvx = gr0[8], npvy = gr0[9];
-      const cdp_t grp = G + (size_t)min(max(tl - 1, 0), L - 1) * NAF;
+      const cdp_t grp = G + (size_t)(FO_DIET ? max(tl - 1, 0) : min(max(tl - 1, 0), L - 1)) * NAF;
       double ppx = grp[0], ppy = grp[1];  // agent mean of the previous sample
       // Scalar loads return out of order, so any use of an s_load result waits for lgkmcnt(0).  Pinning the per-agent
       // constants and the first rows here (an empty asm that names them as SGPR inputs) drains the counter before the
@@ -1199,10 +1221,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         const double ex = nxy.x, ey = nxy.y, ec = ncs.x, es = ncs.y, evx = nvv.x, evy = nvv.y, eth = nth_;
         const double px = npx, py = npy, pc = npc, ps = nps, pyaw = nyaw, pvx = npvx, pvy = npvy;
         {
-          const double *e1 = tj + (size_t)min(t + 1, T - 1) * NEF * TILE;
+          const double *e1 = tj + (size_t)(FO_DIET ? t + 1 : min(t + 1, T - 1)) * NEF * TILE;
           nxy = fo_ld2(e1); ncs = fo_ld2(e1 + EF(2)); nvv = fo_ld2(e1 + EF(6));
           if (lr4s) nth_ = e1[EF(4)];
-          const cdp_t g1 = G + (size_t)min(t + 1, L - 1) * NAF;
+          const cdp_t g1 = G + (size_t)(FO_DIET ? t + 1 : min(t + 1, L - 1)) * NAF;
           npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3]; nyaw = g1[4]; npvx = g1[8]; npvy = g1[9];
         }
         if (do_dce && own && t < L && !(ablate & 1) && !(FO_X & 32)) {
@@ -1258,7 +1280,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           // + pi, is the length of the difference of the two velocity vectors; capped (1e4 m/s) so that the logistic
           // arguments of pass 2 stay in the range of the table exp without a clamp of their own
           const double dvx = evx - pvx, dvy = evy - pvy;
+#if FO_DIET
+          dvw[ring * TILE + lane] = fo_sqrt(fma(dvx, dvx, dvy * dvy));   // (<= 1e4: the prep kernels cap the speeds at 5e3 m/s)
+#else
           dvw[ring * TILE + lane] = fmin(fo_sqrt(fma(dvx, dvx, dvy * dvy)), 1.0e4);
+#endif
           if (lr4s) {
             // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
             double ddx = px - ex, ddy = py - ey;
@@ -1785,6 +1811,7 @@ uint32_t required_metrics(uint32_t m) {  // metric.py:125-147
 }
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+constexpr int AGENT_PAD_ROWS = 256;   // spare rows behind the agent table (unclamped row addresses of the queue kernel)
 
 // one instantiation of the queue kernel per output mode: cost vectors only / + pair scalars / + float64 or float32 lists
 template <bool ALLM, bool SPLIT>
@@ -1858,14 +1885,14 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int Mp = round_up(max_M > 0 ? max_M : 1, TILE);
   int rc;
-  if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)max_T * NEF * Mp))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)(max_T + 1) * NEF * Mp))) return rc;   // (+ a spare row, see fo_sweep_run)
   // worst case number of chunks: one agent per wave
   // one agent per wave, or (small batches) one workgroup per agent -- but then n_tiles * A < 3 072
   const size_t chunks_split = (size_t)max_A + 1, tiles = (size_t)Mp / TILE;
   const size_t chunks = tiles * max_A < 3072 ? chunks_split : (size_t)(max_A + WAVES - 1) / WAVES + 1;
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, chunks * NPS * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_chunk_tab, &ctx->cap_chunk_tab, 2 * (chunks + 1)))) return rc;
-  if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) * NAF))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, ((size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) + AGENT_PAD_ROWS) * NAF))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(max_A > 0 ? max_A : 1) * NAC))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(max_A > 0 ? max_A : 1) * 2))) return rc;
   return FO_OK;
@@ -1888,7 +1915,8 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, (size_t)(A > 0 ? A : 1) * Ta * NAF))) return rc;
+  // (+ AGENT_PAD_ROWS spare rows: the sweep reads row t + 1 of an agent without clamping, up to the trajectory horizon)
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, ((size_t)(A > 0 ? A : 1) * Ta + AGENT_PAD_ROWS) * NAF))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(A > 0 ? A : 1) * NAC))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(A > 0 ? A : 1) * 2))) return rc;
   ctx->A = A;
@@ -1930,7 +1958,8 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   const int Mp = round_up(M, TILE);
   const int n_tiles = Mp / TILE;
   const char *force_generic = getenv("FO_SWEEP_GENERIC");  // debug / A-B aid
-  const bool use_queue = !(force_generic && force_generic[0] == '1');
+  // (the queue kernel reads agent rows up to index T without clamping: horizons far beyond the predictions' take the generic kernel)
+  const bool use_queue = !(force_generic && force_generic[0] == '1') && (!FO_DIET || T <= Ta + AGENT_PAD_ROWS - 1 || A == 0);
   const int wpb = use_queue ? QWAVES : WAVES;  // waves per workgroup of the kernel that will run
   int apw = pick_apw(n_tiles, A, wpb);
   if (const char *e = getenv("FO_SWEEP_APW")) { const int v = atoi(e); if (v >= 1 && v <= 64) apw = v; }  // tuning aid
@@ -1969,7 +1998,8 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     }
   }
   int rc;
-  if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)T * NEF * Mp))) return rc;
+  // (T + 1 rows per tile's worth: the sweep prefetches row t + 1 without clamping, the last tile's last prefetch lands in the spare)
+  if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)(T + 1) * NEF * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)(n_chunks + 1) * NPS * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_chunk_tab, &ctx->cap_chunk_tab, (size_t)2 * (n_chunks + 1)))) return rc;
   if (do_be && A > 0) {

@@ -41,6 +41,13 @@ __global__ void k(double *out, unsigned long long *cyc, double seed) {
     if (OP == 13) { R8(asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(i0) : "v"(x))) }
     if (OP == 14) { R8(asm volatile("v_sqrt_f64 %0, %0" : "+v"(x))) }
     if (OP == 15) { I8(asm volatile("v_readlane_b32 s6, %0, 3\n v_writelane_b32 %0, s6, 4" : "+v"(x) :: "s6")) }
+    // mixed streams (round 3): what a float64 instruction leaves room for in the issue of its own wave
+    if (OP == 16) { R8(asm volatile("v_fma_f64 %0, %0, %1, %2\n s_add_u32 s6, s6, 1" : "+v"(x) : "v"(m), "v"(c) : "s6", "scc")) }
+    if (OP == 17) { R8(asm volatile("v_fma_f64 %0, %0, %2, %3\n v_fma_f32 %1, %1, %1, %1" : "+v"(x), "+v"(f0) : "v"(m), "v"(c))) }
+    if (OP == 18) { R8(asm volatile("v_fma_f64 %0, %0, %2, %3\n v_fma_f32 %1, %1, %1, %1\n s_add_u32 s6, s6, 1" : "+v"(x), "+v"(f0) : "v"(m), "v"(c) : "s6", "scc")) }
+    if (OP == 19) { I8(asm volatile("s_add_u32 s6, s6, 1\n s_add_u32 s7, s7, 1" ::: "s6", "s7", "scc")) }
+    if (OP == 20) { R8(asm volatile("v_fma_f64 %0, %0, %1, %2\n s_add_u32 s6, s6, 1\n s_add_u32 s7, s7, 1\n s_add_u32 s8, s8, 1" : "+v"(x) : "v"(m), "v"(c) : "s6", "s7", "s8", "scc")) }
+    if (OP == 21) { F8(asm volatile("v_fma_f32 %0, %0, %0, %0\n s_add_u32 s6, s6, 1" : "+v"(x) :: "s6", "scc")) }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
@@ -62,7 +69,7 @@ int run(const char *name, int waves_per_simd) {
   CHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost));
   std::sort(h.begin(), h.end());
   const double med = (double)h[h.size() / 2];
-  const int per_iter = (OP == 15) ? 16 : 8;
+  const int per_iter = (OP == 15 || OP == 19) ? 16 : 8;   // (mixed streams: per GROUP of instructions)
   // cycles of SIMD time per wave-instruction = wave time / (instructions per wave * waves sharing the SIMD)
   printf("%-22s waves/SIMD=%d  wave-cycles/instr=%6.2f  SIMD-cycles/instr=%6.2f\n", name, waves_per_simd,
          med / (N * per_iter), med / (N * per_iter) / waves_per_simd);
@@ -71,7 +78,9 @@ int run(const char *name, int waves_per_simd) {
 }
 
 int main() {
-  for (int w : {1, 2, 4}) {
+  for (int w : {1, 2, 3, 4}) {
+    run<16>("f64 + salu (group)", w); run<17>("f64 + f32 (group)", w); run<18>("f64 + f32 + salu (group)", w);
+    run<19>("s_add_u32", w); run<20>("f64 + 3 salu (group)", w); run<21>("f32 + salu (group)", w);
     run<0>("v_fma_f64", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<3>("v_max_f64", w);
     run<12>("v_fma_f64 (sgpr src)", w); run<11>("v_cmp_lt_f64", w);
     run<4>("v_rcp_f64", w); run<5>("v_rsq_f64", w); run<14>("v_sqrt_f64", w); run<6>("v_ldexp_f64", w); run<7>("v_rndne_f64", w);

@@ -22,7 +22,8 @@ def main():
     scs = [S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", f"scenario{i}_geometry.npz")) for i in (1, 2, 3)]
     kinds, n_pts = {}, 0
     for it in range(n):
-        sc = scs[int(rng.integers(3))]
+        si = int(rng.integers(3))
+        sc = scs[si]
         by = {l.lanelet_id: l for l in sc.lanelets}
         ll = sc.lanelets[int(rng.integers(len(sc.lanelets)))]
         c = ll.center
@@ -56,7 +57,7 @@ def main():
         n_pts += len(ref)
         for p in ref:
             kinds[p.source.split(" ")[0] + ":" + p.agent_type] = kinds.get(p.source.split(" ")[0] + ":" + p.agent_type, 0) + 1
-        print(it, "scenario", scs.index(sc) + 1, "step", step, "points", [(p.agent_type, p.source) for p in ref], flush=True)
+        print(it, "scenario", si + 1, "step", step, "points", [(p.agent_type, p.source) for p in ref], flush=True)
     print("all", n, "cases: device == checker;", n_pts, "spawn points:", kinds)
 
 
