@@ -1091,6 +1091,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
 #ifndef FO_CARRY
 #define FO_CARRY 0   // 1: tuning builds -- the first ego row of a chunk is carried over pass 2 instead of re-loaded (measured: float32 lists 0.562 against 0.552, float64 lists 0.637 against 0.650: the 14 live registers cost more than the wait)
 #endif
+    // (Also measured and not kept, round 3: two register sets for the current / next rows that swap roles, the loop
+    // unrolled by two, instead of one set rotated by seven v_mov_b64 and ten s_mov per sample -- 0.552 against 0.541 ms:
+    // 30 spilled registers instead of 8 and a quarter more code cost more than the copies.)
     // the ego row a chunk starts with: pass 1 of the chunk before has already fetched it (its last iteration prefetches
     // row t1); carried over pass 2 in registers, the chunk's first loads do not queue behind that pass's list stores
     // (vmcnt retires in issue order: a load issued after 24 stores waits for their acknowledgement)
