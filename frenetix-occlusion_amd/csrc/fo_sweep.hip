@@ -1201,7 +1201,14 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       unsigned wgate = 0u;  // the same for the whole wave (uniform): some lane is inside the gate.  Bits 16 + (t & 15)
                             // of the same scalar: some lane's impact angle of sample t may sit on a class boundary
       int qn = 0;
-      int ring = tl % DVR;  // row of sample t in the ring of relative speeds
+      // Relative speeds: sample t sits in row t - gbase of the wave's DVR rows.  Pass 2 of this chunk starts one sample
+      // before it (row 0), which the chunk before left in its last row.
+      if (!(SPLIT && t0 > 0) && t0 > seg0) dvw[lane] = dvw[TC * TILE + lane];
+      // the sample ranges of the DCE and of the gate as one unsigned comparison each (scalar instructions are not free:
+      // DESIGN.md section 3.1): DCE on [t0, L), gate on [max(t0, 1), L)
+      const int dce_n = (do_dce && !(ablate & 1) && !(FO_X & 32)) ? max(L - t0, 0) : 0;
+      const int gate_lo = max(t0, 1);
+      const int gate_n = (do_cp && !(ablate & 2) && !(FO_X & 64)) ? max(L - gate_lo, 0) : 0;
       const bool geo = do_hr && !(ablate & 4);
       if (!FO_CARRY || SPLIT || t0 == seg0) {
         const double *e0_ = tj + (size_t)tl * NEF * TILE;
@@ -1220,7 +1227,6 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(Rsum), "s"(gate_far2), "s"(npx),
                    "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy), "s"(npvx), "s"(npvy), "s"(nyaw));
       for (int t = tl; t < t1; ++t) {
-        const bool own = !SPLIT || t >= t0;  // wave-uniform
         const double ex = nxy.x, ey = nxy.y, ec = ncs.x, es = ncs.y, evx = nvv.x, evy = nvv.y, eth = nth_;
         const double px = npx, py = npy, pc = npc, ps = nps, pyaw = nyaw, pvx = npvx, pvy = npvy;
         {
@@ -1230,7 +1236,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           const cdp_t g1 = G + (size_t)(FO_DIET ? t + 1 : min(t + 1, L - 1)) * NAF;
           npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3]; nyaw = g1[4]; npvx = g1[8]; npvy = g1[9];
         }
-        if (do_dce && own && t < L && !(ablate & 1) && !(FO_X & 32)) {
+        if ((unsigned)(t - t0) < (unsigned)dce_n) {
           const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
           const double dx = px - ccx, dy = py - ccy;
           // nothing to gain after the (earliest) zero; otherwise the centres must be close enough
@@ -1284,9 +1290,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           // arguments of pass 2 stay in the range of the table exp without a clamp of their own
           const double dvx = evx - pvx, dvy = evy - pvy;
 #if FO_DIET
-          dvw[ring * TILE + lane] = fo_sqrt(fma(dvx, dvx, dvy * dvy));   // (<= 1e4: the prep kernels cap the speeds at 5e3 m/s)
+          dvw[(t - gbase) * TILE + lane] = fo_sqrt(fma(dvx, dvx, dvy * dvy));   // (<= 1e4: the prep kernels cap the speeds at 5e3 m/s)
 #else
-          dvw[ring * TILE + lane] = fmin(fo_sqrt(fma(dvx, dvx, dvy * dvy)), 1.0e4);
+          dvw[(t - gbase) * TILE + lane] = fmin(fo_sqrt(fma(dvx, dvx, dvy * dvy)), 1.0e4);
 #endif
           if (lr4s) {
             // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
@@ -1302,8 +1308,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             cls_o = (cls_o & ~(3u << sh)) | (co << sh);
           }
         }
-        ring = (ring + 1 == DVR) ? 0 : ring + 1;
-        if (do_cp && own && t >= 1 && t < L && !(ablate & 2) && !(FO_X & 64)) {
+        if ((unsigned)(t - gate_lo) < (unsigned)gate_n) {
           // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
           const double rx = ex - ppx, ry = ey - ppy;
           const double d0 = rx * rx + ry * ry;
@@ -1376,20 +1381,28 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         auto pass2 = [&](auto lr4s_tag) {
           constexpr bool LR4S = decltype(lr4s_tag)::value;
           const double ke_ = hk[0], ko_ = hk[1], ce_ = hk[2], co_ = hk[3];
-          int rr = g0s % DVR;
           // LDS reads of sample t+1 are issued while sample t is evaluated
-          double dvn = dvw[rr * TILE + lane];
+          double dvn = dvw[(g0s - gbase) * TILE + lane];
           double zen = 0.0, zon = 0.0;
           if (LR4S) {
             const int sh = (g0s & 15) * 2;
             zen = zc_tab[(cls_e >> sh) & 3u];
             zon = zc_tab[(cls_o >> sh) & 3u];
           }
+          // Rows that take the long way (wave-uniform mask, one bit per buffer row): some lane of the wave is inside the
+          // gate, the wave's first sample (it seeds the running maxima and indices), and the samples past the harm
+          // length.  On every other row -- 97 % of the samples of the bench workload -- every probability is zero, so are
+          // the risks, and none of the maxima or indices can move.
+          unsigned slow = wgate & 0xffffu;
+          if (gfirst >= g0s) slow |= 1u << (gfirst - gbase);
+          unsigned hvrows = geo ? ~0u : 0u;   // bit row: the sample lies inside the harm length
+          if (geo && Lh < g1s) hvrows = ~(~0u << max(Lh - gbase, 0));
+          slow = __builtin_amdgcn_readfirstlane(slow | ~hvrows);
+          hvrows = __builtin_amdgcn_readfirstlane(hvrows);
           for (int t = g0s; t < g1s; ++t) {
             const int row = t - gbase;
             const double dv = dvn, ze = zen, zo = zon;
-            rr = (rr + 1 == DVR) ? 0 : rr + 1;
-            dvn = dvw[rr * TILE + lane];
+            dvn = dvw[(row + 1) * TILE + lane];
             if (LR4S) {
               const int sh = ((t + 1) & 15) * 2;
               zen = zc_tab[(cls_e >> sh) & 3u];
@@ -1397,10 +1410,12 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             }
             double eh = NAN, oh = NAN, er = NAN, orr = NAN, cp = 0.0;
             float ehf = NAN, ohf = NAN;   // LST_F32: the harm entries of the lists
-            const bool hv = geo && t < Lh;  // wave-uniform
-            if (hv && (FO_X & 8)) {
-              eh = dv; oh = ze + zo;
-            } else if (hv) {
+            // harm of a sample inside the harm length (wave-uniform)
+            auto harm = [&]() {
+              if (FO_X & 8) {
+                eh = dv; oh = ze + zo;
+                return;
+              }
               const bool model = LR4S || prot == 0;   // wave-uniform; otherwise harm is 1 on both sides
               const double nze = LR4S ? fma(ke_, dv, ze) : fma(ke_, dv, ce_), nzo = LR4S ? fma(ko_, dv, zo) : fma(ko_, dv, co_);
               if (LISTS == LST_F64 || !model) {
@@ -1417,13 +1432,15 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                   ohf = fo_logistic_neg_f32(nzo);
                 }
               }
-            }
-            // No lane of the wave is inside the gate at this sample (97 % of the samples of the bench workload): every
-            // probability is zero, so are the risks, and none of the running maxima or indices can move -- they were
-            // seeded by the wave's first sample, which always takes the long way.
-            if (!hv || t == gfirst || ((wgate >> row) & 1u)) {
+            };
+            const bool hv = (hvrows >> row) & 1u;  // wave-uniform: geo && t < Lh
+            if (hv) harm();
+            if (!((slow >> row) & 1u)) {
+              er = 0.0;
+              orr = 0.0;
+            } else {
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
-              if (LISTS != LST_F64 && hv && (LR4S || prot == 0)) {   // the harm values themselves, where a risk may need them
+              if (LISTS != LST_F64 && hv && !(FO_X & 8) && (LR4S || prot == 0)) {   // the harm values themselves, where a risk may need them
                 eh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ke_, dv, ze) : fma(ke_, dv, ce_));
                 oh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ko_, dv, zo) : fma(ko_, dv, co_));
                 if (LISTS == LST_F32) { ehf = (float)eh; ohf = (float)oh; }   // so that risk = harm x cp holds in the lists too
@@ -1437,9 +1454,6 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 if (orr > max_or) { max_or = orr; idx_or = t; }
               }
               if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
-            } else {
-              er = 0.0;
-              orr = 0.0;
             }
             if (LISTS == LST_F64) {
               fo_store_lists(a.lists, ls, li, cp, eh, oh, er, orr);
