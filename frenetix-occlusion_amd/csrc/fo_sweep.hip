@@ -1226,15 +1226,21 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       // loop, which leaves the in-loop wait to cover only the row that was prefetched one iteration ago.
       asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(Rsum), "s"(gate_far2), "s"(npx),
                    "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy), "s"(npvx), "s"(npvy), "s"(nyaw));
+      // rows t+1 as running 32-bit byte offsets from the (uniform) bases of this tile's and this agent's rows: one add
+      // each per sample instead of a 64-bit multiply-add, and the loads take the base from scalar registers
+      unsigned eoff = (unsigned)((tl * NEF * TILE + 2 * lane) * sizeof(double));
+      unsigned goff = (unsigned)(tl * NAF * sizeof(double));
       for (int t = tl; t < t1; ++t) {
         const double ex = nxy.x, ey = nxy.y, ec = ncs.x, es = ncs.y, evx = nvv.x, evy = nvv.y, eth = nth_;
         const double px = npx, py = npy, pc = npc, ps = nps, pyaw = nyaw, pvx = npvx, pvy = npvy;
         {
-          const double *e1 = tj + (size_t)(FO_DIET ? t + 1 : min(t + 1, T - 1)) * NEF * TILE;
+          eoff += (unsigned)(NEF * TILE * sizeof(double));
+          goff += (unsigned)(NAF * sizeof(double));
+          const double *e1 = (const double *)((const char *)tjb + eoff);
           nxy = fo_ld2(e1); ncs = fo_ld2(e1 + EF(2)); nvv = fo_ld2(e1 + EF(6));
-          if (lr4s) nth_ = e1[EF(4)];
-          const cdp_t g1 = G + (size_t)(FO_DIET ? t + 1 : min(t + 1, L - 1)) * NAF;
-          npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3]; nyaw = g1[4]; npvx = g1[8]; npvy = g1[9];
+          const cdp_t g1 = (cdp_t)((const __attribute__((address_space(4))) char *)G + goff);
+          npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3]; npvx = g1[8]; npvy = g1[9];
+          if (lr4s) { nth_ = e1[EF(4)]; nyaw = g1[4]; }   // the headings only enter the LR4S model
         }
         if ((unsigned)(t - t0) < (unsigned)dce_n) {
           const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
