@@ -814,6 +814,11 @@ __device__ __forceinline__ double fo_vmax(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ double fo_vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // exp(z) = 2^(k/256) * e^r, k = rint(256 z / ln 2), |r| <= ln2/512: 256-entry table of 2^(j/256) in LDS (2 KB) and a
 // degree-3 polynomial (remainder r^4/24 < 1.5e-13 relative).  One-step argument reduction: ln2/256 cut to 43
@@ -1066,8 +1071,15 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     // are the logistic of the smallest argument -- 1/(1 + exp(nz)) falls with nz -- so the other samples keep a running
     // minimum of the two arguments and the logistic is taken once per pair.
     double nze_min = INFINITY, nzo_min = INFINITY;
+    // List stores: the three blocks (cp | harm pairs | risk pairs) from per-agent scalar bases plus two running 32-bit
+    // lane offsets (element size 1x and 2x) -- no 64-bit address arithmetic per sample (fo_sweep_run sends batches whose
+    // (T-1) M pair elements pass 4 GB to the generic kernel)
     const size_t ls = (size_t)A * Tm1 * M;
-    size_t li = ((size_t)k * Tm1 + gfirst_) * M + m;  // index of the next sample in the list buffers
+    constexpr unsigned LE = (LISTS == LST_F32) ? 4u : 8u;   // list element size
+    char *const lb0 = (char *)a.lists + (size_t)k * Tm1 * M * LE;
+    char *const lb1 = (char *)a.lists + (ls + (size_t)k * Tm1 * M * 2) * LE;
+    char *const lb2 = (char *)a.lists + (3 * ls + (size_t)k * Tm1 * M * 2) * LE;
+    unsigned lo1 = (unsigned)(gfirst_ * M + m) * LE, lo2 = (unsigned)(gfirst_ * M + m) * (2u * LE);
     // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
     // (harm_model.py:96-97: ego_dv = m_obs/(m_ego+m_obs) dv, obs_dv = m_ego/(m_ego+m_obs) dv)
     const bool lr4s = prot == 1;
@@ -1431,8 +1443,8 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 max_oh = fo_vmax(max_oh, oh);
                 if (LISTS == LST_F32) { ehf = 1.0f; ohf = 1.0f; }
               } else {
-                nze_min = fmin(nze_min, nze);
-                nzo_min = fmin(nzo_min, nzo);
+                nze_min = fo_vmin(nze_min, nze);   // (neither is ever NaN: no canonicalising pair of v_max around it)
+                nzo_min = fo_vmin(nzo_min, nzo);
                 if (LISTS == LST_F32) {   // float32 list entries: hardware exp / rcp (the maxima above stay float64)
                   ehf = fo_logistic_neg_f32(nze);
                   ohf = fo_logistic_neg_f32(nzo);
@@ -1441,6 +1453,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             };
             const bool hv = (hvrows >> row) & 1u;  // wave-uniform: geo && t < Lh
             if (hv) harm();
+            float cpf = 0.0f, erf_ = 0.0f, orf = 0.0f;   // LST_F32: what the lists get (constants on the short branch)
             if (!((slow >> row) & 1u)) {
               er = 0.0;
               orr = 0.0;
@@ -1460,14 +1473,19 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 if (orr > max_or) { max_or = orr; idx_or = t; }
               }
               if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
+              if (LISTS == LST_F32) { cpf = (float)cp; erf_ = (float)er; orf = (float)orr; }
             }
             if (LISTS == LST_F64) {
-              fo_store_lists(a.lists, ls, li, cp, eh, oh, er, orr);
-              li += M;
+              __builtin_nontemporal_store(cp, (double *)(lb0 + lo1));
+              __builtin_nontemporal_store(fo_d2{eh, oh}, (fo_d2 *)(lb1 + lo2));
+              __builtin_nontemporal_store(fo_d2{er, orr}, (fo_d2 *)(lb2 + lo2));
             } else if (LISTS == LST_F32) {
-              fo_store_lists_f32((float *)a.lists, ls, li, (float)cp, ehf, ohf, (float)er, (float)orr);
-              li += M;
+              __builtin_nontemporal_store(cpf, (float *)(lb0 + lo1));
+              __builtin_nontemporal_store(fo_f2{ehf, ohf}, (fo_f2 *)(lb1 + lo2));
+              __builtin_nontemporal_store(fo_f2{erf_, orf}, (fo_f2 *)(lb2 + lo2));
             }
+            lo1 += (unsigned)M * LE;
+            lo2 += (unsigned)M * (2u * LE);
           }
         };
         if (lr4s) pass2(std::true_type{}); else pass2(std::false_type{});
@@ -1982,7 +2000,9 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   const int n_tiles = Mp / TILE;
   const char *force_generic = getenv("FO_SWEEP_GENERIC");  // debug / A-B aid
   // (the queue kernel reads agent rows up to index T without clamping: horizons far beyond the predictions' take the generic kernel)
-  const bool use_queue = !(force_generic && force_generic[0] == '1') && (!FO_DIET || T <= Ta + AGENT_PAD_ROWS - 1 || A == 0);
+  // (the queue kernel addresses one agent's list rows by 32-bit byte offsets: (T-1) M pairs of float64 must stay under 4 GB)
+  const bool use_queue = !(force_generic && force_generic[0] == '1') && (!FO_DIET || T <= Ta + AGENT_PAD_ROWS - 1 || A == 0) &&
+                         (size_t)(T > 1 ? T - 1 : 1) * (size_t)M * 16u < ((size_t)1 << 32);
   const int wpb = use_queue ? QWAVES : WAVES;  // waves per workgroup of the kernel that will run
   int apw = pick_apw(n_tiles, A, wpb);
   if (const char *e = getenv("FO_SWEEP_APW")) { const int v = atoi(e); if (v >= 1 && v <= 64) apw = v; }  // tuning aid
