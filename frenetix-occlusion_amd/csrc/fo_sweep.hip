@@ -335,7 +335,17 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
     c[11] = lr4s ? -hc.lr4s_speed * c[4] : -hc.ped_speed * c[4];
     c[12] = -hc.lr1s_const;
     c[13] = hc.ped_const;
-    c[14] = 0.0; c[15] = 0.0;
+    // Coarse gate test of the sweep: the gate of sample t-1 takes the ego reference point of sample t against the agent
+    // mean of sample t-1; the sweep tests the distance it has anyway -- shifted ego centre t to agent mean t -- against
+    // 5 m + half the inflated length + the longest step of the agent's mean (+ the centre shift, added in the kernel):
+    // |e_t - p_(t-1)| <= |e_t - c_t| + |c_t - p_t| + |p_t - p_(t-1)|
+    double smax = 0.0;
+    for (int u = 1; u < L; ++u) {
+      const double sx_ = pos[2 * ((size_t)i + u)] - pos[2 * ((size_t)i + u - 1)], sy_ = pos[2 * ((size_t)i + u) + 1] - pos[2 * ((size_t)i + u - 1) + 1];
+      smax = fmax(smax, sqrt(sx_ * sx_ + sy_ * sy_));
+    }
+    c[14] = 5.0 + c[2] + 1e-6 + smax * (1.0 + 1e-12);
+    c[15] = 0.0;
     aint[2 * k] = fo_obstacle_protection(type[k]);
     aint[2 * k + 1] = L;
   }
@@ -989,7 +999,14 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     if (k >= A) break;
     const cdp_t G = fo_const(a.atab) + (size_t)k * a.Ta * NAF;
     const cdp_t C = fo_const(a.acst) + (size_t)k * NAC;
-    const double hlB = C[0], hwB = C[1], hdev = C[2], Rsum = C[8], gate_far2 = C[9];
+    const double hlB = C[0], hwB = C[1], hdev = C[2], Rsum = C[8];
+    // coarse gate radius around the agent mean of the same sample, squared (fo_prep_agents_kernel, c[14]); wave-uniform
+    double gate_far2;
+    {
+      const double gf = (C[14] + fabs(a.wb)) * (1.0 + 1e-12);
+      const double gf2 = gf * gf;
+      gate_far2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(gf2)), __builtin_amdgcn_readfirstlane(__double2loint(gf2)));
+    }
     const int prot = fo_const(a.aint)[2 * k], L = fo_const(a.aint)[2 * k + 1];
     const int Lh = min(Tm1, L);
 
@@ -1218,9 +1235,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       if (!(SPLIT && t0 > 0) && t0 > seg0) dvw[lane] = dvw[TC * TILE + lane];
       // the sample ranges of the DCE and of the gate as one unsigned comparison each (scalar instructions are not free:
       // DESIGN.md section 3.1): DCE on [t0, L), gate on [max(t0, 1), L)
-      const int dce_n = (do_dce && !(ablate & 1) && !(FO_X & 32)) ? max(L - t0, 0) : 0;
-      const int gate_lo = max(t0, 1);
-      const int gate_n = (do_cp && !(ablate & 2) && !(FO_X & 64)) ? max(L - gate_lo, 0) : 0;
+      const bool dce_on = do_dce && !(ablate & 1) && !(FO_X & 32), gate_on = do_cp && !(ablate & 2) && !(FO_X & 64);
+      const int rng_n = (dce_on || gate_on) ? max(L - t0, 0) : 0;
+      const double gate_far2c = gate_on ? gate_far2 : -1.0;   // (no distance is below -1: the test never passes)
+      if (!dce_on) thrR2 = -1.0;
       const bool geo = do_hr && !(ablate & 4);
       if (!FO_CARRY || SPLIT || t0 == seg0) {
         const double *e0_ = tj + (size_t)tl * NEF * TILE;
@@ -1230,35 +1248,37 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       // (FO_DIET: rows are addressed without clamping -- rows past an agent's length are read but never used, every use sits
       // behind t < L; the tables end in spare rows, fo_sweep_set_agents / fo_sweep_run)
       const cdp_t gr0 = G + (size_t)(FO_DIET ? tl : min(tl, L - 1)) * NAF;
-      double npx = gr0[0], npy = gr0[1], npc = gr0[2], nps = gr0[3], nyaw = gr0[4], npvx = gr0[8], npvy = gr0[9];
-      const cdp_t grp = G + (size_t)(FO_DIET ? max(tl - 1, 0) : min(max(tl - 1, 0), L - 1)) * NAF;
-      double ppx = grp[0], ppy = grp[1];  // agent mean of the previous sample
+      double px = gr0[0], py = gr0[1], npx = px, npy = py;
+      // Only the mean of the next row is fetched a sample ahead (the first thing a sample needs); heading and velocity
+      // are re-loaded IN PLACE right after their last use in a sample -- no second register set, no copies
+      double pc = gr0[2], ps = gr0[3], pyaw = gr0[4], pvx = gr0[8], pvy = gr0[9];
       // Scalar loads return out of order, so any use of an s_load result waits for lgkmcnt(0).  Pinning the per-agent
       // constants and the first rows here (an empty asm that names them as SGPR inputs) drains the counter before the
       // loop, which leaves the in-loop wait to cover only the row that was prefetched one iteration ago.
-      asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(Rsum), "s"(gate_far2), "s"(npx),
-                   "s"(npy), "s"(npc), "s"(nps), "s"(ppx), "s"(ppy), "s"(npvx), "s"(npvy), "s"(nyaw));
+      asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(Rsum), "s"(gate_far2), "s"(px),
+                   "s"(py), "s"(pc), "s"(ps), "s"(pvx), "s"(pvy), "s"(pyaw));
       // rows t+1 as running 32-bit byte offsets from the (uniform) bases of this tile's and this agent's rows: one add
       // each per sample instead of a 64-bit multiply-add, and the loads take the base from scalar registers
       unsigned eoff = (unsigned)((tl * NEF * TILE + 2 * lane) * sizeof(double));
       unsigned goff = (unsigned)(tl * NAF * sizeof(double));
       for (int t = tl; t < t1; ++t) {
         const double ex = nxy.x, ey = nxy.y, ec = ncs.x, es = ncs.y, evx = nvv.x, evy = nvv.y, eth = nth_;
-        const double px = npx, py = npy, pc = npc, ps = nps, pyaw = nyaw, pvx = npvx, pvy = npvy;
         {
           eoff += (unsigned)(NEF * TILE * sizeof(double));
           goff += (unsigned)(NAF * sizeof(double));
           const double *e1 = (const double *)((const char *)tjb + eoff);
           nxy = fo_ld2(e1); ncs = fo_ld2(e1 + EF(2)); nvv = fo_ld2(e1 + EF(6));
           const cdp_t g1 = (cdp_t)((const __attribute__((address_space(4))) char *)G + goff);
-          npx = g1[0]; npy = g1[1]; npc = g1[2]; nps = g1[3]; npvx = g1[8]; npvy = g1[9];
-          if (lr4s) { nth_ = e1[EF(4)]; nyaw = g1[4]; }   // the headings only enter the LR4S model
+          npx = g1[0]; npy = g1[1];
+          if (lr4s) nth_ = e1[EF(4)];   // the headings only enter the LR4S model
         }
-        if ((unsigned)(t - t0) < (unsigned)dce_n) {
+        const cdp_t g1 = (cdp_t)((const __attribute__((address_space(4))) char *)G + goff);
+        if ((unsigned)(t - t0) < (unsigned)rng_n) {
           const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
           const double dx = px - ccx, dy = py - ccy;
+          const double dd = dx * dx + dy * dy;   // shared by the DCE and the gate: both start from a coarse distance test
           // nothing to gain after the (earliest) zero; otherwise the centres must be close enough
-          const bool near = !(dce == 0.0 && t > tdce) && (dx * dx + dy * dy < thrR2);
+          const bool near = !(dce == 0.0 && t > tdce) && (dd < thrR2);
           if (__ballot(near)) {
             const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
             const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;   // agent centre in the ego frame
@@ -1301,12 +1321,58 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               }
             }
           }
+          // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t.  The two
+          // displaced means are hdev away from the mean: beyond 5 m + hdev none of the three can be in the gate, and the
+          // mean of sample t-1 is at most the agent's longest step from the one of sample t (gate_far2)
+          // (sample 0 has no gate: sorted out on the rare side of the branch)
+          if (__ballot(dd <= gate_far2c)) if (t >= 1) {
+            // (scalar loads on the rare path; the row was read a sample ago)
+            const cdp_t gq = (cdp_t)((const __attribute__((address_space(4))) char *)G + (goff - 2u * (unsigned)(NAF * sizeof(double))));
+            const double rx = ex - gq[0], ry = ey - gq[1];
+            const double d0 = rx * rx + ry * ry;
+            const double devx = pc * hdev, devy = ps * hdev;
+            const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
+            const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
+            const double m2 = fmin(d0, fmin(dp, dm));
+            // the reference tests the ROUNDED distance, !(sqrt(m2) > 5.0) (collision_probability.py:67,75).  The
+            // correctly rounded square root of m2 is 5.0 up to and including m2 = 25 + one ulp (sqrt(25 (1 + d)) = 5 (1 + d/2),
+            // half an ulp of 5.0 is 4.4e-16, one ulp of 25 is 3.6e-15): no square root needed
+            const bool ing = m2 <= 25.000000000000004;
+            const unsigned long long bal = __ballot(ing);
+            if (bal) {
+              const int row = t - t0;  // = (t - 1) - gbase
+              const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+              if (ing) {
+                q[pos] = (unsigned short)(lane | (row << 6));
+                gmask |= 1u << row;
+              }
+              wgate |= 1u << row;
+              qn += __popcll(bal);
+              if (qn >= 64) {
+                process(64);
+                const int rest = qn - 64;
+                unsigned short tmp = 0;
+                if (lane < rest) tmp = q[64 + lane];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane < rest) q[lane] = tmp;
+                qn = rest;
+              }
+            }
+          }
+        }
+        // relative speed of sample t (harm_model.py:92-94): sqrt(ve^2 + va^2 + 2 ve va cos(pdof)), pdof = yaw - theta
+        // + pi, is the length of the difference of the two velocity vectors; capped (1e4 m/s) so that the logistic
+        // arguments of pass 2 stay in the range of the table exp without a clamp of their own
+        double dvx = evx - pvx, dvy = evy - pvy;
+        {
+          // (last use of this sample's velocity above: the next row's takes its place.  The empty asm orders the load
+          // behind the subtraction -- issued earlier it would need registers of its own and a copy)
+          unsigned gb = __builtin_amdgcn_readfirstlane(goff);
+          asm volatile("" : "+v"(dvx), "+v"(dvy), "+s"(gb));
+          const cdp_t g2 = (cdp_t)((const __attribute__((address_space(4))) char *)G + gb);
+          pvx = g2[8]; pvy = g2[9];
         }
         if (geo && t < Lh && !(FO_X & 4)) {
-          // relative speed of sample t (harm_model.py:92-94): sqrt(ve^2 + va^2 + 2 ve va cos(pdof)), pdof = yaw - theta
-          // + pi, is the length of the difference of the two velocity vectors; capped (1e4 m/s) so that the logistic
-          // arguments of pass 2 stay in the range of the table exp without a clamp of their own
-          const double dvx = evx - pvx, dvy = evy - pvy;
 #if FO_DIET
           dvw[(t - gbase) * TILE + lane] = fo_sqrt(fma(dvx, dvx, dvy * dvy));   // (<= 1e4: the prep kernels cap the speeds at 5e3 m/s)
 #else
@@ -1326,44 +1392,16 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             cls_o = (cls_o & ~(3u << sh)) | (co << sh);
           }
         }
-        if ((unsigned)(t - gate_lo) < (unsigned)gate_n) {
-          // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t
-          const double rx = ex - ppx, ry = ey - ppy;
-          const double d0 = rx * rx + ry * ry;
-          bool ing = false;
-          // the two displaced means are hdev away from the mean: beyond 5 m + hdev none of the three can be in the gate
-          if (__ballot(d0 <= gate_far2)) {
-            const double devx = pc * hdev, devy = ps * hdev;
-            const double dp = (rx - devx) * (rx - devx) + (ry - devy) * (ry - devy);
-            const double dm = (rx + devx) * (rx + devx) + (ry + devy) * (ry + devy);
-            const double m2 = fmin(d0, fmin(dp, dm));
-            // the reference tests the ROUNDED distance, !(sqrt(m2) > 5.0) (collision_probability.py:67,75).  The
-            // correctly rounded square root of m2 is 5.0 up to and including m2 = 25 + one ulp (sqrt(25 (1 + d)) = 5 (1 + d/2),
-            // half an ulp of 5.0 is 4.4e-16, one ulp of 25 is 3.6e-15): no square root needed
-            ing = m2 <= 25.000000000000004;
-          }
-          const unsigned long long bal = __ballot(ing);
-          if (bal) {
-            const int row = t - t0;  // = (t - 1) - gbase
-            const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-            if (ing) {
-              q[pos] = (unsigned short)(lane | (row << 6));
-              gmask |= 1u << row;
-            }
-            wgate |= 1u << row;
-            qn += __popcll(bal);
-            if (qn >= 64) {
-              process(64);
-              const int rest = qn - 64;
-              unsigned short tmp = 0;
-              if (lane < rest) tmp = q[64 + lane];
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              if (lane < rest) q[lane] = tmp;
-              qn = rest;
-            }
-          }
+        {
+          // the mean fetched at the top of this sample becomes the current one BEFORE the next loads are issued: scalar
+          // loads return out of order, so the wait in front of these copies would otherwise cover the loads below
+          px = npx; py = npy;
+          unsigned gb = __builtin_amdgcn_readfirstlane(goff);
+          asm volatile("" : "+s"(px), "+s"(py), "+s"(gb));
+          const cdp_t g2 = (cdp_t)((const __attribute__((address_space(4))) char *)G + gb);
+          pc = g2[2]; ps = g2[3];
+          if (lr4s) pyaw = g2[4];
         }
-        ppx = px; ppy = py;
       }
       if (qn > 0) process(qn);
       wgate = __builtin_amdgcn_readfirstlane(wgate);  // uniform by construction; says so to the register allocator
@@ -1612,12 +1650,15 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
 #ifndef FO_WIDE_LISTS
 #define FO_WIDE_LISTS 0   // 1: tuning builds -- the full-output instantiation in the four-wave shape as well
 #endif
+#ifndef FO_WIDE_NONE
+#define FO_WIDE_NONE 1    // 0: tuning builds -- the instantiations without lists in the three-wave shape
+#endif
 #ifndef FO_WIDE_F32
 #define FO_WIDE_F32 0     // 1: the float32-list instantiation in the four-wave shape
 #endif
 template <int LISTS, bool SPLIT>
 struct SweepShape {
-  static constexpr bool wide = (LISTS == LST_NONE || FO_WIDE_LISTS || (LISTS == LST_F32 && FO_WIDE_F32)) && !SPLIT &&
+  static constexpr bool wide = ((LISTS == LST_NONE && FO_WIDE_NONE) || FO_WIDE_LISTS || (LISTS == LST_F32 && FO_WIDE_F32)) && !SPLIT &&
                                FO_MINW == 3 && FO_TC == 8;   // tuning builds override both macros
   static constexpr int tc = wide ? 4 : FO_TC, minw = wide ? 4 : FO_MINW;
 };
