@@ -1651,7 +1651,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
 #define FO_WIDE_LISTS 0   // 1: tuning builds -- the full-output instantiation in the four-wave shape as well
 #endif
 #ifndef FO_WIDE_NONE
-#define FO_WIDE_NONE 1    // 0: tuning builds -- the instantiations without lists in the three-wave shape
+#define FO_WIDE_NONE 0    // 1: the instantiations without lists in the four-wave shape (round 2 and early round 3: faster then; since the scalar diet of round 3 the three-wave shape wins, reduced outputs 0.417 against 0.438 ms)
 #endif
 #ifndef FO_WIDE_F32
 #define FO_WIDE_F32 0     // 1: the float32-list instantiation in the four-wave shape
