@@ -1,9 +1,13 @@
 // fo_api.hip -- context management of the C ABI (include/fo_hip.h).
 #include <hip/hip_runtime.h>
 #include <new>
+#include <cstdlib>
 #include "fo_ctx.hpp"
+#include "fo_agent_rows.hpp"
 
 extern "C" void fo_scene_destroy_(fo_ctx *ctx);  // fo_scene.hip
+extern "C" int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, void *stream);  // fo_scene.hip
+extern "C" int fo_sweep_agents_begin_(fo_ctx *ctx, int A, int Ta, void *stream, fo_agent_table_t *out);   // fo_sweep.hip
 extern "C" int fo_sweep_init_(fo_ctx *ctx);      // fo_sweep.hip
 
 extern "C" {
@@ -74,23 +78,36 @@ int fo_sweep_check(fo_ctx *ctx, void *stream) {
   return FO_OK;
 }
 
-// one planning step = the five stage calls on one stream (include/fo_hip.h, fo_step_t)
+// One planning step on one stream (include/fo_hip.h, fo_step_t): the results of the five stage calls fo_scene_fan ->
+// fo_scene_visibility -> fo_scene_spawn -> fo_sweep_set_agents -> fo_sweep_run, bit for bit, in three launches less -- the
+// ray fan is worked out inside the ray kernel, the sampler's candidate cells are flagged inside the compaction of the
+// occluded cells, and the phantom prediction kernel writes its slots' rows of the sweep's agent table itself.
+// (FO_STEP_STAGES=1 in the environment: the plain sequence of stage calls, for A/B runs.)
 int fo_step_run(fo_ctx *ctx, const fo_step_t *p, void *stream) {
   if (!ctx || !p) return fo_fail(ctx, FO_E_ARG, "fo_step_run: null argument");
   int rc;
-  if ((rc = fo_scene_fan(ctx, p->n_rays, p->ego_yaw, p->fov_deg, p->r, p->polygon_footprint, p->d_dirs, p->d_rmax, p->d_half, stream))) return rc;
-  if ((rc = fo_scene_visibility(ctx, p->ego_x, p->ego_y, p->head_x, p->head_y, p->r, p->full_circle, p->exact_cells, p->n_rays,
-                                p->d_dirs, p->d_rmax, p->d_half, p->d_edge_skip, p->O, p->d_ocorn, p->d_ocen, p->d_oflags,
-                                p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->d_range, p->d_hit_id, p->d_ring, p->d_obst_vis,
-                                p->d_cls, p->d_occ_idx, p->d_n_occ, stream))) return rc;
-  if ((rc = fo_scene_spawn(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->ego_x, p->ego_y, p->head_x, p->head_y,
-                           p->min_ahead, p->max_dist, p->all_occluded, p->max_agents, p->routes, p->type4, p->speed4, p->raw_l4,
-                           p->raw_w4, p->infl_l4, p->infl_w4, p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor,
-                           p->d_cell, p->d_pos0, p->d_yaw0, p->d_n, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape,
-                           p->d_raw_dims, p->d_type, p->d_len, stream))) return rc;
+  static const bool stages = [] { const char *e = getenv("FO_STEP_STAGES"); return e && e[0] == '1'; }();
   const int slots = p->max_agents * (p->routes > 0 ? p->routes : 1);
-  if ((rc = fo_sweep_set_agents(ctx, slots, p->T_agents, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape, p->d_raw_dims, p->d_type,
-                                p->d_len, stream))) return rc;
+  if (stages) {
+    if ((rc = fo_scene_fan(ctx, p->n_rays, p->ego_yaw, p->fov_deg, p->r, p->polygon_footprint, p->d_dirs, p->d_rmax, p->d_half, stream))) return rc;
+    if ((rc = fo_scene_visibility(ctx, p->ego_x, p->ego_y, p->head_x, p->head_y, p->r, p->full_circle, p->exact_cells, p->n_rays,
+                                  p->d_dirs, p->d_rmax, p->d_half, p->d_edge_skip, p->O, p->d_ocorn, p->d_ocen, p->d_oflags,
+                                  p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->d_range, p->d_hit_id, p->d_ring, p->d_obst_vis,
+                                  p->d_cls, p->d_occ_idx, p->d_n_occ, stream))) return rc;
+    if ((rc = fo_scene_spawn(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->ego_x, p->ego_y, p->head_x, p->head_y,
+                             p->min_ahead, p->max_dist, p->all_occluded, p->max_agents, p->routes, p->type4, p->speed4, p->raw_l4,
+                             p->raw_w4, p->infl_l4, p->infl_w4, p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor,
+                             p->d_cell, p->d_pos0, p->d_yaw0, p->d_n, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape,
+                             p->d_raw_dims, p->d_type, p->d_len, stream))) return rc;
+    if ((rc = fo_sweep_set_agents(ctx, slots, p->T_agents, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape, p->d_raw_dims, p->d_type,
+                                  p->d_len, stream))) return rc;
+  } else {
+    if (!p->d_pos || !p->d_yaw || !p->d_v || !p->d_cov || !p->d_shape || !p->d_raw_dims || !p->d_type || !p->d_len || slots < 1)
+      return fo_fail(ctx, FO_E_ARG, "fo_step_run: bad arguments");
+    fo_agent_table_t at;
+    if ((rc = fo_sweep_agents_begin_(ctx, slots, p->T_agents, stream, &at))) return rc;
+    if ((rc = fo_scene_step_(ctx, p, &at, stream))) return rc;
+  }
   return fo_sweep_run(ctx, p->M, p->T, p->d_x, p->d_y, p->d_theta, p->d_vel, p->d_acc, p->d_cost, p->d_safe, p->d_pair_f,
                       p->d_pair_i, p->d_lists, stream);
 }

@@ -28,6 +28,7 @@
 #include <atomic>
 #include <math.h>
 #include "fo_ctx.hpp"
+#include "fo_agent_rows.hpp"
 
 namespace {
 
@@ -80,6 +81,10 @@ struct Scene {
   uint8_t *d_flags = nullptr;     // [cells]
   int32_t *d_blk = nullptr;       // block counts / offsets
   size_t cap_cells = 0, cap_blk = 0;
+  uint8_t *d_flags2 = nullptr;    // the same pair for the candidate flags a fused step writes during the first compaction
+  int32_t *d_blk2 = nullptr;
+  size_t cap_cells2 = 0, cap_blk2 = 0;
+  bool cand_flags_ready = false;  // d_flags2 / d_blk2 hold this step's candidate flags (set by the fused visibility call)
   int32_t *d_cand = nullptr;      // candidate cell list
   int32_t *d_ncand = nullptr;
   int32_t *d_amb = nullptr;       // [cells] window indices of the cells the fan cannot decide
@@ -205,35 +210,54 @@ __device__ __forceinline__ void scan_soup(int E, const double *__restrict__ edge
 }
 
 // ------------------------------------------------------------------------------------------------ fan sector
-__device__ __forceinline__ int fan_ccw(int n_rays, const double *__restrict__ dirs, int i, double rx, double ry) {
-  const double *d = dirs + 2 * (size_t)(i == n_rays ? 0 : i);
-  const double c = d[0] * ry - d[1] * rx;
+// (DIR: where the unit direction of ray i comes from -- the table the fan kernel wrote, or, inside the launch that is
+// still writing that table, the fan's own arithmetic: FanDirs below)
+struct TableDirs {
+  const double *__restrict__ dirs;
+  __device__ __forceinline__ void get(int i, double &cx, double &cy) const { cx = dirs[2 * (size_t)i]; cy = dirs[2 * (size_t)i + 1]; }
+};
+template <class DIR>
+__device__ __forceinline__ int fan_ccw_t(int n_rays, const DIR &D, int i, double rx, double ry) {
+  double d0, d1;
+  D.get(i == n_rays ? 0 : i, d0, d1);
+  const double c = d0 * ry - d1 * rx;
   if (c > 0.0) return 1;
   if (c < 0.0) return 0;
-  return (d[0] * rx + d[1] * ry) > 0.0;
+  return (d0 * rx + d1 * ry) > 0.0;
 }
-__device__ int fan_search(int n_rays, const double *__restrict__ dirs, int a, int b, double rx, double ry) {
-  if (!fan_ccw(n_rays, dirs, a, rx, ry) || fan_ccw(n_rays, dirs, b, rx, ry)) return -1;
+template <class DIR>
+__device__ int fan_search_t(int n_rays, const DIR &D, int a, int b, double rx, double ry) {
+  if (!fan_ccw_t(n_rays, D, a, rx, ry) || fan_ccw_t(n_rays, D, b, rx, ry)) return -1;
   int lo = a, hi = b;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (fan_ccw(n_rays, dirs, mid, rx, ry)) lo = mid; else hi = mid;
+    if (fan_ccw_t(n_rays, D, mid, rx, ry)) lo = mid; else hi = mid;
   }
   return lo;
 }
-__device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full, double rx, double ry) {
+template <class DIR>
+__device__ int fan_sector_t(int n_rays, const DIR &D, int full, double rx, double ry) {
   if (full) {  // thirds: each part spans < pi for every n >= 4 (halves exceed pi by a ray pitch when n is odd)
     const int a = n_rays / 3, b = (2 * n_rays) / 3;
-    int s = fan_search(n_rays, dirs, 0, a, rx, ry);
+    int s = fan_search_t(n_rays, D, 0, a, rx, ry);
     if (s >= 0) return s;
-    s = fan_search(n_rays, dirs, a, b, rx, ry);
+    s = fan_search_t(n_rays, D, a, b, rx, ry);
     if (s >= 0) return s;
-    return fan_search(n_rays, dirs, b, n_rays, rx, ry);
+    return fan_search_t(n_rays, D, b, n_rays, rx, ry);
   }
   const int m = (n_rays - 1) / 2;
-  const int s = fan_search(n_rays, dirs, 0, m, rx, ry);
+  const int s = fan_search_t(n_rays, D, 0, m, rx, ry);
   if (s >= 0) return s;
-  return fan_search(n_rays, dirs, m, n_rays - 1, rx, ry);
+  return fan_search_t(n_rays, D, m, n_rays - 1, rx, ry);
+}
+__device__ __forceinline__ int fan_ccw(int n_rays, const double *__restrict__ dirs, int i, double rx, double ry) {
+  return fan_ccw_t(n_rays, TableDirs{dirs}, i, rx, ry);
+}
+__device__ int fan_search(int n_rays, const double *__restrict__ dirs, int a, int b, double rx, double ry) {
+  return fan_search_t(n_rays, TableDirs{dirs}, a, b, rx, ry);
+}
+__device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full, double rx, double ry) {
+  return fan_sector_t(n_rays, TableDirs{dirs}, full, rx, ry);
 }
 
 // ------------------------------------------------------------------------------------------------ ray fan
@@ -242,18 +266,10 @@ __device__ int fan_sector(int n_rays, const double *__restrict__ dirs, int full,
 // yaw - fov/2 to yaw + fov/2 inclusive (sensor_model.py:115-124).  rmax: range of the reference's polygonal footprint
 // along the ray -- regular 64-gon with a vertex at world angle 0 (Point.buffer(r)) or the 100-point fan of
 // _calc_relevant_sector (:201-209): r cos(d/2) / cos(rel mod d - d/2) with d the angular pitch of the arc points.
-__global__ void fo_fan_kernel(int n, double yaw, double fov, int full, double r, int polygon,
-                              double *__restrict__ dirs, double *__restrict__ rmax, double *__restrict__ half) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// ray i of the fan: unit direction and (want_rmax) the footprint range along it
+__device__ __forceinline__ void fan_ray(int i, int n, double yaw, double fov, int full, double r, int polygon, double &cs,
+                                        double &sn, double &rm) {
   const double two_pi = 6.283185307179586476925286766559;
-  if (half && i < 100) {  // unit directions of the 100-point half fan (radius 1.5 r) of sensor_model.py:85-87
-    const double a = i == 99 ? yaw + 0.25 * two_pi : yaw - 0.25 * two_pi + 0.5 * two_pi * (double)i / 99.0;
-    double sn, cs;
-    sincos(a, &sn, &cs);
-    half[2 * i] = cs;
-    half[2 * i + 1] = sn;
-  }
-  if (i >= n) return;
   double ang, rel, d;
   if (full) {
     ang = yaw + two_pi * (double)i / (double)n;
@@ -264,19 +280,51 @@ __global__ void fo_fan_kernel(int n, double yaw, double fov, int full, double r,
     ang = yaw - 0.5 * fov + rel;
     d = fov / 99.0;
   }
-  double sn, cs;
   sincos(ang, &sn, &cs);
-  dirs[2 * i] = cs;
-  dirs[2 * i + 1] = sn;
-  if (rmax) {
-    double v = r;
-    if (polygon) {
-      const double m = rel - d * floor(rel / d);
-      v = r * cos(0.5 * d) / cos(m - 0.5 * d);
-    }
-    rmax[i] = v;
+  rm = r;
+  if (polygon) {
+    const double m = rel - d * floor(rel / d);
+    rm = r * cos(0.5 * d) / cos(m - 0.5 * d);
   }
 }
+// unit direction i < 100 of the 100-point half fan (radius 1.5 r) of sensor_model.py:85-87
+__device__ __forceinline__ void fan_half_dir(int i, double yaw, double &cs, double &sn) {
+  const double two_pi = 6.283185307179586476925286766559;
+  const double a = i == 99 ? yaw + 0.25 * two_pi : yaw - 0.25 * two_pi + 0.5 * two_pi * (double)i / 99.0;
+  sincos(a, &sn, &cs);
+}
+__global__ void fo_fan_kernel(int n, double yaw, double fov, int full, double r, int polygon,
+                              double *__restrict__ dirs, double *__restrict__ rmax, double *__restrict__ half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (half && i < 100) {
+    double sn, cs;
+    fan_half_dir(i, yaw, cs, sn);
+    half[2 * i] = cs;
+    half[2 * i + 1] = sn;
+  }
+  if (i >= n) return;
+  double sn, cs, rm;
+  fan_ray(i, n, yaw, fov, full, r, polygon, cs, sn, rm);
+  dirs[2 * i] = cs;
+  dirs[2 * i + 1] = sn;
+  if (rmax) rmax[i] = rm;
+}
+// the fan computed inside the ray kernel (fo_step_run: one launch less): every ray workgroup works out its own direction
+// and range and leaves them where the later kernels of the step read them
+struct FanArgs {
+  int on = 0, full = 0, polygon = 0;
+  double yaw = 0, fov = 0;
+  double *dirs = nullptr, *rmax = nullptr, *half = nullptr;
+};
+struct FanDirs {   // the direction of ray i by the fan's arithmetic (bit-identical to the table entry)
+  int n;
+  double yaw, fov;
+  int full;
+  __device__ __forceinline__ void get(int i, double &cx, double &cy) const {
+    double rm;
+    fan_ray(i, n, yaw, fov, full, 1.0, 0, cx, cy, rm);
+  }
+};
 
 // Sector of a uniform full fan (ray i at angle yaw + 2 pi i / n, ray 0 = dirs[0]): a float atan2 of the direction
 // rotated back by ray 0 proposes the index, the exact predicate of fan_sector (ccw(i) and not ccw(i + 1)) confirms it
@@ -318,17 +366,35 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
                                                                  double *__restrict__ range,
                                                                  int32_t *__restrict__ hit_id, double *__restrict__ ring,
                                                                  int32_t *__restrict__ vis32,
-                                                                 int32_t *__restrict__ n_amb) {
+                                                                 int32_t *__restrict__ n_amb, FanArgs fan) {
   __shared__ double sh_t[RAY_WAVES];
   __shared__ int sh_id[RAY_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_amb) *n_amb = 0;  // list of undecided cells of this step (grid kernel)
   if ((int)blockIdx.x < n_rays) {
     const int i = blockIdx.x;
-    const double dx = dirs[2 * i], dy = dirs[2 * i + 1];
+    double dx, dy, rm;
+    if (fan.on) {   // (wave-uniform; the same arithmetic as fo_fan_kernel)
+      fan_ray(i, n_rays, fan.yaw, fan.fov, fan.full, r, fan.polygon, dx, dy, rm);
+      if (!fan.rmax) rm = r;
+      if (threadIdx.x == 0) {
+        fan.dirs[2 * i] = dx;
+        fan.dirs[2 * i + 1] = dy;
+        if (fan.rmax) fan.rmax[i] = rm;
+      }
+      if (fan.half && i == 0 && threadIdx.x < 100) {
+        double hs, hc;
+        fan_half_dir(threadIdx.x, fan.yaw, hc, hs);
+        fan.half[2 * threadIdx.x] = hc;
+        fan.half[2 * threadIdx.x + 1] = hs;
+      }
+    } else {
+      dx = dirs[2 * i];
+      dy = dirs[2 * i + 1];
+      rm = rmax ? rmax[i] : r;  // range of the sensor footprint along this ray
+    }
     double best = INFINITY;
     int id = 0x7fffffff;
-    const double rm = rmax ? rmax[i] : r;  // range of the sensor footprint along this ray
     scan_soup<SKIP>(E, edges, chunk_box, eskip, O, ocorn, oflags, wave, RAY_WAVES, lane, ex, ey, dx, dy, rm, -3, best, id);
     wave_min_hit(best, id);
     if (lane == 0) { sh_t[wave] = best; sh_id[wave] = id; }
@@ -361,7 +427,11 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
     if (threadIdx.x == 0) atomicOr(&vis32[o], 1);
     return;
   }
-  if (cand && fan_sector(n_rays, dirs, full, rx, ry) < 0) cand = false;
+  if (cand) {   // (in the fused launch the table of directions is still being written by the ray workgroups)
+    const int sec = fan.on ? fan_sector_t(n_rays, FanDirs{n_rays, fan.yaw, fan.fov, fan.full}, full, rx, ry)
+                           : fan_sector(n_rays, dirs, full, rx, ry);
+    if (sec < 0) cand = false;
+  }
   if (!cand) return;  // uniform over the workgroup
   const double dx = rx / dist, dy = ry / dist;
   double best = INFINITY;
@@ -863,11 +933,50 @@ __global__ __launch_bounds__(256) void fo_flag_scatter_kernel(const uint8_t *__r
   if (f) out[off + before] = idx;
 }
 
+// candidate cells of the phantom sampler: occluded, on the front towards the visible area (or anywhere when
+// all_occluded), ahead of the ego and within max_dist -- flags + per-block counts for the compaction that follows
+struct SpawnFlagArgs {
+  int on = 0;
+  const uint8_t *cls = nullptr;
+  int nx = 0, ny = 0, ix0 = 0, iy0 = 0, all_occluded = 0;
+  double rx0 = 0, ry0 = 0, cs = 0, ex = 0, ey = 0, hx = 0, hy = 0, min_ahead = 0, max_dist = 0;
+  uint8_t *flag = nullptr;
+  int32_t *blk = nullptr;
+};
+// (whole 256-thread block; wsum: four ints of LDS)
+__device__ __forceinline__ void spawn_flag_block(const SpawnFlagArgs &a, int *wsum) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool in = idx < a.nx * a.ny;
+  const int ix = in ? idx % a.nx : 0, iy = in ? idx / a.nx : 0;
+  const uint8_t *__restrict__ cls = a.cls;
+  uint8_t f = 0;
+  if (in && (cls[idx] & 4)) {
+    int front = a.all_occluded;
+    if (ix > 0 && (cls[idx - 1] & 2)) front = 1;
+    if (ix + 1 < a.nx && (cls[idx + 1] & 2)) front = 1;
+    if (iy > 0 && (cls[idx - a.nx] & 2)) front = 1;
+    if (iy + 1 < a.ny && (cls[idx + a.nx] & 2)) front = 1;
+    if (front) {
+      const double px = a.rx0 + ((double)(a.ix0 + ix) + 0.5) * a.cs, py = a.ry0 + ((double)(a.iy0 + iy) + 0.5) * a.cs;
+      const double rx = px - a.ex, ry = py - a.ey;
+      if (!(rx * a.hx + ry * a.hy < a.min_ahead) && !(rx * rx + ry * ry > a.max_dist * a.max_dist)) f = 1;
+    }
+  }
+  if (in) a.flag[idx] = f;
+  const unsigned long long b = __ballot(f != 0);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) a.blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 // One-launch variant for the usual window sizes (a few hundred blocks): every block sums the counts of the blocks
 // before it itself (a few hundred L2-resident ints) instead of waiting for a separate scan launch; same output.
+// sf.on (fo_step_run): the same launch also flags the phantom sampler's candidate cells for the compaction after this
+// one -- into buffers of their own, this compaction's flags and counts are still being read by other blocks.
 __global__ __launch_bounds__(256) void fo_flag_compact_kernel(const uint8_t *__restrict__ flags, int n,
                                                               const int32_t *__restrict__ cnt,
-                                                              int32_t *__restrict__ out, int32_t *__restrict__ total) {
+                                                              int32_t *__restrict__ out, int32_t *__restrict__ total,
+                                                              SpawnFlagArgs sf) {
   __shared__ int wsum[4], psum[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const bool f = idx < n && flags[idx];
@@ -884,35 +993,16 @@ __global__ __launch_bounds__(256) void fo_flag_compact_kernel(const uint8_t *__r
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = off + wsum[0] + wsum[1] + wsum[2] + wsum[3];
   for (int k = 0; k < w; ++k) off += wsum[k];
   if (f) out[off + before] = idx;
+  if (sf.on) {
+    __syncthreads();   // (wsum is used again)
+    spawn_flag_block(sf, wsum);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ spawn sampling
-__global__ void fo_spawn_flag_kernel(const uint8_t *__restrict__ cls, int nx, int ny, double rx0, double ry0, double cs,
-                                     int ix0, int iy0, double ex, double ey, double hx, double hy, double min_ahead,
-                                     double max_dist, int all_occluded, uint8_t *__restrict__ flag,
-                                     int32_t *__restrict__ blk) {
+__global__ __launch_bounds__(256) void fo_spawn_flag_kernel(SpawnFlagArgs a) {
   __shared__ int wsum[4];
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in = idx < nx * ny;
-  const int ix = in ? idx % nx : 0, iy = in ? idx / nx : 0;
-  uint8_t f = 0;
-  if (in && (cls[idx] & 4)) {
-    int front = all_occluded;
-    if (ix > 0 && (cls[idx - 1] & 2)) front = 1;
-    if (ix + 1 < nx && (cls[idx + 1] & 2)) front = 1;
-    if (iy > 0 && (cls[idx - nx] & 2)) front = 1;
-    if (iy + 1 < ny && (cls[idx + nx] & 2)) front = 1;
-    if (front) {
-      const double px = rx0 + ((double)(ix0 + ix) + 0.5) * cs, py = ry0 + ((double)(iy0 + iy) + 0.5) * cs;
-      const double rx = px - ex, ry = py - ey;
-      if (!(rx * hx + ry * hy < min_ahead) && !(rx * rx + ry * ry > max_dist * max_dist)) f = 1;
-    }
-  }
-  if (in) flag[idx] = f;
-  const unsigned long long b = __ballot(f != 0);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
-  __syncthreads();
-  if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  spawn_flag_block(a, wsum);
 }
 
 struct SpawnTypes {  // per pattern slot (j % 4): type code, speed, raw dims, inflated dims
@@ -991,7 +1081,8 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
     const int32_t *__restrict__ route_count, const double *__restrict__ route_xy, const double *__restrict__ route_s,
     int32_t *__restrict__ cell, double *__restrict__ pos0, double *__restrict__ yaw0, int32_t *__restrict__ n_out,
     double *__restrict__ pos, double *__restrict__ yaw, double *__restrict__ v, double *__restrict__ cov,
-    double *__restrict__ shape, double *__restrict__ raw, int32_t *__restrict__ type, int32_t *__restrict__ len) {
+    double *__restrict__ shape, double *__restrict__ raw, int32_t *__restrict__ type, int32_t *__restrict__ len,
+    int table_on, fo_agent_table_t at) {
   const int lane = threadIdx.x;
   const int slot = blockIdx.x, j = slot / R, r = slot % R;
   // the pick of agent j (repeated by each of its R route slots: a few dozen path segments; saves a launch)
@@ -1095,6 +1186,15 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
   for (int k = lane; k < T; k += 64)
     if (k >= L) { P[2 * k] = 0.0; P[2 * k + 1] = 0.0; Y[k] = 0.0; V[k] = 0.0; }
   if (lane == 0) len[slot] = L;
+  if (table_on) {
+    // fo_step_run: the rows of this slot in the sweep's agent table, written here instead of by a launch of
+    // fo_prep_agents_kernel (same function, same bits: fo_agent_rows.hpp)
+    __threadfence_block();
+    __syncthreads();
+    for (int k = lane; k < T; k += 64)
+      fo_agent_row(slot * T + k, T, pos, yaw, v, cov, shape, raw, type, len, at.ego_mass, at.hlA, at.hwA, at.hc, at.tab, at.cst,
+                   at.aint, at.status, at.gen);
+  }
 }
 
 int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
@@ -1112,13 +1212,18 @@ int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
 }
 
 // flags -> ascending indices (out) + count (d_total)
-int compact(fo_ctx *ctx, Scene *sc, const uint8_t *flags, int n, int32_t *out, int32_t *d_total, hipStream_t s) {
+// (sf: candidate flags of the phantom sampler in the same launch, fo_step_run; *sf_done says whether that happened)
+int compact(fo_ctx *ctx, Scene *sc, const uint8_t *flags, const int32_t *blk, int n, int32_t *out, int32_t *d_total,
+            hipStream_t s, const SpawnFlagArgs *sf = nullptr, bool *sf_done = nullptr) {
   const int nb = (n + 255) / 256;  // block counts were written by the kernel that produced the flags
+  if (sf_done) *sf_done = false;
   if (nb <= 2048) {
-    hipLaunchKernelGGL(fo_flag_compact_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk, out, d_total);
+    SpawnFlagArgs a;
+    if (sf) { a = *sf; if (sf_done) *sf_done = true; }
+    hipLaunchKernelGGL(fo_flag_compact_kernel, dim3(nb), dim3(256), 0, s, flags, n, blk, out, d_total, a);
   } else {
-    hipLaunchKernelGGL(fo_flag_scan_kernel, dim3(1), dim3(1024), 0, s, sc->d_blk, nb, d_total);
-    hipLaunchKernelGGL(fo_flag_scatter_kernel, dim3(nb), dim3(256), 0, s, flags, n, sc->d_blk, out);
+    hipLaunchKernelGGL(fo_flag_scan_kernel, dim3(1), dim3(1024), 0, s, const_cast<int32_t *>(blk), nb, d_total);
+    hipLaunchKernelGGL(fo_flag_scatter_kernel, dim3(nb), dim3(256), 0, s, flags, n, blk, out);
   }
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
@@ -1131,7 +1236,7 @@ extern "C" {
 void fo_scene_destroy_(fo_ctx *ctx) {
   if (!ctx || !ctx->scene) return;
   Scene *sc = (Scene *)ctx->scene;
-  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_rule_rec};
+  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_flags2, sc->d_blk2, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_rule_rec};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   map_release(sc->map);
@@ -1348,14 +1453,19 @@ int fo_scene_fan(fo_ctx *ctx, int n_rays, double ego_yaw, double fov_deg, double
   return FO_OK;
 }
 
-int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, double head_y, double r, int full_circle,
-                        int exact_cells, int n_rays, const double *d_dirs, const double *d_rmax, const double *d_half,
-                        const uint8_t *d_edge_skip, int O, const double *d_ocorn, const double *d_ocen,
-                        const uint8_t *d_oflags, int win_ix0, int win_iy0, int win_nx, int win_ny, double *d_range,
-                        int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
-                        int32_t *d_n_occ, void *stream) {
+// fo_scene_visibility; fan / sf (fo_step_run): the ray fan of fo_scene_fan inside the ray kernel, the candidate flags of
+// fo_scene_spawn inside the compaction -- two launches less, the same bits
+static int scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, double head_y, double r, int full_circle,
+                            int exact_cells, int n_rays, const double *d_dirs, const double *d_rmax, const double *d_half,
+                            const uint8_t *d_edge_skip, int O, const double *d_ocorn, const double *d_ocen,
+                            const uint8_t *d_oflags, int win_ix0, int win_iy0, int win_nx, int win_ny, double *d_range,
+                            int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
+                            int32_t *d_n_occ, void *stream, const FanArgs *fan_in, const SpawnFlagArgs *sf_in) {
   if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_visibility: call fo_scene_set_map first");
   Scene *sc = (Scene *)ctx->scene;
+  sc->cand_flags_ready = false;
+  FanArgs fan;
+  if (fan_in) fan = *fan_in;
   if (n_rays < 4 || !d_dirs || !d_range || !d_hit_id || O < 0 || (O > 0 && (!d_ocorn || !d_ocen || !d_oflags)) ||
       win_nx < 1 || win_ny < 1 || !d_cls || !d_occ_idx || !d_n_occ || !(r > 0))
     return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: bad arguments");
@@ -1374,11 +1484,11 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
   if (d_edge_skip)
     hipLaunchKernelGGL(fo_rays_kernel<true>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
-                       probes ? sc->d_vis32 : nullptr, sc->d_namb);
+                       probes ? sc->d_vis32 : nullptr, sc->d_namb, fan);
   else
     hipLaunchKernelGGL(fo_rays_kernel<false>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
-                       probes ? sc->d_vis32 : nullptr, sc->d_namb);
+                       probes ? sc->d_vis32 : nullptr, sc->d_namb, fan);
   hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->map->d_raster, sc->map->rnx, sc->map->rny, sc->map->x0,
                      sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
                      n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk, probes ? O : 0, sc->d_vis32,
@@ -1397,7 +1507,27 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
                          d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny);
   }
   FO_HIP_TRY(ctx, hipGetLastError());
-  return compact(ctx, sc, sc->d_flags, cells, d_occ_idx, d_n_occ, s);
+  if (sf_in) {
+    if ((rc = fo_reserve(ctx, &sc->d_flags2, &sc->cap_cells2, (size_t)cells))) return rc;
+    if ((rc = fo_reserve(ctx, &sc->d_blk2, &sc->cap_blk2, (size_t)(cells + 255) / 256 + 1))) return rc;
+    SpawnFlagArgs sf = *sf_in;
+    sf.on = 1; sf.cls = d_cls; sf.nx = win_nx; sf.ny = win_ny; sf.ix0 = win_ix0; sf.iy0 = win_iy0;
+    sf.rx0 = sc->map->x0; sf.ry0 = sc->map->y0; sf.cs = sc->map->cs; sf.ex = ego_x; sf.ey = ego_y; sf.hx = head_x; sf.hy = head_y;
+    sf.flag = sc->d_flags2; sf.blk = sc->d_blk2;
+    return compact(ctx, sc, sc->d_flags, sc->d_blk, cells, d_occ_idx, d_n_occ, s, &sf, &sc->cand_flags_ready);
+  }
+  return compact(ctx, sc, sc->d_flags, sc->d_blk, cells, d_occ_idx, d_n_occ, s);
+}
+
+int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, double head_y, double r, int full_circle,
+                        int exact_cells, int n_rays, const double *d_dirs, const double *d_rmax, const double *d_half,
+                        const uint8_t *d_edge_skip, int O, const double *d_ocorn, const double *d_ocen,
+                        const uint8_t *d_oflags, int win_ix0, int win_iy0, int win_nx, int win_ny, double *d_range,
+                        int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
+                        int32_t *d_n_occ, void *stream) {
+  return scene_visibility(ctx, ego_x, ego_y, head_x, head_y, r, full_circle, exact_cells, n_rays, d_dirs, d_rmax, d_half, d_edge_skip,
+                          O, d_ocorn, d_ocen, d_oflags, win_ix0, win_iy0, win_nx, win_ny, d_range, d_hit_id, d_ring, d_obst_vis,
+                          d_cls, d_occ_idx, d_n_occ, stream, nullptr, nullptr);
 }
 
 int fo_scene_future_visibility(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, int t_stride, int n_rays,
@@ -1419,13 +1549,15 @@ int fo_scene_future_visibility(fo_ctx *ctx, int M, int T, const double *d_x, con
   return FO_OK;
 }
 
-int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
+// fo_scene_spawn; at (fo_step_run): the prediction kernel also writes its slots' rows of the sweep's agent table, and the
+// candidate flags may already be there (scene_visibility with sf)
+static int scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
                    double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int all_occluded,
                    int max_agents, int routes, const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
                    const double *infl_l4, const double *infl_w4, int n_path, const double *d_path, int T, double dt,
                    double var0, double var_factor, int32_t *d_cell, double *d_pos0, double *d_yaw0, int32_t *d_n,
                    double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,
-                   int32_t *d_type, int32_t *d_len, void *stream) {
+                   int32_t *d_type, int32_t *d_len, void *stream, const fo_agent_table_t *at) {
   if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn: call fo_scene_set_map first");
   Scene *sc = (Scene *)ctx->scene;
   if (!d_cls || max_agents < 1 || !type4 || !speed4 || !raw_l4 || !raw_w4 || !infl_l4 || !infl_w4 || n_path < 2 ||
@@ -1440,10 +1572,17 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
   int rc;
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
   if ((rc = fo_reserve(ctx, &sc->d_cand, &sc->cap_cand, (size_t)cells))) return rc;
-  hipLaunchKernelGGL(fo_spawn_flag_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, d_cls, win_nx, win_ny, sc->map->x0,
-                     sc->map->y0, sc->map->cs, win_ix0, win_iy0, ego_x, ego_y, head_x, head_y, min_ahead, max_dist, all_occluded ? 1 : 0,
-                     sc->d_flags, sc->d_blk);
-  if ((rc = compact(ctx, sc, sc->d_flags, cells, sc->d_cand, sc->d_ncand, s))) return rc;
+  if (at && sc->cand_flags_ready) {   // flagged during the compaction of the visibility stage
+    sc->cand_flags_ready = false;
+    if ((rc = compact(ctx, sc, sc->d_flags2, sc->d_blk2, cells, sc->d_cand, sc->d_ncand, s))) return rc;
+  } else {
+    SpawnFlagArgs sf;
+    sf.on = 1; sf.cls = d_cls; sf.nx = win_nx; sf.ny = win_ny; sf.ix0 = win_ix0; sf.iy0 = win_iy0; sf.all_occluded = all_occluded ? 1 : 0;
+    sf.rx0 = sc->map->x0; sf.ry0 = sc->map->y0; sf.cs = sc->map->cs; sf.ex = ego_x; sf.ey = ego_y; sf.hx = head_x; sf.hy = head_y;
+    sf.min_ahead = min_ahead; sf.max_dist = max_dist; sf.flag = sc->d_flags; sf.blk = sc->d_blk;
+    hipLaunchKernelGGL(fo_spawn_flag_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sf);
+    if ((rc = compact(ctx, sc, sc->d_flags, sc->d_blk, cells, sc->d_cand, sc->d_ncand, s))) return rc;
+  }
   SpawnTypes st;
   for (int i = 0; i < 4; ++i) {
     st.type[i] = type4[i]; st.speed[i] = speed4[i]; st.raw_l[i] = raw_l4[i]; st.raw_w[i] = raw_w4[i];
@@ -1454,9 +1593,44 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
                      sc->map->x0, sc->map->y0, sc->map->cs, n_path, d_path, sc->map->d_lane_yaw, st, T, dt, var0, var_factor, win_nx, win_ix0,
                      win_iy0, sc->map->rnx, sc->map->rny, routes > 0 ? sc->map->d_lanelet_raster : nullptr, sc->map->R, sc->map->d_route_first,
                      sc->map->d_route_count, sc->map->d_route_xy, sc->map->d_route_s, d_cell, d_pos0, d_yaw0, d_n, d_pos, d_yaw, d_v,
-                     d_cov, d_shape, d_raw_dims, d_type, d_len);
+                     d_cov, d_shape, d_raw_dims, d_type, d_len, at ? 1 : 0, at ? *at : fo_agent_table_t());
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
+}
+
+int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, double ego_x,
+                   double ego_y, double head_x, double head_y, double min_ahead, double max_dist, int all_occluded,
+                   int max_agents, int routes, const int32_t *type4, const double *speed4, const double *raw_l4, const double *raw_w4,
+                   const double *infl_l4, const double *infl_w4, int n_path, const double *d_path, int T, double dt,
+                   double var0, double var_factor, int32_t *d_cell, double *d_pos0, double *d_yaw0, int32_t *d_n,
+                   double *d_pos, double *d_yaw, double *d_v, double *d_cov, double *d_shape, double *d_raw_dims,
+                   int32_t *d_type, int32_t *d_len, void *stream) {
+  return scene_spawn(ctx, d_cls, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, min_ahead, max_dist, all_occluded,
+                     max_agents, routes, type4, speed4, raw_l4, raw_w4, infl_l4, infl_w4, n_path, d_path, T, dt, var0, var_factor,
+                     d_cell, d_pos0, d_yaw0, d_n, d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len, stream, nullptr);
+}
+
+// the scene stages of a planning step in their fused form (fo_step_run, fo_api.hip): fan inside the ray kernel, candidate
+// flags inside the first compaction, the sweep's agent table written by the prediction kernel
+int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, void *stream) {
+  if (!ctx || !p) return FO_E_ARG;
+  if (p->n_rays < 4 || !p->d_dirs || !(p->r > 0) || !(p->fov_deg > 0)) return fo_fail(ctx, FO_E_ARG, "fo_scene_fan: bad arguments");
+  FanArgs fan;
+  fan.on = 1; fan.full = p->fov_deg >= 359.9; fan.polygon = p->polygon_footprint; fan.yaw = p->ego_yaw;
+  fan.fov = p->fov_deg * (3.14159265358979323846 / 180.0);
+  fan.dirs = p->d_dirs; fan.rmax = p->d_rmax; fan.half = p->d_half;
+  SpawnFlagArgs sf;
+  sf.all_occluded = p->all_occluded ? 1 : 0; sf.min_ahead = p->min_ahead; sf.max_dist = p->max_dist;
+  int rc;
+  if ((rc = scene_visibility(ctx, p->ego_x, p->ego_y, p->head_x, p->head_y, p->r, p->full_circle, p->exact_cells, p->n_rays, p->d_dirs,
+                             p->d_rmax, p->d_half, p->d_edge_skip, p->O, p->d_ocorn, p->d_ocen, p->d_oflags, p->win_ix0, p->win_iy0,
+                             p->win_nx, p->win_ny, p->d_range, p->d_hit_id, p->d_ring, p->d_obst_vis, p->d_cls, p->d_occ_idx,
+                             p->d_n_occ, stream, &fan, &sf))) return rc;
+  return scene_spawn(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->ego_x, p->ego_y, p->head_x, p->head_y,
+                     p->min_ahead, p->max_dist, p->all_occluded, p->max_agents, p->routes, p->type4, p->speed4, p->raw_l4,
+                     p->raw_w4, p->infl_l4, p->infl_w4, p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor,
+                     p->d_cell, p->d_pos0, p->d_yaw0, p->d_n, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape,
+                     p->d_raw_dims, p->d_type, p->d_len, stream, at);
 }
 
 int fo_scene_candidate_count(fo_ctx *ctx, int32_t *h_n, void *stream) {

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "fo_ctx.hpp"
+#include "fo_agent_rows.hpp"
 
 namespace {
 
@@ -36,10 +37,10 @@ constexpr int GL_TOTAL = 70;
 constexpr double GL_ASR0 = 0.5235987755982989, GL_ASR1 = 0.775397496610753, GL_ASR2 = 1.1197695149986342,
                  GL_ASR3 = 1.3252308092796046;
 typedef const double __attribute__((address_space(4))) *cdp_gl_t;
-constexpr int NAF = 12;    // agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, rho, asin rho
                            // (96-byte rows: the 32-byte and 16-byte groups the scalar loads fetch stay naturally aligned)
-constexpr int NAC = 16;    // per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type, sum of the
-                           // circumradii, far-gate radius^2, logistic slopes (ego, obstacle) and offsets, -, -
+// NAF = 12 agent fields per (k, t): px, py, cos, sin, yaw, v, 1/(sx*sqrt2), 1/(sy*sqrt2), v cos, v sin, rho, asin rho
+// NAC = 16 per-agent constants: hl_raw, hw_raw, half_len_infl, f_ego, f_obs, prot, len, type, sum of the circumradii,
+// far-gate radius^2, logistic slopes (ego, obstacle) and offsets, coarse gate radius, longest step (tagged) -- fo_agent_rows.hpp
 constexpr int NPS = 14;    // partial-reduction slots
 enum { PS_MIN_DCE = 0, PS_ARG_DCE, PS_MIN_TTC, PS_ARG_TTC, PS_MIN_TTCE, PS_MAX_ER, PS_MAX_OR, PS_ARG_OR, PS_MAX_EH,
        PS_MAX_OH, PS_MAX_CP, PS_MAX_HWC, PS_DCE_FLAG, PS_MAX_BTN };
@@ -258,30 +259,7 @@ __global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int tz,
   }
 }
 
-// obstacle mass / protection class by type (ref: harm_model.py:15-32,158-190)
-__device__ double fo_obstacle_mass(int type, double size) {
-  switch (type) {
-    case FO_TYPE_CAR: case FO_TYPE_PRIORITY_VEHICLE: case FO_TYPE_PARKED_VEHICLE: case FO_TYPE_TAXI:
-      return -1333.5 + 526.9 * pow(size, 0.8);
-    case FO_TYPE_TRUCK: return 25000.0;
-    case FO_TYPE_BUS: return 13000.0;
-    case FO_TYPE_BICYCLE: return 90.0;
-    case FO_TYPE_PEDESTRIAN: return 75.0;
-    case FO_TYPE_TRAIN: return 118800.0;
-    case FO_TYPE_MOTORCYCLE: return 250.0;
-    default: return 0.0;
-  }
-}
-__device__ int fo_obstacle_protection(int type) {
-  switch (type) {
-    case FO_TYPE_CAR: case FO_TYPE_TRUCK: case FO_TYPE_BUS: case FO_TYPE_PRIORITY_VEHICLE:
-    case FO_TYPE_PARKED_VEHICLE: case FO_TYPE_TRAIN: case FO_TYPE_TAXI: return 1;
-    case FO_TYPE_BICYCLE: case FO_TYPE_PEDESTRIAN: case FO_TYPE_MOTORCYCLE: case FO_TYPE_UNKNOWN: return 0;
-    default: return 2;
-  }
-}
-
-// agent predictions -> [A][Ta][NAF] table + [A][NAC] constants (one thread per (k, t))
+// agent predictions -> [A][Ta][NAF] table + [A][NAC] constants (one thread per (k, t); fo_agent_rows.hpp)
 __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ pos, const double *__restrict__ yaw,
                                       const double *__restrict__ v, const double *__restrict__ cov,
                                       const double *__restrict__ shape, const double *__restrict__ raw,
@@ -291,64 +269,7 @@ __global__ void fo_prep_agents_kernel(int A, int Ta, const double *__restrict__ 
                                       int32_t *__restrict__ aint, int *__restrict__ status, int gen) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A * Ta) return;
-  const int k = i / Ta, t = i % Ta;
-  // valid length clamped to the table: the sweep indexes rows with min(t, L-1) and assumes L <= Ta; a longer claim
-  // would read the next agent's rows
-  const int L = min(max(len[k], 0), Ta);
-  double sn, cs;
-  sincos(yaw[i], &sn, &cs);
-  double sxx = cov[4 * (size_t)i], sxy = cov[4 * (size_t)i + 1], syx = cov[4 * (size_t)i + 2], syy = cov[4 * (size_t)i + 3];
-  if (sxx == 0.0 && sxy == 0.0 && syx == 0.0 && syy == 0.0) { sxx = 0.1; syy = 0.1; }  // collision_probability.py:84-86
-  double isx = 1.0 / (sqrt(sxx) * M_SQRT2), isy = 1.0 / (sqrt(syy) * M_SQRT2);
-  double rho = 0.0;
-  if (sxy != 0.0 || syx != 0.0) {  // a covariance with correlation (real agents from a prediction module): the sweep
-    // integrates the bivariate normal over every box (fo_corr_corners; status[1] tells the sweep kernel which of its two
-    // bodies to run); a matrix that is no usable covariance -- asymmetric, not positive, |rho| > 0.99 -- poisons the
-    // row and raises status[0] (fo_sweep_check)
-    rho = 0.5 * (sxy + syx) / sqrt(sxx * syy);
-    if (!(sxx > 0.0) || !(syy > 0.0) || fabs(sxy - syx) > 1e-12 * sqrt(sxx * syy) || !(fabs(rho) <= 0.99)) {
-      if (t < L) atomicMax(status, gen);
-      isx = NAN;
-      isy = NAN;
-      rho = 0.0;
-    } else if (t < L) {
-      atomicMax(status + 1, gen);
-    }
-  }
-  double *o = tab + (size_t)i * NAF;
-  o[0] = pos[2 * (size_t)i]; o[1] = pos[2 * (size_t)i + 1]; o[2] = cs; o[3] = sn; o[4] = yaw[i]; o[5] = v[i];
-  const double vc = fmin(fmax(v[i], -5.0e3), 5.0e3);   // (see fo_prep_traj_kernel)
-  o[6] = isx; o[7] = isy; o[8] = vc * cs; o[9] = vc * sn; o[10] = rho; o[11] = asin(rho);
-  if (t == 0) {
-    const double m_obs = fo_obstacle_mass(type[k], shape[2 * k] * shape[2 * k + 1]);  // inflated footprint (Q8)
-    double *c = cst + (size_t)k * NAC;
-    c[0] = 0.5 * raw[2 * k]; c[1] = 0.5 * raw[2 * k + 1]; c[2] = shape[2 * k] / 2.0;
-    c[3] = m_obs / (ego_mass + m_obs); c[4] = ego_mass / (ego_mass + m_obs);
-    c[5] = (double)fo_obstacle_protection(type[k]); c[6] = (double)L; c[7] = (double)type[k];
-    // what every wave that takes this agent would otherwise recompute
-    c[8] = sqrt(hlA * hlA + hwA * hwA) + sqrt(c[0] * c[0] + c[1] * c[1]);   // circumradii: centre distance - c[8] <= distance
-    c[9] = (5.0 + c[2] + 1e-6) * (5.0 + c[2] + 1e-6);   // beyond 5 m + half the inflated length no mean is in the gate
-    const bool lr4s = fo_obstacle_protection(type[k]) == 1;
-    // logistic arguments as one fma of dv: the speed coefficient times the mass split is folded per agent
-    // (harm_model.py:96-97: ego_dv = m_obs/(m_ego+m_obs) dv, obs_dv = m_ego/(m_ego+m_obs) dv)
-    c[10] = lr4s ? -hc.lr4s_speed * c[3] : -hc.lr1s_speed * c[3];
-    c[11] = lr4s ? -hc.lr4s_speed * c[4] : -hc.ped_speed * c[4];
-    c[12] = -hc.lr1s_const;
-    c[13] = hc.ped_const;
-    // Coarse gate test of the sweep: the gate of sample t-1 takes the ego reference point of sample t against the agent
-    // mean of sample t-1; the sweep tests the distance it has anyway -- shifted ego centre t to agent mean t -- against
-    // 5 m + half the inflated length + the longest step of the agent's mean (+ the centre shift, added in the kernel):
-    // |e_t - p_(t-1)| <= |e_t - c_t| + |c_t - p_t| + |p_t - p_(t-1)|
-    double smax = 0.0;
-    for (int u = 1; u < L; ++u) {
-      const double sx_ = pos[2 * ((size_t)i + u)] - pos[2 * ((size_t)i + u - 1)], sy_ = pos[2 * ((size_t)i + u) + 1] - pos[2 * ((size_t)i + u - 1) + 1];
-      smax = fmax(smax, sqrt(sx_ * sx_ + sy_ * sy_));
-    }
-    c[14] = 5.0 + c[2] + 1e-6 + smax * (1.0 + 1e-12);
-    c[15] = 0.0;
-    aint[2 * k] = fo_obstacle_protection(type[k]);
-    aint[2 * k + 1] = L;
-  }
+  fo_agent_row(i, Ta, pos, yaw, v, cov, shape, raw, type, len, ego_mass, hlA, hwA, hc, tab, cst, aint, status, gen);
 }
 
 // The five per-timestep lists of hr.py:87-98 for sample index i = (k (T-1) + t) M + m, n = A (T-1) M entries per list
@@ -1003,7 +924,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     // coarse gate radius around the agent mean of the same sample, squared (fo_prep_agents_kernel, c[14]); wave-uniform
     double gate_far2;
     {
-      const double gf = (C[14] + fabs(a.wb)) * (1.0 + 1e-12);
+      const unsigned long long key = *(const __attribute__((address_space(4))) unsigned long long *)(C + 15);
+      const double smax = ((unsigned)(key >> 32) == (unsigned)a.gen) ? (double)__uint_as_float((unsigned)key) : 0.0;   // no key of this set: no step
+      const double gf = (C[14] + smax + fabs(a.wb)) * (1.0 + 1e-9);
       const double gf2 = gf * gf;
       gate_far2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(gf2)), __builtin_amdgcn_readfirstlane(__double2loint(gf2)));
     }
@@ -1975,7 +1898,11 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
   if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, chunks * NPS * Mp))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_chunk_tab, &ctx->cap_chunk_tab, 2 * (chunks + 1)))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, ((size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) + AGENT_PAD_ROWS) * NAF))) return rc;
-  if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(max_A > 0 ? max_A : 1) * NAC))) return rc;
+  {
+    const size_t cap0 = ctx->cap_agent_const;
+    if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(max_A > 0 ? max_A : 1) * NAC))) return rc;
+    if (ctx->cap_agent_const != cap0) FO_HIP_TRY(ctx, hipMemset(ctx->d_agent_const, 0, ctx->cap_agent_const * sizeof(double)));   // (generation-tagged slots, fo_prep_agents_kernel)
+  }
   if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(max_A > 0 ? max_A : 1) * 2))) return rc;
   return FO_OK;
 }
@@ -1987,6 +1914,37 @@ int fo_sweep_set_list_format(fo_ctx *ctx, int format) {
   return FO_OK;
 }
 
+// Book-keeping of a new agent set without the launch that fills it: buffers, sizes, generation tag.  `out` says where
+// the rows go -- fo_sweep_set_agents launches fo_prep_agents_kernel on it, the fused planning step (fo_step_run) hands it to
+// the phantom prediction kernel, which writes the rows of its own slots.
+int fo_sweep_agents_begin_(fo_ctx *ctx, int A, int Ta, void *stream, fo_agent_table_t *out) {
+  if (!ctx || !out) return FO_E_ARG;
+  if (!ctx->configured) return fo_fail(ctx, FO_E_STATE, "fo_sweep_set_agents: call fo_sweep_configure first");
+  if (A < 0 || (A > 0 && Ta < 1)) return fo_fail(ctx, FO_E_ARG, "fo_sweep_set_agents: bad arguments (A=%d Ta=%d)", A, Ta);
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  // (+ AGENT_PAD_ROWS spare rows: the sweep reads row t + 1 of an agent without clamping, up to the trajectory horizon)
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, ((size_t)(A > 0 ? A : 1) * Ta + AGENT_PAD_ROWS) * NAF))) return rc;
+  {
+    const size_t cap0 = ctx->cap_agent_const;
+    if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(A > 0 ? A : 1) * NAC))) return rc;
+    if (ctx->cap_agent_const != cap0) FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_agent_const, 0, ctx->cap_agent_const * sizeof(double), s));   // (generation-tagged slots, fo_agent_rows.hpp)
+  }
+  if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(A > 0 ? A : 1) * 2))) return rc;
+  ctx->A = A;
+  ctx->Ta = Ta;
+  if (ctx->status_gen >= (1 << 30)) {  // generations never run out in practice; start over cleanly if they do
+    FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, 2 * sizeof(int), s));
+    FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_agent_const, 0, ctx->cap_agent_const * sizeof(double), s));   // (the tagged slots as well)
+    ctx->status_gen = 0;
+  }
+  out->tab = ctx->d_agent_tab; out->cst = ctx->d_agent_const; out->aint = ctx->d_agent_int; out->status = ctx->d_status;
+  out->gen = ++ctx->status_gen;
+  out->ego_mass = ctx->veh.mass; out->hlA = 0.5 * ctx->veh.length; out->hwA = 0.5 * ctx->veh.width; out->hc = ctx->hc;
+  return FO_OK;
+}
+
 int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const double *d_yaw, const double *d_v,
                         const double *d_cov, const double *d_shape, const double *d_raw_dims, const int32_t *d_type,
                         const int32_t *d_len, void *stream) {
@@ -1994,26 +1952,13 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
   if (!ctx->configured) return fo_fail(ctx, FO_E_STATE, "fo_sweep_set_agents: call fo_sweep_configure first");
   if (A < 0 || (A > 0 && (Ta < 1 || !d_pos || !d_yaw || !d_v || !d_cov || !d_shape || !d_raw_dims || !d_type || !d_len)))
     return fo_fail(ctx, FO_E_ARG, "fo_sweep_set_agents: bad arguments (A=%d Ta=%d)", A, Ta);
-  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = (hipStream_t)stream;
+  fo_agent_table_t at;
   int rc;
-  // (+ AGENT_PAD_ROWS spare rows: the sweep reads row t + 1 of an agent without clamping, up to the trajectory horizon)
-  if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, ((size_t)(A > 0 ? A : 1) * Ta + AGENT_PAD_ROWS) * NAF))) return rc;
-  if ((rc = fo_reserve(ctx, &ctx->d_agent_const, &ctx->cap_agent_const, (size_t)(A > 0 ? A : 1) * NAC))) return rc;
-  if ((rc = fo_reserve(ctx, &ctx->d_agent_int, &ctx->cap_agent_int, (size_t)(A > 0 ? A : 1) * 2))) return rc;
-  ctx->A = A;
-  ctx->Ta = Ta;
-  if (ctx->status_gen >= (1 << 30)) {  // generations never run out in practice; start over cleanly if they do
-    FO_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, 2 * sizeof(int), s));
-    ctx->status_gen = 0;
-  }
-  const int gen = ++ctx->status_gen;
+  if ((rc = fo_sweep_agents_begin_(ctx, A, Ta, stream, &at))) return rc;
   if (A > 0) {
     const int n = A * Ta;
-    hipLaunchKernelGGL(fo_prep_agents_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, Ta, d_pos, d_yaw, d_v, d_cov,
-                       d_shape, d_raw_dims, d_type, d_len, ctx->veh.mass, 0.5 * ctx->veh.length, 0.5 * ctx->veh.width, ctx->hc,
-                       ctx->d_agent_tab, ctx->d_agent_const,
-                       ctx->d_agent_int, ctx->d_status, gen);
+    hipLaunchKernelGGL(fo_prep_agents_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, Ta, d_pos, d_yaw, d_v, d_cov,
+                       d_shape, d_raw_dims, d_type, d_len, at.ego_mass, at.hlA, at.hwA, at.hc, at.tab, at.cst, at.aint, at.status, at.gen);
     FO_HIP_TRY(ctx, hipGetLastError());
   }
   return FO_OK;

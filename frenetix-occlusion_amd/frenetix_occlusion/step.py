@@ -3,9 +3,10 @@
 
 ``PlanningStep`` binds a :class:`SensorModel`, a :class:`SpawnLocator`, a :class:`MetricSweep` (one ego, one context) and
 the candidate-trajectory tensors of a planning loop; :meth:`run` updates the handful of per-step scalars in a
-structure that was filled once and crosses the FFI once -- the same twelve kernel launches the stage-by-stage calls
-queue, without their five ctypes crossings (~90 converted arguments, ~90 us of host time per step; a step of the
-reference's own size needs ~60 us of GPU time).  Nothing is read back: the cost vectors and flags stay in HBM.
+structure that was filled once and crosses the FFI once -- the results of the stage-by-stage calls bit for bit, in nine
+kernel launches instead of their twelve and without their five ctypes crossings (~90 converted arguments, ~90 us of host
+time per step; a step of the reference's own size needs ~90 us of GPU time).  Nothing is read back: the cost vectors
+and flags stay in HBM.
 """
 import ctypes as C
 import math

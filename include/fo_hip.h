@@ -283,7 +283,10 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
  *      ~90 arguments cost the host more than the GPU needs for the step.  The structure is filled once (every pointer
  *      and size of a planning loop is stable); per step the caller updates the ego pose, the window origin and the
  *      spawn range.  NULL-able members are the NULL-able arguments of the single calls.  Stops at the first failing
- *      stage and returns its code. */
+ *      stage and returns its code.  Every output buffer ends up with the bits the five calls would have written; the
+ *      step itself runs in nine launches instead of twelve (the ray fan is worked out inside the ray kernel, the
+ *      sampler's candidate cells are flagged during the compaction of the occluded cells, the prediction kernel writes
+ *      its slots' rows of the sweep's agent table).  FO_STEP_STAGES=1 in the environment: the plain five calls. */
 typedef struct {
   /* fo_scene_fan */
   int32_t n_rays, polygon_footprint;
