@@ -925,7 +925,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     double gate_far2;
     {
       const unsigned long long key = *(const __attribute__((address_space(4))) unsigned long long *)(C + 15);
+      #ifdef FO_NO_SMAX   // (test-the-test builds: tests/test_sweep_gpu.py::test_gate_of_agents_that_jump_between_samples must fail)
+      const double smax = 0.0 * (double)(unsigned)key;
+#else
       const double smax = ((unsigned)(key >> 32) == (unsigned)a.gen) ? (double)__uint_as_float((unsigned)key) : 0.0;   // no key of this set: no step
+#endif
       const double gf = (C[14] + smax + fabs(a.wb)) * (1.0 + 1e-9);
       const double gf2 = gf * gf;
       gate_far2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(gf2)), __builtin_amdgcn_readfirstlane(__double2loint(gf2)));

@@ -427,6 +427,51 @@ def test_every_obstacle_type_and_many_agents(torch_cuda, oracle):
     _compare(oracle, ref, got)
 
 
+def test_gate_of_agents_that_jump_between_samples(torch_cuda, oracle, monkeypatch):
+    """The sweep's coarse gate test works on the distance ego centre t -> agent mean t, although the gate of sample t-1
+    pairs the ego with the agent mean of sample t-1: the agent's longest step is part of the coarse radius
+    (fo_agent_rows.hpp).  Agents whose mean jumps by up to 40 m from sample to sample -- into the gate and out of it
+    again -- must give the oracle's collision probabilities; both kernel variants, two agent sets in a row on ONE
+    context (the longest step sits in a generation-tagged slot that is never reset)."""
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sweep import DEFAULT_METRICS, MetricSweep
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    M, A, T = 200, 24, 31
+    traj = S.make_trajectories(M, T, 0.1, seed=3)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, metrics=DEFAULT_METRICS, ctx=N.Context(0))
+    for rnd in range(2):
+        agents = S.make_agents(A, T, 0.1, seed=40 + rnd, lateral=4.0)
+        pos = agents["pos"]
+        ex, ey = traj["x"], traj["y"]
+        for k in range(A):
+            kind = k % 4
+            if kind == 0:      # sits far away and visits an ego position for single samples
+                pos[k] = pos[k] + np.array([300.0, 0.0])
+                for t in rng.choice(np.arange(1, T - 1), 4, replace=False):
+                    m = int(rng.integers(M))
+                    pos[k, t] = (ex[m, min(t + 1, T - 1)] + rng.uniform(-2, 2), ey[m, min(t + 1, T - 1)] + rng.uniform(-2, 2))
+            elif kind == 1:    # random walk with steps of up to 40 m around the trajectories
+                c = np.array([ex[:, T // 2].mean(), ey[:, T // 2].mean()])
+                pos[k] = c + rng.uniform(-20, 20, (T, 2))
+            elif kind == 2 and rnd == 1:   # smaller steps than the set before: the old maximum must not survive
+                pos[k] = pos[k, :1] + 0.01 * np.arange(T)[:, None]
+        agents["len"] = rng.integers(2, T + 1, A).astype(np.int32)
+        ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, nthreads=8)
+        assert (ref["pair_f"][..., N.PF["max_collision_probability"]] > 0).any()
+        for split in ("0", "1"):
+            monkeypatch.setenv("FO_SWEEP_SPLIT", split)
+            sw.set_agents(agents["pos"], agents["yaw"], agents["v"], agents["cov"], agents["shape"], agents["raw_dims"],
+                          agents["type"], agents["len"])
+            out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj.get("a"), mode="full")
+            torch.cuda.synchronize()
+            got = {"cost": out.cost.cpu().numpy(), "safe": out.safe.cpu().numpy(),
+                   "pair_f": out.pair_f.permute(2, 1, 0).cpu().numpy(), "pair_i": out.pair_i.permute(2, 1, 0).cpu().numpy(),
+                   "lists": out.lists.permute(3, 1, 0, 2).cpu().numpy()}
+            _compare(oracle, ref, got)
+
+
 def test_dce_ties_stationary_and_random_geometry(torch_cuda, oracle):
     """the order-independent DCE scan (probe + lower-bound skips) must reproduce 'first strict minimum' exactly:
     stationary pairs (every timestep ties), symmetric pass-bys (two equal minima), touching rectangles, and a
