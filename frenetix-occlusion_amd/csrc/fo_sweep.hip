@@ -1295,7 +1295,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           // (last use of this sample's velocity above: the next row's takes its place.  The empty asm orders the load
           // behind the subtraction -- issued earlier it would need registers of its own and a copy)
           unsigned gb = __builtin_amdgcn_readfirstlane(goff);
+#if !FO_TRACE   // (the time-line build does without the ordering: its extra kernel argument upsets the uniformity analysis)
           asm volatile("" : "+v"(dvx), "+v"(dvy), "+s"(gb));
+#endif
           const cdp_t g2 = (cdp_t)((const __attribute__((address_space(4))) char *)G + gb);
           pvx = g2[8]; pvy = g2[9];
         }
@@ -1324,7 +1326,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           // loads return out of order, so the wait in front of these copies would otherwise cover the loads below
           px = npx; py = npy;
           unsigned gb = __builtin_amdgcn_readfirstlane(goff);
+#if !FO_TRACE
           asm volatile("" : "+s"(px), "+s"(py), "+s"(gb));
+#endif
           const cdp_t g2 = (cdp_t)((const __attribute__((address_space(4))) char *)G + gb);
           pc = g2[2]; ps = g2[3];
           if (lr4s) pyaw = g2[4];

@@ -32,3 +32,9 @@ print(f"first start spread {st[np.argsort(st)[:full]].max():.1f} us; time with >
       f"{sum(r >= 0.95 * full for r in res) / len(res):.2f} of the span; last 10 % of workgroups end after {np.percentile(en, 90):.1f} us")
 order = np.argsort(st)
 print("start of the i-th workgroup (us), every 256th:", np.round(st[order][::256], 1).tolist())
+# life time by workgroup position in the launch (chunk-major: the tapered phases come last)
+n = len(t)
+idx = np.arange(n)
+for lo, hi in ((0, int(0.5 * n)), (int(0.5 * n), int(0.8 * n)), (int(0.8 * n), int(0.9 * n)), (int(0.9 * n), n)):
+    sel = slice(lo, hi)
+    print(f"workgroups {lo}..{hi}: life mean {life[sel].mean():.1f} us  min {life[sel].min():.1f}  max {life[sel].max():.1f}  start mean {st[sel].mean():.1f}  end mean {en[sel].mean():.1f}")
