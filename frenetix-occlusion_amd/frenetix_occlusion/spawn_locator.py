@@ -235,9 +235,15 @@ class SpawnLocator:
                 yd[i] = (o.current_orientation, o.length, o.width)
                 t = str(o.obstacle_type).lower()
                 fl[i] = 1 | (2 if o.occludes else 0) | (4 if o.obstacle_role == "dynamic" else 0) | (8 if t in ("bicycle", "pedestrian") else 0)
-            d = torch.as_tensor(host).to(self.device)
-            ydev = d[:O * 24].view(torch.float64).view(O, 3)
-            d_yaw, d_dims, d_fl = ydev[:, 0].contiguous(), ydev[:, 1:3].contiguous(), d[O * 24:]
+            # (headings, dimensions and flags -- not the positions -- so the block rarely changes from step to step:
+            # uploaded only when it does)
+            key = host.tobytes()
+            if getattr(self, "_rule_obst_key", None) != key:
+                d = torch.as_tensor(host).to(self.device)
+                ydev = d[:O * 24].view(torch.float64).view(O, 3)
+                self._rule_obst_dev = (ydev[:, 0].contiguous(), ydev[:, 1:3].contiguous(), d[O * 24:])
+                self._rule_obst_key = key
+            d_yaw, d_dims, d_fl = self._rule_obst_dev
             d_vis = sm._buf["ovis"]
         else:
             d_yaw = d_dims = d_fl = d_vis = None
@@ -251,7 +257,12 @@ class SpawnLocator:
                       self._d_path6.data_ptr(), O, p(d_corn), p(d_cen), p(d_yaw), p(d_dims), p(d_fl), p(d_vis),
                       C.byref(pr), self.MAX_RULE_POINTS, self._rule_out.data_ptr(), self._rule_n.data_ptr(),
                       N.current_stream(self._dev_index))
-        h = self._rule_out.cpu().numpy()                                  # the one read-back of the rule path
+        # the one read-back of the rule path: into a pinned buffer, then wait for the stream
+        if getattr(self, "_rule_host", None) is None:
+            self._rule_host = torch.empty(self._rule_out.shape, dtype=self._rule_out.dtype).pin_memory()
+        self._rule_host.copy_(self._rule_out, non_blocking=True)
+        torch.cuda.current_stream(self._dev_index).synchronize()
+        h = self._rule_host.numpy()
         n = int(h[-1:].view(np.int32)[0])
         pts = []
         for q in h[:n * 8].reshape(n, 8):
