@@ -750,6 +750,11 @@ __device__ __forceinline__ double fo_vmin(double a, double b) {
   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ double fo_vmin_neg(double a, double b) {   // min(a, -b), the sign as a source modifier
+  double r;
+  asm("v_min_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // exp(z) = 2^(k/256) * e^r, k = rint(256 z / ln 2), |r| <= ln2/512: 256-entry table of 2^(j/256) in LDS (2 KB) and a
 // degree-3 polynomial (remainder r^4/24 < 1.5e-13 relative).  One-step argument reduction: ln2/256 cut to 43
@@ -1015,6 +1020,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     // are the logistic of the smallest argument -- 1/(1 + exp(nz)) falls with nz -- so the other samples keep a running
     // minimum of the two arguments and the logistic is taken once per pair.
     double nze_min = INFINITY, nzo_min = INFINITY;
+    // Without lists, for the agents of the two-coefficient models (pedestrian, LR1S: prot == 0) with the usual signs of
+    // the speed coefficients (both slopes <= 0): the smallest logistic argument belongs to the LARGEST relative speed,
+    // fma(k, dv, c) is monotonic in dv and so is its rounding -- pass 1 keeps the running maximum of dv (as -dv in
+    // nze_min, no new register) and pass 2 visits the gate rows only.  Wave-uniform.
+    const bool dvmax_mode = FO_DIET && LISTS == LST_NONE && prot == 0 && C[10] <= 0.0 && C[11] <= 0.0 && !(FO_X & 8);
     // List stores: the three blocks (cp | harm pairs | risk pairs) from per-agent scalar bases plus two running 32-bit
     // lane offsets (element size 1x and 2x) -- no 64-bit address arithmetic per sample (fo_sweep_run sends batches whose
     // (T-1) M pair elements pass 4 GB to the generic kernel)
@@ -1303,7 +1313,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         }
         if (geo && t < Lh && !(FO_X & 4)) {
 #if FO_DIET
-          dvw[(t - gbase) * TILE + lane] = fo_sqrt(fma(dvx, dvx, dvy * dvy));   // (<= 1e4: the prep kernels cap the speeds at 5e3 m/s)
+          const double dvv = fo_sqrt(fma(dvx, dvx, dvy * dvy));   // (<= 1e4: the prep kernels cap the speeds at 5e3 m/s)
+          dvw[(t - gbase) * TILE + lane] = dvv;
+          if (LISTS == LST_NONE && dvmax_mode) nze_min = fo_vmin_neg(nze_min, dvv);
 #else
           dvw[(t - gbase) * TILE + lane] = fmin(fo_sqrt(fma(dvx, dvx, dvy * dvy)), 1.0e4);
 #endif
@@ -1386,6 +1398,27 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           if (geo && Lh < g1s) hvrows = ~(~0u << max(Lh - gbase, 0));
           slow = __builtin_amdgcn_readfirstlane(slow | ~hvrows);
           hvrows = __builtin_amdgcn_readfirstlane(hvrows);
+          if (LISTS == LST_NONE && !LR4S && dvmax_mode) {
+            // only the rows that take the long way; the harm maxima come from the running maximum of dv (epilogue)
+            unsigned todo = slow & (~0u << (g0s - gbase)) & ~(~0u << (g1s - gbase));
+            while (todo) {
+              const int row = __builtin_ctz(todo), t = gbase + row;
+              todo &= todo - 1u;
+              const double dv = dvw[row * TILE + lane];
+              double cp = 0.0;
+              if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
+              if ((hvrows >> row) & 1u) {
+                const double eh = fo_logistic_neg<false>(exp_tab, fma(ke_, dv, ce_));
+                const double oh = fo_logistic_neg<false>(exp_tab, fma(ko_, dv, co_));
+                const double er = eh * cp, orr = oh * cp;
+                if (er > max_er || er != er) max_er = er;
+                if (orr > max_or) { max_or = orr; idx_or = t; }
+                if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
+              } else if (cp > max_cp) {
+                max_cp = cp; idx_cp = t; oh_at_cp = NAN;
+              }
+            }
+          } else
           for (int t = g0s; t < g1s; ++t) {
             const int row = t - gbase;
             const double dv = dvn, ze = zen, zo = zon;
@@ -1460,6 +1493,12 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         if (lr4s) pass2(std::true_type{}); else pass2(std::false_type{});
       }
     }
+    if (LISTS == LST_NONE && dvmax_mode) {
+      if (nze_min < INFINITY) {   // nze_min = -(largest relative speed)
+        max_eh = fo_vmax(max_eh, fo_logistic_neg<false>(exp_tab, fma(-hk[0], nze_min, hk[2])));
+        max_oh = fo_vmax(max_oh, fo_logistic_neg<false>(exp_tab, fma(-hk[1], nze_min, hk[3])));
+      }
+    } else
     if (LISTS != LST_F64 && nze_min < INFINITY) {   // (a wave whose samples carry no harm keeps -inf, as the lists path does)
       max_eh = fo_vmax(max_eh, fo_logistic_neg<false>(exp_tab, nze_min));
       max_oh = fo_vmax(max_oh, fo_logistic_neg<false>(exp_tab, nzo_min));
