@@ -1647,8 +1647,19 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   __shared__ unsigned short queue_all[QWAVES * QCAP];
   __shared__ int next_agent;   // FO_DYN: agents of the chunk handed out so far
   if (threadIdx.x == 0) next_agent = 0;
-  for (int i = threadIdx.x; i < ERF_N; i += TILE * QWAVES) erf_tab[i] = a.erf_tab[i];
-  for (int i = threadIdx.x; i < EXP_N; i += TILE * QWAVES) exp_tab[i] = a.exp_tab[i];
+  {
+    // The two tables into LDS.  All of a thread's loads are issued before the first store (written as a loop the copy
+    // compiles to five dependent round trips: load, wait, store, ...).  (A build WITHOUT the copy is no measure of its
+    // cost: the compiler then knows the tables are never written and deletes the code that reads them.)
+    static_assert(TILE * QWAVES == 256 && EXP_N == 256 && ERF_N > 768 && ERF_N <= 1024, "table copy written for 256 threads");
+    const int tt = threadIdx.x;
+    const double2 v0 = a.erf_tab[tt], v1 = a.erf_tab[tt + 256], v2 = a.erf_tab[tt + 512];
+    const double2 v3 = a.erf_tab[min(tt + 768, ERF_N - 1)];
+    const double x0 = a.exp_tab[tt];
+    erf_tab[tt] = v0; erf_tab[tt + 256] = v1; erf_tab[tt + 512] = v2;
+    if (tt + 768 < ERF_N) erf_tab[tt + 768] = v3;
+    exp_tab[tt] = x0;
+  }
   if (threadIdx.x < 4)
     zc_tab[threadIdx.x] = -a.hc.lr4s_const - (threadIdx.x == 0 ? 0.0 : threadIdx.x == 1 ? a.hc.lr4s_side : a.hc.lr4s_rear);
   // (FO_X & 128: register / timing experiments without the second body -- WRONG results for correlated covariances)
@@ -1663,6 +1674,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   }
 #endif
   __syncthreads();
+#if FO_TRACE
+  if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 3] = wall_clock64();   // tables in LDS
+#endif
   if (__builtin_expect(!corr, 1))
     fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all, &next_agent);
   else

@@ -38,3 +38,8 @@ idx = np.arange(n)
 for lo, hi in ((0, int(0.5 * n)), (int(0.5 * n), int(0.8 * n)), (int(0.8 * n), int(0.9 * n)), (int(0.9 * n), n)):
     sel = slice(lo, hi)
     print(f"workgroups {lo}..{hi}: life mean {life[sel].mean():.1f} us  min {life[sel].min():.1f}  max {life[sel].max():.1f}  start mean {st[sel].mean():.1f}  end mean {en[sel].mean():.1f}")
+fill = (t[:, 3] - t[:, 0]) * 0.01
+ok = t[:, 3] > 0
+if ok.any():
+    print(f"start -> tables in LDS (us): mean {fill[ok].mean():.2f}  p50 {np.percentile(fill[ok], 50):.2f}  p95 {np.percentile(fill[ok], 95):.2f}  max {fill[ok].max():.2f}; "
+          f"first 756 workgroups mean {fill[ok][:756].mean():.2f}, the rest {fill[ok][756:].mean():.2f}")
