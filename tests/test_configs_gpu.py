@@ -199,10 +199,13 @@ def test_config3_headline_step_full_outputs_vs_oracle_on_every_pair(torch_cuda, 
     assert 0.0 < float(out.safe.double().mean()) < 1.0
 
 
-def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda):
-    """fo_step_run / PlanningStep (one FFI crossing per planning step) queues the same kernels as the five stage calls:
-    cost vectors, flags, phantom set and cell classes bit-identical, over several ego poses (window origin, spawn range and
-    heading change from step to step)"""
+@pytest.mark.parametrize("routes,footprint", [(0, "polygon"), (2, "circle")])
+def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda, routes, footprint):
+    """fo_step_run / PlanningStep (one FFI crossing per planning step, nine launches: the fan inside the ray kernel, the
+    candidate flags inside the first compaction, the agent table written by the prediction kernel) gives the bits of the
+    five stage calls: cost vectors, flags, pair scalars, phantom set and cell classes, over several ego poses (window
+    origin, spawn range and heading change from step to step); with and without route predictions (R slots per
+    phantom), polygonal and circular sensor footprint (range and half-fan tables written or not)"""
     import yaml
     torch = torch_cuda
     from frenetix_occlusion import _native as N
@@ -218,16 +221,20 @@ def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda):
     ego0 = sc.ego_initial
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
-    cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True)
+    cfg["accelerator"]["spawn"].update(max_agents=A // max(routes, 1), all_occluded=True, routes=routes)
+    if routes:
+        cfg["accelerator"]["spawn"]["pattern"] = ["Car", "Bicycle", "Pedestrian", "Car"]
     yaw0 = float(ego0[2])
     ref = ego0[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw0), math.sin(yaw0)]])
     traj = S.make_trajectories(M, T, 0.1, seed=5, ego_pos=ego0[:2], ego_yaw=yaw0)
     results = {}
     for how in ("stages", "one-call"):
         ctx = N.Context(0)
-        sm = SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx)
+        sm = SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx,
+                         routes=routes, footprint=footprint)
         sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
         sl = SpawnLocator(None, ref, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
+        assert sl.R == max(routes, 1)
         sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, ctx=ctx)
         tr = [torch.as_tensor(traj[k]).cuda() for k in ("x", "y", "theta", "v", "a")]
         ps = PlanningStep(sm, sl, sw, *tr, mode="pair") if how == "one-call" else None
