@@ -48,6 +48,12 @@ __global__ void k(double *out, unsigned long long *cyc, double seed) {
     if (OP == 19) { I8(asm volatile("s_add_u32 s6, s6, 1\n s_add_u32 s7, s7, 1" ::: "s6", "s7", "scc")) }
     if (OP == 20) { R8(asm volatile("v_fma_f64 %0, %0, %1, %2\n s_add_u32 s6, s6, 1\n s_add_u32 s7, s7, 1\n s_add_u32 s8, s8, 1" : "+v"(x) : "v"(m), "v"(c) : "s6", "s7", "s8", "scc")) }
     if (OP == 21) { F8(asm volatile("v_fma_f32 %0, %0, %0, %0\n s_add_u32 s6, s6, 1" : "+v"(x) :: "s6", "scc")) }
+    // v_cndmask variants (round 3: the plain form above measured 14 cycles -- which part of it?)
+    if (OP == 22) { I8(asm volatile("v_cndmask_b32 %0, %1, %0, vcc" : "+v"(x) : "v"(i7))) }
+    if (OP == 23) { I8(asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[4:5]" : "+v"(x) : "v"(i7) : "s4", "s5")) }
+    if (OP == 24) { I8(asm volatile("v_cmp_lt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(i7) : "vcc")) }
+    if (OP == 25) { R8(asm volatile("v_cmp_lt_f64 vcc, %0, %2\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(x), "+v"(i0) : "v"(c), "v"(i7) : "vcc")) }
+    if (OP == 26) { I8(asm volatile("v_max_i32 %0, %0, %1" : "+v"(x) : "v"(i7))) }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
@@ -86,6 +92,8 @@ int main() {
     run<4>("v_rcp_f64", w); run<5>("v_rsq_f64", w); run<14>("v_sqrt_f64", w); run<6>("v_ldexp_f64", w); run<7>("v_rndne_f64", w);
     run<13>("v_cvt_i32_f64", w); run<8>("v_fma_f32", w); run<9>("v_add_u32", w); run<10>("v_cndmask_b32", w);
     run<15>("v_readlane+writelane", w);
+    run<22>("v_cndmask vcc, distinct src", w); run<23>("v_cndmask_e64 sgpr mask", w); run<24>("v_cmp_i32 + v_cndmask (group)", w);
+    run<25>("v_cmp_f64 + v_cndmask (group)", w); run<26>("v_max_i32", w);
   }
   return 0;
 }
