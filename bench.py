@@ -364,6 +364,8 @@ def main():
                          "weak: --M trajectories per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the oracle parity check")
     ap.add_argument("--no-autotune", action="store_true", help="skip the agents-per-wave selection pass of the set-up")
+    ap.add_argument("--entry", default="step", choices=["step", "stages"],
+                    help="scene-based runs: the planning step through fo_step_run (one native call, nine launches) or as the five stage calls")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other output modes, configs[1])")
     ap.add_argument("--order", default="sampler", choices=["sampler", "random"],
                     help="row order of the synthetic trajectories (synthetic.make_trajectories)")
@@ -449,11 +451,21 @@ def main():
         sm.launch(ego[:2], float(ego[2]))
         return sl.sample(ego[:2], float(ego[2]), float(ego[3])).sweep_args()
 
+    planning_steps = {}   # --entry step: one PlanningStep (fo_step_run: the whole step in one native call) per output mode
+
     def step(mode=args.mode, lists=args.lists, res=None, gather=True):
-        a_args = scene_stage() if scene is not None else ag
-        sw.set_agents(*a_args, check=False)
-        if M > 0:
-            res = sw.run(tx, ty, tth, tv, ta, mode=mode, out=res, lists=lists)
+        if scene is not None and args.entry == "step" and M > 0:
+            ps = planning_steps.get((mode, lists))
+            if ps is None:
+                from frenetix_occlusion.step import PlanningStep
+                ps = planning_steps[(mode, lists)] = PlanningStep(scene["sm"], scene["sl"], sw, tx, ty, tth, tv, ta, mode=mode, lists=lists)
+            ego = scene["ego"]
+            res = ps.run(ego[:2], float(ego[2]), float(ego[3]))
+        else:
+            a_args = scene_stage() if scene is not None else ag
+            sw.set_agents(*a_args, check=False)
+            if M > 0:
+                res = sw.run(tx, ty, tth, tv, ta, mode=mode, out=res, lists=lists)
         if use_dist and gather:
             if M == per and M > 0:
                 dist.all_gather_into_tensor(gathered, res.cost)
@@ -571,6 +583,8 @@ def main():
                                     "metric set, T=31 (full planning step)") if args.scene == "scenario1" else
                                    "sweep only: 10k synthetic trajectories x 256 synthetic phantom predictions, T=31",
                        "M_total": M_job, "M_per_gpu": M, "A": A, "A_active": n_active, "T": T, "output_mode": args.mode,
+                       "entry": ("fo_step_run (PlanningStep: one native call per planning step)" if scene is not None and args.entry == "step"
+                                 else "stage calls"),
                        "list_storage": (args.lists + (" (harm entries away from the 5 m gate evaluated in float32; every cost, "
                                                      "flag and pair scalar float64)" if args.lists == "f32" else ""))
                        if args.mode == "full" else None,
