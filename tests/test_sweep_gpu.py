@@ -472,6 +472,44 @@ def test_gate_of_agents_that_jump_between_samples(torch_cuda, oracle, monkeypatc
             _compare(oracle, ref, got)
 
 
+def test_harm_maxima_with_unusual_coefficient_signs(torch_cuda, oracle):
+    """Without lists the harm maxima of the two-coefficient models come from the largest relative speed of a pair --
+    valid while both speed coefficients are positive (the logistic argument then falls with the relative speed); with
+    a negative coefficient the kernel must take the per-sample route again.  Reduced / pair / full outputs against the
+    oracle and against each other for the usual signs, one negative and both negative."""
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sweep import DEFAULT_HARM_COEFF, DEFAULT_METRICS, MetricSweep
+    torch = torch_cuda
+    traj, agents = S.make_batch(200, 12, config_id=7)
+    agents["type"] = np.array([4, 3, 0, 4, 3, 4, 4, 3, 3, 4, 0, 4], dtype=np.int32)   # pedestrians, bicycles, two cars
+    for flip in ((), ("lr1s_speed",), ("lr1s_speed", "ped_speed")):
+        hc = dict(DEFAULT_HARM_COEFF)
+        for k in flip:
+            hc[k] = -hc[k]
+        ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, harm_coeff=hc, nthreads=8)
+        res = {}
+        for mode in ("full", "pair", "reduced"):
+            sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, metrics=DEFAULT_METRICS, harm_coeff=hc)
+            sw.set_agents(agents["pos"], agents["yaw"], agents["v"], agents["cov"], agents["shape"], agents["raw_dims"],
+                          agents["type"], agents["len"])
+            out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj.get("a"), mode=mode)
+            torch.cuda.synchronize()
+            got = {"cost": out.cost.cpu().numpy(), "safe": out.safe.cpu().numpy()}
+            if mode != "reduced":
+                got["pair_f"] = out.pair_f.permute(2, 1, 0).cpu().numpy()
+                got["pair_i"] = out.pair_i.permute(2, 1, 0).cpu().numpy()
+            if mode == "full":
+                got["lists"] = out.lists.permute(3, 1, 0, 2).cpu().numpy()
+                _compare(oracle, ref, got)
+            res[mode] = got
+        # the modes without lists (where the shortcut lives) give the bits of the full mode
+        for mode in ("pair", "reduced"):
+            assert np.array_equal(res[mode]["cost"], res["full"]["cost"], equal_nan=True), (flip, mode)
+            assert np.array_equal(res[mode]["safe"], res["full"]["safe"]), (flip, mode)
+        assert np.array_equal(res["pair"]["pair_f"], res["full"]["pair_f"], equal_nan=True), flip
+        assert np.array_equal(res["pair"]["pair_i"], res["full"]["pair_i"]), flip
+
+
 def test_dce_ties_stationary_and_random_geometry(torch_cuda, oracle):
     """the order-independent DCE scan (probe + lower-bound skips) must reproduce 'first strict minimum' exactly:
     stationary pairs (every timestep ties), symmetric pass-bys (two equal minima), touching rectangles, and a
