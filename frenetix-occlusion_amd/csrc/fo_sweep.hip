@@ -1175,6 +1175,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       const bool dce_on = do_dce && !(ablate & 1) && !(FO_X & 32), gate_on = do_cp && !(ablate & 2) && !(FO_X & 64);
       const int rng_n = (dce_on || gate_on) ? max(L - t0, 0) : 0;
       const double gate_far2c = gate_on ? gate_far2 : -1.0;   // (no distance is below -1: the test never passes)
+      // sample 0 has no gate (there is no sample -1): the radius of the chunk's first sample is -1 there, the loop sets
+      // the real one from its second sample on -- cheaper than a test of t per sample
+      double gate_far2t = (tl == 0) ? -1.0 : gate_far2c;
       if (!dce_on) thrR2 = -1.0;
       const bool geo = do_hr && !(ablate & 4);
       if (!FO_CARRY || SPLIT || t0 == seg0) {
@@ -1261,8 +1264,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t.  The two
           // displaced means are hdev away from the mean: beyond 5 m + hdev none of the three can be in the gate, and the
           // mean of sample t-1 is at most the agent's longest step from the one of sample t (gate_far2)
-          // (sample 0 has no gate: sorted out on the rare side of the branch)
-          if (__ballot(dd <= gate_far2c)) if (t >= 1) {
+          if (__ballot(dd <= gate_far2t)) {
             // (scalar loads on the rare path; the row was read a sample ago)
             const cdp_t gq = (cdp_t)((const __attribute__((address_space(4))) char *)G + (goff - 2u * (unsigned)(NAF * sizeof(double))));
             const double rx = ex - gq[0], ry = ey - gq[1];
@@ -1345,6 +1347,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           pc = g2[2]; ps = g2[3];
           if (lr4s) pyaw = g2[4];
         }
+        gate_far2t = gate_far2c;
       }
       if (qn > 0) process(qn);
       wgate = __builtin_amdgcn_readfirstlane(wgate);  // uniform by construction; says so to the register allocator
