@@ -1217,8 +1217,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           const double ccx = ex + a.wb * ec, ccy = ey + a.wb * es;  // convert_dynamic_obstacle.py:73
           const double dx = px - ccx, dy = py - ccy;
           const double dd = dx * dx + dy * dy;   // shared by the DCE and the gate: both start from a coarse distance test
-          // nothing to gain after the (earliest) zero; otherwise the centres must be close enough
-          const bool near = !(dce == 0.0 && t > tdce) && (dd < thrR2);
+          // the centres must be close enough.  (Nothing is to be gained after the earliest zero: the block below sets
+          // thrR2 to -1 at the sample that holds it -- a zero found here, or the probe's, whose sample always passes this
+          // test: overlapping rectangles have their centres within the sum of the circumradii -- so that one comparison
+          // per sample serves both conditions.)
+          const bool near = dd < thrR2;
           if (__ballot(near)) {
             const double cr = pc * ec + ps * es, sr = ps * ec - pc * es;
             const double ax = ec * dx + es * dy, ay = ec * dy - es * dx;   // agent centre in the ego frame
@@ -1260,6 +1263,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 thrR2 = (thr + Rsum) * (thr + Rsum);
               }
             }
+            if (near && dce == 0.0 && t >= tdce) thrR2 = -1.0;   // the earliest zero is in: no later sample can beat it
           }
           // gate of sample t-1 (collision_probability.py:44-67,75): ego sample t, agent mean t-1, agent heading t.  The two
           // displaced means are hdev away from the mean: beyond 5 m + hdev none of the three can be in the gate, and the
