@@ -106,7 +106,10 @@ int fo_step_run(fo_ctx *ctx, const fo_step_t *p, void *stream) {
       return fo_fail(ctx, FO_E_ARG, "fo_step_run: bad arguments");
     fo_agent_table_t at;
     if ((rc = fo_sweep_agents_begin_(ctx, slots, p->T_agents, stream, &at))) return rc;
-    if ((rc = fo_scene_step_(ctx, p, &at, stream))) return rc;
+    if ((rc = fo_scene_step_(ctx, p, &at, stream))) {
+      ctx->A = 0;   // the agent set was announced but not written: a sweep after this failure evaluates no agents
+      return rc;
+    }
   }
   return fo_sweep_run(ctx, p->M, p->T, p->d_x, p->d_y, p->d_theta, p->d_vel, p->d_acc, p->d_cost, p->d_safe, p->d_pair_f,
                       p->d_pair_i, p->d_lists, stream);

@@ -199,6 +199,46 @@ def test_config3_headline_step_full_outputs_vs_oracle_on_every_pair(torch_cuda, 
     assert 0.0 < float(out.safe.double().mean()) < 1.0
 
 
+def test_failed_planning_step_leaves_no_half_written_agent_set(torch_cuda):
+    """fo_step_run announces the agent set to the sweep before the scene kernels write it (the prediction kernel fills the
+    table); when the scene stage fails, a sweep that follows must not read that table: it evaluates no agents."""
+    import yaml
+    torch = torch_cuda
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as SC
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.step import PlanningStep
+    from frenetix_occlusion.sweep import MetricSweep
+    M, A, T = 300, 8, 31
+    sc = SC.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True)
+    yaw0 = float(ego0[2])
+    ref = ego0[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw0), math.sin(yaw0)]])
+    traj = S.make_trajectories(M, T, 0.1, seed=5, ego_pos=ego0[:2], ego_yaw=yaw0)
+    ctx = N.Context(0)
+    sm = SensorModel(sc.lanelets, ref, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx)
+    sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
+    sl = SpawnLocator(None, ref, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1}, ctx=ctx)
+    tr = [torch.as_tensor(traj[k]).cuda() for k in ("x", "y", "theta", "v", "a")]
+    ps = PlanningStep(sm, sl, sw, *tr, mode="reduced")
+    out = ps.run(ego0[:2], yaw0, 5.0)
+    torch.cuda.synchronize()
+    assert int(sl.batch.n.item()) > 0 and not bool(out.safe.bool().all())     # phantoms, and some candidate is unsafe
+    ps._s.n_path = 1                                                             # fo_scene_spawn rejects a one-point path
+    with pytest.raises(RuntimeError):
+        ps.run(ego0[:2], yaw0, 5.0)
+    res = sw.run(*tr, mode="reduced")
+    torch.cuda.synchronize()
+    assert bool(res.safe.bool().all())                                           # no agents evaluated
+
+
 @pytest.mark.parametrize("routes,footprint", [(0, "polygon"), (2, "circle")])
 def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda, routes, footprint):
     """fo_step_run / PlanningStep (one FFI crossing per planning step, nine launches: the fan inside the ray kernel, the
