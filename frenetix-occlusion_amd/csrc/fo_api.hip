@@ -78,32 +78,52 @@ int fo_sweep_check(fo_ctx *ctx, void *stream) {
   return FO_OK;
 }
 
-// One planning step on one stream (include/fo_hip.h, fo_step_t): the results of the five stage calls fo_scene_fan ->
-// fo_scene_visibility -> fo_scene_spawn -> fo_sweep_set_agents -> fo_sweep_run, bit for bit, in three launches less -- the
-// ray fan is worked out inside the ray kernel, the sampler's candidate cells are flagged inside the compaction of the
-// occluded cells, and the phantom prediction kernel writes its slots' rows of the sweep's agent table itself.
+// One planning step on one stream (include/fo_hip.h, fo_step_t): the results of the stage calls fo_scene_fan ->
+// fo_scene_visibility -> fo_scene_spawn [-> fo_scene_spawn_rules -> fo_scene_spawn_rule_agents] -> fo_sweep_set_agents ->
+// fo_sweep_run, bit for bit, in three launches less -- the ray fan is worked out inside the ray kernel, the sampler's
+// candidate cells are flagged inside the compaction of the occluded cells, and the phantom prediction kernels write their
+// slots' rows of the sweep's agent table themselves.
 // (FO_STEP_STAGES=1 in the environment: the plain sequence of stage calls, for A/B runs.)
 int fo_step_run(fo_ctx *ctx, const fo_step_t *p, void *stream) {
   if (!ctx || !p) return fo_fail(ctx, FO_E_ARG, "fo_step_run: null argument");
   int rc;
   static const bool stages = [] { const char *e = getenv("FO_STEP_STAGES"); return e && e[0] == '1'; }();
-  const int slots = p->max_agents * (p->routes > 0 ? p->routes : 1);
+  if (p->spawn_mode != FO_SPAWN_CELLS && p->spawn_mode != FO_SPAWN_RULES && p->spawn_mode != FO_SPAWN_BOTH)
+    return fo_fail(ctx, FO_E_ARG, "fo_step_run: unknown spawn_mode %d", p->spawn_mode);
+  const bool cells = p->spawn_mode != FO_SPAWN_RULES, rules = p->spawn_mode != FO_SPAWN_CELLS;
+  const int R = p->routes > 0 ? p->routes : 1;
+  const int cell_agents = cells ? p->max_agents : 0, rule_points = rules ? p->max_rule_points : 0;
+  const int slots = (cell_agents + rule_points) * R, slot0 = cell_agents * R;
+  if (!p->d_pos || !p->d_yaw || !p->d_v || !p->d_cov || !p->d_shape || !p->d_raw_dims || !p->d_type || !p->d_len || slots < 1 ||
+      (cells && p->max_agents < 1) || p->T_agents < 1 ||
+      (rules && (p->max_rule_points < 1 || !p->d_rule_points || !p->d_n_rule_points || !p->d_path6 || !p->d_pos0 || !p->d_yaw0)))
+    return fo_fail(ctx, FO_E_ARG, "fo_step_run: bad arguments");
+  if ((rc = fo_sweep_set_list_format(ctx, p->list_format))) return rc;   // the format is an argument of the run
   if (stages) {
     if ((rc = fo_scene_fan(ctx, p->n_rays, p->ego_yaw, p->fov_deg, p->r, p->polygon_footprint, p->d_dirs, p->d_rmax, p->d_half, stream))) return rc;
     if ((rc = fo_scene_visibility(ctx, p->ego_x, p->ego_y, p->head_x, p->head_y, p->r, p->full_circle, p->exact_cells, p->n_rays,
                                   p->d_dirs, p->d_rmax, p->d_half, p->d_edge_skip, p->O, p->d_ocorn, p->d_ocen, p->d_oflags,
                                   p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->d_range, p->d_hit_id, p->d_ring, p->d_obst_vis,
                                   p->d_cls, p->d_occ_idx, p->d_n_occ, stream))) return rc;
-    if ((rc = fo_scene_spawn(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->ego_x, p->ego_y, p->head_x, p->head_y,
-                             p->min_ahead, p->max_dist, p->all_occluded, p->max_agents, p->routes, p->type4, p->speed4, p->raw_l4,
-                             p->raw_w4, p->infl_l4, p->infl_w4, p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor,
-                             p->d_cell, p->d_pos0, p->d_yaw0, p->d_n, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape,
-                             p->d_raw_dims, p->d_type, p->d_len, stream))) return rc;
+    if (cells && (rc = fo_scene_spawn(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->ego_x, p->ego_y, p->head_x, p->head_y,
+                                      p->min_ahead, p->max_dist, p->all_occluded, p->max_agents, p->routes, p->type4, p->speed4, p->raw_l4,
+                                      p->raw_w4, p->infl_l4, p->infl_w4, p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor,
+                                      p->d_cell, p->d_pos0, p->d_yaw0, p->d_n, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape,
+                                      p->d_raw_dims, p->d_type, p->d_len, stream))) return rc;
+    if (rules) {
+      if ((rc = fo_scene_spawn_rules(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->n_path6, p->d_path6, p->O, p->d_ocorn,
+                                     p->d_ocen, p->d_oyaw, p->d_odims, p->d_oflags, p->d_obst_vis, &p->rule, p->max_rule_points,
+                                     p->d_rule_points, p->d_n_rule_points, stream))) return rc;
+      const size_t T = (size_t)p->T_agents, s0 = (size_t)slot0;
+      if ((rc = fo_scene_spawn_rule_agents(ctx, p->max_rule_points, p->d_rule_points, p->d_n_rule_points, p->routes, &p->rule_types,
+                                           p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor, p->d_pos0 + 2 * (size_t)cell_agents,
+                                           p->d_yaw0 + cell_agents, p->d_pos + s0 * T * 2, p->d_yaw + s0 * T, p->d_v + s0 * T,
+                                           p->d_cov + s0 * T * 4, p->d_shape + 2 * s0, p->d_raw_dims + 2 * s0, p->d_type + s0,
+                                           p->d_len + s0, stream))) return rc;
+    }
     if ((rc = fo_sweep_set_agents(ctx, slots, p->T_agents, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape, p->d_raw_dims, p->d_type,
                                   p->d_len, stream))) return rc;
   } else {
-    if (!p->d_pos || !p->d_yaw || !p->d_v || !p->d_cov || !p->d_shape || !p->d_raw_dims || !p->d_type || !p->d_len || slots < 1)
-      return fo_fail(ctx, FO_E_ARG, "fo_step_run: bad arguments");
     fo_agent_table_t at;
     if ((rc = fo_sweep_agents_begin_(ctx, slots, p->T_agents, stream, &at))) return rc;
     if ((rc = fo_scene_step_(ctx, p, &at, stream))) {

@@ -61,13 +61,17 @@ struct StaticMap {
   int n_inter = 0;
   int32_t *d_inter_off = nullptr, *d_inter_lanelet = nullptr;   // intersection i: entries [off[i], off[i+1]) of
   uint8_t *d_inter_kind = nullptr;                              // (lanelet index, kind: 0 incoming, 1 inner)
+  // lanelet centre lines (fo_scene_set_centerlines; optional): vertices center_xy[center_off[p] .. center_off[p+1])
+  int32_t *d_center_off = nullptr;
+  double *d_center_xy = nullptr;
 };
 
 void map_release(StaticMap *m) {
   if (!m || m->refs.fetch_sub(1) > 1) return;
   void *ptrs[] = {m->d_edges, m->d_edge_line, m->d_chunk_box, m->d_sub_box, m->d_raster, m->d_lane_yaw, m->d_route_first,
                   m->d_route_count, m->d_lanelet_raster, m->d_route_xy, m->d_route_s, m->d_poly_off, m->d_poly_xy,
-                  m->d_poly_box, m->d_left0, m->d_pred0, m->d_adj_left, m->d_inter_off, m->d_inter_lanelet, m->d_inter_kind};
+                  m->d_poly_box, m->d_left0, m->d_pred0, m->d_adj_left, m->d_inter_off, m->d_inter_lanelet, m->d_inter_kind,
+                  m->d_center_off, m->d_center_xy};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete m;
@@ -1010,6 +1014,41 @@ struct SpawnTypes {  // per pattern slot (j % 4): type code, speed, raw dims, in
   double speed[4], raw_l[4], raw_w[4], infl_l[4], infl_w[4];
 };
 
+// unit normal from (px, py) towards the closest point of the polyline path [N][2], as an angle in [0, 2 pi)
+// (agent.py:475-481 + helper_functions.py:38-64); the whole wave calls this, the lanes share the search for the closest
+// segment (per lane ascending i, first minimum; across lanes the smallest (d2, i)), the result is wave-uniform
+__device__ __forceinline__ double heading_to_curve(int lane, int N, const double *__restrict__ path, double px, double py) {
+  double best = INFINITY, qx = px, qy = py;
+  int bi = 0x7fffffff;
+  for (int i = lane; i + 1 < N; i += 64) {
+    const double ax = path[2 * i], ay = path[2 * i + 1], bx = path[2 * i + 2], by = path[2 * i + 3];
+    const double ex = bx - ax, ey = by - ay;
+    const double l2 = ex * ex + ey * ey;
+    double t = 0.0;
+    if (l2 > 0.0) {
+      t = ((px - ax) * ex + (py - ay) * ey) / l2;
+      if (t < 0.0) t = 0.0;
+      if (t > 1.0) t = 1.0;
+    }
+    const double cx = ax + t * ex, cy = ay + t * ey;
+    const double d2 = (px - cx) * (px - cx) + (py - cy) * (py - cy);
+    if (d2 < best) { best = d2; qx = cx; qy = cy; bi = i; }   // per lane: ascending i, first minimum
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {                    // across lanes: smallest (d2, i) = first minimum
+    const double b2 = __shfl_xor(best, off), x2 = __shfl_xor(qx, off), y2 = __shfl_xor(qy, off);
+    const int i2 = __shfl_xor(bi, off);
+    if (b2 < best || (b2 == best && i2 < bi)) { best = b2; qx = x2; qy = y2; bi = i2; }
+  }
+  const double vx = qx - px, vy = qy - py;
+  const double nn = sqrt(vx * vx + vy * vy);
+  double ux = 1.0, uy = 0.0;
+  if (nn > 0.0) { ux = vx / nn; uy = vy / nn; }
+  double a = atan2(uy, ux);
+  if (a < 0.0) a += 2.0 * M_PI;
+  return a;
+}
+
 // evenly spaced pick of the candidates + heading per phantom: pedestrians -> unit vector to the closest point of the
 // ego reference path (agent.py:475-481 + helper_functions.py:38-76); vehicles -> lane heading raster at their cell
 // Phantom slot j of the step (the whole wave calls this; every result is wave-uniform): which candidate cell it takes
@@ -1033,87 +1072,48 @@ __device__ __forceinline__ bool spawn_pick(int j, int lane, const int32_t *__res
   a = NAN;
   if (type != FO_TYPE_PEDESTRIAN && lane_yaw && wx >= 0 && wx < rnx && wy >= 0 && wy < rny)
     a = lane_yaw[(size_t)wy * rnx + wx];
-  if (isnan(a)) {  // wave-uniform
-    double best = INFINITY, qx = px, qy = py;
-    int bi = 0x7fffffff;
-    for (int i = lane; i + 1 < N; i += 64) {
-      const double ax = path[2 * i], ay = path[2 * i + 1], bx = path[2 * i + 2], by = path[2 * i + 3];
-      const double ex = bx - ax, ey = by - ay;
-      const double l2 = ex * ex + ey * ey;
-      double t = 0.0;
-      if (l2 > 0.0) {
-        t = ((px - ax) * ex + (py - ay) * ey) / l2;
-        if (t < 0.0) t = 0.0;
-        if (t > 1.0) t = 1.0;
-      }
-      const double cx = ax + t * ex, cy = ay + t * ey;
-      const double d2 = (px - cx) * (px - cx) + (py - cy) * (py - cy);
-      if (d2 < best) { best = d2; qx = cx; qy = cy; bi = i; }   // per lane: ascending i, first minimum
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {                    // across lanes: smallest (d2, i) = first minimum
-      const double b2 = __shfl_xor(best, off), x2 = __shfl_xor(qx, off), y2 = __shfl_xor(qy, off);
-      const int i2 = __shfl_xor(bi, off);
-      if (b2 < best || (b2 == best && i2 < bi)) { best = b2; qx = x2; qy = y2; bi = i2; }
-    }
-    const double vx = qx - px, vy = qy - py;
-    const double nn = sqrt(vx * vx + vy * vy);
-    double ux = 1.0, uy = 0.0;
-    if (nn > 0.0) { ux = vx / nn; uy = vy / nn; }
-    a = atan2(uy, ux);
-    if (a < 0.0) a += 2.0 * M_PI;
-  }
+  if (isnan(a)) a = heading_to_curve(lane, N, path, px, py);  // wave-uniform
   return true;
 }
 
-// Predictions in the layout fo_sweep_set_agents consumes, one wave per prediction slot (j, r), r < R:
-//   vehicle whose cell lies on a lanelet with routes -> route r of that lanelet: the reference's min-var(v) Frenet sample
-//     (speed held along the route, quintic lateral move to the nearest of d1 in {-0.5, 0, 0.5}); constant speed along the route's
-//     centre line, initial lateral offset kept (what the reference's min-var(v) Frenet sample amounts to; replaces
-//     route_planner.py:31-90 + frenetix_handler.py + agent.py:283-426); the prediction ends where the route ends;
-//   pedestrian / off-lane vehicle / no route table -> r = 0: straight constant velocity (agent.py:451-536), r > 0 empty.
-// Slots of agents j >= n are inactive (len = 0).
-__global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
-    int max_agents, int R, const int32_t *__restrict__ cand, const int32_t *__restrict__ n_cand, double rx0, double ry0,
-    double cs, int n_path, const double *__restrict__ path, const double *__restrict__ lane_yaw, SpawnTypes st, int T,
-    double dt, double var0, double factor, int nx, int ix0, int iy0, int rnx, int rny,
-    const int32_t *__restrict__ lanelet_raster, int RT, const int32_t *__restrict__ route_first,
-    const int32_t *__restrict__ route_count, const double *__restrict__ route_xy, const double *__restrict__ route_s,
-    int32_t *__restrict__ cell, double *__restrict__ pos0, double *__restrict__ yaw0, int32_t *__restrict__ n_out,
-    double *__restrict__ pos, double *__restrict__ yaw, double *__restrict__ v, double *__restrict__ cov,
-    double *__restrict__ shape, double *__restrict__ raw, int32_t *__restrict__ type, int32_t *__restrict__ len,
-    int table_on, fo_agent_table_t at) {
-  const int lane = threadIdx.x;
-  const int slot = blockIdx.x, j = slot / R, r = slot % R;
-  // the pick of agent j (repeated by each of its R route slots: a few dozen path segments; saves a launch)
-  const int n_c = *n_cand;
-  int ci;
-  double p0x, p0y, a0;
-  const bool on = spawn_pick(j, lane, cand, n_c, nx, rx0, ry0, cs, ix0, iy0, max_agents, st, n_path, path, lane_yaw, rnx,
-                             rny, ci, p0x, p0y, a0);
-  if (r == 0 && lane == 0) {
-    cell[j] = ci; pos0[2 * j] = p0x; pos0[2 * j + 1] = p0y; yaw0[j] = a0;
-    if (j == 0) *n_out = n_c < max_agents ? n_c : max_agents;
-  }
-  const int sdx = j & 3;
-  const double spd = st.speed[sdx];
-  double *P = pos + (size_t)slot * T * 2, *Y = yaw + (size_t)slot * T, *V = v + (size_t)slot * T;
-  double *C = cov + (size_t)slot * T * 4;
+// route tables of the static map as the prediction kernels read them (fo_scene_set_routes)
+struct RouteView {
+  int RT = 0;                       // routes per lanelet in the table (0 = no table)
+  const int32_t *first = nullptr, *count = nullptr;
+  const double *xy = nullptr, *s = nullptr;
+};
+
+// where the prediction kernels write: the arrays fo_sweep_set_agents consumes (whole arrays; `slot` indexes them)
+struct PredOut {
+  double *pos, *yaw, *v, *cov, *shape, *raw;
+  int32_t *type, *len;
+};
+
+// One prediction slot, written by one wave (every argument wave-uniform):
+//   on && ll >= 0 && the lanelet ll has routes -> route r of that lanelet: the reference's min-var(v) Frenet sample (speed
+//     held along the route, quintic lateral move to the nearest of d1 in {-0.5, 0, 0.5}; replaces route_planner.py:31-90
+//     + frenetix_handler.py + agent.py:283-426); the prediction ends where the route ends;
+//   on, otherwise -> r = 0: straight constant velocity along heading a0 (agent.py:451-536), r > 0 empty;
+//   !on -> inactive (len = 0).
+// table_on (fo_step_run): the slot's rows of the sweep's agent table as well, instead of a launch of fo_prep_agents_kernel
+// (same function, same bits: fo_agent_rows.hpp).
+__device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool on, double p0x, double p0y, double a0,
+                                                 int atype, double spd, double raw_l, double raw_w, double infl_l,
+                                                 double infl_w, int ll, const RouteView &rv, int T, double dt, double var0,
+                                                 double factor, const PredOut &o, int table_on, const fo_agent_table_t &at) {
+  double *P = o.pos + (size_t)slot * T * 2, *Y = o.yaw + (size_t)slot * T, *V = o.v + (size_t)slot * T;
+  double *C = o.cov + (size_t)slot * T * 4;
   for (int k = lane; k < T; k += 64) {
     const double var = var0 * pow(factor, (double)k);  // agent.py:273
     C[4 * k] = var; C[4 * k + 1] = 0.0; C[4 * k + 2] = 0.0; C[4 * k + 3] = var;
   }
   if (lane == 0) {
-    shape[2 * slot] = st.infl_l[sdx]; shape[2 * slot + 1] = st.infl_w[sdx];
-    raw[2 * slot] = st.raw_l[sdx]; raw[2 * slot + 1] = st.raw_w[sdx];
-    type[slot] = st.type[sdx];
+    o.shape[2 * slot] = infl_l; o.shape[2 * slot + 1] = infl_w;
+    o.raw[2 * slot] = raw_l; o.raw[2 * slot + 1] = raw_w;
+    o.type[slot] = atype;
   }
-  int ll = -1;
-  if (on && lanelet_raster && st.type[sdx] != FO_TYPE_PEDESTRIAN) {
-    const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
-    if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny) ll = lanelet_raster[(size_t)wy * rnx + wx];
-  }
-  const bool routed = on && ll >= 0 && r < RT && route_count[(size_t)ll * RT] > 0;
+  const int RT = rv.RT;
+  const bool routed = on && ll >= 0 && r < RT && rv.count[(size_t)ll * RT] > 0;
   int L = 0;
   if (on && !routed && r == 0) {  // straight constant velocity
     const double a = a0;
@@ -1124,10 +1124,10 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
       P[2 * k] = p0x + t * vx; P[2 * k + 1] = p0y + t * vy; Y[k] = a; V[k] = spd;
     }
     L = T;
-  } else if (routed && route_count[(size_t)ll * RT + r] >= 2) {
-    const int nv = route_count[(size_t)ll * RT + r];
-    const double *q = route_xy + 2 * (size_t)route_first[(size_t)ll * RT + r];
-    const double *sq = route_s + route_first[(size_t)ll * RT + r];
+  } else if (routed && rv.count[(size_t)ll * RT + r] >= 2) {
+    const int nv = rv.count[(size_t)ll * RT + r];
+    const double *q = rv.xy + 2 * (size_t)rv.first[(size_t)ll * RT + r];
+    const double *sq = rv.s + rv.first[(size_t)ll * RT + r];
     const double px = p0x, py = p0y;
     double best = INFINITY, s0 = 0.0, d0 = 0.0;
     int bi = 0x7fffffff;
@@ -1185,16 +1185,45 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
   }
   for (int k = lane; k < T; k += 64)
     if (k >= L) { P[2 * k] = 0.0; P[2 * k + 1] = 0.0; Y[k] = 0.0; V[k] = 0.0; }
-  if (lane == 0) len[slot] = L;
+  if (lane == 0) o.len[slot] = L;
   if (table_on) {
-    // fo_step_run: the rows of this slot in the sweep's agent table, written here instead of by a launch of
-    // fo_prep_agents_kernel (same function, same bits: fo_agent_rows.hpp)
     __threadfence_block();
     __syncthreads();
     for (int k = lane; k < T; k += 64)
-      fo_agent_row(slot * T + k, T, pos, yaw, v, cov, shape, raw, type, len, at.ego_mass, at.hlA, at.hwA, at.hc, at.tab, at.cst,
-                   at.aint, at.status, at.gen);
+      fo_agent_row(slot * T + k, T, o.pos, o.yaw, o.v, o.cov, o.shape, o.raw, o.type, o.len, at.ego_mass, at.hlA, at.hwA, at.hc, at.tab,
+                   at.cst, at.aint, at.status, at.gen);
   }
+}
+
+// Phantoms sampled in the occluded cells: one wave per prediction slot (j, r), r < R.  A vehicle whose cell lies on a
+// lanelet with routes gets one prediction per candidate route; pedestrians / off-lane vehicles / no route table: one
+// straight prediction in r = 0.  Slots of agents j >= n are inactive (len = 0).
+__global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
+    int max_agents, int R, const int32_t *__restrict__ cand, const int32_t *__restrict__ n_cand, double rx0, double ry0,
+    double cs, int n_path, const double *__restrict__ path, const double *__restrict__ lane_yaw, SpawnTypes st, int T,
+    double dt, double var0, double factor, int nx, int ix0, int iy0, int rnx, int rny,
+    const int32_t *__restrict__ lanelet_raster, RouteView rv, int32_t *__restrict__ cell, double *__restrict__ pos0,
+    double *__restrict__ yaw0, int32_t *__restrict__ n_out, PredOut o, int table_on, fo_agent_table_t at) {
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x, j = slot / R, r = slot % R;
+  // the pick of agent j (repeated by each of its R route slots: a few dozen path segments; saves a launch)
+  const int n_c = *n_cand;
+  int ci;
+  double p0x, p0y, a0;
+  const bool on = spawn_pick(j, lane, cand, n_c, nx, rx0, ry0, cs, ix0, iy0, max_agents, st, n_path, path, lane_yaw, rnx,
+                             rny, ci, p0x, p0y, a0);
+  if (r == 0 && lane == 0) {
+    cell[j] = ci; pos0[2 * j] = p0x; pos0[2 * j + 1] = p0y; yaw0[j] = a0;
+    if (j == 0) *n_out = n_c < max_agents ? n_c : max_agents;
+  }
+  const int sdx = j & 3;
+  int ll = -1;
+  if (on && lanelet_raster && st.type[sdx] != FO_TYPE_PEDESTRIAN) {
+    const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
+    if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny) ll = lanelet_raster[(size_t)wy * rnx + wx];
+  }
+  spawn_write_slot(lane, slot, r, on, p0x, p0y, a0, st.type[sdx], st.speed[sdx], st.raw_l[sdx], st.raw_w[sdx], st.infl_l[sdx],
+                   st.infl_w[sdx], ll, rv, T, dt, var0, factor, o, table_on, at);
 }
 
 int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
@@ -1304,7 +1333,7 @@ int fo_scene_set_map(fo_ctx *ctx, int P, const int32_t *h_poly_off, const double
                    (void **)&sc->map->d_edge_line, (void **)&sc->map->d_sub_box, (void **)&sc->map->d_poly_off,
                    (void **)&sc->map->d_poly_xy, (void **)&sc->map->d_poly_box, (void **)&sc->map->d_left0, (void **)&sc->map->d_pred0,
                    (void **)&sc->map->d_adj_left, (void **)&sc->map->d_inter_off, (void **)&sc->map->d_inter_lanelet,
-                   (void **)&sc->map->d_inter_kind}) {
+                   (void **)&sc->map->d_inter_kind, (void **)&sc->map->d_center_off, (void **)&sc->map->d_center_xy}) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   }
   int32_t *d_off = nullptr;
@@ -1589,11 +1618,13 @@ static int scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_i
     st.infl_l[i] = infl_l4[i]; st.infl_w[i] = infl_w4[i];
   }
   const int R = routes > 0 ? routes : 1;
+  RouteView rv;
+  if (routes > 0) { rv.RT = sc->map->R; rv.first = sc->map->d_route_first; rv.count = sc->map->d_route_count; rv.xy = sc->map->d_route_xy; rv.s = sc->map->d_route_s; }
+  PredOut po{d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len};
   hipLaunchKernelGGL(fo_spawn_predict_kernel, dim3(max_agents * R), dim3(64), 0, s, max_agents, R, sc->d_cand, sc->d_ncand,
                      sc->map->x0, sc->map->y0, sc->map->cs, n_path, d_path, sc->map->d_lane_yaw, st, T, dt, var0, var_factor, win_nx, win_ix0,
-                     win_iy0, sc->map->rnx, sc->map->rny, routes > 0 ? sc->map->d_lanelet_raster : nullptr, sc->map->R, sc->map->d_route_first,
-                     sc->map->d_route_count, sc->map->d_route_xy, sc->map->d_route_s, d_cell, d_pos0, d_yaw0, d_n, d_pos, d_yaw, d_v,
-                     d_cov, d_shape, d_raw_dims, d_type, d_len, at ? 1 : 0, at ? *at : fo_agent_table_t());
+                     win_iy0, sc->map->rnx, sc->map->rny, routes > 0 ? sc->map->d_lanelet_raster : nullptr, rv, d_cell, d_pos0, d_yaw0,
+                     d_n, po, at ? 1 : 0, at ? *at : fo_agent_table_t());
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
 }
@@ -1611,10 +1642,17 @@ int fo_scene_spawn(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, 
 }
 
 // the scene stages of a planning step in their fused form (fo_step_run, fo_api.hip): fan inside the ray kernel, candidate
-// flags inside the first compaction, the sweep's agent table written by the prediction kernel
+// flags inside the first compaction, the sweep's agent table written by the prediction kernels
+int fo_scene_rule_agents_(fo_ctx *ctx, int max_points, const double *d_points, const int32_t *d_n_points, int routes,
+                          const fo_rule_agent_types_t *types, int n_path, const double *d_path, int T, double dt, double var0,
+                          double var_factor, int slot0, int agent0, double *d_pos0, double *d_yaw0, double *d_pos, double *d_yaw,
+                          double *d_v, double *d_cov, double *d_shape, double *d_raw_dims, int32_t *d_type, int32_t *d_len,
+                          void *stream, const fo_agent_table_t *at);   // fo_spawn_rules.hpp
+
 int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, void *stream) {
   if (!ctx || !p) return FO_E_ARG;
   if (p->n_rays < 4 || !p->d_dirs || !(p->r > 0) || !(p->fov_deg > 0)) return fo_fail(ctx, FO_E_ARG, "fo_scene_fan: bad arguments");
+  const bool cells = p->spawn_mode != FO_SPAWN_RULES, rules = p->spawn_mode != FO_SPAWN_CELLS;
   FanArgs fan;
   fan.on = 1; fan.full = p->fov_deg >= 359.9; fan.polygon = p->polygon_footprint; fan.yaw = p->ego_yaw;
   fan.fov = p->fov_deg * (3.14159265358979323846 / 180.0);
@@ -1625,12 +1663,23 @@ int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, 
   if ((rc = scene_visibility(ctx, p->ego_x, p->ego_y, p->head_x, p->head_y, p->r, p->full_circle, p->exact_cells, p->n_rays, p->d_dirs,
                              p->d_rmax, p->d_half, p->d_edge_skip, p->O, p->d_ocorn, p->d_ocen, p->d_oflags, p->win_ix0, p->win_iy0,
                              p->win_nx, p->win_ny, p->d_range, p->d_hit_id, p->d_ring, p->d_obst_vis, p->d_cls, p->d_occ_idx,
-                             p->d_n_occ, stream, &fan, &sf))) return rc;
-  return scene_spawn(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->ego_x, p->ego_y, p->head_x, p->head_y,
-                     p->min_ahead, p->max_dist, p->all_occluded, p->max_agents, p->routes, p->type4, p->speed4, p->raw_l4,
-                     p->raw_w4, p->infl_l4, p->infl_w4, p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor,
-                     p->d_cell, p->d_pos0, p->d_yaw0, p->d_n, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape,
-                     p->d_raw_dims, p->d_type, p->d_len, stream, at);
+                             p->d_n_occ, stream, &fan, cells ? &sf : nullptr))) return rc;
+  if (cells && (rc = scene_spawn(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->ego_x, p->ego_y, p->head_x, p->head_y,
+                                 p->min_ahead, p->max_dist, p->all_occluded, p->max_agents, p->routes, p->type4, p->speed4, p->raw_l4,
+                                 p->raw_w4, p->infl_l4, p->infl_w4, p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor,
+                                 p->d_cell, p->d_pos0, p->d_yaw0, p->d_n, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape,
+                                 p->d_raw_dims, p->d_type, p->d_len, stream, at))) return rc;
+  if (rules) {
+    const int R = p->routes > 0 ? p->routes : 1, cell_agents = cells ? p->max_agents : 0;
+    if ((rc = fo_scene_spawn_rules(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->n_path6, p->d_path6, p->O, p->d_ocorn,
+                                   p->d_ocen, p->d_oyaw, p->d_odims, p->d_oflags, p->d_obst_vis, &p->rule, p->max_rule_points,
+                                   p->d_rule_points, p->d_n_rule_points, stream))) return rc;
+    if ((rc = fo_scene_rule_agents_(ctx, p->max_rule_points, p->d_rule_points, p->d_n_rule_points, p->routes, &p->rule_types, p->n_path,
+                                    p->d_path, p->T_agents, p->dt, p->var0, p->var_factor, cell_agents * R, cell_agents, p->d_pos0,
+                                    p->d_yaw0, p->d_pos, p->d_yaw, p->d_v, p->d_cov, p->d_shape, p->d_raw_dims, p->d_type, p->d_len,
+                                    stream, at))) return rc;
+  }
+  return FO_OK;
 }
 
 int fo_scene_candidate_count(fo_ctx *ctx, int32_t *h_n, void *stream) {

@@ -813,6 +813,54 @@ __global__ void fo_spawn_rules_select_kernel(RuleView v, RuleParams pr, int O, c
   *n_out = n < max_out ? n : max_out;
 }
 
+
+// ---------------------------------------------------------------- rule points -> phantom agents, on the device
+// Replaces the loop of FOInterface.evaluate_scenario over the spawn points (interface.py:186-198) with
+// FOAgentManager.add_agent (agent.py:46-141) behind it: one wave per prediction slot (point i, route r).  Reads the records
+// fo_spawn_rules_select_kernel wrote -- type, x, y, orientation (NaN = derive), s, d, source, obstacle -- in HBM.
+struct RuleAgentTypes { double speed[3], raw_l[3], raw_w[3], infl_l[3], infl_w[3]; };   // 0 Car, 1 Bicycle, 2 Pedestrian
+
+__global__ __launch_bounds__(64) void fo_spawn_rule_predict_kernel(
+    RuleView v, int max_points, const double *__restrict__ points, const int32_t *__restrict__ n_points, int R, RuleAgentTypes ty,
+    int n_path, const double *__restrict__ path, const int32_t *__restrict__ center_off, const double *__restrict__ center_xy,
+    RouteView rv, int T, double dt, double var0, double factor, int slot0, int agent0, double *__restrict__ pos0,
+    double *__restrict__ yaw0, PredOut o, int table_on, fo_agent_table_t at) {
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x / R, r = blockIdx.x % R, slot = slot0 + blockIdx.x;
+  const int n = min(max(*n_points, 0), max_points);
+  const bool on = i < n;
+  const double *rec = points + 8 * (size_t)i;
+  const int type = on ? (int)rec[0] : RL_TYPE_PED;
+  const int ti = type == RL_TYPE_CAR ? 0 : type == RL_TYPE_BICYCLE ? 1 : 2;
+  const double px = on ? rec[1] : 0.0, py = on ? rec[2] : 0.0;
+  const int src = on ? (int)rec[6] : 0;
+  double a0 = on ? rec[3] : 0.0;
+  int ll = -1;
+  if (on && ti == 2) {                                           // OAPPedestrianAgent._create_ped_trajectory (agent.py:451-481)
+    if (a0 != a0) {
+      const double *curve = path;
+      int nc = n_path;
+      if ((src == RL_SRC_LEFT || src == RL_SRC_RIGHT) && center_off) {       // mode 'lane_center' (interface.py:194)
+        const int lc = rl_lanelet_of(v, px, py);
+        if (lc >= 0 && center_off[lc + 1] - center_off[lc] >= 2) { curve = center_xy + 2 * (size_t)center_off[lc]; nc = center_off[lc + 1] - center_off[lc]; }
+      }
+      a0 = heading_to_curve(lane, nc, curve, px, py);
+    }
+  } else if (on) {                                               // OAPVehicleAgent (agent.py:283-312): the lanelet under the point
+    ll = rv.RT > 0 ? rl_lanelet_of(v, px, py) : -1;
+    if (ll >= 0 && rv.count[(size_t)ll * rv.RT] >= 2) {          // heading of the record: first segment of route 0
+      const double *q = rv.xy + 2 * (size_t)rv.first[(size_t)ll * rv.RT];
+      a0 = atan2(q[3] - q[1], q[2] - q[0]);
+    } else {
+      ll = -1;
+      a0 = heading_to_curve(lane, n_path, path, px, py);
+    }
+  }
+  if (r == 0 && lane == 0) { pos0[2 * (agent0 + i)] = px; pos0[2 * (agent0 + i) + 1] = py; yaw0[agent0 + i] = a0; }
+  spawn_write_slot(lane, slot, r, on, px, py, a0, type, ty.speed[ti], ty.raw_l[ti], ty.raw_w[ti], ty.infl_l[ti], ty.infl_w[ti], ll, rv, T,
+                   dt, var0, factor, o, table_on, at);
+}
+
 }  // namespace
 
 extern "C" {
@@ -894,6 +942,72 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
                      sc->d_rule_rec, max_out, d_out, d_n_out);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
+}
+
+
+int fo_scene_set_centerlines(fo_ctx *ctx, int P, const int32_t *h_off, const double *h_xy) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_set_centerlines: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  StaticMap *m = sc->map;
+  if (P != m->P || !h_off || h_off[0] != 0) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_centerlines: bad arguments (P=%d, the map has %d lanelets)", P, m->P);
+  for (int p = 0; p < P; ++p)
+    if (h_off[p + 1] < h_off[p]) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_centerlines: offsets must not decrease (lanelet %d)", p);
+  const int NV = h_off[P];
+  if (NV > 0 && !h_xy) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_centerlines: null vertex table");
+  if (m->refs.load() > 1)
+    return fo_fail(ctx, FO_E_STATE, "fo_scene_set_centerlines: the static map is shared (fo_scene_share_map); set the centre lines on the owner before sharing");
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (void **q : {(void **)&m->d_center_off, (void **)&m->d_center_xy})
+    if (*q) { (void)hipFree(*q); *q = nullptr; }
+  FO_HIP_TRY(ctx, hipMalloc((void **)&m->d_center_off, sizeof(int32_t) * (P + 1)));
+  FO_HIP_TRY(ctx, hipMalloc((void **)&m->d_center_xy, sizeof(double) * 2 * (size_t)(NV > 0 ? NV : 1)));
+  FO_HIP_TRY(ctx, hipMemcpy(m->d_center_off, h_off, sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice));
+  if (NV > 0) FO_HIP_TRY(ctx, hipMemcpy(m->d_center_xy, h_xy, sizeof(double) * 2 * (size_t)NV, hipMemcpyHostToDevice));
+  return FO_OK;
+}
+
+// fo_scene_spawn_rule_agents; slot0 / agent0 / at (fo_step_run): the rule agents' slots follow the cell sampler's in the
+// same arrays, and the kernel writes its slots' rows of the sweep's agent table
+int fo_scene_rule_agents_(fo_ctx *ctx, int max_points, const double *d_points, const int32_t *d_n_points, int routes,
+                          const fo_rule_agent_types_t *types, int n_path, const double *d_path, int T, double dt, double var0,
+                          double var_factor, int slot0, int agent0, double *d_pos0, double *d_yaw0, double *d_pos, double *d_yaw,
+                          double *d_v, double *d_cov, double *d_shape, double *d_raw_dims, int32_t *d_type, int32_t *d_len,
+                          void *stream, const fo_agent_table_t *at) {
+  if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn_rule_agents: call fo_scene_set_map first");
+  Scene *sc = (Scene *)ctx->scene;
+  StaticMap *m = sc->map;
+  if (max_points < 1 || !d_points || !d_n_points || !types || n_path < 2 || !d_path || T < 1 || !d_pos0 || !d_yaw0 || !d_pos ||
+      !d_yaw || !d_v || !d_cov || !d_shape || !d_raw_dims || !d_type || !d_len || slot0 < 0 || agent0 < 0)
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rule_agents: bad arguments (max_points=%d n_path=%d T=%d)", max_points, n_path, T);
+  if (!m->d_poly_off) return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn_rule_agents: the map holds no lanelet polygons");
+  if (routes < 0 || (routes > 0 && !m->d_route_first))
+    return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn_rule_agents: routes = %d needs fo_scene_set_routes first", routes);
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RuleView v{};
+  v.x0 = m->x0; v.y0 = m->y0; v.cs = m->cs; v.P = m->P; v.poly_off = m->d_poly_off; v.poly_xy = m->d_poly_xy; v.poly_box = m->d_poly_box;
+  RuleAgentTypes ty;
+  for (int i = 0; i < 3; ++i) {
+    ty.speed[i] = types->speed[i]; ty.raw_l[i] = types->raw_l[i]; ty.raw_w[i] = types->raw_w[i];
+    ty.infl_l[i] = types->infl_l[i]; ty.infl_w[i] = types->infl_w[i];
+  }
+  RouteView rv;
+  if (routes > 0) { rv.RT = m->R; rv.first = m->d_route_first; rv.count = m->d_route_count; rv.xy = m->d_route_xy; rv.s = m->d_route_s; }
+  const int R = routes > 0 ? routes : 1;
+  PredOut po{d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len};
+  hipLaunchKernelGGL(fo_spawn_rule_predict_kernel, dim3(max_points * R), dim3(64), 0, (hipStream_t)stream, v, max_points, d_points,
+                     d_n_points, R, ty, n_path, d_path, m->d_center_off, m->d_center_xy, rv, T, dt, var0, var_factor, slot0, agent0,
+                     d_pos0, d_yaw0, po, at ? 1 : 0, at ? *at : fo_agent_table_t());
+  FO_HIP_TRY(ctx, hipGetLastError());
+  return FO_OK;
+}
+
+int fo_scene_spawn_rule_agents(fo_ctx *ctx, int max_points, const double *d_points, const int32_t *d_n_points, int routes,
+                               const fo_rule_agent_types_t *types, int n_path, const double *d_path, int T, double dt,
+                               double var0, double var_factor, double *d_pos0, double *d_yaw0, double *d_pos, double *d_yaw,
+                               double *d_v, double *d_cov, double *d_shape, double *d_raw_dims, int32_t *d_type,
+                               int32_t *d_len, void *stream) {
+  return fo_scene_rule_agents_(ctx, max_points, d_points, d_n_points, routes, types, n_path, d_path, T, dt, var0, var_factor, 0, 0,
+                               d_pos0, d_yaw0, d_pos, d_yaw, d_v, d_cov, d_shape, d_raw_dims, d_type, d_len, stream, nullptr);
 }
 
 }  // extern "C"

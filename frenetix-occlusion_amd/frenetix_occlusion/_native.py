@@ -31,6 +31,7 @@ EXPORTS = [
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read", "fo_sweep_timing_read_each",
     "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
     "fo_scene_candidate_count", "fo_scene_set_topology", "fo_scene_spawn_rules", "fo_step_run",
+    "fo_scene_set_centerlines", "fo_scene_spawn_rule_agents",
 ]
 
 
@@ -53,6 +54,14 @@ class SpawnRuleParams(C.Structure):       # fo_spawn_rule_params_t
                                           "max_static", "max_dynamic")])
 
 
+class RuleAgentTypes(C.Structure):       # fo_rule_agent_types_t: index 0 Car, 1 Bicycle, 2 Pedestrian
+    _fields_ = [(n, C.c_double * 3) for n in ("speed", "raw_l", "raw_w", "infl_l", "infl_w")]
+
+
+SPAWN_CELLS, SPAWN_RULES, SPAWN_BOTH = 0, 1, 2
+SPAWN_MODE = {"cells": SPAWN_CELLS, "rules": SPAWN_RULES, "both": SPAWN_BOTH}
+
+
 class Step(C.Structure):       # fo_step_t (include/fo_hip.h): the arguments of one planning step's five stage calls
     _fields_ = [("n_rays", C.c_int32), ("polygon_footprint", C.c_int32), ("ego_yaw", C.c_double), ("fov_deg", C.c_double),
                 ("r", C.c_double), ("d_dirs", C.c_void_p), ("d_rmax", C.c_void_p), ("d_half", C.c_void_p),
@@ -71,7 +80,10 @@ class Step(C.Structure):       # fo_step_t (include/fo_hip.h): the arguments of 
                 ("d_cov", C.c_void_p), ("d_shape", C.c_void_p), ("d_raw_dims", C.c_void_p), ("d_type", C.c_void_p),
                 ("d_len", C.c_void_p), ("M", C.c_int32), ("T", C.c_int32), ("d_x", C.c_void_p), ("d_y", C.c_void_p),
                 ("d_theta", C.c_void_p), ("d_vel", C.c_void_p), ("d_acc", C.c_void_p), ("d_cost", C.c_void_p),
-                ("d_safe", C.c_void_p), ("d_pair_f", C.c_void_p), ("d_pair_i", C.c_void_p), ("d_lists", C.c_void_p)]
+                ("d_safe", C.c_void_p), ("d_pair_f", C.c_void_p), ("d_pair_i", C.c_void_p), ("d_lists", C.c_void_p),
+                ("list_format", C.c_int32), ("spawn_mode", C.c_int32), ("n_path6", C.c_int32), ("max_rule_points", C.c_int32),
+                ("d_path6", C.c_void_p), ("d_oyaw", C.c_void_p), ("d_odims", C.c_void_p), ("rule", SpawnRuleParams),
+                ("rule_types", RuleAgentTypes), ("d_rule_points", C.c_void_p), ("d_n_rule_points", C.c_void_p)]
 
 
 class NativeError(RuntimeError):
@@ -137,6 +149,9 @@ def load():
     lib.fo_scene_set_topology.argtypes = [vp, C.c_int, dp, ip, ip, C.c_int, ip, ip, dp]
     lib.fo_scene_spawn_rules.argtypes = ([vp, dp] + [C.c_int] * 5 + [dp, C.c_int] + [dp] * 6 + [C.POINTER(SpawnRuleParams), C.c_int,
                                                                                           dp, ip, vp])
+    lib.fo_scene_set_centerlines.argtypes = [vp, C.c_int, ip, dp]
+    lib.fo_scene_spawn_rule_agents.argtypes = ([vp, C.c_int, dp, ip, C.c_int, C.POINTER(RuleAgentTypes), C.c_int, dp, C.c_int]
+                                               + [D] * 3 + [dp] * 8 + [ip, ip, vp])
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("fo_destroy", "fo_last_error", "fo_build_id"):
@@ -188,6 +203,7 @@ class Context:
         if rc != FO_OK:
             raise NativeError(rc, "fo_create failed (is a gfx950 GPU visible? there is no CPU fallback)")
         self.device = int(device)
+        self.list_format = "f64"      # element type of the per-timestep lists the context writes (fo_sweep_set_list_format)
 
     def close(self):
         h = getattr(self, "_h", None)

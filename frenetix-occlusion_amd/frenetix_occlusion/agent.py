@@ -36,8 +36,8 @@ class FOAgentManager:
         self.debug = debug
         self.device = device if device is not None else torch.device("cuda", 0)
         self.real_agents = []
-        self._batch = None            # PhantomBatch from the spawn kernel (device)
-        self._n_batch = 0             # active slots in it
+        self._batch = None            # PhantomBatch from the spawn kernels (device)
+        self._live = None             # agent indices of the batch that are alive this step (None: not read back yet)
         self._batch_agents = None     # PhantomAgent objects of those slots (built on first access)
         self._manual = []             # agents added through add_agent() (host-side predictions)
         self._external = []           # (obstacle id, prediction dict, type name) of REAL agents (extension, see below)
@@ -47,7 +47,7 @@ class FOAgentManager:
 
     # ---- reference API ------------------------------------------------------------------------------------
     def reset(self):
-        self._batch, self._n_batch, self._batch_agents = None, 0, None
+        self._batch, self._live, self._batch_agents = None, None, None
         self._manual = []
         self._external = []
         self._pred_cache = None
@@ -275,14 +275,36 @@ class FOAgentManager:
         self._pred_cache = None
 
     # ---- device side ------------------------------------------------------------------------------------------
-    def attach_batch(self, batch: PhantomBatch, n_active: int):
-        """take over the spawn kernel's output (n_active slots are live)"""
+    def attach_batch(self, batch: PhantomBatch, n_active=None):
+        """take over the spawn kernels' output.  Which of its agents are alive is read from the device when a host view
+        (``phantom_agents``, ``predictions``, ``has_phantoms``) first needs it; ``n_active`` (the number of live
+        cell-sampled agents, for a batch without rule agents) spares that copy when the caller knows it already."""
         if self._batch_agents:                       # ids of the batch being replaced
             gone = {a.agent_id for a in self._batch_agents}
             self.all_obstacle_id = [i for i in self.all_obstacle_id if i not in gone]
             self._step_ids = [i for i in self._step_ids if i not in gone]
-        self._batch, self._n_batch, self._batch_agents = batch, int(n_active), None
+        self._batch, self._batch_agents = batch, None
+        self._live = list(range(int(n_active))) if (n_active is not None and not batch.n_rule_points) else None
         self._pred_cache = None
+
+    def _live_agents(self):
+        if self._batch is None:
+            return []
+        if self._live is None:
+            self._live = self._batch.live_agents()
+        return self._live
+
+    @property
+    def _n_batch(self):
+        return len(self._live_agents())
+
+    def may_have_phantoms(self):
+        """True when a sweep has something to evaluate or MAY have: a device batch is attached (its live count stays in HBM
+        -- asking for it would stall the step; a batch without live agents leaves every trajectory safe), or host-side
+        agents exist"""
+        if self._batch is not None and self._live is None:
+            return True
+        return self.has_phantoms()              # the live agents are known on the host already: the exact answer
 
     def has_phantoms(self):
         return self._n_batch > 0 or bool(self._manual) or bool(self._external)
@@ -297,18 +319,20 @@ class FOAgentManager:
         """agent.py:39: list of phantom agents of this step (objects are created on first access)"""
         if self._batch_agents is None:
             self._batch_agents = []
-            n = self._n_batch
-            if n:
+            live = self._live_agents()
+            if live:
                 b = self._batch
-                pos0, yaw0 = b.pos0[:n].cpu().numpy(), b.yaw0[:n].cpu().numpy()
+                h = b.host_head()
                 R = b.R
-                typ, raw = b.type[:n * R:R].cpu().numpy(), b.raw_dims[:n * R:R].cpu().numpy()
-                ln, v0 = b.len[:n * R].cpu().numpy().reshape(n, R), b.v[:n * R, 0].cpu().numpy().reshape(n, R)
-                for j in range(n):
-                    r0 = int(np.argmax(ln[j] > 0))     # first prediction that exists carries the speed
-                    self._batch_agents.append(PhantomAgent(self._create_id(), TYPE_NAME[int(typ[j])], pos0[j],
-                                                           float(yaw0[j]), float(v0[j, r0]), float(raw[j, 0]),
-                                                           float(raw[j, 1])))
+                idx = torch.as_tensor(live, device=b.len.device)
+                raw = b.raw_dims[idx * R].cpu().numpy()
+                ln = b.len.view(-1, R)[idx].cpu().numpy()
+                v0 = b.v[:, 0].reshape(-1, R)[idx].cpu().numpy()
+                for q, j in enumerate(live):
+                    r0 = int(np.argmax(ln[q] > 0))     # first prediction that exists carries the speed
+                    self._batch_agents.append(PhantomAgent(self._create_id(), TYPE_NAME[int(h["type"][j * R])], h["pos0"][j].copy(),
+                                                           float(h["yaw0"][j]), float(v0[q, r0]), float(raw[q, 0]),
+                                                           float(raw[q, 1])))
         return self._batch_agents + self._manual
 
     def sweep_arrays(self):
@@ -363,22 +387,23 @@ class FOAgentManager:
             return self._pred_cache
         out, order = {}, []
         agents = self.phantom_agents
-        n = self._n_batch
-        if n:
+        live = self._live_agents()
+        if live:
             b = self._batch
             R = b.R
-            pos, yaw, v = b.pos[:n * R].cpu().numpy(), b.yaw[:n * R].cpu().numpy(), b.v[:n * R].cpu().numpy()
-            cov, shape, ln = b.cov[:n * R].cpu().numpy(), b.shape[:n * R].cpu().numpy(), b.len[:n * R].cpu().numpy()
-            for j in range(n):
-                a = agents[j]
+            sl = (torch.as_tensor(live, device=b.len.device)[:, None] * R + torch.arange(R, device=b.len.device)[None]).reshape(-1)
+            pos, yaw, v = b.pos[sl].cpu().numpy(), b.yaw[sl].cpu().numpy(), b.v[sl].cpu().numpy()
+            cov, shape, ln = b.cov[sl].cpu().numpy(), b.shape[sl].cpu().numpy(), b.len[sl].cpu().numpy()
+            for q, j in enumerate(live):
+                a = agents[q]
                 a.predictions = []
                 for r in range(R):                      # one prediction per candidate route (agent.py:410-424)
-                    slot, L = j * R + r, int(ln[j * R + r])
+                    k, slot, L = q * R + r, j * R + r, int(ln[q * R + r])
                     if L <= 0:
                         continue
-                    pred = {"orientation_list": yaw[slot, :L], "v_list": v[slot, :L], "pos_list": pos[slot, :L],
-                            "shape": {"length": float(shape[slot, 0]), "width": float(shape[slot, 1])},
-                            "cov_list": cov[slot, :L]}
+                    pred = {"orientation_list": yaw[k, :L], "v_list": v[k, :L], "pos_list": pos[k, :L],
+                            "shape": {"length": float(shape[k, 0]), "width": float(shape[k, 1])},
+                            "cov_list": cov[k, :L]}
                     pid = int(str(a.agent_id) + str(len(a.predictions)))       # agent.py:179-183
                     a.predictions.append(pred)
                     out[pid] = pred

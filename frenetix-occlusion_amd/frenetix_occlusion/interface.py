@@ -11,8 +11,11 @@ per-step stage runs in libfo_hip.so on one MI355X:
 
 Deviations from the reference (documented in DESIGN.md): ``visible_area`` is a ring polygon + cell mask
 (:class:`~frenetix_occlusion.sensor_model.VisibleArea`) instead of a shapely geometry; spawn points come from the
-occluded-cell frontier instead of the three GEOS rule families; no matplotlib (``plot`` is accepted and ignored);
-metric ``'be'`` implies ``'ttc'`` (the reference raises KeyError when ``'be'`` is activated without it).
+occluded-cell frontier (``accelerator.spawn.mode: cells``, the default) and / or from the reference's three rule families
+evaluated on the cell classes (``rules`` / ``both``: fo_scene_spawn_rules -> fo_scene_spawn_rule_agents, device resident --
+the spawn points never leave HBM on their way into the sweep, ``spawn_points`` is a lazily read host view); no matplotlib
+(``plot`` is accepted and ignored); metric ``'be'`` implies ``'ttc'`` (the reference raises KeyError when ``'be'`` is
+activated without it).
 """
 import os
 import time
@@ -67,11 +70,15 @@ class FOInterface:
 
         self.ctx = N.Context(self.device.index)
         self.fo_obstacles = FOObstacles(self.cr_scenario.obstacles)
+        spawn_acc = acc.get("spawn") or {}
+        routes = int(spawn_acc.get("routes", 0))
+        if routes == 0 and str(spawn_acc.get("mode", "cells")) != "cells":
+            routes = 3     # the rule families' vehicles follow the routes of their lanelet (agent.py:283-312)
         self.sensor_model = SensorModel(lanelet_network=self.lanelet_network, ref_path=self.ego_reference_path,
                                         sensor_radius=self.sensor_radius, sensor_angle=self.sensor_angle,
                                         visualization=None, debug=self.debug, ctx=self.ctx,
                                         n_rays=int(acc.get("rays", 720)), cell_size=float(acc.get("cell_size", 0.5)),
-                                        device=self.device.index, routes=int((acc.get("spawn") or {}).get("routes", 0)),
+                                        device=self.device.index, routes=routes,
                                         footprint=str(acc.get("footprint", "polygon")),
                                         enclosed_holes=str(acc.get("enclosed_holes", "transparent")),
                                         cell_visibility=str(acc.get("cell_visibility", "exact")),
@@ -140,16 +147,13 @@ class FOInterface:
         self.fo_obstacles.update_multipolygon()
         t0 = self._tick("visibility_ms", t0)
 
-        # phantom sampling + predictions stay on the device; the spawn-point list is the reference's host view
+        # phantom sampling, the rule families and the predictions of both stay on the device (interface.py:186-198 without
+        # find_spawn_points' polygons and without add_agent); the spawn-point list is the reference's host view, read back
+        # when somebody looks at it
         self.spawn_points = self.spawn_locator.find_spawn_points(self.ego_pos, self.ego_orientation, self.ego_pos_cl,
-                                                                 ego_v)
+                                                                 ego_v, lazy=True)
         t0 = self._tick("spawn_ms", t0)
-        if self.spawn_locator.batch is not None:
-            self.agent_manager.attach_batch(self.spawn_locator.batch, self.spawn_locator.n_cell_points)
-        for sp in self.spawn_locator.rule_points:       # rule-based points become agents the reference's way (:192-198)
-            mode = "lane_center" if sp.source in ("left turn", "right turn") else "ref_path"
-            self.agent_manager.add_agent(pos=sp.position, velocity="default", agent_type=sp.agent_type,
-                                         timestep=self.timestep, horizon=3.0, mode=mode, orientation=sp.orientation)
+        self.agent_manager.attach_batch(self.spawn_locator.batch)
         if self.debug:
             for sp in self.spawn_points:
                 print("Phantom agent of type {} added to scenario at position {}".format(sp.agent_type, sp.position))
@@ -163,7 +167,8 @@ class FOInterface:
                 types[oid] = getattr(t, "value", t) or "car"
             self.agent_manager.set_external_predictions(self.predictions, types)
         self._tick("agents_ms", t0)
-        self.step_timing["n_spawn_points"] = len(self.spawn_points)
+        if self._timing_sync:          # (counting them reads the device)
+            self.step_timing["n_spawn_points"] = len(self.spawn_points)
         self._tick("evaluate_scenario_ms", t_all)
         return self.sensor_model.visible_area
 
@@ -180,7 +185,9 @@ class FOInterface:
         """All candidates of a planning step in one launch.  ``trajectories``: list of trajectory objects
         (``.cartesian.{x,y,theta,v,a}``) or a dict of [M,T] arrays / device tensors.  Returns a
         :class:`~frenetix_occlusion.metrics.metric.BatchAssessment` (``.cost [M,16]``, ``.safe [M]`` on the device), or
-        None when there are no phantom agents (every trajectory is then safe, metric.py:44-45).  With
+        None when the host knows that there are no phantom agents (every trajectory is then safe, metric.py:44-45;
+        while the phantom set of the step has not been looked at from the host, its size stays in HBM and the sweep runs
+        over a possibly empty set -- every trajectory safe as well).  With
         ``mode='full'`` and a list input, later ``trajectory_safety_assessment(t)`` calls for the same objects are
         served from this batch."""
         remember = trajectories if (mode == "full" and not isinstance(trajectories, dict)) else None

@@ -177,9 +177,13 @@ _UNBUILT = object()
 
 
 class _LazyDict(dict):
-    """a dict whose values are produced on first access: every key is there from the start (order, ``in``, ``len`` and
-    iteration are a plain dict's), unbuilt values are placeholders that ``[]``, ``get``, ``items``, ``values``, ``==`` and
-    ``materialize`` replace by the real thing"""
+    """a dict whose values are produced on first access: every key is there from the start (order, ``in`` and ``len`` are
+    a plain dict's), unbuilt values are placeholders that every read replaces by the real thing.
+
+    It stays a ``dict`` subclass (the reference returns plain dicts and a planner may test ``isinstance(r, dict)``), so
+    the C-level shortcuts CPython takes for dicts must not see the placeholders: ``dict(m)``, ``{**m}`` and
+    ``d.update(m)`` copy the raw storage only while ``tp_iter`` is dict's own -- overriding ``__iter__`` / ``keys`` sends
+    them through ``keys()`` + ``__getitem__``; ``pop`` / ``popitem`` / ``setdefault`` / ``|`` are overridden one by one"""
 
     def _build(self, key):
         raise NotImplementedError
@@ -191,8 +195,53 @@ class _LazyDict(dict):
             dict.__setitem__(self, key, v)
         return v
 
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def keys(self):
+        return dict.keys(self)
+
     def get(self, key, default=None):
         return self[key] if key in self else default
+
+    def pop(self, key, *default):
+        if key in self:
+            v = self[key]
+            dict.__delitem__(self, key)
+            return v
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+    def popitem(self):
+        if not len(self):
+            raise KeyError("popitem(): dictionary is empty")
+        k = next(reversed(self))
+        return k, self.pop(k)
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self[key]
+        dict.__setitem__(self, key, default)
+        return default
+
+    def __or__(self, other):
+        if not isinstance(other, dict):
+            return NotImplemented
+        out = dict(self.materialize())
+        out.update(other)
+        return out
+
+    def __ror__(self, other):
+        if not isinstance(other, dict):
+            return NotImplemented
+        out = dict(other)
+        out.update(self)
+        return out
+
+    def __ior__(self, other):
+        dict.update(self, other)
+        return self
 
     def materialize(self):
         for k in list(dict.keys(self)):
@@ -209,6 +258,9 @@ class _LazyDict(dict):
 
     def __eq__(self, other):
         return dict.__eq__(self.materialize(), other.materialize() if isinstance(other, _LazyDict) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
 
     __hash__ = None
 
@@ -291,12 +343,17 @@ class Metric:
         if self._agents_version is not None:
             return
         arrs = self.agent_manager.sweep_arrays()
-        self.sweep.set_agents(*arrs, check=True)
+        # the blocking covariance check only where a caller's matrices can come in: the spawn kernels write diag(var, var)
+        am = self.agent_manager
+        self.sweep.set_agents(*arrs, check=bool(getattr(am, "_manual", True) or getattr(am, "_external", True)))
         self._agents_version = 1
 
     def evaluate_batch(self, trajectories, mode="reduced", remember=None):
         """one launch for the whole candidate set.  trajectories: list of trajectory objects or dict of [M,T] arrays."""
-        if not self.agent_manager.has_phantoms() or not self.metrics:
+        am = self.agent_manager
+        # (a device batch whose live count is still in HBM counts as "may have": asking would stall the step, and a sweep
+        # over inactive slots leaves every trajectory safe)
+        if not (am.may_have_phantoms() if hasattr(am, "may_have_phantoms") else am.has_phantoms()) or not self.metrics:
             return None                                          # metric.py:44-45: ({}, True) for every trajectory
         arr = trajectories_to_arrays(trajectories)
         self._upload_agents()

@@ -293,6 +293,11 @@ class SensorModel:
             self.ctx.call("fo_scene_set_edge_lines", len(edges), line.ctypes.data)
         if lanelets:
             self._set_topology(lanelets)
+            # centre lines: a pedestrian spawned behind a turn heads for the centre of its lanelet (agent.py:459-467)
+            coff = np.zeros(len(lanelets) + 1, dtype=np.int32)
+            coff[1:] = np.cumsum([len(ll.center) for ll in lanelets])
+            cxy = np.ascontiguousarray(np.concatenate([np.asarray(ll.center, dtype=np.float64).reshape(-1, 2) for ll in lanelets]))
+            self.ctx.call("fo_scene_set_centerlines", len(lanelets), coff.ctypes.data, cxy.ctypes.data)
         self.route_table = self.lanelet_raster = None
         if self.routes > 0 and lanelets is not None:
             from .scenario import RouteTable, lanelet_index_raster
@@ -351,18 +356,28 @@ class SensorModel:
         """obstacle corner points / centres / flags of the current step -> HBM (a few hundred bytes)"""
         dev = self.device
         if obstacles is not None and len(obstacles) > 0:
-            corn, cen, flags = obstacles.arrays() if hasattr(obstacles, "arrays") else obstacles
+            yaw = dims = None
+            if hasattr(obstacles, "arrays_full"):      # + what the spawn rule families read (headings, dimensions, role bits)
+                corn, cen, flags, yaw, dims = obstacles.arrays_full()
+            else:
+                corn, cen, flags = obstacles.arrays() if hasattr(obstacles, "arrays") else obstacles
             O = len(flags)
-            # one host buffer, one copy: corners [O,4,2] | centres [O,2] | flags [O]
-            host = np.empty(O * 81, dtype=np.uint8)
+            # one host buffer, one copy: corners [O,4,2] | centres [O,2] | headings [O] | dimensions [O,2] | flags [O]
+            host = np.zeros(O * 105, dtype=np.uint8)
             host[:O * 64].view(np.float64)[:] = np.asarray(corn, dtype=np.float64).reshape(-1)
             host[O * 64:O * 80].view(np.float64)[:] = np.asarray(cen, dtype=np.float64).reshape(-1)
-            host[O * 80:] = np.asarray(flags, dtype=np.uint8)
+            if yaw is not None:
+                host[O * 80:O * 88].view(np.float64)[:] = yaw
+                host[O * 88:O * 104].view(np.float64)[:] = np.asarray(dims, dtype=np.float64).reshape(-1)
+            host[O * 104:] = np.asarray(flags, dtype=np.uint8)
             d = torch.as_tensor(host).to(dev)
             self._obst = (d[:O * 64].view(torch.float64).view(O, 4, 2), d[O * 64:O * 80].view(torch.float64).view(O, 2),
-                          d[O * 80:], O)
+                          d[O * 104:], O)
+            self._obst_rule = (d[O * 80:O * 88].view(torch.float64), d[O * 88:O * 104].view(torch.float64).view(O, 2)) \
+                if yaw is not None else None
         else:
             self._obst = (None, None, None, 0)
+            self._obst_rule = None
         return self._obst
 
     def _buffers(self, w, O):

@@ -1,4 +1,5 @@
-"""Phantom-agent spawn sampling in the occluded cells (host side of ``fo_scene_spawn``, include/fo_hip.h).
+"""Phantom-agent spawn stage (host side of ``fo_scene_spawn`` / ``fo_scene_spawn_rules`` / ``fo_scene_spawn_rule_agents``,
+include/fo_hip.h).
 
 Mirrors the reference's ``SpawnLocator.find_spawn_points(ego_pos, ego_orientation, ego_pos_cl, ego_v)``
 (ref: spawn_locator.py:80-139) and its ``SpawnPoint`` record (:18-27).  The reference finds <= ~5 spawn points with
@@ -9,6 +10,7 @@ constant-velocity predictions of the spawned agents straight into the layout ``f
 phantom set never leaves HBM between sampling and the metric sweep.
 """
 import math
+from collections.abc import Sequence
 from dataclasses import dataclass
 from typing import Optional
 
@@ -38,12 +40,16 @@ class SpawnPoint:
 
 @dataclass
 class PhantomBatch:
-    """device-resident phantom predictions, exactly the argument list of ``MetricSweep.set_agents``"""
-    n: torch.Tensor          # int32 [1]  number of active slots
-    cell: torch.Tensor       # int32 [max_agents] window cell index (-1 = unused slot)
-    pos0: torch.Tensor       # [max_agents,2]
-    yaw0: torch.Tensor       # [max_agents]
-    pos: torch.Tensor        # [slots,T,2]      slots = max_agents * R
+    """device-resident phantom predictions, exactly the argument list of ``MetricSweep.set_agents``.
+
+    Agent axis: ``n_cell_agents`` slots of the cell sampler (``fo_scene_spawn``) first, then ``n_rule_points`` slots of the
+    reference's rule families (``fo_scene_spawn_rules`` -> ``fo_scene_spawn_rule_agents``); every agent owns ``R``
+    consecutive prediction slots (one per candidate route of a phantom vehicle)."""
+    n: torch.Tensor          # int32 [1]  number of active cell-sampled agents
+    cell: torch.Tensor       # int32 [n_cell_agents] window cell index (-1 = unused slot)
+    pos0: torch.Tensor       # [agents,2]     agents = n_cell_agents + n_rule_points
+    yaw0: torch.Tensor       # [agents]
+    pos: torch.Tensor        # [slots,T,2]    slots = agents * R
     yaw: torch.Tensor        # [slots,T]
     v: torch.Tensor          # [slots,T]
     cov: torch.Tensor        # [slots,T,2,2]
@@ -52,23 +58,74 @@ class PhantomBatch:
     type: torch.Tensor       # int32 [slots]
     len: torch.Tensor        # int32 [slots]  (valid samples of the prediction, 0 = unused slot)
     R: int = 1               # prediction slots per agent: slot j * R + r (r = candidate route of a phantom vehicle)
-    head: Optional[torch.Tensor] = None   # uint8: one allocation backing pos0 | yaw0 | n | type (one copy to the host)
+    head: Optional[torch.Tensor] = None   # uint8: one allocation backing pos0 | yaw0 | rule_points | n, rule_n | type
+    n_cell_agents: int = 0
+    n_rule_points: int = 0
+    rule_points: Optional[torch.Tensor] = None   # [n_rule_points, 8] records of fo_scene_spawn_rules
+    rule_n: Optional[torch.Tensor] = None        # int32 [1]
+    _host: Optional[dict] = None                 # host copy of the head for the current step (lazy views)
 
     def sweep_args(self):
         return self.pos, self.yaw, self.v, self.cov, self.shape, self.raw_dims, self.type, self.len
 
+    def invalidate(self):
+        self._host = None
+
     def host_head(self):
-        """(n, pos0 [A,2], yaw0 [A], type [slots]) on the host with ONE device-to-host copy"""
-        A, S_ = self.pos0.shape[0], self.type.shape[0]
-        if self.head is None:
-            return int(self.n.item()), self.pos0.cpu().numpy(), self.yaw0.cpu().numpy(), self.type.cpu().numpy()
-        h = self.head.cpu().numpy()
-        o1, o2, o3 = A * 16, A * 24, A * 24 + 8
-        return (int(h[o2:o2 + 4].view(np.int32)[0]), h[:o1].view(np.float64).reshape(A, 2), h[o1:o2].view(np.float64),
-                h[o3:o3 + 4 * S_].view(np.int32))
+        """dict(n, rule_n, pos0 [agents,2], yaw0 [agents], rule_points [n_rule_points,8], type [slots]) on the host with ONE
+        device-to-host copy per step (cached until :meth:`invalidate`)"""
+        if self._host is None:
+            A, S_, Rp = self.pos0.shape[0], self.type.shape[0], self.n_rule_points
+            h = self.head.cpu().numpy()
+            o1, o2 = A * 16, A * 24
+            o3 = o2 + Rp * 64
+            o4 = o3 + 8
+            cnt = h[o3:o4].view(np.int32)
+            self._host = dict(n=int(cnt[0]) if self.n_cell_agents else 0, rule_n=min(int(cnt[1]), Rp) if Rp else 0,
+                              pos0=h[:o1].view(np.float64).reshape(A, 2), yaw0=h[o1:o2].view(np.float64),
+                              rule_points=h[o2:o3].view(np.float64).reshape(Rp, 8), type=h[o4:o4 + 4 * S_].view(np.int32))
+        return self._host
+
+    def live_agents(self):
+        """agent indices (rows of pos0 / yaw0; first prediction slot = index * R) that are alive this step, cell-sampled
+        agents first, then the rule families' in the reference's order"""
+        h = self.host_head()
+        return list(range(h["n"])) + [self.n_cell_agents + i for i in range(h["rule_n"])]
+
+
+class LazySpawnPoints(Sequence):
+    """``FOInterface.spawn_points`` / the result of ``find_spawn_points(lazy=True)``: the reference's list of
+    :class:`SpawnPoint` (interface.py:186), read back from the device when it is first looked at -- the planning step
+    itself never waits for it."""
+
+    def __init__(self, build):
+        self._build, self._items = build, None
+
+    def _get(self):
+        if self._items is None:
+            self._items = list(self._build())
+            self._build = None
+        return self._items
+
+    def __len__(self):
+        return len(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __eq__(self, other):
+        return self._get() == (other._get() if isinstance(other, LazySpawnPoints) else other)
+
+    def __repr__(self):
+        return repr(self._get())
 
 
 class SpawnLocator:
+    SOURCE_NAME = {1: "behind_dynamic_obstacle", 2: "behind static obstacle", 3: "left turn", 4: "right turn"}
+
     def __init__(self, agent_manager, ref_path, config, sensor_model, cosy_cl=None, fo_obstacles=None,
                  visualization=None, debug=False, max_agents=None, pattern=None, dt=0.1, horizon=3.0):
         self.agent_manager = agent_manager
@@ -94,9 +151,11 @@ class SpawnLocator:
         self.mode = str(acc.get("mode", "cells"))                  # "cells" | "rules" | "both" (fo_scene_spawn_rules)
         if self.mode not in ("cells", "rules", "both"):
             raise ValueError("accelerator.spawn.mode must be 'cells', 'rules' or 'both'")
-        self.rule_points = []
-        self._rules = None
+        # capacity of the rule families' output (the reference's YAML maxima allow 2 + 2 + 1 points, Q11)
+        self.max_rule_points = int(acc.get("max_rule_points", 8))
         self.routes = int(acc.get("routes", 0)) if sensor_model.route_table is not None else 0
+        if self.routes == 0 and sensor_model.route_table is not None and self.mode != "cells":
+            self.routes = int(sensor_model.route_table.R)       # rule vehicles follow their lanelet's routes (agent.py:283-312)
         self.R = max(self.routes, 1)                               # prediction slots per agent
         self.all_occluded = bool(acc.get("all_occluded", False))   # False: only the visible/occluded frontier
         self.max_dist_override = acc.get("max_dist")               # None: the reference's max(4 v, 25) m
@@ -118,36 +177,86 @@ class SpawnLocator:
         self._t4 = np.array(t4, dtype=np.int32)
         self._s4, self._rl, self._rw = np.array(s4), np.array(rl), np.array(rw)
         self._il, self._iw = np.array(il), np.array(iw)
+        # the three agent types the rule families spawn (fo_rule_agent_types_t: 0 Car, 1 Bicycle, 2 Pedestrian)
+        self.rule_types = N.RuleAgentTypes()
+        for i, key in enumerate(("car", "bicycle", "pedestrian")):
+            c = am.get(key)
+            if c is None:
+                continue
+            big = key == "bicycle"
+            fl = pr["size_factor_length_l"] if big else pr["size_factor_length_s"]
+            fw = pr["size_factor_width_l"] if big else pr["size_factor_width_s"]
+            self.rule_types.speed[i] = float(c["default_velocity"])
+            self.rule_types.raw_l[i], self.rule_types.raw_w[i] = float(c["length"]), float(c["width"])
+            self.rule_types.infl_l[i], self.rule_types.infl_w[i] = float(c["length"]) * fl, float(c["width"]) * fw
         self._d_path = torch.as_tensor(self.ref_path).to(self.device)
         self.batch: Optional[PhantomBatch] = None
         self.spawn_points = []
+        self._rule_points, self._n_cell_points = [], 0
+
+    def _settle(self):
+        if isinstance(self.spawn_points, LazySpawnPoints):
+            self.spawn_points._get()
+
+    @property
+    def rule_points(self):
+        """the spawn points of the rule families among ``spawn_points`` (reads them back if that has not happened yet)"""
+        self._settle()
+        return self._rule_points
+
+    @property
+    def n_cell_points(self):
+        self._settle()
+        return self._n_cell_points
+
+    @property
+    def n_cell_agents(self):
+        return self.max_agents if self.mode in ("cells", "both") else 0
+
+    @property
+    def n_rule_points(self):
+        return self.max_rule_points if self.mode in ("rules", "both") else 0
 
     def _alloc(self):
-        dev, A, T = self.device, self.max_agents, self.T
+        dev, T = self.device, self.T
+        Ac, Rp = self.n_cell_agents, self.n_rule_points
+        A = Ac + Rp
         S_ = A * self.R                                            # prediction slots: slot j * R + r
         f = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
         i = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
-        # what find_spawn_points reads back lives in one allocation: pos0 | yaw0 | n (+ pad) | type
-        o1, o2, o3 = A * 16, A * 24, A * 24 + 8
-        head = torch.zeros(o3 + 4 * S_ + 4, dtype=torch.uint8, device=dev)
-        return PhantomBatch(n=head[o2:o2 + 4].view(torch.int32), cell=i(A), pos0=head[:o1].view(torch.float64).view(A, 2),
+        # what the host views read back lives in one allocation: pos0 | yaw0 | rule points | n, rule_n | type
+        o1, o2 = A * 16, A * 24
+        o3 = o2 + Rp * 64
+        o4 = o3 + 8
+        head = torch.zeros(o4 + 4 * S_ + 4, dtype=torch.uint8, device=dev)
+        cnt = head[o3:o4].view(torch.int32)
+        return PhantomBatch(n=cnt[0:1], cell=i(max(Ac, 1)), pos0=head[:o1].view(torch.float64).view(A, 2),
                             yaw0=head[o1:o2].view(torch.float64), pos=f(S_, T, 2), yaw=f(S_, T), v=f(S_, T),
                             cov=f(S_, T, 2, 2), shape=f(S_, 2), raw_dims=f(S_, 2),
-                            type=head[o3:o3 + 4 * S_].view(torch.int32), len=i(S_), R=self.R, head=head)
+                            type=head[o4:o4 + 4 * S_].view(torch.int32), len=i(S_), R=self.R, head=head,
+                            n_cell_agents=Ac, n_rule_points=Rp,
+                            rule_points=head[o2:o3].view(torch.float64).view(Rp, 8) if Rp else None,
+                            rule_n=cnt[1:2] if Rp else None)
 
     def max_distance(self, ego_v):
         if self.max_dist_override is not None:
             return float(self.max_dist_override)
         return max(S_THRESHOLD_TIME * float(ego_v), S_THRESHOLD_MIN)
 
+    def _batch_for_step(self):
+        if self.batch is None:
+            self.batch = self._alloc()
+        self.batch.invalidate()
+        return self.batch
+
     def sample(self, ego_pos, ego_orientation, ego_v) -> PhantomBatch:
         """device-only path: frontier candidates -> evenly spaced pick -> headings -> predictions (no host sync)"""
         sm = self.sensor_model
         if sm.cell_class is None:
             raise RuntimeError("SpawnLocator: call SensorModel.calc_visible_and_occluded_area first")
-        if self.batch is None:
-            self.batch = self._alloc()
-        b, w = self.batch, sm.window
+        if self.n_cell_agents == 0:
+            raise RuntimeError("SpawnLocator.sample: spawn.mode 'rules' has no cell-sampled agents")
+        b, w = self._batch_for_step(), sm.window
         c = lambda a: a.ctypes.data
         self.ctx.call("fo_scene_spawn", sm.cell_class.data_ptr(), w.ix0, w.iy0, w.nx, w.ny, float(ego_pos[0]),
                       float(ego_pos[1]), math.cos(ego_orientation), math.sin(ego_orientation), self.min_ahead,
@@ -160,12 +269,9 @@ class SpawnLocator:
         return b
 
     # ---------------------------------------------------------------- the reference's rule families, on the device
-    SOURCE_NAME = {1: "behind_dynamic_obstacle", 2: "behind static obstacle", 3: "left turn", 4: "right turn"}
-    MAX_RULE_POINTS = 16
-
     def _rule_setup(self):
-        """one-off: the polyline frame of the reference path as the table fo_scene_spawn_rules reads, the output buffers
-        (the lanelet topology belongs to the static map: SensorModel._set_topology)"""
+        """one-off: the polyline frame of the reference path as the table fo_scene_spawn_rules reads, the switches and
+        maxima of the YAML (the lanelet topology belongs to the static map: SensorModel._set_topology)"""
         from .scenario import lanelets_of
         from .utils.curvilinear import PolylineCS
         sm = self.sensor_model
@@ -176,13 +282,9 @@ class SpawnLocator:
         tab[:-1, 3], tab[:-1, 4:6] = self._cs.seg_len, self._cs.tangent
         self._d_path6 = torch.as_tensor(tab).to(self.device)
         try:
-            lanelets = lanelets_of(sm.lanelet_network)
+            P = len(lanelets_of(sm.lanelet_network))
         except Exception:
-            lanelets = []
-        self._rule_lanelets = lanelets
-        P = len(lanelets)
-        self._rule_out = torch.zeros(self.MAX_RULE_POINTS * 8 + 1, dtype=torch.float64, device=self.device)
-        self._rule_n = self._rule_out[-1:].view(torch.int32)[:1]
+            P = 0
         sl = self.config["spawn_locator"]
         ped = self.config["agent_manager"]["pedestrian"]
         self._rule_cfg = dict(behind_static=int(bool(sl.get("spawn_point_behind_static_obstacle", True))),
@@ -193,16 +295,13 @@ class SpawnLocator:
                               ped_width=float(ped["width"]), ped_length=float(ped["length"]))
         self._rules_ready = True
 
-    def _rule_points_device(self, ego_pos, ego_orientation, ego_pos_cl, ego_v):
-        """``spawn.mode: rules``: the three rule families of the reference evaluated by fo_scene_spawn_rules on the cell
-        classes of this step, in HBM; the host supplies the step's scalars (curvilinear ego position, s_threshold,
-        the ego's intention from the curvature of the next 40 m of the reference path, spawn_locator.py:113,678-741)
-        and reads the handful of spawn points back."""
-        import ctypes as C
+    def rule_params(self, ego_pos, ego_orientation, ego_pos_cl, ego_v):
+        """the step's scalars of the rule families (``fo_spawn_rule_params_t``): curvilinear ego position, ``s_threshold``
+        (spawn_locator.py:113), the reference window and the ego's intention from the curvature of the next 40 m of the
+        reference path (:678-741) -- a few host operations on cached tables, nothing is read from the device"""
         from .utils.curvilinear import curvature
         if not getattr(self, "_rules_ready", False):
             self._rule_setup()
-        sm = self.sensor_model
         if ego_pos_cl is None:
             ego_pos_cl = self._cs.convert_to_curvilinear_coords(float(ego_pos[0]), float(ego_pos[1]))
         s_ego = float(ego_pos_cl[0])
@@ -218,84 +317,93 @@ class SpawnLocator:
                 self._intent_key = key
             intention = self._intent
         self.last_intention = ("straight ahead", "left turn", "right turn")[intention]
-        # obstacle attributes the rules read beyond the corner points (one small upload per step)
-        obst = list(self.fo_obstacles) if self.fo_obstacles is not None else []
-        O = len(obst)
-        d_corn, d_cen, d_flags, O_dev = getattr(sm, "_obst", (None, None, None, 0))
-        if O != O_dev:
-            raise RuntimeError("SpawnLocator: the obstacles of this step have not been uploaded (SensorModel.upload_obstacles)")
-        p = lambda t: t.data_ptr() if t is not None else None
-        if O:
-            host = np.zeros(O * 25, dtype=np.uint8)
-            yd = host[:O * 24].view(np.float64).reshape(O, 3)
-            fl = host[O * 24:]
-            for i, o in enumerate(obst):
-                if o.current_pos is None:
-                    continue
-                yd[i] = (o.current_orientation, o.length, o.width)
-                t = str(o.obstacle_type).lower()
-                fl[i] = 1 | (2 if o.occludes else 0) | (4 if o.obstacle_role == "dynamic" else 0) | (8 if t in ("bicycle", "pedestrian") else 0)
-            # (headings, dimensions and flags -- not the positions -- so the block rarely changes from step to step:
-            # uploaded only when it does)
-            key = host.tobytes()
-            if getattr(self, "_rule_obst_key", None) != key:
-                d = torch.as_tensor(host).to(self.device)
-                ydev = d[:O * 24].view(torch.float64).view(O, 3)
-                self._rule_obst_dev = (ydev[:, 0].contiguous(), ydev[:, 1:3].contiguous(), d[O * 24:])
-                self._rule_obst_key = key
-            d_yaw, d_dims, d_fl = self._rule_obst_dev
-            d_vis = sm._buf["ovis"]
-        else:
-            d_yaw = d_dims = d_fl = d_vis = None
-        pr = N.SpawnRuleParams(float(ego_pos[0]), float(ego_pos[1]), float(ego_orientation), s_ego, float(ego_pos_cl[1]),
-                               s_ego + max(float(ego_v) * S_THRESHOLD_TIME, S_THRESHOLD_MIN),
-                               self._rule_cfg["ped_width"], self._rule_cfg["ped_length"], intention, i0, i1,
-                               self._rule_cfg["behind_static"], self._rule_cfg["behind_turn"], self._rule_cfg["behind_dynamic"],
-                               self._rule_cfg["max_static"], self._rule_cfg["max_dynamic"])
-        w = sm.window
+        c = self._rule_cfg
+        return N.SpawnRuleParams(float(ego_pos[0]), float(ego_pos[1]), float(ego_orientation), s_ego, float(ego_pos_cl[1]),
+                                 s_ego + max(float(ego_v) * S_THRESHOLD_TIME, S_THRESHOLD_MIN), c["ped_width"], c["ped_length"],
+                                 intention, i0, i1, c["behind_static"], c["behind_turn"], c["behind_dynamic"], c["max_static"],
+                                 c["max_dynamic"])
+
+    def rule_obstacle_ptrs(self):
+        """(O, corners, centres, headings, dimensions, flags, visibility) device pointers of this step's obstacles as the rule
+        kernels read them: everything ``SensorModel.upload_obstacles`` put into HBM from ``FOObstacles.arrays_full``"""
+        sm = self.sensor_model
+        d_corn, d_cen, d_flags, O = getattr(sm, "_obst", (None, None, None, 0))
+        if O == 0:
+            return (0,) + (None,) * 6
+        rl = getattr(sm, "_obst_rule", None)
+        if rl is None:
+            raise RuntimeError("SpawnLocator: the spawn rule families need the obstacles' headings and dimensions "
+                               "(SensorModel.upload_obstacles with an FOObstacles)")
+        return O, d_corn.data_ptr(), d_cen.data_ptr(), rl[0].data_ptr(), rl[1].data_ptr(), d_flags.data_ptr(), sm._buf["ovis"].data_ptr()
+
+    def queue_rules(self, ego_pos, ego_orientation, ego_pos_cl, ego_v) -> PhantomBatch:
+        """``spawn.mode: rules | both``, device-only: the three rule families of the reference on the cell classes of this
+        step (``fo_scene_spawn_rules``), then their spawn points become phantom agents with predictions in the sweep's layout
+        (``fo_scene_spawn_rule_agents``) -- the reference's find_spawn_points -> add_agent flow (interface.py:186-198) without a
+        read-back.  The host supplies the step's scalars (:meth:`rule_params`)."""
+        import ctypes as C
+        sm = self.sensor_model
+        if sm.cell_class is None:
+            raise RuntimeError("SpawnLocator: call SensorModel.calc_visible_and_occluded_area first")
+        if self.n_rule_points == 0:
+            raise RuntimeError("SpawnLocator.queue_rules: spawn.mode 'cells' has no rule stage")
+        pr = self.rule_params(ego_pos, ego_orientation, ego_pos_cl, ego_v)
+        b = self.batch if self.batch is not None else self._batch_for_step()
+        b.invalidate()
+        O, corn, cen, oyaw, odims, ofl, ovis = self.rule_obstacle_ptrs()
+        w, st = sm.window, N.current_stream(self._dev_index)
         self.ctx.call("fo_scene_spawn_rules", sm.cell_class.data_ptr(), w.ix0, w.iy0, w.nx, w.ny, int(self._d_path6.shape[0]),
-                      self._d_path6.data_ptr(), O, p(d_corn), p(d_cen), p(d_yaw), p(d_dims), p(d_fl), p(d_vis),
-                      C.byref(pr), self.MAX_RULE_POINTS, self._rule_out.data_ptr(), self._rule_n.data_ptr(),
-                      N.current_stream(self._dev_index))
-        # the one read-back of the rule path: into a pinned buffer, then wait for the stream
-        if getattr(self, "_rule_host", None) is None:
-            self._rule_host = torch.empty(self._rule_out.shape, dtype=self._rule_out.dtype).pin_memory()
-        self._rule_host.copy_(self._rule_out, non_blocking=True)
-        torch.cuda.current_stream(self._dev_index).synchronize()
-        h = self._rule_host.numpy()
-        n = int(h[-1:].view(np.int32)[0])
-        pts = []
-        for q in h[:n * 8].reshape(n, 8):
+                      self._d_path6.data_ptr(), O, corn, cen, oyaw, odims, ofl, ovis, C.byref(pr), b.n_rule_points,
+                      b.rule_points.data_ptr(), b.rule_n.data_ptr(), st)
+        a0, s0, T = b.n_cell_agents, b.n_cell_agents * b.R, self.T
+        self.ctx.call("fo_scene_spawn_rule_agents", b.n_rule_points, b.rule_points.data_ptr(), b.rule_n.data_ptr(), self.routes,
+                      C.byref(self.rule_types), int(self.ref_path.shape[0]), self._d_path.data_ptr(), T, self.dt, self.var0,
+                      self.var_factor, b.pos0[a0:].data_ptr(), b.yaw0[a0:].data_ptr(), b.pos[s0:].data_ptr(), b.yaw[s0:].data_ptr(),
+                      b.v[s0:].data_ptr(), b.cov[s0:].data_ptr(), b.shape[s0:].data_ptr(), b.raw_dims[s0:].data_ptr(),
+                      b.type[s0:].data_ptr(), b.len[s0:].data_ptr(), st)
+        return b
+
+    def _points_from_head(self, b):
+        """the reference's SpawnPoint list from the batch's host head (one device-to-host copy per step)"""
+        h = b.host_head()
+        cells, rules = [], []
+        typ = h["type"][:: b.R]                # agent j's type = type of its first prediction slot
+        for j in range(h["n"]):
+            cl = None
+            if self.cosy_cl is not None:
+                try:
+                    cl = np.asarray(self.cosy_cl.convert_to_curvilinear_coords(h["pos0"][j, 0], h["pos0"][j, 1]))
+                except Exception:   # out of the projection domain: the reference skips silently (:228-231)
+                    cl = None
+            cells.append(SpawnPoint(h["pos0"][j].copy(), TYPE_NAME[int(typ[j])], cl, "occluded frontier", float(h["yaw0"][j])))
+        obst = list(self.fo_obstacles) if self.fo_obstacles is not None else []
+        for q in h["rule_points"][:h["rule_n"]]:
             src = self.SOURCE_NAME[int(q[6])]
             if int(q[6]) == 2:
                 src += " " + str(obst[int(q[7])].obstacle_id)             # spawn_locator.py:462
             cl = None if np.isnan(q[4]) else np.array([q[4], q[5]])
-            pts.append(SpawnPoint(np.array([q[1], q[2]]), TYPE_NAME[int(q[0])], cl, src, None if np.isnan(q[3]) else float(q[3])))
-        return pts
+            rules.append(SpawnPoint(np.array([q[1], q[2]]), TYPE_NAME[int(q[0])], cl, src, None if np.isnan(q[3]) else float(q[3])))
+        return cells, rules
 
-    def find_spawn_points(self, ego_pos, ego_orientation, ego_pos_cl, ego_v):
-        """reference signature (spawn_locator.py:80): returns list[SpawnPoint].  Cell-sampled points come from the
-        device (one small D2H copy); rule-based points (mode 'rules' / 'both') come from ``fo_scene_spawn_rules`` -- the
-        reference's three rule families on the device -- and are turned into agents by the caller through
-        ``FOAgentManager.add_agent``."""
-        self.spawn_points, self.rule_points = [], []
+    def _materialize(self, b):
+        cells, rules = self._points_from_head(b)
+        self._n_cell_points, self._rule_points = len(cells), rules
+        return cells + rules
+
+    def find_spawn_points(self, ego_pos, ego_orientation, ego_pos_cl, ego_v, lazy=False):
+        """reference signature (spawn_locator.py:80): returns list[SpawnPoint].  Everything is decided on the device --
+        cell-sampled points by ``fo_scene_spawn``, the reference's three rule families (mode 'rules' / 'both') by
+        ``fo_scene_spawn_rules`` -- and the agents with their predictions are written there too; the list is the host's view
+        of it.  ``lazy=True`` (what FOInterface.evaluate_scenario uses) returns a :class:`LazySpawnPoints` that reads the
+        points back when first looked at, so that the step itself never waits for the device."""
+        self.spawn_points, self._rule_points, self._n_cell_points = [], [], 0
+        b = self._batch_for_step()
         if self.mode in ("cells", "both"):
-            b = self.sample(ego_pos, ego_orientation, ego_v)
-            n, pos0, yaw0, typ_slots = b.host_head()
-            typ = typ_slots[:: b.R]                # agent j's type = type of its first prediction slot
-            for j in range(n):
-                cl = None
-                if self.cosy_cl is not None:
-                    try:
-                        cl = np.asarray(self.cosy_cl.convert_to_curvilinear_coords(pos0[j, 0], pos0[j, 1]))
-                    except Exception:   # out of the projection domain: the reference skips silently (:228-231)
-                        cl = None
-                self.spawn_points.append(SpawnPoint(pos0[j].copy(), TYPE_NAME[int(typ[j])], cl, "occluded frontier",
-                                                    float(yaw0[j])))
-        else:
-            self.batch = None
-        self.n_cell_points = len(self.spawn_points)
+            self.sample(ego_pos, ego_orientation, ego_v)
         if self.mode in ("rules", "both"):
-            self.rule_points = self._rule_points_device(ego_pos, ego_orientation, ego_pos_cl, ego_v)
-            self.spawn_points = self.spawn_points + self.rule_points
+            self.queue_rules(ego_pos, ego_orientation, ego_pos_cl, ego_v)
+        if lazy:
+            self.spawn_points = LazySpawnPoints(lambda: self._materialize(b))
+        else:
+            self.spawn_points = self._materialize(b)
         return self.spawn_points

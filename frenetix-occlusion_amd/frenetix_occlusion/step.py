@@ -1,5 +1,5 @@
 """One planning step in one native call (``fo_step_run``, include/fo_hip.h): ray fan -> cell classes -> phantom sampling
-+ predictions -> agent table -> metric sweep -> threshold reduction.
+and / or the reference's spawn rule families + predictions -> agent table -> metric sweep -> threshold reduction.
 
 ``PlanningStep`` binds a :class:`SensorModel`, a :class:`SpawnLocator`, a :class:`MetricSweep` (one ego, one context) and
 the candidate-trajectory tensors of a planning loop; :meth:`run` updates the handful of per-step scalars in a
@@ -43,8 +43,8 @@ class PlanningStep:
         if mode == "full":
             self.out.lists_raw = torch.empty((N.NL * A * max(self.T - 1, 0) * self.M,), dtype=ldt, device=dev)
         self.out.lists_shape = (A, max(self.T - 1, 0), self.M)
-        self.ctx.call("fo_sweep_set_list_format", N.LISTS_F32 if lists == "f32" else N.LISTS_F64)
-        sweep._list_format = lists
+        # (the list format is a member of the step structure: every run re-asserts it, whatever other callers of the
+        # context have set in between)
         sweep.reserve(self.M, self.T, A, spawn_locator.T)
         self._s = None
         self._key = None
@@ -60,8 +60,7 @@ class PlanningStep:
         s.d_dirs, s.d_rmax, s.d_half = p(dirs), p(rmax) if poly else None, p(half) if poly else None
         s.full_circle = 1 if sm.sensor_angle >= 359.9 else 0
         s.exact_cells = 1 if sm.cell_visibility == "exact" else 0
-        d_corn, d_cen, d_flags, _ = getattr(sm, "_obst", (None, None, None, 0))
-        s.O, s.d_ocorn, s.d_ocen, s.d_oflags = O, p(d_corn), p(d_cen), p(d_flags)
+        s.O = O
         buf = sm._buffers(w, O)
         s.win_nx, s.win_ny = w.nx, w.ny
         s.d_range, s.d_hit_id, s.d_ring, s.d_obst_vis = p(buf["rng"]), p(buf["hit"]), p(buf["ring"]), p(buf["ovis"])
@@ -78,19 +77,42 @@ class PlanningStep:
         s.d_x, s.d_y, s.d_theta, s.d_vel, s.d_acc = (p(q) for q in self.traj)
         o = self.out
         s.d_cost, s.d_safe, s.d_pair_f, s.d_pair_i, s.d_lists = p(o.cost), p(o.safe), p(o.pair_f), p(o.pair_i), p(o.lists_raw)
+        s.list_format = N.LISTS_F32 if self.lists == "f32" else N.LISTS_F64
+        s.spawn_mode = N.SPAWN_MODE[sl.mode]
+        if sl.mode != "cells":       # the reference's rule families, device resident
+            if not getattr(sl, "_rules_ready", False):
+                sl._rule_setup()
+            s.n_path6, s.d_path6 = int(sl._d_path6.shape[0]), p(sl._d_path6)
+            s.max_rule_points, s.d_rule_points, s.d_n_rule_points = b.n_rule_points, p(b.rule_points), p(b.rule_n)
+            s.rule_types = sl.rule_types
         self._buf = buf
         return s
 
-    def run(self, ego_pos, ego_orientation, ego_v) -> SweepResult:
-        """queue one planning step on the current stream; returns the (reused) device outputs"""
+    def run(self, ego_pos, ego_orientation, ego_v, ego_pos_cl=None) -> SweepResult:
+        """queue one planning step on the current stream; returns the (reused) device outputs.  ``ego_pos_cl``: the ego's
+        curvilinear position (s, d) for the spawn rule families (default: its projection on the reference path)"""
         sm, sl = self.sm, self.sl
         yaw = float(ego_orientation)
         w = sm._window_for(ego_pos)
         O = getattr(sm, "_obst", (None, None, None, 0))[3]
-        key = (w.nx, w.ny, O, id(getattr(sm, "_obst", (None,))[0]))
+        key = (w.nx, w.ny, O)
         if self._s is None or key != self._key:
             self._s, self._key = self._fill(w, O), key
         s = self._s
+        # the obstacle tensors are re-allocated by every upload_obstacles: their pointers are per-step members (and the
+        # tensors stay referenced here for as long as the structure points at them)
+        self._obst_ref = (getattr(sm, "_obst", (None, None, None, 0)), getattr(sm, "_obst_rule", None))
+        d_corn, d_cen, d_flags, _ = self._obst_ref[0]
+        q = lambda t: None if t is None else t.data_ptr()
+        s.d_ocorn, s.d_ocen, s.d_oflags = q(d_corn), q(d_cen), q(d_flags)
+        if sl.mode != "cells":
+            rl = self._obst_ref[1]
+            if O and rl is None:
+                raise RuntimeError("PlanningStep: the spawn rule families need the obstacles' headings and dimensions "
+                                   "(SensorModel.upload_obstacles with an FOObstacles)")
+            s.d_oyaw, s.d_odims = (q(rl[0]), q(rl[1])) if O else (None, None)
+            s.rule = sl.rule_params(ego_pos, yaw, ego_pos_cl, ego_v)
+        self.batch.invalidate()
         skip = sm._edge_skip_for(sm.enclosed_hole_rings(ego_pos, yaw))
         s.d_edge_skip = None if skip is None else skip.data_ptr()
         s.ego_yaw, s.ego_x, s.ego_y, s.head_x, s.head_y = yaw, float(ego_pos[0]), float(ego_pos[1]), math.cos(yaw), math.sin(yaw)
@@ -103,4 +125,5 @@ class PlanningStep:
         sm.range, sm.hit_id, sm.cell_class = b["rng"], b["hit"], b["cls"]
         sm.occluded_idx_buffer, sm.n_occluded = b["occ"], b["n_occ"]
         self.sw.A, self.sw.Ta = int(self.batch.pos.shape[0]), sl.T
+        self.ctx.list_format = self.lists
         return self.out

@@ -154,9 +154,9 @@ class MetricSweep:
         if lists not in ("f64", "f32"):
             raise ValueError(f"unknown list format '{lists}'")
         ldt = torch.float32 if lists == "f32" else torch.float64
-        if lists != getattr(self, "_list_format", "f64"):
+        if lists != getattr(self.ctx, "list_format", "f64"):     # per-context state: cached on the Context, not here
             self.ctx.call("fo_sweep_set_list_format", N.LISTS_F32 if lists == "f32" else N.LISTS_F64)
-            self._list_format = lists
+            self.ctx.list_format = lists
         ins = [x, y, theta, v] + ([a] if a is not None else [])
         if all(isinstance(q, np.ndarray) and q.ndim == 2 and q.shape == ins[0].shape for q in ins) and ins[0].size:
             up = self._upload_packed(ins)

@@ -84,3 +84,18 @@ class FOObstacles:
             corn[i], cen[i] = o.current_corner_points, o.current_pos
             flags[i] = 1 | (2 if o.occludes else 0)
         return corn, cen, flags
+
+    def arrays_full(self):
+        """``arrays()`` plus what the spawn rule families read (fo_scene_spawn_rules): headings [O], dimensions [O,2]
+        (length, width), and two more flag bits -- bit2 dynamic role, bit3 type bicycle or pedestrian
+        (spawn_locator.py:209-210).  The visibility kernels test bits 0 and 1 only, so one flag array serves both."""
+        corn, cen, flags = self.arrays()
+        O = len(self.fo_obstacles)
+        yaw, dims = np.zeros(O), np.zeros((O, 2))
+        for i, o in enumerate(self.fo_obstacles):
+            if o.current_pos is None:
+                continue
+            yaw[i], dims[i] = o.current_orientation, (o.length, o.width)
+            t = str(o.obstacle_type).lower()
+            flags[i] |= (4 if o.obstacle_role == "dynamic" else 0) | (8 if t in ("bicycle", "pedestrian") else 0)
+        return corn, cen, flags, yaw, dims

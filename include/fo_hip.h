@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 7
+#define FO_ABI_VERSION 8
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -275,6 +275,38 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
                          const double *d_odims, const uint8_t *d_oflags, const uint8_t *d_obst_vis,
                          const fo_spawn_rule_params_t *params, int max_out, double *d_out, int32_t *d_n_out, void *stream);
 
+/* One-off, optional, after fo_scene_set_map (HOST arrays, lanelet index = order of the polygons): the centre line of every
+ * lanelet, vertices xy[off[p] .. off[p+1]).  Read by fo_scene_spawn_rule_agents: a pedestrian spawned behind a turn heads
+ * for the centre of the lanelet it stands on (mode 'lane_center', agent.py:459-467; interface.py:194).  Part of the
+ * static map (FO_E_STATE while the map is shared, like fo_scene_set_routes). */
+int fo_scene_set_centerlines(fo_ctx *ctx, int P, const int32_t *h_off, const double *h_xy);
+
+/* per agent type the rule families spawn -- index 0 Car, 1 Bicycle, 2 Pedestrian: default speed, un-inflated and inflated
+ * dimensions (YAML agent_manager section; agent.py:69-140,402-409,523-524) */
+typedef struct { double speed[3], raw_l[3], raw_w[3], infl_l[3], infl_w[3]; } fo_rule_agent_types_t;
+
+/* Per step, after fo_scene_spawn_rules on the same stream: the rule families' spawn points become phantom agents ON THE
+ * DEVICE (replaces the loop over spawn points of FOInterface.evaluate_scenario, interface.py:186-198, with
+ * FOAgentManager.add_agent, agent.py:46-141, OAPPedestrianAgent, :429-536, and OAPVehicleAgent, :283-426, behind it).
+ * d_points [max_points][8] / d_n_points [1]: the records fo_scene_spawn_rules wrote (read in HBM, never on the host).
+ * Point i owns R = max(routes, 1) prediction slots i * R + r of the outputs, which have the layout
+ * fo_sweep_set_agents consumes (slots of points >= *d_n_points and unused route slots get len 0):
+ *   Pedestrian -> heading = the record's (static-obstacle rule: lanelet heading + 90 deg, spawn_locator.py:459-460) or,
+ *     when the record carries none, the unit normal towards a curve (agent.py:475-481): the centre line of the first
+ *     lanelet that holds the point for the turn rules (mode 'lane_center'; the ego reference path when the point is on
+ *     no lanelet -- the reference's latent None there is not reproduced, Q12), the ego reference path d_path
+ *     [n_path][2] otherwise (mode 'ref_path'); straight constant-velocity prediction in slot r = 0 (agent.py:483-505);
+ *   Car / Bicycle -> the first lanelet that holds the point; with routes > 0 (fo_scene_set_routes) one prediction per
+ *     candidate route of that lanelet (the min-var(v) Frenet sample, see fo_scene_spawn), heading of record = first
+ *     segment of route 0; off-lanelet or without a route table: heading towards d_path, one straight prediction.
+ * d_pos0 [max_points][2] / d_yaw0 [max_points]: spawn position and initial heading per point (host views read them
+ * lazily). */
+int fo_scene_spawn_rule_agents(fo_ctx *ctx, int max_points, const double *d_points, const int32_t *d_n_points, int routes,
+                               const fo_rule_agent_types_t *types, int n_path, const double *d_path, int T, double dt,
+                               double var0, double var_factor, double *d_pos0, double *d_yaw0, double *d_pos, double *d_yaw,
+                               double *d_v, double *d_cov, double *d_shape, double *d_raw_dims, int32_t *d_type,
+                               int32_t *d_len, void *stream);
+
 /* ---- one planning step in one call: fo_scene_fan -> fo_scene_visibility -> fo_scene_spawn -> fo_sweep_set_agents ->
  *      fo_sweep_run on one stream, with the arguments of those five entry points (same names, same meaning) in one
  *      structure.  What it replaces is the reference's FOInterface.evaluate_scenario + M x trajectory_safety_assessment
@@ -286,7 +318,10 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
  *      stage and returns its code.  Every output buffer ends up with the bits the five calls would have written; the
  *      step itself runs in nine launches instead of twelve (the ray fan is worked out inside the ray kernel, the
  *      sampler's candidate cells are flagged during the compaction of the occluded cells, the prediction kernel writes
- *      its slots' rows of the sweep's agent table).  FO_STEP_STAGES=1 in the environment: the plain five calls. */
+ *      its slots' rows of the sweep's agent table).  FO_STEP_STAGES=1 in the environment: the plain stage calls.
+ *      With spawn_mode FO_SPAWN_RULES / FO_SPAWN_BOTH the rule families run between the visibility and the sweep:
+ *      fo_scene_spawn_rules (two launches) and fo_scene_spawn_rule_agents (one, which also writes its slots' rows of the
+ *      agent table) -- the reference's find_spawn_points -> add_agent flow (interface.py:186-198) without leaving HBM. */
 typedef struct {
   /* fo_scene_fan */
   int32_t n_rays, polygon_footprint;
@@ -324,7 +359,26 @@ typedef struct {
   double *d_pair_f;
   int32_t *d_pair_i;
   double *d_lists;
+  /* element type of d_lists for THIS run (FO_LISTS_F64 / FO_LISTS_F32); the step sets the context's format to it before
+   * the sweep, so a stale fo_sweep_set_list_format of another caller cannot make the kernel write the other width */
+  int32_t list_format;
+  /* Which spawn stage feeds the sweep (interface.py:186-198).  FO_SPAWN_CELLS: fo_scene_spawn, the build's own sampling in
+   * the occluded cells.  FO_SPAWN_RULES: the reference's three rule families, fo_scene_spawn_rules ->
+   * fo_scene_spawn_rule_agents, device resident (no read-back, no host add_agent).  FO_SPAWN_BOTH: cells first, then
+   * rules.  Slot layout of the prediction arrays d_pos ... d_len: [max_agents * R] cell slots (FO_SPAWN_RULES: none),
+   * then [max_rule_points * R] rule slots, R = max(routes, 1); d_pos0 / d_yaw0 hold max_agents (+ max_rule_points)
+   * entries the same way. */
+  int32_t spawn_mode;
+  /* fo_scene_spawn_rules (d_cls + window, obstacles as above; d_oflags then carries the rule bits 2 and 3 as well) and
+   * fo_scene_spawn_rule_agents (d_path, T_agents, dt, var0, var_factor, routes as above) */
+  int32_t n_path6, max_rule_points;
+  const double *d_path6, *d_oyaw, *d_odims;
+  fo_spawn_rule_params_t rule;
+  fo_rule_agent_types_t rule_types;
+  double *d_rule_points;
+  int32_t *d_n_rule_points;
 } fo_step_t;
+enum { FO_SPAWN_CELLS = 0, FO_SPAWN_RULES = 1, FO_SPAWN_BOTH = 2 };
 int fo_step_run(fo_ctx *ctx, const fo_step_t *step, void *stream);
 
 #ifdef __cplusplus

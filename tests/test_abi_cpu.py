@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(native):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fo_hip.h but not exported"
     assert sorted(native.EXPORTS) == declared
-    assert lib.fo_abi_version() == 7
+    assert lib.fo_abi_version() == 8
     import __graft_entry__ as g
     assert native.build_id() == g.source_id()      # the library in the tree is the tree's
 
@@ -79,3 +79,22 @@ def test_c_example_compiles_as_plain_c(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
         assert r.returncode == 1 and "fo_create failed" in r.stderr
+
+
+def test_ctypes_structures_have_the_layout_of_the_header(native, tmp_path):
+    """the ctypes mirrors of fo_step_t / fo_spawn_rule_params_t / fo_rule_agent_types_t (frenetix_occlusion/_native.py) against
+    what a C compiler makes of include/fo_hip.h: size and the offset of every member"""
+    import ctypes as C
+    import subprocess
+    fields = [n for n, *_ in native.Step._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "fo_hip.h"', 'int main(void) {',
+             'printf("%zu %zu %zu\\n", sizeof(fo_step_t), sizeof(fo_spawn_rule_params_t), sizeof(fo_rule_agent_types_t));']
+    lines += ['printf("%%zu\\n", offsetof(fo_step_t, %s));' % f for f in fields]
+    lines += ['return 0; }']
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", str(src), "-I" + os.path.join(ROOT, "include"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(v) for v in out[:3]] == [C.sizeof(native.Step), C.sizeof(native.SpawnRuleParams), C.sizeof(native.RuleAgentTypes)]
+    assert [int(v) for v in out[3:]] == [getattr(native.Step, f).offset for f in fields]

@@ -280,3 +280,45 @@ def test_pedestrian_heading_without_a_given_orientation_known_answers():
     # the velocity components are rounded to 3 decimals (agent.py:492-493, Q12)
     p = c.predictions[0]["pos_list"]
     np.testing.assert_allclose(p[10] - p[0], [round(1.4 * math.cos(c.initial_orientation), 3), round(1.4 * math.sin(c.initial_orientation), 3)], atol=1e-12)
+
+
+def test_lazy_result_dicts_never_leak_placeholders_through_dict_fast_paths():
+    """The per-trajectory result is a dict SUBCLASS with lazily built values (metrics/metric.py); CPython copies a dict
+    subclass through C shortcuts that bypass ``__getitem__`` unless ``__iter__`` is overridden.  Every way a planner may
+    copy or merge the result must deliver built values (the reference returns plain dicts, metric.py:35-100)."""
+    from frenetix_occlusion.metrics import metric as MM
+
+    class Lazy(MM._LazyDict):
+        def __init__(self, keys, depth=1):
+            super().__init__((k, MM._UNBUILT) for k in keys)
+            self.built, self.depth = [], depth
+
+        def _build(self, key):
+            self.built.append(key)
+            return Lazy(("x", "y"), 0) if (self.depth and key == "hr") else ("built", key)
+
+    plain = {"cp": ("built", "cp"), "hr": {"x": ("built", "x"), "y": ("built", "y")}, "wttc": ("built", "wttc")}
+    mk = lambda: Lazy(("cp", "hr", "wttc"))
+    assert isinstance(mk(), dict)
+    assert dict(mk()) == plain and {**mk()} == plain and mk().copy() == plain
+    d = {}
+    d.update(mk())
+    assert d == plain
+    assert ({"a": 1} | mk()) == {"a": 1, **plain} and (mk() | {"a": 1}) == {**plain, "a": 1}
+    m = mk()
+    assert {**m}["hr"]["x"] == ("built", "x")
+    assert m.pop("cp") == ("built", "cp") and "cp" not in m and m.pop("cp", 7) == 7
+    with pytest.raises(KeyError):
+        m.pop("cp")
+    assert m.popitem() == ("wttc", ("built", "wttc")) and list(m) == ["hr"]
+    assert m.setdefault("hr", 0) == {"x": ("built", "x"), "y": ("built", "y")} and m.setdefault("new", 5) == 5
+    m = mk()
+    assert list(m.keys()) == ["cp", "hr", "wttc"] and len(m) == 3 and "hr" in m and m.built == []   # keys cost nothing
+    assert m.get("wttc") == ("built", "wttc") and m.built == ["wttc"] and m.get("nope", 3) == 3
+    assert [v for _, v in mk().items()][0] == ("built", "cp") and list(mk().values())[2] == ("built", "wttc")
+    assert mk() == plain and not (mk() != plain) and mk() == mk()
+    import copy
+    import pickle
+    assert pickle.loads(pickle.dumps(mk())) == plain and copy.deepcopy(mk()) == plain
+    assert all(v is not MM._UNBUILT for v in dict(mk()).values())
+    assert "_UNBUILT" not in repr(mk()) and "object object" not in repr(mk())

@@ -152,7 +152,8 @@ def test_manual_agents_and_error_conventions(torch_cuda, oracle, tmp_path):
 def test_rule_based_spawn_points_through_the_interface(torch_cuda, oracle, tmp_path):
     """accelerator.spawn.mode = rules / both on scenario 3 (right turn at an intersection, parked car in the side
     street): the reference's 'behind turn' rule evaluated on the GPU's cell classes puts a pedestrian behind the
-    corner; rule points become agents through add_agent and are assessed like every other phantom."""
+    corner; rule points become agents on the device (fo_scene_spawn_rule_agents) and are assessed like every other
+    phantom."""
     import yaml
     from frenetix_occlusion import interface
     from frenetix_occlusion import scenario as S

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""ms per step of `spawn.mode: rules` (the reference's rule families on the device) on the scenario-1 fixture: scene stage
-+ fo_scene_spawn_rules + the read-back of the spawn points, as SpawnLocator.find_spawn_points issues them."""
+"""ms per step of `spawn.mode: rules` (the reference's rule families on the device) on the scenario-1 fixture:
+fo_scene_spawn_rules + fo_scene_spawn_rule_agents as SpawnLocator.find_spawn_points issues them, with and without the
+read-back of the spawn-point list (the planning step itself never reads it: lazy view)."""
 import math
 import os
 import sys
@@ -40,19 +41,18 @@ for step in (0, 8, 25, 60):
         pts = sl.find_spawn_points(ego, yaw, None, float(ego0[3]))
     dt_rules = (time.perf_counter() - t0) / n
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    sl._rule_out.zero_()
     torch.cuda.synchronize()
     # device time of the two rule kernels alone (events around the launches, no read-back)
     import frenetix_occlusion.spawn_locator as SLM
     cpu = torch.Tensor.cpu
     e0.record()
     for _ in range(50):
-        sl._rule_points_device(ego, yaw, None, float(ego0[3]))
+        sl.find_spawn_points(ego, yaw, None, float(ego0[3]), lazy=True)
     e1.record()
     torch.cuda.synchronize()
     print(f"step {step}: {len(pts)} rule points ({[p.agent_type for p in pts]}), find_spawn_points {dt_rules * 1e3:.3f} ms "
-          f"(host + device + read-back), per call by events {e0.elapsed_time(e1) / 50:.3f} ms")
+          f"(host + device + read-back), device only (rules + agents, lazy list) by events {e0.elapsed_time(e1) / 50:.3f} ms")
     if os.environ.get("FO_RULE_TRACE"):
-        h = sl._rule_out.cpu().numpy()[120:128]
+        h = sl.batch.rule_points.cpu().numpy()[-1]
         if h[0] != 0:
             print("   dynamic-rule phases (us): ", np.round(np.diff(h[:7]) * 0.01, 1).tolist(), "(membership, labelling, sizes, centroid+checks, car fit, bicycle fit)")
