@@ -731,6 +731,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #ifndef FO_X
 #define FO_X 0       // timing experiments only (tools/build_variant.sh x1 -DFO_X=1 ...): 1 no pass 2, 2 no probe, 4 no harm
 #endif               // geometry in pass 1, 8 pass 2 without its arithmetic, 32 no DCE in pass 1, 64 no gate, 128 no second (correlated) body -- WRONG results
+enum { HM_LR4S = 0, HM_DVMAX = 1, HM_GENERIC = 2 };   // pass-2 bodies by harm model (see dvmax_mode in the kernel)
 constexpr int TC = FO_TC;
 constexpr int DVR = TC + 1;          // rows of the per-wave ring of relative speeds: samples t0-1 .. t1-1 are live at once
 constexpr int WROWS = TC + DVR;      // LDS rows (64 doubles each) per wave
@@ -1024,7 +1025,12 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     // the speed coefficients (both slopes <= 0): the smallest logistic argument belongs to the LARGEST relative speed,
     // fma(k, dv, c) is monotonic in dv and so is its rounding -- pass 1 keeps the running maximum of dv (as -dv in
     // nze_min, no new register) and pass 2 visits the gate rows only.  Wave-uniform.
-    const bool dvmax_mode = FO_DIET && LISTS == LST_NONE && prot == 0 && C[10] <= 0.0 && C[11] <= 0.0 && !(FO_X & 8);
+    // (round 4: in EVERY output mode -- the per-wave ring holds the SQUARED relative speed, pass 1 takes no square root, and
+    // pass 2 runs one of three bodies chosen once per agent: HM_DVMAX for these agents, HM_LR4S, HM_GENERIC for the rest
+    // -- agents without a harm model, speed coefficients of unusual sign.  With the lists the running maximum is kept by
+    // pass 2, which walks every sample anyway; without them by pass 1, and pass 2 visits the gate rows only.  The maxima are
+    // the same arithmetic in all three output modes: logistic at sqrt(max dv^2).)
+    const bool dvmax_mode = FO_DIET && prot == 0 && C[10] <= 0.0 && C[11] <= 0.0 && !(FO_X & 8);
     // List stores: the three blocks (cp | harm pairs | risk pairs) from per-agent scalar bases plus two running 32-bit
     // lane offsets (element size 1x and 2x) -- no 64-bit address arithmetic per sample (fo_sweep_run sends batches whose
     // (T-1) M pair elements pass 4 GB to the generic kernel)
@@ -1318,13 +1324,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           pvx = g2[8]; pvy = g2[9];
         }
         if (geo && t < Lh && !(FO_X & 4)) {
-#if FO_DIET
-          const double dvv = fo_sqrt(fma(dvx, dvx, dvy * dvy));   // (<= 1e4: the prep kernels cap the speeds at 5e3 m/s)
-          dvw[(t - gbase) * TILE + lane] = dvv;
-          if (LISTS == LST_NONE && dvmax_mode) nze_min = fo_vmin_neg(nze_min, dvv);
-#else
-          dvw[(t - gbase) * TILE + lane] = fmin(fo_sqrt(fma(dvx, dvx, dvy * dvy)), 1.0e4);
-#endif
+          // squared (<= 1e8: the prep kernels cap the speeds at 5e3 m/s); pass 2 takes the root where it needs the speed
+          const double dv2_ = fma(dvx, dvx, dvy * dvy);
+          dvw[(t - gbase) * TILE + lane] = dv2_;
+          if (LISTS == LST_NONE && dvmax_mode) nze_min = fo_vmin_neg(nze_min, dv2_);
           if (lr4s) {
             // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
             double ddx = px - ex, ddy = py - ey;
@@ -1384,9 +1387,13 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       if ((do_cp || do_hr) && g0s < g1s && !(FO_X & 1)) {
         // one instantiation per harm model: the LR4S path (impact classes -> logistic offsets) and the pedestrian /
         // LR1S path keep separate register and constant sets
-        auto pass2 = [&](auto lr4s_tag) {
-          constexpr bool LR4S = decltype(lr4s_tag)::value;
+        auto pass2 = [&](auto hm_tag) {
+          constexpr int HM = decltype(hm_tag)::value;
+          constexpr bool LR4S = HM == HM_LR4S, DVMAX = HM == HM_DVMAX;
           const double ke_ = hk[0], ko_ = hk[1], ce_ = hk[2], co_ = hk[3];
+          // float32 list entries of the two-coefficient models: logistic arguments in units of ln 2 (v_exp_f32 is 2^x)
+          const float kef_ = (float)(ke_ * 1.4426950408889634), kof_ = (float)(ko_ * 1.4426950408889634);
+          const float cef_ = (float)(ce_ * 1.4426950408889634), cof_ = (float)(co_ * 1.4426950408889634);
           // LDS reads of sample t+1 are issued while sample t is evaluated
           double dvn = dvw[(g0s - gbase) * TILE + lane];
           double zen = 0.0, zon = 0.0;
@@ -1405,13 +1412,13 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           if (geo && Lh < g1s) hvrows = ~(~0u << max(Lh - gbase, 0));
           slow = __builtin_amdgcn_readfirstlane(slow | ~hvrows);
           hvrows = __builtin_amdgcn_readfirstlane(hvrows);
-          if (LISTS == LST_NONE && !LR4S && dvmax_mode) {
-            // only the rows that take the long way; the harm maxima come from the running maximum of dv (epilogue)
+          if (LISTS == LST_NONE && DVMAX) {
+            // only the rows that take the long way; the harm maxima come from the running maximum of dv^2 (epilogue)
             unsigned todo = slow & (~0u << (g0s - gbase)) & ~(~0u << (g1s - gbase));
             while (todo) {
               const int row = __builtin_ctz(todo), t = gbase + row;
               todo &= todo - 1u;
-              const double dv = dvw[row * TILE + lane];
+              const double dv = fo_sqrt(dvw[row * TILE + lane]);
               double cp = 0.0;
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
               if ((hvrows >> row) & 1u) {
@@ -1443,8 +1450,26 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 eh = dv; oh = ze + zo;
                 return;
               }
+              if (DVMAX) {
+                // two-coefficient model, the usual signs: the maxima come from the running maximum of dv^2 (epilogue); what
+                // is left per sample is the list entry -- float64: root + two table logistics; float32: root, two fmas
+                // and two logistics on the hardware transcendentals (|error| < 4e-7: v_sqrt_f32 and the float32 fma add
+                // 1e-7 |nz| to the argument, the slope of the logistic is <= 1/4)
+                if (LISTS != LST_NONE) nze_min = fo_vmin_neg(nze_min, dv);
+                if (LISTS == LST_F64) {
+                  const double dvs = fo_sqrt(dv);
+                  eh = fo_logistic_neg<false>(exp_tab, fma(ke_, dvs, ce_));
+                  oh = fo_logistic_neg<false>(exp_tab, fma(ko_, dvs, co_));
+                } else if (LISTS == LST_F32) {
+                  const float dvf = __builtin_amdgcn_sqrtf((float)dv);
+                  ehf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(kef_, dvf, cef_)));
+                  ohf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(kof_, dvf, cof_)));
+                }
+                return;
+              }
               const bool model = LR4S || prot == 0;   // wave-uniform; otherwise harm is 1 on both sides
-              const double nze = LR4S ? fma(ke_, dv, ze) : fma(ke_, dv, ce_), nzo = LR4S ? fma(ko_, dv, zo) : fma(ko_, dv, co_);
+              const double dvs = fo_sqrt(dv);          // (the ring holds dv^2)
+              const double nze = LR4S ? fma(ke_, dvs, ze) : fma(ke_, dvs, ce_), nzo = LR4S ? fma(ko_, dvs, zo) : fma(ko_, dvs, co_);
               if (LISTS == LST_F64 || !model) {
                 eh = model ? fo_logistic_neg<false>(exp_tab, nze) : 1.0;
                 oh = model ? fo_logistic_neg<false>(exp_tab, nzo) : 1.0;
@@ -1468,9 +1493,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               orr = 0.0;
             } else {
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
-              if (LISTS != LST_F64 && hv && !(FO_X & 8) && (LR4S || prot == 0)) {   // the harm values themselves, where a risk may need them
-                eh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ke_, dv, ze) : fma(ke_, dv, ce_));
-                oh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ko_, dv, zo) : fma(ko_, dv, co_));
+              if (LISTS != LST_F64 && hv && !(FO_X & 8) && (LR4S || DVMAX || prot == 0)) {   // the harm values themselves, where a risk may need them
+                const double dvs = fo_sqrt(dv);
+                eh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ke_, dvs, ze) : fma(ke_, dvs, ce_));
+                oh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ko_, dvs, zo) : fma(ko_, dvs, co_));
                 if (LISTS == LST_F32) { ehf = (float)eh; ohf = (float)oh; }   // so that risk = harm x cp holds in the lists too
               }
               if (hv) {
@@ -1497,13 +1523,16 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             lo2 += (unsigned)M * (2u * LE);
           }
         };
-        if (lr4s) pass2(std::true_type{}); else pass2(std::false_type{});
+        if (lr4s) pass2(std::integral_constant<int, HM_LR4S>{});
+        else if (dvmax_mode) pass2(std::integral_constant<int, HM_DVMAX>{});
+        else pass2(std::integral_constant<int, HM_GENERIC>{});
       }
     }
-    if (LISTS == LST_NONE && dvmax_mode) {
-      if (nze_min < INFINITY) {   // nze_min = -(largest relative speed)
-        max_eh = fo_vmax(max_eh, fo_logistic_neg<false>(exp_tab, fma(-hk[0], nze_min, hk[2])));
-        max_oh = fo_vmax(max_oh, fo_logistic_neg<false>(exp_tab, fma(-hk[1], nze_min, hk[3])));
+    if (dvmax_mode) {
+      if (nze_min < INFINITY) {   // nze_min = -(largest squared relative speed)
+        const double dvm = fo_sqrt(-nze_min);
+        max_eh = fo_vmax(max_eh, fo_logistic_neg<false>(exp_tab, fma(hk[0], dvm, hk[2])));
+        max_oh = fo_vmax(max_oh, fo_logistic_neg<false>(exp_tab, fma(hk[1], dvm, hk[3])));
       }
     } else
     if (LISTS != LST_F64 && nze_min < INFINITY) {   // (a wave whose samples carry no harm keeps -inf, as the lists path does)
