@@ -9,6 +9,8 @@ One "step" = one planning step of BASELINE.json configs[2] with every input alre
     occluded cells + their predictions  ->  agent table  ->  trajectory x agent metric sweep (DCE / TTC / TTCE / WTTC /
     CP / harm / risk over T = 31) for 10 000 candidate trajectories  ->  threshold reduction
     (+ one RCCL all-gather of the per-trajectory cost vectors when N > 1).
+`roofline.bound` names the binding unit from the committed rocprofv3 counters of the loaded library (`profiles/`): "hbm"
+only where the counter traffic passes 60 % of the 6.3 TB/s the chip reaches, else "valu-issue" with `valu_issue_frac`.
 
 N > 1 (BASELINE configs[3]): ONE batch of --M trajectories is block-partitioned over the ranks (`--scaling strong`, the
 default; M/N per rank, scene stage and agents replicated, `cost [M][16]` all-gathered) -- `--scaling weak` gives every
@@ -17,12 +19,18 @@ per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT se
 exits with their status; under `torch.distributed.run` it uses the environment it is given.
 
 Output lists: `--lists f32` (default) stores the five per-timestep lists as float32 -- the storage SURVEY 8d prices
-(648 B per pair); `--lists f64` stores them as float64 like the reference's numpy arrays.  All arithmetic that reaches
-a cost vector, a flag or a per-pair scalar is float64 in both.
+(648 B per pair) -- and evaluates the harm entries away from the 5 m gate in float32 (`dtype` says "f64+f32lists"); `--lists
+f32x` stores float32 but computes every entry in float64 (the price of that shortcut: `config.f32_exact_lists`); `--lists
+f64` stores them as float64 like the reference's numpy arrays.  All arithmetic that reaches a cost vector, a flag or a
+per-pair scalar is float64 in all three.
 
-Set-up (untimed, before the W warm-up steps): the real step is timed for four agents-per-wave settings of the sweep
-kernel and the best one kept -- which also brings the GPU to its sustained clocks, so that the timed K steps do not
-depend on W (`--no-autotune` skips it).  `--scene scenario1 --M 2000 --A 32` runs BASELINE configs[1] instead.
+Set-up (untimed, before the W warm-up steps): the library measures the sweep kernel's four agents-per-wave settings on the
+batch (`fo_sweep_autotune`, part of the C ABI: any caller gets the same choice) and keeps the best for the shape -- which
+also brings the GPU to its sustained clocks, so that the timed K steps do not depend on W (`--no-autotune` skips it).
+`--scene scenario1 --M 2000 --A 32` runs BASELINE configs[1] instead.  Beside the headline the default run measures
+(`config.*`): the other list formats, reduced outputs, `shard_probe` (the step of a 1/8, 1/4, 1/2 shard of the batch and
+the RCCL all-gather of one cost block, on this one GPU), `small_batch` (configs[1]) and `rules_step` (the reference's
+own spawn rule families as a device-resident step).
 
 Prints ONE JSON line on rank 0.  `value` = trajectory x agent metric evaluations per second over all ranks.
 `roofline` follows SURVEY 8d: algorithmic bytes = 620 B per trajectory + 636 B per agent + 648 B per pair (full
@@ -246,7 +254,7 @@ def cpu_and_parity(S, N, traj, agents, out, lists_fmt, want_parity=True):
                                           "here: shapely / commonroad / frenetix are not installable)"}
     parity = None
     if par is not None:
-        ltol = 1e-6 if lists_fmt == "f32" else 1e-9
+        ltol = 1e-9 if lists_fmt == "f64" else 1e-6
         parity = dict(par, checked_against="oracle/fo_oracle.c on every pair of the batch (full outputs)", tol_float=1e-9,
                       tol_lists=ltol, lists=lists_fmt,
                       ok=bool(par["float_max_abs_err"] <= 1e-9 and par["list_max_abs_err"] <= ltol and
@@ -254,25 +262,44 @@ def cpu_and_parity(S, N, traj, agents, out, lists_fmt, want_parity=True):
     return cpu, parity
 
 
-def committed_traffic(N, lists_fmt):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary -- WRITE_SIZE + 2 x FETCH_SIZE (gfx950
-    correction), KB -> bytes -- but only when that profile was taken with THIS library: profiles/<tag>_build.json holds
-    the fo_build_id() of the run; anything else prints null."""
+HBM_ACHIEVABLE_GBS = 6300.0   # what a plain fill reaches on this chip (guide; tools/microbench/write_bw.py)
+
+
+def committed_pmc(N, mode, lists_fmt):
+    """What the committed rocprofv3 summary of THIS library says about the dominant kernel of an output mode:
+    HBM traffic per launch (WRITE_SIZE + 2 x FETCH_SIZE, the guide's gfx950 correction; KB -> bytes), the VALU issue fraction
+    SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs), and
+    the binding unit: 'hbm' where traffic / time passes 60 % of the 6.3 TB/s the chip reaches, else 'valu-issue'.
+    profiles/<tag>_build.json must name the fo_build_id() of the loaded library, else everything is None."""
     import csv
-    tag = os.environ.get("FO_PROFILE_TAG", "r03_final")
+    base = os.environ.get("FO_PROFILE_TAG", "r04")
+    tag = base + {"full/f32": "_final", "full/f64": "_f64lists", "full/f32x": "_f32x", "reduced": "_reduced",
+                  "pair": "_pair"}.get(mode + ("/" + lists_fmt if mode == "full" else ""), "_final")
+    want = {"full/f32": "fo_sweep_queue_kernel<true, 2", "full/f64": "fo_sweep_queue_kernel<true, 1",
+            "full/f32x": "fo_sweep_queue_kernel<true, 3", "reduced": "fo_sweep_queue_kernel<false, 0",
+            "pair": "fo_sweep_queue_kernel<true, 0"}[mode + ("/" + lists_fmt if mode == "full" else "")]
+    out = {"traffic": None, "valu_issue_frac": None, "bound": None, "profile": tag, "hbm_traffic_gbs": None}
     try:
         with open(os.path.join(ROOT, "profiles", f"{tag}_build.json")) as f:
             meta = json.load(f)
-        if meta.get("build_id") != N.build_id() or meta.get("lists", "f64") != lists_fmt:
-            return None, tag
-        want = "fo_sweep_queue_kernel<true, 2" if lists_fmt == "f32" else "fo_sweep_queue_kernel<true, 1"
+        if meta.get("build_id") != N.build_id():
+            return out
         with open(os.path.join(ROOT, "profiles", f"{tag}_summary.csv")) as f:
             for row in csv.DictReader(f):
-                if row["kernel"].startswith(want) and row.get("WRITE_SIZE") and row.get("FETCH_SIZE"):
-                    return (float(row["WRITE_SIZE"]) + 2.0 * float(row["FETCH_SIZE"])) * 1024.0, tag
+                if not row["kernel"].startswith(want) or ", false>" not in row["kernel"]:
+                    continue
+                t_s = float(row["avg_ns"]) * 1e-9
+                if row.get("WRITE_SIZE") and row.get("FETCH_SIZE"):
+                    out["traffic"] = (float(row["WRITE_SIZE"]) + 2.0 * float(row["FETCH_SIZE"])) * 1024.0
+                    out["hbm_traffic_gbs"] = out["traffic"] / t_s / 1e9
+                if row.get("SQ_INSTS_VALU") and row.get("GRBM_GUI_ACTIVE"):
+                    out["valu_issue_frac"] = float(row["SQ_INSTS_VALU"]) * 4.0 / (1024.0 * float(row["GRBM_GUI_ACTIVE"]) / 8.0)
+                if out["hbm_traffic_gbs"] is not None:
+                    out["bound"] = "hbm" if out["hbm_traffic_gbs"] > 0.6 * HBM_ACHIEVABLE_GBS else "valu-issue"
+                break
     except Exception:
         pass
-    return None, tag
+    return out
 
 
 def small_batch_step(local_rank, steps=300):
@@ -346,13 +373,146 @@ def small_batch_step(local_rank, steps=300):
             "sweep_grid": sw.ctx.last_launch()["grid"]}
 
 
+def rules_step(local_rank, steps=300):
+    """The reference's own spawn semantics as a device-resident planning step (fo_step_run, spawn_mode FO_SPAWN_RULES): scenario1
+    geometry, 2 000 candidates, the three rule families of spawn_locator.py:145-578 on the cell classes -> their spawn points
+    -> phantom agents with predictions -> sweep, nothing read back.  Two poses of the fixture: time step 0 and the step at
+    which a visible dynamic obstacle qualifies for the Car / Bicycle rule (its candidate region is built: the dear case)."""
+    import numpy as np
+    import torch
+    import yaml
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as SC
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.step import PlanningStep
+    from frenetix_occlusion.sweep import MetricSweep
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    M, T = 2000, 31
+    ctx = N.Context(local_rank)
+    sc = SC.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"].update(mode="rules", routes=3, max_rule_points=8)
+    yaw = float(ego0[2])
+    path = ego0[None, :2] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    obs = FOObstacles(sc.obstacles)
+    sm = SensorModel(sc.lanelets, path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx, device=local_rank,
+                     routes=3, intersections=sc.intersections)
+    sl = SpawnLocator(None, path, cfg, sm, fo_obstacles=obs, dt=0.1, horizon=(T - 1) * 0.1)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds=THR, device=local_rank, ctx=ctx)
+    traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 2, ego_pos=ego0[:2], ego_yaw=yaw)
+    tr = [torch.as_tensor(traj[k]).to(f"cuda:{local_rank}") for k in ("x", "y", "theta", "v", "a")]
+    ps = PlanningStep(sm, sl, sw, *tr, mode="reduced")
+    out = {"workload": "scenario1 geometry, 2000 trajectories, spawn.mode rules (the reference's three rule families on the device, "
+                       "<= 8 spawn points x 3 route slots), T=31, reduced outputs, fo_step_run", "steps": steps, "poses": {}}
+    for step in (0, 8, 25, 60):
+        ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
+        obs.update(step)
+        sm.upload_obstacles(obs)
+        for _ in range(50):
+            ps.run(ego, yaw, float(ego0[3]))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ps.run(ego, yaw, float(ego0[3]))
+        t_issue = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        h = sl.batch.host_head()
+        kinds = [int(q[0]) for q in h["rule_points"][:h["rule_n"]]]
+        out["poses"][f"step{step}"] = {"ms_per_step": dt * 1e3, "host_issue_ms_per_step": t_issue * 1e3, "spawn_points": h["rule_n"],
+                                       "types": [{0: "Car", 3: "Bicycle", 4: "Pedestrian"}[k] for k in kinds],
+                                       "intention": sl.last_intention}
+    out["ms_per_step"] = max(v["ms_per_step"] for v in out["poses"].values())
+    out["ms_per_step_definition"] = "the slowest of the four poses"
+    return out
+
+
+def shard_probe(scene, sw, tensors, local_rank, N, steps=200):
+    """What ONE GPU can measure about BASELINE configs[3] (the 10k x 256 batch block-partitioned over 8 / 4 / 2 GPUs): the planning
+    step of a 1/8, 1/4 and 1/2 shard -- same scene stage, same agents, the library's measured agents-per-wave for the shard's
+    shape -- and the all-gather of a [M/8][16] cost block through RCCL on one rank."""
+    import numpy as np
+    import torch
+    from frenetix_occlusion.step import PlanningStep
+    ego = scene["ego"]
+    M_total = int(tensors[0].shape[0])
+    res = {"definition": "ms per planning step of a shard of the headline batch on ONE GPU (scene stage + sampling + sweep + reduction; "
+                         "reduced outputs = what a rank all-gathers, and full outputs with float32 lists)", "shards": {}}
+    for div in (8, 4, 2):
+        m = -(-M_total // div)
+        row = {"M": m}
+        for mode in ("reduced", "full"):
+            tr = [t[:m] for t in tensors]
+            ps = PlanningStep(scene["sm"], scene["sl"], sw, *tr, mode=mode, lists="f32")
+            ps.run(ego[:2], float(ego[2]), float(ego[3]))
+            o = sw.run(*tr, mode=mode, lists="f32", autotune=40)      # per-shape choice, kept in the context
+            del o
+            for _ in range(40):
+                ps.run(ego[:2], float(ego[2]), float(ego[3]))
+            torch.cuda.synchronize()
+            sw.ctx.timing(True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ps.run(ego[:2], float(ego[2]), float(ego[3]))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            kms, kn = sw.ctx.timing_read()
+            sw.ctx.timing(False)
+            ll = sw.ctx.last_launch()
+            row[mode] = {"ms_per_step": dt * 1e3, "sweep_kernel_ms": kms / max(kn, 1), "sweep_grid": ll["grid"],
+                         "agents_per_wave": ll["agents_per_wave"]}
+            del ps
+        res["shards"][f"1/{div}"] = row
+    # the collective alone, one rank: [M/8][16] float64 through RCCL.  (RCCL prints a version banner into the C library's
+    # stdout buffer, which would surface after the JSON line: stdout points at stderr while RCCL is alive.)
+    import ctypes
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        import torch.distributed as dist
+        own = not dist.is_initialized()
+        if own:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        per = -(-M_total // 8)
+        mine = torch.zeros((per, N.NC), dtype=torch.float64, device=f"cuda:{local_rank}")
+        gathered = torch.empty((per, N.NC), dtype=torch.float64, device=f"cuda:{local_rank}")
+        for _ in range(20):
+            dist.all_gather_into_tensor(gathered, mine)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(100):
+            dist.all_gather_into_tensor(gathered, mine)
+        e1.record()
+        torch.cuda.synchronize()
+        res["allgather_ms"] = e0.elapsed_time(e1) / 100
+        res["allgather"] = f"all_gather_into_tensor of one [{per}][16] float64 block, RCCL, world size 1 (launch + protocol floor; no xGMI hop)"
+        if own:
+            dist.destroy_process_group()
+    except Exception as e:        # RCCL unavailable on the box: say so, keep the line
+        res["allgather_ms"], res["allgather"] = None, f"not measured: {type(e).__name__}: {e}"
+    finally:
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="full", choices=["full", "pair", "reduced"])
-    ap.add_argument("--lists", default="f32", choices=["f32", "f64"],
+    ap.add_argument("--lists", default="f32", choices=["f32", "f64", "f32x"],
                     help="element type of the per-timestep lists of --mode full (f32: SURVEY 8d's storage; f64: the reference's)")
     ap.add_argument("--M", type=int, default=10000)
     ap.add_argument("--A", type=int, default=256)
@@ -487,27 +647,19 @@ def main():
     if scene is not None:
         n_active = int(scene["sl"].batch.n.item())
     sw.ctx.timing(False)
-    # Set-up, before the W warm-up steps: pick the sweep kernel's agents-per-wave for this batch shape by timing the
-    # real step (4 candidates x (20 + 100) steps, ~0.4 s).  The same pass brings the GPU to its sustained clocks: a
-    # cold MI355X runs the first few dozen steps 10-15 % slower, so without it the result would depend on W.
+    # Set-up, before the W warm-up steps: the LIBRARY measures the sweep kernel's agents-per-wave settings on this batch
+    # (fo_sweep_autotune: 4 settings x 100 launches, ~0.3 s) and keeps the best for the shape -- what any caller of the C ABI
+    # gets, no environment variable.  The same pass brings the GPU to its sustained clocks: a cold MI355X runs the first
+    # few dozen steps 10-15 % slower, so without it the result would depend on W.
     tune = {}
-    if not os.environ.get("FO_SWEEP_APW") and not args.no_autotune:
-        for apw in (1, 2, 4, 8):
-            os.environ["FO_SWEEP_APW"] = str(apw)
-            for _ in range(20):
-                out = step(res=out, gather=False)
-            torch.cuda.synchronize()
-            t_a = time.perf_counter()
-            for _ in range(100):
-                out = step(res=out, gather=False)
-            torch.cuda.synchronize()
-            tune[apw] = (time.perf_counter() - t_a) / 100
-        best = min(tune, key=tune.get)
-        if use_dist:      # one setting for the whole job
-            b = torch.tensor([best], device=dev)
-            dist.broadcast(b, 0)
-            best = int(b.item())
-        os.environ["FO_SWEEP_APW"] = str(best)
+    if not os.environ.get("FO_SWEEP_APW") and not args.no_autotune and M > 0:
+        o_t = sw.run(tx, ty, tth, tv, ta, mode=args.mode, lists=args.lists, autotune=100)
+        tune = dict(sw.last_autotune["ms"])
+        del o_t
+        torch.cuda.empty_cache()
+        for _ in range(100):
+            out = step(res=out, gather=False)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = step(res=out)
     if use_dist:
@@ -565,13 +717,14 @@ def main():
         achieved = a8d / kern_s / 1e9
         launch = sw.ctx.last_launch()
         default_workload = (args.scene == "urban" and M_total == 10000 and A == 256 and T == 31 and args.mode == "full")
-        traffic, ptag = (None, None)
+        pmc = {"traffic": None, "valu_issue_frac": None, "bound": None, "profile": None, "hbm_traffic_gbs": None}
         if default_workload and world == 1:
-            traffic, ptag = committed_traffic(N, args.lists)
+            pmc = committed_pmc(N, args.mode, args.lists)
+        dtype = "f64" if (args.mode != "full" or args.lists == "f64") else ("f64+f32lists" if args.lists == "f32" else "f64 (lists stored f32)")
         res = {
             "metric": "trajectory_x_agent_metric_evals_per_sec", "value": pairs / elapsed, "unit": "pair-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: synthetic urban lanelet net, 10k trajectories x 256 phantoms, "
                                     "360 deg ray-cast @ 0.5 deg, T=31 (full planning step)" if world == 1 else
                                     "BASELINE configs[3]: the synthetic 10k x 256 batch of configs[2] block-partitioned "
@@ -586,18 +739,28 @@ def main():
                        "entry": ("fo_step_run (PlanningStep: one native call per planning step)" if scene is not None and args.entry == "step"
                                  else "stage calls"),
                        "list_storage": (args.lists + (" (harm entries away from the 5 m gate evaluated in float32; every cost, "
-                                                     "flag and pair scalar float64)" if args.lists == "f32" else ""))
+                                                     "flag and pair scalar float64)" if args.lists == "f32" else
+                                                     " (float64 results rounded to float32 at the store)" if args.lists == "f32x" else ""))
                        if args.mode == "full" else None,
                        "traj_order": args.order, "metrics": ["hr", "ttc", "ttce", "dce", "wttc", "cp"],
                        "scene_stage_ms": scene_ms, "sweep_kernel_ms": kern_s * 1e3,
-                       "agents_per_wave": int(os.environ["FO_SWEEP_APW"]) if os.environ.get("FO_SWEEP_APW") else None,
-                       "setup_autotune_ms_per_step": {str(k): round(v * 1e3, 4) for k, v in tune.items()},
+                       "agents_per_wave": launch["agents_per_wave"],
+                       "agents_per_wave_source": ("FO_SWEEP_APW (environment)" if os.environ.get("FO_SWEEP_APW") else
+                                                  "fo_sweep_autotune (library: measured per batch shape, kept in the context)" if tune
+                                                  else "static rule of fo_sweep_run"),
+                       "setup_autotune_ms_per_sweep": {str(k): round(v, 4) for k, v in tune.items()},
                        "boundary_edges": scene["edges"] if scene else None, "rays": 720 if scene else None,
                        "parallelism": f"traj-shard x{world}", "ranks_seen": dist.get_world_size() if use_dist else 1,
                        "allgather_ms": ag_ms, "allgather_bytes_per_rank": per * N.NC * 8 if use_dist else None,
                        "build_id": N.build_id()},
-            "roofline": {"bound": "hbm", "kernel": "fo_sweep_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_profile": ptag,
+            # bound: the unit the committed PMC summary of this library names (HBM only where the counter traffic passes 60 %
+            # of the 6.3 TB/s the chip reaches); achieved / peak / frac stay SURVEY 8d's byte figure on the HBM peak
+            "roofline": {"bound": pmc["bound"] or "unknown (no PMC summary of this library under profiles/)",
+                         "kernel": "fo_sweep_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"], "traffic_profile": pmc["profile"],
+                         "hbm_traffic_gbs": pmc["hbm_traffic_gbs"], "hbm_achievable_gbs": HBM_ACHIEVABLE_GBS,
+                         "valu_issue_frac": pmc["valu_issue_frac"],
+                         "valu_issue_frac_definition": "SQ_INSTS_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed PMC summary",
                          "bytes_definition": "SURVEY 8d, fp32 storage: 620 B/trajectory + 636 B/agent + per pair 48 B "
                                              "scalars (+ 600 B lists in full mode); 64 B/trajectory in reduced mode",
                          "algorithmic_bytes_per_launch": a8d, "stored_bytes_per_launch": ast,
@@ -636,18 +799,30 @@ def main():
                 kms_r, kn_r = sw.ctx.timing_read()
                 sw.ctx.timing(False)
                 ks = kms_r / max(kn_r, 1) / 1e3
-                b8, bs = bytes_8d(M, n_active, T, mode), bytes_stored(M, n_active, T, mode, lists)
+                b8, bs = bytes_8d(M, n_active, T, mode), bytes_stored(M, n_active, T, mode, "f32" if lists != "f64" else "f64")
                 del r
-                return {"ms_per_step": dt_r * 1e3, "pair_evals_per_sec": M * n_active / dt_r, "sweep_kernel_ms": ks * 1e3,
-                        "frac": b8 / ks / 1e9 / HBM_PEAK_GBS, "frac_stored_bytes": bs / ks / 1e9 / HBM_PEAK_GBS, "steps": n}
+                pm = committed_pmc(N, mode, lists)
+                d_ = {"ms_per_step": dt_r * 1e3, "pair_evals_per_sec": M * n_active / dt_r, "sweep_kernel_ms": ks * 1e3,
+                      "bound": pm["bound"], "valu_issue_frac": pm["valu_issue_frac"], "hbm_traffic_gbs": pm["hbm_traffic_gbs"],
+                      "profile": pm["profile"], "steps": n}
+                if mode != "reduced":     # (64 B per trajectory against a compute-bound kernel: a byte fraction says nothing there)
+                    d_.update(frac=b8 / ks / 1e9 / HBM_PEAK_GBS, frac_stored_bytes=bs / ks / 1e9 / HBM_PEAK_GBS)
+                return d_
             del out
             torch.cuda.empty_cache()
             # the same step with the lists in the other element type, and with reduced outputs (cost vectors + flags:
             # what a planner loop consumes), beside the headline
-            other = "f64" if args.lists == "f32" else "f32"
-            res["config"][f"{other}_lists"] = side("full", other)
+            for other in ("f64", "f32x", "f32"):
+                if other != args.lists:
+                    res["config"][{"f64": "f64_lists", "f32": "f32_lists", "f32x": "f32_exact_lists"}[other]] = side("full", other)
+            res["config"]["f32_exact_lists"]["what"] = ("float64 arithmetic for every list entry, rounded to float32 at the store "
+                                                        "(FO_LISTS_F32_EXACT): against the headline, the price of its float32 harm entries")
             res["config"]["reduced_outputs"] = side("reduced", args.lists)
+            res["config"]["shard_probe"] = shard_probe(scene, sw, (tx, ty, tth, tv, ta), local_rank, N)
+            planning_steps.clear()
+            torch.cuda.empty_cache()
             res["config"]["small_batch"] = small_batch_step(local_rank)
+            res["config"]["rules_step"] = rules_step(local_rank)
         if use_dist:   # RCCL's start-up banner sits in the C library's stdout buffer: let it out first, the JSON line last
             import ctypes
             ctypes.CDLL(None).fflush(None)

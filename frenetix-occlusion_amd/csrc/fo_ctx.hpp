@@ -53,6 +53,12 @@ struct fo_ctx {
   hipEvent_t *ev_start = nullptr, *ev_stop = nullptr;
   int n_timed = 0;
 
+  // ---- agents-per-wave of the sweep kernel measured per batch shape (fo_sweep_autotune)
+  struct Tuned { int n_tiles, A, T, lst; bool pair; int apw; };
+  static constexpr int kMaxTuned = 16;
+  Tuned tuned[kMaxTuned];
+  int n_tuned = 0, next_tuned = 0, force_apw = 0;
+
   // ---- scene (ray-cast / grid) state lives in fo_scene.hip
   void *scene = nullptr;
 };

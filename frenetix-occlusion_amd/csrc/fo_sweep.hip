@@ -309,7 +309,11 @@ __device__ __forceinline__ float fo_logistic_neg_f32(double nz) {
 }
 
 // ------------------------------------------------------------------------------------------------ the sweep
-enum { LST_NONE = 0, LST_F64 = 1, LST_F32 = 2 };   // per-timestep list output of a sweep instantiation
+enum { LST_NONE = 0, LST_F64 = 1, LST_F32 = 2, LST_F32X = 3 };   // per-timestep list output of a sweep instantiation
+// LST_F32X (FO_LISTS_F32_EXACT): float32 elements like LST_F32, but every entry is the float64 result rounded at the store --
+// the arithmetic of LST_F64, the bytes of LST_F32; what the float32 shortcut of LST_F32 saves is the difference of the two
+__host__ __device__ constexpr bool lst_is32(int l) { return l == LST_F32 || l == LST_F32X; }
+__host__ __device__ constexpr bool lst_exact(int l) { return l == LST_F64 || l == LST_F32X; }
 struct SweepArgs {
   int M, Mp, T, A, Ta, n_tiles, nt8, apw;  // apw = agents per wave
   const double *traj;    // [n_tiles][T][NEF][64]
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
       if (LISTS && valid) {
         const size_t ls = (size_t)A * Tm1 * M;
         for (int t = 0; t < Tm1; ++t) {
-          if (LISTS == LST_F32) fo_store_lists_f32((float *)a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
+          if (lst_is32(LISTS)) fo_store_lists_f32((float *)a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
           else fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
         }
       }
@@ -954,7 +958,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       if (LISTS) {
         const size_t ls = (size_t)A * Tm1 * M;
         for (int t = 0; t < Tm1; ++t) {
-          if (LISTS == LST_F32) fo_store_lists_f32((float *)a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
+          if (lst_is32(LISTS)) fo_store_lists_f32((float *)a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
           else fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
         }
       }
@@ -1035,7 +1039,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     // lane offsets (element size 1x and 2x) -- no 64-bit address arithmetic per sample (fo_sweep_run sends batches whose
     // (T-1) M pair elements pass 4 GB to the generic kernel)
     const size_t ls = (size_t)A * Tm1 * M;
-    constexpr unsigned LE = (LISTS == LST_F32) ? 4u : 8u;   // list element size
+    constexpr unsigned LE = lst_is32(LISTS) ? 4u : 8u;   // list element size
     char *const lb0 = (char *)a.lists + (size_t)k * Tm1 * M * LE;
     char *const lb1 = (char *)a.lists + (ls + (size_t)k * Tm1 * M * 2) * LE;
     char *const lb2 = (char *)a.lists + (3 * ls + (size_t)k * Tm1 * M * 2) * LE;
@@ -1456,7 +1460,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 // and two logistics on the hardware transcendentals (|error| < 4e-7: v_sqrt_f32 and the float32 fma add
                 // 1e-7 |nz| to the argument, the slope of the logistic is <= 1/4)
                 if (LISTS != LST_NONE) nze_min = fo_vmin_neg(nze_min, dv);
-                if (LISTS == LST_F64) {
+                if (lst_exact(LISTS)) {
                   const double dvs = fo_sqrt(dv);
                   eh = fo_logistic_neg<false>(exp_tab, fma(ke_, dvs, ce_));
                   oh = fo_logistic_neg<false>(exp_tab, fma(ko_, dvs, co_));
@@ -1470,7 +1474,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               const bool model = LR4S || prot == 0;   // wave-uniform; otherwise harm is 1 on both sides
               const double dvs = fo_sqrt(dv);          // (the ring holds dv^2)
               const double nze = LR4S ? fma(ke_, dvs, ze) : fma(ke_, dvs, ce_), nzo = LR4S ? fma(ko_, dvs, zo) : fma(ko_, dvs, co_);
-              if (LISTS == LST_F64 || !model) {
+              if (lst_exact(LISTS) || !model) {
                 eh = model ? fo_logistic_neg<false>(exp_tab, nze) : 1.0;
                 oh = model ? fo_logistic_neg<false>(exp_tab, nzo) : 1.0;
                 max_eh = fo_vmax(max_eh, eh);
@@ -1493,7 +1497,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               orr = 0.0;
             } else {
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
-              if (LISTS != LST_F64 && hv && !(FO_X & 8) && (LR4S || DVMAX || prot == 0)) {   // the harm values themselves, where a risk may need them
+              if (!lst_exact(LISTS) && hv && !(FO_X & 8) && (LR4S || DVMAX || prot == 0)) {   // the harm values themselves, where a risk may need them
                 const double dvs = fo_sqrt(dv);
                 eh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ke_, dvs, ze) : fma(ke_, dvs, ce_));
                 oh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ko_, dvs, zo) : fma(ko_, dvs, co_));
@@ -1510,11 +1514,14 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
               if (LISTS == LST_F32) { cpf = (float)cp; erf_ = (float)er; orf = (float)orr; }
             }
+            if (LISTS == LST_F32X) {   // the float64 results, rounded at the store
+              ehf = (float)eh; ohf = (float)oh; cpf = (float)cp; erf_ = (float)er; orf = (float)orr;
+            }
             if (LISTS == LST_F64) {
               __builtin_nontemporal_store(cp, (double *)(lb0 + lo1));
               __builtin_nontemporal_store(fo_d2{eh, oh}, (fo_d2 *)(lb1 + lo2));
               __builtin_nontemporal_store(fo_d2{er, orr}, (fo_d2 *)(lb2 + lo2));
-            } else if (LISTS == LST_F32) {
+            } else if (lst_is32(LISTS)) {
               __builtin_nontemporal_store(cpf, (float *)(lb0 + lo1));
               __builtin_nontemporal_store(fo_f2{ehf, ohf}, (fo_f2 *)(lb1 + lo2));
               __builtin_nontemporal_store(fo_f2{erf_, orf}, (fo_f2 *)(lb2 + lo2));
@@ -1535,7 +1542,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         max_oh = fo_vmax(max_oh, fo_logistic_neg<false>(exp_tab, fma(hk[1], dvm, hk[3])));
       }
     } else
-    if (LISTS != LST_F64 && nze_min < INFINITY) {   // (a wave whose samples carry no harm keeps -inf, as the lists path does)
+    if (!lst_exact(LISTS) && nze_min < INFINITY) {   // (a wave whose samples carry no harm keeps -inf, as the lists path does)
       max_eh = fo_vmax(max_eh, fo_logistic_neg<false>(exp_tab, nze_min));
       max_oh = fo_vmax(max_oh, fo_logistic_neg<false>(exp_tab, nzo_min));
     }
@@ -1920,6 +1927,11 @@ template <bool ALLM, bool SPLIT>
 void launch_queue(int lst, bool pair, dim3 g, dim3 b, hipStream_t s, const SweepArgs &a) {
   if (lst == LST_F64) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F64, ALLM, SPLIT>), g, b, 0, s, a);
   else if (lst == LST_F32) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F32, ALLM, SPLIT>), g, b, 0, s, a);
+  else if (lst == LST_F32X) {
+    // one instantiation only (the default metric set on a full grid); fo_sweep_run sends every other case to the generic
+    // kernel, which has this arithmetic anyway (float64 throughout, converted at the store)
+    if constexpr (ALLM && !SPLIT) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F32X, true, false>), g, b, 0, s, a);
+  }
   else if (pair) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
   else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
 }
@@ -1990,10 +2002,18 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
   if ((rc = fo_reserve(ctx, &ctx->d_traj_tab, &ctx->cap_traj_tab, (size_t)(max_T + 1) * NEF * Mp))) return rc;   // (+ a spare row, see fo_sweep_run)
   // worst case number of chunks: one agent per wave
   // one agent per wave, or (small batches) one workgroup per agent -- but then n_tiles * A < 3 072
-  const size_t chunks_split = (size_t)max_A + 1, tiles = (size_t)Mp / TILE;
-  const size_t chunks = tiles * max_A < 3072 ? chunks_split : (size_t)(max_A + WAVES - 1) / WAVES + 1;
-  if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, chunks * NPS * Mp))) return rc;
-  if ((rc = fo_reserve(ctx, &ctx->d_chunk_tab, &ctx->cap_chunk_tab, 2 * (chunks + 1)))) return rc;
+  // partial rows: (chunks + 1) x NPS x Mp doubles, for EVERY batch of at most max_M trajectories and max_A agents --
+  // a full grid has <= ceil(A / 4) + 1 chunks of one agent per wave at worst; a batch below 3 072 (tile, agent) pairs takes
+  // the horizon-split form (when max_T allows it) with one chunk per agent, but then tiles x A < 3 072 bounds the product
+  // (tiles x (A + 2) <= 3 072 + 2 tiles)
+  const size_t tiles = (size_t)Mp / TILE;
+  size_t partial = ((size_t)(max_A + WAVES - 1) / WAVES + 2) * NPS * Mp;
+  if (max_T <= QWAVES * TC) {
+    const size_t split_cells = (3072 + 2 * tiles) < tiles * ((size_t)max_A + 2) ? (3072 + 2 * tiles) : tiles * ((size_t)max_A + 2);
+    if (split_cells * NPS * TILE > partial) partial = split_cells * NPS * TILE;
+  }
+  if ((rc = fo_reserve(ctx, &ctx->d_partial, &ctx->cap_partial, partial))) return rc;
+  if ((rc = fo_reserve(ctx, &ctx->d_chunk_tab, &ctx->cap_chunk_tab, 2 * ((size_t)max_A + 3)))) return rc;
   if ((rc = fo_reserve(ctx, &ctx->d_agent_tab, &ctx->cap_agent_tab, ((size_t)(max_A > 0 ? max_A : 1) * (max_Ta > 0 ? max_Ta : 1) + AGENT_PAD_ROWS) * NAF))) return rc;
   {
     const size_t cap0 = ctx->cap_agent_const;
@@ -2006,7 +2026,8 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta) {
 
 int fo_sweep_set_list_format(fo_ctx *ctx, int format) {
   if (!ctx) return FO_E_ARG;
-  if (format != FO_LISTS_F64 && format != FO_LISTS_F32) return fo_fail(ctx, FO_E_ARG, "fo_sweep_set_list_format: unknown format %d", format);
+  if (format != FO_LISTS_F64 && format != FO_LISTS_F32 && format != FO_LISTS_F32_EXACT)
+    return fo_fail(ctx, FO_E_ARG, "fo_sweep_set_list_format: unknown format %d", format);
   ctx->list_format = format;
   return FO_OK;
 }
@@ -2077,22 +2098,34 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   hipStream_t s = (hipStream_t)stream;
   const int A = ctx->A, Ta = ctx->Ta;
   if (d_lists && A > 0 && T > 1 && !(ctx->mask & (FO_M_CP | FO_M_HR)))  // nothing will write them: all-ones = NaN
-    FO_HIP_TRY(ctx, hipMemsetAsync(d_lists, 0xFF, (ctx->list_format == FO_LISTS_F32 ? sizeof(float) : sizeof(double)) *
+    FO_HIP_TRY(ctx, hipMemsetAsync(d_lists, 0xFF, (ctx->list_format != FO_LISTS_F64 ? sizeof(float) : sizeof(double)) *
                                                      FO_NL * (size_t)A * (T - 1) * M, s));
   const int Mp = round_up(M, TILE);
   const int n_tiles = Mp / TILE;
   const char *force_generic = getenv("FO_SWEEP_GENERIC");  // debug / A-B aid
   // (the queue kernel reads agent rows up to index T without clamping: horizons far beyond the predictions' take the generic kernel)
   // (the queue kernel addresses one agent's list rows by 32-bit byte offsets: (T-1) M pairs of float64 must stay under 4 GB)
-  const bool use_queue = !(force_generic && force_generic[0] == '1') && (!FO_DIET || T <= Ta + AGENT_PAD_ROWS - 1 || A == 0) &&
+  bool use_queue = !(force_generic && force_generic[0] == '1') && (!FO_DIET || T <= Ta + AGENT_PAD_ROWS - 1 || A == 0) &&
                          (size_t)(T > 1 ? T - 1 : 1) * (size_t)M * 16u < ((size_t)1 << 32);
+  const int lst_mode = !d_lists ? LST_NONE : ctx->list_format == FO_LISTS_F32 ? LST_F32 : ctx->list_format == FO_LISTS_F32_EXACT ? LST_F32X : LST_F64;
+  {  // FO_LISTS_F32_EXACT has one queue-kernel instantiation (default metric set, full grid); everything else: generic kernel
+    const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
+    if (lst_mode == LST_F32X && ((ctx->mask & all5) != all5 || getenv("FO_SWEEP_ABLATE"))) use_queue = false;
+  }
   const int wpb = use_queue ? QWAVES : WAVES;  // waves per workgroup of the kernel that will run
   int apw = pick_apw(n_tiles, A, wpb);
+  // a setting fo_sweep_autotune measured for this shape on this context wins over the static choice
+  for (int i = 0; i < ctx->n_tuned; ++i) {
+    const fo_ctx::Tuned &tu = ctx->tuned[i];
+    if (tu.n_tiles == n_tiles && tu.A == A && tu.T == T && tu.lst == lst_mode && tu.pair == (d_pair_f != nullptr)) apw = tu.apw;
+  }
+  if (ctx->force_apw > 0) apw = ctx->force_apw;   // (fo_sweep_autotune while it measures)
   if (const char *e = getenv("FO_SWEEP_APW")) { const int v = atoi(e); if (v >= 1 && v <= 64) apw = v; }  // tuning aid
   // Small batches: with one agent per wave the grid is n_tiles x A waves; below the 3 072 wave slots of the chip the
   // horizon of every agent is split over the four waves of a workgroup instead (one workgroup per tile and agent).
   bool split = use_queue && T <= QWAVES * TC && (long)n_tiles * A < 3072;
   if (const char *e = getenv("FO_SWEEP_SPLIT")) split = use_queue && T <= QWAVES * TC && e[0] == '1';  // tests, A/B runs
+  if (lst_mode == LST_F32X) split = false;
   if (split) apw = 1;
   // Tapered grid (queue kernel, grids beyond one round of the chip): agents per wave halve from phase to phase down to
   // one -- see SweepArgs::ph_n.  f[]: fraction of the agents per phase; FO_SWEEP_TAPER="f0,f1,f2" overrides them
@@ -2171,7 +2204,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     if (trace_path && !d_trace) (void)hipMalloc((void **)&d_trace, sizeof(long long) * 4 * 65536);
     a.trace = trace_path ? d_trace : nullptr;
 #endif
-    const int lst = !d_lists ? LST_NONE : ctx->list_format == FO_LISTS_F32 ? LST_F32 : LST_F64;
+    const int lst = lst_mode;
     if (use_queue) {
       const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
       const bool allm = (a.mask & all5) == all5 && a.ablate == 0;
@@ -2181,7 +2214,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
       else launch_queue<false, false>(lst, d_pair_f != nullptr, g, b, s, a);
     } else {
       if (lst == LST_F64) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_F64>), g, b, 0, s, a);
-      else if (lst == LST_F32) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_F32>), g, b, 0, s, a);
+      else if (lst_is32(lst)) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_F32>), g, b, 0, s, a);   // (converts at the store: exact)
       else if (d_pair_f) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_NONE>), g, b, 0, s, a);
       else hipLaunchKernelGGL((fo_sweep_generic_kernel<false, LST_NONE>), g, b, 0, s, a);
     }
@@ -2211,6 +2244,61 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
                      ctx->thr, ctx->mask, be_btn, d_cost, d_safe, ctx->d_status, ctx->status_gen);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
+}
+
+// Per-shape choice of the sweep kernel's agents-per-wave, measured on the caller's own batch (include/fo_hip.h).
+int fo_sweep_autotune(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta, const double *d_v,
+                      const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f, int32_t *d_pair_i, double *d_lists,
+                      int reps, int *best_apw, double *ms4, void *stream) {
+  if (!ctx) return FO_E_ARG;
+  if (reps < 1) return fo_fail(ctx, FO_E_ARG, "fo_sweep_autotune: reps must be positive");
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int A = ctx->A;
+  const int n_tiles = round_up(M > 0 ? M : 1, TILE) / TILE;
+  const int lst = !d_lists ? LST_NONE : ctx->list_format == FO_LISTS_F32 ? LST_F32 : ctx->list_format == FO_LISTS_F32_EXACT ? LST_F32X : LST_F64;
+  static const int cand[4] = {1, 2, 4, 8};
+  hipEvent_t e0, e1;
+  FO_HIP_TRY(ctx, hipEventCreate(&e0));
+  FO_HIP_TRY(ctx, hipEventCreate(&e1));
+  int rc = FO_OK, best = 0;
+  double best_ms = INFINITY;
+  const bool was_timing = ctx->timing;
+  ctx->timing = false;
+  for (int c = 0; c < 4 && rc == FO_OK; ++c) {
+    ctx->force_apw = cand[c];
+    for (int i = 0; i < (reps + 3) / 4 && rc == FO_OK; ++i)
+      rc = fo_sweep_run(ctx, M, T, d_x, d_y, d_theta, d_v, d_a, d_cost, d_safe, d_pair_f, d_pair_i, d_lists, stream);
+    if (rc == FO_OK && hipEventRecord(e0, s) != hipSuccess) rc = FO_E_HIP;
+    for (int i = 0; i < reps && rc == FO_OK; ++i)
+      rc = fo_sweep_run(ctx, M, T, d_x, d_y, d_theta, d_v, d_a, d_cost, d_safe, d_pair_f, d_pair_i, d_lists, stream);
+    float ms = 0.f;
+    if (rc == FO_OK && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                        hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) rc = FO_E_HIP;
+    if (rc == FO_OK) {
+      if (ms4) ms4[c] = (double)ms / reps;
+      if ((double)ms / reps < best_ms) { best_ms = (double)ms / reps; best = cand[c]; }
+    }
+  }
+  ctx->force_apw = 0;
+  ctx->timing = was_timing;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != FO_OK) return rc == FO_E_HIP ? fo_fail(ctx, FO_E_HIP, "fo_sweep_autotune: HIP event failure") : rc;
+  // remember (replace an entry of the same shape; the table is small and round-robin)
+  int slot = -1;
+  for (int i = 0; i < ctx->n_tuned; ++i) {
+    const fo_ctx::Tuned &tu = ctx->tuned[i];
+    if (tu.n_tiles == n_tiles && tu.A == A && tu.T == T && tu.lst == lst && tu.pair == (d_pair_f != nullptr)) slot = i;
+  }
+  if (slot < 0) {
+    if (ctx->n_tuned < fo_ctx::kMaxTuned) slot = ctx->n_tuned++;
+    else slot = ctx->next_tuned++ % fo_ctx::kMaxTuned;
+  }
+  ctx->tuned[slot] = fo_ctx::Tuned{n_tiles, A, T, lst, d_pair_f != nullptr, best};
+  if (best_apw) *best_apw = best;
+  // leave the outputs of a run with the chosen setting behind
+  return fo_sweep_run(ctx, M, T, d_x, d_y, d_theta, d_v, d_a, d_cost, d_safe, d_pair_f, d_pair_i, d_lists, stream);
 }
 
 int fo_sweep_timing(fo_ctx *ctx, int enable) {

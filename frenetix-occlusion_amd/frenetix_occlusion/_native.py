@@ -11,7 +11,8 @@ LIB_PATH = os.environ.get("FO_HIP_LIB") or os.path.join(os.path.dirname(_HERE), 
 
 FO_OK, FO_E_ARG, FO_E_UNSUPPORTED_COV, FO_E_HIP, FO_E_NOMEM, FO_E_STATE = 0, -1, -2, -3, -4, -5
 NPF, NPI, NL, NC = 12, 4, 5, 16
-LISTS_F64, LISTS_F32 = 0, 1
+LISTS_F64, LISTS_F32, LISTS_F32_EXACT = 0, 1, 2
+LIST_FORMAT = {"f64": LISTS_F64, "f32": LISTS_F32, "f32x": LISTS_F32_EXACT}   # f32x: float64 arithmetic, float32 store
 
 PF = {"dce": 0, "ttc": 1, "ttce": 2, "max_ego_risk": 3, "max_obst_risk": 4, "max_obst_harm_with_cp": 5,
       "max_ego_harm": 6, "max_obst_harm": 7, "max_collision_probability": 8, "be_decel": 9, "be_btn": 10}
@@ -31,7 +32,7 @@ EXPORTS = [
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read", "fo_sweep_timing_read_each",
     "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
     "fo_scene_candidate_count", "fo_scene_set_topology", "fo_scene_spawn_rules", "fo_step_run",
-    "fo_scene_set_centerlines", "fo_scene_spawn_rule_agents",
+    "fo_scene_set_centerlines", "fo_scene_spawn_rule_agents", "fo_sweep_autotune",
 ]
 
 
@@ -126,6 +127,8 @@ def load():
     lib.fo_sweep_set_agents.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, vp]
     lib.fo_sweep_run.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, vp]
     lib.fo_sweep_check.argtypes = [vp, vp]
+    lib.fo_sweep_autotune.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, C.c_int, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_double), vp]
     lib.fo_sweep_timing.argtypes = [vp, C.c_int]
     lib.fo_sweep_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.fo_sweep_timing_read_each.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]

@@ -34,7 +34,9 @@ class PlanningStep:
             spawn_locator.batch = spawn_locator._alloc()
         self.batch = spawn_locator.batch
         A = int(self.batch.pos.shape[0])
-        ldt = torch.float32 if lists == "f32" else torch.float64
+        if lists not in N.LIST_FORMAT:
+            raise ValueError(f"unknown list format '{lists}'")
+        ldt = torch.float64 if lists == "f64" else torch.float32
         self.out = SweepResult(cost=torch.empty((self.M, N.NC), dtype=torch.float64, device=dev),
                                safe=torch.empty((self.M,), dtype=torch.uint8, device=dev))
         if mode in ("pair", "full"):
@@ -77,7 +79,7 @@ class PlanningStep:
         s.d_x, s.d_y, s.d_theta, s.d_vel, s.d_acc = (p(q) for q in self.traj)
         o = self.out
         s.d_cost, s.d_safe, s.d_pair_f, s.d_pair_i, s.d_lists = p(o.cost), p(o.safe), p(o.pair_f), p(o.pair_i), p(o.lists_raw)
-        s.list_format = N.LISTS_F32 if self.lists == "f32" else N.LISTS_F64
+        s.list_format = N.LIST_FORMAT[self.lists]
         s.spawn_mode = N.SPAWN_MODE[sl.mode]
         if sl.mode != "cells":       # the reference's rule families, device resident
             if not getattr(sl, "_rules_ready", False):

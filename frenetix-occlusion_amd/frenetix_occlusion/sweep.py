@@ -147,15 +147,18 @@ class MetricSweep:
                 got = None if t is None else (tuple(t.shape), t.dtype, str(t.device))
                 raise ValueError(f"out.{name}: need contiguous {w[0]} {w[1]} on {self.device}, got {got}")
 
-    def run(self, x, y, theta, v, a=None, mode="reduced", out: Optional[SweepResult] = None, lists="f64") -> SweepResult:
+    def run(self, x, y, theta, v, a=None, mode="reduced", out: Optional[SweepResult] = None, lists="f64",
+            autotune=0) -> SweepResult:
         """x,y,theta,v[,a]: [M,T].  mode: 'reduced' (cost+safe), 'pair' (+ per-pair scalars), 'full' (+ lists).
-        lists: element type of the per-timestep lists of mode 'full' -- 'f64' (the reference's numpy dtype) or 'f32'
-        (half the bytes; cost / safe / pair outputs are identical, see fo_sweep_set_list_format in include/fo_hip.h)."""
-        if lists not in ("f64", "f32"):
+        lists: element type of the per-timestep lists of mode 'full' -- 'f64' (the reference's numpy dtype), 'f32'
+        (half the bytes; cost / safe / pair outputs are identical, see fo_sweep_set_list_format in include/fo_hip.h) or
+        'f32x' (float32 storage of the float64 results).  autotune = n > 0: instead of one run, let the library time its
+        agents-per-wave settings on this batch (n launches each) and keep the best for the shape (``last_autotune``)."""
+        if lists not in N.LIST_FORMAT:
             raise ValueError(f"unknown list format '{lists}'")
-        ldt = torch.float32 if lists == "f32" else torch.float64
+        ldt = torch.float64 if lists == "f64" else torch.float32
         if lists != getattr(self.ctx, "list_format", "f64"):     # per-context state: cached on the Context, not here
-            self.ctx.call("fo_sweep_set_list_format", N.LISTS_F32 if lists == "f32" else N.LISTS_F64)
+            self.ctx.call("fo_sweep_set_list_format", N.LIST_FORMAT[lists])
             self.ctx.list_format = lists
         ins = [x, y, theta, v] + ([a] if a is not None else [])
         if all(isinstance(q, np.ndarray) and q.ndim == 2 and q.shape == ins[0].shape for q in ins) and ins[0].size:
@@ -181,8 +184,16 @@ class MetricSweep:
                 out.lists_raw = torch.empty((N.NL * A * max(T - 1, 0) * M,), dtype=ldt, device=self.device)
         p = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
         self._last_inputs = (x, y, theta, v, a)
-        self.ctx.call("fo_sweep_run", M, T, p(x), p(y), p(theta), p(v), p(a), p(out.cost), p(out.safe),
-                      p(out.pair_f), p(out.pair_i), p(out.lists_raw), self._stream())
+        if autotune:
+            # measure the kernel's agents-per-wave settings on THIS batch and keep the best for the shape (fo_sweep_autotune)
+            import ctypes as C
+            best, ms4 = C.c_int(), (C.c_double * 4)()
+            self.ctx.call("fo_sweep_autotune", M, T, p(x), p(y), p(theta), p(v), p(a), p(out.cost), p(out.safe),
+                          p(out.pair_f), p(out.pair_i), p(out.lists_raw), int(autotune), C.byref(best), ms4, self._stream())
+            self.last_autotune = {"agents_per_wave": best.value, "ms": {k: ms4[i] for i, k in enumerate((1, 2, 4, 8))}}
+        else:
+            self.ctx.call("fo_sweep_run", M, T, p(x), p(y), p(theta), p(v), p(a), p(out.cost), p(out.safe),
+                          p(out.pair_f), p(out.pair_i), p(out.lists_raw), self._stream())
         if getattr(self, "_stage", None) is not None:
             self._stage_busy = torch.cuda.Event()   # last consumer of the staging buffer (see _upload_packed)
             self._stage_busy.record()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 8
+#define FO_ABI_VERSION 9
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -94,7 +94,10 @@ int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta);
  * pair.  Collision probabilities and risks are the float64 results rounded at the store; harm entries away from the 5 m
  * gate are evaluated in float32 (hardware exp / rcp, |error| < 4e-7 -- north_star's tolerance is 1e-5).  cost, safe,
  * pair_f and pair_i are float64 / exact and bit-identical in both formats. */
-enum { FO_LISTS_F64 = 0, FO_LISTS_F32 = 1 };
+/* FO_LISTS_F32_EXACT: float32 elements in the same layout as FO_LISTS_F32, every entry the float64 result rounded at the
+ * store (the arithmetic of FO_LISTS_F64, the bytes of FO_LISTS_F32; bench.py times it beside FO_LISTS_F32 so that the
+ * price of the float32 harm entries is a number). */
+enum { FO_LISTS_F64 = 0, FO_LISTS_F32 = 1, FO_LISTS_F32_EXACT = 2 };
 int fo_sweep_set_list_format(fo_ctx *ctx, int format);
 
 /* replaces: agent_manager.predictions (agent.py:179-183) as read by every metric */
@@ -110,6 +113,17 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
 int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
                  const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
                  int32_t *d_pair_i, double *d_lists, void *stream);
+
+/* The sweep kernel gives every wave `agents per wave` agents of a tile; the best value (1, 2, 4 or 8) depends on the batch
+ * shape (how many workgroups the grid has against the chip's 768 slots).  fo_sweep_run picks one by a static rule;
+ * fo_sweep_autotune MEASURES the four settings on the caller's own batch -- `reps` launches each, HIP events on `stream` --
+ * and remembers the fastest for every later fo_sweep_run / fo_step_run on this context with the same shape (number of
+ * 64-trajectory tiles, agent slots, horizon, output mode, list format).  Arguments as for fo_sweep_run (agents set
+ * before); the outputs hold a complete result afterwards.  best_apw / ms4 [4] (ms per launch for 1, 2, 4, 8) may be
+ * NULL.  Synchronises the stream; call it once when a planning loop starts.  (No counterpart in the reference.) */
+int fo_sweep_autotune(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
+                      const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
+                      int32_t *d_pair_i, double *d_lists, int reps, int *best_apw, double *ms4, void *stream);
 
 /* Blocks until `stream` has drained, then returns FO_E_UNSUPPORTED_COV if the last fo_sweep_set_agents met a matrix
  * that is no usable covariance -- asymmetric, not positive, or |correlation| > 0.99 (those agents' collision
@@ -359,7 +373,7 @@ typedef struct {
   double *d_pair_f;
   int32_t *d_pair_i;
   double *d_lists;
-  /* element type of d_lists for THIS run (FO_LISTS_F64 / FO_LISTS_F32); the step sets the context's format to it before
+  /* element type of d_lists for THIS run (FO_LISTS_F64 / FO_LISTS_F32 / FO_LISTS_F32_EXACT); the step sets the context's format to it before
    * the sweep, so a stale fo_sweep_set_list_format of another caller cannot make the kernel write the other width */
   int32_t list_format;
   /* Which spawn stage feeds the sweep (interface.py:186-198).  FO_SPAWN_CELLS: fo_scene_spawn, the build's own sampling in

@@ -698,9 +698,111 @@ def gen_sampling_matrix():
     print("sampling_matrix.npz", np.array(mats).shape)
 
 
+def gen_shadow_geometry():
+    """The shadow geometry of the reference's sensor model, from its OWN arithmetic: utils/helper_functions.py
+    (create_polygon_from_vertices :79-96, get_polygon_from_obstacle_occlusion / _identify_projection_points :139-176) and
+    sensor_model.SensorModel._calc_relevant_sector (:201-209) are pure numpy up to the final shapely ``Polygon(...)``
+    constructor.  Imported unmodified with ``shapely.geometry.Polygon`` replaced by a class that RECORDS its vertex list,
+    they hand over the reference's own quad / wedge / sector vertices for random inputs -- inputs and outputs only go to
+    shadow_geometry.npz.  (What GEOS then does with those polygons -- difference, intersection -- is not run: absent.)"""
+    class RecPolygon:
+        def __init__(self, shell=None, holes=None):
+            self.vertices = np.array([np.asarray(v, dtype=np.float64) for v in shell], dtype=np.float64)
+
+    class Dummy:
+        def __init__(self, *a, **kw):
+            pass
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    mp = mod("shapely.geometry.multipolygon", MultiPolygon=Dummy)
+    mod("shapely", geometry=mod("shapely.geometry", Polygon=RecPolygon, Point=Dummy, MultiPolygon=Dummy, LineString=Dummy,
+                                multipolygon=mp),
+        affinity=mod("shapely.affinity", rotate=Dummy, translate=Dummy))
+    sys.path.insert(0, REF)
+    import frenetix_occlusion.utils.helper_functions as hf
+    from frenetix_occlusion.sensor_model import SensorModel
+    rng = np.random.default_rng(20240141)
+    # (a) boundary shadows: quad of a vertex pair (helper_functions.py:79-96)
+    n = 200
+    ego_a = rng.uniform(-60.0, 60.0, size=(n, 2))
+    ang = rng.uniform(0.0, 2.0 * np.pi, n)
+    dist = rng.uniform(0.2, 55.0, n)
+    v1 = ego_a + dist[:, None] * np.stack((np.cos(ang), np.sin(ang)), -1)
+    v2 = v1 + rng.uniform(-4.0, 4.0, size=(n, 2))
+    v2[:5] = v1[:5]                                    # degenerate pairs (a repeated vertex)
+    v2[5:10] = ego_a[5:10] + 2.5 * (v1[5:10] - ego_a[5:10])     # collinear with the ego: zero-area quad
+    quads = np.array([hf.create_polygon_from_vertices(v1[i], v2[i], ego_a[i]).vertices for i in range(n)])
+    # (b) obstacle shadows: silhouette pair + wedge (helper_functions.py:139-176)
+    m = 200
+    ego_b = rng.uniform(-40.0, 40.0, size=(m, 2))
+    yaw = rng.uniform(-np.pi, np.pi, m)
+    length, width = rng.uniform(0.5, 12.0, m), rng.uniform(0.4, 3.0, m)
+    cdist = rng.uniform(0.3, 50.0, m)
+    cang = rng.uniform(0.0, 2.0 * np.pi, m)
+    cen = ego_b + cdist[:, None] * np.stack((np.cos(cang), np.sin(cang)), -1)
+    # special geometries: axis-aligned rectangles seen along an axis (ties among the 16 angles), the ego on the extension of
+    # a side, the ego close to a corner, the ego almost touching a long side
+    yaw[:8] = 0.0
+    cen[:8] = ego_b[:8] + np.array([[10.0, 0.0], [0.0, 7.0], [-6.0, 0.0], [0.0, -3.0], [5.0, 5.0], [-5.0, 5.0], [12.0, 0.0], [0.0, 9.0]])
+    length[:8], width[:8] = 4.0, 2.0
+    yaw[8:12] = np.pi / 2
+    cen[8:12] = ego_b[8:12] + np.array([[3.0, 0.0], [1.0 + 1e-9, 5.0], [-1.0, -7.0], [20.0, 2.0]])
+    length[8:12], width[8:12] = 4.0, 2.0
+    corners = np.zeros((m, 4, 2))
+    for i in range(m):
+        base = np.array([[-length[i] / 2, -width[i] / 2], [-length[i] / 2, width[i] / 2], [length[i] / 2, width[i] / 2],
+                         [length[i] / 2, -width[i] / 2]])
+        c, s_ = np.cos(yaw[i]), np.sin(yaw[i])
+        corners[i] = base @ np.array([[c, s_], [-s_, c]]) + cen[i]
+    for i in range(12, 20):                           # the ego 5 cm .. 1 m off a corner, outside the rectangle
+        k = i % 4
+        out_dir = corners[i, k] - cen[i]
+        ego_b[i] = corners[i, k] + out_dir / np.linalg.norm(out_dir) * (0.05 + 0.12 * (i - 12))
+    for i in range(20, 26):                           # the ego 0.3 .. 1.5 m off the middle of a side
+        a, b = corners[i, 0], corners[i, 1]
+        nrm = np.array([-(b - a)[1], (b - a)[0]])
+        nrm = nrm / np.linalg.norm(nrm)
+        if np.dot(nrm, a - cen[i]) < 0:
+            nrm = -nrm
+        ego_b[i] = 0.5 * (a + b) + nrm * (0.3 + 0.24 * (i - 20))
+    wedges, c1s, c2s = np.zeros((m, 4, 2)), np.zeros((m, 2)), np.zeros((m, 2))
+    for i in range(m):
+        poly, c1, c2 = hf.get_polygon_from_obstacle_occlusion(ego_b[i], corners[i])
+        wedges[i], c1s[i], c2s[i] = poly.vertices, c1, c2
+    # (c) sectors (sensor_model.py:201-209): full / open fans, factors 1.0 and 1.5 (the occluded area's half disc, :85-87)
+    cases = []
+    for i in range(12):
+        ego = rng.uniform(-50.0, 50.0, 2)
+        yaw_e = rng.uniform(-np.pi, np.pi)
+        r = [30.0, 50.0, 80.0][i % 3]
+        fov = [90.0, 120.0, 180.0, 270.0, 359.0, 45.0][i % 6]
+        half = np.radians(fov) / 2.0
+        for a0, a1, fac in ((yaw_e - half, yaw_e + half, 1.0), (yaw_e - np.pi / 2, yaw_e + np.pi / 2, 1.5)):
+            self_ = types.SimpleNamespace(ego_pos=ego, sensor_radius=r)
+            sec = SensorModel._calc_relevant_sector(self_, a0, a1, factor=fac)
+            cases.append((ego, r, a0, a1, fac, sec.vertices))
+    np.savez_compressed(os.path.join(OUT, "shadow_geometry.npz"),
+                        quad_ego=ego_a, quad_v1=v1, quad_v2=v2, quad_ref=quads,
+                        wedge_ego=ego_b, wedge_corners=corners, wedge_ref=wedges, wedge_c1=c1s, wedge_c2=c2s,
+                        sector_ego=np.array([c[0] for c in cases]), sector_r=np.array([c[1] for c in cases]),
+                        sector_a0=np.array([c[2] for c in cases]), sector_a1=np.array([c[3] for c in cases]),
+                        sector_factor=np.array([c[4] for c in cases]), sector_ref=np.array([c[5] for c in cases]))
+    print("shadow_geometry.npz quads", quads.shape, "wedges", wedges.shape, "sectors", np.array([c[5] for c in cases]).shape)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sampling":     # only the sampling-matrix fixture
         gen_sampling_matrix()
+    elif len(sys.argv) > 1 and sys.argv[1] == "shadow":     # only the shadow-geometry fixture
+        gen_shadow_geometry()
     else:
         main()
         gen_sampling_matrix()
+        # (the shadow-geometry fixture needs its own process: its recording Polygon stub would shadow the inert stubs above)
+        import subprocess
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "shadow"])

@@ -148,6 +148,22 @@ def _unit(v):
     return v / np.linalg.norm(v)
 
 
+def shadow_quad(v1, v2, ego):
+    """ref helper_functions.py:79-96 (create_polygon_from_vertices): the area a boundary vertex pair hides from the ego --
+    [v1, v2, v2 + 100 (v2 - ego), v1 + 100 (v1 - ego)]; pinned to the reference's own function by tests/golden/shadow_geometry.npz"""
+    v1, v2, ego = (np.asarray(q, float) for q in (v1, v2, ego))
+    return np.array([v1, v2, v2 + 100 * (v2 - ego), v1 + 100 * (v1 - ego)])
+
+
+def obstacle_wedge(ego, corners):
+    """ref helper_functions.py:139-176 (get_polygon_from_obstacle_occlusion): (wedge [c1, c2, c2 + 100 u(c2 - ego),
+    c1 + 100 u(c1 - ego)], c1, c2) with (c1, c2) the corner pair that subtends the largest angle at the ego; pinned like
+    shadow_quad"""
+    ego = np.asarray(ego, float)
+    c1, c2 = _projection_points(ego, np.asarray(corners, float).reshape(4, 2))
+    return np.array([c1, c2, c2 + _unit(c2 - ego) * 100, c1 + _unit(c1 - ego) * 100]), c1, c2
+
+
 def _projection_points(ego, corners):
     """ref helper_functions.py:143-166: the corner pair subtending the largest angle at the ego."""
     best, ret = 0.0, (corners[0], corners[0])
@@ -179,10 +195,7 @@ def classify(q, lanelet_polys, boundary_edges, ego, yaw, r, fov_deg=360.0, obsta
         if points_in_polygon(np.concatenate((e[:, :2], e[:, 2:]), 0), foot).all():
             casts[lab == k] = False
     pieces = _clip_segments_to_polygon(boundary_edges[casts], foot, convex=fov_deg >= 359.9)
-    quads = np.empty((len(pieces), 4, 2))
-    quads[:, 0], quads[:, 1] = pieces[:, :2], pieces[:, 2:]
-    quads[:, 2] = pieces[:, 2:] + 100.0 * (pieces[:, 2:] - ego)
-    quads[:, 3] = pieces[:, :2] + 100.0 * (pieces[:, :2] - ego)
+    quads = np.array([shadow_quad(e[:2], e[2:], ego) for e in pieces]).reshape(-1, 4, 2)
     cand = np.nonzero(vis)[0]                               # only road cells inside the footprint can lose visibility
     vis[cand] &= ~_in_quads(q[cand], quads)
     for corn, bike in zip(obstacle_corners, obstacle_is_bicycle):
@@ -195,8 +208,7 @@ def classify(q, lanelet_polys, boundary_edges, ego, yaw, r, fov_deg=360.0, obsta
         la, lb = np.linalg.norm(ax), np.linalg.norm(ay)
         infl = np.array([c + sx * (0.5 * la + 0.005) * ax / la + sy * (0.5 * lb + 0.005) * ay / lb
                          for sx, sy in ((-1, -1), (1, -1), (1, 1), (-1, 1))])
-        c1, c2 = _projection_points(ego, corn)
-        occl = np.array([c1, c2, c2 + _unit(c2 - ego) * 100.0, c1 + _unit(c1 - ego) * 100.0])
+        occl, _, _ = obstacle_wedge(ego, corn)
         cand = np.nonzero(vis)[0]
         vis[cand] &= ~_in_quads(q[cand], np.array([infl, occl]))
     half = sector_polygon(ego, 1.5 * r, yaw - math.radians(90), yaw + math.radians(90))

@@ -1,5 +1,7 @@
 """Parity of the HIP sweep (through the C ABI, libfo_hip.so) against the CPU oracle and the reference's golden
 vectors.  Needs a real MI355X: run with `pytest -m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -245,6 +247,60 @@ def test_float32_lists_generic_kernel_and_metric_subset(torch_cuda, oracle, monk
     monkeypatch.delenv("FO_SWEEP_GENERIC")
     g32 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("dce",), lists="f32")
     assert g32["lists"].dtype == np.float32 and np.isnan(g32["lists"]).all()
+
+
+@pytest.mark.parametrize("M,A,cfg", [(300, 16, 1), (2000, 32, 2), (70, 9, 8)])
+def test_float32_exact_lists_are_the_float64_lists_rounded(torch_cuda, oracle, monkeypatch, M, A, cfg):
+    """fo_sweep_set_list_format(FO_LISTS_F32_EXACT) / lists='f32x': float32 storage of the float64 results -- every list entry
+    equals the float64-list mode's entry rounded to float32 (the queue kernel's instantiation for the default metric set; a
+    metric subset goes through the generic kernel, which converts at the store as well), everything else bit-identical"""
+    from frenetix_occlusion import synthetic as S
+    traj, agents = S.make_batch(M, A, config_id=cfg)
+    if cfg == 8:
+        agents["len"] = np.array([31, 1, 2, 30, 17, 31, 5, 29, 0], dtype=np.int32)
+    thr = {"harm": 0.3, "risk": 0.2, "ttc": 1.0, "dce": 0.05, "cp": 0.8}
+    g64 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr)
+    gx = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, lists="f32x")
+    assert gx["lists"].dtype == np.float32
+    for k in ("cost", "safe", "pair_i"):
+        assert np.array_equal(gx[k], g64[k]), k
+    assert np.array_equal(gx["pair_f"], g64["pair_f"], equal_nan=True)
+    assert np.array_equal(gx["lists"], g64["lists"].astype(np.float32), equal_nan=True)
+    # metric subset -> generic kernel: against the oracle
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
+    gxs = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32x")
+    monkeypatch.setenv("FO_SWEEP_GENERIC", "1")    # (its float64 twin: the generic kernel with float64 lists)
+    g64s = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
+    _compare_f32_lists(ref["lists"], gxs, g64s)
+    assert np.array_equal(gxs["lists"], g64s["lists"].astype(np.float32), equal_nan=True)
+
+
+def test_autotune_measures_and_keeps_a_setting_without_changing_results(torch_cuda):
+    """fo_sweep_autotune: the library times the sweep kernel's agents-per-wave settings on the caller's batch, remembers the
+    best for the shape, and leaves a complete result; later runs of that shape use it, other shapes keep the static rule"""
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sweep import MetricSweep
+    traj, agents = S.make_batch(4000, 64, config_id=4)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds={"harm": 0.1, "risk": 1})
+    sw.set_agents(*[agents[k] for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")])
+    args = [traj[k] for k in ("x", "y", "theta", "v", "a")]
+    plain = sw.run(*args, mode="pair")
+    torch_cuda.cuda.synchronize()
+    want = [t.cpu().numpy().copy() for t in (plain.cost, plain.safe, plain.pair_f, plain.pair_i)]
+    tuned = sw.run(*args, mode="pair", autotune=5)
+    torch_cuda.cuda.synchronize()
+    best = sw.last_autotune["agents_per_wave"]
+    assert best in (1, 2, 4, 8) and set(sw.last_autotune["ms"]) == {1, 2, 4, 8} and all(v > 0 for v in sw.last_autotune["ms"].values())
+    assert sw.last_autotune["ms"][best] == min(sw.last_autotune["ms"].values())
+    for a, b in zip(want, (tuned.cost, tuned.safe, tuned.pair_f, tuned.pair_i)):
+        assert np.array_equal(a, b.cpu().numpy(), equal_nan=True)
+    again = sw.run(*args, mode="pair")
+    torch_cuda.cuda.synchronize()
+    if os.environ.get("FO_SWEEP_SPLIT") is None:
+        assert sw.ctx.last_launch()["agents_per_wave"] == best
+    assert np.array_equal(again.cost.cpu().numpy(), want[0], equal_nan=True)
+    sw.run(*[q[:1000] for q in args], mode="pair")                 # another shape: not in the table
+    torch_cuda.cuda.synchronize()
 
 
 def test_metric_subset_config1(torch_cuda, oracle):
