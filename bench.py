@@ -413,12 +413,16 @@ def rules_step(local_rank, steps=300):
         ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
         obs.update(step)
         sm.upload_obstacles(obs)
+        # (the planner hands the ego's curvilinear position to evaluate_scenario, interface.py:148: an input of the step)
+        if not getattr(sl, "_rules_ready", False):
+            sl._rule_setup()
+        ego_cl = sl._cs.convert_to_curvilinear_coords(float(ego[0]), float(ego[1]))
         for _ in range(50):
-            ps.run(ego, yaw, float(ego0[3]))
+            ps.run(ego, yaw, float(ego0[3]), ego_cl)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            ps.run(ego, yaw, float(ego0[3]))
+            ps.run(ego, yaw, float(ego0[3]), ego_cl)
         t_issue = (time.perf_counter() - t0) / steps
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps

@@ -96,6 +96,8 @@ struct Scene {
   size_t cap_amb = 0;
   double *d_rule_rec = nullptr;   // [1 + O][24] per-workgroup records of the spawn rule families (fo_spawn_rules.hpp)
   size_t cap_rule_rec = 0;
+  int *d_rule_lab = nullptr, *d_rule_cnt = nullptr;   // dynamic rule: [O][97 x 97] lattice labels, [O] arrival counters
+  size_t cap_rule_lab = 0, cap_rule_cnt = 0;
 };
 
 Scene *scene_of(fo_ctx *ctx) {
@@ -1265,7 +1267,7 @@ extern "C" {
 void fo_scene_destroy_(fo_ctx *ctx) {
   if (!ctx || !ctx->scene) return;
   Scene *sc = (Scene *)ctx->scene;
-  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_flags2, sc->d_blk2, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_rule_rec};
+  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_flags2, sc->d_blk2, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_rule_rec, sc->d_rule_lab, sc->d_rule_cnt};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   map_release(sc->map);

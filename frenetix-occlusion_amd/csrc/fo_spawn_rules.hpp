@@ -16,8 +16,8 @@
 // [n][6] = x, y, s, segment length, unit tangent is built on the host once per reference path).
 // Checked against oracle/fo_spawn_rules_ref.py (an independent NumPy restatement of the same definitions).
 //
-// Launch shape: one workgroup for the turn rule + one per obstacle (static rule: a wave; dynamic rule: 256 threads and
-// 76 KB of LDS for the 97 x 97 candidate lattice), then one small workgroup that applies what depends on the order of
+// Launch shape: one workgroup for the turn rule + one per obstacle (static rule: a wave; dynamic rule: 1 024 threads and
+// 100 KB of LDS for the 97 x 97 candidate lattice), then one small workgroup that applies what depends on the order of
 // the obstacles (sorted by distance, the maxima of the YAML, 5 m between pedestrians) and writes the spawn points.
 
 namespace {
@@ -40,6 +40,9 @@ constexpr double RL_AREA_CAR = 9.0, RL_AREA_BIKE = 1.7;   // :72
 constexpr int RL_LAT = 97;                         // nodes per side of the 0.25 m candidate lattice (2 x 12 m + 1)
 constexpr int RL_MAXSAMP = 1024;                   // samples of a rule polyline (cs/8 steps; 40 m at cs = 0.5 -> 641)
 constexpr int RL_REC = 24;                         // doubles per per-workgroup record
+constexpr int RL_PATHV = 512;                      // vertices of the reference path table held in LDS (longer paths: read from HBM)
+constexpr int RL_PARTS = 8;                        // workgroups that share a dynamic obstacle's candidate lattice
+constexpr int RL_PVERT = 1024;                     // vertices of a dynamic obstacle's <= 8 candidate lanelet polygons held in LDS
 
 enum { RL_TYPE_CAR = 0, RL_TYPE_BICYCLE = 3, RL_TYPE_PED = 4 };
 enum { RL_SRC_DYNAMIC = 1, RL_SRC_STATIC = 2, RL_SRC_LEFT = 3, RL_SRC_RIGHT = 4 };
@@ -131,6 +134,35 @@ __device__ inline bool rl_to_curv(const RuleView &v, double x, double y, double 
     const double d2 = (x - fx) * (x - fx) + (y - fy) * (y - fy);
     if (d2 < best) { best = d2; k = i; bt = t; btc = tc; }
   }
+  const double *q = v.path + 6 * (size_t)k;
+  if ((k == 0 && bt < 0.0) || (k == ns - 1 && bt > q[3])) return false;
+  const double fx = q[0] + btc * q[4], fy = q[1] + btc * q[5];
+  s = q[2] + btc;
+  d = (x - fx) * (-q[5]) + (y - fy) * q[4];
+  return true;
+}
+// the same projection by a whole wave (every lane must call it with the same point): lane l takes the segments l, l + 64,
+// ...; the wave keeps the smallest (distance, segment index) -- the first minimum of the sequential scan -- and every
+// lane returns it.  (The sequential form is a chain of ~n_path dependent trips to the table in HBM.)
+__device__ inline bool rl_to_curv_wave(const RuleView &v, double x, double y, double &s, double &d) {
+  const int ns = v.n_path - 1, lane = threadIdx.x & 63;
+  double best = INFINITY, bt = 0.0, btc = 0.0;
+  int k = 0x7fffffff;
+  for (int i = lane; i < ns; i += 64) {
+    const double *q = v.path + 6 * (size_t)i;
+    const double t = (x - q[0]) * q[4] + (y - q[1]) * q[5];
+    const double tc = fmin(fmax(t, 0.0), q[3]);
+    const double fx = q[0] + tc * q[4], fy = q[1] + tc * q[5];
+    const double d2 = (x - fx) * (x - fx) + (y - fy) * (y - fy);
+    if (d2 < best) { best = d2; k = i; bt = t; btc = tc; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double b2 = __shfl_xor(best, off), t2 = __shfl_xor(bt, off), c2 = __shfl_xor(btc, off);
+    const int k2 = __shfl_xor(k, off);
+    if (b2 < best || (b2 == best && k2 < k)) { best = b2; k = k2; bt = t2; btc = c2; }
+  }
+  if (k == 0x7fffffff) return false;
   const double *q = v.path + 6 * (size_t)k;
   if ((k == 0 && bt < 0.0) || (k == ns - 1 && bt > q[3])) return false;
   const double fx = q[0] + btc * q[4], fy = q[1] + btc * q[5];
@@ -249,16 +281,18 @@ __device__ void rl_turn_rule(const RuleView &v, const RuleParams &pr, double *re
     inside[i] = (rl_class_at(v, x, y) & 4) ? 1 : 0;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (lane != 0) return;
   // runs of consecutive samples in occluded cells: the first point of the only run, of the LAST run when there are several (:528)
-  int n_runs = 0, first_of_last = -1;
-  for (int i = 0; i < ns; ++i)
-    if (inside[i] && (i == 0 || !inside[i - 1])) { ++n_runs; first_of_last = i; }
-  if (n_runs == 0) return;
+  int first_of_last = -1;
+  for (int i = lane; i < ns; i += 64)
+    if (inside[i] && (i == 0 || !inside[i - 1])) first_of_last = i;      // ascending per lane: its last run start
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) first_of_last = max(first_of_last, __shfl_xor(first_of_last, off));
+  if (first_of_last < 0) return;
   double fx, fy;
   rl_sample(lx, ly, cum, nw, fmin((double)first_of_last * step, total), fx, fy);
   double s_int, d_int;
-  if (!rl_to_curv(v, fx, fy, s_int, d_int)) return;
+  if (!rl_to_curv_wave(v, fx, fy, s_int, d_int)) return;
+  if (lane != 0) return;
   double s_ph = s_int + (left ? -0.5 : 0.0);
   if (s_ph > pr.s_threshold || s_ph < pr.ego_s + 3.0) return;                    // :542
   const double d_ph = left ? 1.0 : -1.0, d_off = d_ph + (left ? 3.0 : 0.0);     // :546
@@ -284,13 +318,13 @@ __device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, i
   if (lane == 0) { rec[2] = 0.0; rec[8] = 0.0; }
   if (sqrt((pr.ego_x - cx) * (pr.ego_x - cx) + (pr.ego_y - cy) * (pr.ego_y - cy)) > RL_MAX_DIST_OBST) return;   // :369
   double ob_s, ob_d;
-  if (!rl_to_curv(v, cx, cy, ob_s, ob_d)) return;
+  if (!rl_to_curv_wave(v, cx, cy, ob_s, ob_d)) return;
   // :380 compares with ego s + s_threshold although s_threshold already contains ego s (kept as in the reference)
   if (pr.ego_s + pr.s_threshold < ob_s || ob_s < pr.ego_s + 3.0) return;
   double s_min = INFINITY, s_max = -INFINITY, d_min = INFINITY, d_max = -INFINITY;
   for (int i = 0; i < 4; ++i) {
     double s, d;
-    if (!rl_to_curv(v, oc[2 * i], oc[2 * i + 1], s, d)) return;
+    if (!rl_to_curv_wave(v, oc[2 * i], oc[2 * i + 1], s, d)) return;
     s_min = fmin(s_min, s); s_max = fmax(s_max, s); d_min = fmin(d_min, d); d_max = fmax(d_max, d);
   }
   s_min -= 0.8; s_max += 0.8; d_min -= 0.8; d_max += 0.8;                          // :384-390
@@ -322,10 +356,11 @@ __device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, i
       if ((oflags[j] & 1) && ovis[j] && rl_seg_rect_distance(ax, ay, bx, by, ocorn + 8 * (size_t)j) <= pr.ped_width / 2.0) blocked = true;
     if (__ballot(blocked)) continue;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double spx = 0.0, spy = 0.0;
+    bool okp = false;
     if (lane == 0) {
       // candidates: where "the disc touches the visible area" flips, the sample just outside (:414-415)
       int n_c = 0;
-      double spx = 0.0, spy = 0.0;
       bool found = false;
       int only = -1;
       for (int i = 0; i + 1 < ns; ++i)
@@ -343,7 +378,7 @@ __device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, i
             if ((rl_class_at(v, sx[c], sy[c]) & 4) && dd < bestd) { bestd = dd; spx = sx[c]; spy = sy[c]; found = true; }
           }
       }
-      bool okp = found;
+      okp = found;
       if (okp) {
         bool any, all;
         rl_disc(v, spx, spy, 0.15, 2, any, all);
@@ -351,11 +386,16 @@ __device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, i
         rl_disc(v, spx, spy, 0.15, 1, any, all);
         if (!all) okp = false;                                                    // :444
       }
-      double ss = 0.0, sd = 0.0;
-      if (okp && !rl_to_curv(v, spx, spy, ss, sd)) okp = false;
-      if (okp && !have_yaw) okp = false;
+    }
+    // the point's curvilinear position: projected by the whole wave (lane 0 holds the point)
+    const bool okw = __shfl((int)okp, 0) != 0;
+    spx = __shfl(spx, 0);
+    spy = __shfl(spy, 0);
+    double ss = 0.0, sd = 0.0;
+    const bool okc = okw && rl_to_curv_wave(v, spx, spy, ss, sd);
+    if (lane == 0) {
       double *r = rec + 2 + 6 * li;
-      r[0] = okp ? 1.0 : 0.0; r[1] = spx; r[2] = spy; r[3] = ss; r[4] = sd; r[5] = yaw_l + 1.5707963267948966;
+      r[0] = (okc && have_yaw) ? 1.0 : 0.0; r[1] = spx; r[2] = spy; r[3] = ss; r[4] = sd; r[5] = yaw_l + 1.5707963267948966;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
@@ -367,66 +407,103 @@ struct RlFit { double area, cx, cy, jac; bool any; };
 // rec: [0] distance, [1] role = 2, [2] car valid, [3] car x, [4] car y, [5] bicycle valid, [6] x, [7] y
 __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, const double *ocorn, const double *ocen,
                                 const double *oyaw, const double *odims, double *rec, int *lab, double *red, int *ired,
-                                unsigned char *fitok) {
+                                unsigned char *fitok, double *polyv, int part, int *g_lab, int *g_cnt) {
   const int tid = threadIdx.x, nth = blockDim.x;
   const double cx = ocen[2 * o], cy = ocen[2 * o + 1], oy = oyaw[o], olen = odims[2 * o], owid = odims[2 * o + 1];
   const double *oc = ocorn + 8 * (size_t)o;
-  __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn, s_ego_ll, s_inter;
-  __shared__ double s_c[2], s_yaw;
+  __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn, s_ego_ll, s_inter, s_nin, s_in[16], s_vll[64], s_relc, s_curv_ok;
+  __shared__ int s_poff[9], s_plds;
+  __shared__ double s_c[2], s_yaw, s_pbox[32], s_obsd[2];
   // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
   // oncoming neighbours (adj_left) of the lanelets under every fifth vertex of the reference window.  Flags per lanelet
-  // in ired[0, P): bit0 relevant, bit1 inner -- computed once, in parallel (P <= 97 x 97)
+  // in ired[0, P): bit0 relevant, bit1 inner.  Every "which lanelet holds this point" below is asked of all lanelets at
+  // once, a thread per (point, lanelet) -- the first lanelet in list order by atomicMin -- instead of one thread walking
+  // the polygon table in HBM
   if (v.P > RL_LAT * RL_LAT) return;
   for (int p = tid; p < v.P; p += nth) ired[p] = 0;
   if (tid == 0) {
     rec[2] = 0.0; rec[5] = 0.0;
-    s_go = 0;
-    s_npol = 0;
-    s_inter = -1;
-    s_ego_ll = rl_lanelet_of(v, pr.ego_x, pr.ego_y);
-    for (int it = 0; it < v.n_inter && s_inter < 0 && s_ego_ll >= 0; ++it)
-      for (int e = v.inter_off[it]; e < v.inter_off[it + 1]; ++e)
-        if (v.inter_lanelet[e] == s_ego_ll) { s_inter = it; break; }
+    s_go = 0; s_npol = 0; s_inter = -1; s_ego_ll = 0x7fffffff; s_nin = 0; s_relc = 0; s_curv_ok = 0;
+  }
+  if (tid < 64) s_vll[tid] = 0x7fffffff;
+  __syncthreads();
+  for (int p = tid; p < v.P; p += nth) {
+    if (rl_in_polygon(v, p, pr.ego_x, pr.ego_y)) atomicMin(&s_ego_ll, p);
+    if (rl_in_polygon(v, p, cx, cy)) { const int q = atomicAdd(&s_nin, 1); if (q < 16) s_in[q] = p; }   // the obstacle's lanelets
+  }
+  if (tid < 64) {   // the obstacle's curvilinear position (wave 0)
+    double ob_s, ob_d;
+    const bool okc = rl_to_curv_wave(v, cx, cy, ob_s, ob_d);
+    if (tid == 0) { s_curv_ok = okc ? 1 : 0; s_obsd[0] = ob_s; s_obsd[1] = ob_d; }
   }
   __syncthreads();
-  if (s_ego_ll < 0) return;
+  if (s_ego_ll == 0x7fffffff) return;
+  if (tid == 0)
+    for (int it = 0; it < v.n_inter && s_inter < 0; ++it)
+      for (int e = v.inter_off[it]; e < v.inter_off[it + 1]; ++e)
+        if (v.inter_lanelet[e] == s_ego_ll) { s_inter = it; break; }
+  __syncthreads();
   if (s_inter >= 0) {
     for (int e = v.inter_off[s_inter] + tid; e < v.inter_off[s_inter + 1]; e += nth) {
       const int p = v.inter_lanelet[e];
       atomicOr(&ired[p], (p != s_ego_ll ? 1 : 0) | (v.inter_kind[e] == 1 ? 2 : 0));
     }
   } else if (v.adj_left) {
-    for (int i = pr.win_i0 + 5 * tid; i < pr.win_i1; i += 5 * nth) {
-      const double *q = v.path + 6 * (size_t)i;
-      const int ll = rl_lanelet_of(v, q[0], q[1]);
-      if (ll >= 0 && v.adj_left[ll] >= 0) atomicOr(&ired[v.adj_left[ll]], 1);
+    const int nv = min((pr.win_i1 - pr.win_i0 + 4) / 5, 64);   // every fifth vertex of the reference window (40 m: a dozen)
+    for (long long w = tid; w < (long long)nv * v.P; w += nth) {
+      const int vi = (int)(w / v.P), p = (int)(w % v.P);
+      const double *q = v.path + 6 * (size_t)(pr.win_i0 + 5 * vi);
+      if (rl_in_polygon(v, p, q[0], q[1])) atomicMin(&s_vll[vi], p);
+    }
+    __syncthreads();
+    if (tid < nv) {
+      const int ll = s_vll[tid];
+      if (ll != 0x7fffffff && v.adj_left[ll] >= 0) atomicOr(&ired[v.adj_left[ll]], 1);
     }
   }
   __syncthreads();
   if (tid == 0) {
     do {
       if (sqrt((pr.ego_x - cx) * (pr.ego_x - cx) + (pr.ego_y - cy) * (pr.ego_y - cy)) > RL_MAX_DIST_OBST) break;   // :215
-      // the obstacle's lanelets (all that hold its centre, list order)
-      int n_ob = 0, first_rel = -1;
+      // the obstacle's lanelets (all that hold its centre) in list order
+      const int n_ob = min(s_nin, 16);
+      for (int i = 1; i < n_ob; ++i) {   // (a point lies on a handful of lanelets: insertion sort)
+        const int key = s_in[i];
+        int j = i - 1;
+        while (j >= 0 && s_in[j] > key) { s_in[j + 1] = s_in[j]; --j; }
+        s_in[j + 1] = key;
+      }
+      int first_rel = -1;
       bool any_rel = false, all_inner = true;
-      for (int p = 0; p < v.P; ++p)
-        if (rl_in_polygon(v, p, cx, cy)) {
-          ++n_ob;
-          if (ired[p] & 1) { any_rel = true; if (first_rel < 0) first_rel = p; if (s_npol < 7) s_pol[s_npol++] = p; }
-          if (!(ired[p] & 2)) all_inner = false;
-        }
+      for (int i = 0; i < n_ob; ++i) {
+        const int p = s_in[i];
+        if (ired[p] & 1) { any_rel = true; if (first_rel < 0) first_rel = p; if (s_npol < 7) s_pol[s_npol++] = p; }
+        if (!(ired[p] & 2)) all_inner = false;
+      }
       if (!any_rel) break;                                                        // :222
-      double ob_s, ob_d;
-      if (!rl_to_curv(v, cx, cy, ob_s, ob_d)) break;
-      if (ob_s < pr.ego_s + 3.0 || fabs(ob_d) > 15.0) break;                      // :234
+      if (!s_curv_ok) break;
+      if (s_obsd[0] < pr.ego_s + 3.0 || fabs(s_obsd[1]) > 15.0) break;            // :234
       if (s_inter >= 0 && n_ob > 0 && all_inner && v.pred0 && v.pred0[first_rel] >= 0 && s_npol < 8) s_pol[s_npol++] = v.pred0[first_rel];   // :249-252
       s_go = 1;
+      // where the candidate polygons' vertices go in LDS (member() below); too many vertices: read from HBM as before
+      int tot = 0;
+      for (int i = 0; i < s_npol; ++i) { s_poff[i] = tot; tot += v.poly_off[s_pol[i] + 1] - v.poly_off[s_pol[i]]; }
+      s_poff[s_npol] = tot;
+      s_plds = tot <= RL_PVERT;
     } while (false);
   }
   __syncthreads();
   if (!s_go) return;
   RL_TICK(0);
   const int npol = s_npol;
+  const bool plds = s_plds != 0;
+  if (plds) {
+    for (int i = 0; i < npol; ++i) {
+      const int b0 = v.poly_off[s_pol[i]], n_ = s_poff[i + 1] - s_poff[i];
+      for (int k = tid; k < 2 * n_; k += nth) polyv[2 * s_poff[i] + k] = v.poly_xy[2 * (size_t)b0 + k];
+    }
+    if (tid < 4 * npol) s_pbox[tid] = v.poly_box[4 * (size_t)s_pol[tid >> 2] + (tid & 3)];
+  }
   // (the relevance flags move to the end of `lab`'s companion array later; keep a compact copy for the centroid test)
   unsigned char *relflag = fitok + 1536;   // [P] bit0: relevant -- only consulted for the few lanelets holding the centroid
   const bool rel_fits = v.P <= 512;
@@ -453,8 +530,10 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
         const double ex = oc[2 * j] - oc[2 * i], ey = oc[2 * j + 1] - oc[2 * i + 1];
         const double den = dx * ey - dy * ex, wx = oc[2 * i] - pr.ego_x, wy = oc[2 * i + 1] - pr.ego_y;
         if (fabs(den) > 1e-14) {
-          const double t = (wx * ey - wy * ex) / den, u = (wx * dy - wy * dx) / den;
-          hit = t >= 0.0 && t <= 1.0 && u >= 0.0 && u <= 1.0;
+          // t = tn / den and u = un / den in [0, 1] without the divisions: a correctly rounded quotient is <= 1 exactly
+          // when |tn| <= |den| and >= 0 exactly when the signs agree (or tn = 0)
+          const double tn = wx * ey - wy * ex, un = wx * dy - wy * dx;
+          hit = den > 0.0 ? (tn >= 0.0 && tn <= den && un >= 0.0 && un <= den) : (tn <= 0.0 && tn >= den && un <= 0.0 && un >= den);
         }
       }
       if (!hit) return false;
@@ -462,75 +541,126 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
       return false;
     }
     bool ok = false;                                                                // possible_polygon (:255)
-    for (int i = 0; i < npol && !ok; ++i) ok = rl_in_polygon(v, s_pol[i], x, y);
+    if (!plds) {
+      for (int i = 0; i < npol && !ok; ++i) ok = rl_in_polygon(v, s_pol[i], x, y);
+      return ok;
+    }
+    for (int i = 0; i < npol && !ok; ++i) {   // rl_in_polygon on the copy in LDS (the same arithmetic)
+      const double *bb = s_pbox + 4 * i;
+      if (x < bb[0] || x > bb[2] || y < bb[1] || y > bb[3]) continue;
+      const int b0 = s_poff[i], e0 = s_poff[i + 1];
+      int c = 0;
+      for (int k = b0, j = e0 - 1; k < e0; j = k++) {
+        const double xi = polyv[2 * k], yi = polyv[2 * k + 1], xj = polyv[2 * j], yj = polyv[2 * j + 1];
+        if ((yi > y) != (yj > y)) {
+          const double xc = xi + (y - yi) * (xj - xi) / (yj - yi);
+          if (x < xc) c ^= 1;
+        }
+      }
+      ok = c != 0;
+    }
     return ok;
   };
   // the 0.25 m lattice around the obstacle; label = linear index where the node is a member, INT_MAX elsewhere
   const double h = 0.25;
   constexpr int NL = RL_LAT * RL_LAT;
-  for (int i = tid; i < NL; i += nth) {
-    const int ix = i % RL_LAT, iy = i / RL_LAT;
-    lab[i] = member(cx + (-RL_BUFFER_SIDE + (double)ix * h), cy + (-RL_BUFFER_SIDE + (double)iy * h)) ? i : 0x7fffffff;
+  // RL_PARTS workgroups (on as many CUs) share the lattice: each decides its slice of the nodes -- membership is arithmetic,
+  // ~300 float64 operations per node, and one CU's four SIMDs are the limit -- and writes it to the obstacle's lattice in
+  // HBM; the workgroup that finishes LAST (a counter per obstacle) loads the whole lattice and goes on alone, the others
+  // are done.  (Every workgroup took the same decisions up to here: they read the same inputs.)
+  {
+    const int chunk = (NL + RL_PARTS - 1) / RL_PARTS, i1 = min((part + 1) * chunk, NL);
+    for (int i = part * chunk + tid; i < i1; i += nth) {
+      const int ix = i % RL_LAT, iy = i / RL_LAT;
+      g_lab[i] = member(cx + (-RL_BUFFER_SIDE + (double)ix * h), cy + (-RL_BUFFER_SIDE + (double)iy * h)) ? i : 0x7fffffff;
+    }
+    __shared__ int s_ticket;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(g_cnt, 1);
+    __syncthreads();
+    if (s_ticket != RL_PARTS - 1) return;
+    if (tid == 0) *g_cnt = 0;   // for the next planning step (launches on a stream are ordered)
+    __threadfence();
+    const volatile int *gl = g_lab;
+    for (int i = tid; i < NL; i += nth) lab[i] = gl[i];
   }
   __syncthreads();
   RL_TICK(1);
-  // connected parts (4-neighbourhood, scipy.ndimage.label's default): minimum-label propagation, whole rows then whole
-  // columns per round; every part ends up carrying its smallest linear index (= scipy's numbering order)
-  for (int round = 0; round < 64; ++round) {
+  // connected parts (4-neighbourhood, scipy.ndimage.label's default) by label equivalence (Hawick et al.): every member node
+  // starts as its own root (label = linear index); a round links the root of every node whose neighbourhood holds a smaller
+  // label to that label (atomicMin), then flattens every node to its root by pointer jumping; labels only ever decrease
+  // and stay inside their part, so every part ends up carrying its smallest linear index (= scipy's numbering order) after
+  // a handful of rounds, whatever its shape -- and every thread of the workgroup works in every round
+  for (int round = 0; round < 256; ++round) {
     if (tid == 0) s_changed = 0;
     __syncthreads();
-    // a thread per row, then per column: the whole line is loaded into registers (independent LDS loads, one wait), swept
-    // both ways there, and written back -- a sweep over LDS itself is a chain of ~200 dependent round trips
     bool ch = false;
-    if (tid < RL_LAT) {
-      int line[RL_LAT];
-#pragma unroll
-      for (int c = 0; c < RL_LAT; ++c) line[c] = lab[tid * RL_LAT + c];
-#pragma unroll
-      for (int c = 1; c < RL_LAT; ++c)
-        if (line[c] != 0x7fffffff && line[c - 1] < line[c]) { line[c] = line[c - 1]; ch = true; }
-#pragma unroll
-      for (int c = RL_LAT - 2; c >= 0; --c)
-        if (line[c] != 0x7fffffff && line[c + 1] < line[c]) { line[c] = line[c + 1]; ch = true; }
-#pragma unroll
-      for (int c = 0; c < RL_LAT; ++c) lab[tid * RL_LAT + c] = line[c];
-    }
-    __syncthreads();
-    if (tid < RL_LAT) {
-      int line[RL_LAT];
-#pragma unroll
-      for (int r = 0; r < RL_LAT; ++r) line[r] = lab[r * RL_LAT + tid];
-#pragma unroll
-      for (int r = 1; r < RL_LAT; ++r)
-        if (line[r] != 0x7fffffff && line[r - 1] < line[r]) { line[r] = line[r - 1]; ch = true; }
-#pragma unroll
-      for (int r = RL_LAT - 2; r >= 0; --r)
-        if (line[r] != 0x7fffffff && line[r + 1] < line[r]) { line[r] = line[r + 1]; ch = true; }
-#pragma unroll
-      for (int r = 0; r < RL_LAT; ++r) lab[r * RL_LAT + tid] = line[r];
+    for (int i = tid; i < NL; i += nth) {
+      const int l = lab[i];
+      if (l == 0x7fffffff) continue;
+      const int ix = i % RL_LAT, iy = i / RL_LAT;
+      int m = l;
+      if (ix > 0) m = min(m, lab[i - 1]);
+      if (ix + 1 < RL_LAT) m = min(m, lab[i + 1]);
+      if (iy > 0) m = min(m, lab[i - RL_LAT]);
+      if (iy + 1 < RL_LAT) m = min(m, lab[i + RL_LAT]);
+      if (m < l) { atomicMin(&lab[l], m); ch = true; }
     }
     if (ch) s_changed = 1;
+    __syncthreads();
+    for (int i = tid; i < NL; i += nth) {
+      int r = lab[i];
+      if (r == 0x7fffffff) continue;
+      while (true) {
+        const int q = lab[r];
+        if (q == r) break;
+        r = q;
+      }
+      lab[i] = r;
+    }
     __syncthreads();
     if (!s_changed) break;
     __syncthreads();
   }
   RL_TICK(2);
-  // the largest part (first maximum in label order, :279-281): sizes by the roots' labels
+  // the largest part (first maximum in label order, :279-281): sizes by the roots' labels.  A thread counts a contiguous
+  // stretch of nodes and adds a run of equal labels with one atomic (neighbours in a row mostly share their part)
   if (tid == 0) { s_best = -1; s_bestn = 0; }
   for (int i = tid; i < NL; i += nth) ired[i] = 0;
   __syncthreads();
-  for (int i = tid; i < NL; i += nth)
-    if (lab[i] != 0x7fffffff) atomicAdd(&ired[lab[i]], 1);
+  {
+    const int per = (NL + nth - 1) / nth, i0 = tid * per, i1 = min(i0 + per, NL);
+    int run_l = 0x7fffffff, run_n = 0;
+    for (int i = i0; i < i1; ++i) {
+      const int l = lab[i];
+      if (l == run_l) { ++run_n; continue; }
+      if (run_n > 0 && run_l != 0x7fffffff) atomicAdd(&ired[run_l], run_n);
+      run_l = l; run_n = 1;
+    }
+    if (run_n > 0 && run_l != 0x7fffffff) atomicAdd(&ired[run_l], run_n);
+  }
   __syncthreads();
-  {   // first maximum in label order: per-thread (count, smallest label), then thread 0 over the 256 partials
+  {   // first maximum in label order: per-thread (count, smallest label), then thread 0 over the partials
     int bn = 0, bi = -1;
     for (int i = tid; i < NL; i += nth)
       if (ired[i] > bn || (ired[i] == bn && bn > 0 && i < bi)) { bn = ired[i]; bi = i; }
     red[2 * tid] = (double)bn; red[2 * tid + 1] = (double)bi;
     __syncthreads();
-    if (tid == 0)
-      for (int i = 0; i < nth; ++i) {
+    // (two levels: 32 threads fold nth / 32 partials each, thread 0 folds those -- the order is fixed, the rule associative)
+    const int grp = nth / 32;
+    if (tid < 32) {
+      int gn = 0, gl = -1;
+      for (int i = tid * grp; i < (tid + 1) * grp; ++i) {
         const int n_ = (int)red[2 * i], l_ = (int)red[2 * i + 1];
+        if (n_ > gn || (n_ == gn && n_ > 0 && l_ < gl)) { gn = n_; gl = l_; }
+      }
+      red[2 * tid * grp] = (double)gn; red[2 * tid * grp + 1] = (double)gl;
+    }
+    __syncthreads();
+    if (tid == 0)
+      for (int t = 0; t < 32; ++t) {
+        const int n_ = (int)red[2 * t * grp], l_ = (int)red[2 * t * grp + 1];
         if (n_ > s_bestn || (n_ == s_bestn && n_ > 0 && l_ < s_best)) { s_bestn = n_; s_best = l_; }
       }
     __syncthreads();
@@ -544,10 +674,19 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     if (lab[i] == best) { ax += cx + (-RL_BUFFER_SIDE + (double)(i % RL_LAT) * h); ay += cy + (-RL_BUFFER_SIDE + (double)(i / RL_LAT) * h); }
   red[2 * tid] = ax; red[2 * tid + 1] = ay;
   __syncthreads();
-  if (tid == 0) {
-    double sx_ = 0.0, sy_ = 0.0;
-    for (int i = 0; i < nth; ++i) { sx_ += red[2 * i]; sy_ += red[2 * i + 1]; }
-    s_c[0] = sx_ / (double)s_bestn; s_c[1] = sy_ / (double)s_bestn;
+  {
+    const int grp = nth / 32;   // fixed summation order: per thread, then 32 groups of consecutive threads, then thread 0
+    if (tid < 32) {
+      double sx_ = 0.0, sy_ = 0.0;
+      for (int i = tid * grp; i < (tid + 1) * grp; ++i) { sx_ += red[2 * i]; sy_ += red[2 * i + 1]; }
+      red[2 * tid * grp] = sx_; red[2 * tid * grp + 1] = sy_;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double sx_ = 0.0, sy_ = 0.0;
+      for (int t = 0; t < 32; ++t) { sx_ += red[2 * t * grp]; sy_ += red[2 * t * grp + 1]; }
+      s_c[0] = sx_ / (double)s_bestn; s_c[1] = sy_ / (double)s_bestn;
+    }
   }
   __syncthreads();
   // membership of arbitrary points in the chosen part: the defining sets hold and the nearest lattice node belongs to it
@@ -556,12 +695,17 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     if (ix < 0 || ix >= RL_LAT || iy < 0 || iy >= RL_LAT) return false;
     return lab[iy * RL_LAT + ix] == best && member(x, y);
   };
+  if (rel_fits) {   // the centroid must lie on a relevant lanelet (:287-291): every lanelet asked at once
+    for (int p = tid; p < v.P; p += nth)
+      if ((relflag[p] & 1) && rl_in_polygon(v, p, s_c[0], s_c[1])) s_relc = 1;
+    __syncthreads();
+  }
   if (tid == 0) {
     s_go = 0;
     do {
       // the centroid must lie on a relevant lanelet (:287-291)
-      bool rel_c = false;
-      for (int p = 0; p < v.P && !rel_c; ++p)
+      bool rel_c = rel_fits && s_relc;
+      for (int p = 0; !rel_fits && p < v.P && !rel_c; ++p)
         if (rl_in_polygon(v, p, s_c[0], s_c[1])) {
           if (rel_fits) {
             rel_c = relflag[p] & 1;
@@ -593,7 +737,7 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
   const double fc = cos(s_yaw), fs = sin(s_yaw);
   __shared__ double s_fit[4];   // area, cx, cy, jaccard
   __shared__ int s_fitany;
-  __shared__ int s_a0[32], s_a1[32], s_hr[72], s_hc[72], s_nv;
+  __shared__ int s_a0[32], s_a1[32], s_hr[72], s_hc[72], s_nv, s_pr[64], s_pc[64];
   auto fit = [&](double ccx, double ccy, double length, double width) {
     const double fh = 0.1;
     const int nx_ = (int)rint(length / fh), ny_ = (int)rint(width / fh), np_ = nx_ * ny_;   // (ny_ <= 32)
@@ -608,6 +752,13 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     }
     red[3 * tid] = fx; red[3 * tid + 1] = fy; red[3 * tid + 2] = (double)cnt;
     __syncthreads();
+    const int grp = nth / 32;
+    if (tid < 32) {   // first level of the fixed-order sum (see the centroid above)
+      double sx_ = 0.0, sy_ = 0.0, n = 0.0;
+      for (int i = tid * grp; i < (tid + 1) * grp; ++i) { sx_ += red[3 * i]; sy_ += red[3 * i + 1]; n += red[3 * i + 2]; }
+      red[3 * tid * grp] = sx_; red[3 * tid * grp + 1] = sy_; red[3 * tid * grp + 2] = n;
+    }
+    __syncthreads();
     // the clipped part's convex hull needs only the first and last clipped point of every lattice row (the rest of a row
     // lies between them): a thread per row finds them while thread 0 adds up the partial sums
     if (tid >= 64 && tid < 64 + ny_) {
@@ -619,7 +770,7 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     }
     if (tid == 0) {
       double sx_ = 0.0, sy_ = 0.0, n = 0.0;
-      for (int i = 0; i < nth; ++i) { sx_ += red[3 * i]; sy_ += red[3 * i + 1]; n += red[3 * i + 2]; }
+      for (int t = 0; t < 32; ++t) { sx_ += red[3 * t * grp]; sy_ += red[3 * t * grp + 1]; n += red[3 * t * grp + 2]; }
       s_fitany = n > 0.0;
       s_fit[0] = n * fh * fh; s_fit[1] = n > 0.0 ? sx_ / n : 0.0; s_fit[2] = n > 0.0 ? sy_ / n : 0.0;
       s_fit[3] = ((int)n == np_) ? 1.0 : 0.0;
@@ -630,7 +781,7 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     if (tid == 0) {
       // monotone chain in LATTICE coordinates (row, column) -- integers, so the turn tests are exact; the points come
       // sorted (rows ascending, first before last); collinear points are dropped like QHull drops them
-      int pr_[64], pc_[64], np2 = 0;
+      int *pr_ = s_pr, *pc_ = s_pc, np2 = 0;   // (LDS: arrays indexed at run time would live in scratch memory)
       for (int r = 0; r < ny_; ++r) {
         if (s_a0[r] < 0) continue;
         pr_[np2] = r; pc_[np2] = s_a0[r]; ++np2;
@@ -689,17 +840,30 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
 
 // flags of an obstacle at this step: bit0 present, bit1 occludes (not a bicycle), bit2 dynamic role, bit3 type bicycle or
 // pedestrian (never triggers the dynamic rule, :209-210)
-__global__ __launch_bounds__(256) void fo_spawn_rules_kernel(RuleView v, RuleParams pr, int O, const double *__restrict__ ocorn,
+constexpr int RL_THREADS = 1024;   // the dynamic rule's lattice work spreads over sixteen waves (the other rules use one)
+__global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, RuleParams pr, int O, const double *__restrict__ ocorn,
                                                              const double *__restrict__ ocen, const double *__restrict__ oyaw,
                                                              const double *__restrict__ odims, const uint8_t *__restrict__ oflags,
-                                                             const uint8_t *__restrict__ ovis, double *__restrict__ recs) {
+                                                             const uint8_t *__restrict__ ovis, double *__restrict__ recs,
+                                                             int *__restrict__ g_lab, int *__restrict__ g_cnt) {
   // one LDS arena, carved per rule (the dynamic rule needs the two lattice arrays: 2 x 37.6 KB)
   __shared__ int lab[RL_LAT * RL_LAT];
   __shared__ int ired[RL_LAT * RL_LAT];
-  __shared__ double red[3 * 256];
+  __shared__ double red[3 * RL_THREADS];
   __shared__ unsigned char bytes[2048];
+  __shared__ double polyv[2 * RL_PVERT];   // dynamic rule: the vertices of the candidate region's lanelet polygons
+  // the reference path table into LDS: the projections and the arc-length searches of every rule are chains of dependent
+  // reads of it (a binary search in HBM costs eight round trips of ~0.6 us; in LDS, of ~30 ns)
+  __shared__ double pathv[6 * RL_PATHV];
+  if (v.n_path <= RL_PATHV) {
+    for (int i = threadIdx.x; i < 6 * v.n_path; i += blockDim.x) pathv[i] = v.path[i];
+    v.path = pathv;
+  }
   double *rec = recs + (size_t)blockIdx.x * RL_REC;
-  if (threadIdx.x < RL_REC) rec[threadIdx.x] = 0.0;
+  if ((int)blockIdx.x <= O) {   // (helper blocks never touch a record: the obstacle's own block clears it, the last part writes it)
+    if (threadIdx.x < RL_REC) rec[threadIdx.x] = 0.0;
+    __threadfence();
+  }
   __syncthreads();
   if (blockIdx.x == 0) {
     if (threadIdx.x < 64 && pr.behind_turn && pr.intention != 0) {
@@ -708,8 +872,18 @@ __global__ __launch_bounds__(256) void fo_spawn_rules_kernel(RuleView v, RulePar
     }
     return;
   }
-  const int o = blockIdx.x - 1;
+  // blocks 1 .. O: an obstacle each (its record, the static rule, part 0 of the dynamic rule's lattice); blocks beyond: the
+  // other RL_PARTS - 1 parts of the dynamic rule's lattice of obstacle (b - 1 - O) / (RL_PARTS - 1)
+  const bool helper = (int)blockIdx.x > O;
+  const int o = helper ? ((int)blockIdx.x - 1 - O) / (RL_PARTS - 1) : (int)blockIdx.x - 1;
+  const int part = helper ? 1 + ((int)blockIdx.x - 1 - O) % (RL_PARTS - 1) : 0;
+  rec = recs + (size_t)(1 + o) * RL_REC;
   const bool vis = (oflags[o] & 1) && ovis[o];
+  if (helper) {
+    if (vis && (oflags[o] & 4) && !(oflags[o] & 8) && pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1))
+      rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, part, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
+    return;
+  }
   const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
   if (threadIdx.x == 0) rec[0] = sqrt(dx * dx + dy * dy);
   if (!vis) return;
@@ -723,7 +897,7 @@ __global__ __launch_bounds__(256) void fo_spawn_rules_kernel(RuleView v, RulePar
   if (oflags[o] & 8) return;                                   // bicycles and pedestrians (:209-210)
   if (threadIdx.x == 0) rec[1] = 2.0;
   if (pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1))   // straight ahead or left turn (:124-126)
-    rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes);
+    rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, 0, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
 }
 
 // what depends on the order of the obstacles: both lists sorted by distance (stable), the maxima of the YAML compared
@@ -936,8 +1110,14 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
   pr.intention = params->intention; pr.win_i0 = params->win_i0; pr.win_i1 = params->win_i1;
   pr.behind_static = params->behind_static; pr.behind_turn = params->behind_turn; pr.behind_dynamic = params->behind_dynamic;
   pr.max_static = params->max_static; pr.max_dynamic = params->max_dynamic;
-  hipLaunchKernelGGL(fo_spawn_rules_kernel, dim3(1 + O), dim3(256), 0, s, v, pr, O, d_ocorn, d_ocen, d_oyaw, d_odims, d_oflags,
-                     d_obst_vis, sc->d_rule_rec);
+  {  // lattice hand-off of the dynamic rule: [O][97 x 97] labels + a counter per obstacle (zero between launches)
+    const size_t cap0 = sc->cap_rule_cnt;
+    if ((rc = fo_reserve(ctx, &sc->d_rule_lab, &sc->cap_rule_lab, (size_t)(O > 0 ? O : 1) * RL_LAT * RL_LAT))) return rc;
+    if ((rc = fo_reserve(ctx, &sc->d_rule_cnt, &sc->cap_rule_cnt, (size_t)(O > 0 ? O : 1)))) return rc;
+    if (sc->cap_rule_cnt != cap0) FO_HIP_TRY(ctx, hipMemsetAsync(sc->d_rule_cnt, 0, sc->cap_rule_cnt * sizeof(int), s));
+  }
+  hipLaunchKernelGGL(fo_spawn_rules_kernel, dim3(1 + O * RL_PARTS), dim3(RL_THREADS), 0, s, v, pr, O, d_ocorn, d_ocen, d_oyaw, d_odims,
+                     d_oflags, d_obst_vis, sc->d_rule_rec, sc->d_rule_lab, sc->d_rule_cnt);
   hipLaunchKernelGGL(fo_spawn_rules_select_kernel, dim3(1), dim3(64), 0, s, v, pr, O, d_ocorn, d_oflags, d_obst_vis,
                      sc->d_rule_rec, max_out, d_out, d_n_out);
   FO_HIP_TRY(ctx, hipGetLastError());

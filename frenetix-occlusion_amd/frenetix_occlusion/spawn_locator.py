@@ -9,6 +9,7 @@ the ego (:234,381) and not beyond max(4 v_ego, 25) m (:113, constants :65-66).  
 constant-velocity predictions of the spawned agents straight into the layout ``fo_sweep_set_agents`` reads, so the
 phantom set never leaves HBM between sampling and the metric sweep.
 """
+import bisect
 import math
 from collections.abc import Sequence
 from dataclasses import dataclass
@@ -276,6 +277,7 @@ class SpawnLocator:
         from .utils.curvilinear import PolylineCS
         sm = self.sensor_model
         self._cs = PolylineCS(self.ref_path)
+        self._s_list = self._cs.s.tolist()
         n = len(self.ref_path)
         tab = np.zeros((n, 6))
         tab[:, :2], tab[:, 2] = self._cs.path, self._cs.s
@@ -295,6 +297,17 @@ class SpawnLocator:
                               ped_width=float(ped["width"]), ped_length=float(ped["length"]))
         self._rules_ready = True
 
+    def _nearest_vertex(self, s):
+        """``np.argmin(np.abs(ref_s - s))`` (spawn_locator.py:684-687: the first index of the smallest distance) by bisection
+        on the path's arc lengths -- this runs every planning step on the host"""
+        sl = self._s_list
+        i = bisect.bisect_left(sl, s)
+        if i <= 0:
+            return 0
+        if i >= len(sl):
+            return len(sl) - 1
+        return i - 1 if abs(sl[i - 1] - s) <= abs(sl[i] - s) else i
+
     def rule_params(self, ego_pos, ego_orientation, ego_pos_cl, ego_v):
         """the step's scalars of the rule families (``fo_spawn_rule_params_t``): curvilinear ego position, ``s_threshold``
         (spawn_locator.py:113), the reference window and the ego's intention from the curvature of the next 40 m of the
@@ -305,9 +318,7 @@ class SpawnLocator:
         if ego_pos_cl is None:
             ego_pos_cl = self._cs.convert_to_curvilinear_coords(float(ego_pos[0]), float(ego_pos[1]))
         s_ego = float(ego_pos_cl[0])
-        ref_s = self._cs.s
-        i0 = int(np.argmin(np.abs(ref_s - s_ego)))                       # :678-693
-        i1 = int(np.argmin(np.abs(ref_s - (s_ego + 40.0))))
+        i0, i1 = self._nearest_vertex(s_ego), self._nearest_vertex(s_ego + 40.0)   # :678-693
         intention = 0
         if i1 - i0 >= 3:                                                  # :729-741
             key = (i0, i1)
