@@ -30,6 +30,11 @@ namespace {
 #else
 #define RL_TICK(i) do { } while (0)
 #endif
+#if FO_RULE_TRACE == 2   // tuning: stamps INSIDE the first rectangle fit instead of after the two fits (slots 5, 6, 7)
+#define RL_TICKF(i) do { __syncthreads(); if (threadIdx.x == 0 && rec[16 + (i)] == 0.0) rec[16 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define RL_TICKF(i) do { } while (0)
+#endif
 
 constexpr double RL_MAX_DIST_OBST = 30.0;          // spawn_locator.py:69
 constexpr double RL_MIN_DIST_PED = 5.0;            // :73
@@ -41,7 +46,7 @@ constexpr int RL_LAT = 97;                         // nodes per side of the 0.25
 constexpr int RL_MAXSAMP = 1024;                   // samples of a rule polyline (cs/8 steps; 40 m at cs = 0.5 -> 641)
 constexpr int RL_REC = 24;                         // doubles per per-workgroup record
 constexpr int RL_PATHV = 512;                      // vertices of the reference path table held in LDS (longer paths: read from HBM)
-constexpr int RL_PARTS = 8;                        // workgroups that share a dynamic obstacle's candidate lattice
+constexpr int RL_PARTS = 16;                       // workgroups that share a dynamic obstacle's candidate lattice
 constexpr int RL_PVERT = 1024;                     // vertices of a dynamic obstacle's <= 8 candidate lanelet polygons held in LDS
 
 enum { RL_TYPE_CAR = 0, RL_TYPE_BICYCLE = 3, RL_TYPE_PED = 4 };
@@ -516,12 +521,13 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
   const double oc_c = cos(oy), oc_s = sin(oy);
   // (the tests are a conjunction: cheapest first -- distance, the obstacle grown by 1 m, shadow / occluded class -- and
   // the lanelet polygons, the dear ones, last)
-  auto member = [&](double x, double y) {
+  // returns 0 (not a member) or 1 + the slot of a candidate polygon that holds the point; `hint`: the slot asked first
+  auto member_idx = [&](double x, double y, int hint) -> int {
     const double rx = x - cx, ry = y - cy;
-    if (!(sqrt(rx * rx + ry * ry) <= RL_BUFFER_SIDE)) return false;
+    if (!(sqrt(rx * rx + ry * ry) <= RL_BUFFER_SIDE)) return 0;
     const double lx_ = oc_c * rx + oc_s * ry, ly_ = -oc_s * rx + oc_c * ry;
     const double ex_ = fmax(fabs(lx_) - olen / 2.0, 0.0), ey_ = fmax(fabs(ly_) - owid / 2.0, 0.0);
-    if (!(sqrt(ex_ * ex_ + ey_ * ey_) > 1.0)) return false;                       // minus the obstacle grown by 1 m
+    if (!(sqrt(ex_ * ex_ + ey_ * ey_) > 1.0)) return 0;                           // minus the obstacle grown by 1 m
     if (wedge) {   // the obstacle's own shadow: the sight line ego -> point crosses the rectangle (:264)
       bool hit = false;
       const double dx = x - pr.ego_x, dy = y - pr.ego_y;
@@ -536,17 +542,19 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
           hit = den > 0.0 ? (tn >= 0.0 && tn <= den && un >= 0.0 && un <= den) : (tn <= 0.0 && tn >= den && un <= 0.0 && un >= den);
         }
       }
-      if (!hit) return false;
+      if (!hit) return 0;
     } else if (!(rl_class_at(v, x, y) & 4)) {   // the global occluded area (:272)
-      return false;
+      return 0;
     }
-    bool ok = false;                                                                // possible_polygon (:255)
-    if (!plds) {
-      for (int i = 0; i < npol && !ok; ++i) ok = rl_in_polygon(v, s_pol[i], x, y);
-      return ok;
-    }
-    for (int i = 0; i < npol && !ok; ++i) {   // rl_in_polygon on the copy in LDS (the same arithmetic)
-      const double *bb = s_pbox + 4 * i;
+    // possible_polygon (:255): the union of the candidate lanelet polygons -- any order of asking gives the same answer;
+    // the polygon that held the nearest lattice node goes first (it holds most points around that node as well)
+    for (int q = 0; q < npol; ++q) {
+      const int i = q == 0 ? hint : (q <= hint ? q - 1 : q);
+      if (!plds) {
+        if (rl_in_polygon(v, s_pol[i], x, y)) return i + 1;
+        continue;
+      }
+      const double *bb = s_pbox + 4 * i;            // rl_in_polygon on the copy in LDS (the same arithmetic)
       if (x < bb[0] || x > bb[2] || y < bb[1] || y > bb[3]) continue;
       const int b0 = s_poff[i], e0 = s_poff[i + 1];
       int c = 0;
@@ -557,9 +565,9 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
           if (x < xc) c ^= 1;
         }
       }
-      ok = c != 0;
+      if (c != 0) return i + 1;
     }
-    return ok;
+    return 0;
   };
   // the 0.25 m lattice around the obstacle; label = linear index where the node is a member, INT_MAX elsewhere
   const double h = 0.25;
@@ -572,7 +580,8 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     const int chunk = (NL + RL_PARTS - 1) / RL_PARTS, i1 = min((part + 1) * chunk, NL);
     for (int i = part * chunk + tid; i < i1; i += nth) {
       const int ix = i % RL_LAT, iy = i / RL_LAT;
-      g_lab[i] = member(cx + (-RL_BUFFER_SIDE + (double)ix * h), cy + (-RL_BUFFER_SIDE + (double)iy * h)) ? i : 0x7fffffff;
+      const int mi = member_idx(cx + (-RL_BUFFER_SIDE + (double)ix * h), cy + (-RL_BUFFER_SIDE + (double)iy * h), 0);
+      g_lab[i] = mi ? (i | ((mi - 1) << 16)) : 0x7fffffff;      // (+ which polygon held the node: the fits' hint)
     }
     __shared__ int s_ticket;
     __threadfence();
@@ -583,7 +592,7 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     if (tid == 0) *g_cnt = 0;   // for the next planning step (launches on a stream are ordered)
     __threadfence();
     const volatile int *gl = g_lab;
-    for (int i = tid; i < NL; i += nth) lab[i] = gl[i];
+    for (int i = tid; i < NL; i += nth) { const int w = gl[i]; lab[i] = w == 0x7fffffff ? w : (w & 0xffff); }
   }
   __syncthreads();
   RL_TICK(1);
@@ -672,28 +681,27 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
   double ax = 0.0, ay = 0.0;
   for (int i = tid; i < NL; i += nth)
     if (lab[i] == best) { ax += cx + (-RL_BUFFER_SIDE + (double)(i % RL_LAT) * h); ay += cy + (-RL_BUFFER_SIDE + (double)(i / RL_LAT) * h); }
-  red[2 * tid] = ax; red[2 * tid + 1] = ay;
+  // fixed summation order: per thread, a butterfly over the wave (every lane ends with the same total), the waves in order
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { ax += __shfl_xor(ax, off); ay += __shfl_xor(ay, off); }
+  if ((tid & 63) == 0) { red[2 * (tid >> 6)] = ax; red[2 * (tid >> 6) + 1] = ay; }
   __syncthreads();
-  {
-    const int grp = nth / 32;   // fixed summation order: per thread, then 32 groups of consecutive threads, then thread 0
-    if (tid < 32) {
-      double sx_ = 0.0, sy_ = 0.0;
-      for (int i = tid * grp; i < (tid + 1) * grp; ++i) { sx_ += red[2 * i]; sy_ += red[2 * i + 1]; }
-      red[2 * tid * grp] = sx_; red[2 * tid * grp + 1] = sy_;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double sx_ = 0.0, sy_ = 0.0;
-      for (int t = 0; t < 32; ++t) { sx_ += red[2 * t * grp]; sy_ += red[2 * t * grp + 1]; }
-      s_c[0] = sx_ / (double)s_bestn; s_c[1] = sy_ / (double)s_bestn;
-    }
+  if (tid == 0) {
+    double sx_ = 0.0, sy_ = 0.0;
+    for (int w = 0; w < nth / 64; ++w) { sx_ += red[2 * w]; sy_ += red[2 * w + 1]; }
+    s_c[0] = sx_ / (double)s_bestn; s_c[1] = sy_ / (double)s_bestn;
   }
   __syncthreads();
-  // membership of arbitrary points in the chosen part: the defining sets hold and the nearest lattice node belongs to it
+  // (ired is free from here on: it takes the polygon slot that held each lattice node, the hint of member_idx)
+  {
+    const volatile int *gl = g_lab;
+    for (int i = tid; i < NL; i += nth) { const int w = gl[i]; ired[i] = w == 0x7fffffff ? 0 : (w >> 16); }
+  }
+  __syncthreads();
   auto in_region = [&](double x, double y) {
     const int ix = (int)rint((x - (cx - RL_BUFFER_SIDE)) / h), iy = (int)rint((y - (cy - RL_BUFFER_SIDE)) / h);
     if (ix < 0 || ix >= RL_LAT || iy < 0 || iy >= RL_LAT) return false;
-    return lab[iy * RL_LAT + ix] == best && member(x, y);
+    return lab[iy * RL_LAT + ix] == best && member_idx(x, y, ired[iy * RL_LAT + ix]) != 0;
   };
   if (rel_fits) {   // the centroid must lie on a relevant lanelet (:287-291): every lanelet asked at once
     for (int p = tid; p < v.P; p += nth)
@@ -737,7 +745,8 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
   const double fc = cos(s_yaw), fs = sin(s_yaw);
   __shared__ double s_fit[4];   // area, cx, cy, jaccard
   __shared__ int s_fitany;
-  __shared__ int s_a0[32], s_a1[32], s_hr[72], s_hc[72], s_nv, s_pr[64], s_pc[64];
+  __shared__ int s_a0[32], s_a1[32], s_nv, s_np2, s_pr[64], s_pc[64];
+  __shared__ unsigned long long s_bestA;
   auto fit = [&](double ccx, double ccy, double length, double width) {
     const double fh = 0.1;
     const int nx_ = (int)rint(length / fh), ny_ = (int)rint(width / fh), np_ = nx_ * ny_;   // (ny_ <= 32)
@@ -750,15 +759,12 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
       fitok[i] = ok ? 1 : 0;
       if (ok) { ++cnt; fx += x; fy += y; }
     }
-    red[3 * tid] = fx; red[3 * tid + 1] = fy; red[3 * tid + 2] = (double)cnt;
+    double fn = (double)cnt;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { fx += __shfl_xor(fx, off); fy += __shfl_xor(fy, off); fn += __shfl_xor(fn, off); }
+    if ((tid & 63) == 0) { red[3 * (tid >> 6)] = fx; red[3 * (tid >> 6) + 1] = fy; red[3 * (tid >> 6) + 2] = fn; }
     __syncthreads();
-    const int grp = nth / 32;
-    if (tid < 32) {   // first level of the fixed-order sum (see the centroid above)
-      double sx_ = 0.0, sy_ = 0.0, n = 0.0;
-      for (int i = tid * grp; i < (tid + 1) * grp; ++i) { sx_ += red[3 * i]; sy_ += red[3 * i + 1]; n += red[3 * i + 2]; }
-      red[3 * tid * grp] = sx_; red[3 * tid * grp + 1] = sy_; red[3 * tid * grp + 2] = n;
-    }
-    __syncthreads();
+    RL_TICKF(5);
     // the clipped part's convex hull needs only the first and last clipped point of every lattice row (the rest of a row
     // lies between them): a thread per row finds them while thread 0 adds up the partial sums
     if (tid >= 64 && tid < 64 + ny_) {
@@ -770,68 +776,94 @@ __device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, 
     }
     if (tid == 0) {
       double sx_ = 0.0, sy_ = 0.0, n = 0.0;
-      for (int t = 0; t < 32; ++t) { sx_ += red[3 * t * grp]; sy_ += red[3 * t * grp + 1]; n += red[3 * t * grp + 2]; }
+      for (int w = 0; w < nth / 64; ++w) { sx_ += red[3 * w]; sy_ += red[3 * w + 1]; n += red[3 * w + 2]; }
       s_fitany = n > 0.0;
       s_fit[0] = n * fh * fh; s_fit[1] = n > 0.0 ? sx_ / n : 0.0; s_fit[2] = n > 0.0 ? sy_ / n : 0.0;
       s_fit[3] = ((int)n == np_) ? 1.0 : 0.0;
-      s_nv = 0;
     }
     __syncthreads();
+    RL_TICKF(6);
     if (!s_fitany || s_fit[3] == 1.0) return;   // nothing clipped in, or nothing clipped off (Jaccard 1)
-    if (tid == 0) {
-      // monotone chain in LATTICE coordinates (row, column) -- integers, so the turn tests are exact; the points come
-      // sorted (rows ascending, first before last); collinear points are dropped like QHull drops them
-      int *pr_ = s_pr, *pc_ = s_pc, np2 = 0;   // (LDS: arrays indexed at run time would live in scratch memory)
-      for (int r = 0; r < ny_; ++r) {
-        if (s_a0[r] < 0) continue;
-        pr_[np2] = r; pc_[np2] = s_a0[r]; ++np2;
-        if (s_a1[r] != s_a0[r]) { pr_[np2] = r; pc_[np2] = s_a1[r]; ++np2; }
+    // The smallest rectangle over the edge directions of the clipped part's convex hull (:716-724), without building the
+    // hull: the enclosing rectangle of smallest area has a side along a hull edge (Freeman & Shapira), so the minimum over
+    // the directions of ALL point pairs is the minimum over the hull's edge directions -- a superset of directions cannot
+    // undercut the global optimum, and it contains the hull's.  <= 64 points (first and last clipped point of every lattice
+    // row, integer lattice coordinates), <= 2 016 pairs over the workgroup, each spanning the extents of all points; the
+    // smallest area is kept by atomicMin on its bit pattern (positive doubles order like their bits).  Fewer than three
+    // points, or all on one line (QHull raises there): Jaccard 0.
+    if (tid < 64) {
+      // the candidate list (wave 0: a lane per lattice row): first and last clipped point of the row, but only where the left
+      // (first points) or right (last points) chain turns strictly outwards against its neighbours in the rows below and
+      // above -- every vertex of the convex hull does; points on straight stretches (most: the part is a clipped
+      // rectangle) and in dents do not, they neither span an extent nor define a hull edge
+      const int r = tid;
+      const int a0 = r < ny_ ? s_a0[r] : -1, a1 = r < ny_ ? s_a1[r] : -1;
+      int rp = -1, rn = -1;
+      if (a0 >= 0) {
+        for (int q = r - 1; q >= 0 && rp < 0; --q) if (s_a0[q] >= 0) rp = q;
+        for (int q = r + 1; q < ny_ && rn < 0; ++q) if (s_a0[q] >= 0) rn = q;
       }
-      int k = 0;
-      auto turn = [&](int i) {   // cross product (hull[k-2] -> hull[k-1]) x (hull[k-2] -> point i)
-        return (s_hr[k - 1] - s_hr[k - 2]) * (pc_[i] - s_hc[k - 2]) - (s_hc[k - 1] - s_hc[k - 2]) * (pr_[i] - s_hr[k - 2]);
-      };
-      for (int i = 0; i < np2; ++i) {
-        while (k >= 2 && turn(i) <= 0) --k;
-        s_hr[k] = pr_[i]; s_hc[k] = pc_[i]; ++k;
+      bool k0 = a0 >= 0, k1 = a0 >= 0 && a1 != a0;
+      if (a0 >= 0 && rp >= 0 && rn >= 0) {
+        const int zl = (r - rp) * (s_a0[rn] - a0) - (a0 - s_a0[rp]) * (rn - r);   // > 0: the left chain bulges to smaller columns here
+        const int zr = (r - rp) * (s_a1[rn] - a1) - (a1 - s_a1[rp]) * (rn - r);   // < 0: the right chain bulges to larger columns
+        if (a1 != a0) { k0 = zl > 0; k1 = zr < 0; }
+        else k0 = zl > 0 || zr < 0;
       }
-      const int lower = k + 1;
-      for (int i = np2 - 2; i >= 0; --i) {
-        while (k >= lower && turn(i) <= 0) --k;
-        s_hr[k] = pr_[i]; s_hc[k] = pc_[i]; ++k;
+      const int cnt = (k0 ? 1 : 0) + (k1 ? 1 : 0);
+      int incl = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (tid >= off) incl += t; }
+      int pos = incl - cnt;
+      if (k0) { s_pr[pos] = r; s_pc[pos] = a0; ++pos; }
+      if (k1) { s_pr[pos] = r; s_pc[pos] = a1; }
+      if (tid == 63) s_np2 = incl;
+      // a proper polygon?  fewer than three clipped points, or all of them on one line (QHull raises there): Jaccard 0
+      const int n_all = __popcll(__ballot(a0 >= 0)) + __popcll(__ballot(a0 >= 0 && a1 != a0));
+      const int rf = __ffsll((long long)__ballot(a0 >= 0)) - 1;      // first row that holds a point
+      bool off = false;
+      if (rf >= 0 && a0 >= 0) {
+        const int c0 = s_a0[rf];
+        const int rl = 63 - __clzll((long long)__ballot(a0 >= 0));    // last such row; the line through (rf, c0) and (rl, its last point)
+        const int dc = s_a1[rl] - c0, dr = rl - rf;
+        off = (dr * (a0 - c0) - dc * (r - rf) != 0) || (dr * (a1 - c0) - dc * (r - rf) != 0);
       }
-      s_nv = k - 1;   // the last point repeats the first
+      const bool proper = n_all >= 3 && __ballot(off) != 0;
+      if (tid == 0) { s_nv = proper ? 3 : 0; s_bestA = 0x7ff0000000000000ull; }   // +inf
     }
     __syncthreads();
-    const int nv = s_nv;
-    if (nv < 3) return;   // degenerate (QHull raises): Jaccard 0
-    // the smallest rectangle over the hull's edge directions (:716-724), a thread per edge; lengths in lattice units
-    if (tid < nv) {
-      double ex = (double)(s_hc[(tid + 1) % nv] - s_hc[tid]), ey = (double)(s_hr[(tid + 1) % nv] - s_hr[tid]);
+    const int np2 = s_np2;
+    for (int w = tid; w < np2 * np2; w += nth) {
+      const int i = w / np2, j = w % np2;
+      if (i >= j) continue;
+      double ex = (double)(s_pc[j] - s_pc[i]), ey = (double)(s_pr[j] - s_pr[i]);
       const double nn = sqrt(ex * ex + ey * ey);
       ex /= nn; ey /= nn;
       double a1n = INFINITY, a1x = -INFINITY, a2n = INFINITY, a2x = -INFINITY;
-      for (int q = 0; q < nv; ++q) {
-        const double p1 = (double)s_hc[q] * ex + (double)s_hr[q] * ey, p2 = (double)s_hc[q] * (-ey) + (double)s_hr[q] * ex;
+      for (int q = 0; q < np2; ++q) {
+        const double p1 = (double)s_pc[q] * ex + (double)s_pr[q] * ey, p2 = (double)s_pc[q] * (-ey) + (double)s_pr[q] * ex;
         a1n = fmin(a1n, p1); a1x = fmax(a1x, p1); a2n = fmin(a2n, p2); a2x = fmax(a2x, p2);
       }
-      red[tid] = ((a1x - a1n) * fh + fh) * ((a2x - a2n) * fh + fh);
+      const double area = ((a1x - a1n) * fh + fh) * ((a2x - a2n) * fh + fh);
+      atomicMin(&s_bestA, (unsigned long long)__double_as_longlong(area));
     }
     __syncthreads();
-    if (tid == 0) {
-      double bestA = INFINITY;
-      for (int i = 0; i < nv; ++i) bestA = fmin(bestA, red[i]);
-      s_fit[3] = fmin(1.0, s_fit[0] / bestA);
-    }
+    RL_TICKF(7);
+    if (s_nv < 3) return;   // degenerate (QHull raises): Jaccard 0
+    if (tid == 0) s_fit[3] = fmin(1.0, s_fit[0] / __longlong_as_double((long long)s_bestA));
     __syncthreads();
   };
   fit(s_c[0], s_c[1], 5.5, 2.5);
+#if FO_RULE_TRACE != 2
   RL_TICK(5);
+#endif
   if (!s_fitany) return;
   const double car_a = s_fit[0], car_x = s_fit[1], car_y = s_fit[2], car_j = s_fit[3];
   __syncthreads();
   fit(car_x, car_y, 2.0, 1.0);
+#if FO_RULE_TRACE != 2
   RL_TICK(6);
+#endif
   if (tid == 0) {
     if (car_a >= RL_AREA_CAR && car_j > 0.98) { rec[2] = 1.0; rec[3] = car_x; rec[4] = car_y; }
     if (s_fitany && s_fit[0] >= RL_AREA_BIKE && s_fit[3] > 0.98) { rec[5] = 1.0; rec[6] = s_fit[1]; rec[7] = s_fit[2]; }

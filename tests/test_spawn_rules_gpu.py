@@ -160,3 +160,75 @@ def test_scenario1_steps(torch_cuda):
         _same(dev, ref, view)
         n_pts += len(ref)
     assert n_pts > 0
+
+
+def _random_case(rng, scs):
+    """one random case of tools/spawn_rules_fuzz.py: a scenario, an ego pose near a lanelet centre line, a reference path
+    straight ahead or along the centre lines of the lanelet and its successors, a time step, a speed"""
+    si = int(rng.integers(len(scs)))
+    sc = scs[si]
+    by = {l.lanelet_id: l for l in sc.lanelets}
+    ll = sc.lanelets[int(rng.integers(len(sc.lanelets)))]
+    c = ll.center
+    i = int(rng.integers(0, max(len(c) - 2, 1)))
+    ego = c[i] + rng.normal(0.0, 0.3, 2)
+    yaw = math.atan2(c[i + 1, 1] - c[i, 1], c[i + 1, 0] - c[i, 0]) + float(rng.normal(0.0, 0.05))
+    if rng.random() < 0.5:
+        path = ego[None] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    else:
+        parts, cur = [c[max(i - 3, 0):]], ll
+        for _ in range(3):
+            if not cur.successors:
+                break
+            cur = by.get(cur.successors[int(rng.integers(len(cur.successors)))])
+            if cur is None:
+                break
+            parts.append(cur.center[1:])
+        path = np.concatenate(parts)
+        path = path[np.concatenate(([True], np.hypot(np.diff(path[:, 0]), np.diff(path[:, 1])) > 1e-6))]
+    return si, sc, path, ego, yaw, int(rng.integers(0, 80)), float(rng.uniform(2.0, 12.0))
+
+
+def test_fifty_seeded_random_cases_on_the_three_scenarios(torch_cuda):
+    """50 seeded cases of tools/spawn_rules_fuzz.py (random poses, paths with and without turns, time steps of scenario 1 / 2 / 3):
+    device == checker on every one; the seed is chosen so that all three rule families fire"""
+    from frenetix_occlusion import scenario as S
+    scs = [S.load_geometry_npz(os.path.join(GOLDEN, f"scenario{i}_geometry.npz")) for i in (1, 2, 3)]
+    rng = np.random.default_rng(3)
+    kinds, done, seen = {}, 0, set()
+    while done < 50:
+        si, sc, path, ego, yaw, step, v = _random_case(rng, scs)
+        if len(path) < 4:
+            continue
+        try:
+            dev, ref, view = _both(torch_cuda, sc.lanelets, sc.obstacles, path, ego, yaw, v, intersections=sc.intersections,
+                                   timestep=step, n_rays=360)
+        except ValueError:          # ego outside the path's projection domain: nothing to compare
+            continue
+        _same(dev, ref, view)
+        done += 1
+        seen.add(si)
+        for p in ref:
+            key = p.source.split(" ")[0] + ":" + p.agent_type
+            kinds[key] = kinds.get(key, 0) + 1
+    assert seen == {0, 1, 2}
+    assert any(k.startswith("behind_dynamic") for k in kinds) and any(k.startswith("behind:") for k in kinds)
+    assert any(k.startswith(("left", "right")) for k in kinds), kinds
+
+
+def test_urban_grid_rule_cases(torch_cuda):
+    """the BASELINE configs[2] city grid (9 360 boundary pieces, 64 parked cars, ~600 lanelets): the rule families at the
+    bench's ego pose and at poses along two streets -- pedestrians behind parked cars, device == checker"""
+    from frenetix_occlusion import scenario as S
+    sc = S.synthetic_urban_grid()
+    ego0 = sc.ego_initial
+    n_pts = 0
+    for k, (dx, dyaw) in enumerate(((0.0, 0.0), (14.0, 0.0), (31.0, 0.0), (-12.0, 0.0), (6.0, 0.03))):
+        yaw = float(ego0[2]) + dyaw
+        ego = ego0[:2] + dx * np.array([math.cos(ego0[2]), math.sin(ego0[2])])
+        path = ego[None] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+        dev, ref, view = _both(torch_cuda, sc.lanelets, sc.obstacles, path, ego, yaw, 8.0, intersections=getattr(sc, "intersections", None),
+                               timestep=0, n_rays=720)
+        _same(dev, ref, view)
+        n_pts += len(ref)
+    assert n_pts > 0

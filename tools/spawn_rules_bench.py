@@ -52,7 +52,11 @@ for step in (0, 8, 25, 60):
     torch.cuda.synchronize()
     print(f"step {step}: {len(pts)} rule points ({[p.agent_type for p in pts]}), find_spawn_points {dt_rules * 1e3:.3f} ms "
           f"(host + device + read-back), device only (rules + agents, lazy list) by events {e0.elapsed_time(e1) / 50:.3f} ms")
-    if os.environ.get("FO_RULE_TRACE"):
+    if os.environ.get("FO_RULE_TRACE"):     # tuning builds: tools/build_variant_scene.sh rtrace -DFO_RULE_TRACE=1 (or =2: stamps inside the first fit)
         h = sl.batch.rule_points.cpu().numpy()[-1]
         if h[0] != 0:
-            print("   dynamic-rule phases (us): ", np.round(np.diff(h[:7]) * 0.01, 1).tolist(), "(membership, labelling, sizes, centroid+checks, car fit, bicycle fit)")
+            two = os.environ["FO_RULE_TRACE"] == "2"
+            d = np.diff(h[:8] if two else h[:7]) * 0.01
+            print("   dynamic-rule phases (us): ", np.round(d, 1).tolist(),
+                  "(membership, labelling, sizes, centroid+checks | car fit: clip, sums + rows, hull + rectangle)" if two else
+                  "(membership, labelling, sizes, centroid+checks, car fit, bicycle fit)")
