@@ -6,11 +6,11 @@ set -u
 TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-autotune $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-autotune --no-extras $*"
 # the kernel-trace pass runs the bench step 200 times at one kernel configuration (no agents-per-wave selection pass,
 # which would mix four configurations into the average; 150 untimed steps bring the clocks up like that pass does) so
 # that its average kernel duration is comparable with the HIP-event figure bench.py prints
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 bench.py --no-cpu-baseline --no-autotune --warmup 150 $* > $OUT/${TAG}_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 bench.py --no-cpu-baseline --no-autotune --no-extras --warmup 150 $* > $OUT/${TAG}_stats.log 2>&1
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" \
            "FETCH_SIZE GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
@@ -19,7 +19,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/${TAG}_pmc$i -o run -- python3 bench.py $ARGS > $OUT/${TAG}_pmc$i.log 2>&1
 done
 # which library these numbers belong to (bench.py prints roofline.traffic only when this id equals the loaded library's)
-LISTS=f32; case " $* " in *" --lists f64 "*) LISTS=f64;; esac
+LISTS=f32; case " $* " in *" --lists f64 "*) LISTS=f64;; *" --lists f32x "*) LISTS=f32x;; esac
 python3 - > $OUT/${TAG}_build.json <<PY
 import json, sys
 sys.path.insert(0, "frenetix-occlusion_amd")
