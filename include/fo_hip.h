@@ -85,7 +85,9 @@ const char *fo_build_id(void);
 int fo_sweep_configure(fo_ctx *ctx, const fo_vehicle_t *veh, const fo_harm_coeff_t *hc, const fo_thresholds_t *thr,
                        uint32_t metric_mask, double dt);        /* Metric.__init__ (metric.py:22-33), HR._load_param */
 
-/* pre-size the context's HBM workspace so that fo_sweep_run never allocates (needed before hipGraph capture) */
+/* pre-size the context's HBM workspace so that fo_sweep_run never allocates (needed before hipGraph capture) -- for EVERY
+ * batch of at most max_M trajectories, max_A agent slots and horizons up to max_T (a smaller batch may take the kernel's
+ * horizon-split form, which keeps more partial rows per trajectory: the reservation covers that case as well) */
 int fo_sweep_reserve(fo_ctx *ctx, int max_M, int max_T, int max_A, int max_Ta);
 
 /* Element type of the per-timestep lists (d_lists of fo_sweep_run).  FO_LISTS_F64 (default): float64, the reference's
