@@ -356,19 +356,25 @@ def small_batch_step(local_rank, steps=300):
     for _ in range(100):
         step()
     torch.cuda.synchronize()
+    # three timed runs, the median reported: at 0.09 ms per step the host thread that issues the step matters, and its
+    # cores are shared with whatever else runs on the box (all three runs are in `ms_per_step_runs`)
+    runs = []
     sw.ctx.timing(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    t_issue = (time.perf_counter() - t0) / steps
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        t_issue_ = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        runs.append(((time.perf_counter() - t0) / steps, t_issue_))
     kms, kn = sw.ctx.timing_read()
     sw.ctx.timing(False)
+    dt, t_issue = sorted(runs)[1]
     return {"workload": "BASELINE configs[1]: scenario1 geometry, 2000 trajectories x 32 phantom slots, T=31, reduced outputs",
             "ms_per_step": dt * 1e3, "host_issue_ms_per_step": t_issue * 1e3, "ms_per_step_stage_calls": dt_stages * 1e3,
             "entry": "fo_step_run (one native call per planning step); ms_per_step_stage_calls = the same step as five "
                      "stage calls from Python",
+            "ms_per_step_runs": [r[0] * 1e3 for r in runs],
             "sweep_kernel_ms": kms / max(kn, 1), "A_active": int(sl.batch.n.item()), "steps": steps,
             "sweep_grid": sw.ctx.last_launch()["grid"]}
 

@@ -361,30 +361,42 @@ __device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, i
       if ((oflags[j] & 1) && ovis[j] && rl_seg_rect_distance(ax, ay, bx, by, ocorn + 8 * (size_t)j) <= pr.ped_width / 2.0) blocked = true;
     if (__ballot(blocked)) continue;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // candidates: where "the disc touches the visible area" flips, the sample just outside (:414-415) -- a lane per sample
+    // pair; one candidate: that one; several (MultiPoint, :419-433): the one nearest to the lanelet's first left vertex among
+    // those inside the occluded area (the first of equally near ones: smallest (distance, index) over the wave)
     double spx = 0.0, spy = 0.0;
     bool okp = false;
-    if (lane == 0) {
-      // candidates: where "the disc touches the visible area" flips, the sample just outside (:414-415)
-      int n_c = 0;
-      bool found = false;
-      int only = -1;
-      for (int i = 0; i + 1 < ns; ++i)
+    {
+      int n_c = 0, only = -1;
+      for (int i = lane; i + 1 < ns; i += 64)
         if (near[i] != near[i + 1]) { ++n_c; only = near[i] ? i + 1 : i; }
-      if (n_c == 1) {
-        spx = sx[only]; spy = sy[only]; found = true;
-      } else if (n_c > 1) {                                                       // MultiPoint (:419-433): nearest to the lanelet's first left vertex, inside the occluded area
+      int n_all = n_c, only_all = only;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) { n_all += __shfl_xor(n_all, off); only_all = max(only_all, __shfl_xor(only_all, off)); }
+      bool found = false;
+      if (n_all == 1) {
+        spx = sx[only_all]; spy = sy[only_all]; found = true;
+      } else if (n_all > 1) {
         const int ll = rl_lanelet_of(v, cx, cy);
         const double anx = (ll >= 0 && v.left0) ? v.left0[2 * ll] : cx, any_ = (ll >= 0 && v.left0) ? v.left0[2 * ll + 1] : cy;
         double bestd = INFINITY;
-        for (int i = 0; i + 1 < ns; ++i)
+        int bc = 0x7fffffff, bi = 0x7fffffff;   // candidate sample, and the sample pair it came from (orders ties)
+        for (int i = lane; i + 1 < ns; i += 64)
           if (near[i] != near[i + 1]) {
             const int c = near[i] ? i + 1 : i;
             const double dd = sqrt((anx - sx[c]) * (anx - sx[c]) + (any_ - sy[c]) * (any_ - sy[c]));
-            if ((rl_class_at(v, sx[c], sy[c]) & 4) && dd < bestd) { bestd = dd; spx = sx[c]; spy = sy[c]; found = true; }
+            if ((rl_class_at(v, sx[c], sy[c]) & 4) && dd < bestd) { bestd = dd; bc = c; bi = i; }   // ascending per lane: first minimum
           }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const double d2 = __shfl_xor(bestd, off);
+          const int c2 = __shfl_xor(bc, off), i2 = __shfl_xor(bi, off);
+          if (d2 < bestd || (d2 == bestd && i2 < bi)) { bestd = d2; bc = c2; bi = i2; }
+        }
+        if (bc != 0x7fffffff) { spx = sx[bc]; spy = sy[bc]; found = true; }
       }
       okp = found;
-      if (okp) {
+      if (okp && lane == 0) {
         bool any, all;
         rl_disc(v, spx, spy, 0.15, 2, any, all);
         if (any) okp = false;                                                     // :440
