@@ -96,6 +96,9 @@ struct Scene {
   size_t cap_amb = 0;
   double *d_rule_rec = nullptr;   // [1 + O][24] per-workgroup records of the spawn rule families (fo_spawn_rules.hpp)
   size_t cap_rule_rec = 0;
+  double shadow_length = 100.0;   // where an obstacle's shadow wedge ends (helper_functions.py:145-146); <= 0 or inf: nowhere
+  double *d_ofar = nullptr;       // [O][3] per step: half-plane beyond the end of each obstacle's wedge
+  size_t cap_ofar = 0;
   int *d_rule_lab = nullptr, *d_rule_cnt = nullptr;   // dynamic rule: [O][97 x 97] lattice labels, [O] arrival counters
   size_t cap_rule_lab = 0, cap_rule_cnt = 0;
 };
@@ -496,6 +499,38 @@ __device__ __forceinline__ int in_obstacle_skin(int O, const double *__restrict_
   return 0;
 }
 
+// Where an obstacle's shadow ENDS in the reference (helper_functions.py:139-176): the occlusion polygon is the quad
+// [c1, c2, c2 + L u(c2 - ego), c1 + L u(c1 - ego)], L = 100 m, with (c1, c2) the corner pair that subtends the largest angle
+// at the ego (_identify_projection_points: all 4 x 4 ordered pairs, arccos of the clipped dot product of the unit vectors,
+// strictly greater wins, first in loop order).  Beyond the chord between the two end points the obstacle hides nothing.
+// out[3] = (a, b, c): a point lies beyond that chord iff a x + b y + c > 0 (the ego on the other side); a = b = 0, c = -1
+// when there is no such chord (length <= 0 or infinite: shadows without end, or a degenerate view).
+__device__ inline void wedge_far_halfplane(double ex, double ey, const double *__restrict__ c, double length, double *out) {
+  out[0] = 0.0; out[1] = 0.0; out[2] = -1.0;
+  if (!(length > 0.0) || !(length < INFINITY)) return;
+  double best = 0.0;
+  int i1 = -1, i2 = -1;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const double r1x = c[2 * i] - ex, r1y = c[2 * i + 1] - ey, r2x = c[2 * j] - ex, r2y = c[2 * j + 1] - ey;
+      const double n1 = sqrt(r1x * r1x + r1y * r1y), n2 = sqrt(r2x * r2x + r2y * r2y);
+      const double u1x = r1x / n1, u1y = r1y / n1, u2x = r2x / n2, u2y = r2y / n2;
+      const double ang = acos(fmin(fmax(u1x * u2x + u1y * u2y, -1.0), 1.0));
+      if (ang > best) { best = ang; i1 = i; i2 = j; }
+    }
+  if (i1 < 0) return;
+  const double r1x = c[2 * i1] - ex, r1y = c[2 * i1 + 1] - ey, r2x = c[2 * i2] - ex, r2y = c[2 * i2 + 1] - ey;
+  const double n1 = sqrt(r1x * r1x + r1y * r1y), n2 = sqrt(r2x * r2x + r2y * r2y);
+  const double c4x = c[2 * i1] + r1x / n1 * length, c4y = c[2 * i1 + 1] + r1y / n1 * length;   // c1 + L u(c1 - ego)
+  const double c3x = c[2 * i2] + r2x / n2 * length, c3y = c[2 * i2 + 1] + r2y / n2 * length;   // c2 + L u(c2 - ego)
+  double a = -(c4y - c3y), b = c4x - c3x;
+  double cc = -(a * c3x + b * c3y);
+  const double ge = a * ex + b * ey + cc;
+  if (ge == 0.0 || ge != ge) return;
+  if (ge > 0.0) { a = -a; b = -b; cc = -cc; }
+  out[0] = a; out[1] = b; out[2] = cc;
+}
+
 // ------------------------------------------------------------------------------------------------ cell grid
 __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int rny, double rx0, double ry0, double cs,
                                int ix0, int iy0, int nx, int ny, double ex, double ey, double hx, double hy, double r,
@@ -505,9 +540,16 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
                                int32_t *__restrict__ vis32, uint8_t *__restrict__ vis, int exact, int E,
                                const int32_t *__restrict__ hit_id, const double *__restrict__ rmax,
                                int32_t *__restrict__ amb, int32_t *__restrict__ n_amb,
-                               const double *__restrict__ half, const int32_t *__restrict__ edge_line) {
+                               const double *__restrict__ half, const int32_t *__restrict__ edge_line,
+                               const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags, double shadow_length,
+                               double *__restrict__ ofar, int n_obst) {
   __shared__ int wsum[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  // where the obstacles' shadows end (read by the settle kernel, the next launch): a thread per obstacle
+  if (ofar && idx < n_obst && ocorn) {
+    if ((oflags[idx] & 1) && (oflags[idx] & 2)) wedge_far_halfplane(ex, ey, ocorn + 8 * (size_t)idx, shadow_length, ofar + 3 * (size_t)idx);
+    else { ofar[3 * idx] = 0.0; ofar[3 * idx + 1] = 0.0; ofar[3 * idx + 2] = -1.0; }
+  }
   if (vis && idx < O) {  // obstacle-visibility flags of the probe workgroups (previous launch); self-cleaning
     vis[idx] = vis32[idx] ? 1 : 0;
     vis32[idx] = 0;
@@ -602,7 +644,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
     int O, const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags, double rx0, double ry0, double cs, int ix0, int iy0, int nx, double ex,
     double ey, double hx, double hy, double r, const double *__restrict__ half, const int32_t *__restrict__ amb,
     const int32_t *__restrict__ n_amb, uint8_t *__restrict__ cls, uint8_t *__restrict__ occ_flag,
-    int32_t *__restrict__ blk, int ny) {
+    int32_t *__restrict__ blk, int ny, const double *__restrict__ ofar) {
   if ((int)blockIdx.x >= SETTLE_BLOCKS) {
     // Workgroups past the cell part: one per obstacle.  sensor_model.py:183 takes the obstacle grown by 5 mm out of
     // the visible area, so a centre the grid kernel found visible inside that skin loses the bit here (the undecided
@@ -679,6 +721,8 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
       const int o = gi >> 2, sd = gi & 3, s2 = (sd + 1) & 3;
       if (!((oflags[o] & 1) && (oflags[o] & 2))) continue;
       const double *c = ocorn + 8 * (size_t)o;
+      // the obstacle hides the centre unless the centre lies beyond the end of its shadow wedge (wedge_far_halfplane)
+      if (ofar && ofar[3 * o] * px + ofar[3 * o + 1] * py + ofar[3 * o + 2] > 0.0) continue;
       hit |= crosses(c[2 * sd], c[2 * sd + 1], c[2 * s2], c[2 * s2 + 1]);
     }
     int blocked = __syncthreads_or(hit);
@@ -1267,7 +1311,7 @@ extern "C" {
 void fo_scene_destroy_(fo_ctx *ctx) {
   if (!ctx || !ctx->scene) return;
   Scene *sc = (Scene *)ctx->scene;
-  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_flags2, sc->d_blk2, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_rule_rec, sc->d_rule_lab, sc->d_rule_cnt};
+  void *ptrs[] = {sc->d_vis32, sc->d_flags, sc->d_blk, sc->d_flags2, sc->d_blk2, sc->d_cand, sc->d_ncand, sc->d_amb, sc->d_namb, sc->d_rule_rec, sc->d_rule_lab, sc->d_rule_cnt, sc->d_ofar};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   map_release(sc->map);
@@ -1434,6 +1478,13 @@ int fo_scene_set_routes(fo_ctx *ctx, int P, int R, const int32_t *h_first, const
   return FO_OK;
 }
 
+int fo_scene_set_shadow_length(fo_ctx *ctx, double length) {
+  if (!ctx) return FO_E_ARG;
+  if (length != length) return fo_fail(ctx, FO_E_ARG, "fo_scene_set_shadow_length: NaN");
+  scene_of(ctx)->shadow_length = length;
+  return FO_OK;
+}
+
 int fo_scene_map_info(fo_ctx *ctx, double *x0, double *y0, double *cs, int *nx, int *ny, int *n_edges) {
   if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_map_info: no map set");
   Scene *sc = (Scene *)ctx->scene;
@@ -1520,22 +1571,28 @@ static int scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head
     hipLaunchKernelGGL(fo_rays_kernel<false>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
                        probes ? sc->d_vis32 : nullptr, sc->d_namb, fan);
+  // where the obstacles' shadows end: worked out by the grid kernel (a thread per obstacle), read by the settle kernel
+  double *far = nullptr;
+  if (exact_cells && O > 0 && sc->shadow_length > 0.0 && sc->shadow_length < INFINITY) {
+    if ((rc = fo_reserve(ctx, &sc->d_ofar, &sc->cap_ofar, (size_t)3 * O))) return rc;
+    far = sc->d_ofar;
+  }
   hipLaunchKernelGGL(fo_grid_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, sc->map->d_raster, sc->map->rnx, sc->map->rny, sc->map->x0,
                      sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
                      n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk, probes ? O : 0, sc->d_vis32,
                      probes ? d_obst_vis : nullptr, exact_cells ? 1 : 0, sc->map->E, d_hit_id, d_rmax, sc->d_amb,
-                     sc->d_namb, d_half, sc->map->d_edge_line);
+                     sc->d_namb, d_half, sc->map->d_edge_line, d_ocorn, d_oflags, sc->shadow_length, far, O);
   if (exact_cells) {
     if ((uintptr_t)d_cls & 3) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: d_cls must be 4-byte aligned");
     const dim3 sgrid(SETTLE_BLOCKS + O), sblock(64 * RAY_WAVES);
     if (d_edge_skip)
       hipLaunchKernelGGL(fo_settle_kernel<true>, sgrid, sblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O,
                          d_ocorn, d_oflags, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
-                         d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny);
+                         d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny, far);
     else
       hipLaunchKernelGGL(fo_settle_kernel<false>, sgrid, sblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O,
                          d_ocorn, d_oflags, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
-                         d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny);
+                         d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny, far);
   }
   FO_HIP_TRY(ctx, hipGetLastError());
   if (sf_in) {

@@ -32,7 +32,7 @@ EXPORTS = [
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read", "fo_sweep_timing_read_each",
     "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
     "fo_scene_candidate_count", "fo_scene_set_topology", "fo_scene_spawn_rules", "fo_step_run",
-    "fo_scene_set_centerlines", "fo_scene_spawn_rule_agents", "fo_sweep_autotune",
+    "fo_scene_set_centerlines", "fo_scene_spawn_rule_agents", "fo_sweep_autotune", "fo_scene_set_shadow_length",
 ]
 
 
@@ -153,6 +153,7 @@ def load():
     lib.fo_scene_spawn_rules.argtypes = ([vp, dp] + [C.c_int] * 5 + [dp, C.c_int] + [dp] * 6 + [C.POINTER(SpawnRuleParams), C.c_int,
                                                                                           dp, ip, vp])
     lib.fo_scene_set_centerlines.argtypes = [vp, C.c_int, ip, dp]
+    lib.fo_scene_set_shadow_length.argtypes = [vp, C.c_double]
     lib.fo_scene_spawn_rule_agents.argtypes = ([vp, C.c_int, dp, ip, C.c_int, C.POINTER(RuleAgentTypes), C.c_int, dp, C.c_int]
                                                + [D] * 3 + [dp] * 8 + [ip, ip, vp])
     for name in EXPORTS:

@@ -82,6 +82,7 @@ class FOInterface:
                                         footprint=str(acc.get("footprint", "polygon")),
                                         enclosed_holes=str(acc.get("enclosed_holes", "transparent")),
                                         cell_visibility=str(acc.get("cell_visibility", "exact")),
+                                        shadow_length=float(acc.get("shadow_length", 100.0)),
                                         share_map_with=share_map_with.sensor_model if share_map_with is not None else None,
                                         intersections=getattr(self.cr_scenario, "intersections", None) or
                                         getattr(self.lanelet_network, "intersections", None))

@@ -198,7 +198,7 @@ class SensorModel:
     def __init__(self, lanelet_network, ref_path, sensor_radius=30, sensor_angle=90, debug=True, visualization=None,
                  ctx: Optional[N.Context] = None, n_rays=720, cell_size=0.5, device=0, routes=0,
                  footprint="polygon", enclosed_holes="transparent", cell_visibility="exact", share_map_with=None,
-                 intersections=None):
+                 intersections=None, shadow_length=100.0):
         """lanelet_network: a :class:`~frenetix_occlusion.scenario.MapGeometry`, a list of
         :class:`~frenetix_occlusion.scenario.Lanelet`, or an object with ``.lanelets`` (duck-typed CommonRoad).
 
@@ -207,6 +207,10 @@ class SensorModel:
         no shadow (the reference walks exterior rings only, sensor_model.py:126-131), "occlude" = every boundary piece
         occludes.  cell_visibility: "exact" = cells the ray fan cannot decide (their two enclosing rays stop at
         different occluders) are settled by the reference's set algebra at the cell centre, "fan" = chord rule only.
+        shadow_length: where an obstacle's occlusion polygon ends, metres along its two silhouette sight lines (100 in the
+        reference, helper_functions.py:145-146; it matters for an obstacle seen from so close by that the chord between the
+        two end points passes inside the sensor radius); ``math.inf`` = the physical shadow, which never ends.  Read by the
+        exact cell settlement only.
         share_map_with: another SensorModel of the same scenario on the same GPU (an ego of a multi-ego run): the static
         map is neither recomputed on the host nor uploaded again, both contexts read one copy in HBM
         (``fo_scene_share_map``); ``lanelet_network`` is then ignored."""
@@ -215,11 +219,15 @@ class SensorModel:
             raise ValueError("footprint: 'polygon' | 'circle'; enclosed_holes: 'transparent' | 'occlude'; "
                              "cell_visibility: 'exact' | 'fan'")
         self.footprint, self.enclosed_holes, self.cell_visibility = footprint, enclosed_holes, cell_visibility
+        self.shadow_length = float(shadow_length)
+        if not self.shadow_length > 0.0:
+            raise ValueError("shadow_length: a positive length in metres, or inf")
         if not torch.cuda.is_available():
             raise RuntimeError("SensorModel needs a ROCm GPU (no CPU fallback)")
         self.device = torch.device("cuda", int(device))
         self._dev_index = int(device)
         self.ctx = ctx or N.Context(self.device.index)
+        self.ctx.call("fo_scene_set_shadow_length", self.shadow_length)
         self.lanelet_network = lanelet_network
         self.ref_path = ref_path
         self.visualization = visualization

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 9
+#define FO_ABI_VERSION 10
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -184,6 +184,15 @@ int fo_scene_set_routes(fo_ctx *ctx, int P, int R, const int32_t *h_first, const
  * cells at real corners and depth discontinuities.  Without it every piece is its own chain. */
 int fo_scene_set_edge_lines(fo_ctx *ctx, int E, const int32_t *h_line);
 int fo_scene_map_info(fo_ctx *ctx, double *x0, double *y0, double *cs, int *nx, int *ny, int *n_edges);
+/* Where an obstacle's shadow ends.  The reference builds an obstacle's occlusion polygon from the two silhouette corners
+ * and the points `length` = 100 m beyond them along the sight lines (helper_functions.py:139-176: get_polygon_from_obstacle_
+ * occlusion, _identify_projection_points): behind the chord between those two end points the obstacle hides nothing.  Seen
+ * from close by (a 9 m truck within ~1.5 m) that chord falls inside the sensor range.  Default 100.0 = the reference's;
+ * <= 0 or infinity = shadows without end.  Applied where cells are settled exactly (exact_cells of fo_scene_visibility:
+ * every cell behind an obstacle is); the first-hit ranges / hit ids / the visible polygon's ring are unaffected.  The
+ * reference's boundary shadows end at 101 x the vertex distance (:91-92), which the ray fan does not represent: inside
+ * 1.5 r = 75 m that takes a boundary vertex within 0.74 m of the ego. */
+int fo_scene_set_shadow_length(fo_ctx *ctx, double length);
 int fo_scene_copy_raster(fo_ctx *ctx, uint8_t *h_out);
 
 /* Ray fan about the ego heading, written on the device (replaces the angle bookkeeping of

@@ -102,7 +102,13 @@ typedef struct {
   const uint8_t *oflags;
   const double *half_dirs; /* [100][2] unit directions of the reference's 1.5 r half fan, or NULL = true half disc */
   const int32_t *edge_line; /* [E] straight-line chain of each boundary piece, or NULL = every piece on its own */
+  double shadow_length;     /* where an obstacle's occlusion polygon ends (helper_functions.py:145-146: 100 m along the two
+                             * silhouette sight lines); <= 0 or infinity: nowhere */
 } fo_oracle_exact_t;
+/* the silhouette corner pair of a rectangle seen from ego (helper_functions.py:150-176, _identify_projection_points) and the
+ * half-plane beyond the chord between the two wedge end points: c12[4] = c1, c2; abc[3]: a x + b y + c > 0 <=> beyond.
+ * Returns 1 when such a chord exists (finite positive length, non-degenerate view), else 0 (abc = 0, 0, -1). */
+int fo_oracle_wedge_far(const double *ego, const double *corners, double length, double *c12, double *abc);
 int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double ry0, double cs, int ix0, int iy0,
                    int nx, int ny, const double *ego, const double *hdir, double r, int full, int n_rays,
                    const double *dirs, const double *range, uint8_t *cls, int32_t *occ_idx, int32_t *n_occ,

@@ -195,12 +195,13 @@ def raycast(edges, ocorn, oflags, ego, dirs, r, rmax=None, edge_skip=None):
 class _Exact(C.Structure):
     _fields_ = [("hit_id", C.c_void_p), ("rmax", C.c_void_p), ("E", C.c_int), ("edges", C.c_void_p),
                 ("edge_skip", C.c_void_p), ("O", C.c_int), ("ocorn", C.c_void_p), ("oflags", C.c_void_p),
-                ("half_dirs", C.c_void_p), ("edge_line", C.c_void_p)]
+                ("half_dirs", C.c_void_p), ("edge_line", C.c_void_p), ("shadow_length", C.c_double)]
 
 
 def grid(raster, rx0, ry0, cs, ix0, iy0, nx, ny, ego, hdir, r, full, dirs, rng, exact=None, return_n_exact=False):
     """exact: None (fan rule only) or dict(hit_id=, edges=, ocorn=, oflags=, rmax=None, edge_skip=None,
-    half_dirs=None, edge_line=None)"""
+    half_dirs=None, edge_line=None, shadow_length=100.0): shadow_length is where an obstacle's occlusion polygon ends
+    (helper_functions.py:145-146); math.inf = the wedge never ends"""
     raster = _u8(raster)
     rny, rnx = raster.shape
     ego, hdir, dirs, rng = _f64(ego), _f64(hdir), _f64(dirs), _f64(rng)
@@ -221,7 +222,7 @@ def grid(raster, rx0, ry0, cs, ix0, iy0, nx, ny, ego, hdir, r, full, dirs, rng, 
         keep = [hid, edges, ocorn, oflags, rmax, skip, half, line]
         adr = lambda a: a.ctypes.data if a is not None and a.size else None
         ex = _Exact(adr(hid), adr(rmax), edges.shape[0], adr(edges), adr(skip), ocorn.shape[0], adr(ocorn), adr(oflags),
-                     adr(half), adr(line))
+                     adr(half), adr(line), float(exact.get("shadow_length", 100.0)))
     lib().fo_oracle_grid(_p(raster, C.c_uint8), C.c_int(rnx), C.c_int(rny), C.c_double(rx0), C.c_double(ry0),
                          C.c_double(cs), C.c_int(ix0), C.c_int(iy0), C.c_int(nx), C.c_int(ny), _p(ego), _p(hdir),
                          C.c_double(r), C.c_int(1 if full else 0), C.c_int(dirs.shape[0]), _p(dirs), _p(rng),
@@ -231,6 +232,16 @@ def grid(raster, rx0, ry0, cs, ix0, iy0, nx, ny, ego, hdir, r, full, dirs, rng, 
     if return_n_exact:
         return cls, occ[:n_occ.value].copy(), int(n_ex.value)
     return cls, occ[:n_occ.value].copy()
+
+
+def wedge_far(ego, corners, length=100.0):
+    """silhouette corner pair of a rectangle seen from ego and the far-chord half-plane of its occlusion polygon
+    (helper_functions.py:139-176): returns (c1, c2, abc or None)"""
+    ego, corners = _f64(ego), _f64(corners).reshape(4, 2)
+    c12, abc = np.zeros(4), np.zeros(3)
+    lib().fo_oracle_wedge_far.restype = C.c_int
+    ok = lib().fo_oracle_wedge_far(_p(ego), _p(corners), C.c_double(length), _p(c12), _p(abc))
+    return c12[:2].copy(), c12[2:].copy(), (abc if ok else None)
 
 
 def obstacle_visibility(edges, ocorn, ocen, oflags, ego, r, full, dirs, edge_skip=None, hit_id=None):

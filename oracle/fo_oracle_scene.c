@@ -166,8 +166,42 @@ static int fan_sector(int n_rays, const double *dirs, int full, double rx, doubl
  * [v1, v2, v2 + 100 (v2 - ego), v1 + 100 (v1 - ego)] (helper_functions.py:79-96) and obstacle occlusion polygons
  * (:133-141) contain a point iff the open segment ego -> point crosses the occluding piece.  Same predicate as
  * ray_segment with the unnormalised direction (rx, ry); "t < 1" is decided on tn and denom without the division. */
+/* Where an obstacle's shadow ends in the reference (helper_functions.py:139-176, restated: every ordered corner pair, the
+ * arccos of the clipped dot product of the unit sight lines, the strictly largest angle first met wins; the occlusion polygon
+ * runs from the two corners to the points `length` beyond them along their sight lines). */
+int fo_oracle_wedge_far(const double *ego, const double *c, double length, double *c12, double *abc) {
+  abc[0] = 0.0; abc[1] = 0.0; abc[2] = -1.0;
+  double best = 0.0;
+  int i1 = -1, i2 = -1;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const double r1x = c[2 * i] - ego[0], r1y = c[2 * i + 1] - ego[1], r2x = c[2 * j] - ego[0], r2y = c[2 * j + 1] - ego[1];
+      const double n1 = sqrt(r1x * r1x + r1y * r1y), n2 = sqrt(r2x * r2x + r2y * r2y);
+      const double u1x = r1x / n1, u1y = r1y / n1, u2x = r2x / n2, u2y = r2y / n2;
+      double d = u1x * u2x + u1y * u2y;
+      d = d < -1.0 ? -1.0 : (d > 1.0 ? 1.0 : d);
+      const double ang = acos(d);
+      if (ang > best) { best = ang; i1 = i; i2 = j; }
+    }
+  if (i1 < 0) return 0;
+  if (c12) { c12[0] = c[2 * i1]; c12[1] = c[2 * i1 + 1]; c12[2] = c[2 * i2]; c12[3] = c[2 * i2 + 1]; }
+  if (!(length > 0.0) || !(length < INFINITY)) return 0;
+  const double r1x = c[2 * i1] - ego[0], r1y = c[2 * i1 + 1] - ego[1], r2x = c[2 * i2] - ego[0], r2y = c[2 * i2 + 1] - ego[1];
+  const double n1 = sqrt(r1x * r1x + r1y * r1y), n2 = sqrt(r2x * r2x + r2y * r2y);
+  const double c4x = c[2 * i1] + r1x / n1 * length, c4y = c[2 * i1 + 1] + r1y / n1 * length;
+  const double c3x = c[2 * i2] + r2x / n2 * length, c3y = c[2 * i2 + 1] + r2y / n2 * length;
+  double a = -(c4y - c3y), b = c4x - c3x;
+  double cc = -(a * c3x + b * c3y);
+  const double ge = a * ego[0] + b * ego[1] + cc;
+  if (ge == 0.0 || ge != ge) return 0;
+  if (ge > 0.0) { a = -a; b = -b; cc = -cc; }
+  abc[0] = a; abc[1] = b; abc[2] = cc;
+  return 1;
+}
+
 static int blocked_before(int E, const double *edges, const uint8_t *edge_skip, int O, const double *ocorn,
-                          const uint8_t *oflags, double ox, double oy, double rx, double ry) {
+                          const uint8_t *oflags, double ox, double oy, double rx, double ry, const double *ofar, double px,
+                          double py) {
   for (int e = 0; e < E + 4 * O; ++e) {
     double ax, ay, bx, by;
     if (e < E) {
@@ -177,6 +211,8 @@ static int blocked_before(int E, const double *edges, const uint8_t *edge_skip, 
     } else {
       const int o = (e - E) >> 2, sd = (e - E) & 3, s2 = (sd + 1) & 3;
       if (!(oflags[o] & 1) || !(oflags[o] & 2)) continue;
+      /* beyond the end of the obstacle's occlusion polygon it hides nothing */
+      if (ofar && ofar[3 * o] * px + ofar[3 * o + 1] * py + ofar[3 * o + 2] > 0.0) continue;
       const double *c = ocorn + 8 * (size_t)o;
       ax = c[2 * sd]; ay = c[2 * sd + 1]; bx = c[2 * s2]; by = c[2 * s2 + 1];
     }
@@ -233,6 +269,14 @@ int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double r
                    const fo_oracle_exact_t *exact, int32_t *n_exact) {
   int cnt = 0, n_ex = 0;
   const double r2 = r * r, ro2 = (1.5 * r) * (1.5 * r);
+  double *ofar = NULL;
+  if (exact && exact->O > 0 && exact->shadow_length > 0.0 && exact->shadow_length < INFINITY) {
+    ofar = (double *)malloc(sizeof(double) * 3 * (size_t)exact->O);
+    for (int o = 0; o < exact->O; ++o) {
+      ofar[3 * o] = 0.0; ofar[3 * o + 1] = 0.0; ofar[3 * o + 2] = -1.0;
+      if ((exact->oflags[o] & 1) && (exact->oflags[o] & 2)) fo_oracle_wedge_far(ego, exact->ocorn + 8 * (size_t)o, exact->shadow_length, NULL, ofar + 3 * o);
+    }
+  }
   for (int iy = 0; iy < ny; ++iy) {
     for (int ix = 0; ix < nx; ++ix) {
       const int wx = ix0 + ix, wy = iy0 + iy;
@@ -271,7 +315,7 @@ int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double r
                 const double cf = (fjx - fix) * (ry - fiy) - (fjy - fiy) * (rx - fix);
                 ++n_ex;
                 vis = cf >= 0.0 && !blocked_before(exact->E, exact->edges, exact->edge_skip, exact->O, exact->ocorn,
-                                                   exact->oflags, ego[0], ego[1], rx, ry);
+                                                   exact->oflags, ego[0], ego[1], rx, ry, ofar, px, py);
               }
             }
           }
@@ -304,6 +348,7 @@ int fo_oracle_grid(const uint8_t *raster, int rnx, int rny, double rx0, double r
       }
     }
   }
+  free(ofar);
   *n_occ = cnt;
   if (n_exact) *n_exact = n_ex;
   return 0;

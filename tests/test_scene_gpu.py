@@ -28,7 +28,7 @@ def _default_config():
 
 
 def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_rays=720, radius=50.0, max_agents=32,
-                ref_path=None, all_occluded=False, max_dist=None):
+                ref_path=None, all_occluded=False, max_dist=None, shadow_length=100.0):
     from frenetix_occlusion.sensor_model import SensorModel, ray_dirs
     from frenetix_occlusion.spawn_locator import SpawnLocator
     from frenetix_occlusion.utils.fo_obstacle import FOObstacles
@@ -37,7 +37,8 @@ def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_r
     if ref_path is None:
         s = np.linspace(0.0, 60.0, 61)
         ref_path = ego[None, :2] + s[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
-    sm = SensorModel(sc.lanelets, ref_path, sensor_radius=radius, sensor_angle=sensor_angle, n_rays=n_rays)
+    sm = SensorModel(sc.lanelets, ref_path, sensor_radius=radius, sensor_angle=sensor_angle, n_rays=n_rays,
+                     shadow_length=shadow_length)
     obst = FOObstacles(sc.obstacles)
     obst.update(timestep)
     sm.calc_visible_and_occluded_area(timestep, ego[:2], yaw, obst)
@@ -78,7 +79,8 @@ def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_r
     from frenetix_occlusion.sensor_model import half_fan_dirs
     half = sm.half_dirs.cpu().numpy()
     np.testing.assert_allclose(half, half_fan_dirs(yaw), rtol=0, atol=4e-15)
-    ex = dict(hit_id=hid_ref, edges=geo.edges, ocorn=corn, oflags=flags, rmax=rmax, edge_skip=skip, half_dirs=half, edge_line=geo.edge_line)
+    ex = dict(hit_id=hid_ref, edges=geo.edges, ocorn=corn, oflags=flags, rmax=rmax, edge_skip=skip, half_dirs=half, edge_line=geo.edge_line,
+              shadow_length=shadow_length)
     cls_ref, occ_ref, n_exact = oracle.grid(raster_ref, x0, y0, cs, w.ix0, w.iy0, w.nx, w.ny, ego[:2], hd, radius, full,
                                             dirs, rng_ref, exact=ex, return_n_exact=True)
     assert np.array_equal(sm.cell_class.cpu().numpy(), cls_ref)
@@ -218,6 +220,37 @@ def test_obstacle_lit_between_its_probe_points_is_visible(torch_cuda, oracle):
     sm.calc_visible_and_occluded_area(0, ego[:2], 0.0, ob)
     assert sm.visible_objects_timestep == [1, 2, 3, 4]
     assert len(sm.obstacle_occlusions[1]) > 10          # the rays its side stops
+
+
+def test_shadow_of_an_obstacle_ends_where_the_references_polygon_does(torch_cuda, oracle):
+    """helper_functions.py:145-146 (the occlusion polygon ends 100 m along the two silhouette sight lines): a truck across
+    the road ~1 m ahead of the ego subtends so wide an angle that the far chord passes ~18 m away; the road beyond it is
+    visible in the reference (tests/test_scene_pointwise.py proves the oracle equal to the reference's set algebra there).
+    Device == oracle bit for bit with the default length, with other lengths and with the physical shadow (inf), on
+    scenario 1 and in an open room; plus several obstacles at once, one of them a bicycle (casts no shadow)."""
+    from frenetix_occlusion import scenario as S
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    yaw = float(ego[2])
+    fwd, left = np.array([math.cos(yaw), math.sin(yaw)]), np.array([-math.sin(yaw), math.cos(yaw)])
+    seen = {}
+    for gap, shift in ((1.0, 0.0), (0.6, 2.0)):
+        cen = ego[:2] + (gap + 1.25) * fwd + shift * left
+        truck = S.Obstacle(900, "static", "truck", 12.0, 2.5, 0, np.array([cen[0], cen[1], yaw + 0.5 * math.pi, 0.0]),
+                           np.zeros((0, 4)))
+        sc2 = S.Scenario(sc.dt, sc.lanelets, [truck] + list(sc.obstacles), sc.intersections, sc.ego_initial, sc.benchmark_id)
+        for L in (100.0, 30.0, math.inf):
+            seen[(gap, L)] = _check_step(torch_cuda, oracle, sc2, ego, 7.63, 0, shadow_length=L)["vis_cells"]
+        assert seen[(gap, 30.0)] > seen[(gap, 100.0)] > seen[(gap, math.inf)]
+    xs = np.linspace(-60.0, 60.0, 2)
+    room = S.Lanelet(1, np.stack((xs, np.full(2, 60.0)), -1), np.stack((xs, np.full(2, -60.0)), -1))
+    mk = lambda i, x, y, l, w, yw, typ="car": S.Obstacle(i, "static", typ, l, w, 0, np.array([x, y, yw, 0.0]), np.zeros((0, 4)))
+    sc3 = S.Scenario(0.1, [room], [mk(1, 2.0, 0.3, 2.5, 14.0, 0.1), mk(2, -1.5, 0.0, 2.0, 9.0, -0.2),
+                                   mk(3, 0.5, 2.2, 6.0, 1.0, 0.0, "bicycle"), mk(4, 0.0, -9.0, 4.5, 1.8, 0.4)])
+    e3 = np.array([0.0, 0.0, 0.0, 5.0])
+    a = _check_step(torch_cuda, oracle, sc3, e3, 5.0, 0)["vis_cells"]
+    b = _check_step(torch_cuda, oracle, sc3, e3, 5.0, 0, shadow_length=math.inf)["vis_cells"]
+    assert a > b + 200
 
 
 def test_footprint_and_hole_options(torch_cuda, oracle):

@@ -17,7 +17,7 @@ import ref_pointwise as RP
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _classes(oracle, sc, ego, yaw, r, fov, timestep, n_rays=720, cs=0.5, exact=True):
+def _classes(oracle, sc, ego, yaw, r, fov, timestep, n_rays=720, cs=0.5, exact=True, shadow_length=100.0):
     g = S.MapGeometry.from_lanelets(sc.lanelets)
     corn, cen, flags, _ = sc.obstacle_arrays(timestep)
     xy = g.poly_xy
@@ -34,7 +34,7 @@ def _classes(oracle, sc, ego, yaw, r, fov, timestep, n_rays=720, cs=0.5, exact=T
     rng, hid, _ = oracle.raycast(g.edges, corn.reshape(-1, 8), flags, ego, dirs, r, rmax=rmax, edge_skip=skip)
     hd = np.array([math.cos(yaw), math.sin(yaw)])
     ex = dict(hit_id=hid, edges=g.edges, ocorn=corn.reshape(-1, 8), oflags=flags, rmax=rmax, edge_skip=skip,
-              half_dirs=half_fan_dirs(yaw), edge_line=g.edge_line) if exact else None
+              half_dirs=half_fan_dirs(yaw), edge_line=g.edge_line, shadow_length=shadow_length) if exact else None
     cls, _, n_exact = oracle.grid(raster, x0, y0, cs, 0, 0, nx, ny, ego, hd, r, fov >= 359.9, dirs, rng, exact=ex,
                                   return_n_exact=True)
     iy, ix = np.mgrid[0:ny, 0:nx]
@@ -71,6 +71,33 @@ def test_cell_classes_equal_the_reference_set_algebra_at_every_cell_centre(oracl
     assert np.array_equal(s["vis"], s["o_vis"])
     assert np.array_equal(s["occ"], s["o_occ"])
     assert 0 < s["n_exact"] < 0.5 * (s["vis"].sum() + s["occ"].sum())   # the fan decides most cells on its own
+
+
+def test_an_obstacle_seen_from_one_metre_ends_its_shadow_where_the_references_polygon_does(oracle):
+    """helper_functions.py:145-146: the occlusion polygon of an obstacle ends 100 m along its two silhouette sight lines.
+    A 12 m truck across the road one metre ahead of the ego subtends ~160 deg: the chord between the two end points passes ~18 m from the
+    ego, and the road beyond it is VISIBLE to the reference.  The default (shadow_length 100) reproduces that cell for
+    cell; with the physical shadow (inf) those cells are hidden."""
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego = sc.ego_initial
+    yaw = float(ego[2])
+    fwd = np.array([math.cos(yaw), math.sin(yaw)])
+    left = np.array([-math.sin(yaw), math.cos(yaw)])
+    for gap, shift in ((1.0, 0.0), (0.6, 2.0)):
+        # across the road, `gap` metres ahead of the ego
+        cen = ego[:2] + (gap + 1.25) * fwd + shift * left
+        truck = S.Obstacle(900, "static", "truck", 12.0, 2.5, 0, np.array([cen[0], cen[1], yaw + 0.5 * math.pi, 0.0]),
+                           np.zeros((0, 4)))
+        sc2 = S.Scenario(sc.dt, sc.lanelets, [truck], sc.intersections, sc.ego_initial, sc.benchmark_id)
+        s = _classes(oracle, sc2, ego[:2], yaw, 50.0, 360.0, 0)
+        assert np.array_equal(s["vis"], s["o_vis"]) and np.array_equal(s["occ"], s["o_occ"])
+        # the cells beyond the far chord: hidden by the physical shadow, visible in the reference
+        t = _classes(oracle, sc2, ego[:2], yaw, 50.0, 360.0, 0, shadow_length=math.inf)
+        lost = s["o_vis"] & ~t["o_vis"]
+        assert lost.sum() > 50 and not (t["o_vis"] & ~s["o_vis"]).any()
+        _, _, abc = oracle.wedge_far(ego[:2], truck.corners(truck.initial), 100.0)
+        q = s["q"][lost]
+        assert (abc[0] * q[:, 0] + abc[1] * q[:, 1] + abc[2] > 0.0).all()
 
 
 def test_moving_ego_keeps_the_cell_classes_equal_to_the_reference_set_algebra(oracle):

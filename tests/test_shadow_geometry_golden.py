@@ -127,3 +127,43 @@ def test_oracle_obstacle_shadow_agrees_with_the_references_wedge_plus_obstacle(g
         n_in += int(want.sum())
         n_out += int((~want).sum())
     assert n_in > 500 and n_out > 1000
+
+
+def test_oracle_silhouette_pair_and_far_chord_equal_the_references(g, oracle):
+    """the oracle's C statement of _identify_projection_points and of the polygon's far edge (fo_oracle_wedge_far, what
+    fo_oracle_grid ends an obstacle's shadow with, and what the device's wedge_far_halfplane restates)"""
+    rng = np.random.default_rng(9)
+    for ego, corn, ref, c1, c2 in zip(g["wedge_ego"], g["wedge_corners"], g["wedge_ref"], g["wedge_c1"], g["wedge_c2"]):
+        a, b, abc = oracle.wedge_far(ego, corn, 100.0)
+        assert np.array_equal(a, c1) and np.array_equal(b, c2)
+        assert abc is not None
+        c3, c4 = ref[2], ref[3]                                    # [c1, c2, c2 + 100 u2, c1 + 100 u1]
+        # the line through the reference's two end points, ego on the negative side
+        for q in (c3, c4):
+            assert abs(abc[0] * q[0] + abc[1] * q[1] + abc[2]) < 1e-9 * max(1.0, float(np.hypot(abc[0], abc[1])))
+        assert abc[0] * ego[0] + abc[1] * ego[1] + abc[2] < 0.0
+        assert oracle.wedge_far(ego, corn, math.inf)[2] is None and oracle.wedge_far(ego, corn, 0.0)[2] is None
+    # with the far chord, the oracle's predicate equals point-in-(wedge or obstacle) everywhere -- no restriction to the
+    # ego's side of the chord as in the test above
+    n_in = n_out = n_beyond = 0
+    none_e = np.zeros((0, 4))
+    for ego, corn, ref in zip(g["wedge_ego"], g["wedge_corners"], g["wedge_ref"]):
+        if RP.points_in_polygon(ego[None], corn)[0]:
+            continue
+        cen = corn.mean(0)
+        u = (cen - ego) / np.linalg.norm(cen - ego)
+        w = np.array([-u[1], u[0]])
+        p = ego[None] + rng.uniform(0.5, 130.0, (80, 1)) * u[None] + rng.uniform(-60.0, 60.0, (80, 1)) * w[None]
+        p = p[(_edge_margin(p, ref) > 1e-6) & (_edge_margin(p, corn) > 1e-6)]
+        _, _, abc = oracle.wedge_far(ego, corn, 100.0)
+        beyond = abc[0] * p[:, 0] + abc[1] * p[:, 1] + abc[2] > 0.0
+        want = RP._in_quads(p, ref[None]) | RP.points_in_polygon(p, corn)
+        d = p - ego[None]
+        dist = np.hypot(d[:, 0], d[:, 1])
+        rng_, hid, _ = oracle.raycast(none_e, corn[None], np.array([3], np.uint8), ego, d / dist[:, None], 1.0e4)
+        got = ((rng_ < dist) & ~beyond) | RP.points_in_polygon(p, corn)
+        assert np.array_equal(got, want), (ego, corn)
+        n_in += int(want.sum())
+        n_out += int((~want).sum())
+        n_beyond += int(((rng_ < dist) & beyond).sum())
+    assert n_in > 300 and n_out > 1000 and n_beyond > 100
