@@ -11,8 +11,11 @@ bash tools/collect_profiles.sh ${R}_reduced --mode reduced
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_small_batch_stats -o run -- python3 bench.py --scene scenario1 --M 2000 --A 32 --mode reduced --no-cpu-baseline --no-autotune --warmup 100 --steps 200 --no-extras > gpurun_out/${R}_small_batch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_spawn_rules_stats -o run -- python3 tools/spawn_rules_bench.py > gpurun_out/${R}_spawn_rules.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_rules_step_stats -o run -- python3 tools/rules_step_bench.py > gpurun_out/${R}_rules_step.log 2>&1
-python bench.py > gpurun_out/${R}_final_bench.json 2> gpurun_out/${R}_final_bench.err
 for t in ${R}_final ${R}_f64lists ${R}_f32x ${R}_reduced; do python3 tools/summarize_pmc.py $t gpurun_out gpurun_out/summ > /dev/null; done
+# the default bench line quotes the committed counters of the library it runs (roofline.bound / traffic / valu_issue_frac): put
+# this run's summaries where it looks for them (on the box's copy of the tree; tools/copy_profiles.sh does the same at home)
+for t in ${R}_final ${R}_f64lists ${R}_f32x ${R}_reduced; do cp gpurun_out/summ/${t}_summary.csv gpurun_out/summ/${t}_build.json profiles/; done
+python bench.py > gpurun_out/${R}_final_bench.json 2> gpurun_out/${R}_final_bench.err
 # keep the merge small: drop the raw counter dumps
 find gpurun_out -name "*counter_collection.csv" -delete; find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*agent_info.csv" -delete
 ls gpurun_out/summ; du -sh gpurun_out
