@@ -416,7 +416,7 @@ def rules_step(local_rank, steps=60):
     out = {"workload": "scenario1 geometry, 2000 trajectories, spawn.mode rules (the reference's three rule families on the device, "
                        "<= 8 spawn points x 3 route slots), T=31, reduced outputs, fo_step_run; the ego drives the scenario's first 61 "
                        "time steps (0.76 m per step), every pose timed on its own", "steps_per_pose": steps, "poses": {}}
-    per, n_dyn, n_pts = [], 0, 0
+    per, n_dyn, n_pts, worst = [], 0, 0, 0.0
     for step in range(61):
         ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
         obs.update(step)
@@ -428,12 +428,18 @@ def rules_step(local_rank, steps=60):
         for _ in range(10):
             ps.run(ego, yaw, float(ego0[3]), ego_cl)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            ps.run(ego, yaw, float(ego0[3]), ego_cl)
-        t_issue = (time.perf_counter() - t0) / steps
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        # three batches per pose, the median one counts (a pose is ~5 ms of GPU time: one 30 ms stall of the box -- seen once in
+        # twenty runs, on a pose without spawn points -- would otherwise carry the whole drive's mean); the worst is kept beside it
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(steps // 3):
+                ps.run(ego, yaw, float(ego0[3]), ego_cl)
+            t_issue = (time.perf_counter() - t0) / (steps // 3)
+            torch.cuda.synchronize()
+            runs.append(((time.perf_counter() - t0) / (steps // 3), t_issue))
+        worst = max(worst, max(r[0] for r in runs) * 1e3)
+        dt, t_issue = sorted(runs)[1]
         h = sl.batch.host_head()
         kinds = [{0: "Car", 3: "Bicycle", 4: "Pedestrian"}[int(q[0])] for q in h["rule_points"][:h["rule_n"]]]
         per.append(dt * 1e3)
@@ -444,7 +450,9 @@ def rules_step(local_rank, steps=60):
     out["ms_per_step"] = float(np.mean(per))
     out["ms_per_step_max"] = float(np.max(per))
     out["ms_per_step_p50"] = float(np.median(per))
-    out["ms_per_step_definition"] = "mean over the 61 poses of the drive (max / median beside it)"
+    out["ms_per_step_worst_batch"] = worst
+    out["ms_per_step_definition"] = ("mean over the 61 poses of the drive (max / median pose beside it); a pose = the median of three "
+                                     "batches of steps_per_pose / 3 steps, the slowest single batch of the drive under worst_batch")
     out["spawn_points_total"], out["poses_with_a_phantom_vehicle"] = n_pts, int(n_dyn)
     return out
 
