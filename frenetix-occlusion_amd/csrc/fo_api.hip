@@ -4,11 +4,18 @@
 #include <cstdlib>
 #include "fo_ctx.hpp"
 #include "fo_agent_rows.hpp"
+#include "fo_prep_traj.hpp"
 
 extern "C" void fo_scene_destroy_(fo_ctx *ctx);  // fo_scene.hip
-extern "C" int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, void *stream);  // fo_scene.hip
+extern "C" int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, const fo_prep_args_t *prep, void *stream);  // fo_scene.hip
 extern "C" int fo_sweep_agents_begin_(fo_ctx *ctx, int A, int Ta, void *stream, fo_agent_table_t *out);   // fo_sweep.hip
 extern "C" int fo_sweep_init_(fo_ctx *ctx);      // fo_sweep.hip
+extern "C" int fo_sweep_plan_(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta, const double *d_v,
+                              const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f, int32_t *d_pair_i, double *d_lists,
+                              void *stream, fo_prep_args_t *prep);   // fo_sweep.hip
+extern "C" int fo_sweep_run_prepped_(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
+                                     const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
+                                     int32_t *d_pair_i, double *d_lists, void *stream);   // fo_sweep.hip
 
 extern "C" {
 
@@ -80,7 +87,8 @@ int fo_sweep_check(fo_ctx *ctx, void *stream) {
 
 // One planning step on one stream (include/fo_hip.h, fo_step_t): the results of the stage calls fo_scene_fan ->
 // fo_scene_visibility -> fo_scene_spawn [-> fo_scene_spawn_rules -> fo_scene_spawn_rule_agents] -> fo_sweep_set_agents ->
-// fo_sweep_run, bit for bit, in three launches less -- the ray fan is worked out inside the ray kernel, the sampler's
+// fo_sweep_run, bit for bit, in four launches less -- the ray fan is worked out inside the ray kernel (whose spare workgroups
+// also write the sweep's tile table of the candidates), the sampler's
 // candidate cells are flagged inside the compaction of the occluded cells, and the phantom prediction kernels write their
 // slots' rows of the sweep's agent table themselves.
 // (FO_STEP_STAGES=1 in the environment: the plain sequence of stage calls, for A/B runs.)
@@ -125,11 +133,21 @@ int fo_step_run(fo_ctx *ctx, const fo_step_t *p, void *stream) {
                                   p->d_len, stream))) return rc;
   } else {
     fo_agent_table_t at;
+    fo_prep_args_t prep;
     if ((rc = fo_sweep_agents_begin_(ctx, slots, p->T_agents, stream, &at))) return rc;
-    if ((rc = fo_scene_step_(ctx, p, &at, stream))) {
+    // the sweep's plan for this batch (argument checks, grid, work buffers): its tile table of the candidates is written by
+    // extra workgroups of the scene stage's first launch
+    if ((rc = fo_sweep_plan_(ctx, p->M, p->T, p->d_x, p->d_y, p->d_theta, p->d_vel, p->d_acc, p->d_cost, p->d_safe, p->d_pair_f,
+                             p->d_pair_i, p->d_lists, stream, &prep))) {
+      ctx->A = 0;
+      return rc;
+    }
+    if ((rc = fo_scene_step_(ctx, p, &at, &prep, stream))) {
       ctx->A = 0;   // the agent set was announced but not written: a sweep after this failure evaluates no agents
       return rc;
     }
+    return fo_sweep_run_prepped_(ctx, p->M, p->T, p->d_x, p->d_y, p->d_theta, p->d_vel, p->d_acc, p->d_cost, p->d_safe, p->d_pair_f,
+                                 p->d_pair_i, p->d_lists, stream);
   }
   return fo_sweep_run(ctx, p->M, p->T, p->d_x, p->d_y, p->d_theta, p->d_vel, p->d_acc, p->d_cost, p->d_safe, p->d_pair_f,
                       p->d_pair_i, p->d_lists, stream);

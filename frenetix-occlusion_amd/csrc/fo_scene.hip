@@ -28,6 +28,7 @@
 #include <atomic>
 #include <math.h>
 #include "fo_ctx.hpp"
+#include "fo_prep_traj.hpp"
 #include "fo_agent_rows.hpp"
 
 namespace {
@@ -375,9 +376,18 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
                                                                  double *__restrict__ range,
                                                                  int32_t *__restrict__ hit_id, double *__restrict__ ring,
                                                                  int32_t *__restrict__ vis32,
-                                                                 int32_t *__restrict__ n_amb, FanArgs fan) {
+                                                                 int32_t *__restrict__ n_amb, FanArgs fan,
+                                                                 const fo_prep_args_t prep) {
   __shared__ double sh_t[RAY_WAVES];
   __shared__ int sh_id[RAY_WAVES];
+  // Workgroups past the rays and probes (fo_step_run): the sweep's tile table of the candidate trajectories -- independent
+  // of the scene, written while this launch leaves most of the chip idle instead of by a launch of its own before the sweep.
+  if ((int)blockIdx.x >= n_rays + (vis32 ? 5 * O : 0)) {
+    __shared__ double prep_sh[2 * FO_PREP_TZ * (FO_PREP_TILE + 1)];
+    const int e = (int)blockIdx.x - (n_rays + (vis32 ? 5 * O : 0));
+    fo_prep_traj_block(prep, e % prep.n_tiles, (e / prep.n_tiles) & 1, e / (2 * prep.n_tiles), prep_sh);
+    return;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_amb) *n_amb = 0;  // list of undecided cells of this step (grid kernel)
   if ((int)blockIdx.x < n_rays) {
@@ -505,20 +515,32 @@ __device__ __forceinline__ int in_obstacle_skin(int O, const double *__restrict_
 // strictly greater wins, first in loop order).  Beyond the chord between the two end points the obstacle hides nothing.
 // out[3] = (a, b, c): a point lies beyond that chord iff a x + b y + c > 0 (the ego on the other side); a = b = 0, c = -1
 // when there is no such chord (length <= 0 or infinite: shadows without end, or a degenerate view).
-__device__ inline void wedge_far_halfplane(double ex, double ey, const double *__restrict__ c, double length, double *out) {
+// Sixteen consecutive lanes per obstacle (q = lane & 15 = the ordered corner pair i = q >> 2, j = q & 3): one arccos per lane
+// instead of a chain of sixteen; the largest angle with the smallest q among equals = the reference's "strictly greater, first
+// in loop order".  Every lane of the group must call; lane q == 0 writes.
+__device__ inline void wedge_far_halfplane(int q, double ex, double ey, const double *__restrict__ c, double length, double *out) {
+  const bool on = length > 0.0 && length < INFINITY;
+  const int i = q >> 2, j = q & 3;
+  double ang;
+  {
+    const double r1x = c[2 * i] - ex, r1y = c[2 * i + 1] - ey, r2x = c[2 * j] - ex, r2y = c[2 * j + 1] - ey;
+    const double n1 = sqrt(r1x * r1x + r1y * r1y), n2 = sqrt(r2x * r2x + r2y * r2y);
+    const double u1x = r1x / n1, u1y = r1y / n1, u2x = r2x / n2, u2y = r2y / n2;
+    ang = acos(fmin(fmax(u1x * u2x + u1y * u2y, -1.0), 1.0));
+  }
+  // (an angle that is not > 0 -- zero or NaN -- never replaces the initial "none": key -1)
+  double best = ang > 0.0 ? ang : -1.0;
+  int bq = ang > 0.0 ? q : 16;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    const double b2 = __shfl_xor(best, off, 16);
+    const int q2 = __shfl_xor(bq, off, 16);
+    if (b2 > best || (b2 == best && q2 < bq)) { best = b2; bq = q2; }
+  }
+  if (q != 0) return;
   out[0] = 0.0; out[1] = 0.0; out[2] = -1.0;
-  if (!(length > 0.0) || !(length < INFINITY)) return;
-  double best = 0.0;
-  int i1 = -1, i2 = -1;
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) {
-      const double r1x = c[2 * i] - ex, r1y = c[2 * i + 1] - ey, r2x = c[2 * j] - ex, r2y = c[2 * j + 1] - ey;
-      const double n1 = sqrt(r1x * r1x + r1y * r1y), n2 = sqrt(r2x * r2x + r2y * r2y);
-      const double u1x = r1x / n1, u1y = r1y / n1, u2x = r2x / n2, u2y = r2y / n2;
-      const double ang = acos(fmin(fmax(u1x * u2x + u1y * u2y, -1.0), 1.0));
-      if (ang > best) { best = ang; i1 = i; i2 = j; }
-    }
-  if (i1 < 0) return;
+  if (!on || bq >= 16) return;
+  const int i1 = bq >> 2, i2 = bq & 3;
   const double r1x = c[2 * i1] - ex, r1y = c[2 * i1 + 1] - ey, r2x = c[2 * i2] - ex, r2y = c[2 * i2 + 1] - ey;
   const double n1 = sqrt(r1x * r1x + r1y * r1y), n2 = sqrt(r2x * r2x + r2y * r2y);
   const double c4x = c[2 * i1] + r1x / n1 * length, c4y = c[2 * i1 + 1] + r1y / n1 * length;   // c1 + L u(c1 - ego)
@@ -545,10 +567,11 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
                                double *__restrict__ ofar, int n_obst) {
   __shared__ int wsum[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  // where the obstacles' shadows end (read by the settle kernel, the next launch): a thread per obstacle
-  if (ofar && idx < n_obst && ocorn) {
-    if ((oflags[idx] & 1) && (oflags[idx] & 2)) wedge_far_halfplane(ex, ey, ocorn + 8 * (size_t)idx, shadow_length, ofar + 3 * (size_t)idx);
-    else { ofar[3 * idx] = 0.0; ofar[3 * idx + 1] = 0.0; ofar[3 * idx + 2] = -1.0; }
+  // where the obstacles' shadows end (read by the settle kernel, the next launch): sixteen lanes per obstacle
+  if (ofar && ocorn && (idx >> 4) < n_obst) {   // (uniform over each group of sixteen lanes: blocks are multiples of 16)
+    const int o = idx >> 4;
+    if ((oflags[o] & 1) && (oflags[o] & 2)) wedge_far_halfplane(idx & 15, ex, ey, ocorn + 8 * (size_t)o, shadow_length, ofar + 3 * (size_t)o);
+    else if ((idx & 15) == 0) { ofar[3 * o] = 0.0; ofar[3 * o + 1] = 0.0; ofar[3 * o + 2] = -1.0; }
   }
   if (vis && idx < O) {  // obstacle-visibility flags of the probe workgroups (previous launch); self-cleaning
     vis[idx] = vis32[idx] ? 1 : 0;
@@ -1542,7 +1565,8 @@ static int scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head
                             const uint8_t *d_edge_skip, int O, const double *d_ocorn, const double *d_ocen,
                             const uint8_t *d_oflags, int win_ix0, int win_iy0, int win_nx, int win_ny, double *d_range,
                             int32_t *d_hit_id, double *d_ring, uint8_t *d_obst_vis, uint8_t *d_cls, int32_t *d_occ_idx,
-                            int32_t *d_n_occ, void *stream, const FanArgs *fan_in, const SpawnFlagArgs *sf_in) {
+                            int32_t *d_n_occ, void *stream, const FanArgs *fan_in, const SpawnFlagArgs *sf_in,
+                            const fo_prep_args_t *prep_in = nullptr) {
   if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_visibility: call fo_scene_set_map first");
   Scene *sc = (Scene *)ctx->scene;
   sc->cand_flags_ready = false;
@@ -1562,18 +1586,21 @@ static int scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head
   const int cells = win_nx * win_ny;
   if (probes && O > cells) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: more obstacles than window cells");
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
-  const dim3 rgrid(n_rays + (probes ? 5 * O : 0)), rblock(64 * RAY_WAVES);
+  const fo_prep_args_t prep = prep_in ? *prep_in : fo_prep_args_t();
+  const dim3 rgrid(n_rays + (probes ? 5 * O : 0) + prep.blocks()), rblock(64 * RAY_WAVES);
   if (d_edge_skip)
     hipLaunchKernelGGL(fo_rays_kernel<true>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
-                       probes ? sc->d_vis32 : nullptr, sc->d_namb, fan);
+                       probes ? sc->d_vis32 : nullptr, sc->d_namb, fan, prep);
   else
     hipLaunchKernelGGL(fo_rays_kernel<false>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
                        d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
-                       probes ? sc->d_vis32 : nullptr, sc->d_namb, fan);
+                       probes ? sc->d_vis32 : nullptr, sc->d_namb, fan, prep);
   // where the obstacles' shadows end: worked out by the grid kernel (a thread per obstacle), read by the settle kernel
   double *far = nullptr;
   if (exact_cells && O > 0 && sc->shadow_length > 0.0 && sc->shadow_length < INFINITY) {
+    if ((size_t)16 * O > (size_t)(cells + 255) / 256 * 256)
+      return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: more than a sixteenth as many obstacles as window cells");
     if ((rc = fo_reserve(ctx, &sc->d_ofar, &sc->cap_ofar, (size_t)3 * O))) return rc;
     far = sc->d_ofar;
   }
@@ -1708,7 +1735,7 @@ int fo_scene_rule_agents_(fo_ctx *ctx, int max_points, const double *d_points, c
                           double *d_v, double *d_cov, double *d_shape, double *d_raw_dims, int32_t *d_type, int32_t *d_len,
                           void *stream, const fo_agent_table_t *at);   // fo_spawn_rules.hpp
 
-int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, void *stream) {
+int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, const fo_prep_args_t *prep, void *stream) {
   if (!ctx || !p) return FO_E_ARG;
   if (p->n_rays < 4 || !p->d_dirs || !(p->r > 0) || !(p->fov_deg > 0)) return fo_fail(ctx, FO_E_ARG, "fo_scene_fan: bad arguments");
   const bool cells = p->spawn_mode != FO_SPAWN_RULES, rules = p->spawn_mode != FO_SPAWN_CELLS;
@@ -1722,7 +1749,7 @@ int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, 
   if ((rc = scene_visibility(ctx, p->ego_x, p->ego_y, p->head_x, p->head_y, p->r, p->full_circle, p->exact_cells, p->n_rays, p->d_dirs,
                              p->d_rmax, p->d_half, p->d_edge_skip, p->O, p->d_ocorn, p->d_ocen, p->d_oflags, p->win_ix0, p->win_iy0,
                              p->win_nx, p->win_ny, p->d_range, p->d_hit_id, p->d_ring, p->d_obst_vis, p->d_cls, p->d_occ_idx,
-                             p->d_n_occ, stream, &fan, cells ? &sf : nullptr))) return rc;
+                             p->d_n_occ, stream, &fan, cells ? &sf : nullptr, prep))) return rc;
   if (cells && (rc = scene_spawn(ctx, p->d_cls, p->win_ix0, p->win_iy0, p->win_nx, p->win_ny, p->ego_x, p->ego_y, p->head_x, p->head_y,
                                  p->min_ahead, p->max_dist, p->all_occluded, p->max_agents, p->routes, p->type4, p->speed4, p->raw_l4,
                                  p->raw_w4, p->infl_l4, p->infl_w4, p->n_path, p->d_path, p->T_agents, p->dt, p->var0, p->var_factor,

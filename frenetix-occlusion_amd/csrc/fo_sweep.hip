@@ -19,11 +19,13 @@
 #include <type_traits>
 #include "fo_ctx.hpp"
 #include "fo_agent_rows.hpp"
+#include "fo_prep_traj.hpp"
 
 namespace {
 
 constexpr int TILE = 64;   // trajectories per wave
 constexpr int WAVES = 4;   // waves per workgroup
+static_assert(TILE == FO_PREP_TILE, "fo_prep_traj.hpp");
 constexpr int NEF = 8;     // ego fields per (t, trajectory): x, y, cos, sin, theta, v, v cos, v sin -- stored as four
                            // pairs per trajectory, [t][pair][trajectory][2]: one 16-byte load per lane fetches two
                            // fields (a vector-memory instruction costs the CU ~10 cycles whatever its width)
@@ -206,57 +208,9 @@ __device__ __forceinline__ double fo_round3_fast(double v) { return fo_div1000(_
 // HBM read (along T) and the HBM write (along trajectories) are contiguous; sincos(theta) is taken once here.
 // Within a tile every (t, field) row is 512 contiguous bytes = one wave-wide load, and field / timestep strides
 // are compile-time constants (immediate offsets in the sweep's loads).
-__global__ __launch_bounds__(256) void fo_prep_traj_kernel(int M, int T, int tz, const double *__restrict__ x,
-                                                           const double *__restrict__ y,
-                                                           const double *__restrict__ th,
-                                                           const double *__restrict__ v, double *__restrict__ tab,
-                                                           int *__restrict__ chunk_tab, int n_chunks, int wpb, int n0, int n1,
-                                                           int n2, int a0, int a1, int a2, int a3) {
+__global__ __launch_bounds__(256) void fo_prep_traj_kernel(const fo_prep_args_t p) {
   extern __shared__ double sh[];  // [2][tz][TILE+1]
-  // the chunk table of the sweep launch that follows on this stream (SweepArgs::chunk_tab): phases of n0 / n1 / n2 / the
-  // remaining chunks with a0 / a1 / a2 / a3 agents per wave
-  if (chunk_tab && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-    for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) {
-      int k0, ap;
-      if (c < n0) { ap = a0; k0 = c * a0; }
-      else if (c < n0 + n1) { ap = a1; k0 = n0 * a0 + (c - n0) * a1; }
-      else if (c < n0 + n1 + n2) { ap = a2; k0 = n0 * a0 + n1 * a1 + (c - n0 - n1) * a2; }
-      else { ap = a3; k0 = n0 * a0 + n1 * a1 + n2 * a2 + (c - n0 - n1 - n2) * a3; }
-      chunk_tab[2 * c] = k0 * wpb;
-      chunk_tab[2 * c + 1] = ap;
-    }
-  const int m0 = blockIdx.x * TILE;
-  const int n = min(TILE, M - m0);
-  const int ld = TILE + 1;
-  const int f = blockIdx.y;  // 0: positions (x, y); 1: heading and speed -> (cos, sin), (theta, v), (v cos, v sin)
-  const int t0 = blockIdx.z * tz, nt = min(tz, T - t0);   // this block's slice of the horizon (latency: short blocks)
-  if (nt <= 0) return;
-  const double *s0 = (f == 0 ? x : th) + (size_t)m0 * T + t0, *s1 = (f == 0 ? y : v) + (size_t)m0 * T + t0;
-  double *sh1 = sh + (size_t)tz * ld;
-  for (int i = threadIdx.x; i < n * nt; i += blockDim.x) {
-    const int ml = i / nt, tl = i - ml * nt;
-    sh[tl * ld + ml] = s0[(size_t)ml * T + tl];
-    sh1[tl * ld + ml] = s1[(size_t)ml * T + tl];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < nt * TILE; i += blockDim.x) {
-    const int tl = i / TILE, ml = i % TILE;
-    const int src = tl * ld + min(ml, n - 1);  // pad lanes replicate the last trajectory of the tile
-    const double a0 = sh[src], a1 = sh1[src];
-    fo_d2 *dst = (fo_d2 *)(tab + ((size_t)blockIdx.x * T + t0 + tl) * NEF * TILE) + ml;  // pair p of lane ml: dst[p * TILE]
-    if (f == 0) {
-      dst[0 * TILE] = fo_d2{a0, a1};
-    } else {
-      double sn, cs;
-      sincos(a0, &sn, &cs);
-      // (speeds beyond 5 km/s are capped in the velocity components the harm model reads: the relative speed then stays
-      // below 1e4 m/s, inside the range of the sweep's table exp, without a clamp per sample)
-      const double vc = fmin(fmax(a1, -5.0e3), 5.0e3);
-      dst[1 * TILE] = fo_d2{cs, sn};
-      dst[2 * TILE] = fo_d2{a0, a1};
-      dst[3 * TILE] = fo_d2{vc * cs, vc * sn};
-    }
-  }
+  fo_prep_traj_block(p, blockIdx.x, blockIdx.y, blockIdx.z, sh);   // fo_prep_traj.hpp
 }
 
 // agent predictions -> [A][Ta][NAF] table + [A][NAC] constants (one thread per (k, t); fo_agent_rows.hpp)
@@ -908,8 +862,8 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
   bool w_dce_flag = false;
 
   // agents of this wave: chunk -> (first agent, agents per wave), see SweepArgs::chunk_tab
-  const int apw_ = SPLIT ? 1 : fo_const(a.chunk_tab)[2 * chunk + 1];
-  const int k0 = SPLIT ? chunk : fo_const(a.chunk_tab)[2 * chunk] + wave * apw_;
+  const int apw_ = SPLIT ? a.apw : fo_const(a.chunk_tab)[2 * chunk + 1];   // SPLIT: agents per WORKGROUP, one after the other
+  const int k0 = SPLIT ? chunk * a.apw : fo_const(a.chunk_tab)[2 * chunk] + wave * apw_;
   // the samples this wave owns: everything, or time chunk `wave` of the agent the workgroup shares
   const int seg0 = SPLIT ? wave * TC : 0, seg1 = SPLIT ? min(seg0 + TC, a.T) : a.T;
   const int gfirst_ = max(seg0 - 1, 0);  // first harm / cp sample this wave evaluates for an agent
@@ -1558,7 +1512,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         sp[8 * TILE] = (double)idx_cp; sp[9 * TILE] = oh_at_cp;
       }
       __syncthreads();
-      if (wave > 0) continue;
+      if (wave == 0)
       for (int w = 1; w < QWAVES; ++w) {
         const double *sp = cpbuf_all + w * (WROWS * TILE) + lane;
         const double d_w = sp[0 * TILE];
@@ -1570,6 +1524,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         max_oh = fmax(max_oh, sp[6 * TILE]);
         if (sp[7 * TILE] > max_cp) { max_cp = sp[7 * TILE]; idx_cp = (int)sp[8 * TILE]; oh_at_cp = sp[9 * TILE]; }
       }
+      // more agents to come: the other waves' rows are theirs again once wave 0 has read them
+      if (kk + 1 < apw_ && k + 1 < A) __syncthreads();
+      if (wave > 0) continue;
     }
     // ------------------------------------------------------------------ per-pair scalars
     const double dce_m = (dce < INFINITY) ? fo_div1000(dce) : dce;                          // np.round(d, 3)
@@ -2082,9 +2039,16 @@ int fo_sweep_set_agents(fo_ctx *ctx, int A, int Ta, const double *d_pos, const d
   return FO_OK;
 }
 
-int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
-                 const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
-                 int32_t *d_pair_i, double *d_lists, void *stream) {
+}  // extern "C"
+
+namespace {
+// fo_sweep_run.  plan_only: everything up to the first launch -- argument checks, the grid plan, the work buffers -- and
+// *plan_only = what the tile-table launch would have been given (fo_step_run hands it to the scene stage's ray kernel, whose
+// extra workgroups write the table); prepped: that has happened on this stream, skip the launch.
+int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
+              const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
+              int32_t *d_pair_i, double *d_lists, void *stream, fo_prep_args_t *plan_only, bool prepped) {
+  if (plan_only) *plan_only = fo_prep_args_t();
   if (!ctx) return FO_E_ARG;
   if (!ctx->configured) return fo_fail(ctx, FO_E_STATE, "fo_sweep_run: call fo_sweep_configure first");
   if (M < 0 || T < 1 || (M > 0 && (!d_x || !d_y || !d_theta || !d_v || !d_cost || !d_safe)))
@@ -2097,7 +2061,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   const int A = ctx->A, Ta = ctx->Ta;
-  if (d_lists && A > 0 && T > 1 && !(ctx->mask & (FO_M_CP | FO_M_HR)))  // nothing will write them: all-ones = NaN
+  if (!plan_only && d_lists && A > 0 && T > 1 && !(ctx->mask & (FO_M_CP | FO_M_HR)))  // nothing will write them: all-ones = NaN
     FO_HIP_TRY(ctx, hipMemsetAsync(d_lists, 0xFF, (ctx->list_format != FO_LISTS_F64 ? sizeof(float) : sizeof(double)) *
                                                      FO_NL * (size_t)A * (T - 1) * M, s));
   const int Mp = round_up(M, TILE);
@@ -2126,12 +2090,19 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   bool split = use_queue && T <= QWAVES * TC && (long)n_tiles * A < 3072;
   if (const char *e = getenv("FO_SWEEP_SPLIT")) split = use_queue && T <= QWAVES * TC && e[0] == '1';  // tests, A/B runs
   if (lst_mode == LST_F32X) split = false;
-  if (split) apw = 1;
+  if (split) {
+    // agents per workgroup of the horizon-split form, one after the other: 1.  (Measured on 2 000 x 32, 1 024 (tile, agent)
+    // pairs on 768 resident workgroups: 2 / 3 / 4 agents per workgroup -- one round instead of two -- take 64 / 56 / 81 us
+    // against 39: the launch lasts as long as its heaviest workgroup, the agents next to the candidates' path, and those
+    // come in pairs.  FO_SWEEP_SPLIT_APW: tests, A/B runs.)
+    apw = 1;
+    if (const char *e = getenv("FO_SWEEP_SPLIT_APW")) { const int v = atoi(e); if (v >= 1 && v <= 16) apw = v; }
+  }
   // Tapered grid (queue kernel, grids beyond one round of the chip): agents per wave halve from phase to phase down to
   // one -- see SweepArgs::ph_n.  f[]: fraction of the agents per phase; FO_SWEEP_TAPER="f0,f1,f2" overrides them
   // ("0" = no taper), a tuning aid.
   int ph_n[3] = {0, 0, 0}, ph_a[4] = {apw, apw, apw, apw};
-  int n_chunks = A > 0 ? (split ? A : (A + wpb * apw - 1) / (wpb * apw)) : 0;
+  int n_chunks = A > 0 ? (split ? (A + apw - 1) / apw : (A + wpb * apw - 1) / (wpb * apw)) : 0;
   ph_n[0] = n_chunks;   // one phase unless tapered below
   if (use_queue && !split && apw >= 2 && A > 0) {
     double f[3] = {0.85, 0.10, 0.0};
@@ -2168,11 +2139,17 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
   }
 
   if (A > 0) {
-    const int tz = T > 8 ? 8 : T;   // horizon slice per block
-    hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 2, (T + tz - 1) / tz), dim3(256),
-                       (size_t)2 * tz * (TILE + 1) * sizeof(double), s, M, T, tz, d_x, d_y, d_theta, d_v, ctx->d_traj_tab,
-                       ctx->d_chunk_tab, n_chunks, wpb, ph_n[0], ph_n[1], ph_n[2], ph_a[0], ph_a[1], ph_a[2], ph_a[3]);
-    FO_HIP_TRY(ctx, hipGetLastError());
+    const int tz = T > FO_PREP_TZ ? FO_PREP_TZ : T;   // horizon slice per block
+    fo_prep_args_t pa;
+    pa.on = 1; pa.M = M; pa.T = T; pa.tz = tz; pa.n_tiles = n_tiles; pa.nz = (T + tz - 1) / tz;
+    pa.x = d_x; pa.y = d_y; pa.th = d_theta; pa.v = d_v; pa.tab = ctx->d_traj_tab; pa.chunk_tab = ctx->d_chunk_tab;
+    pa.n_chunks = n_chunks; pa.wpb = wpb; pa.n0 = ph_n[0]; pa.n1 = ph_n[1]; pa.n2 = ph_n[2];
+    pa.a0 = ph_a[0]; pa.a1 = ph_a[1]; pa.a2 = ph_a[2]; pa.a3 = ph_a[3];
+    if (plan_only) { *plan_only = pa; return FO_OK; }
+    if (!prepped) {
+      hipLaunchKernelGGL(fo_prep_traj_kernel, dim3(n_tiles, 2, pa.nz), dim3(256), (size_t)2 * tz * (TILE + 1) * sizeof(double), s, pa);
+      FO_HIP_TRY(ctx, hipGetLastError());
+    }
     SweepArgs a{};
     a.M = M; a.Mp = Mp; a.T = T; a.A = A; a.Ta = Ta; a.n_tiles = n_tiles; a.nt8 = (n_tiles + 7) / 8; a.apw = apw;
     a.chunk_tab = ctx->d_chunk_tab;
@@ -2230,6 +2207,7 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
     }
 #endif
   }
+  if (plan_only) return FO_OK;   // (no agents: nothing to prepare)
   const double *be_btn = nullptr;
   if (do_be && A > 0 && T >= 1) {
     double *dist = ctx->d_be_dist, *mina = ctx->d_be_dist + (size_t)T * Mp;
@@ -2244,6 +2222,30 @@ int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y
                      ctx->thr, ctx->mask, be_btn, d_cost, d_safe, ctx->d_status, ctx->status_gen);
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fo_sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
+                 const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
+                 int32_t *d_pair_i, double *d_lists, void *stream) {
+  return sweep_run(ctx, M, T, d_x, d_y, d_theta, d_v, d_a, d_cost, d_safe, d_pair_f, d_pair_i, d_lists, stream, nullptr, false);
+}
+
+// the two halves of fo_sweep_run for the fused planning step (fo_step_run, fo_api.hip): plan -> *prep; [the scene stage writes
+// the tile table] -> run without the table launch
+int fo_sweep_plan_(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
+                   const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
+                   int32_t *d_pair_i, double *d_lists, void *stream, fo_prep_args_t *prep) {
+  if (!prep) return FO_E_ARG;
+  return sweep_run(ctx, M, T, d_x, d_y, d_theta, d_v, d_a, d_cost, d_safe, d_pair_f, d_pair_i, d_lists, stream, prep, false);
+}
+int fo_sweep_run_prepped_(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, const double *d_theta,
+                          const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
+                          int32_t *d_pair_i, double *d_lists, void *stream) {
+  return sweep_run(ctx, M, T, d_x, d_y, d_theta, d_v, d_a, d_cost, d_safe, d_pair_f, d_pair_i, d_lists, stream, nullptr, true);
 }
 
 // Per-shape choice of the sweep kernel's agents-per-wave, measured on the caller's own batch (include/fo_hip.h).

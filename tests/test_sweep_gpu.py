@@ -727,14 +727,18 @@ def test_horizon_split_variant_is_bit_identical(torch_cuda, monkeypatch):
         agents["len"] = rng.integers(0, T + 1, A).astype(np.int32)
         agents["type"] = rng.integers(0, 11, A).astype(np.int32)
         outs = []
-        for flag in ("1", "0"):
+        # (FO_SWEEP_SPLIT_APW: agents a workgroup of the split form takes one after the other -- 1 unless set; a ragged last
+        # workgroup with 3 and 5)
+        for flag, per_wg in (("1", "1"), ("0", "1"), ("1", "2"), ("1", "3"), ("1", "5")):
             monkeypatch.setenv("FO_SWEEP_SPLIT", flag)
+            monkeypatch.setenv("FO_SWEEP_SPLIT_APW", per_wg)
             outs.append(_hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.2, "risk": 0.1, "ttc": 1.0}))
             red = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.2, "risk": 0.1, "ttc": 1.0},
                              mode="reduced")
             assert np.array_equal(red["cost"], outs[-1]["cost"], equal_nan=True) and np.array_equal(red["safe"], outs[-1]["safe"])
-        for k in ("cost", "safe", "pair_f", "pair_i", "lists"):
-            assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (M, A, T, k)
+        for o in outs[1:]:
+            for k in ("cost", "safe", "pair_f", "pair_i", "lists"):
+                assert np.array_equal(outs[0][k], o[k], equal_nan=True), (M, A, T, k)
 
 
 def test_correlated_covariances_against_the_oracle_and_the_diagonal_limit(torch_cuda, oracle):
