@@ -1169,12 +1169,15 @@ struct PredOut {
 __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool on, double p0x, double p0y, double a0,
                                                  int atype, double spd, double raw_l, double raw_w, double infl_l,
                                                  double infl_w, int ll, const RouteView &rv, int T, double dt, double var0,
-                                                 double factor, const PredOut &o, int table_on, const fo_agent_table_t &at) {
+                                                 double factor, const PredOut &o, int table_on, const fo_agent_table_t &at, double vpow) {
   double *P = o.pos + (size_t)slot * T * 2, *Y = o.yaw + (size_t)slot * T, *V = o.v + (size_t)slot * T;
   double *C = o.cov + (size_t)slot * T * 4;
+  // (what lane k < 64 writes for sample k, kept for the table rows at the end: r_*)
+  double r_var = 0.0, r_px = 0.0, r_py = 0.0, r_yaw = 0.0, r_v = 0.0;
   for (int k = lane; k < T; k += 64) {
-    const double var = var0 * pow(factor, (double)k);  // agent.py:273
+    const double var = var0 * (k == lane ? vpow : pow(factor, (double)k));  // agent.py:273; vpow = pow(factor, lane), worked out by the caller
     C[4 * k] = var; C[4 * k + 1] = 0.0; C[4 * k + 2] = 0.0; C[4 * k + 3] = var;
+    if (k == lane) r_var = var;
   }
   if (lane == 0) {
     o.shape[2 * slot] = infl_l; o.shape[2 * slot + 1] = infl_w;
@@ -1190,15 +1193,29 @@ __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool
     const double vy = __builtin_rint(spd * sin(a) * 1000.0) / 1000.0;
     for (int k = lane; k < T; k += 64) {
       const double t = (double)k * dt;
-      P[2 * k] = p0x + t * vx; P[2 * k + 1] = p0y + t * vy; Y[k] = a; V[k] = spd;
+      const double x_ = p0x + t * vx, y_ = p0y + t * vy;
+      P[2 * k] = x_; P[2 * k + 1] = y_; Y[k] = a; V[k] = spd;
+      if (k == lane) { r_px = x_; r_py = y_; r_yaw = a; r_v = spd; }
     }
     L = T;
   } else if (routed && rv.count[(size_t)ll * RT + r] >= 2) {
     const int nv = rv.count[(size_t)ll * RT + r];
-    const double *q = rv.xy + 2 * (size_t)rv.first[(size_t)ll * RT + r];
-    const double *sq = rv.s + rv.first[(size_t)ll * RT + r];
+    const double *qg = rv.xy + 2 * (size_t)rv.first[(size_t)ll * RT + r];
+    const double *sg = rv.s + rv.first[(size_t)ll * RT + r];
+    // a route of up to ROUTE_LDS vertices is read once, into LDS: the per-sample binary search below is then a chain of LDS
+    // reads instead of global ones (the kernel is one chain of dependent round trips; this one had six links)
+    constexpr int ROUTE_LDS = 256;
+    __shared__ double rt_q[2 * ROUTE_LDS], rt_s[ROUTE_LDS];
+    const bool staged = nv <= ROUTE_LDS;
+    if (staged) {
+      for (int i = lane; i < nv; i += 64) { rt_q[2 * i] = qg[2 * i]; rt_q[2 * i + 1] = qg[2 * i + 1]; rt_s[i] = sg[i]; }
+      __syncthreads();
+    }
     const double px = p0x, py = p0y;
-    double best = INFINITY, s0 = 0.0, d0 = 0.0;
+    double s0 = 0.0, d0 = 0.0, d1 = -0.5, s_end = 0.0;
+    const double t1 = 3.0;
+    auto follow = [&](const double *q, const double *sq) {
+    double best = INFINITY;
     int bi = 0x7fffffff;
     for (int i = lane; i + 1 < nv; i += 64) {  // closest point of the route: per lane ascending i, first minimum
       const double ax = q[2 * i], ay = q[2 * i + 1], ex = q[2 * i + 2] - ax, ey = q[2 * i + 3] - ay;
@@ -1223,11 +1240,10 @@ __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool
     }
     // the Frenet sample the reference keeps (agent.py:349-379 on the nine samples of frenetix_handler.py:82-105): end speed
     // v0, lateral target d1 = the one of {-0.5, 0, 0.5} nearest to d0 (first of equally near ones), quintic d(t) over 3 s
-    double d1 = -0.5;
+    d1 = -0.5;
     if (fabs(0.0 - d0) < fabs(d1 - d0)) d1 = 0.0;
     if (fabs(0.5 - d0) < fabs(d1 - d0)) d1 = 0.5;
-    const double t1 = 3.0;
-    const double s_end = sq[nv - 1];
+    s_end = sq[nv - 1];
     for (int k = lane; k < T; k += 64) {
       const double tk = (double)k * dt, sk = s0 + spd * tk;
       if (sk > s_end) continue;
@@ -1242,11 +1258,14 @@ __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool
       const double tau = tk < t1 ? tk / t1 : 1.0;
       const double dk = d0 + (d1 - d0) * (tau * tau * tau * (10.0 + tau * (-15.0 + 6.0 * tau)));
       const double dd = (d1 - d0) * (30.0 * tau * tau * (1.0 + tau * (-2.0 + tau))) / t1;
-      P[2 * k] = q[2 * m] + loc * ux + dk * (-uy);
-      P[2 * k + 1] = q[2 * m + 1] + loc * uy + dk * ux;
-      Y[k] = atan2(uy, ux) + atan2(dd, spd);
-      V[k] = sqrt(spd * spd + dd * dd);
+      const double x_ = q[2 * m] + loc * ux + dk * (-uy), y_ = q[2 * m + 1] + loc * uy + dk * ux;
+      const double yw_ = atan2(uy, ux) + atan2(dd, spd), v_ = sqrt(spd * spd + dd * dd);
+      P[2 * k] = x_; P[2 * k + 1] = y_; Y[k] = yw_; V[k] = v_;
+      if (k == lane) { r_px = x_; r_py = y_; r_yaw = yw_; r_v = v_; }
     }
+    };
+    if (staged) follow(rt_q, rt_s);
+    else follow(qg, sg);
     // number of samples on the route: sk is non-decreasing in k, so the valid samples are a prefix
     int cnt = 0;
     for (int k = 0; k < T; ++k) cnt += (s0 + spd * ((double)k * dt) > s_end) ? 0 : 1;
@@ -1255,7 +1274,15 @@ __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool
   for (int k = lane; k < T; k += 64)
     if (k >= L) { P[2 * k] = 0.0; P[2 * k + 1] = 0.0; Y[k] = 0.0; V[k] = 0.0; }
   if (lane == 0) o.len[slot] = L;
-  if (table_on) {
+  if (table_on && T <= 64) {
+    // the slot's rows of the sweep's agent table from the values just written, a lane per sample (no read-back through
+    // memory, one atomic for the agent's longest step)
+    fo_agent_sample_t q;
+    q.px = r_px; q.py = r_py; q.ppx = __shfl_up(r_px, 1); q.ppy = __shfl_up(r_py, 1); q.yaw = r_yaw; q.v = r_v;
+    q.sxx = r_var; q.sxy = 0.0; q.syx = 0.0; q.syy = r_var;
+    fo_agent_row_core<true>(lane < T, slot, lane, T, L, q, infl_l, infl_w, raw_l, raw_w, atype, at.ego_mass, at.hlA, at.hwA, at.hc, at.tab,
+                            at.cst, at.aint, at.status, at.gen);
+  } else if (table_on) {
     __threadfence_block();
     __syncthreads();
     for (int k = lane; k < T; k += 64)
@@ -1277,6 +1304,9 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
   const int slot = blockIdx.x, j = slot / R, r = slot % R;
   // the pick of agent j (repeated by each of its R route slots: a few dozen path segments; saves a launch)
   const int n_c = *n_cand;
+  // (the covariance growth factor of this lane's sample: a page of arithmetic with no input from memory -- here, under the
+  // first round trip of the chain that follows)
+  const double vpow = pow(factor, (double)lane);
   int ci;
   double p0x, p0y, a0;
   const bool on = spawn_pick(j, lane, cand, n_c, nx, rx0, ry0, cs, ix0, iy0, max_agents, st, n_path, path, lane_yaw, rnx,
@@ -1292,7 +1322,7 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
     if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny) ll = lanelet_raster[(size_t)wy * rnx + wx];
   }
   spawn_write_slot(lane, slot, r, on, p0x, p0y, a0, st.type[sdx], st.speed[sdx], st.raw_l[sdx], st.raw_w[sdx], st.infl_l[sdx],
-                   st.infl_w[sdx], ll, rv, T, dt, var0, factor, o, table_on, at);
+                   st.infl_w[sdx], ll, rv, T, dt, var0, factor, o, table_on, at, vpow);
 }
 
 int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {

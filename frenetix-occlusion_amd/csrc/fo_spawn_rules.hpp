@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(64) void fo_spawn_rule_predict_kernel(
   const int lane = threadIdx.x;
   const int i = blockIdx.x / R, r = blockIdx.x % R, slot = slot0 + blockIdx.x;
   const int n = min(max(*n_points, 0), max_points);
+  const double vpow = pow(factor, (double)lane);   // (spawn_write_slot; here: under the first round trip)
   const bool on = i < n;
   const double *rec = points + 8 * (size_t)i;
   const int type = on ? (int)rec[0] : RL_TYPE_PED;
@@ -1076,7 +1077,7 @@ __global__ __launch_bounds__(64) void fo_spawn_rule_predict_kernel(
   }
   if (r == 0 && lane == 0) { pos0[2 * (agent0 + i)] = px; pos0[2 * (agent0 + i) + 1] = py; yaw0[agent0 + i] = a0; }
   spawn_write_slot(lane, slot, r, on, px, py, a0, type, ty.speed[ti], ty.raw_l[ti], ty.raw_w[ti], ty.infl_l[ti], ty.infl_w[ti], ll, rv, T,
-                   dt, var0, factor, o, table_on, at);
+                   dt, var0, factor, o, table_on, at, vpow);
 }
 
 }  // namespace
