@@ -359,7 +359,9 @@ def small_batch_step(local_rank, steps=300):
     # three timed runs, the median reported: at 0.09 ms per step the host thread that issues the step matters, and its
     # cores are shared with whatever else runs on the box (all three runs are in `ms_per_step_runs`)
     runs = []
-    sw.ctx.timing(True)
+    # (HIP events around every 16th sweep launch: an event record is a barrier packet of its own -- around every launch
+    # the two records cost 6 us of the 80 us step, measured with FO_BENCH_TIME_EVERY_SMALL=1 / 1000)
+    sw.ctx.timing(True, every=int(os.environ.get("FO_BENCH_TIME_EVERY_SMALL", "16")))
     for _ in range(3):
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -480,7 +482,7 @@ def shard_probe(scene, sw, tensors, local_rank, N, steps=200):
             for _ in range(40):
                 ps.run(ego[:2], float(ego[2]), float(ego[3]))
             torch.cuda.synchronize()
-            sw.ctx.timing(True)
+            sw.ctx.timing(True, every=4)
             t0 = time.perf_counter()
             for _ in range(steps):
                 ps.run(ego[:2], float(ego[2]), float(ego[3]))
@@ -690,8 +692,12 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP events around the sweep kernel of every timed step (FO_BENCH_TIME_EVERY=k: every k-th; measured: no gain)
-    sw.ctx.timing(True, every=int(os.environ.get("FO_BENCH_TIME_EVERY", "1")))
+    # HIP events around the sweep kernel of every 4th timed step (FO_BENCH_TIME_EVERY=k): the two event records of a launch
+    # are barrier packets of their own and cost the step ~6 us (1 % here, 7 % at the reference's own size, small_batch_step)
+    time_every = int(os.environ.get("FO_BENCH_TIME_EVERY", "4"))
+    if args.steps < 4 * time_every:
+        time_every = 1
+    sw.ctx.timing(True, every=time_every)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(res=out)
@@ -790,7 +796,7 @@ def main():
                                              "scalars (+ 600 B lists in full mode); 64 B/trajectory in reduced mode",
                          "algorithmic_bytes_per_launch": a8d, "stored_bytes_per_launch": ast,
                          "achieved_stored": ast / kern_s / 1e9, "frac_stored_bytes": ast / kern_s / 1e9 / HBM_PEAK_GBS,
-                         "kernel_ms": kern_s * 1e3, "launches_timed": kern_n,
+                         "kernel_ms": kern_s * 1e3, "launches_timed": kern_n, "timed_every": time_every,
                          "kernel_ms_p50": float(np.percentile(kern_each, 50)) if kern_each else None,
                          "kernel_ms_p95": float(np.percentile(kern_each, 95)) if kern_each else None,
                          "grid": launch["grid"], "block": launch["block"],
@@ -815,7 +821,7 @@ def main():
                 for _ in range(60):
                     r = step(mode, lists, r)
                 torch.cuda.synchronize()
-                sw.ctx.timing(True)
+                sw.ctx.timing(True, every=4)
                 t_r = time.perf_counter()
                 for _ in range(n):
                     r = step(mode, lists, r)

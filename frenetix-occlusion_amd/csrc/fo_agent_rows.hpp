@@ -58,7 +58,8 @@ __device__ __forceinline__ void fo_agent_row_core(bool valid, int k, int t, int 
                                                   double shape_l, double shape_w, double raw_l, double raw_w, int type,
                                                   double ego_mass, double hlA, double hwA, const fo_harm_coeff_t &hc,
                                                   double *__restrict__ tab, double *__restrict__ cst,
-                                                  int32_t *__restrict__ aint, int *__restrict__ status, int gen) {
+                                                  int32_t *__restrict__ aint, int *__restrict__ status, int gen,
+                                                  double m_obs_known = -1.0) {
 #pragma clang fp contract(off)
   unsigned long long key = 0ull;
   if (valid) {
@@ -86,7 +87,7 @@ __device__ __forceinline__ void fo_agent_row_core(bool valid, int k, int t, int 
   double *o = tab + i * NAF;
   o[0] = q.px; o[1] = q.py; o[2] = cs; o[3] = sn; o[4] = q.yaw; o[5] = q.v;
   const double vc = fmin(fmax(q.v, -5.0e3), 5.0e3);   // (see fo_prep_traj_kernel)
-  o[6] = isx; o[7] = isy; o[8] = vc * cs; o[9] = vc * sn; o[10] = rho; o[11] = asin(rho);
+  o[6] = isx; o[7] = isy; o[8] = vc * cs; o[9] = vc * sn; o[10] = rho; o[11] = rho == 0.0 ? rho : asin(rho);   // (asin(+-0) = +-0)
   // Coarse gate test of the sweep: the gate of sample t-1 takes the ego reference point of sample t against the agent
   // mean of sample t-1; the sweep tests the distance it has anyway -- shifted ego centre t to agent mean t -- against
   // 5 m + half the inflated length (c[14]) + the longest step of the agent's mean + the centre shift:
@@ -101,7 +102,9 @@ __device__ __forceinline__ void fo_agent_row_core(bool valid, int k, int t, int 
   }
   if (!WAVE_KEY && key) atomicMax((unsigned long long *)(cst + (size_t)k * NAC + 15), key);
   if (t == 0) {
-    const double m_obs = fo_obstacle_mass(type, shape_l * shape_w);  // inflated footprint (Q8)
+    // inflated footprint (Q8); m_obs_known: the caller has worked it out already (the same call, earlier: a single wave's
+    // dependent float64 chain is what a prediction workgroup's time consists of)
+    const double m_obs = m_obs_known >= 0.0 ? m_obs_known : fo_obstacle_mass(type, shape_l * shape_w);
     double *c = cst + (size_t)k * NAC;
     c[0] = 0.5 * raw_l; c[1] = 0.5 * raw_w; c[2] = shape_l / 2.0;
     c[3] = m_obs / (ego_mass + m_obs); c[4] = ego_mass / (ego_mass + m_obs);

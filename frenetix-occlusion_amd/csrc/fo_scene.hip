@@ -1105,10 +1105,14 @@ __device__ __forceinline__ double heading_to_curve(int lane, int N, const double
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {                    // across lanes: smallest (d2, i) = first minimum
-    const double b2 = __shfl_xor(best, off), x2 = __shfl_xor(qx, off), y2 = __shfl_xor(qy, off);
+    const double b2 = __shfl_xor(best, off);
     const int i2 = __shfl_xor(bi, off);
-    if (b2 < best || (b2 == best && i2 < bi)) { best = b2; qx = x2; qy = y2; bi = i2; }
+    if (b2 < best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
   }
+  // (the winner's closest point from the lane that holds it -- segment i lives in lane i mod 64 -- instead of carrying it
+  // through the six exchange steps)
+  qx = __shfl(qx, bi & 63);
+  qy = __shfl(qy, bi & 63);
   const double vx = qx - px, vy = qy - py;
   const double nn = sqrt(vx * vx + vy * vy);
   double ux = 1.0, uy = 0.0;
@@ -1118,6 +1122,15 @@ __device__ __forceinline__ double heading_to_curve(int lane, int N, const double
   return a;
 }
 
+#ifndef FO_PRED_TRACE
+#define FO_PRED_TRACE 0   // tuning builds: wall-clock stamps of one prediction workgroup's phases (fo_debug_pred_ticks, tools/pred_trace.py)
+#endif
+#if FO_PRED_TRACE
+__device__ long long g_pred_ticks[16];
+#define PRED_TICK(i) do { if (blockIdx.x == FO_PRED_TRACE && threadIdx.x == 0) g_pred_ticks[i] = wall_clock64(); } while (0)
+#else
+#define PRED_TICK(i) do { } while (0)
+#endif
 // evenly spaced pick of the candidates + heading per phantom: pedestrians -> unit vector to the closest point of the
 // ego reference path (agent.py:475-481 + helper_functions.py:38-76); vehicles -> lane heading raster at their cell
 // Phantom slot j of the step (the whole wave calls this; every result is wave-uniform): which candidate cell it takes
@@ -1169,7 +1182,7 @@ struct PredOut {
 __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool on, double p0x, double p0y, double a0,
                                                  int atype, double spd, double raw_l, double raw_w, double infl_l,
                                                  double infl_w, int ll, const RouteView &rv, int T, double dt, double var0,
-                                                 double factor, const PredOut &o, int table_on, const fo_agent_table_t &at, double vpow) {
+                                                 double factor, const PredOut &o, int table_on, const fo_agent_table_t &at, double vpow, double m_obs) {
   double *P = o.pos + (size_t)slot * T * 2, *Y = o.yaw + (size_t)slot * T, *V = o.v + (size_t)slot * T;
   double *C = o.cov + (size_t)slot * T * 4;
   // (what lane k < 64 writes for sample k, kept for the table rows at the end: r_*)
@@ -1234,10 +1247,12 @@ __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {  // across lanes: smallest (d2, i)
-      const double b2 = __shfl_xor(best, off), s2 = __shfl_xor(s0, off), dd2 = __shfl_xor(d0, off);
+      const double b2 = __shfl_xor(best, off);
       const int i2 = __shfl_xor(bi, off);
-      if (b2 < best || (b2 == best && i2 < bi)) { best = b2; bi = i2; s0 = s2; d0 = dd2; }
+      if (b2 < best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
     }
+    s0 = __shfl(s0, bi & 63);   // (from the lane that holds the winning segment)
+    d0 = __shfl(d0, bi & 63);
     // the Frenet sample the reference keeps (agent.py:349-379 on the nine samples of frenetix_handler.py:82-105): end speed
     // v0, lateral target d1 = the one of {-0.5, 0, 0.5} nearest to d0 (first of equally near ones), quintic d(t) over 3 s
     d1 = -0.5;
@@ -1264,6 +1279,7 @@ __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool
       if (k == lane) { r_px = x_; r_py = y_; r_yaw = yw_; r_v = v_; }
     }
     };
+    PRED_TICK(6);
     if (staged) follow(rt_q, rt_s);
     else follow(qg, sg);
     // number of samples on the route: sk is non-decreasing in k, so the valid samples are a prefix
@@ -1274,6 +1290,7 @@ __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool
   for (int k = lane; k < T; k += 64)
     if (k >= L) { P[2 * k] = 0.0; P[2 * k + 1] = 0.0; Y[k] = 0.0; V[k] = 0.0; }
   if (lane == 0) o.len[slot] = L;
+  PRED_TICK(7);
   if (table_on && T <= 64) {
     // the slot's rows of the sweep's agent table from the values just written, a lane per sample (no read-back through
     // memory, one atomic for the agent's longest step)
@@ -1281,7 +1298,7 @@ __device__ __forceinline__ void spawn_write_slot(int lane, int slot, int r, bool
     q.px = r_px; q.py = r_py; q.ppx = __shfl_up(r_px, 1); q.ppy = __shfl_up(r_py, 1); q.yaw = r_yaw; q.v = r_v;
     q.sxx = r_var; q.sxy = 0.0; q.syx = 0.0; q.syy = r_var;
     fo_agent_row_core<true>(lane < T, slot, lane, T, L, q, infl_l, infl_w, raw_l, raw_w, atype, at.ego_mass, at.hlA, at.hwA, at.hc, at.tab,
-                            at.cst, at.aint, at.status, at.gen);
+                            at.cst, at.aint, at.status, at.gen, m_obs);
   } else if (table_on) {
     __threadfence_block();
     __syncthreads();
@@ -1303,14 +1320,17 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
   const int lane = threadIdx.x;
   const int slot = blockIdx.x, j = slot / R, r = slot % R;
   // the pick of agent j (repeated by each of its R route slots: a few dozen path segments; saves a launch)
+  PRED_TICK(0);
   const int n_c = *n_cand;
   // (the covariance growth factor of this lane's sample: a page of arithmetic with no input from memory -- here, under the
   // first round trip of the chain that follows)
   const double vpow = pow(factor, (double)lane);
+  const double m_obs = table_on ? fo_obstacle_mass(st.type[j & 3], st.infl_l[j & 3] * st.infl_w[j & 3]) : -1.0;   // (as well)
   int ci;
   double p0x, p0y, a0;
   const bool on = spawn_pick(j, lane, cand, n_c, nx, rx0, ry0, cs, ix0, iy0, max_agents, st, n_path, path, lane_yaw, rnx,
                              rny, ci, p0x, p0y, a0);
+  PRED_TICK(4);
   if (r == 0 && lane == 0) {
     cell[j] = ci; pos0[2 * j] = p0x; pos0[2 * j + 1] = p0y; yaw0[j] = a0;
     if (j == 0) *n_out = n_c < max_agents ? n_c : max_agents;
@@ -1321,8 +1341,10 @@ __global__ __launch_bounds__(64) void fo_spawn_predict_kernel(
     const int wx = ix0 + ci % nx, wy = iy0 + ci / nx;
     if (wx >= 0 && wx < rnx && wy >= 0 && wy < rny) ll = lanelet_raster[(size_t)wy * rnx + wx];
   }
+  PRED_TICK(5);
   spawn_write_slot(lane, slot, r, on, p0x, p0y, a0, st.type[sdx], st.speed[sdx], st.raw_l[sdx], st.raw_w[sdx], st.infl_l[sdx],
-                   st.infl_w[sdx], ll, rv, T, dt, var0, factor, o, table_on, at, vpow);
+                   st.infl_w[sdx], ll, rv, T, dt, var0, factor, o, table_on, at, vpow, m_obs);
+  PRED_TICK(9);
 }
 
 int ensure_cells(fo_ctx *ctx, Scene *sc, size_t cells) {
@@ -1797,6 +1819,10 @@ int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, 
   }
   return FO_OK;
 }
+
+#if FO_PRED_TRACE
+int fo_debug_pred_ticks(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pred_ticks), sizeof(long long) * 16); }
+#endif
 
 int fo_scene_candidate_count(fo_ctx *ctx, int32_t *h_n, void *stream) {
   if (!ctx || !ctx->scene || !h_n) return FO_E_ARG;

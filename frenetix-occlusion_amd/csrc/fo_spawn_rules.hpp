@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(64) void fo_spawn_rule_predict_kernel(
   }
   if (r == 0 && lane == 0) { pos0[2 * (agent0 + i)] = px; pos0[2 * (agent0 + i) + 1] = py; yaw0[agent0 + i] = a0; }
   spawn_write_slot(lane, slot, r, on, px, py, a0, type, ty.speed[ti], ty.raw_l[ti], ty.raw_w[ti], ty.infl_l[ti], ty.infl_w[ti], ll, rv, T,
-                   dt, var0, factor, o, table_on, at, vpow);
+                   dt, var0, factor, o, table_on, at, vpow, -1.0);
 }
 
 }  // namespace
