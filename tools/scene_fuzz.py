@@ -1,6 +1,9 @@
 """One-off robustness run on the GPU box: the scene stage against the oracle (bit-exact ranges, hit ids, cell classes,
 occluded indices, visibility flags, spawn cells) at many random poses / fans / radii on the three scenario maps and
-the city grid.  Reuses the checker of tests/test_scene_gpu.py.  usage: python tools/scene_fuzz.py [n] [seed]"""
+the city grid.  Reuses the checker of tests/test_scene_gpu.py.  usage: python tools/scene_fuzz.py [n] [seed] [near]
+near: one to three extra obstacles of random size and heading 0.2-4 m from the ego (so close that the end of their occlusion
+polygons falls inside the sensor range) and a random shadow length -- the far-chord half-planes (16 arccos per obstacle, device
+libm against the host's) under the bit-exact comparison of the cell classes."""
 import math
 import os
 import sys
@@ -19,6 +22,7 @@ import test_scene_gpu as TG  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    near = len(sys.argv) > 3 and sys.argv[3] == "near"
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     oracle.build()
     maps = [S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", f"scenario{k}_geometry.npz")) for k in (1, 2, 3)]
@@ -36,8 +40,25 @@ def main():
         n_rays = int(rng.choice([720, 720, 361, 97, 180]))
         ts = int(rng.integers(0, 80))
         ego = np.array([pos[0], pos[1], yaw, 8.0])
+        L = 100.0
+        if near:
+            extra = []
+            for q in range(int(rng.integers(1, 4))):
+                ln, wd = float(rng.uniform(1.5, 14.0)), float(rng.uniform(0.8, 3.0))
+                oy = float(rng.uniform(-math.pi, math.pi))
+                # centre such that the nearest point of the rectangle is 0.2-4 m from the ego, along a random bearing
+                b = float(rng.uniform(-math.pi, math.pi))
+                gap = float(rng.uniform(0.2, 4.0))
+                # support of the rectangle along -bearing
+                hx, hy = math.cos(oy), math.sin(oy)
+                sup = abs(0.5 * ln * (hx * math.cos(b) + hy * math.sin(b))) + abs(0.5 * wd * (-hy * math.cos(b) + hx * math.sin(b)))
+                cen = pos + (gap + sup) * np.array([math.cos(b), math.sin(b)])
+                typ = "bicycle" if rng.integers(8) == 0 else "truck"
+                extra.append(S.Obstacle(9000 + q, "static", typ, ln, wd, 0, np.array([cen[0], cen[1], oy, 0.0]), np.zeros((0, 4))))
+            sc = S.Scenario(sc.dt, sc.lanelets, extra + list(sc.obstacles), sc.intersections, sc.ego_initial, sc.benchmark_id)
+            L = float(rng.choice([100.0, 100.0, 30.0, 10.0, math.inf]))
         st = TG._check_step(torch, oracle, sc, ego, 8.0, ts, sensor_angle=fov, n_rays=n_rays, radius=r,
-                            max_agents=int(rng.choice([5, 32, 256])), all_occluded=bool(rng.integers(2)))
+                            max_agents=int(rng.choice([5, 32, 256])), all_occluded=bool(rng.integers(2)), shadow_length=L)
         for key in tot:
             tot[key] += st[key]
         print(it, "map", k, np.round(pos, 2), round(yaw, 2), fov, r, n_rays, ts, st, flush=True)
