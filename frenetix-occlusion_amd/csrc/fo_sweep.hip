@@ -816,6 +816,14 @@ typedef const int32_t __attribute__((address_space(4))) *cip_t;
 __device__ __forceinline__ cdp_t fo_const(const double *p) { return (cdp_t)(unsigned long long)p; }
 __device__ __forceinline__ cip_t fo_const(const int32_t *p) { return (cip_t)(unsigned long long)p; }
 
+// tuning builds (-DFO_TRACE=1): four more wall-clock stamps per workgroup, by wave 0, in rows [32768 + blockIdx] of the trace
+// buffer (tools/split_trace.py): 0 the agent's constants and first rows resident, 1 pass 1 of the (last) chunk done, 2 pass 2
+// done, 3 the agent's horizon segments folded
+#if FO_TRACE
+#define SW_STAMP(i) do { if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)(32768 + blockIdx.x) + (i)] = wall_clock64(); } while (0)
+#else
+#define SW_STAMP(i) do { } while (0)
+#endif
 // ALLM: the default metric set (dce, cp, ttc, ttce, hr all active, no debug ablation) is compiled with the flags as
 // constants -- fewer wave-uniform masks to keep in SGPRs, fewer branches; any other selection takes the generic copy.
 // SPLIT (small batches, where one agent per wave leaves most SIMDs with a single wave): the four waves of a workgroup
@@ -898,6 +906,20 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       const double gf2 = gf * gf;
       gate_far2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(gf2)), __builtin_amdgcn_readfirstlane(__double2loint(gf2)));
     }
+    // Horizon-split form: the operands of the DCE probe (below) are asked for here, together with the agent's constants and
+    // its length -- one round trip instead of two at the head of a workgroup that lives for ~15 us (the probe's choice of
+    // samples only seeds a threshold; any sample of the segment serves).  Four samples, every second one of the segment.
+    double sp_vx[4], sp_vy[4], sp_gx[4], sp_gy[4];
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = min(seg0 + 2 * u, T - 1);
+        const fo_d2 xy = fo_ld2(tj + (size_t)t * NEF * TILE);
+        sp_vx[u] = xy.x; sp_vy[u] = xy.y;
+        const cdp_t g = G + (size_t)t * NAF;
+        sp_gx[u] = g[0]; sp_gy[u] = g[1];
+      }
+    }
     const int prot = fo_const(a.aint)[2 * k], L = fo_const(a.aint)[2 * k + 1];
     const int Lh = min(Tm1, L);
 
@@ -939,6 +961,17 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       // Every second sample is enough for a seed (on the bench workload the exact geometry runs as rarely as with all
       // of them; stride 4 would cost a quarter more) -- and halves the loads of this phase.
       constexpr int PS = 2;
+      if constexpr (SPLIT) {
+        asm volatile("; probe operands resident" ::"s"(sp_gx[0]), "s"(sp_gy[0]), "s"(sp_gx[1]), "s"(sp_gy[1]), "s"(sp_gx[2]),
+                     "s"(sp_gy[2]), "s"(sp_gx[3]), "s"(sp_gy[3]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = seg0 + 2 * u;
+          const double rx = sp_gx[u] - sp_vx[u], ry = sp_gy[u] - sp_vy[u];
+          const double c2 = rx * rx + ry * ry;
+          if (t < Ld && c2 < bestc) { bestc = c2; tb = t; }
+        }
+      } else
 #pragma unroll 1
       for (int t8 = 0; seg0 + t8 * PS < Ld; t8 += 8) {
         double vx[8], vy[8], gpx[8], gpy[8];
@@ -1161,6 +1194,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       // loop, which leaves the in-loop wait to cover only the row that was prefetched one iteration ago.
       asm volatile("; scalar operands resident" ::"s"(hlB), "s"(hwB), "s"(hdev), "s"(Rsum), "s"(gate_far2), "s"(px),
                    "s"(py), "s"(pc), "s"(ps), "s"(pvx), "s"(pvy), "s"(pyaw));
+      SW_STAMP(0);
       // rows t+1 as running 32-bit byte offsets from the (uniform) bases of this tile's and this agent's rows: one add
       // each per sample instead of a 64-bit multiply-add, and the loads take the base from scalar registers
       unsigned eoff = (unsigned)((tl * NEF * TILE + 2 * lane) * sizeof(double));
@@ -1339,6 +1373,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         }
       }
 
+      SW_STAMP(1);
       // ---------------------------------------------------------------- pass 2: harm, risk, maxima, lists
       // of the gate samples g in [max(t0-1, 0), t1-1) -- harm index g, cp index g (Q6)
       const int g0s = max(gbase, 0), g1s = t1 - 1;
@@ -1488,6 +1523,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         else if (dvmax_mode) pass2(std::integral_constant<int, HM_DVMAX>{});
         else pass2(std::integral_constant<int, HM_GENERIC>{});
       }
+      SW_STAMP(2);
     }
     if (dvmax_mode) {
       if (nze_min < INFINITY) {   // nze_min = -(largest squared relative speed)
@@ -1528,6 +1564,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       if (kk + 1 < apw_ && k + 1 < A) __syncthreads();
       if (wave > 0) continue;
     }
+    SW_STAMP(3);
     // ------------------------------------------------------------------ per-pair scalars
     const double dce_m = (dce < INFINITY) ? fo_div1000(dce) : dce;                          // np.round(d, 3)
     const double ttce = fo_round3_fast((double)tdce * a.dt);                                // ttce.py:39
@@ -1574,11 +1611,14 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
   }
 
   // ---------------- combine the waves of the workgroup (ascending agent order); scratch aliases the cp buffers
-  __syncthreads();
+  // (horizon-split form: wave 0 has folded every agent's segments and holds the workgroup's values -- no exchange, the other
+  // waves are done)
+  if (SPLIT && wave > 0) return;
+  if (!SPLIT) __syncthreads();
   double *red = cpbuf_all;
   double w_min_ttc = w_min_tttc == 0x7fffffff ? INFINITY : fo_round3_fast((double)w_min_tttc * a.dt);
   double w_min_ttce = w_min_tttce == 0x7fffffff ? INFINITY : fo_round3_fast((double)w_min_tttce * a.dt);
-  if (wave > 0) {
+  if (!SPLIT && wave > 0) {
     double *rp = red + (size_t)(wave - 1) * NPS * TILE + lane;
     rp[PS_MIN_DCE * TILE] = w_min_dce; rp[PS_ARG_DCE * TILE] = (double)w_arg_dce; rp[PS_MIN_TTC * TILE] = w_min_ttc;
     rp[PS_ARG_TTC * TILE] = (double)w_arg_ttc; rp[PS_MIN_TTCE * TILE] = w_min_ttce; rp[PS_MAX_ER * TILE] = w_max_er;
@@ -1586,8 +1626,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     rp[PS_MAX_OH * TILE] = w_max_oh; rp[PS_MAX_CP * TILE] = w_max_cp; rp[PS_MAX_HWC * TILE] = w_max_hwc;
     rp[PS_DCE_FLAG * TILE] = w_dce_flag ? 1.0 : 0.0; rp[PS_MAX_BTN * TILE] = 0.0;
   }
-  __syncthreads();
+  if (!SPLIT) __syncthreads();
   if (wave == 0) {
+    if (!SPLIT)
     for (int w = 0; w < QWAVES - 1; ++w) {
       const double *rp = red + (size_t)w * NPS * TILE + lane;
       // (ties keep the smaller agent index: with FO_DYN the waves' agents interleave, without it wave order = agent order
@@ -2200,9 +2241,11 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
 #if FO_TRACE
     if (a.trace && getenv("FO_SWEEP_TRACE_DUMP")) {   // (set for the one launch that is to be dumped)
       (void)hipStreamSynchronize(s);
-      long long *h = (long long *)malloc(sizeof(long long) * 4 * grid);
-      (void)hipMemcpy(h, d_trace, sizeof(long long) * 4 * grid, hipMemcpyDeviceToHost);
-      if (FILE *f = fopen(trace_path, "wb")) { fwrite(h, sizeof(long long), 4 * (size_t)grid, f); fclose(f); }
+      // (FO_SWEEP_TRACE_PHASES: the per-workgroup phase stamps as well, rows [32768, 32768 + grid) -- tools/split_trace.py)
+      const size_t rows = getenv("FO_SWEEP_TRACE_PHASES") && grid <= 32768 ? (size_t)32768 + grid : (size_t)grid;
+      long long *h = (long long *)malloc(sizeof(long long) * 4 * rows);
+      (void)hipMemcpy(h, d_trace, sizeof(long long) * 4 * rows, hipMemcpyDeviceToHost);
+      if (FILE *f = fopen(trace_path, "wb")) { fwrite(h, sizeof(long long), 4 * rows, f); fclose(f); }
       free(h);
     }
 #endif
