@@ -1088,7 +1088,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
 #pragma unroll 1
           for (int jm = -1; jm <= 1; ++jm) {
             const double qx = rx - jm * devx, qy = ry - jm * devy;
-#pragma unroll 1
+            // (horizon-split form: the three boxes of a row side by side -- a wave that flushes at every sample is bound by
+            // the latency of this loop, twelve table reads in flight instead of four; elsewhere the registers are dearer)
+#pragma unroll (SPLIT && !PAIR ? 3 : 1)
             for (int b = -1; b <= 1; ++b) {
               const double cx = qx + b * bxs, cy = qy + b * bys;
 #if FO_ERF_GROUP == 4
