@@ -186,6 +186,22 @@ __device__ __forceinline__ bool chunk_culled(const double *__restrict__ box, dou
   return false;
 }
 
+#ifndef FO_PRED_TRACE
+#define FO_PRED_TRACE 0   // tuning builds: wall-clock stamps of one prediction workgroup's phases (fo_debug_pred_ticks, tools/pred_trace.py)
+#endif
+#if FO_PRED_TRACE
+__device__ long long g_pred_ticks[16], g_ray_ticks[16];
+#define PRED_TICK(i) do { if (blockIdx.x == FO_PRED_TRACE && threadIdx.x == 0) g_pred_ticks[i] = wall_clock64(); } while (0)
+#define RAY_TICK(i) do { if (blockIdx.x == FO_PRED_TRACE && threadIdx.x == 0) g_ray_ticks[i] = wall_clock64(); } while (0)
+#define FO_PRED_TRACE_BLOCK FO_PRED_TRACE
+#define RAY_NOTE(i, v) do { g_ray_ticks[i] = (long long)(v); } while (0)
+#else
+#define PRED_TICK(i) do { } while (0)
+#define RAY_TICK(i) do { } while (0)
+#define FO_PRED_TRACE_BLOCK (-1)
+#define RAY_NOTE(i, v) do { } while (0)
+#endif
+
 template <bool SKIP>
 __device__ __forceinline__ void scan_soup(int E, const double *__restrict__ edges, const double *__restrict__ chunk_box,
                                           const uint8_t *__restrict__ eskip, int O, const double *__restrict__ ocorn,
@@ -197,6 +213,7 @@ __device__ __forceinline__ void scan_soup(int E, const double *__restrict__ edge
     // a lane per chunk box: one round trip culls 64 chunks; the survivors are then scanned a lane per piece
     const int cc = cb + lane;
     unsigned long long live = __ballot(cc < nc && !chunk_culled(chunk_box + 4 * (size_t)(cc < nc ? cc : 0), ox, oy, dx, dy, tmax));
+    if (cb == 0) { RAY_TICK(5); if (threadIdx.x == 0 && blockIdx.x == FO_PRED_TRACE_BLOCK) RAY_NOTE(12, __popcll(live)); }
     while (live) {
       const int c = cb + __builtin_ctzll(live);
       live &= live - 1;
@@ -208,6 +225,7 @@ __device__ __forceinline__ void scan_soup(int E, const double *__restrict__ edge
       if (t < best || (t == best && gi < best_id)) { best = t; best_id = gi; }
     }
   }
+  RAY_TICK(6);
   // obstacle sides, interleaved over the whole workgroup
   for (int k = wave * 64 + lane; k < 4 * O; k += 64 * n_waves) {
     const int o = k >> 2, sd = k & 3, s2 = (sd + 1) & 3;
@@ -393,6 +411,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
   if ((int)blockIdx.x < n_rays) {
     const int i = blockIdx.x;
     double dx, dy, rm;
+    RAY_TICK(0);
     if (fan.on) {   // (wave-uniform; the same arithmetic as fo_fan_kernel)
       fan_ray(i, n_rays, fan.yaw, fan.fov, fan.full, r, fan.polygon, dx, dy, rm);
       if (!fan.rmax) rm = r;
@@ -414,10 +433,14 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
     }
     double best = INFINITY;
     int id = 0x7fffffff;
+    RAY_TICK(1);
     scan_soup<SKIP>(E, edges, chunk_box, eskip, O, ocorn, oflags, wave, RAY_WAVES, lane, ex, ey, dx, dy, rm, -3, best, id);
+    RAY_TICK(2);
     wave_min_hit(best, id);
+    RAY_TICK(3);
     if (lane == 0) { sh_t[wave] = best; sh_id[wave] = id; }
     __syncthreads();
+    RAY_TICK(4);
     if (threadIdx.x == 0) {
       for (int w = 1; w < RAY_WAVES; ++w)
         if (sh_t[w] < best || (sh_t[w] == best && sh_id[w] < id)) { best = sh_t[w]; id = sh_id[w]; }
@@ -431,6 +454,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
         ring[2 * i] = ex + best * dx;
         ring[2 * i + 1] = ey + best * dy;
       }
+      RAY_TICK(7);
     }
     return;
   }
@@ -1122,15 +1146,6 @@ __device__ __forceinline__ double heading_to_curve(int lane, int N, const double
   return a;
 }
 
-#ifndef FO_PRED_TRACE
-#define FO_PRED_TRACE 0   // tuning builds: wall-clock stamps of one prediction workgroup's phases (fo_debug_pred_ticks, tools/pred_trace.py)
-#endif
-#if FO_PRED_TRACE
-__device__ long long g_pred_ticks[16];
-#define PRED_TICK(i) do { if (blockIdx.x == FO_PRED_TRACE && threadIdx.x == 0) g_pred_ticks[i] = wall_clock64(); } while (0)
-#else
-#define PRED_TICK(i) do { } while (0)
-#endif
 // evenly spaced pick of the candidates + heading per phantom: pedestrians -> unit vector to the closest point of the
 // ego reference path (agent.py:475-481 + helper_functions.py:38-76); vehicles -> lane heading raster at their cell
 // Phantom slot j of the step (the whole wave calls this; every result is wave-uniform): which candidate cell it takes
@@ -1822,6 +1837,7 @@ int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, 
 
 #if FO_PRED_TRACE
 int fo_debug_pred_ticks(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pred_ticks), sizeof(long long) * 16); }
+int fo_debug_ray_ticks(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_ticks), sizeof(long long) * 16); }
 #endif
 
 int fo_scene_candidate_count(fo_ctx *ctx, int32_t *h_n, void *stream) {

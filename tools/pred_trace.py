@@ -25,3 +25,13 @@ print("step", round(r["ms_per_step"], 4))
 for i in sorted(names):
     if t[i]:
         print(f"{names[i]:>22s}: {(t[i] - t0) * 0.01:6.2f} us")
+
+if hasattr(lib, "fo_debug_ray_ticks"):
+    t = (ctypes.c_longlong * 16)()
+    assert lib.fo_debug_ray_ticks(t) == 0
+    t = np.array(list(t), dtype=np.int64)
+    rn = {0: "start", 1: "direction known", 5: "first boxes culled", 6: "pieces scanned", 2: "obstacle sides", 3: "wave minimum", 4: "workgroup barrier", 7: "written"}
+    print("ray workgroup (same block index), wave 0; surviving chunks of the first group:", int(t[12]))
+    for i in (0, 1, 5, 6, 2, 3, 4, 7):
+        if t[i]:
+            print(f"{rn[i]:>22s}: {(t[i] - t[0]) * 0.01:6.2f} us")
