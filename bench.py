@@ -419,7 +419,7 @@ def rules_step(local_rank, steps=60):
                        "<= 8 spawn points x 3 route slots), T=31, reduced outputs, fo_step_run; the ego drives the scenario's first 61 "
                        "time steps (0.76 m per step), every pose timed on its own", "steps_per_pose": steps, "poses": {}}
     per, n_dyn, n_pts, worst = [], 0, 0, 0.0
-    for step in range(61):
+    for step in range(min(61, int(os.environ.get("FO_RULES_LAST_POSE", "60")) + 1)):   # (the variable: tools/rule_wtrace.py)
         ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
         obs.update(step)
         sm.upload_obstacles(obs)

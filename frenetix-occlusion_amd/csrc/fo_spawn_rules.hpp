@@ -30,6 +30,13 @@ namespace {
 #else
 #define RL_TICK(i) do { } while (0)
 #endif
+// (per-workgroup stamps of the whole rule kernel: RL_WTICK(i), i < 8, row blockIdx of g_rule_wticks -- fo_debug_rule_wticks)
+#if FO_RULE_TRACE
+__device__ long long g_rule_wticks[8 * 1024];
+#define RL_WTICK(i) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == (i >= 8 ? 1 : 0) && blockIdx.x < 1024) g_rule_wticks[8 * blockIdx.x + ((i) & 7)] = wall_clock64(); } while (0)
+#else
+#define RL_WTICK(i) do { } while (0)
+#endif
 #if FO_RULE_TRACE == 2   // tuning: stamps INSIDE the first rectangle fit instead of after the two fits (slots 5, 6, 7)
 #define RL_TICKF(i) do { __syncthreads(); if (threadIdx.x == 0 && rec[16 + (i)] == 0.0) rec[16 + (i)] = (double)wall_clock64(); } while (0)
 #else
@@ -175,6 +182,53 @@ __device__ inline bool rl_to_curv_wave(const RuleView &v, double x, double y, do
   d = (x - fx) * (-q[5]) + (y - fy) * q[4];
   return true;
 }
+// N points at once (every lane calls with the same points): the N searches share the pass over the segments and their
+// exchanges overlap -- the arithmetic per point is rl_to_curv_wave's (same bits); ok bit n = point n projects onto the path.
+// (A projection alone is six exchange steps of LDS-crossbar latency: one after the other, the five of an obstacle's centre
+// and corners cost the static rule 10 us.)
+template <int N>
+__device__ inline unsigned rl_to_curv_wave_n(const RuleView &v, const double *x, const double *y, double *s, double *d) {
+  const int ns = v.n_path - 1, lane = threadIdx.x & 63;
+  double best[N], bt[N], btc[N];
+  int k[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) { best[n] = INFINITY; bt[n] = 0.0; btc[n] = 0.0; k[n] = 0x7fffffff; }
+  for (int i = lane; i < ns; i += 64) {
+    const double *q = v.path + 6 * (size_t)i;
+    const double q0 = q[0], q1 = q[1], q3 = q[3], q4 = q[4], q5 = q[5];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double t = (x[n] - q0) * q4 + (y[n] - q1) * q5;
+      const double tc = fmin(fmax(t, 0.0), q3);
+      const double fx = q0 + tc * q4, fy = q1 + tc * q5;
+      const double d2 = (x[n] - fx) * (x[n] - fx) + (y[n] - fy) * (y[n] - fy);
+      if (d2 < best[n]) { best[n] = d2; k[n] = i; bt[n] = t; btc[n] = tc; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double b2 = __shfl_xor(best[n], off);
+      const int k2 = __shfl_xor(k[n], off);
+      if (b2 < best[n] || (b2 == best[n] && k2 < k[n])) { best[n] = b2; k[n] = k2; }
+    }
+  }
+  unsigned ok = 0u;
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    if (k[n] == 0x7fffffff) continue;
+    // (segment i lives in lane i mod 64: its parameters from there instead of through the six exchange steps)
+    const double t_ = __shfl(bt[n], k[n] & 63), tc_ = __shfl(btc[n], k[n] & 63);
+    const double *q = v.path + 6 * (size_t)k[n];
+    if ((k[n] == 0 && t_ < 0.0) || (k[n] == ns - 1 && t_ > q[3])) continue;
+    const double fx = q[0] + tc_ * q[4], fy = q[1] + tc_ * q[5];
+    s[n] = q[2] + tc_;
+    d[n] = (x[n] - fx) * (-q[5]) + (y[n] - fy) * q[4];
+    ok |= 1u << n;
+  }
+  return ok;
+}
 __device__ inline bool rl_to_cart(const RuleView &v, double s, double d, double &x, double &y) {
   const int n = v.n_path;
   if (s < v.path[2] || s > v.path[6 * (size_t)(n - 1) + 2]) return false;
@@ -253,7 +307,7 @@ __device__ inline void rl_sample(const double *px, const double *py, const doubl
 
 // ---------------------------------------------------------------- pedestrian behind a turn (one wave)
 // rec: [0] valid, [1] x, [2] y, [3] s_ph, [4] d (the lateral phantom offset), [5] source
-__device__ void rl_turn_rule(const RuleView &v, const RuleParams &pr, double *rec, double *lx, double *ly, double *cum,
+__device__ __forceinline__ void rl_turn_rule(const RuleView &v, const RuleParams &pr, double *rec, double *lx, double *ly, double *cum,
                              unsigned char *inside) {
   const int lane = threadIdx.x & 63;
   if (lane == 0) rec[0] = 0.0;
@@ -311,31 +365,40 @@ __device__ void rl_turn_rule(const RuleView &v, const RuleParams &pr, double *re
   rec[0] = 1.0;   // (the obstacle and heading conditions, :557-572, are applied by the selection workgroup)
 }
 
-// ---------------------------------------------------------------- pedestrian behind a static obstacle (one wave)
+// ---------------------------------------------------------------- pedestrian behind a static obstacle (two waves)
 // rec: [0] distance to the ego, [1] role (1 static candidate, 2 dynamic candidate, 0 nothing), per line li = 0, 1:
 // [2 + 6 li] valid, x, y, s, d, yaw
-__device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, int O, const double *ocorn, const double *ocen,
+// Wave li of the workgroup takes cross line li (the rear and the front end of the obstacle's extent along the path): the two
+// lines are independent chains of projections and class look-ups, a wave's worth of latency each.  Both waves work out the
+// obstacle's extent for themselves (the same arithmetic: no exchange); sx, sy, near: this wave's scratch.
+__device__ __forceinline__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, int O, const double *ocorn, const double *ocen,
                                const uint8_t *oflags, const uint8_t *ovis, double *rec, double *sx, double *sy,
-                               unsigned char *near) {
+                               unsigned char *near, int li) {
   const int lane = threadIdx.x & 63;
   const double cx = ocen[2 * o], cy = ocen[2 * o + 1];
   const double *oc = ocorn + 8 * (size_t)o;
-  if (lane == 0) { rec[2] = 0.0; rec[8] = 0.0; }
+  if (lane == 0) rec[2 + 6 * li] = 0.0;
   if (sqrt((pr.ego_x - cx) * (pr.ego_x - cx) + (pr.ego_y - cy) * (pr.ego_y - cy)) > RL_MAX_DIST_OBST) return;   // :369
-  double ob_s, ob_d;
-  if (!rl_to_curv_wave(v, cx, cy, ob_s, ob_d)) return;
+  // the centre and the four corners in one pass over the path (rl_to_curv_wave_n)
+  const double p5x[5] = {cx, oc[0], oc[2], oc[4], oc[6]}, p5y[5] = {cy, oc[1], oc[3], oc[5], oc[7]};
+  double p5s[5], p5d[5];
+  RL_WTICK(2);
+  const unsigned ok5 = rl_to_curv_wave_n<5>(v, p5x, p5y, p5s, p5d);
+  RL_WTICK(3);
+  if (!(ok5 & 1u)) return;
+  const double ob_s = p5s[0];
   // :380 compares with ego s + s_threshold although s_threshold already contains ego s (kept as in the reference)
   if (pr.ego_s + pr.s_threshold < ob_s || ob_s < pr.ego_s + 3.0) return;
+  if (ok5 != 31u) return;
   double s_min = INFINITY, s_max = -INFINITY, d_min = INFINITY, d_max = -INFINITY;
-  for (int i = 0; i < 4; ++i) {
-    double s, d;
-    if (!rl_to_curv_wave(v, oc[2 * i], oc[2 * i + 1], s, d)) return;
-    s_min = fmin(s_min, s); s_max = fmax(s_max, s); d_min = fmin(d_min, d); d_max = fmax(d_max, d);
+  for (int i = 1; i < 5; ++i) {
+    s_min = fmin(s_min, p5s[i]); s_max = fmax(s_max, p5s[i]); d_min = fmin(d_min, p5d[i]); d_max = fmax(d_max, p5d[i]);
   }
   s_min -= 0.8; s_max += 0.8; d_min -= 0.8; d_max += 0.8;                          // :384-390
   double yaw_l = 0.0;
   const bool have_yaw = rl_lane_yaw_at(v, cx, cy, yaw_l);
-  for (int li = 0; li < 2; ++li) {
+  RL_WTICK(4);
+  for (int once = 0; once < 1; ++once) {   // (this wave's line; `continue` = no point on it)
     const double s_line = li == 0 ? s_min : s_max;
     double ax, ay, bx, by;
     if (!rl_to_cart(v, s_line, d_min, ax, ay) || !rl_to_cart(v, s_line, d_max, bx, by)) continue;
@@ -355,6 +418,7 @@ __device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, i
       t_vis = t_vis || (c & 2);
       near[i] = rl_disc_touches(v, x, y, b, 2) ? 1 : 0;
     }
+    RL_WTICK(5);
     if (!__ballot(t_occ) || !__ballot(t_vis)) continue;                           // :406-408
     bool blocked = false;                                                         // :409-411: any VISIBLE obstacle within half a pedestrian width
     for (int j = lane; j < O; j += 64)
@@ -410,6 +474,7 @@ __device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, i
     spy = __shfl(spy, 0);
     double ss = 0.0, sd = 0.0;
     const bool okc = okw && rl_to_curv_wave(v, spx, spy, ss, sd);
+    RL_WTICK(6);
     if (lane == 0) {
       double *r = rec + 2 + 6 * li;
       r[0] = (okc && have_yaw) ? 1.0 : 0.0; r[1] = spx; r[2] = spy; r[3] = ss; r[4] = sd; r[5] = yaw_l + 1.5707963267948966;
@@ -422,7 +487,7 @@ __device__ void rl_static_rule(const RuleView &v, const RuleParams &pr, int o, i
 struct RlFit { double area, cx, cy, jac; bool any; };
 
 // rec: [0] distance, [1] role = 2, [2] car valid, [3] car x, [4] car y, [5] bicycle valid, [6] x, [7] y
-__device__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, const double *ocorn, const double *ocen,
+__device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, const double *ocorn, const double *ocen,
                                 const double *oyaw, const double *odims, double *rec, int *lab, double *red, int *ired,
                                 unsigned char *fitok, double *polyv, int part, int *g_lab, int *g_cnt) {
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -899,6 +964,7 @@ __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, 
   // the reference path table into LDS: the projections and the arc-length searches of every rule are chains of dependent
   // reads of it (a binary search in HBM costs eight round trips of ~0.6 us; in LDS, of ~30 ns)
   __shared__ double pathv[6 * RL_PATHV];
+  RL_WTICK(0);
   if (v.n_path <= RL_PATHV) {
     for (int i = threadIdx.x; i < 6 * v.n_path; i += blockDim.x) pathv[i] = v.path[i];
     v.path = pathv;
@@ -909,6 +975,7 @@ __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, 
     __threadfence();
   }
   __syncthreads();
+  RL_WTICK(1);
   if (blockIdx.x == 0) {
     if (threadIdx.x < 64 && pr.behind_turn && pr.intention != 0) {
       double *lx = (double *)lab, *ly = lx + 256, *cum = ly + 256;
@@ -923,25 +990,29 @@ __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, 
   const int part = helper ? 1 + ((int)blockIdx.x - 1 - O) % (RL_PARTS - 1) : 0;
   rec = recs + (size_t)(1 + o) * RL_REC;
   const bool vis = (oflags[o] & 1) && ovis[o];
-  if (helper) {
-    if (vis && (oflags[o] & 4) && !(oflags[o] & 8) && pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1))
-      rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, part, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
-    return;
+  // (one call site for the dynamic rule, inlined: a call would put the kernel's RuleView on a stack in scratch memory -- and a
+  // kernel with a private segment is dispatched noticeably later than one without, measured ~15 us here)
+  const bool dyn_rule = vis && (oflags[o] & 4) && !(oflags[o] & 8) && pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1);
+  if (helper && !dyn_rule) return;
+  if (!helper) {
+    const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
+    if (threadIdx.x == 0) rec[0] = sqrt(dx * dx + dy * dy);
   }
-  const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
-  if (threadIdx.x == 0) rec[0] = sqrt(dx * dx + dy * dy);
   if (!vis) return;
   const bool dynamic = oflags[o] & 4;
   if (!dynamic) {
     if (threadIdx.x == 0) rec[1] = 1.0;
-    if (threadIdx.x < 64 && pr.behind_static)
-      rl_static_rule(v, pr, o, O, ocorn, ocen, oflags, ovis, rec, (double *)lab, (double *)lab + RL_MAXSAMP, bytes);
+    if (threadIdx.x < 128 && pr.behind_static) {
+      const int li = threadIdx.x >> 6;
+      rl_static_rule(v, pr, o, O, ocorn, ocen, oflags, ovis, rec, (double *)lab + 2 * RL_MAXSAMP * li, (double *)lab + 2 * RL_MAXSAMP * li + RL_MAXSAMP,
+                     bytes + RL_MAXSAMP * li, li);
+    }
     return;
   }
   if (oflags[o] & 8) return;                                   // bicycles and pedestrians (:209-210)
-  if (threadIdx.x == 0) rec[1] = 2.0;
-  if (pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1))   // straight ahead or left turn (:124-126)
-    rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, 0, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
+  if (!helper && threadIdx.x == 0) rec[1] = 2.0;
+  if (dyn_rule)                                                // straight ahead or left turn (:124-126)
+    rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, part, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
 }
 
 // what depends on the order of the obstacles: both lists sorted by distance (stable), the maxima of the YAML compared
@@ -1083,6 +1154,10 @@ __global__ __launch_bounds__(64) void fo_spawn_rule_predict_kernel(
 }  // namespace
 
 extern "C" {
+
+#if FO_RULE_TRACE
+int fo_debug_rule_wticks(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rule_wticks), sizeof(long long) * 8 * 1024); }
+#endif
 
 int fo_scene_set_topology(fo_ctx *ctx, int P, const double *h_left0, const int32_t *h_pred0, const int32_t *h_adj_left,
                           int n_inter, const int32_t *h_inter_off, const int32_t *h_inter_lanelet,
