@@ -965,19 +965,22 @@ __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, 
   // reads of it (a binary search in HBM costs eight round trips of ~0.6 us; in LDS, of ~30 ns)
   __shared__ double pathv[6 * RL_PATHV];
   RL_WTICK(0);
-  if (v.n_path <= RL_PATHV) {
-    for (int i = threadIdx.x; i < 6 * v.n_path; i += blockDim.x) pathv[i] = v.path[i];
-    v.path = pathv;
-  }
-  double *rec = recs + (size_t)blockIdx.x * RL_REC;
-  if ((int)blockIdx.x <= O) {   // (helper blocks never touch a record: the obstacle's own block clears it, the last part writes it)
-    if (threadIdx.x < RL_REC) rec[threadIdx.x] = 0.0;
-    __threadfence();
-  }
-  __syncthreads();
-  RL_WTICK(1);
-  if (blockIdx.x == 0) {
-    if (threadIdx.x < 64 && pr.behind_turn && pr.intention != 0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // Only the dynamic rule needs the whole workgroup.  The others run on its first wave or two, which do not wait for the other
+  // fourteen to be launched (sixteen waves of this size arrive over ~6 us): every wave that has nothing to do leaves at once,
+  // the working waves copy the path table into LDS for themselves and meet no workgroup barrier.
+  auto own_path = [&](double *dst) {   // this wave's copy of the path table (a wave's LDS accesses are ordered)
+    if (v.n_path <= RL_PATHV) {
+      for (int i = lane; i < 6 * v.n_path; i += 64) dst[i] = v.path[i];
+      v.path = dst;
+    }
+  };
+  if (blockIdx.x == 0) {   // the turn rule's record
+    if (wave > 0) return;
+    double *rec = recs;
+    for (int i = lane; i < RL_REC; i += 64) rec[i] = 0.0;
+    if (pr.behind_turn && pr.intention != 0) {
+      own_path(pathv);
       double *lx = (double *)lab, *ly = lx + 256, *cum = ly + 256;
       rl_turn_rule(v, pr, rec, lx, ly, cum, bytes);
     }
@@ -988,31 +991,53 @@ __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, 
   const bool helper = (int)blockIdx.x > O;
   const int o = helper ? ((int)blockIdx.x - 1 - O) / (RL_PARTS - 1) : (int)blockIdx.x - 1;
   const int part = helper ? 1 + ((int)blockIdx.x - 1 - O) % (RL_PARTS - 1) : 0;
-  rec = recs + (size_t)(1 + o) * RL_REC;
+  double *rec = recs + (size_t)(1 + o) * RL_REC;
   const bool vis = (oflags[o] & 1) && ovis[o];
   // (one call site for the dynamic rule, inlined: a call would put the kernel's RuleView on a stack in scratch memory -- and a
-  // kernel with a private segment is dispatched noticeably later than one without, measured ~15 us here)
+  // kernel with a private segment is dispatched noticeably later than one without, measured ~11 us here)
   const bool dyn_rule = vis && (oflags[o] & 4) && !(oflags[o] & 8) && pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1);
   if (helper && !dyn_rule) return;
-  if (!helper) {
-    const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
-    if (threadIdx.x == 0) rec[0] = sqrt(dx * dx + dy * dy);
-  }
-  if (!vis) return;
-  const bool dynamic = oflags[o] & 4;
-  if (!dynamic) {
-    if (threadIdx.x == 0) rec[1] = 1.0;
-    if (threadIdx.x < 128 && pr.behind_static) {
-      const int li = threadIdx.x >> 6;
-      rl_static_rule(v, pr, o, O, ocorn, ocen, oflags, ovis, rec, (double *)lab + 2 * RL_MAXSAMP * li, (double *)lab + 2 * RL_MAXSAMP * li + RL_MAXSAMP,
-                     bytes + RL_MAXSAMP * li, li);
+  if (!dyn_rule) {
+    // the obstacle's own workgroup without the dynamic rule: wave 0 keeps the record's head and the first cross line of the
+    // static rule, wave 1 the second (helper workgroups never touch a record; the selection kernel is the next launch)
+    if (wave >= 2) return;
+    for (int i = lane; i < RL_REC; i += 64)
+      if ((i >= 8 && i < 14) == (wave == 1)) rec[i] = 0.0;
+    if (wave == 0 && lane == 0) {
+      const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
+      rec[0] = sqrt(dx * dx + dy * dy);
+    }
+    if (!vis) return;
+    if (oflags[o] & 4) {                                       // a dynamic obstacle the rule does not apply to
+      if (!(oflags[o] & 8) && wave == 0 && lane == 0) rec[1] = 2.0;   // (bicycles and pedestrians, :209-210: no role)
+      return;
+    }
+    if (wave == 0 && lane == 0) rec[1] = 1.0;
+    if (pr.behind_static) {
+      own_path(wave == 0 ? pathv : red);
+      rl_static_rule(v, pr, o, O, ocorn, ocen, oflags, ovis, rec, (double *)lab + 2 * RL_MAXSAMP * wave, (double *)lab + 2 * RL_MAXSAMP * wave + RL_MAXSAMP,
+                     bytes + RL_MAXSAMP * wave, wave);
     }
     return;
   }
-  if (oflags[o] & 8) return;                                   // bicycles and pedestrians (:209-210)
-  if (!helper && threadIdx.x == 0) rec[1] = 2.0;
-  if (dyn_rule)                                                // straight ahead or left turn (:124-126)
-    rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, part, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
+  // the dynamic rule (straight ahead or left turn, :124-126): all sixteen waves, sixteen workgroups per obstacle
+  if (v.n_path <= RL_PATHV) {
+    for (int i = threadIdx.x; i < 6 * v.n_path; i += blockDim.x) pathv[i] = v.path[i];
+    v.path = pathv;
+  }
+  if (!helper) {
+    // (no fence behind the clear: the only other writer of the record is the rule's last part, which takes its ticket after this
+    // workgroup has released its own -- rl_dynamic_rule fences before the ticket)
+    if (threadIdx.x < RL_REC) rec[threadIdx.x] = 0.0;
+  }
+  __syncthreads();
+  RL_WTICK(1);
+  if (!helper && threadIdx.x == 0) {
+    const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
+    rec[0] = sqrt(dx * dx + dy * dy);
+    rec[1] = 2.0;
+  }
+  rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, part, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
 }
 
 // what depends on the order of the obstacles: both lists sorted by distance (stable), the maxima of the YAML compared
