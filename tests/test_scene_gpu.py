@@ -253,6 +253,22 @@ def test_shadow_of_an_obstacle_ends_where_the_references_polygon_does(torch_cuda
     assert a > b + 200
 
 
+def test_shadow_length_argument_checks(torch_cuda):
+    import math
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    ctx = N.Context(0)
+    with pytest.raises(Exception, match="NaN"):
+        ctx.call("fo_scene_set_shadow_length", float("nan"))
+    ctx.call("fo_scene_set_shadow_length", math.inf)
+    ctx.call("fo_scene_set_shadow_length", 100.0)
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    for bad in (0.0, -5.0, float("nan")):
+        with pytest.raises(ValueError):
+            SensorModel(sc.lanelets, None, shadow_length=bad)
+
+
 def test_footprint_and_hole_options(torch_cuda, oracle):
     """footprint="circle" / enclosed_holes="occlude" restore the exact-radius, every-piece-occludes variant"""
     from frenetix_occlusion import scenario as S
