@@ -382,8 +382,11 @@ __device__ __forceinline__ int fan_sector_uniform(int n_rays, const double *__re
 // kernel turns into the byte flag and clears again for the next step.
 constexpr int RAY_WAVES = 5;
 constexpr int SETTLE_BLOCKS = 1024;  // grid of the settle kernel (grid-stride over the undecided cells)
-template <bool SKIP>
-__global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const double *__restrict__ edges,
+// NW: waves per workgroup -- RAY_WAVES, or 1 for maps whose boundary soup is a single group of chunk boxes (<= 64 chunks = 4 096
+// pieces: only the first wave of five would have pieces to scan; one-wave workgroups are dispatched five times faster and
+// meet no barrier)
+template <bool SKIP, int NW>
+__global__ __launch_bounds__(64 * NW) void fo_rays_kernel(int E, const double *__restrict__ edges,
                                                                  const double *__restrict__ chunk_box,
                                                                  const uint8_t *__restrict__ eskip, int O,
                                                                  const double *__restrict__ ocorn,
@@ -396,8 +399,8 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
                                                                  int32_t *__restrict__ vis32,
                                                                  int32_t *__restrict__ n_amb, FanArgs fan,
                                                                  const fo_prep_args_t prep) {
-  __shared__ double sh_t[RAY_WAVES];
-  __shared__ int sh_id[RAY_WAVES];
+  __shared__ double sh_t[NW];
+  __shared__ int sh_id[NW];
   // Workgroups past the rays and probes (fo_step_run): the sweep's tile table of the candidate trajectories -- independent
   // of the scene, written while this launch leaves most of the chip idle instead of by a launch of its own before the sweep.
   if ((int)blockIdx.x >= n_rays + (vis32 ? 5 * O : 0)) {
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
     double best = INFINITY;
     int id = 0x7fffffff;
     RAY_TICK(1);
-    scan_soup<SKIP>(E, edges, chunk_box, eskip, O, ocorn, oflags, wave, RAY_WAVES, lane, ex, ey, dx, dy, rm, -3, best, id);
+    scan_soup<SKIP>(E, edges, chunk_box, eskip, O, ocorn, oflags, wave, NW, lane, ex, ey, dx, dy, rm, -3, best, id);
     RAY_TICK(2);
     wave_min_hit(best, id);
     RAY_TICK(3);
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
     __syncthreads();
     RAY_TICK(4);
     if (threadIdx.x == 0) {
-      for (int w = 1; w < RAY_WAVES; ++w)
+      for (int w = 1; w < NW; ++w)
         if (sh_t[w] < best || (sh_t[w] == best && sh_id[w] < id)) { best = sh_t[w]; id = sh_id[w]; }
       if (!(best <= rm)) { best = rm; id = -1; }
       range[i] = best;
@@ -479,12 +482,12 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_rays_kernel(int E, const do
   const double dx = rx / dist, dy = ry / dist;
   double best = INFINITY;
   int id = 0x7fffffff;
-  scan_soup<SKIP>(E, edges, chunk_box, eskip, O, ocorn, oflags, wave, RAY_WAVES, lane, ex, ey, dx, dy, dist, E + o, best, id);
+  scan_soup<SKIP>(E, edges, chunk_box, eskip, O, ocorn, oflags, wave, NW, lane, ex, ey, dx, dy, dist, E + o, best, id);
   wave_min_hit(best, id);
   if (lane == 0) sh_t[wave] = best;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < RAY_WAVES; ++w) best = fmin(best, sh_t[w]);
+    for (int w = 1; w < NW; ++w) best = fmin(best, sh_t[w]);
     double t = best;
     if (!(t <= dist)) t = dist;  // first_hit(..., rmax = dist)
     if (t >= dist - 0.01) atomicOr(&vis32[o], 1);
@@ -685,8 +688,8 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
 // (grid-stride over the list), its threads share the soup like a ray workgroup; "t < 1" along the unnormalised
 // direction is decided on tn and denom, no division.  Thread 0 writes the class and keeps the per-block counts of
 // the occluded-cell compaction in step.
-template <bool SKIP>
-__global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
+template <bool SKIP, int NW>
+__global__ __launch_bounds__(64 * NW) void fo_settle_kernel(
     int E, const double *__restrict__ edges, const double *__restrict__ chunk_box, const uint8_t *__restrict__ eskip,
     int O, const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags, double rx0, double ry0, double cs, int ix0, int iy0, int nx, double ex,
     double ey, double hx, double hy, double r, const double *__restrict__ half, const int32_t *__restrict__ amb,
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
     if (ixb < ixa || iyb < iya) return;
     const int w = ixb - ixa + 1, h = iyb - iya + 1;
     unsigned int *words = (unsigned int *)cls;
-    for (int t = threadIdx.x; t < w * h; t += 64 * RAY_WAVES) {
+    for (int t = threadIdx.x; t < w * h; t += 64 * NW) {
       const int ix = ixa + t % w, iy = iya + t / w;
       const int idx = iy * nx + ix;
       const int sh = 8 * (idx & 3);
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
     const double px = rx0 + ((double)wx + 0.5) * cs, py = ry0 + ((double)wy + 0.5) * cs;
     const double rx = px - ex, ry = py - ey;
     int hit = 0;
-    constexpr int stride = 64 * RAY_WAVES;
+    constexpr int stride = 64 * NW;
     auto crosses = [&](double ax, double ay, double bx, double by) -> int {
       const double sx = bx - ax, sy = by - ay;
       const double denom = rx * sy - ry * sx;
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(64 * RAY_WAVES) void fo_settle_kernel(
     };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nc = (E + 63) >> 6;
-    for (int cb = wave * 64; cb < nc; cb += RAY_WAVES * 64) {  // culled like the ray scan (segment ego -> centre)
+    for (int cb = wave * 64; cb < nc; cb += NW * 64) {  // culled like the ray scan (segment ego -> centre)
       const int cc = cb + lane;
       unsigned long long live = __ballot(cc < nc && !chunk_culled(chunk_box + 4 * (size_t)(cc < nc ? cc : 0), ex, ey, rx, ry, 1.0));
       while (live) {
@@ -1653,16 +1656,20 @@ static int scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head
   const int cells = win_nx * win_ny;
   if (probes && O > cells) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: more obstacles than window cells");
   if ((rc = ensure_cells(ctx, sc, (size_t)cells))) return rc;
-  const fo_prep_args_t prep = prep_in ? *prep_in : fo_prep_args_t();
-  const dim3 rgrid(n_rays + (probes ? 5 * O : 0) + prep.blocks()), rblock(64 * RAY_WAVES);
-  if (d_edge_skip)
-    hipLaunchKernelGGL(fo_rays_kernel<true>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
-                       d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
-                       probes ? sc->d_vis32 : nullptr, sc->d_namb, fan, prep);
-  else
-    hipLaunchKernelGGL(fo_rays_kernel<false>, rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, d_ocorn,
-                       d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,
-                       probes ? sc->d_vis32 : nullptr, sc->d_namb, fan, prep);
+  fo_prep_args_t prep = prep_in ? *prep_in : fo_prep_args_t();
+  // one wave per ray / probe / undecided cell where the soup is a single group of chunk boxes (see fo_rays_kernel) and the
+  // obstacle sides fit a wave; the tile table's spare workgroups then take horizon slices of two samples (a lane handles two
+  // elements, as in the 256-thread shape)
+  const bool one_wave = (sc->map->E + 63) / 64 <= 64 && 4 * O <= 64 && !getenv("FO_SCENE_FIVE_WAVES");
+  if (one_wave && prep.on) { prep.tz = prep.T > 2 ? 2 : prep.T; prep.nz = (prep.T + prep.tz - 1) / prep.tz; }
+  const dim3 rgrid(n_rays + (probes ? 5 * O : 0) + prep.blocks()), rblock(64 * (one_wave ? 1 : RAY_WAVES));
+#define FO_LAUNCH_RAYS(SK, NW_)                                                                                                       \
+  hipLaunchKernelGGL((fo_rays_kernel<SK, NW_>), rgrid, rblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, \
+                     d_ocorn, d_ocen, d_oflags, ego_x, ego_y, n_rays, d_dirs, r, d_rmax, full_circle, d_range, d_hit_id, d_ring,        \
+                     probes ? sc->d_vis32 : nullptr, sc->d_namb, fan, prep)
+  if (d_edge_skip) { if (one_wave) FO_LAUNCH_RAYS(true, 1); else FO_LAUNCH_RAYS(true, RAY_WAVES); }
+  else { if (one_wave) FO_LAUNCH_RAYS(false, 1); else FO_LAUNCH_RAYS(false, RAY_WAVES); }
+#undef FO_LAUNCH_RAYS
   // where the obstacles' shadows end: worked out by the grid kernel (a thread per obstacle), read by the settle kernel
   double *far = nullptr;
   if (exact_cells && O > 0 && sc->shadow_length > 0.0 && sc->shadow_length < INFINITY) {
@@ -1678,15 +1685,14 @@ static int scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head
                      sc->d_namb, d_half, sc->map->d_edge_line, d_ocorn, d_oflags, sc->shadow_length, far, O);
   if (exact_cells) {
     if ((uintptr_t)d_cls & 3) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: d_cls must be 4-byte aligned");
-    const dim3 sgrid(SETTLE_BLOCKS + O), sblock(64 * RAY_WAVES);
-    if (d_edge_skip)
-      hipLaunchKernelGGL(fo_settle_kernel<true>, sgrid, sblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O,
-                         d_ocorn, d_oflags, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
-                         d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny, far);
-    else
-      hipLaunchKernelGGL(fo_settle_kernel<false>, sgrid, sblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O,
-                         d_ocorn, d_oflags, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r,
-                         d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny, far);
+    const dim3 sgrid(SETTLE_BLOCKS + O), sblock(64 * (one_wave ? 1 : RAY_WAVES));
+#define FO_LAUNCH_SETTLE(SK, NW_)                                                                                                       \
+  hipLaunchKernelGGL((fo_settle_kernel<SK, NW_>), sgrid, sblock, 0, s, sc->map->E, sc->map->d_edges, sc->map->d_chunk_box, d_edge_skip, O, \
+                     d_ocorn, d_oflags, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, ego_x, ego_y, head_x, head_y, r, \
+                     d_half, sc->d_amb, sc->d_namb, d_cls, sc->d_flags, sc->d_blk, win_ny, far)
+    if (d_edge_skip) { if (one_wave) FO_LAUNCH_SETTLE(true, 1); else FO_LAUNCH_SETTLE(true, RAY_WAVES); }
+    else { if (one_wave) FO_LAUNCH_SETTLE(false, 1); else FO_LAUNCH_SETTLE(false, RAY_WAVES); }
+#undef FO_LAUNCH_SETTLE
   }
   FO_HIP_TRY(ctx, hipGetLastError());
   if (sf_in) {
