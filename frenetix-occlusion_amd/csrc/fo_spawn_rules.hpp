@@ -133,6 +133,19 @@ __device__ inline int rl_lanelet_of(const RuleView &v, double x, double y) {   /
   return -1;
 }
 
+// the same by a whole wave (every lane calls with the same point): lane l tests the lanelets l, l + 64, ...; the first group
+// with a hit decides, its lowest lane = the first lanelet in list order.  (One lane walking the list is a chain of dependent
+// round trips: bounding box after bounding box.)
+__device__ inline int rl_lanelet_of_wave(const RuleView &v, double x, double y) {
+  const int lane = threadIdx.x & 63;
+  for (int p0 = 0; p0 < v.P; p0 += 64) {
+    const int p = p0 + lane;
+    const unsigned long long hit = __ballot(p < v.P && rl_in_polygon(v, p, x, y));
+    if (hit) return p0 + __builtin_ctzll(hit);
+  }
+  return -1;
+}
+
 // ---- polyline frame (utils/curvilinear.PolylineCS): d positive to the left; false outside the projection domain
 __device__ inline bool rl_to_curv(const RuleView &v, double x, double y, double &s, double &d) {
   const int ns = v.n_path - 1;
@@ -441,7 +454,7 @@ __device__ __forceinline__ void rl_static_rule(const RuleView &v, const RulePara
       if (n_all == 1) {
         spx = sx[only_all]; spy = sy[only_all]; found = true;
       } else if (n_all > 1) {
-        const int ll = rl_lanelet_of(v, cx, cy);
+        const int ll = rl_lanelet_of_wave(v, cx, cy);
         const double anx = (ll >= 0 && v.left0) ? v.left0[2 * ll] : cx, any_ = (ll >= 0 && v.left0) ? v.left0[2 * ll + 1] : cy;
         double bestd = INFINITY;
         int bc = 0x7fffffff, bi = 0x7fffffff;   // candidate sample, and the sample pair it came from (orders ties)
@@ -1156,13 +1169,13 @@ __global__ __launch_bounds__(64) void fo_spawn_rule_predict_kernel(
       const double *curve = path;
       int nc = n_path;
       if ((src == RL_SRC_LEFT || src == RL_SRC_RIGHT) && center_off) {       // mode 'lane_center' (interface.py:194)
-        const int lc = rl_lanelet_of(v, px, py);
+        const int lc = rl_lanelet_of_wave(v, px, py);
         if (lc >= 0 && center_off[lc + 1] - center_off[lc] >= 2) { curve = center_xy + 2 * (size_t)center_off[lc]; nc = center_off[lc + 1] - center_off[lc]; }
       }
       a0 = heading_to_curve(lane, nc, curve, px, py);
     }
   } else if (on) {                                               // OAPVehicleAgent (agent.py:283-312): the lanelet under the point
-    ll = rv.RT > 0 ? rl_lanelet_of(v, px, py) : -1;
+    ll = rv.RT > 0 ? rl_lanelet_of_wave(v, px, py) : -1;
     if (ll >= 0 && rv.count[(size_t)ll * rv.RT] >= 2) {          // heading of the record: first segment of route 0
       const double *q = rv.xy + 2 * (size_t)rv.first[(size_t)ll * rv.RT];
       a0 = atan2(q[3] - q[1], q[2] - q[0]);
