@@ -423,12 +423,13 @@ __global__ __launch_bounds__(64 * NW) void fo_rays_kernel(int E, const double *_
         fan.dirs[2 * i + 1] = dy;
         if (fan.rmax) fan.rmax[i] = rm;
       }
-      if (fan.half && i == 0 && threadIdx.x < 100) {
-        double hs, hc;
-        fan_half_dir(threadIdx.x, fan.yaw, hc, hs);
-        fan.half[2 * threadIdx.x] = hc;
-        fan.half[2 * threadIdx.x + 1] = hs;
-      }
+      if (fan.half && i == 0)
+        for (int k = threadIdx.x; k < 100; k += 64 * NW) {   // (a workgroup may be a single wave)
+          double hs, hc;
+          fan_half_dir(k, fan.yaw, hc, hs);
+          fan.half[2 * k] = hc;
+          fan.half[2 * k + 1] = hs;
+        }
     } else {
       dx = dirs[2 * i];
       dy = dirs[2 * i + 1];

@@ -281,7 +281,7 @@ def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda, rou
         got = []
         for i in range(4):
             ego = ego0[:2] + 1.3 * i * np.array([math.cos(yaw0), math.sin(yaw0)])
-            yaw, v = yaw0 + 0.02 * i, 5.0 + 2.0 * i
+            yaw, v = yaw0 + 0.02 * i + (0.33 if i == 3 else 0.0), 5.0 + 2.0 * i
             if ps is not None:
                 out = ps.run(ego, yaw, v)
             else:
@@ -289,11 +289,15 @@ def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda, rou
                 sw.set_agents(*sl.sample(ego, yaw, v).sweep_args(), check=False)
                 out = sw.run(*tr, mode="pair")
             torch.cuda.synchronize()
+            # (the fan tables too: the one-call step writes them inside the ray kernel, whose workgroups may be a single wave
+            # -- a table left partly unwritten would only show at the few rim cells that consult it)
+            fan_d, fan_r, fan_h = sm._fan_buffers()
+            tables = np.concatenate([t.cpu().numpy().ravel() for t in ([fan_d, fan_r, fan_h] if footprint == "polygon" else [fan_d])])
             got.append((out.cost.cpu().numpy().copy(), out.safe.cpu().numpy().copy(), out.pair_f.cpu().numpy().copy(),
-                        sm.cell_class.cpu().numpy().copy(), sl.batch.pos.cpu().numpy().copy(), int(sl.batch.n.item())))
+                        sm.cell_class.cpu().numpy().copy(), sl.batch.pos.cpu().numpy().copy(), int(sl.batch.n.item()), tables))
         results[how] = got
     for a, b in zip(results["stages"], results["one-call"]):
         assert a[5] == b[5] and a[5] > 0
-        for x, y in zip(a[:5], b[:5]):
+        for x, y in zip(a[:5] + (a[6],), b[:5] + (b[6],)):
             assert np.array_equal(x, y, equal_nan=True)
     assert not np.array_equal(results["stages"][0][3], results["stages"][3][3])      # the steps did differ

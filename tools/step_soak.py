@@ -59,8 +59,12 @@ def main():
                         sm.cell_class.cpu().numpy(), sl.batch.pos.cpu().numpy(), sl.batch.len.cpu().numpy(), int(sl.batch.n.item())))
         a, b = got
         assert a[7] == b[7], (i, a[7], b[7])
-        for x, y in zip(a[:7], b[:7]):
-            assert np.array_equal(x, y, equal_nan=True), i
+        names = ("cost", "safe", "pair_f", "pair_i", "cell_class", "agent pos", "agent len")
+        for nm, x, y in zip(names, a[:7], b[:7]):
+            if not np.array_equal(x, y, equal_nan=True):
+                d = np.argwhere(~((x == y) | ((x != x) & (y != y))))
+                raise AssertionError(f"pose {i} ego {ego} yaw {yaw} v {v}: {nm} differs in {len(d)} of {x.size} elements, first at {d[0]}: "
+                                     f"{x[tuple(d[0])]!r} (stages) vs {y[tuple(d[0])]!r} (one call)")
         n_ph += a[7]
     print(f"{n} random poses: the one-call step and the stage calls agree bit for bit ({n_ph / n:.1f} phantoms per step)")
 
