@@ -341,9 +341,10 @@ int fo_scene_spawn_rule_agents(fo_ctx *ctx, int max_points, const double *d_poin
  *      and size of a planning loop is stable); per step the caller updates the ego pose, the window origin and the
  *      spawn range.  NULL-able members are the NULL-able arguments of the single calls.  Stops at the first failing
  *      stage and returns its code.  Every output buffer ends up with the bits the five calls would have written; the
- *      step itself runs in nine launches instead of twelve (the ray fan is worked out inside the ray kernel, the
- *      sampler's candidate cells are flagged during the compaction of the occluded cells, the prediction kernel writes
- *      its slots' rows of the sweep's agent table).  FO_STEP_STAGES=1 in the environment: the plain stage calls.
+ *      step itself runs in eight launches instead of twelve (the ray fan is worked out inside the ray kernel, whose spare
+ *      workgroups also write the sweep's tile table of the candidates; the sampler's candidate cells are flagged during
+ *      the compaction of the occluded cells; the prediction kernel writes its slots' rows of the sweep's agent table).
+ *      FO_STEP_STAGES=1 in the environment: the plain stage calls.
  *      With spawn_mode FO_SPAWN_RULES / FO_SPAWN_BOTH the rule families run between the visibility and the sweep:
  *      fo_scene_spawn_rules (two launches) and fo_scene_spawn_rule_agents (one, which also writes its slots' rows of the
  *      agent table) -- the reference's find_spawn_points -> add_agent flow (interface.py:186-198) without leaving HBM. */

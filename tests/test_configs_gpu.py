@@ -241,7 +241,7 @@ def test_failed_planning_step_leaves_no_half_written_agent_set(torch_cuda):
 
 @pytest.mark.parametrize("routes,footprint", [(0, "polygon"), (2, "circle")])
 def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda, routes, footprint):
-    """fo_step_run / PlanningStep (one FFI crossing per planning step, nine launches: the fan inside the ray kernel, the
+    """fo_step_run / PlanningStep (one FFI crossing per planning step, eight launches: the fan and the tile table inside the ray kernel, the
     candidate flags inside the first compaction, the agent table written by the prediction kernel) gives the bits of the
     five stage calls: cost vectors, flags, pair scalars, phantom set and cell classes, over several ego poses (window
     origin, spawn range and heading change from step to step); with and without route predictions (R slots per
