@@ -34,3 +34,29 @@ def test_sweep_kernel_register_and_lds_budgets(tmp_path):
     assert len(seen) == 17 and (True, 3, True, False) in seen
     for (pair, lists, allm, split), (lds, vgpr) in seen.items():
         assert vgpr <= 168 and 3 * lds <= 160 * 1024, (pair, lists, allm, split, lds, vgpr)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_scene_kernels_have_no_private_segment(tmp_path):
+    """A kernel with a private segment (a stack or spills in scratch memory) is dispatched late: the rule kernel once kept its
+    by-value RuleView argument on a stack -- 284 B per lane, more than the runtime keeps allocated between dispatches at 1 024
+    threads per workgroup -- and every launch paid ~11 us for it.  None of the scene-stage kernels may
+    have one; and the horizon-split instantiations of the sweep (the small planning step) may not either."""
+    csrc = os.path.join(ROOT, "frenetix-occlusion_amd", "csrc")
+    import __graft_entry__ as g
+    for src in ("fo_scene.hip", "fo_sweep.hip"):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.check_call([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + csrc] +
+                              g.HIP_SOURCES[src] + ["-S", "--cuda-device-only", "-o", out, os.path.join(csrc, src)],
+                              stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+        n = 0
+        for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size: (\d+)", txt, re.S):
+            name, scratch = m.group(1), int(m.group(2))
+            if src == "fo_scene.hip":
+                assert scratch == 0, (name, scratch)
+                n += 1
+            elif "fo_sweep_queue_kernel" in name and re.search(r"queue_kernelILb0ELi0ELb\dELb1E", name):   # reduced outputs, split
+                assert scratch == 0, (name, scratch)
+                n += 1
+        assert n >= (12 if src == "fo_scene.hip" else 2), (src, n)
