@@ -152,24 +152,24 @@ def launcher_selftest(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from frenetix_occlusion.distributed import shard_bounds
+    from frenetix_occlusion.distributed import CostGather, shard_bounds
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     M, NC = args.M, 16
-    lo, hi = shard_bounds(M, world, rank)
-    per = -(-M // world)
-    mine = torch.full((per, NC), float("nan"), dtype=torch.float64)
+    cg = CostGather(M, device="cpu")          # the product's split: bounds, pre-allocated blocks, the one collective
+    assert cg.world == world and cg.rank == rank
+    lo, hi, per = cg.lo, cg.hi, cg.per
     rows = torch.arange(lo, hi, dtype=torch.float64)
-    mine[: hi - lo] = rows[:, None] * 16.0 + torch.arange(NC, dtype=torch.float64)[None, :]
-    gathered = torch.empty((world * per, NC), dtype=torch.float64)
+    cg.block().copy_(rows[:, None] * 16.0 + torch.arange(NC, dtype=torch.float64)[None, :])
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dist.all_gather_into_tensor(gathered, mine)
+        cg.gather()
     dist.barrier()
     el = time.perf_counter() - t0
     # rank r's block sits at rows [r per, r per + its length): put the blocks back to back
+    gathered = cg.gathered
     parts = [gathered[r * per: r * per + (shard_bounds(M, world, r)[1] - shard_bounds(M, world, r)[0])] for r in range(world)]
     full = torch.cat(parts)
     want = torch.arange(M, dtype=torch.float64)[:, None] * 16.0 + torch.arange(NC, dtype=torch.float64)[None, :]
@@ -322,6 +322,7 @@ def small_batch_step(local_rank, steps=300):
     ego = sc.ego_initial
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=45.0)
     yaw = float(ego[2])
     ref = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
@@ -508,16 +509,17 @@ def shard_probe(scene, sw, tensors, local_rank, N, steps=200):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        from frenetix_occlusion.distributed import CostGather
         per = -(-M_total // 8)
-        mine = torch.zeros((per, N.NC), dtype=torch.float64, device=f"cuda:{local_rank}")
-        gathered = torch.empty((per, N.NC), dtype=torch.float64, device=f"cuda:{local_rank}")
+        cg1 = CostGather(per, device=torch.device("cuda", local_rank), force=True)    # one rank's block, through RCCL
+        cg1.block().zero_()
         for _ in range(20):
-            dist.all_gather_into_tensor(gathered, mine)
+            cg1.gather()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(100):
-            dist.all_gather_into_tensor(gathered, mine)
+            cg1.gather()
         e1.record()
         torch.cuda.synchronize()
         res["allgather_ms"] = e0.elapsed_time(e1) / 100
@@ -569,7 +571,7 @@ def main():
     import torch
     from frenetix_occlusion import _native as N
     from frenetix_occlusion import synthetic as S
-    from frenetix_occlusion.distributed import shard_bounds
+    from frenetix_occlusion.distributed import CostGather
     from frenetix_occlusion.sweep import MetricSweep
 
     rank = int(os.environ.get("RANK", "0"))
@@ -587,9 +589,19 @@ def main():
     torch.cuda.set_device(dev)
 
     M_total, A, T = args.M, args.A, args.T
-    if scaling == "strong":      # BASELINE configs[3]: ONE batch of --M trajectories, block-partitioned over the ranks
-        lo, hi = shard_bounds(M_total, world, rank)
-        M, per = hi - lo, -(-M_total // world)
+    # The trajectory split is the product's (frenetix_occlusion.distributed.CostGather: block bounds, the two pre-allocated
+    # blocks of the collective, the one all_gather_into_tensor): the step below hands it to PlanningStep / writes its cost
+    # rows into its block.  strong (BASELINE configs[3]): ONE batch of --M trajectories, block-partitioned over the ranks;
+    # weak: every rank its own --M trajectories = block `rank` of a batch of world x M.
+    cg = None
+    if use_dist:
+        cg = CostGather(M_total if scaling == "strong" else M_total * world, device=torch.device("cuda", local_rank),
+                        force=(world == 1))
+        if cg.world != world:
+            raise RuntimeError(f"the process group has {cg.world} ranks, WORLD_SIZE says {world}")
+    if scaling == "strong":
+        lo, hi = (cg.lo, cg.hi) if cg is not None else (0, M_total)
+        M, per = hi - lo, (cg.per if cg is not None else M_total)
     else:
         lo, M, per = 0, M_total, M_total
     ctx = N.Context(local_rank)
@@ -612,6 +624,7 @@ def main():
         ego = sc.ego_initial
         with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
             cfg = yaml.safe_load(f)
+            cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
         cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=45.0)
         ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
         sm = SensorModel(sc.lanelets, ref_path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5,
@@ -629,9 +642,8 @@ def main():
     traj = {k: v[lo:lo + M] for k, v in traj_all.items()} if scaling == "strong" else traj_all
     tx, ty, tth, tv, ta = (d(traj[k]) for k in ("x", "y", "theta", "v", "a"))
     out = None
-    # every rank contributes a block of `per` rows (the last one padded) -- all_gather_into_tensor wants equal blocks
-    mine = torch.full((per, N.NC), float("nan"), dtype=torch.float64, device=dev) if use_dist else None
-    gathered = torch.empty((world * per, N.NC), dtype=torch.float64, device=dev) if use_dist else None
+    # strong scaling through PlanningStep(shard=cg): the step object takes the WHOLE batch and the split, and slices itself
+    full = tuple(d(traj_all[k]) for k in ("x", "y", "theta", "v", "a")) if (cg is not None and scaling == "strong") else None
 
     def scene_stage():
         sm, sl, ego = scene["sm"], scene["sl"], scene["ego"]
@@ -641,25 +653,27 @@ def main():
     planning_steps = {}   # --entry step: one PlanningStep (fo_step_run: the whole step in one native call) per output mode
 
     def step(mode=args.mode, lists=args.lists, res=None, gather=True):
+        sharded_step = full is not None and gather     # (the set-up passes measure the kernel alone: no collective)
         if scene is not None and args.entry == "step" and M > 0:
-            ps = planning_steps.get((mode, lists))
+            ps = planning_steps.get((mode, lists, sharded_step))
             if ps is None:
                 from frenetix_occlusion.step import PlanningStep
-                ps = planning_steps[(mode, lists)] = PlanningStep(scene["sm"], scene["sl"], sw, tx, ty, tth, tv, ta, mode=mode, lists=lists)
+                ps = planning_steps[(mode, lists, sharded_step)] = (
+                    PlanningStep(scene["sm"], scene["sl"], sw, *full, mode=mode, lists=lists, shard=cg) if sharded_step else
+                    PlanningStep(scene["sm"], scene["sl"], sw, tx, ty, tth, tv, ta, mode=mode, lists=lists))
             ego = scene["ego"]
-            res = ps.run(ego[:2], float(ego[2]), float(ego[3]))
+            res = ps.run(ego[:2], float(ego[2]), float(ego[3]))       # (sharded: ends with cg.gather())
+            if sharded_step:
+                return res
         else:
             a_args = scene_stage() if scene is not None else ag
             sw.set_agents(*a_args, check=False)
             if M > 0:
+                if res is None and cg is not None and scaling == "strong":
+                    res = sw.alloc_out(M, T, sw.A, mode, lists, cost=cg.block())    # cost rows straight into the collective's block
                 res = sw.run(tx, ty, tth, tv, ta, mode=mode, out=res, lists=lists)
-        if use_dist and gather:
-            if M == per and M > 0:
-                dist.all_gather_into_tensor(gathered, res.cost)
-            else:
-                if M > 0:
-                    mine[:M].copy_(res.cost)
-                dist.all_gather_into_tensor(gathered, mine)
+        if cg is not None and gather:
+            cg.gather(res.cost if M > 0 else None)      # (no copy when the rows were written into the block)
         return res
 
     # Everything slow on the host side happens first (the first timing() call creates the event pool; the check and the
@@ -723,7 +737,7 @@ def main():
         torch.cuda.synchronize()
         e0.record()
         for _ in range(100):
-            dist.all_gather_into_tensor(gathered, mine if (M != per or M == 0) else out.cost)
+            cg.gather()
         e1.record()
         torch.cuda.synchronize()
         ag_ms = e0.elapsed_time(e1) / 100
@@ -781,7 +795,10 @@ def main():
                                                   else "static rule of fo_sweep_run"),
                        "setup_autotune_ms_per_sweep": {str(k): round(v, 4) for k, v in tune.items()},
                        "boundary_edges": scene["edges"] if scene else None, "rays": 720 if scene else None,
-                       "parallelism": f"traj-shard x{world}", "ranks_seen": dist.get_world_size() if use_dist else 1,
+                       "parallelism": f"traj-shard x{world}", "ranks_seen": cg.world if cg is not None else 1,
+                       "split": (("frenetix_occlusion.distributed.CostGather" + (" inside PlanningStep(shard=...)" if (full is not None and scene is not None and args.entry == "step") else ""))
+                                 if cg is not None else None),
+                       "allgathers_issued": cg.calls if cg is not None else 0,
                        "allgather_ms": ag_ms, "allgather_bytes_per_rank": per * N.NC * 8 if use_dist else None,
                        "build_id": N.build_id()},
             # bound: the unit the committed PMC summary of this library names (HBM only where the counter traffic passes 60 %

@@ -511,7 +511,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   __shared__ double s_c[2], s_yaw, s_pbox[32], s_obsd[2];
   // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
   // oncoming neighbours (adj_left) of the lanelets under every fifth vertex of the reference window.  Flags per lanelet
-  // in ired[0, P): bit0 relevant, bit1 inner.  Every "which lanelet holds this point" below is asked of all lanelets at
+  // in ired[0, P): bit0 relevant, bit1 inner, bit2 holds the obstacle's centre.  Every "which lanelet holds this point" below is asked of all lanelets at
   // once, a thread per (point, lanelet) -- the first lanelet in list order by atomicMin -- instead of one thread walking
   // the polygon table in HBM
   if (v.P > RL_LAT * RL_LAT) return;
@@ -524,7 +524,11 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   __syncthreads();
   for (int p = tid; p < v.P; p += nth) {
     if (rl_in_polygon(v, p, pr.ego_x, pr.ego_y)) atomicMin(&s_ego_ll, p);
-    if (rl_in_polygon(v, p, cx, cy)) { const int q = atomicAdd(&s_nin, 1); if (q < 16) s_in[q] = p; }   // the obstacle's lanelets
+    if (rl_in_polygon(v, p, cx, cy)) {   // the obstacle's lanelets (also flagged: more than sixteen are re-collected in list order below)
+      atomicOr(&ired[p], 4);
+      const int q = atomicAdd(&s_nin, 1);
+      if (q < 16) s_in[q] = p;
+    }
   }
   if (tid < 64) {   // the obstacle's curvilinear position (wave 0)
     double ob_s, ob_d;
@@ -560,8 +564,16 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   if (tid == 0) {
     do {
       if (sqrt((pr.ego_x - cx) * (pr.ego_x - cx) + (pr.ego_y - cy) * (pr.ego_y - cy)) > RL_MAX_DIST_OBST) break;   // :215
-      // the obstacle's lanelets (all that hold its centre) in list order
-      const int n_ob = min(s_nin, 16);
+      // the obstacle's lanelets (all that hold its centre) in list order.  Up to sixteen arrived through the atomic counter
+      // in any order and are sorted; MORE than sixteen (a centre on a pile of overlapping lanelets) would leave a subset that
+      // depends on the arrival order -- and the sixteen workgroups of an obstacle must take identical decisions before their
+      // hand-off ticket below -- so the first sixteen in list order are collected from the flags instead
+      int n_ob = min(s_nin, 16);
+      if (s_nin > 16) {
+        n_ob = 0;
+        for (int p = 0; p < v.P && n_ob < 16; ++p)
+          if (ired[p] & 4) s_in[n_ob++] = p;
+      }
       for (int i = 1; i < n_ob; ++i) {   // (a point lies on a handful of lanelets: insertion sort)
         const int key = s_in[i];
         int j = i - 1;
@@ -1012,7 +1024,10 @@ __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, 
   if (helper && !dyn_rule) return;
   if (!dyn_rule) {
     // the obstacle's own workgroup without the dynamic rule: wave 0 keeps the record's head and the first cross line of the
-    // static rule, wave 1 the second (helper workgroups never touch a record; the selection kernel is the next launch)
+    // static rule, wave 1 the second (helper workgroups of an obstacle WITHOUT the dynamic rule have returned above; with it,
+    // every part clears the two validity words rec[2] / rec[5] in rl_dynamic_rule before its hand-off ticket -- the same value
+    // from sixteen writers, ordered before the last part's results by the fence in front of the ticket; the selection kernel
+    // is the next launch)
     if (wave >= 2) return;
     for (int i = lane; i < RL_REC; i += 64)
       if ((i >= 8 && i < 14) == (wave == 1)) rec[i] = 0.0;
@@ -1251,6 +1266,16 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
   if (!m->d_poly_off) return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn_rules: the map holds no lanelet polygons");
   if (params->win_i0 < 0 || params->win_i1 > n_path || params->win_i1 < params->win_i0)
     return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: reference window [%d, %d) outside the path", params->win_i0, params->win_i1);
+  {
+    // the select kernel compares the maxima BEFORE appending and a dynamic obstacle can yield two points (Q11): what the three
+    // families can emit.  A smaller buffer would silently lose the last points in the reference's order (the turn rule's
+    // pedestrian first) -- phantoms the sweep then never sees.
+    const int can = (params->behind_dynamic ? (params->max_dynamic > 0 ? params->max_dynamic : 0) + 2 : 0) +
+                    (params->behind_static ? (params->max_static > 0 ? params->max_static : 0) + 1 : 0) + (params->behind_turn ? 1 : 0);
+    if (max_out < can)
+      return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: max_out = %d cannot hold the %d spawn points max_dynamic = %d / "
+                     "max_static = %d allow", max_out, can, params->max_dynamic, params->max_static);
+  }
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   int rc;

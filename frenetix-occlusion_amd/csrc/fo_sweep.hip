@@ -61,86 +61,42 @@ __global__ void fo_erf_table_kernel(double2 *tab) {
   tab[i] = make_double2(erf(x0), 1.1283791670955125738961589031 * exp(-x0 * x0));
 }
 
-// Same table, fewer VALU operations (used by the queue kernel): the node index comes from the low word of
-// au * 128 + 1.5 * 2^52 (no rint / convert instruction), and the Taylor polynomial is evaluated in y = x0 d and
-// s = d^2:  erf(x0 + d) = e + g d P,
-//   P = (1 - s/3 + s^2/10) + y (-1 + s/2) + y^2 (2/3 - 2 s/5) - y^3/3 + 2 y^4/15 + O(5th order) ,
-// which is the expansion of fo_erf_lds regrouped (same truncation error, < 3e-16 absolute).
-__device__ __forceinline__ double fo_erf_fast(const double2 *__restrict__ tab, double u) {
-  const double au = fmin(fabs(u), 6.0);
-  const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
-  const double tm = fma(au, ERF_SCALE, MAGIC);
-  const double fi = tm - MAGIC;               // rint(au * 128), exact
-  const int i = __double2loint(tm);           // the same integer, read from the mantissa
-  const double d = fma(fi, -1.0 / ERF_SCALE, au);
-  const double y = (fi * (1.0 / ERF_SCALE)) * d;
-  const double sq = d * d;
-  const double2 e = tab[i];
-  const double a0 = fma(sq, fma(sq, 0.1, -1.0 / 3.0), 1.0);
-  const double a1 = fma(sq, 0.5, -1.0);
-  const double a2 = fma(sq, -0.4, 2.0 / 3.0);
-  double p = fma(y, 2.0 / 15.0, -1.0 / 3.0);
-  p = fma(p, y, a2);
-  p = fma(p, y, a1);
-  p = fma(p, y, a0);
-  return copysign(fma(e.y * d, p, e.x), u);
-}
-
-// The same with the argument already multiplied by 128 (the caller folds the factor into 1/(sigma sqrt 2), once per
-// sample): the node index is the low word of |v| + 1.5 * 2^52, d' = |v| - node is the offset in units of 1/128, and the
-// powers of two that turn d' and y' = node d' back into d and y = x0 d are folded into the coefficients (S = 2^-14 per
-// power of y or s, Q = 2^-7 for the leading d) -- 19 VALU operations instead of 24, no constant that has to be moved
-// into a vector register first.
+// The queue kernel's erf: same nodes, fewer VALU operations.  Its copy of the table in LDS holds (erf(x0), g(x0)/128) and the
+// caller hands over the argument already multiplied by 128 (folded into 1/(sigma sqrt 2), once per sample): the node index is
+// the low word of |v| + 1.5 * 2^52 (no rint / convert instruction), d = |v| - node is the offset in table steps, and the
+// Taylor step is evaluated in y = x0 d_true (= node * d * 2^-14) and s = d^2:
+//   erf(x0 + d_true) = e + g d_true P,   P = (1 - s/3) + y (-1 + s/2) + y^2 (2/3) - y^3/3 + [s^2/10 - 2 s y^2/5 + 2 y^4/15] + ...
+// FO_ERF_ORDER 4 (default) drops the bracket: what is left out is g(x0) d^5 (1/10 - 2 x0^2/5 + 2 x0^4/15), at most 1.13 * 0.1 *
+// 256^-5 = 1.0e-13 per erf, 3e-13 on a collision probability (nine products of two differences, / 12).  The 36 erf of an
+// in-gate sample are the largest single item of the sweep kernel: every instruction here is ~1.2 % of its run time (round 5:
+// 19 -> 16 operations per erf -2.5 %).  The polynomial is grouped so that every fma has at most ONE constant that is not an
+// inline operand (1.0, 2.0): a VOP3 instruction of this chip reads one literal / SGPR pair, and a second constant costs two
+// v_mov_b32 per erf to park it in a register.
+//   P = a0 + y (a1 + u/3),  a0 = 1 - s/3,  a1 = -1 + s/2,  u = y (2 - y)
+// FO_ERF_ORDER 3 (tuning builds): P = a0 + y (-1 + 2 y / 3), 4.3e-11 per erf, 2.5e-10 on a collision probability.
+#ifndef FO_ERF_ORDER
+#define FO_ERF_ORDER 4
+#endif
 __device__ __forceinline__ double fo_erf_fast128(const double2 *__restrict__ tab, double v) {
-  constexpr double S = 0x1p-14, Q = 0x1p-7;
+  constexpr double S = 0x1p-14;
   const double av = fmin(fabs(v), 768.0);
   const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
   const double tm = av + MAGIC;
   const double fi = tm - MAGIC;               // rint(|v|), exact
   const int i = __double2loint(tm);
   const double d = av - fi;
-  const double y = fi * d;
-  const double sq = d * d;
   const double2 e = tab[i];
-  const double a0 = fma(sq, fma(sq, 0.1 * S * S * Q, -(1.0 / 3.0) * S * Q), Q);
-  const double a1 = fma(sq, 0.5 * S * S * Q, -S * Q);
-  const double a2 = fma(sq, -0.4 * S * S * S * Q, (2.0 / 3.0) * S * S * Q);
-  double p = fma(y, (2.0 / 15.0) * S * S * S * S * Q, -(1.0 / 3.0) * S * S * S * Q);
-  p = fma(p, y, a2);
-  p = fma(p, y, a1);
-  p = fma(p, y, a0);
+  const double y = fi * (d * S);
+  const double sq = d * d;
+  const double a0 = fma(sq, -S / 3.0, 1.0);
+#if FO_ERF_ORDER >= 4
+  const double a1 = fma(sq, S / 2.0, -1.0);
+  const double u = y * (2.0 - y);
+  const double p = fma(y, fma(u, 1.0 / 3.0, a1), a0);
+#else
+  const double p = fma(fma(y, 2.0 / 3.0, -1.0), y, a0);
+#endif
   return copysign(fma(e.y * d, p, e.x), v);
-}
-
-// four erf evaluations with the four LDS gathers issued back to back (one lgkmcnt wait instead of four)
-__device__ __forceinline__ void fo_erf_fast4(const double2 *__restrict__ tab, double u0, double u1, double u2, double u3,
-                                             double *out) {
-  const double MAGIC = 6755399441055744.0;
-  const double u[4] = {u0, u1, u2, u3};
-  double au[4], tm[4];
-  double2 e[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    au[i] = fmin(fabs(u[i]), 6.0);
-    tm[i] = fma(au[i], ERF_SCALE, MAGIC);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) e[i] = tab[__double2loint(tm[i])];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const double fi = tm[i] - MAGIC;
-    const double d = fma(fi, -1.0 / ERF_SCALE, au[i]);
-    const double y = (fi * (1.0 / ERF_SCALE)) * d;
-    const double sq = d * d;
-    const double a0 = fma(sq, fma(sq, 0.1, -1.0 / 3.0), 1.0);
-    const double a1 = fma(sq, 0.5, -1.0);
-    const double a2 = fma(sq, -0.4, 2.0 / 3.0);
-    double p = fma(y, 2.0 / 15.0, -1.0 / 3.0);
-    p = fma(p, y, a2);
-    p = fma(p, y, a1);
-    p = fma(p, y, a0);
-    out[i] = copysign(fma(e[i].y * d, p, e[i].x), u[i]);
-  }
 }
 
 // offset of ego field f from a row pointer that already points at the lane's first pair (row base + 2 lane)
@@ -267,6 +223,11 @@ enum { LST_NONE = 0, LST_F64 = 1, LST_F32 = 2, LST_F32X = 3 };   // per-timestep
 // LST_F32X (FO_LISTS_F32_EXACT): float32 elements like LST_F32, but every entry is the float64 result rounded at the store --
 // the arithmetic of LST_F64, the bytes of LST_F32; what the float32 shortcut of LST_F32 saves is the difference of the two
 __host__ __device__ constexpr bool lst_is32(int l) { return l == LST_F32 || l == LST_F32X; }
+// (Round 5, measured and dropped for FO_LISTS_F32_EXACT, all within +-0.5 % of this form: the shape of the float32-list
+// instantiation -- running minima of the logistic arguments, harm maxima from the epilogue -- with float64 list entries from a
+// table exponential of degree 2 on the rows without a gate lane; both logistic values of a sample through one reciprocal; the
+// square root of sample t+1 taken beside the exponentials of sample t.  The instantiation stays pass 2 of the float64 lists
+// with conversions at the store: every entry is the float64-list mode's entry, rounded.)
 __host__ __device__ constexpr bool lst_exact(int l) { return l == LST_F64 || l == LST_F32X; }
 struct SweepArgs {
   int M, Mp, T, A, Ta, n_tiles, nt8, apw;  // apw = agents per wave
@@ -668,8 +629,8 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 //   pass 2 (t loop)  harm + risk + running maxima + coalesced list stores, cp read back from cpbuf.
 // exp() for the logistic models is a 64-entry 2^(j/64) table + degree-5 polynomial (~15 VALU ops).
 // Supports T-1 <= TQ; longer horizons take the generic kernel.
-#ifndef FO_ERF_GROUP
-#define FO_ERF_GROUP 1  // table gathers of the CP boxes issued together (4) or one at a time (1: fewer live registers)
+#ifndef FO_ERF_AFFINE
+#define FO_ERF_AFFINE 1  // erf arguments of the nine boxes by running sums in table units (0: tuning builds, the per-box products)
 #endif
 #ifndef FO_TC
 #define FO_TC 8      // timesteps per chunk of the two-pass scheme (rows of the per-wave cp buffer)
@@ -720,7 +681,10 @@ __device__ __forceinline__ double fo_vmin_neg(double a, double b) {   // min(a, 
 // significant bits, so k * hi is exact for |k| < 2^10 and the dropped tail costs |k| * 2.1e-16 (< 1e-12 relative over
 // the arguments the logistic models produce, z in [-5e3, 6]; a logistic value moves by a quarter of that).  Few distinct
 // float64 constants on purpose: every one of them occupies an SGPR pair for the whole loop.
-template <bool CLAMP = true>
+#ifndef FO_EXP_EARLY_SCALE
+#define FO_EXP_EARLY_SCALE 1
+#endif
+template <bool CLAMP = true, int DEG = 3>
 __device__ __forceinline__ double fo_exp_tab(const double *__restrict__ tab2, double z) {
   if (CLAMP) z = fmin(fmax(z, -700.0), 700.0);  // CLAMP = false: the caller bounds the argument
   const double MAGIC = 6755399441055744.0;                          // 1.5 * 2^52
@@ -729,24 +693,62 @@ __device__ __forceinline__ double fo_exp_tab(const double *__restrict__ tab2, do
   const int k = __double2loint(tm);
   const double r = fma(kf, -0x1.62e42fefa3800p-9, z);               // ln2/256, 43 significant bits
   const double tv = tab2[k & (EXP_N - 1)];
-  double p = fma(r, 1.0 / 6.0, 0.5);
+  double p;
+  if (DEG >= 3) {
+    p = fma(r, 1.0 / 6.0, 0.5);
+    p = fma(p, r, 1.0);
+  } else {
+    p = fma(r, 0.5, 1.0);   // degree 2: remainder r^3/6 < 4.2e-10 relative (a logistic value moves by a quarter of that)
+  }
   p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
+#if FO_EXP_EARLY_SCALE
+  return ldexp(tv, k >> 8) * p;   // the scaling beside the polynomial, not behind it (exact either way)
+#else
   return ldexp(tv * p, k >> 8);
+#endif
+}
+// 1 + exp(z), the denominator of the logistic models: the table entry is scaled while the polynomial is evaluated, and
+// the product and the 1 are one fma -- mul, ldexp, add in a row became ldexp and fma (one instruction less per logistic).
+template <bool CLAMP = true, int DEG = 3>
+__device__ __forceinline__ double fo_exp1p_tab(const double *__restrict__ tab2, double z) {
+#if FO_EXP_EARLY_SCALE
+  if (CLAMP) z = fmin(fmax(z, -700.0), 700.0);
+  const double MAGIC = 6755399441055744.0;
+  const double tm = fma(z, 369.3299304675746, MAGIC);
+  const double kf = tm - MAGIC;
+  const int k = __double2loint(tm);
+  const double r = fma(kf, -0x1.62e42fefa3800p-9, z);
+  const double tv = ldexp(tab2[k & (EXP_N - 1)], k >> 8);
+  double p;
+  if (DEG >= 3) {
+    p = fma(r, 1.0 / 6.0, 0.5);
+    p = fma(p, r, 1.0);
+  } else {
+    p = fma(r, 0.5, 1.0);
+  }
+  p = fma(p, r, 1.0);
+  return fma(tv, p, 1.0);
+#else
+  return 1.0 + fo_exp_tab<CLAMP, DEG>(tab2, z);
+#endif
 }
 
 // 1 / (1 + exp(nz)); v_rcp_f64 (measured ~3e-8 relative) + one Newton step (1.6e-14 against the oracle)
 #ifndef FO_RCP_NR
 #define FO_RCP_NR 1
 #endif
-template <bool CLAMP = true>
+template <bool CLAMP = true, int DEG = 3>
 __device__ __forceinline__ double fo_logistic_neg(const double *__restrict__ tab2, double nz) {
-  const double d = 1.0 + fo_exp_tab<CLAMP>(tab2, nz);
+  const double d = fo_exp1p_tab<CLAMP, DEG>(tab2, nz);
   double y = __builtin_amdgcn_rcp(d);
 #pragma unroll
   for (int i = 0; i < FO_RCP_NR; ++i) y = fma(fma(-d, y, 1.0), y, y);
   return y;
 }
+
+// (Round 5, measured and dropped: both logistic values of a sample through ONE reciprocal -- y = 1/(d1 d2), s1 = y d2,
+// s2 = y d1: a quarter-rate v_rcp_f64 and a Newton step less for three multiplications -- 0.5398 against 0.5410 ms: the chain
+// add -> mul -> rcp -> fma -> fma -> mul is two operations longer than add -> rcp -> fma -> fma, and the chain is what counts.)
 
 // Box probabilities under a CORRELATED covariance (collision_probability.py:117 hands any 2x2 matrix to mvnun).  With
 // L(h, k) = P(X > h, Y > k) for the standardised pair, Drezner & Wesolowsky / Genz write
@@ -1085,6 +1087,27 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           const double rx = qex - qpx, ry = qey - qpy;
           const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
           double acc = 0.0;
+#if FO_ERF_AFFINE
+          // The 36 erf arguments are affine in (mean j, box b, side): in units of the table spacing,
+          //   X(j, b, +-) = (rx - j devx + b bxs +- off_x) 128 / (sigma_x sqrt 2)
+          // -- scaled once per sample, then two running sums and one add per argument instead of an add and a multiplication
+          // (four operations less per box; the arguments move by ~1e-13 of a table step)
+          const double DX = devx * qisx, DY = devy * qisy, BX = bxs * qisx, BY = bys * qisy;
+          const double ox = a.off_x * qisx, oy = a.off_y * qisy;
+          double qx = fma(rx, qisx, DX), qy = fma(ry, qisy, DY);   // j = -1
+#pragma unroll 1
+          for (int jm = 0; jm < 3; ++jm) {
+            double cx = qx - BX, cy = qy - BY;                      // b = -1
+#pragma unroll (SPLIT && !PAIR ? 3 : 1)
+            for (int b = 0; b < 3; ++b) {
+              const double fx = fo_erf_fast128(erf_tab, cx + ox) - fo_erf_fast128(erf_tab, cx - ox);
+              const double fy = fo_erf_fast128(erf_tab, cy + oy) - fo_erf_fast128(erf_tab, cy - oy);
+              acc = fma(fx, fy, acc);
+              cx += BX; cy += BY;
+            }
+            qx -= DX; qy -= DY;
+          }
+#else
 #pragma unroll 1
           for (int jm = -1; jm <= 1; ++jm) {
             const double qx = rx - jm * devx, qy = ry - jm * devy;
@@ -1093,18 +1116,12 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
 #pragma unroll (SPLIT && !PAIR ? 3 : 1)
             for (int b = -1; b <= 1; ++b) {
               const double cx = qx + b * bxs, cy = qy + b * bys;
-#if FO_ERF_GROUP == 4
-              double e4[4];  // the four table gathers of one box are issued together, then evaluated
-              fo_erf_fast4(erf_tab, (cx + a.off_x) * qisx, (cx - a.off_x) * qisx, (cy + a.off_y) * qisy,
-                           (cy - a.off_y) * qisy, e4);
-              acc = fma(e4[0] - e4[1], e4[2] - e4[3], acc);
-#else
               const double fx = fo_erf_fast128(erf_tab, (cx + a.off_x) * qisx) - fo_erf_fast128(erf_tab, (cx - a.off_x) * qisx);
               const double fy = fo_erf_fast128(erf_tab, (cy + a.off_y) * qisy) - fo_erf_fast128(erf_tab, (cy - a.off_y) * qisy);
               acc = fma(fx, fy, acc);
-#endif
             }
           }
+#endif
           // (1/2)(1/2) of the two Phi differences, /3 (:122).  A row poisoned by fo_prep_agents_kernel (no usable
           // covariance: 1/sigma = NaN) must read NaN: the table erf clamps its argument, which would turn the NaN into
           // erf(+-6) and the probability into 0
@@ -1438,7 +1455,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               zon = zc_tab[(cls_o >> sh) & 3u];
             }
             double eh = NAN, oh = NAN, er = NAN, orr = NAN, cp = 0.0;
-            float ehf = NAN, ohf = NAN;   // LST_F32: the harm entries of the lists
+            float ehf = NAN, ohf = NAN;   // float32 lists: the harm entries
             // harm of a sample inside the harm length (wave-uniform)
             auto harm = [&]() {
               if (FO_X & 8) {
@@ -1481,9 +1498,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               }
             };
             const bool hv = (hvrows >> row) & 1u;  // wave-uniform: geo && t < Lh
+            const bool slow_row = (slow >> row) & 1u;
             if (hv) harm();
-            float cpf = 0.0f, erf_ = 0.0f, orf = 0.0f;   // LST_F32: what the lists get (constants on the short branch)
-            if (!((slow >> row) & 1u)) {
+            float cpf = 0.0f, erf_ = 0.0f, orf = 0.0f;   // float32 lists: what they get (constants on the short branch)
+            if (!slow_row) {
               er = 0.0;
               orr = 0.0;
             } else {
@@ -1699,8 +1717,10 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
     const double2 v0 = a.erf_tab[tt], v1 = a.erf_tab[tt + 256], v2 = a.erf_tab[tt + 512];
     const double2 v3 = a.erf_tab[min(tt + 768, ERF_N - 1)];
     const double x0 = a.exp_tab[tt];
-    erf_tab[tt] = v0; erf_tab[tt + 256] = v1; erf_tab[tt + 512] = v2;
-    if (tt + 768 < ERF_N) erf_tab[tt + 768] = v3;
+    // (g / 128: fo_erf_fast128 measures the offset from a node in table steps)
+    erf_tab[tt] = make_double2(v0.x, v0.y * 0x1p-7); erf_tab[tt + 256] = make_double2(v1.x, v1.y * 0x1p-7);
+    erf_tab[tt + 512] = make_double2(v2.x, v2.y * 0x1p-7);
+    if (tt + 768 < ERF_N) erf_tab[tt + 768] = make_double2(v3.x, v3.y * 0x1p-7);
     exp_tab[tt] = x0;
   }
   if (threadIdx.x < 4)
@@ -1923,17 +1943,21 @@ inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 constexpr int AGENT_PAD_ROWS = 256;   // spare rows behind the agent table (unclamped row addresses of the queue kernel)
 
 // one instantiation of the queue kernel per output mode: cost vectors only / + pair scalars / + float64 or float32 lists
+// false: no instantiation for this combination (fo_sweep_run sends those to the generic kernel BEFORE it plans the grid; a
+// change of its conditions must not end in a launch that silently writes nothing)
 template <bool ALLM, bool SPLIT>
-void launch_queue(int lst, bool pair, dim3 g, dim3 b, hipStream_t s, const SweepArgs &a) {
+bool launch_queue(int lst, bool pair, dim3 g, dim3 b, hipStream_t s, const SweepArgs &a) {
   if (lst == LST_F64) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F64, ALLM, SPLIT>), g, b, 0, s, a);
   else if (lst == LST_F32) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F32, ALLM, SPLIT>), g, b, 0, s, a);
   else if (lst == LST_F32X) {
     // one instantiation only (the default metric set on a full grid); fo_sweep_run sends every other case to the generic
     // kernel, which has this arithmetic anyway (float64 throughout, converted at the store)
     if constexpr (ALLM && !SPLIT) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F32X, true, false>), g, b, 0, s, a);
+    else return false;
   }
   else if (pair) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
   else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
+  return true;
 }
 
 // agents per wave in the first phase of the (tapered) grid: long workgroups keep the per-workgroup start-up (table fill,
@@ -2228,10 +2252,13 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
     if (use_queue) {
       const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
       const bool allm = (a.mask & all5) == all5 && a.ablate == 0;
-      if (allm && split) launch_queue<true, true>(lst, d_pair_f != nullptr, g, b, s, a);
-      else if (split) launch_queue<false, true>(lst, d_pair_f != nullptr, g, b, s, a);
-      else if (allm) launch_queue<true, false>(lst, d_pair_f != nullptr, g, b, s, a);
-      else launch_queue<false, false>(lst, d_pair_f != nullptr, g, b, s, a);
+      const bool launched = allm && split ? launch_queue<true, true>(lst, d_pair_f != nullptr, g, b, s, a)
+                            : split       ? launch_queue<false, true>(lst, d_pair_f != nullptr, g, b, s, a)
+                            : allm        ? launch_queue<true, false>(lst, d_pair_f != nullptr, g, b, s, a)
+                                          : launch_queue<false, false>(lst, d_pair_f != nullptr, g, b, s, a);
+      if (!launched)
+        return fo_fail(ctx, FO_E_STATE, "fo_sweep_run: no queue-kernel instantiation for list format %d with allm=%d split=%d "
+                       "(internal: such batches belong to the generic kernel)", lst, (int)allm, (int)split);
     } else {
       if (lst == LST_F64) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_F64>), g, b, 0, s, a);
       else if (lst_is32(lst)) hipLaunchKernelGGL((fo_sweep_generic_kernel<true, LST_F32>), g, b, 0, s, a);   // (converts at the store: exact)

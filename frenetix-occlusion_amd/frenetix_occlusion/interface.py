@@ -11,9 +11,10 @@ per-step stage runs in libfo_hip.so on one MI355X:
 
 Deviations from the reference (documented in DESIGN.md): ``visible_area`` is a ring polygon + cell mask
 (:class:`~frenetix_occlusion.sensor_model.VisibleArea`) instead of a shapely geometry; spawn points come from the
-occluded-cell frontier (``accelerator.spawn.mode: cells``, the default) and / or from the reference's three rule families
-evaluated on the cell classes (``rules`` / ``both``: fo_scene_spawn_rules -> fo_scene_spawn_rule_agents, device resident --
-the spawn points never leave HBM on their way into the sweep, ``spawn_points`` is a lazily read host view); no matplotlib
+reference's three rule families evaluated on the cell classes (``accelerator.spawn.mode: rules``, the default:
+fo_scene_spawn_rules -> fo_scene_spawn_rule_agents, device resident -- the spawn points never leave HBM on their way into
+the sweep, ``spawn_points`` is a list that reads them back when first looked at) and / or from the occluded-cell frontier
+(``cells`` / ``both``: the sampler of the BASELINE configurations, not what the reference spawns); no matplotlib
 (``plot`` is accepted and ignored); metric ``'be'`` implies ``'ttc'`` (the reference raises KeyError when ``'be'`` is
 activated without it).
 """
@@ -72,7 +73,7 @@ class FOInterface:
         self.fo_obstacles = FOObstacles(self.cr_scenario.obstacles)
         spawn_acc = acc.get("spawn") or {}
         routes = int(spawn_acc.get("routes", 0))
-        if routes == 0 and str(spawn_acc.get("mode", "cells")) != "cells":
+        if routes == 0 and str(spawn_acc.get("mode", "rules")) != "cells":
             routes = 3     # the rule families' vehicles follow the routes of their lanelet (agent.py:283-312)
         self.sensor_model = SensorModel(lanelet_network=self.lanelet_network, ref_path=self.ego_reference_path,
                                         sensor_radius=self.sensor_radius, sensor_angle=self.sensor_angle,
@@ -182,7 +183,7 @@ class FOInterface:
         return metrics, safety_assessment
 
     # ---------------------------------------------------------------------------------------- batched entry (new)
-    def trajectory_safety_assessment_batch(self, trajectories, mode="reduced"):
+    def trajectory_safety_assessment_batch(self, trajectories, mode="reduced", shard=None):
         """All candidates of a planning step in one launch.  ``trajectories``: list of trajectory objects
         (``.cartesian.{x,y,theta,v,a}``) or a dict of [M,T] arrays / device tensors.  Returns a
         :class:`~frenetix_occlusion.metrics.metric.BatchAssessment` (``.cost [M,16]``, ``.safe [M]`` on the device), or
@@ -190,10 +191,16 @@ class FOInterface:
         while the phantom set of the step has not been looked at from the host, its size stays in HBM and the sweep runs
         over a possibly empty set -- every trajectory safe as well).  With
         ``mode='full'`` and a list input, later ``trajectory_safety_assessment(t)`` calls for the same objects are
-        served from this batch."""
+        served from this batch.
+
+        ``shard`` (one process per GPU, BASELINE configs[3]): True (the default ``torch.distributed`` group), a process
+        group or a :class:`~frenetix_occlusion.distributed.CostGather` -- every rank runs the same planning step
+        (``evaluate_scenario`` is replicated: cheaper than a broadcast) and calls this with the same candidates; each
+        evaluates its block of them and ONE all-gather of the cost rows gives every rank ``cost [M,16]`` / ``safe [M]`` of
+        all candidates (``distributed.select_trajectory`` then picks the same trajectory everywhere)."""
         remember = trajectories if (mode == "full" and not isinstance(trajectories, dict)) else None
         t0 = time.perf_counter()
-        ba = self.metrics.evaluate_batch(trajectories, mode=mode, remember=remember)
+        ba = self.metrics.evaluate_batch(trajectories, mode=mode, remember=remember, shard=shard)
         self._tick("assessment_batch_ms", t0)
         self.step_timing["assessment_batch_size"] = 0 if ba is None else len(ba)
         return ba

@@ -78,6 +78,13 @@ class BatchAssessment:
     def __init__(self, res: SweepResult, prediction_slots, metric_order, mode):
         self.result = res
         self.cost, self.safe = res.cost, res.safe
+        # A batch split over the ranks of a process group (evaluate_batch(..., shard=...)): `cost` / `safe` / column() cover
+        # ALL trajectories on every rank (the all-gathered cost matrix); the per-pair outputs and result_dict() cover this
+        # rank's rows [rows[0], rows[1]) and are addressed by the LOCAL index m - rows[0]
+        self.rows = res.rows
+        if res.cost_all is not None:
+            self.cost = res.cost_all
+            self.safe = (res.cost_all[:, N.COST["safe"]] > 0.5).to(torch.uint8)
         self.prediction_slots = prediction_slots
         self.metric_order = metric_order
         self.mode = mode
@@ -348,8 +355,14 @@ class Metric:
         self.sweep.set_agents(*arrs, check=bool(getattr(am, "_manual", True) or getattr(am, "_external", True)))
         self._agents_version = 1
 
-    def evaluate_batch(self, trajectories, mode="reduced", remember=None):
-        """one launch for the whole candidate set.  trajectories: list of trajectory objects or dict of [M,T] arrays."""
+    def evaluate_batch(self, trajectories, mode="reduced", remember=None, shard=None):
+        """one launch for the whole candidate set.  trajectories: list of trajectory objects or dict of [M,T] arrays.
+
+        ``shard`` (BASELINE configs[3]): True / a ``torch.distributed`` process group / a
+        :class:`~frenetix_occlusion.distributed.CostGather` -- every rank calls this with the SAME candidate set and the same
+        phantom agents, evaluates its contiguous block of the trajectories and contributes the block's cost rows to one
+        all-gather; the returned assessment's ``cost`` / ``safe`` cover all M trajectories on every rank, its per-pair
+        outputs this rank's rows (``BatchAssessment.rows``)."""
         am = self.agent_manager
         # (a device batch whose live count is still in HBM counts as "may have": asking would stall the step, and a sweep
         # over inactive slots leaves every trajectory safe)
@@ -357,7 +370,24 @@ class Metric:
             return None                                          # metric.py:44-45: ({}, True) for every trajectory
         arr = trajectories_to_arrays(trajectories)
         self._upload_agents()
-        res = self.sweep.run(arr["x"], arr["y"], arr["theta"], arr["v"], arr.get("a"), mode=mode, lists=self.list_storage)
+        cg = None
+        if shard is not None and shard is not False:
+            from ..distributed import as_gather
+            cg = as_gather(shard, len(arr["x"]), device=self.sweep.device)
+        if cg is None:
+            res = self.sweep.run(arr["x"], arr["y"], arr["theta"], arr["v"], arr.get("a"), mode=mode, lists=self.list_storage)
+        else:
+            # this rank's block of the candidates; its cost rows are written straight into the block of the collective
+            lo, hi = cg.lo, cg.hi
+            loc = {k: (None if arr.get(k) is None else arr[k][lo:hi]) for k in ("x", "y", "theta", "v", "a")}
+            T = int(arr["x"].shape[1]) if len(arr["x"]) else 0
+            # (a collective over host memory -- gloo, two ranks on one GPU -- takes a copy of the rows instead)
+            direct = cg.device == self.sweep.device
+            res = self.sweep.alloc_out(hi - lo, T, self.sweep.A, mode, self.list_storage, cost=cg.block() if direct else None)
+            if hi > lo:
+                res = self.sweep.run(loc["x"], loc["y"], loc["theta"], loc["v"], loc["a"], mode=mode, out=res,
+                                     lists=self.list_storage)
+            res.cost_all, res.rows = cg.gather(None if direct or hi == lo else res.cost), (lo, hi)
         _ = self.agent_manager.predictions if mode == "full" else None
         slots = getattr(self.agent_manager, "prediction_slots", None) if mode == "full" else None
         ba = BatchAssessment(res, slots, self.metrics, mode)
@@ -365,7 +395,8 @@ class Metric:
             self._batch = ba
             # strong references: id() is only unique among live objects, and the planner may drop its list and
             # build new trajectory objects (re-sampling at a higher density) before asking for single results
-            self._batch_objs = list(remember)
+            # (a sharded batch remembers this rank's block: the per-trajectory results of the others live on their ranks)
+            self._batch_objs = list(remember) if cg is None else list(remember)[cg.lo:cg.hi]
             self._batch_ids = {id(t): i for i, t in enumerate(self._batch_objs)}
         return ba
 

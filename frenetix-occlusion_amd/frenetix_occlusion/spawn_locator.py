@@ -11,7 +11,7 @@ phantom set never leaves HBM between sampling and the metric sweep.
 """
 import bisect
 import math
-from collections.abc import Sequence
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -65,12 +65,23 @@ class PhantomBatch:
     rule_points: Optional[torch.Tensor] = None   # [n_rule_points, 8] records of fo_scene_spawn_rules
     rule_n: Optional[torch.Tensor] = None        # int32 [1]
     _host: Optional[dict] = None                 # host copy of the head for the current step (lazy views)
+    _pending: Optional[object] = None            # weak reference to the step's unread LazySpawnPoints
+    step: int = 0                                # planning steps queued on this batch (bumped by invalidate)
 
     def sweep_args(self):
         return self.pos, self.yaw, self.v, self.cov, self.shape, self.raw_dims, self.type, self.len
 
     def invalidate(self):
+        """called before the NEXT step's kernels are queued on these buffers.  A lazily read spawn-point list of the step
+        that ends here which somebody still holds (a planner that logs or plots ``spawn_points`` late) is read back now,
+        while the buffers still hold its step -- the locator and the interface have dropped their own references by then, so
+        a live weak reference means an outside holder; nobody holding one costs nothing."""
+        old = self._pending() if self._pending is not None else None
+        if old is not None:
+            old._get()
+        self._pending = None
         self._host = None
+        self.step += 1
 
     def host_head(self):
         """dict(n, rule_n, pos0 [agents,2], yaw0 [agents], rule_points [n_rule_points,8], type [slots]) on the host with ONE
@@ -94,34 +105,73 @@ class PhantomBatch:
         return list(range(h["n"])) + [self.n_cell_agents + i for i in range(h["rule_n"])]
 
 
-class LazySpawnPoints(Sequence):
+class LazySpawnPoints(list):
     """``FOInterface.spawn_points`` / the result of ``find_spawn_points(lazy=True)``: the reference's list of
     :class:`SpawnPoint` (interface.py:186), read back from the device when it is first looked at -- the planning step
-    itself never waits for it."""
+    itself never waits for it.
 
-    def __init__(self, build):
-        self._build, self._items = build, None
+    A ``list`` subclass (the reference returns a plain list: ``isinstance(x, list)``, ``x + [...]``, ``[...] + x``, ``in``,
+    slicing, ``==``, ``sorted`` ... keep working): every Python-level access fills the list's own storage once.  C code
+    that reads a list's storage directly without going through its methods (``json.dumps``) sees what has been filled so
+    far -- call ``len()`` first.  A list that is still unread when the next planning step is queued on the same buffers is
+    read back at that moment (``PhantomBatch.invalidate``), so a late reader gets ITS step's points; one that was created
+    for a step whose buffers are gone raises."""
+
+    def __init__(self, build, batch=None):
+        super().__init__()
+        self._build, self._batch = build, batch
+        self._step = batch.step if batch is not None else None
+
+    @property
+    def materialised(self):
+        return self._build is None
 
     def _get(self):
-        if self._items is None:
-            self._items = list(self._build())
-            self._build = None
-        return self._items
+        if self._build is not None:
+            if self._batch is not None and self._batch.step != self._step:
+                raise RuntimeError("LazySpawnPoints: the device buffers of this list's planning step have been reused "
+                                   "(the list was not alive when the next step was queued)")
+            build, self._build, self._batch = self._build, None, None
+            list.extend(self, build())
+        return self
 
-    def __len__(self):
-        return len(self._get())
+    def _f(name):     # noqa: N805 -- every read-side list method fills the storage first
+        base = getattr(list, name)
 
-    def __getitem__(self, i):
-        return self._get()[i]
+        def method(self, *a, **k):
+            self._get()
+            return base(self, *a, **k)
+        method.__name__ = name
+        return method
 
-    def __iter__(self):
-        return iter(self._get())
+    for _n in ("__len__", "__getitem__", "__iter__", "__contains__", "__reversed__", "__add__", "__mul__", "__rmul__",
+               "__iadd__", "__imul__", "__setitem__", "__delitem__", "__lt__", "__le__", "__gt__", "__ge__",
+               "append", "extend", "insert", "pop", "remove", "clear", "index", "count", "sort", "reverse", "copy"):
+        locals()[_n] = _f(_n)
+    del _n, _f
+
+    def __radd__(self, other):
+        return list(other) + list(self._get())
 
     def __eq__(self, other):
-        return self._get() == (other._get() if isinstance(other, LazySpawnPoints) else other)
+        self._get()
+        if isinstance(other, LazySpawnPoints):
+            other._get()
+        return list.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __bool__(self):
+        return len(self) > 0
 
     def __repr__(self):
-        return repr(self._get())
+        return list.__repr__(self._get())
+
+    def __reduce__(self):
+        return (list, (list(self._get()),))
 
 
 class SpawnLocator:
@@ -149,11 +199,15 @@ class SpawnLocator:
         self.dt = float(dt)
         self.T = int(horizon / self.dt) + 1                      # agent.py:496
         self.min_ahead = float(acc.get("min_ahead", MIN_AHEAD))
-        self.mode = str(acc.get("mode", "cells"))                  # "cells" | "rules" | "both" (fo_scene_spawn_rules)
+        self.mode = str(acc.get("mode", "rules"))                  # "rules" (the reference's semantics) | "cells" | "both"
         if self.mode not in ("cells", "rules", "both"):
             raise ValueError("accelerator.spawn.mode must be 'cells', 'rules' or 'both'")
-        # capacity of the rule families' output (the reference's YAML maxima allow 2 + 2 + 1 points, Q11)
-        self.max_rule_points = int(acc.get("max_rule_points", 8))
+        # capacity of the rule families' output: the maxima of the YAML are compared with '>' BEFORE appending and a dynamic
+        # obstacle can yield a Car and a Bicycle (Q11, spawn_locator.py:212,304-309,365), so the three families emit up to
+        # (max_dynamic + 2) + (max_static + 1) + 1 points -- never less room than that, whatever the YAML says
+        sl_cfg = (config.get("spawn_locator") or {}) if isinstance(config, dict) else {}
+        self.max_rule_points = max(int(acc.get("max_rule_points", 8)),
+                                   int(sl_cfg.get("max_dynamic_spawn_points", 1)) + int(sl_cfg.get("max_static_spawn_points", 1)) + 4)
         self.routes = int(acc.get("routes", 0)) if sensor_model.route_table is not None else 0
         if self.routes == 0 and sensor_model.route_table is not None and self.mode != "cells":
             self.routes = int(sensor_model.route_table.R)       # rule vehicles follow their lanelet's routes (agent.py:283-312)
@@ -414,7 +468,8 @@ class SpawnLocator:
         if self.mode in ("rules", "both"):
             self.queue_rules(ego_pos, ego_orientation, ego_pos_cl, ego_v)
         if lazy:
-            self.spawn_points = LazySpawnPoints(lambda: self._materialize(b))
+            self.spawn_points = LazySpawnPoints(lambda: self._materialize(b), b)
+            b._pending = weakref.ref(self.spawn_points)
         else:
             self.spawn_points = self._materialize(b)
         return self.spawn_points

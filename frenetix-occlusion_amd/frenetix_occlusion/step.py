@@ -3,7 +3,7 @@ and / or the reference's spawn rule families + predictions -> agent table -> met
 
 ``PlanningStep`` binds a :class:`SensorModel`, a :class:`SpawnLocator`, a :class:`MetricSweep` (one ego, one context) and
 the candidate-trajectory tensors of a planning loop; :meth:`run` updates the handful of per-step scalars in a
-structure that was filled once and crosses the FFI once -- the results of the stage-by-stage calls bit for bit, in nine
+structure that was filled once and crosses the FFI once -- the results of the stage-by-stage calls bit for bit, in eight
 kernel launches instead of their twelve and without their five ctypes crossings (~90 converted arguments, ~90 us of host
 time per step; a step of the reference's own size needs ~90 us of GPU time).  Nothing is read back: the cost vectors
 and flags stay in HBM.
@@ -18,7 +18,12 @@ from .sweep import SweepResult
 
 
 class PlanningStep:
-    def __init__(self, sensor_model, spawn_locator, sweep, x, y, theta, v, a=None, mode="reduced", lists="f64"):
+    def __init__(self, sensor_model, spawn_locator, sweep, x, y, theta, v, a=None, mode="reduced", lists="f64", shard=None):
+        """``shard`` (BASELINE configs[3]: one process per GPU, every rank builds the same step): True / a process group / a
+        :class:`~frenetix_occlusion.distributed.CostGather` for the batch size -- this rank's step covers its contiguous
+        block of the candidates (scene stage and phantoms replicated), writes the block's cost rows into the collective's
+        block and :meth:`run` ends with the ONE all-gather of the path: ``out.cost_all`` = cost [M_total, 16] on every rank,
+        ``out.rows`` = this rank's rows; every other output holds those rows only."""
         if not (sensor_model.ctx is spawn_locator.ctx is sweep.ctx):
             raise ValueError("PlanningStep: the three stages must share one context (one ego, one GPU)")
         if mode not in ("reduced", "pair", "full"):
@@ -29,6 +34,12 @@ class PlanningStep:
         dev = sweep.device
         t = lambda q: None if q is None else torch.as_tensor(q).to(device=dev, dtype=torch.float64).contiguous()
         self.traj = [t(x), t(y), t(theta), t(v), t(a)]
+        self.gather = None
+        if shard is not None and shard is not False:
+            from .distributed import as_gather
+            self.gather = as_gather(shard, int(self.traj[0].shape[0]), device=dev)
+            lo, hi = self.gather.lo, self.gather.hi
+            self.traj = [None if q is None else q[lo:hi] for q in self.traj]      # (row blocks of [M,T]: still contiguous)
         self.M, self.T = int(self.traj[0].shape[0]), int(self.traj[0].shape[1])
         if spawn_locator.batch is None:
             spawn_locator.batch = spawn_locator._alloc()
@@ -37,8 +48,14 @@ class PlanningStep:
         if lists not in N.LIST_FORMAT:
             raise ValueError(f"unknown list format '{lists}'")
         ldt = torch.float64 if lists == "f64" else torch.float32
-        self.out = SweepResult(cost=torch.empty((self.M, N.NC), dtype=torch.float64, device=dev),
+        # (the cost rows go straight into the collective's block when that lives on this GPU -- RCCL; a collective over host
+        # memory -- gloo -- takes a copy of them in run())
+        self._direct = self.gather is not None and self.gather.device == dev
+        self.out = SweepResult(cost=(self.gather.block() if self._direct else
+                                     torch.empty((self.M, N.NC), dtype=torch.float64, device=dev)),
                                safe=torch.empty((self.M,), dtype=torch.uint8, device=dev))
+        if self.gather is not None:
+            self.out.rows = (self.gather.lo, self.gather.hi)
         if mode in ("pair", "full"):
             self.out.pair_f = torch.empty((N.NPF, A, self.M), dtype=torch.float64, device=dev)
             self.out.pair_i = torch.empty((N.NPI, A, self.M), dtype=torch.int32, device=dev)
@@ -128,4 +145,7 @@ class PlanningStep:
         sm.occluded_idx_buffer, sm.n_occluded = b["occ"], b["n_occ"]
         self.sw.A, self.sw.Ta = int(self.batch.pos.shape[0]), sl.T
         self.ctx.list_format = self.lists
+        if self.gather is not None:
+            # the one collective of the path, queued behind the step
+            self.out.cost_all = self.gather.gather(None if self._direct or self.M == 0 else self.out.cost)
         return self.out

@@ -37,6 +37,10 @@ class SweepResult:
     pair_i: Optional[torch.Tensor] = None  # [4, A, M] int32
     lists_raw: Optional[torch.Tensor] = None  # [5 A (T-1) M] float64 (or float32, lists="f32"), layout of include/fo_hip.h
     lists_shape: tuple = (0, 0, 0)         # (A, T-1, M)
+    # trajectory batch split over the ranks of a process group (distributed.CostGather): every output above holds this
+    # rank's rows [rows[0], rows[1]) of the batch; cost_all is the all-gathered cost matrix [M_total, 16] of every rank
+    cost_all: Optional[torch.Tensor] = None
+    rows: Optional[tuple] = None
 
     def list_views(self):
         """five strided [A, T-1, M] views (no copy), order of ``_native.LST``"""
@@ -131,6 +135,20 @@ class MetricSweep:
         if check:
             self.ctx.call("fo_sweep_check", self._stream())
 
+    def alloc_out(self, M, T, A, mode, lists="f64", cost=None) -> SweepResult:
+        """output buffers of one batch shape; ``cost``: a caller's [M,16] float64 block to write the cost rows into (the
+        block a rank contributes to the all-gather of a sharded batch, distributed.CostGather.block)"""
+        ldt = torch.float64 if lists == "f64" else torch.float32
+        out = SweepResult(cost=cost if cost is not None else torch.empty((M, N.NC), dtype=torch.float64, device=self.device),
+                          safe=torch.empty((M,), dtype=torch.uint8, device=self.device))
+        if mode in ("pair", "full"):
+            out.pair_f = torch.empty((N.NPF, A, M), dtype=torch.float64, device=self.device)
+            out.pair_i = torch.empty((N.NPI, A, M), dtype=torch.int32, device=self.device)
+        if mode == "full":
+            out.lists_raw = torch.empty((N.NL * A * max(T - 1, 0) * M,), dtype=ldt, device=self.device)
+        out.lists_shape = (A, max(T - 1, 0), M)
+        return out
+
     def _check_out(self, out, M, T, A, mode, ldt=torch.float64):
         """a reused SweepResult must match the batch: the kernels write with the strides of the *current* M/A/T"""
         want = {"cost": ((M, N.NC), torch.float64), "safe": ((M,), torch.uint8),
@@ -175,13 +193,7 @@ class MetricSweep:
         if out is not None:
             self._check_out(out, M, T, A, mode, ldt)
         else:
-            out = SweepResult(cost=torch.empty((M, N.NC), dtype=torch.float64, device=self.device),
-                              safe=torch.empty((M,), dtype=torch.uint8, device=self.device))
-            if mode in ("pair", "full"):
-                out.pair_f = torch.empty((N.NPF, A, M), dtype=torch.float64, device=self.device)
-                out.pair_i = torch.empty((N.NPI, A, M), dtype=torch.int32, device=self.device)
-            if mode == "full":
-                out.lists_raw = torch.empty((N.NL * A * max(T - 1, 0) * M,), dtype=ldt, device=self.device)
+            out = self.alloc_out(M, T, A, mode, lists)
         p = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
         self._last_inputs = (x, y, theta, v, a)
         if autotune:

@@ -294,7 +294,10 @@ typedef struct {
  * occludes, bit2 dynamic role, bit3 type bicycle or pedestrian), d_obst_vis [O] = visible_objects_timestep of
  * fo_scene_visibility.  Output d_out [max_out][8]: type (FO_TYPE_*), x, y, orientation (NaN = to be derived,
  * agent.py:475-481), curvilinear s, d (NaN = none), source (1 behind dynamic obstacle, 2 behind static obstacle, 3 left
- * turn, 4 right turn), obstacle index (-1 = none), in the reference's order (dynamic, static, turn); d_n_out [1]. */
+ * turn, 4 right turn), obstacle index (-1 = none), in the reference's order (dynamic, static, turn); d_n_out [1].
+ * max_out must hold what the maxima allow -- (max_dynamic + 2) + (max_static + 1) + 1 points with all three families
+ * switched on: the reference compares its maxima before it appends, and one dynamic obstacle can yield a Car and a Bicycle
+ * (spawn_locator.py:212,304-309,365) -- else FO_E_ARG (a short buffer would drop the last points unnoticed). */
 int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, int n_path,
                          const double *d_path6, int O, const double *d_ocorn, const double *d_ocen, const double *d_oyaw,
                          const double *d_odims, const uint8_t *d_oflags, const uint8_t *d_obst_vis,

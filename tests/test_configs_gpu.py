@@ -30,6 +30,7 @@ def _interface(tmp_path, scenario_file, ego, metrics=None, thresholds=None, spaw
     from frenetix_occlusion import synthetic as SY
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     if metrics:
         cfg["metrics"]["activated_metrics"] = list(metrics)
     if thresholds:
@@ -165,6 +166,7 @@ def test_config3_headline_step_full_outputs_vs_oracle_on_every_pair(torch_cuda, 
     ego = sc.ego_initial
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=45.0)
     ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
     sm = SensorModel(sc.lanelets, ref_path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx)
@@ -218,6 +220,7 @@ def test_failed_planning_step_leaves_no_half_written_agent_set(torch_cuda):
     ego0 = sc.ego_initial
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True)
     yaw0 = float(ego0[2])
     ref = ego0[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw0), math.sin(yaw0)]])
@@ -262,6 +265,7 @@ def test_planning_step_in_one_native_call_equals_the_stage_calls(torch_cuda, rou
     ego0 = sc.ego_initial
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     cfg["accelerator"]["spawn"].update(max_agents=A // max(routes, 1), all_occluded=True, routes=routes)
     if routes:
         cfg["accelerator"]["spawn"]["pattern"] = ["Car", "Bicycle", "Pedestrian", "Car"]

@@ -1,0 +1,146 @@
+"""The trajectory split of BASELINE configs[3] on the product path, on the GPU: ``Metric.evaluate_batch`` /
+``FOInterface.trajectory_safety_assessment_batch`` / ``PlanningStep`` with ``shard=`` over ``distributed.CostGather``.
+
+* world size 1 through RCCL (backend "nccl") in this process: the HIP sweep writes its cost rows into the collective's block,
+  ``all_gather_into_tensor`` runs, results bit-identical to the unsharded call;
+* two ranks on ONE GPU (what this box has), collective over gloo: block partition + HIP sweep per rank + one all-gather,
+  bit-identical to the single-process result, the same trajectory picked on every rank;
+* two ranks on two GPUs over RCCL: skipped unless ``torch.cuda.device_count() >= 2``.
+Children are separate processes started with their RANK / WORLD_SIZE environment before they touch a GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def nccl_world1(torch_cuda):
+    import torch.distributed as dist
+    own = not dist.is_initialized()
+    if own:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch_cuda.device("cuda", 0))
+    yield dist
+    if own:
+        dist.destroy_process_group()
+
+
+def test_world_size_one_nccl_sharded_sweep_is_bit_identical(torch_cuda, nccl_world1):
+    torch = torch_cuda
+    from frenetix_occlusion import distributed as D
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.metrics.metric import Metric
+    assert nccl_world1.get_backend() == "nccl" and nccl_world1.get_world_size() == 1
+    M, A = 1000, 24
+    traj, agents = S.make_batch(M, A, config_id=31)
+
+    class AM:       # the agent registry as far as Metric needs it
+        dt = 0.1
+        _manual = False
+        _external = False
+
+        def has_phantoms(self):
+            return True
+
+        def sweep_arrays(self):
+            return [agents[k] for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "type", "len")]
+
+        predictions = {}
+
+    cfg = {"activated_metrics": ["hr", "ttc", "ttce", "dce", "wttc", "cp"],
+           "metric_thresholds": {"harm": 0.3, "risk": 0.2, "be": None, "cp": None, "ttc": None, "wttc": None, "ttce": None, "dce": None}}
+    me = Metric(cfg, S.VEHICLE_BMW320I, AM())
+    plain = me.evaluate_batch(traj, mode="pair")
+    torch.cuda.synchronize()
+    want = [t.cpu().numpy().copy() for t in (plain.cost, plain.safe, plain.result.pair_f, plain.result.pair_i)]
+    cg = D.CostGather(M, force=True)         # world size 1, but THROUGH the collective (RCCL)
+    assert cg.collective and cg.device.type == "cuda" and (cg.lo, cg.hi, cg.per) == (0, M, M)
+    ptrs = (cg.mine.data_ptr(), cg.gathered.data_ptr())
+    for i in range(3):
+        ba = me.evaluate_batch(traj, mode="pair", shard=cg)
+    torch.cuda.synchronize()
+    assert cg.calls == 3 and ptrs == (cg.mine.data_ptr(), cg.gathered.data_ptr())
+    assert ba.result.cost.data_ptr() == cg.mine.data_ptr()            # the sweep wrote into the collective's block
+    assert ba.cost.data_ptr() == cg.gathered.data_ptr() and ba.rows == (0, M)
+    got = [t.cpu().numpy() for t in (ba.cost, ba.safe, ba.result.pair_f, ba.result.pair_i)]
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g, equal_nan=True)
+    assert D.select_trajectory(ba.cost) == D.select_trajectory(plain.cost)
+    # shard=True: the default group, no forced collective at world size 1 -- same numbers
+    ba2 = me.evaluate_batch(traj, mode="reduced", shard=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(ba2.cost.cpu().numpy(), want[0], equal_nan=True)
+    with pytest.raises(ValueError):
+        me.evaluate_batch(traj, mode="reduced", shard=D.CostGather(M + 1))
+
+
+def _run_ranks(tmp_path, world, backend, M=333):
+    port = _free_port()
+    out = str(tmp_path / f"dist_{backend}_{world}.npz")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--backend", backend,
+                                       "--M", str(M), "--out", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    return np.load(out)
+
+
+def _check(z, world, M):
+    assert int(z["world"]) == world and int(z["n_agents"]) > 0
+    assert z["cost_iface"].shape == (M, 16)
+    assert np.array_equal(z["cost_iface"], z["ref_cost"], equal_nan=True)          # gathered == unsharded, bit for bit
+    assert np.array_equal(z["safe_iface"], z["ref_safe"])
+    assert np.array_equal(z["cost_step"], z["ref_cost_step"], equal_nan=True)
+    assert np.array_equal(z["cost_step"], z["ref_cost"], equal_nan=True)           # the one-call step and the stage calls agree too
+    assert int(z["pick"]) == int(z["ref_pick"])
+    lo, hi = (int(q) for q in z["rows"])
+    assert (lo, hi) == (0, -(-M // world))
+    assert np.array_equal(z["local_pair"], z["ref_pair"][:, :, lo:hi], equal_nan=True)   # per-pair outputs: the rank's own rows
+
+
+def test_two_ranks_on_one_gpu_shard_the_planning_step(torch_cuda, tmp_path):
+    z = _run_ranks(tmp_path, 2, "gloo", M=333)
+    _check(z, 2, 333)
+
+
+def test_two_ranks_two_gpus_rccl(torch_cuda, tmp_path):
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device); the one-GPU form of the same worker ran above")
+    z = _run_ranks(tmp_path, 2, "nccl", M=333)
+    _check(z, 2, 333)

@@ -76,6 +76,7 @@ def test_interface_entry_and_empty_batch(torch_cuda, tmp_path):
     from frenetix_occlusion import interface, scenario as S, synthetic as SY
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     p = tmp_path / "occ.yaml"
     p.write_text(yaml.safe_dump(cfg))
     sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))

@@ -282,6 +282,83 @@ def test_pedestrian_heading_without_a_given_orientation_known_answers():
     np.testing.assert_allclose(p[10] - p[0], [round(1.4 * math.cos(c.initial_orientation), 3), round(1.4 * math.sin(c.initial_orientation), 3)], atol=1e-12)
 
 
+HEADING_KAT = [((4.0, 3.0), 1.5 * math.pi), ((4.0, -2.0), 0.5 * math.pi), ((13.0, 5.0), math.pi), ((12.0, -2.0), 0.75 * math.pi),
+               ((-3.0, 4.0), 2.0 * math.pi - math.atan2(4.0, 3.0)), ((10.0, 14.0), 1.5 * math.pi),
+               ((8.0, 3.0), 0.0), ((9.5, 0.25), 1.5 * math.pi)]      # inside the corner: the nearer leg wins
+
+
+def test_pedestrian_heading_known_answers_hold_for_the_oracle_as_well(oracle):
+    """the same closed-form cases (an L-shaped path: left / right of a leg, inside and outside the kink, beyond both ends)
+    for the checker of the device kernels, oracle/fo_oracle_scene.c fo_oracle_spawn_headings -- and for the host path, so
+    that the three statements of agent.py:475-481 (host numpy, C oracle, HIP kernel: tests/test_rules_step_gpu.py) hang on
+    one list of known answers"""
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.agent import FOAgentManager
+    path = np.array([[0.0, 0.0], [10.0, 0.0], [10.0, 10.0]])
+    pos = np.array([p for p, _ in HEADING_KAT])
+    want = np.array([a for _, a in HEADING_KAT])
+    got = oracle.spawn_headings(pos, np.full(len(pos), 4, dtype=np.int32), path)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-15)
+    cfg = {"pedestrian": {"length": 0.3, "width": 0.5, "default_velocity": 1.4},
+           "prediction": {"variance_factor": 1.05, "size_factor_length_s": 1.2, "size_factor_width_s": 1.3,
+                          "size_factor_length_l": 1.4, "size_factor_width_l": 2.5}}
+    am = FOAgentManager(S.Scenario(0.1, [], []), path, cfg, 0, device="cpu")
+    np.testing.assert_allclose([am._heading_towards_path(q) for q in pos], want, rtol=0, atol=1e-15)
+
+
+def test_ego_intention_thresholds_on_circular_arcs():
+    """spawn_locator.py:729-741: left turn if max curvature > 0.10, right turn if min < -0.10, by
+    compute_curvature_from_polyline [ext: np.gradient of the coordinates w.r.t. the path length, twice].  On a circle sampled
+    at equal steps the central differences return the radius exactly (every interior vertex: kappa), the one-sided ends
+    kappa/2 and 3 kappa/4 -- so arcs of kappa = +-0.09 read "straight ahead" and +-0.11 a turn at the reference path's
+    spacings, and the decision does not hinge on the ends."""
+    from frenetix_occlusion.utils.curvilinear import curvature
+    for kappa in (0.09, -0.09, 0.11, -0.11):
+        for ds in (0.2, 0.5, 1.0):
+            n = int(40.0 / ds) + 1                      # the 40 m window of spawn_locator.py:678-693
+            s = np.arange(n) * ds
+            R, sg = 1.0 / abs(kappa), math.copysign(1.0, kappa)
+            xy = np.stack((R * np.sin(s / R), sg * R * (1.0 - np.cos(s / R))), -1)
+            k = curvature(xy)
+            np.testing.assert_allclose(k[2:-2], kappa, rtol=1e-9)
+            assert abs(k[0]) == pytest.approx(abs(kappa) / 2, rel=2e-3) and abs(k[1]) == pytest.approx(0.75 * abs(kappa), rel=2e-3)
+            intention = "left turn" if k.max() > 0.10 else "right turn" if k.min() < -0.10 else "straight ahead"
+            assert intention == {0.09: "straight ahead", -0.09: "straight ahead", 0.11: "left turn", -0.11: "right turn"}[kappa]
+    # a straight lead-in in front of the arc (what a planner's route looks like) does not change the decision
+    lead = np.stack((np.linspace(-10.0, -0.5, 20), np.zeros(20)), -1)
+    s = np.arange(41) * 0.5
+    for kappa, want in ((0.11, "left turn"), (-0.11, "right turn"), (0.09, "straight ahead")):
+        R, sg = 1.0 / abs(kappa), math.copysign(1.0, kappa)
+        xy = np.concatenate((lead, np.stack((R * np.sin(s / R), sg * R * (1.0 - np.cos(s / R))), -1)))
+        k = curvature(xy)
+        assert ("left turn" if k.max() > 0.10 else "right turn" if k.min() < -0.10 else "straight ahead") == want
+
+
+def test_lazy_spawn_points_behave_like_the_references_list():
+    """FOInterface.spawn_points is a list (interface.py:186) that fills itself from the device on first use"""
+    import json
+    from frenetix_occlusion.spawn_locator import LazySpawnPoints, PhantomBatch
+    calls = []
+    x = LazySpawnPoints(lambda: (calls.append(1), [3, 1, 2])[1])
+    assert isinstance(x, list) and not x.materialised and calls == []
+    assert x + [4] == [3, 1, 2, 4] and [0] + x == [0, 3, 1, 2] and calls == [1]
+    assert len(x) == 3 and x[1:] == [1, 2] and 2 in x and sorted(x) == [1, 2, 3] and x == [3, 1, 2] and bool(x)
+    assert json.dumps(x) == "[3, 1, 2]" and calls == [1] and x.materialised
+    assert not LazySpawnPoints(lambda: []) and LazySpawnPoints(lambda: []) == []
+    # a list whose step's buffers were reused before anybody held it raises instead of returning the next step's points;
+    # one that is still alive when the next step is queued is read back at that moment
+    import weakref
+    b = PhantomBatch(*([None] * 12))
+    y = LazySpawnPoints(lambda: ["step 0"], b)
+    b._pending = weakref.ref(y)
+    b.invalidate()
+    assert y.materialised and y == ["step 0"]
+    z = LazySpawnPoints(lambda: ["step 1"], b)
+    b.step += 1                         # (as if the list had not been registered)
+    with pytest.raises(RuntimeError):
+        len(z)
+
+
 def test_lazy_result_dicts_never_leak_placeholders_through_dict_fast_paths():
     """The per-trajectory result is a dict SUBCLASS with lazily built values (metrics/metric.py); CPython copies a dict
     subclass through C shortcuts that bypass ``__getitem__`` unless ``__iter__`` is overridden.  Every way a planner may

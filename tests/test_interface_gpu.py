@@ -30,6 +30,7 @@ def _setup(tmp_path, thresholds=None, max_agents=16, metrics=None, include_real_
     from frenetix_occlusion import synthetic as SY
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     cfg["accelerator"]["spawn"]["max_agents"] = max_agents
     cfg["accelerator"]["include_real_agents"] = include_real_agents
     if thresholds:
@@ -160,6 +161,7 @@ def test_rule_based_spawn_points_through_the_interface(torch_cuda, oracle, tmp_p
     from frenetix_occlusion import synthetic as SY
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario3_geometry.npz"))
     by = {l.lanelet_id: l for l in sc.lanelets}
     parts = [by[1].center]

@@ -152,10 +152,14 @@ def _device_agents(b):
     return h, dict(pos=pos, yaw=yaw, v=v, cov=cov, shape=shape, raw=raw, type=typ, len=ln)
 
 
-def test_rule_agents_on_the_device_equal_the_host_add_agent_flow(torch_cuda):
+def test_rule_agents_on_the_device_equal_the_host_add_agent_flow(torch_cuda, oracle):
+    """... and, for the rule families' Cars and Bicycles, the C oracle's route predictions (fo_oracle_route_predictions: the
+    checker of the cell sampler's vehicles, pinned by tests/golden/routes.npz and sampling_matrix.npz) from the same spawn
+    pose, the lanelet under it and the map's route table -- an anchor outside the product for the vehicle half"""
     torch = torch_cuda
+    from frenetix_occlusion import scenario as SCN
     from frenetix_occlusion.spawn_locator import TYPE_CODE
-    T, n_ped, n_veh, n_multi = 31, 0, 0, 0
+    T, n_ped, n_veh, n_multi, n_anchor = 31, 0, 0, 0, 0
     for name, lanelets, obstacles, path, ego, yaw, v, inter, step in _scenes():
         k = _stack(torch, lanelets, obstacles, path, inter, step, ego=ego, yaw=yaw)
         k.sm.upload_obstacles(k.obs)
@@ -195,7 +199,31 @@ def test_rule_agents_on_the_device_equal_the_host_add_agent_flow(torch_cuda):
                 assert tuple(dev["raw"][s]) == (ag.length, ag.width)
         for s in range((a0 + h["rule_n"]) * R, len(dev["len"])):
             assert dev["len"][s] == 0                                     # slots of points that do not exist
+        # oracle-side anchor of the vehicles: pose + lanelet + route table -> predictions by oracle/fo_oracle.c
+        vi = [i for i, sp in enumerate(points) if sp.agent_type != "Pedestrian"]
+        if vi and k.sm.route_table is not None:
+            tab = k.sm.route_table
+            lan = []
+            for i in vi:
+                inside = [q for q, ll in enumerate(lanelets) if SCN.points_in_polygon(points[i].position.reshape(1, 2), ll.polygon)[0]]
+                lan.append(inside[0] if inside else -1)
+            types = np.array([TYPE_CODE[points[i].agent_type.lower()] for i in vi], dtype=np.int32)
+            speed = np.array([CFG["agent_manager"][points[i].agent_type.lower()]["default_velocity"] for i in vi], dtype=np.float64)
+            pos0 = np.stack([points[i].position for i in vi])
+            po, yo, vo, co, lo = oracle.route_predictions(pos0, types, speed, np.array(lan, dtype=np.int32), R, tab.first, tab.count,
+                                                          tab.xy, tab.s, h["yaw0"][[a0 + i for i in vi]], T, 0.1, 0.1, 1.05)
+            for q, i in enumerate(vi):
+                for r in range(R):
+                    s_, so = (a0 + i) * R + r, q * R + r
+                    assert dev["len"][s_] == lo[so], (name, i, r)
+                    L = int(lo[so])
+                    np.testing.assert_allclose(dev["pos"][s_, :L], po[so, :L], rtol=0, atol=1e-9, err_msg=f"{name} {i} {r}")
+                    np.testing.assert_allclose(dev["yaw"][s_, :L], yo[so, :L], rtol=0, atol=1e-12)
+                    np.testing.assert_allclose(dev["v"][s_, :L], vo[so, :L], rtol=0, atol=1e-12)
+                    np.testing.assert_allclose(dev["cov"][s_, :L], co[so, :L], rtol=1e-13, atol=0)
+                    n_anchor += L > 0
     assert n_ped >= 3 and n_veh >= 3 and n_multi >= 1, (n_ped, n_veh, n_multi)   # pedestrians, vehicles on one and on several routes
+    assert n_anchor >= 3, n_anchor
 
 
 def test_one_call_rules_step_equals_the_sweep_over_the_host_built_agents(torch_cuda):
@@ -308,7 +336,7 @@ def test_interface_in_rules_mode_keeps_the_spawn_points_on_the_device(torch_cuda
     for step in (0, 8, 25):
         ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
         fo.evaluate_scenario({}, ego, yaw, None, float(ego0[3]), step)
-        assert isinstance(fo.spawn_points, LazySpawnPoints) and fo.spawn_points._items is None   # nothing read back yet
+        assert isinstance(fo.spawn_points, LazySpawnPoints) and not fo.spawn_points.materialised   # nothing read back yet
         traj = SY.make_trajectories(64, 31, 0.1, seed=1, ego_pos=ego, ego_yaw=yaw)
         ba = fo.trajectory_safety_assessment_batch(traj, mode="reduced")
         assert ba is not None and ba.cost.shape == (64, 16)

@@ -24,7 +24,9 @@ def _default_config():
     import yaml
     from frenetix_occlusion import interface
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
-        return yaml.safe_load(f)
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
+    return cfg
 
 
 def _check_step(torch, oracle, sc, ego, v_ego, timestep, sensor_angle=360.0, n_rays=720, radius=50.0, max_agents=32,

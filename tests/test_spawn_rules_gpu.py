@@ -232,3 +232,109 @@ def test_urban_grid_rule_cases(torch_cuda):
         _same(dev, ref, view)
         n_pts += len(ref)
     assert n_pts > 0
+
+
+def test_interface_with_the_default_yaml_spawns_what_the_reference_rules_spawn(torch_cuda):
+    """``FOInterface(..., config_path=None)`` -- the packaged YAML, untouched -- runs the reference's spawn semantics
+    (interface.py:186-198: find_spawn_points = the three rule families): on scenario 1 at steps 0 / 8 / 25 / 60 its
+    ``spawn_points`` are the checker's (oracle/fo_spawn_rules_ref.py) for the same visibility, and one phantom agent per point
+    reaches the registry.  The spawn-point list is a ``list`` that reads the device when first looked at; one kept past the
+    next planning step still holds ITS step's points."""
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion import synthetic as SY
+    from frenetix_occlusion.spawn_locator import LazySpawnPoints
+    from frenetix_occlusion.utils.curvilinear import PolylineCS
+    from oracle.fo_spawn_rules_ref import CellView, SpawnRules
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    yaw = float(ego0[2])
+    path = ego0[None, :2] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    v = SY.VEHICLE_BMW320I
+    veh = SimpleNamespace(length=v[0], width=v[1], wb_rear_axle=v[2], mass=v[3], a_max=v[4])
+    fo = interface.FOInterface(sc, path, veh, 0.1)                       # config_path=None: the defaults
+    assert fo.config["accelerator"]["spawn"]["mode"] == "rules" and fo.spawn_locator.mode == "rules"
+    assert fo.spawn_locator.n_cell_agents == 0 and fo.spawn_locator.max_rule_points >= 6
+    cs = PolylineCS(path)
+    sm = fo.sensor_model
+
+    def lane_yaw_at(xy):
+        (x0, y0), (nx, ny) = sm.raster_origin, sm.raster_dims
+        ix, iy = int(math.floor((xy[0] - x0) / sm.cell_size)), int(math.floor((xy[1] - y0) / sm.cell_size))
+        if not (0 <= ix < nx and 0 <= iy < ny) or np.isnan(sm.lane_yaw[iy, ix]):
+            return None
+        return float(sm.lane_yaw[iy, ix])
+
+    def lanelet_of(xy):
+        for ll in sc.lanelets:
+            if S.points_in_polygon(np.asarray(xy, float).reshape(1, 2), ll.polygon)[0]:
+                return ll
+        return None
+    n_pts, kept = 0, []
+    for step in (0, 8, 25, 60):
+        ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
+        ego_cl = cs.convert_to_curvilinear_coords(ego[0], ego[1])
+        fo.evaluate_scenario({}, ego, yaw, ego_cl, float(ego0[3]), step, None)
+        pts = fo.spawn_points
+        assert isinstance(pts, list) and isinstance(pts, LazySpawnPoints) and not pts.materialised    # nothing read back yet
+        kept.append((step, pts))
+        if step != 8:              # (step 8's list stays unread until the NEXT step has been queued, see below)
+            dev = list(pts)
+            torch_cuda.cuda.synchronize()
+            view = CellView(sm.cell_class.cpu().numpy(), sm.window)
+            rules = SpawnRules(fo.config, path, cs, lane_yaw_at, lanelet_of, fo.fo_obstacles, lanelets=sc.lanelets,
+                               intersections=sc.intersections or [])
+            ref = rules.find(view, ego, ego_cl, float(ego0[3]), yaw)
+            _same(dev, ref, view)
+            assert len(fo.agent_manager.phantom_agents) == len(ref)
+            assert [a.agent_type for a in fo.agent_manager.phantom_agents] == [p.agent_type for p in ref]
+            n_pts += len(ref)
+            assert pts + [] == dev and [] + pts == dev and (len(pts) > 0) == bool(pts)              # list semantics
+    assert n_pts > 0
+    # the list of step 8 was first read after step 25 (and 60) had been queued on the same buffers: it was read back when
+    # step 25 began, and holds the points of step 8 -- those of a fresh interface driven to step 8 only
+    late = [p for st, p in kept if st == 8][0]
+    assert late.materialised
+    fo2 = interface.FOInterface(sc, path, veh, 0.1)
+    ego = ego0[:2] + 0.7634 * 8 * np.array([math.cos(yaw), math.sin(yaw)])
+    fo2.evaluate_scenario({}, ego, yaw, cs.convert_to_curvilinear_coords(ego[0], ego[1]), float(ego0[3]), 8, None)
+    want = list(fo2.spawn_points)
+    assert [(p.agent_type, p.source) for p in late] == [(p.agent_type, p.source) for p in want]
+    for a, b in zip(late, want):
+        assert np.array_equal(a.position, b.position)
+
+
+def test_rule_point_capacity_follows_the_yaml_maxima(torch_cuda):
+    """max_dynamic / max_static = 3 allow (3 + 2) + (3 + 1) + 1 = 10 rule points (the maxima are compared before appending,
+    Q11): the locator sizes its buffers for that whatever ``max_rule_points`` says, and the C entry refuses a smaller one"""
+    import copy
+    import ctypes as C
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    cfg = copy.deepcopy(CFG)
+    cfg["spawn_locator"].update(max_static_spawn_points=3, max_dynamic_spawn_points=3)
+    cfg["accelerator"]["spawn"]["max_rule_points"] = 8
+    lanes = [_straight(S, 1, -10, 120, -3.5, 0.0), _straight(S, 2, -10, 120, 0.0, 3.5)]
+    path = np.stack((np.linspace(-5, 115, 241), np.full(241, -1.0)), -1)
+    cars = [S.Obstacle(70 + i, "static", "parkedVehicle", 4.5, 1.8, 0, np.array([12.0 + 7.0 * i, -2.4, 0.0, 0.0]), np.zeros((0, 4)))
+            for i in range(6)]
+    obs = FOObstacles(cars)
+    obs.update(0)
+    sm = SensorModel(lanes, path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720)
+    sm.calc_visible_and_occluded_area(0, np.array([0.0, -1.0]), 0.0, obs)
+    sl = SpawnLocator(None, path, cfg, sm, fo_obstacles=obs)
+    assert sl.max_rule_points == 10
+    pts = sl.find_spawn_points(np.array([0.0, -1.0]), 0.0, None, 12.0)
+    torch_cuda.cuda.synchronize()
+    assert 1 <= len(pts) <= 4 and all(p.agent_type == "Pedestrian" for p in pts)
+    b = sl.batch
+    pr = sl.rule_params(np.array([0.0, -1.0]), 0.0, None, 12.0)
+    O, corn, cen, oyaw, odims, ofl, ovis = sl.rule_obstacle_ptrs()
+    w = sm.window
+    with pytest.raises(N.NativeError):
+        sl.ctx.call("fo_scene_spawn_rules", sm.cell_class.data_ptr(), w.ix0, w.iy0, w.nx, w.ny, int(sl._d_path6.shape[0]),
+                    sl._d_path6.data_ptr(), O, corn, cen, oyaw, odims, ofl, ovis, C.byref(pr), 8, b.rule_points.data_ptr(),
+                    b.rule_n.data_ptr(), N.current_stream(0))

@@ -249,11 +249,23 @@ def test_float32_lists_generic_kernel_and_metric_subset(torch_cuda, oracle, monk
     assert g32["lists"].dtype == np.float32 and np.isnan(g32["lists"]).all()
 
 
+def _assert_rounded_float64(got32, want64, tol=1e-9):
+    """every float32 entry is a float64 value within `tol` of `want64`, rounded to float32 (half a float32 ulp + tol)"""
+    assert got32.dtype == np.float32
+    assert np.array_equal(np.isnan(got32), np.isnan(want64))
+    f = np.isfinite(want64)
+    half_ulp = 0.5 * np.spacing(np.abs(want64[f]).astype(np.float32)).astype(np.float64)
+    err = np.abs(got32[f].astype(np.float64) - want64[f])
+    assert (err <= half_ulp + tol).all(), float((err - half_ulp).max())
+    return float(np.mean(got32[f] != want64[f].astype(np.float32)))
+
+
 @pytest.mark.parametrize("M,A,cfg", [(300, 16, 1), (2000, 32, 2), (70, 9, 8)])
 def test_float32_exact_lists_are_the_float64_lists_rounded(torch_cuda, oracle, monkeypatch, M, A, cfg):
     """fo_sweep_set_list_format(FO_LISTS_F32_EXACT) / lists='f32x': float32 storage of the float64 results -- every list entry
     equals the float64-list mode's entry rounded to float32 (the queue kernel's instantiation for the default metric set; a
-    metric subset goes through the generic kernel, which converts at the store as well), everything else bit-identical"""
+    metric subset goes through the generic kernel, which converts at the store as well), everything else bit-identical; and
+    against the oracle every entry is a float64 value within 1e-9 of the oracle's, rounded to float32"""
     from frenetix_occlusion import synthetic as S
     traj, agents = S.make_batch(M, A, config_id=cfg)
     if cfg == 8:
@@ -266,6 +278,8 @@ def test_float32_exact_lists_are_the_float64_lists_rounded(torch_cuda, oracle, m
         assert np.array_equal(gx[k], g64[k]), k
     assert np.array_equal(gx["pair_f"], g64["pair_f"], equal_nan=True)
     assert np.array_equal(gx["lists"], g64["lists"].astype(np.float32), equal_nan=True)
+    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, nthreads=8)
+    _assert_rounded_float64(gx["lists"], ref["lists"], tol=1e-9)
     # metric subset -> generic kernel: against the oracle
     ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
     gxs = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32x")

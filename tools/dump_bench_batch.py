@@ -20,6 +20,7 @@ sc = SC.synthetic_urban_grid()
 ego = sc.ego_initial
 with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
     cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
 cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=45.0)
 ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
 sm = SensorModel(sc.lanelets, ref_path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx, device=0)

@@ -18,6 +18,7 @@ sc = SC.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario1_geome
 ego = sc.ego_initial
 with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
     cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
 cfg["accelerator"]["spawn"].update(max_agents=32, routes=0)
 yaw = float(ego[2])
 path = ego[None, :2] + np.linspace(0.0, 60.0, 61)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])

@@ -25,7 +25,8 @@ def loops(path, key="queue_kernelILb1ELi2ELb1ELb0E"):
         res.setdefault(cur,{}).setdefault(c,0); res[cur][c]+=1
     m=re.search(key+r".*?\.sgpr_spill_count: (\d+).*?\.vgpr_spill_count: (\d+)", open(path).read(), re.S)
     return res
-r=loops(sys.argv[1])
+KEY={"f32":"queue_kernelILb1ELi2ELb1ELb0E","f32x":"queue_kernelILb1ELi3ELb1ELb0E","f64":"queue_kernelILb1ELi1ELb1ELb0E","none":"queue_kernelILb1ELi0ELb1ELb0E"}
+r=loops(sys.argv[1], KEY.get(sys.argv[2] if len(sys.argv)>2 else "f32x", sys.argv[2] if len(sys.argv)>2 else ""))
 # pass-1 loops: the two depth-3 loops with the most v64 (body CORR=false first in file order -> smaller label number)
 d3=[(k,v) for k,v in r.items() if k[1]==3 and v.get("v64",0)>150]
 d3.sort(key=lambda kv:int(kv[0][0].split("_")[1]))

@@ -64,6 +64,7 @@ class Ego:
         sc = SC.load_geometry_npz(os.path.join(ROOT, "tests", "golden", f"scenario{2 + idx % 2}_geometry.npz"))
         with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
             cfg = yaml.safe_load(f)
+            cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
         cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=40.0)
         yaw = float(pose[2])
         ref = pose[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])

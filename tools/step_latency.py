@@ -21,6 +21,7 @@ def main():
     M = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     cfg["accelerator"]["spawn"].update(mode=mode, max_agents=32)
     sc = S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", "scenario3_geometry.npz"))
     by = {l.lanelet_id: l for l in sc.lanelets}

@@ -28,6 +28,7 @@ def main():
     ego0 = sc.ego_initial
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
+        cfg["accelerator"]["spawn"]["mode"] = "cells"   # the BASELINE-config sampler (the YAML default is the reference's rule families)
     cfg["accelerator"]["spawn"].update(max_agents=A // 2, all_occluded=True, routes=2, pattern=["Car", "Bicycle", "Pedestrian", "Car"])
     yaw0 = float(ego0[2])
     ref = ego0[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(yaw0), math.sin(yaw0)]])
