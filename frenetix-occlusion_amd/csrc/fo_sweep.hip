@@ -65,17 +65,22 @@ __global__ void fo_erf_table_kernel(double2 *tab) {
 // caller hands over the argument already multiplied by 128 (folded into 1/(sigma sqrt 2), once per sample): the node index is
 // the low word of |v| + 1.5 * 2^52 (no rint / convert instruction), d = |v| - node is the offset in table steps, and the
 // Taylor step is evaluated in y = x0 d_true (= node * d * 2^-14) and s = d^2:
-//   erf(x0 + d_true) = e + g d_true P,   P = (1 - s/3) + y (-1 + s/2) + y^2 (2/3) - y^3/3 + [s^2/10 - 2 s y^2/5 + 2 y^4/15] + ...
-// FO_ERF_ORDER 4 (default) drops the bracket: what is left out is g(x0) d^5 (1/10 - 2 x0^2/5 + 2 x0^4/15), at most 1.13 * 0.1 *
-// 256^-5 = 1.0e-13 per erf, 3e-13 on a collision probability (nine products of two differences, / 12).  The 36 erf of an
-// in-gate sample are the largest single item of the sweep kernel: every instruction here is ~1.2 % of its run time (round 5:
-// 19 -> 16 operations per erf -2.5 %).  The polynomial is grouped so that every fma has at most ONE constant that is not an
-// inline operand (1.0, 2.0): a VOP3 instruction of this chip reads one literal / SGPR pair, and a second constant costs two
-// v_mov_b32 per erf to park it in a register.
-//   P = a0 + y (a1 + u/3),  a0 = 1 - s/3,  a1 = -1 + s/2,  u = y (2 - y)
-// FO_ERF_ORDER 3 (tuning builds): P = a0 + y (-1 + 2 y / 3), 4.3e-11 per erf, 2.5e-10 on a collision probability.
+//   erf(x0 + d_true) = e + g d_true P,   P = (1 - s/3) + y (-1 + 2 y/3) + [y s/2 - y^3/3] + [s^2/10 - 2 s y^2/5 + 2 y^4/15] + ...
+//   evaluated as  P = a0 + y (-1 + 2 y / 3),  a0 = 1 - s/3.
+// The bracket is never evaluated: it contributes g(x0) d^5 (1/10 - 2 x0^2/5 + 2 x0^4/15) <= 1.13 * 0.1 * 256^-5 = 1.0e-13.
+// FO_ERF_ORDER 3 (default) also leaves out the two cubic terms  y s/2 - y^3/3 = d^3 x0 (1/2 - x0^2/3):  what is dropped is
+// g(x0) d^4 x0 (1/2 - x0^2/3), at most 0.18 * 256^-4 = 4.3e-11 per erf (at x0 = 0.6, |d| = 1/256; a fifth of that on average
+// over d), i.e. <= 2.6e-10 on a collision probability (nine products of two differences of erf, / 12; measured on the bench
+// batch against the oracle: see parity.float_max_abs_err of the bench line) -- a quarter of the 1e-9 every float output of
+// this library is tested to, four orders inside the 1e-5 the task allows, and far below what the float32 list storage keeps.
+// The price of the two terms is three instructions per erf, and the 36 erf of an in-gate sample are the one part of the
+// sweep kernel whose instructions count three times (the waves that hold the few agents next to the candidates' path carry
+// all of it, and their workgroups wait for them): 19 -> 16 -> 14 operations per erf took 6.5 % off the kernel (round 5).
+// FO_ERF_ORDER 4: the cubic terms kept, P = a0 + y (a1 + u/3), a1 = -1 + s/2, u = y (2 - y): 1.0e-13 per erf.
+// Either way the polynomial is grouped so that every fma has at most ONE constant that is not an inline operand (1.0, 2.0): a
+// VOP3 instruction of this chip reads one literal / SGPR pair, and a second constant costs two v_mov_b32 per erf to park it.
 #ifndef FO_ERF_ORDER
-#define FO_ERF_ORDER 4
+#define FO_ERF_ORDER 3
 #endif
 __device__ __forceinline__ double fo_erf_fast128(const double2 *__restrict__ tab, double v) {
   constexpr double S = 0x1p-14;
@@ -629,9 +634,6 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 //   pass 2 (t loop)  harm + risk + running maxima + coalesced list stores, cp read back from cpbuf.
 // exp() for the logistic models is a 64-entry 2^(j/64) table + degree-5 polynomial (~15 VALU ops).
 // Supports T-1 <= TQ; longer horizons take the generic kernel.
-#ifndef FO_ERF_AFFINE
-#define FO_ERF_AFFINE 1  // erf arguments of the nine boxes by running sums in table units (0: tuning builds, the per-box products)
-#endif
 #ifndef FO_TC
 #define FO_TC 8      // timesteps per chunk of the two-pass scheme (rows of the per-wave cp buffer)
 #endif
@@ -646,6 +648,9 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #endif
 #ifndef FO_DYN
 #define FO_DYN 0     // 1: the waves of a workgroup draw the chunk's agents one by one from an LDS counter (tuning builds)
+#endif
+#ifndef FO_POOL
+#define FO_POOL 1    // in-gate samples pooled over the workgroup's four waves at the end of every pass 1 (0: tuning builds -- every wave evaluates its own, inline)
 #endif
 #ifndef FO_X
 #define FO_X 0       // timing experiments only (tools/build_variant.sh x1 -DFO_X=1 ...): 1 no pass 2, 2 no probe, 4 no harm
@@ -838,8 +843,11 @@ template <bool PAIR, int LISTS, bool ALLM, bool SPLIT, bool CORR, int TC_>
 __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const double2 *__restrict__ erf_tab,
                                                     const double *__restrict__ exp_tab, const double *__restrict__ zc_tab,
                                                     double *__restrict__ hk_all, double *__restrict__ cpbuf_all,
-                                                    unsigned short *__restrict__ queue_all, int *__restrict__ next_agent) {
+                                                    unsigned short *__restrict__ queue_all, int *__restrict__ next_agent,
+                                                    int *__restrict__ pool_i, double *__restrict__ pool_hd) {
   constexpr int TC = TC_, DVR = TC + 1, WROWS = TC + DVR;   // this instantiation's chunk length (see fo_sweep_queue_kernel)
+  constexpr bool POOL = FO_POOL != 0 && SPLIT;            // (measured: lock step costs the full grid 9 %, see pool_round)
+  constexpr int QCAPX = POOL ? TILE * TC : QCAP;            // queue entries per wave: a chunk's worth with the pool
   static_assert(!SPLIT || WROWS >= 10, "the horizon-split fold parks ten values per lane in the wave's rows");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -858,7 +866,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
   double *cpw = cpbuf_all + wave * (WROWS * TILE);
   double *dvw = cpw + TC * TILE;
   double *hk = hk_all + wave * 4;
-  unsigned short *q = queue_all + wave * QCAP;
+  unsigned short *q = queue_all + wave * QCAPX;
   const bool do_dce = ALLM || (a.mask & FO_M_DCE), do_cp = ALLM || (a.mask & FO_M_CP), do_hr = ALLM || (a.mask & FO_M_HR);
   const bool do_ttc = ALLM || (a.mask & FO_M_TTC), do_ttce = ALLM || (a.mask & FO_M_TTCE);
   const uint32_t ablate = ALLM ? 0u : a.ablate;
@@ -871,13 +879,138 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
   int w_arg_dce = -1, w_arg_ttc = -1, w_arg_or = -1;  // agent indices as integers: three VGPRs less than as doubles
   bool w_dce_flag = false;
 
+
+  // Evaluates queued in-gate samples, one per lane (collision_probability.py:77-122).  `item` = lane | row << 6 of a queue
+  // entry of agent kq (half inflated length hdq) in the chunk whose buffer row 0 holds gate sample gbq; the probability goes
+  // to row `row` of the cp rows at cpq.  With the workgroup-wide pool (below) the lanes of one call hold entries of up to
+  // four agents -- whichever wave evaluates them.
+  auto gate_items = [&](bool valid, int item, int kq, double hdq, int gbq, double *cpq) {
+    if (valid) {
+      const int src = item & 63, row = item >> 6, ti = gbq + row;
+      const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + 2 * src;  // ego sample ti+1 of trajectory `src`
+      const fo_d2 qxy = fo_ld2(e), qcs = fo_ld2(e + EF(2));
+      const double qex = qxy.x, qey = qxy.y, qec = qcs.x, qes = qcs.y;
+      const double *g0 = a.atab + ((size_t)kq * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti
+      const double qpx = g0[0], qpy = g0[1], qisx = g0[6] * ERF_SCALE, qisy = g0[7] * ERF_SCALE;
+      const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
+      const double devx = qc1 * hdq, devy = qs1 * hdq;
+      const double rx = qex - qpx, ry = qey - qpy;
+      const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
+      double acc = 0.0;
+      // The 36 erf arguments are affine in (mean j, box b, side): in units of the table spacing,
+      //   X(j, b, +-) = (rx - j devx + b bxs +- off_x) 128 / (sigma_x sqrt 2)
+      // -- scaled once per sample, then two running sums and one add per argument instead of an add and a multiplication
+      // (four operations less per box; the arguments move by ~1e-13 of a table step)
+      const double DX = devx * qisx, DY = devy * qisy, BX = bxs * qisx, BY = bys * qisy;
+      const double ox = a.off_x * qisx, oy = a.off_y * qisy;
+      double qx = fma(rx, qisx, DX), qy = fma(ry, qisy, DY);   // j = -1
+#pragma unroll 1
+      for (int jm = 0; jm < 3; ++jm) {
+        double cx = qx - BX, cy = qy - BY;                      // b = -1
+        // (horizon-split form: the three boxes of a row side by side -- a wave that flushes at every sample is bound by
+        // the latency of this loop, twelve table reads in flight instead of four; elsewhere the registers are dearer)
+#pragma unroll (SPLIT && !PAIR ? 3 : 1)
+        for (int b = 0; b < 3; ++b) {
+          const double fx = fo_erf_fast128(erf_tab, cx + ox) - fo_erf_fast128(erf_tab, cx - ox);
+          const double fy = fo_erf_fast128(erf_tab, cy + oy) - fo_erf_fast128(erf_tab, cy - oy);
+          acc = fma(fx, fy, acc);
+          cx += BX; cy += BY;
+        }
+        qx -= DX; qy -= DY;
+      }
+      // (1/2)(1/2) of the two Phi differences, /3 (:122).  A row poisoned by fo_prep_agents_kernel (no usable
+      // covariance: 1/sigma = NaN) must read NaN: the table erf clamps its argument, which would turn the NaN into
+      // erf(+-6) and the probability into 0
+      cpq[row * TILE + src] = (qisx != qisx || qisy != qisy) ? NAN : acc * (0.25 / 3.0);
+    }
+    if (CORR) {
+      // Covariances with correlation: a second walk over the same queued samples adds the correlation integral of
+      // the nine boxes to the value stored above.  It re-reads its operands (nothing of the evaluation above stays
+      // live: this body shares the kernel's register budget with the usual one); whole batches without a
+      // correlated sample skip it, and asin(rho) = 0 makes it vanish lane by lane.
+      __asm__ volatile("" ::: "memory");
+      const double asr = valid ? a.atab[((size_t)kq * a.Ta + gbq + (item >> 6)) * NAF + 11] : 0.0;
+      if (__ballot(asr != 0.0)) {
+        const double ar = fabs(asr);   // asin is monotonic: the rule thresholds are compared as angles
+        const int rule = __ballot(ar > GL_ASR3) ? 4 : __ballot(ar > GL_ASR2) ? 3 : __ballot(ar > GL_ASR1) ? 2
+                         : __ballot(ar > GL_ASR0) ? 1 : 0;
+        const cdp_gl_t gl = (cdp_gl_t)(unsigned long long)(a.gl + 2 * gl_first(rule));
+        const int nn = gl_nodes(rule);
+        if (valid) {
+          const int src = item & 63, row = item >> 6, ti = gbq + row;
+          const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + 2 * src;
+          const double *g0 = a.atab + ((size_t)kq * a.Ta + ti) * NAF;
+          const fo_d2 qxy = fo_ld2(e), qcs = fo_ld2(e + EF(2));
+          // everything in units of the standard deviations (times sqrt 2) along x and y
+          const double ix0 = g0[6], iy0 = g0[7];
+          const double rx = (qxy.x - g0[0]) * ix0, ry = (qxy.y - g0[1]) * iy0;
+          const double devx = g0[NAF + 2] * hdq * ix0, devy = g0[NAF + 3] * hdq * iy0;
+          const double bxs = a.len3 * qcs.x * ix0, bys = a.len3 * qcs.y * iy0;
+          const double ox = a.off_x * ix0, oy = a.off_y * iy0;
+          double csum = 0.0;
+#pragma unroll 1
+          for (int i = 0; i < nn; ++i) {
+            const double sn = fo_sin_halfpi(asr * gl[2 * i]);   // node and weight are wave-uniform: scalar loads
+            const double c2 = 1.0 / fma(-sn, sn, 1.0);
+            double S = 0.0;
+#pragma unroll 1
+            for (int jm = -1; jm <= 1; ++jm) {
+              const double qx = rx - jm * devx, qy = ry - jm * devy;
+#pragma unroll 1
+              for (int b = -1; b <= 1; ++b) {
+                const double cx = qx + b * bxs, cy = qy + b * bys;
+                S += fo_corr_corners(exp_tab, cx - ox, cx + ox, cy - oy, cy + oy, 2.0 * sn, c2);
+              }
+            }
+            csum = fma(gl[2 * i + 1], S, csum);
+          }
+          cpq[row * TILE + src] = fma(asr * (1.0 / 3.0), csum, cpq[row * TILE + src]);
+        }
+      }
+    }
+  };
+  // Workgroup-wide pool (POOL).  The gate work is the one part of the sweep that is NOT spread evenly: on the bench batch 56 of
+  // the 256 agents have any sample inside the 5 m gate and 26 of them hold 84 % of the 1.4 million in-gate samples -- the wave
+  // that holds such an agent evaluates up to seventeen batches of 36 x 64 erf for it while its three siblings have none, and
+  // the workgroup lives as long as that wave (tools/sweep_stats.py; the model in DESIGN.md section 3.1 puts 5-20 % of the
+  // wave slots of a launch into waiting for it).  So pass 1 only QUEUES its in-gate samples (a chunk's worth: up to 64 x TC per
+  // wave), and at the end of pass 1 the four waves of the workgroup meet (the chunk loop runs in step for that: every wave
+  // takes part in every round, with an empty queue where its agent slot is unused), pool their queues and deal the batches
+  // of 64 round robin: every wave evaluates a quarter of the workgroup's samples, whoever queued them, and writes the
+  // probabilities into the owner's rows.  A second barrier, then pass 2 as before.  Fuller batches come with it (one
+  // remainder per workgroup and chunk instead of four).
+  auto pool_round = [&](int qn_, int k_, double hd_, int gb_) {
+    static_assert(!POOL || QWAVES == 4, "the pool's prefix over the waves' queue lengths is written for four waves");
+    if (lane == 0) { pool_i[wave] = qn_; pool_i[QWAVES + wave] = k_; pool_i[2 * QWAVES + wave] = gb_; pool_hd[wave] = hd_; }
+    __syncthreads();
+    const int n0 = __builtin_amdgcn_readfirstlane(pool_i[0]), n1 = __builtin_amdgcn_readfirstlane(pool_i[1]);
+    const int n2 = __builtin_amdgcn_readfirstlane(pool_i[2]), n3 = __builtin_amdgcn_readfirstlane(pool_i[3]);
+    const int c1 = n0 + n1, c2 = c1 + n2, total = c2 + n3;
+#pragma unroll 1
+    for (int b = wave; (b << 6) < total; b += QWAVES) {
+      const int i = (b << 6) + lane;
+      const bool valid = i < total;
+      const int o = valid ? (i >= n0) + (i >= c1) + (i >= c2) : 0;
+      const int li = i - (o == 0 ? 0 : o == 1 ? n0 : o == 2 ? c1 : c2);
+      int item = 0, kq = 0, gbq = 0;
+      double hdq = 0.0;
+      if (valid) { item = queue_all[o * QCAPX + li]; kq = pool_i[QWAVES + o]; gbq = pool_i[2 * QWAVES + o]; hdq = pool_hd[o]; }
+      gate_items(valid, item, kq, hdq, gbq, cpbuf_all + o * (WROWS * TILE));
+    }
+    __syncthreads();
+  };
+
   // agents of this wave: chunk -> (first agent, agents per wave), see SweepArgs::chunk_tab
   const int apw_ = SPLIT ? a.apw : fo_const(a.chunk_tab)[2 * chunk + 1];   // SPLIT: agents per WORKGROUP, one after the other
   const int k0 = SPLIT ? chunk * a.apw : fo_const(a.chunk_tab)[2 * chunk] + wave * apw_;
   // the samples this wave owns: everything, or time chunk `wave` of the agent the workgroup shares
   const int seg0 = SPLIT ? wave * TC : 0, seg1 = SPLIT ? min(seg0 + TC, a.T) : a.T;
   const int gfirst_ = max(seg0 - 1, 0);  // first harm / cp sample this wave evaluates for an agent
-  constexpr bool DYN = FO_DYN && !SPLIT;
+  constexpr bool DYN = FO_DYN && !SPLIT && !POOL;
+  // POOL: the rounds a wave without an agent in this slot still takes part in (the barriers are the workgroup's)
+  auto dead_rounds = [&]() {
+    for (int t0 = seg0; t0 < seg1; t0 += TC) pool_round(0, 0, 0.0, 0);
+  };
   const int kbase = k0 - wave * apw_, kcount = apw_ * QWAVES;   // the chunk's agents [kbase, kbase + kcount)
   for (int kk = 0;; ++kk) {
     int k;
@@ -891,7 +1024,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       if (kk >= apw_) break;
       k = k0 + kk;
     }
-    if (k >= A) break;
+    if (k >= A) {
+      if (POOL && !SPLIT) { dead_rounds(); continue; }   // (the other waves' slots may be in use)
+      break;
+    }
     const cdp_t G = fo_const(a.atab) + (size_t)k * a.Ta * NAF;
     const cdp_t C = fo_const(a.acst) + (size_t)k * NAC;
     const double hlB = C[0], hwB = C[1], hdev = C[2], Rsum = C[8];
@@ -940,6 +1076,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           else fo_store_lists<false>(a.lists, ls, ((size_t)k * Tm1 + t) * M + m, NAN, NAN, NAN, NAN, NAN);
         }
       }
+      if (POOL && !SPLIT) dead_rounds();
       continue;
     }
 
@@ -1071,108 +1208,10 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       const int tl = (SPLIT && t0 > 0) ? t0 - 1 : t0;
       const int gbase = t0 - 1;  // gate sample of buffer row 0
 
-      // evaluates n (<= 64) queued in-gate samples, one per lane (collision_probability.py:77-122)
+      // (without the workgroup-wide pool: evaluates this wave's n (<= 64) queued samples)
       auto process = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < n) {
-          const int item = q[lane];
-          const int src = item & 63, row = item >> 6, ti = gbase + row;
-          const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + 2 * src;  // ego sample ti+1 of trajectory `src`
-          const fo_d2 qxy = fo_ld2(e), qcs = fo_ld2(e + EF(2));
-          const double qex = qxy.x, qey = qxy.y, qec = qcs.x, qes = qcs.y;
-          const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;      // agent mean / covariance: sample ti
-          const double qpx = g0[0], qpy = g0[1], qisx = g0[6] * ERF_SCALE, qisy = g0[7] * ERF_SCALE;
-          const double qc1 = g0[NAF + 2], qs1 = g0[NAF + 3];             // agent heading: sample ti+1 (Q1); ti+1 < L
-          const double devx = qc1 * hdev, devy = qs1 * hdev;
-          const double rx = qex - qpx, ry = qey - qpy;
-          const double bxs = a.len3 * qec, bys = a.len3 * qes;           // rear-axle based boxes (Q2)
-          double acc = 0.0;
-#if FO_ERF_AFFINE
-          // The 36 erf arguments are affine in (mean j, box b, side): in units of the table spacing,
-          //   X(j, b, +-) = (rx - j devx + b bxs +- off_x) 128 / (sigma_x sqrt 2)
-          // -- scaled once per sample, then two running sums and one add per argument instead of an add and a multiplication
-          // (four operations less per box; the arguments move by ~1e-13 of a table step)
-          const double DX = devx * qisx, DY = devy * qisy, BX = bxs * qisx, BY = bys * qisy;
-          const double ox = a.off_x * qisx, oy = a.off_y * qisy;
-          double qx = fma(rx, qisx, DX), qy = fma(ry, qisy, DY);   // j = -1
-#pragma unroll 1
-          for (int jm = 0; jm < 3; ++jm) {
-            double cx = qx - BX, cy = qy - BY;                      // b = -1
-#pragma unroll (SPLIT && !PAIR ? 3 : 1)
-            for (int b = 0; b < 3; ++b) {
-              const double fx = fo_erf_fast128(erf_tab, cx + ox) - fo_erf_fast128(erf_tab, cx - ox);
-              const double fy = fo_erf_fast128(erf_tab, cy + oy) - fo_erf_fast128(erf_tab, cy - oy);
-              acc = fma(fx, fy, acc);
-              cx += BX; cy += BY;
-            }
-            qx -= DX; qy -= DY;
-          }
-#else
-#pragma unroll 1
-          for (int jm = -1; jm <= 1; ++jm) {
-            const double qx = rx - jm * devx, qy = ry - jm * devy;
-            // (horizon-split form: the three boxes of a row side by side -- a wave that flushes at every sample is bound by
-            // the latency of this loop, twelve table reads in flight instead of four; elsewhere the registers are dearer)
-#pragma unroll (SPLIT && !PAIR ? 3 : 1)
-            for (int b = -1; b <= 1; ++b) {
-              const double cx = qx + b * bxs, cy = qy + b * bys;
-              const double fx = fo_erf_fast128(erf_tab, (cx + a.off_x) * qisx) - fo_erf_fast128(erf_tab, (cx - a.off_x) * qisx);
-              const double fy = fo_erf_fast128(erf_tab, (cy + a.off_y) * qisy) - fo_erf_fast128(erf_tab, (cy - a.off_y) * qisy);
-              acc = fma(fx, fy, acc);
-            }
-          }
-#endif
-          // (1/2)(1/2) of the two Phi differences, /3 (:122).  A row poisoned by fo_prep_agents_kernel (no usable
-          // covariance: 1/sigma = NaN) must read NaN: the table erf clamps its argument, which would turn the NaN into
-          // erf(+-6) and the probability into 0
-          cpw[row * TILE + src] = (qisx != qisx || qisy != qisy) ? NAN : acc * (0.25 / 3.0);
-        }
-        if (CORR) {
-          // Covariances with correlation: a second walk over the same queued samples adds the correlation integral of
-          // the nine boxes to the value stored above.  It re-reads its operands (nothing of the evaluation above stays
-          // live: this body shares the kernel's register budget with the usual one); whole batches without a
-          // correlated sample skip it, and asin(rho) = 0 makes it vanish lane by lane.
-          __asm__ volatile("" ::: "memory");
-          const double asr = lane < n ? a.atab[((size_t)k * a.Ta + gbase + (q[lane] >> 6)) * NAF + 11] : 0.0;
-          if (__ballot(asr != 0.0)) {
-            const double ar = fabs(asr);   // asin is monotonic: the rule thresholds are compared as angles
-            const int rule = __ballot(ar > GL_ASR3) ? 4 : __ballot(ar > GL_ASR2) ? 3 : __ballot(ar > GL_ASR1) ? 2
-                             : __ballot(ar > GL_ASR0) ? 1 : 0;
-            const cdp_gl_t gl = (cdp_gl_t)(unsigned long long)(a.gl + 2 * gl_first(rule));
-            const int nn = gl_nodes(rule);
-            if (lane < n) {
-              const int item = q[lane];
-              const int src = item & 63, row = item >> 6, ti = gbase + row;
-              const double *e = tjb + (size_t)(ti + 1) * NEF * TILE + 2 * src;
-              const double *g0 = a.atab + ((size_t)k * a.Ta + ti) * NAF;
-              const fo_d2 qxy = fo_ld2(e), qcs = fo_ld2(e + EF(2));
-              // everything in units of the standard deviations (times sqrt 2) along x and y
-              const double ix0 = g0[6], iy0 = g0[7];
-              const double rx = (qxy.x - g0[0]) * ix0, ry = (qxy.y - g0[1]) * iy0;
-              const double devx = g0[NAF + 2] * hdev * ix0, devy = g0[NAF + 3] * hdev * iy0;
-              const double bxs = a.len3 * qcs.x * ix0, bys = a.len3 * qcs.y * iy0;
-              const double ox = a.off_x * ix0, oy = a.off_y * iy0;
-              double csum = 0.0;
-#pragma unroll 1
-              for (int i = 0; i < nn; ++i) {
-                const double sn = fo_sin_halfpi(asr * gl[2 * i]);   // node and weight are wave-uniform: scalar loads
-                const double c2 = 1.0 / fma(-sn, sn, 1.0);
-                double S = 0.0;
-#pragma unroll 1
-                for (int jm = -1; jm <= 1; ++jm) {
-                  const double qx = rx - jm * devx, qy = ry - jm * devy;
-#pragma unroll 1
-                  for (int b = -1; b <= 1; ++b) {
-                    const double cx = qx + b * bxs, cy = qy + b * bys;
-                    S += fo_corr_corners(exp_tab, cx - ox, cx + ox, cy - oy, cy + oy, 2.0 * sn, c2);
-                  }
-                }
-                csum = fma(gl[2 * i + 1], S, csum);
-              }
-              cpw[row * TILE + src] = fma(asr * (1.0 / 3.0), csum, cpw[row * TILE + src]);
-            }
-          }
-        }
+        gate_items(lane < n, lane < n ? (int)q[lane] : 0, k, hdev, gbase, cpw);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
 
@@ -1219,6 +1258,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       unsigned eoff = (unsigned)((tl * NEF * TILE + 2 * lane) * sizeof(double));
       unsigned goff = (unsigned)(tl * NAF * sizeof(double));
       for (int t = tl; t < t1; ++t) {
+        // (Round 5, measured and dropped: the ego's velocity -- and heading -- of sample t asked for at the top of iteration t
+        // instead of one iteration ahead with the pose -- three register pairs and three v_mov_b64 less per sample -- and no row
+        // fetched ahead at all: 0.536-0.540 ms against 0.542, inside the noise, and 2 % slower together with the shorter erf step.)
         const double ex = nxy.x, ey = nxy.y, ec = ncs.x, es = ncs.y, evx = nvv.x, evy = nvv.y, eth = nth_;
         {
           eoff += (unsigned)(NEF * TILE * sizeof(double));
@@ -1308,7 +1350,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
               }
               wgate |= 1u << row;
               qn += __popcll(bal);
-              if (qn >= 64) {
+              if (!POOL && qn >= 64) {
                 process(64);
                 const int rest = qn - 64;
                 unsigned short tmp = 0;
@@ -1367,7 +1409,8 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         }
         gate_far2t = gate_far2c;
       }
-      if (qn > 0) process(qn);
+      if (POOL) pool_round(qn, k, hdev, gbase);
+      else if (qn > 0) process(qn);
       wgate = __builtin_amdgcn_readfirstlane(wgate);  // uniform by construction; says so to the register allocator
       const unsigned wband = wgate >> 16;
       if (lr4s && wband) {
@@ -1545,6 +1588,8 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       }
       SW_STAMP(2);
     }
+    // (horizon-split form, a wave whose segment lies beyond the horizon: it still takes part in the agent's pool round)
+    if (POOL && SPLIT && !(seg0 < seg1)) pool_round(0, 0, 0.0, 0);
     if (dvmax_mode) {
       if (nze_min < INFINITY) {   // nze_min = -(largest squared relative speed)
         const double dvm = fo_sqrt(-nze_min);
@@ -1705,7 +1750,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   constexpr int BUFROWS = QWAVES * WROWS > (QWAVES - 1) * NPS ? QWAVES * WROWS : (QWAVES - 1) * NPS;
   __shared__ double cpbuf_all[BUFROWS * TILE];  // per wave: TC rows of collision probabilities, DVR rows of
                                                        // relative speeds; also the cross-wave reduction scratch
-  __shared__ unsigned short queue_all[QWAVES * QCAP];
+  __shared__ unsigned short queue_all[QWAVES * (FO_POOL && SPLIT ? TILE * TCK : QCAP)];   // per wave: in-gate samples (lane | row << 6)
+  __shared__ int pool_i[3 * QWAVES];       // FO_POOL, per wave: queue length, agent, gate sample of buffer row 0
+  __shared__ double pool_hd[QWAVES];       //          half the agent's inflated length
   __shared__ int next_agent;   // FO_DYN: agents of the chunk handed out so far
   if (threadIdx.x == 0) next_agent = 0;
   {
@@ -1741,9 +1788,9 @@ void fo_sweep_queue_kernel(const SweepArgs a) {
   if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 3] = wall_clock64();   // tables in LDS
 #endif
   if (__builtin_expect(!corr, 1))
-    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all, &next_agent);
+    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, false, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all, &next_agent, pool_i, pool_hd);
   else
-    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, true, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all, &next_agent);
+    fo_sweep_queue_body<PAIR, LISTS, ALLM, SPLIT, true, TCK>(a, erf_tab, exp_tab, zc_tab, hk_all, cpbuf_all, queue_all, &next_agent, pool_i, pool_hd);
 #if FO_TRACE
   if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 1] = wall_clock64();
 #endif

@@ -164,6 +164,32 @@ def load():
     return lib
 
 
+_pyhost = False
+
+
+def pyhost():
+    """the CPython helper module ``_fo_pyhost`` (csrc/fo_pyhost.c: packs trajectory OBJECTS into the pinned staging buffer
+    with the C API), or None when it has not been built -- the callers then use their numpy statement of the same loop.
+    (Host glue between Python objects and host memory, not part of the C ABI and not a compute path.)"""
+    global _pyhost
+    if _pyhost is False:
+        _pyhost = None
+        try:
+            import importlib.machinery
+            import importlib.util
+            import sysconfig
+            path = os.path.join(os.path.dirname(_HERE), "lib", "_fo_pyhost" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+            if os.path.exists(path) and not os.environ.get("FO_NO_PYHOST"):
+                loader = importlib.machinery.ExtensionFileLoader("_fo_pyhost", path)
+                spec = importlib.util.spec_from_file_location("_fo_pyhost", path, loader=loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+                _pyhost = mod
+        except Exception:       # a module built for another interpreter: the numpy path serves
+            _pyhost = None
+    return _pyhost
+
+
 def build_id():
     """hash of the sources the loaded library was built from (fo_build_id)"""
     return load().fo_build_id().decode()

@@ -89,6 +89,8 @@ class BatchAssessment:
         self.metric_order = metric_order
         self.mode = mode
         self._host = None
+        self._fast = None
+        self._hr_tpl = None
 
     def __len__(self):
         return int(self.cost.shape[0])
@@ -133,16 +135,31 @@ class BatchAssessment:
         call instead of building thirty per-prediction entries it never opens."""
         if self.result.lists_raw is None:
             raise RuntimeError("result_dict needs the batch to be evaluated with mode='full'")
-        h = self._to_host()
-        return LazyMetrics(self, m), bool(h["safe"][m])
+        if self._fast is None:
+            # what every per-trajectory call of the step needs, made once: the flags and the cost rows as Python lists (a
+            # numpy scalar read costs more than the rest of the call), the key template of the result dict
+            h = self._to_host()
+            self._fast = (h["safe"].astype(bool).tolist(), h["cost"].tolist(), dict.fromkeys(self.metric_order, _UNBUILT))
+        return LazyMetrics(self, m), self._fast[0][m]
+
+    def _hr_template(self, lazy):
+        """(key template of an 'hr' sub-dict, prediction id -> slot): which predictions carry an entry depends on the
+        prediction alone (harm_model.py:65-66: none for an empty horizon), not on the trajectory -- made once per batch"""
+        if self._hr_tpl is None:
+            hi = self._to_host()["pair_i"]
+            valid = hi[N.PI["hr_valid"], :, 0] if hi is not None else lazy._column()[1][N.PI["hr_valid"]]
+            slot = {pid: k for pid, k in self.prediction_slots if valid[k]}
+            tpl = dict.fromkeys(slot, _UNBUILT)
+            tpl.update(dict.fromkeys(LazyHR.ALL, 0.0))
+            self._hr_tpl = (tpl, slot, [N.COST[key] for key in LazyHR.ALL])
+        return self._hr_tpl
 
     def _build_metric(self, m, name, lazy):
         """sub-dict of metric `name` for trajectory m; ``lazy._column()`` = that trajectory's column (see _column), gathered
         on first need and shared by the metrics of one LazyMetrics ('wttc' and the six maxima of 'hr' do not need it)"""
-        h = self._to_host()
-        cost = h["cost"][m]
+        cost = self._fast[1][m]                      # (result_dict made the lists)
         if name == "wttc":
-            return float(cost[N.COST["wttc"]])
+            return cost[N.COST["wttc"]]
         if name == "hr":
             return LazyHR(self, m, cost, lazy)
         pf, pi, ls, n_valid, pf_l, pi_l = lazy._column()
@@ -285,7 +302,7 @@ class LazyMetrics(_LazyDict):
     """result dict of one trajectory (keys = the activated metrics in the reference's order, metric.py:125-147)"""
 
     def __init__(self, batch, m):
-        super().__init__((name, _UNBUILT) for name in batch.metric_order)
+        dict.__init__(self, batch._fast[2])          # the key template: every metric unbuilt
         self._batch, self._m, self._col = batch, m, None
 
     def _column(self):
@@ -305,12 +322,12 @@ class LazyHR(_LazyDict):
            "max_collision_probability_all", "max_obst_harm_with_cp_all")
 
     def __init__(self, batch, m, cost, lazy):
-        hi = batch._to_host()["pair_i"]
-        # which predictions carry an 'hr' entry (harm_model.py:65-66: none for an empty horizon): from the host mirror of
-        # the batch when there is one, else from the trajectory's gathered column
-        valid = hi[N.PI["hr_valid"], :, m] if hi is not None else lazy._column()[1][N.PI["hr_valid"]]
-        self._slot = {pid: k for pid, k in batch.prediction_slots if valid[k]}
-        super().__init__([(pid, _UNBUILT) for pid in self._slot] + [(key, float(cost[N.COST[key]])) for key in self.ALL])
+        # the keys (one per prediction with a harm model, then the six maxima) come from a template made once per batch; a
+        # call that reads the flag and the maxima -- what a planner does per candidate -- costs a dict copy and six stores
+        tpl, self._slot, idx = batch._hr_template(lazy)
+        dict.__init__(self, tpl)
+        for key, i in zip(self.ALL, idx):
+            dict.__setitem__(self, key, cost[i])
         self._batch, self._lazy = batch, lazy
 
     def _build(self, key):
@@ -368,7 +385,12 @@ class Metric:
         # over inactive slots leaves every trajectory safe)
         if not (am.may_have_phantoms() if hasattr(am, "may_have_phantoms") else am.has_phantoms()) or not self.metrics:
             return None                                          # metric.py:44-45: ({}, True) for every trajectory
-        arr = trajectories_to_arrays(trajectories)
+        arr = None
+        if not isinstance(trajectories, dict) and len(trajectories):
+            # the planner's objects: packed into the pinned staging buffer by the native helper, one host-to-device copy
+            arr = self.sweep.upload_trajectory_objects(trajectories)
+        if arr is None:
+            arr = trajectories_to_arrays(trajectories)
         self._upload_agents()
         cg = None
         if shard is not None and shard is not False:

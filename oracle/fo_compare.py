@@ -25,14 +25,14 @@ def _dev(a, b):
 
 def compare(ref, got, atol=1e-9):
     """ref: oracle.sweep output (with lists); got: the same keys from the implementation under test.
-    Returns dict(float_max_abs_err, list_max_abs_err, int_mismatches, pattern_mismatches, pairs).
+    Returns dict(float_max_abs_err, list_max_abs_err, list_err_beyond_f32_rounding, int_mismatches, pattern_mismatches, pairs).
 
     Plateau rule (as in tests/test_sweep_gpu.py): where several samples lie within 2 atol of a pair's largest collision
     probability, float noise decides np.argmax's "first maximum" (hr.py:81) and harm_with_cp = obst_harm[argmax cp]
     follows; on those pairs harm_with_cp is checked against the oracle's harm at the index `got` picked, and argmax
     indices count as mismatches only where the maximum is unique and numerically significant."""
     PF, PI, C, L = O.PF, O.PI, O.COST, O.LST
-    worst, lworst, imis, pmis = 0.0, 0.0, 0, 0
+    worst, lworst, lbeyond, imis, pmis = 0.0, 0.0, 0.0, 0, 0
     lists = ref.get("lists")
     have_lists = lists is not None and lists.shape[-1] > 0
     plateau = np.zeros(ref["pair_f"].shape[:2], dtype=bool)
@@ -64,6 +64,14 @@ def compare(ref, got, atol=1e-9):
         if got.get("lists") is not None:
             d, bad = _dev(lists, got["lists"])
             lworst, pmis = max(lworst, d), pmis + bad
+            if got["lists"].dtype == np.float32:
+                # float32 STORAGE of float64 results: how far the float64 value behind an entry can have been from the
+                # oracle's -- the deviation beyond half a float32 ulp of the oracle's value (what the rounding explains)
+                g64 = got["lists"].astype(np.float64)
+                fin = np.isfinite(lists) & np.isfinite(g64)
+                if fin.any():
+                    half = 0.5 * np.spacing(np.abs(lists[fin]).astype(np.float32)).astype(np.float64)
+                    lbeyond = max(lbeyond, float(np.maximum(np.abs(g64[fin] - lists[fin]) - half, 0.0).max()))
     for name in COST_FLOATS:
         a, b = ref["cost"][:, C[name]], got["cost"][:, C[name]]
         if name == "max_obst_harm_with_cp_all":
@@ -74,8 +82,8 @@ def compare(ref, got, atol=1e-9):
     for name in ("argmin_dce", "argmin_ttc", "safe"):
         imis += int((ref["cost"][:, C[name]] != got["cost"][:, C[name]]).sum())
     imis += int((np.asarray(ref["safe"]) != np.asarray(got["safe"])).sum())
-    return {"float_max_abs_err": worst, "list_max_abs_err": lworst, "int_mismatches": imis, "pattern_mismatches": pmis,
-            "pairs": int(ref["pair_f"].shape[0] * ref["pair_f"].shape[1])}
+    return {"float_max_abs_err": worst, "list_max_abs_err": lworst, "list_err_beyond_f32_rounding": lbeyond,
+            "int_mismatches": imis, "pattern_mismatches": pmis, "pairs": int(ref["pair_f"].shape[0] * ref["pair_f"].shape[1])}
 
 
 def merge(acc, part):
@@ -83,6 +91,7 @@ def merge(acc, part):
         return dict(part)
     return {"float_max_abs_err": max(acc["float_max_abs_err"], part["float_max_abs_err"]),
             "list_max_abs_err": max(acc["list_max_abs_err"], part["list_max_abs_err"]),
+            "list_err_beyond_f32_rounding": max(acc.get("list_err_beyond_f32_rounding", 0.0), part.get("list_err_beyond_f32_rounding", 0.0)),
             "int_mismatches": acc["int_mismatches"] + part["int_mismatches"],
             "pattern_mismatches": acc["pattern_mismatches"] + part["pattern_mismatches"],
             "pairs": acc["pairs"] + part["pairs"]}

@@ -399,3 +399,35 @@ def test_lazy_result_dicts_never_leak_placeholders_through_dict_fast_paths():
     assert pickle.loads(pickle.dumps(mk())) == plain and copy.deepcopy(mk()) == plain
     assert all(v is not MM._UNBUILT for v in dict(mk()).values())
     assert "_UNBUILT" not in repr(mk()) and "object object" not in repr(mk())
+
+
+def test_native_trajectory_packer_equals_the_numpy_gather():
+    """csrc/fo_pyhost.c (CPython extension, built by __graft_entry__.build_pyhost): [5][M][T] blocks from the planner's
+    trajectory objects, bit for bit what metrics.metric.trajectories_to_arrays gathers; lists / float32 / strided vectors are
+    converted, a vector of another length raises like the Python path"""
+    import __graft_entry__ as g
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion.metrics.metric import trajectories_to_arrays
+    if g.build_pyhost() is None:
+        pytest.skip("no C compiler / Python headers here")
+    H = N.pyhost()
+    assert H is not None
+    rng = np.random.default_rng(5)
+    M, T = 300, 31
+    objs = [SimpleNamespace(cartesian=SimpleNamespace(**{k: rng.normal(size=T) for k in ("x", "y", "theta", "v", "a")})) for _ in range(M)]
+    objs[3].cartesian.x = list(objs[3].cartesian.x)                        # a list
+    objs[4].cartesian.y = objs[4].cartesian.y.astype(np.float32)           # another dtype
+    objs[5].cartesian.v = np.repeat(objs[5].cartesian.v, 2)[::2]           # a strided view
+    want = trajectories_to_arrays(objs)
+    out = np.full((5, M, T), np.nan)
+    H.pack_trajectories(objs, out, ("x", "y", "theta", "v", "a"))
+    for i, k in enumerate(("x", "y", "theta", "v", "a")):
+        assert np.array_equal(out[i], want[k]), k
+    H.pack_trajectories(tuple(objs), out, ("x", "y", "theta", "v", "a"))   # tuples as well
+    objs[7].cartesian.a = np.zeros(T + 1)
+    with pytest.raises(ValueError):
+        H.pack_trajectories(objs, out, ("x", "y", "theta", "v", "a"))
+    with pytest.raises(ValueError):
+        H.pack_trajectories(objs[:10], out, ("x", "y", "theta", "v", "a"))
+    with pytest.raises(AttributeError):
+        H.pack_trajectories([SimpleNamespace(cartesian=SimpleNamespace(x=np.zeros(T)))] * M, out, ("x", "y", "theta", "v", "a"))

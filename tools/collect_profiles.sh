@@ -19,7 +19,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/${TAG}_pmc$i -o run -- python3 bench.py $ARGS > $OUT/${TAG}_pmc$i.log 2>&1
 done
 # which library these numbers belong to (bench.py prints roofline.traffic only when this id equals the loaded library's)
-LISTS=f32; case " $* " in *" --lists f64 "*) LISTS=f64;; *" --lists f32x "*) LISTS=f32x;; esac
+LISTS=f32x; case " $* " in *" --lists f64 "*) LISTS=f64;; *" --lists f32 "*) LISTS=f32;; esac
 python3 - > $OUT/${TAG}_build.json <<PY
 import json, sys
 sys.path.insert(0, "frenetix-occlusion_amd")
