@@ -52,7 +52,7 @@ class Thresholds(C.Structure):
 class SpawnRuleParams(C.Structure):       # fo_spawn_rule_params_t
     _fields_ = ([(n, C.c_double) for n in ("ego_x", "ego_y", "ego_yaw", "ego_s", "ego_d", "s_threshold", "ped_width", "ped_length")] +
                 [(n, C.c_int32) for n in ("intention", "win_i0", "win_i1", "behind_static", "behind_turn", "behind_dynamic",
-                                          "max_static", "max_dynamic")])
+                                          "max_static", "max_dynamic", "n_dynamic_plus1", "reserved_")])
 
 
 class RuleAgentTypes(C.Structure):       # fo_rule_agent_types_t: index 0 Car, 1 Bicycle, 2 Pedestrian

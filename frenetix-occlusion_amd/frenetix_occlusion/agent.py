@@ -324,10 +324,15 @@ class FOAgentManager:
                 b = self._batch
                 h = b.host_head()
                 R = b.R
-                idx = torch.as_tensor(live, device=b.len.device)
-                raw = b.raw_dims[idx * R].cpu().numpy()
-                ln = b.len.view(-1, R)[idx].cpu().numpy()
-                v0 = b.v[:, 0].reshape(-1, R)[idx].cpu().numpy()
+                idx = np.asarray(live, dtype=np.int64)
+                if b.body is not None:           # one device-to-host copy of the step's predictions, shared with .predictions
+                    hb = b.host_body()
+                    raw, ln, v0 = hb["raw_dims"][idx * R], hb["len"].reshape(-1, R)[idx], hb["v"][:, 0].reshape(-1, R)[idx]
+                else:
+                    ti = torch.as_tensor(live, device=b.len.device)
+                    raw = b.raw_dims[ti * R].cpu().numpy()
+                    ln = b.len.view(-1, R)[ti].cpu().numpy()
+                    v0 = b.v[:, 0].reshape(-1, R)[ti].cpu().numpy()
                 for q, j in enumerate(live):
                     r0 = int(np.argmax(ln[q] > 0))     # first prediction that exists carries the speed
                     self._batch_agents.append(PhantomAgent(self._create_id(), TYPE_NAME[int(h["type"][j * R])], h["pos0"][j].copy(),
@@ -391,9 +396,14 @@ class FOAgentManager:
         if live:
             b = self._batch
             R = b.R
-            sl = (torch.as_tensor(live, device=b.len.device)[:, None] * R + torch.arange(R, device=b.len.device)[None]).reshape(-1)
-            pos, yaw, v = b.pos[sl].cpu().numpy(), b.yaw[sl].cpu().numpy(), b.v[sl].cpu().numpy()
-            cov, shape, ln = b.cov[sl].cpu().numpy(), b.shape[sl].cpu().numpy(), b.len[sl].cpu().numpy()
+            if b.body is not None:
+                hb = b.host_body()
+                sl = (np.asarray(live, dtype=np.int64)[:, None] * R + np.arange(R)[None]).reshape(-1)
+                pos, yaw, v, cov, shape, ln = (hb[k_][sl] for k_ in ("pos", "yaw", "v", "cov", "shape", "len"))
+            else:
+                sl = (torch.as_tensor(live, device=b.len.device)[:, None] * R + torch.arange(R, device=b.len.device)[None]).reshape(-1)
+                pos, yaw, v = b.pos[sl].cpu().numpy(), b.yaw[sl].cpu().numpy(), b.v[sl].cpu().numpy()
+                cov, shape, ln = b.cov[sl].cpu().numpy(), b.shape[sl].cpu().numpy(), b.len[sl].cpu().numpy()
             for q, j in enumerate(live):
                 a = agents[q]
                 a.predictions = []

@@ -68,6 +68,8 @@ class FOInterface:
         self.include_real_agents = bool(acc.get("include_real_agents", False))
         self._timing_sync = str(acc.get("timing", "issue")) == "device"
         self.step_timing = {}
+        self._one_call = bool(acc.get("one_call", True))
+        self._scene_step = None
 
         self.ctx = N.Context(self.device.index)
         self.fo_obstacles = FOObstacles(self.cr_scenario.obstacles)
@@ -143,17 +145,32 @@ class FOInterface:
 
         self.fo_obstacles.update(self.timestep)
         t0 = self._tick("obstacles_ms", t0)
-        self.sensor_model.calc_visible_and_occluded_area(timestep=self.timestep, ego_pos=self.ego_pos,
-                                                         ego_orientation=self.ego_orientation,
-                                                         obstacles=self.fo_obstacles)
-        self.fo_obstacles.update_multipolygon()
-        t0 = self._tick("visibility_ms", t0)
-
-        # phantom sampling, the rule families and the predictions of both stay on the device (interface.py:186-198 without
-        # find_spawn_points' polygons and without add_agent); the spawn-point list is the reference's host view, read back
-        # when somebody looks at it
-        self.spawn_points = self.spawn_locator.find_spawn_points(self.ego_pos, self.ego_orientation, self.ego_pos_cl,
-                                                                 ego_v, lazy=True)
+        # The GPU side of the step -- ray fan, cell classes, visible objects, phantom sampling and / or the reference's rule
+        # families, their agents and predictions, the sweep's agent table -- is ONE native call (fo_step_run through a
+        # PlanningStep without candidate trajectories; ``accelerator.one_call: False`` queues the stage calls instead).
+        # Nothing of interface.py:186-198's find_spawn_points -> add_agent loop runs on the host; the spawn-point list is the
+        # reference's host view, read back when somebody looks at it.
+        sm, sl = self.sensor_model, self.spawn_locator
+        if self._one_call:
+            if self._scene_step is None:
+                from .step import PlanningStep
+                empty = torch.empty((0, sl.T), dtype=torch.float64, device=self.device)
+                self._scene_step = PlanningStep(sm, sl, self.metrics.sweep, empty, empty, empty, empty, empty, mode="reduced")
+            sm.timestep = self.timestep
+            sl.spawn_points, sl._rule_points, sl._n_cell_points = [], [], 0   # (last step's list: only an outside holder keeps it alive)
+            sm.upload_obstacles(self.fo_obstacles)
+            self._scene_step.run(self.ego_pos, self.ego_orientation, ego_v, self.ego_pos_cl)
+            sm.adopt_step(self.ego_pos, self.ego_orientation)
+            sm.read_visible_objects(self.timestep, self.fo_obstacles)
+            self.fo_obstacles.update_multipolygon()
+            t0 = self._tick("visibility_ms", t0)
+            self.spawn_points = sl.lazy_spawn_points()
+        else:
+            sm.calc_visible_and_occluded_area(timestep=self.timestep, ego_pos=self.ego_pos,
+                                              ego_orientation=self.ego_orientation, obstacles=self.fo_obstacles)
+            self.fo_obstacles.update_multipolygon()
+            t0 = self._tick("visibility_ms", t0)
+            self.spawn_points = sl.find_spawn_points(self.ego_pos, self.ego_orientation, self.ego_pos_cl, ego_v, lazy=True)
         t0 = self._tick("spawn_ms", t0)
         self.agent_manager.attach_batch(self.spawn_locator.batch)
         if self.debug:
@@ -168,6 +185,8 @@ class FOInterface:
                 t = getattr(ob, "obstacle_type", None)
                 types[oid] = getattr(t, "value", t) or "car"
             self.agent_manager.set_external_predictions(self.predictions, types)
+        if self._one_call and not (self.agent_manager._manual or self.agent_manager._external):
+            self.metrics.agents_uploaded()        # fo_step_run wrote the sweep's agent table from the device batch
         self._tick("agents_ms", t0)
         if self._timing_sync:          # (counting them reads the device)
             self.step_timing["n_spawn_points"] = len(self.spawn_points)

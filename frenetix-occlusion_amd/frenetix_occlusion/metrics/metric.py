@@ -89,6 +89,7 @@ class BatchAssessment:
         self.metric_order = metric_order
         self.mode = mode
         self._host = None
+        self._small = None
         self._fast = None
         self._hr_tpl = None
 
@@ -103,16 +104,24 @@ class BatchAssessment:
 
     HOST_CACHE_BYTES = 256 << 20     # per-pair outputs up to this size are mirrored on the host in one copy
 
+    def _host_small(self):
+        """cost vectors and flags of the batch on the host (one small copy: what a planner that reads the flag and the six
+        'hr' maxima per candidate needs -- the per-pair outputs stay in HBM until somebody opens a sub-dict)"""
+        if self._small is None:
+            r = self.result
+            self._small = {"cost": r.cost.cpu().numpy(), "safe": r.safe.cpu().numpy()}
+        return self._small
+
     def _to_host(self):
         if self._host is None:
             r = self.result
             big = r.lists_raw is not None and r.lists_raw.numel() * r.lists_raw.element_size() > self.HOST_CACHE_BYTES
-            self._host = {"cost": r.cost.cpu().numpy(), "safe": r.safe.cpu().numpy(),
-                          "pair_f": None if (r.pair_f is None or big) else r.pair_f.cpu().numpy(),
-                          "pair_i": None if (r.pair_i is None or big) else r.pair_i.cpu().numpy(),
-                          # one copy of the raw buffer; the five lists are strided views of it
-                          "lists": None if (r.lists_raw is None or big) else
-                          list_views(r.lists_raw.cpu().numpy(), *r.lists_shape)}
+            self._host = dict(self._host_small(),
+                              pair_f=None if (r.pair_f is None or big) else r.pair_f.cpu().numpy(),
+                              pair_i=None if (r.pair_i is None or big) else r.pair_i.cpu().numpy(),
+                              # one copy of the raw buffer; the five lists are strided views of it
+                              lists=None if (r.lists_raw is None or big) else
+                              list_views(r.lists_raw.cpu().numpy(), *r.lists_shape))
         return self._host
 
     def _column(self, m):
@@ -138,16 +147,19 @@ class BatchAssessment:
         if self._fast is None:
             # what every per-trajectory call of the step needs, made once: the flags and the cost rows as Python lists (a
             # numpy scalar read costs more than the rest of the call), the key template of the result dict
-            h = self._to_host()
-            self._fast = (h["safe"].astype(bool).tolist(), h["cost"].tolist(), dict.fromkeys(self.metric_order, _UNBUILT))
+            h = self._host_small()
+            # (tuples of floats: the garbage collector stops tracking them, 2 000 lists it would walk at every collection)
+            self._fast = (tuple(h["safe"].astype(bool).tolist()), tuple(map(tuple, h["cost"].tolist())),
+                          dict.fromkeys(self.metric_order, _UNBUILT))
         return LazyMetrics(self, m), self._fast[0][m]
 
     def _hr_template(self, lazy):
         """(key template of an 'hr' sub-dict, prediction id -> slot): which predictions carry an entry depends on the
         prediction alone (harm_model.py:65-66: none for an empty horizon), not on the trajectory -- made once per batch"""
         if self._hr_tpl is None:
-            hi = self._to_host()["pair_i"]
-            valid = hi[N.PI["hr_valid"], :, 0] if hi is not None else lazy._column()[1][N.PI["hr_valid"]]
+            # (one row of the index block: whether a prediction has a harm model does not depend on the trajectory)
+            valid = (self._host["pair_i"][N.PI["hr_valid"], :, 0] if self._host is not None and self._host["pair_i"] is not None
+                     else self.result.pair_i[N.PI["hr_valid"], :, 0].cpu().numpy())
             slot = {pid: k for pid, k in self.prediction_slots if valid[k]}
             tpl = dict.fromkeys(slot, _UNBUILT)
             tpl.update(dict.fromkeys(LazyHR.ALL, 0.0))
@@ -298,22 +310,36 @@ class _LazyDict(dict):
         return (dict, (dict(self.materialize()),))
 
 
+class _Column:
+    """the per-pair outputs of ONE trajectory, gathered from the batch on first need and shared by the sub-dicts of its
+    result (a plain holder: the dicts point at it, it points at neither of them -- no reference cycle, so a result dict
+    is freed when the planner drops it instead of waiting for the garbage collector; 2 000 cyclic results per step made the
+    first pass over a batch cost 25 us per call instead of 3)"""
+    __slots__ = ("batch", "m", "col")
+
+    def __init__(self, batch, m):
+        self.batch, self.m, self.col = batch, m, None
+
+    def _column(self):
+        if self.col is None:
+            pf, pi, ls = self.batch._column(self.m)          # [NPF, A], [NPI, A], [NL, A, T-1]
+            # entries past a list's length are NaN (hr.py:87-98 stops at min(T-1, len(prediction))): lengths per slot
+            self.col = (pf, pi, ls, (~np.isnan(ls)).sum(axis=2), pf.tolist(), pi.tolist())
+        return self.col
+
+
 class LazyMetrics(_LazyDict):
     """result dict of one trajectory (keys = the activated metrics in the reference's order, metric.py:125-147)"""
 
     def __init__(self, batch, m):
         dict.__init__(self, batch._fast[2])          # the key template: every metric unbuilt
-        self._batch, self._m, self._col = batch, m, None
+        self._batch, self._m, self._c = batch, m, _Column(batch, m)
 
     def _column(self):
-        if self._col is None:
-            pf, pi, ls = self._batch._column(self._m)        # [NPF, A], [NPI, A], [NL, A, T-1]
-            # entries past a list's length are NaN (hr.py:87-98 stops at min(T-1, len(prediction))): lengths per slot
-            self._col = (pf, pi, ls, (~np.isnan(ls)).sum(axis=2), pf.tolist(), pi.tolist())
-        return self._col
+        return self._c._column()
 
     def _build(self, key):
-        return self._batch._build_metric(self._m, key, self)
+        return self._batch._build_metric(self._m, key, self._c)
 
 
 class LazyHR(_LazyDict):
@@ -362,6 +388,11 @@ class Metric:
         self._batch = None
         self._batch_ids = {}
         self._batch_objs = []
+
+    def agents_uploaded(self):
+        """the planning step (fo_step_run) has written the sweep's agent table from the device batch of this step: the next
+        evaluate_batch need not upload it again"""
+        self._agents_version = 1
 
     def _upload_agents(self):
         if self._agents_version is not None:

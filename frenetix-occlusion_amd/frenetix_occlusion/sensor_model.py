@@ -378,6 +378,9 @@ class SensorModel:
                 host[O * 80:O * 88].view(np.float64)[:] = yaw
                 host[O * 88:O * 104].view(np.float64)[:] = np.asarray(dims, dtype=np.float64).reshape(-1)
             host[O * 104:] = np.asarray(flags, dtype=np.uint8)
+            # obstacles whose flags allow the dynamic-obstacle rule (present, dynamic role, no bicycle / pedestrian): a count the
+            # rule launch wants from the host (fo_spawn_rule_params_t::n_dynamic_plus1); None = flags without role bits
+            self._n_dyn_candidates = int(((host[O * 104:] & 13) == 5).sum()) if yaw is not None else None
             d = torch.as_tensor(host).to(dev)
             self._obst = (d[:O * 64].view(torch.float64).view(O, 4, 2), d[O * 64:O * 80].view(torch.float64).view(O, 2),
                           d[O * 104:], O)
@@ -386,6 +389,7 @@ class SensorModel:
         else:
             self._obst = (None, None, None, 0)
             self._obst_rule = None
+            self._n_dyn_candidates = 0
         return self._obst
 
     def _buffers(self, w, O):
@@ -510,10 +514,31 @@ class SensorModel:
     def calc_visible_and_occluded_area(self, timestep, ego_pos, ego_orientation, obstacles):
         """reference entry point.  obstacles: an FOObstacles (already updated to `timestep`) or None."""
         self.timestep = timestep
-        self.visible_objects_timestep = []
-        self.obstacle_occlusions.clear()
         _, _, _, O = self.upload_obstacles(obstacles)
         self.launch(ego_pos, ego_orientation)
+        return self.read_visible_objects(timestep, obstacles)
+
+    def adopt_step(self, ego_pos, ego_orientation):
+        """after a one-call planning step (``PlanningStep.run`` / ``fo_step_run``) queued this object's kernels: what
+        :meth:`launch` leaves behind -- the visible / occluded area objects over the step's buffers"""
+        b, w = self._buf, self.window
+        full = self.sensor_angle >= 359.9
+        self.ego_pos, self.ego_orientation = np.asarray(ego_pos, dtype=np.float64), float(ego_orientation)
+        dirs, rmax, half = self._fan_buffers()
+        poly = self.footprint == "polygon"
+        self.dirs, self.rmax, self.half_dirs = dirs, (rmax if poly else None), (half if poly else None)
+        self.visible_area = VisibleArea(self.ego_pos, b["ring"], b["rng"], b["hit"], b["cls"], w, full, VISIBLE)
+        self.occluded_area = VisibleArea(self.ego_pos, b["ring"], b["rng"], b["hit"], b["cls"], w, full, OCCLUDED)
+        return self.visible_area
+
+    def read_visible_objects(self, timestep, obstacles):
+        """the side effects the reference's sensor model leaves on its obstacles (sensor_model.py:58-101, 183):
+        ``visible_objects_timestep``, ``current_visible`` / ``last_visible_at_ts`` per obstacle, ``obstacle_occlusions`` --
+        one device-to-host copy of the step's hit ids and visibility flags (the only point of a step where the host waits
+        for the device, and only when there are obstacles)"""
+        self.visible_objects_timestep = []
+        self.obstacle_occlusions.clear()
+        O = getattr(self, "_obst", (None, None, None, 0))[3]
         if O:
             hv = self._buf["hv"].cpu().numpy()
             hit_h = hv[:4 * self.n_rays].view(np.int32)

@@ -64,7 +64,9 @@ class PhantomBatch:
     n_rule_points: int = 0
     rule_points: Optional[torch.Tensor] = None   # [n_rule_points, 8] records of fo_scene_spawn_rules
     rule_n: Optional[torch.Tensor] = None        # int32 [1]
+    body: Optional[torch.Tensor] = None   # uint8: one allocation backing pos | yaw | v | cov | shape | raw_dims | len
     _host: Optional[dict] = None                 # host copy of the head for the current step (lazy views)
+    _host_body: Optional[dict] = None            # host copy of the body (the predictions) for the current step
     _pending: Optional[object] = None            # weak reference to the step's unread LazySpawnPoints
     step: int = 0                                # planning steps queued on this batch (bumped by invalidate)
 
@@ -81,7 +83,25 @@ class PhantomBatch:
             old._get()
         self._pending = None
         self._host = None
+        self._host_body = None
         self.step += 1
+
+    def host_body(self):
+        """dict(pos [slots,T,2], yaw [slots,T], v [slots,T], cov [slots,T,2,2], shape [slots,2], raw_dims [slots,2], len [slots])
+        on the host with ONE device-to-host copy per step (the reference's views of the phantom set -- ``phantom_agents``,
+        ``predictions`` -- are cut from it; cached until :meth:`invalidate`)"""
+        if self._host_body is None:
+            S_, T = self.pos.shape[0], self.pos.shape[1]
+            h = self.body.cpu().numpy()
+            o, out = 0, {}
+            for name, shp in (("pos", (S_, T, 2)), ("yaw", (S_, T)), ("v", (S_, T)), ("cov", (S_, T, 2, 2)), ("shape", (S_, 2)),
+                              ("raw_dims", (S_, 2))):
+                n = int(np.prod(shp)) * 8
+                out[name] = h[o:o + n].view(np.float64).reshape(shp)
+                o += n
+            out["len"] = h[o:o + 4 * S_].view(np.int32)
+            self._host_body = out
+        return self._host_body
 
     def host_head(self):
         """dict(n, rule_n, pos0 [agents,2], yaw0 [agents], rule_points [n_rule_points,8], type [slots]) on the host with ONE
@@ -285,10 +305,17 @@ class SpawnLocator:
         o4 = o3 + 8
         head = torch.zeros(o4 + 4 * S_ + 4, dtype=torch.uint8, device=dev)
         cnt = head[o3:o4].view(torch.int32)
+        # the predictions live in one allocation as well: pos | yaw | v | cov | shape | raw_dims (float64) | len (int32) -- the host
+        # views of a step (FOAgentManager.phantom_agents / .predictions) cost one copy instead of ten
+        sizes = [S_ * T * 2, S_ * T, S_ * T, S_ * T * 4, S_ * 2, S_ * 2]
+        body = torch.zeros(8 * sum(sizes) + 4 * S_, dtype=torch.uint8, device=dev)
+        offs = np.concatenate(([0], np.cumsum(sizes))) * 8
+        fv = lambda k, *shape: body[int(offs[k]):int(offs[k + 1])].view(torch.float64).view(*shape)
         return PhantomBatch(n=cnt[0:1], cell=i(max(Ac, 1)), pos0=head[:o1].view(torch.float64).view(A, 2),
-                            yaw0=head[o1:o2].view(torch.float64), pos=f(S_, T, 2), yaw=f(S_, T), v=f(S_, T),
-                            cov=f(S_, T, 2, 2), shape=f(S_, 2), raw_dims=f(S_, 2),
-                            type=head[o4:o4 + 4 * S_].view(torch.int32), len=i(S_), R=self.R, head=head,
+                            yaw0=head[o1:o2].view(torch.float64), pos=fv(0, S_, T, 2), yaw=fv(1, S_, T), v=fv(2, S_, T),
+                            cov=fv(3, S_, T, 2, 2), shape=fv(4, S_, 2), raw_dims=fv(5, S_, 2),
+                            type=head[o4:o4 + 4 * S_].view(torch.int32), len=body[int(offs[6]):].view(torch.int32), R=self.R,
+                            head=head, body=body,
                             n_cell_agents=Ac, n_rule_points=Rp,
                             rule_points=head[o2:o3].view(torch.float64).view(Rp, 8) if Rp else None,
                             rule_n=cnt[1:2] if Rp else None)
@@ -383,10 +410,13 @@ class SpawnLocator:
             intention = self._intent
         self.last_intention = ("straight ahead", "left turn", "right turn")[intention]
         c = self._rule_cfg
+        # how many of this step's obstacles can take the dynamic rule at all (host flags: present, dynamic role, no bicycle /
+        # pedestrian): the rule's big workgroups are launched for those only (fo_spawn_rule_params_t::n_dynamic_plus1)
+        n_dyn = getattr(self.sensor_model, "_n_dyn_candidates", None)
         return N.SpawnRuleParams(float(ego_pos[0]), float(ego_pos[1]), float(ego_orientation), s_ego, float(ego_pos_cl[1]),
                                  s_ego + max(float(ego_v) * S_THRESHOLD_TIME, S_THRESHOLD_MIN), c["ped_width"], c["ped_length"],
                                  intention, i0, i1, c["behind_static"], c["behind_turn"], c["behind_dynamic"], c["max_static"],
-                                 c["max_dynamic"])
+                                 c["max_dynamic"], 0 if n_dyn is None else n_dyn + 1, 0)
 
     def rule_obstacle_ptrs(self):
         """(O, corners, centres, headings, dimensions, flags, visibility) device pointers of this step's obstacles as the rule
@@ -454,6 +484,15 @@ class SpawnLocator:
         cells, rules = self._points_from_head(b)
         self._n_cell_points, self._rule_points = len(cells), rules
         return cells + rules
+
+    def lazy_spawn_points(self):
+        """the spawn-point list of a step that was queued elsewhere (``PlanningStep.run`` / ``fo_step_run`` on this locator's
+        batch): the reference's list, read back from the device when first looked at"""
+        b = self.batch
+        self._rule_points, self._n_cell_points = [], 0
+        self.spawn_points = LazySpawnPoints(lambda: self._materialize(b), b)
+        b._pending = weakref.ref(self.spawn_points)
+        return self.spawn_points
 
     def find_spawn_points(self, ego_pos, ego_orientation, ego_pos_cl, ego_v, lazy=False):
         """reference signature (spawn_locator.py:80): returns list[SpawnPoint].  Everything is decided on the device --

@@ -139,7 +139,7 @@ class PlanningStep:
         s.max_dist = sl.max_distance(ego_v)
         self.ctx._check(self.ctx._lib.fo_step_run(self.ctx._h, C.byref(s), N.current_stream(sm._dev_index)))
         # the stage objects see the step as if they had queued it themselves
-        sm.window, sm.ego_pos, sm.ego_orientation = w, ego_pos, yaw
+        sm.window, sm.ego_pos, sm.ego_orientation, sm.edge_skip = w, ego_pos, yaw, skip
         b = self._buf
         sm.range, sm.hit_id, sm.cell_class = b["rng"], b["hit"], b["cls"]
         sm.occluded_idx_buffer, sm.n_occluded = b["occ"], b["n_occ"]

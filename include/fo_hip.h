@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 10
+#define FO_ABI_VERSION 11
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -280,12 +280,17 @@ int fo_scene_set_topology(fo_ctx *ctx, int P, const double *h_left0, const int32
 /* per-step scalars of the rules: ego pose, its curvilinear position, s_threshold = s_ego + max(4 v_ego, 25)
  * (spawn_locator.py:65-66,113), the ego's intention (0 straight ahead, 1 left turn, 2 right turn: curvature of the next
  * 40 m of the reference path, :678-693,729-741) and that window as vertex range [win_i0, win_i1) of the path table, the
- * switches and maxima of the YAML (spawn_locator section), the pedestrian's width / length (agent_manager section) */
+ * switches and maxima of the YAML (spawn_locator section), the pedestrian's width / length (agent_manager section).
+ * n_dynamic_plus1 (ABI 11): 1 + the number of this step's obstacles whose flags allow the dynamic-obstacle rule at all -- present
+ * (bit0), dynamic role (bit2), neither bicycle nor pedestrian (bit3 clear) -- or 0 = not told (every obstacle is assumed to).  The
+ * rule's lattice workgroups (sixteen per obstacle, a CU each) are launched for that many obstacles only, and not at all for none:
+ * the flags are the caller's own data, whether such an obstacle is visible stays a decision of the device. */
 typedef struct {
   double ego_x, ego_y, ego_yaw, ego_s, ego_d, s_threshold;
   double ped_width, ped_length;
   int32_t intention, win_i0, win_i1;
   int32_t behind_static, behind_turn, behind_dynamic, max_static, max_dynamic;
+  int32_t n_dynamic_plus1, reserved_;
 } fo_spawn_rule_params_t;
 
 /* Per step, after fo_scene_visibility on the same stream.  d_cls + window: that call's cell classes.  d_path6 [n_path][6]:

@@ -22,7 +22,17 @@ ego = sc.ego_initial
 ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
 v = SY.VEHICLE_BMW320I
 veh = SimpleNamespace(length=v[0], width=v[1], wb_rear_axle=v[2], mass=v[3], a_max=v[4])
-fo = interface.FOInterface(sc, ref_path, veh, 0.1)
+# the BASELINE-config sampler (32 phantom slots around the ego), so that every call has something to report -- the default YAML
+# runs the reference's rule families, which spawn nothing at scenario 1's first pose
+import tempfile
+import yaml
+with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+    cfg = yaml.safe_load(f)
+cfg["accelerator"]["spawn"].update(mode="cells", max_agents=32)
+with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+    yaml.safe_dump(cfg, f)
+fo = interface.FOInterface(sc, ref_path, veh, 0.1, config_path=f.name)
+os.remove(f.name)
 traj = SY.make_trajectories(M, seed=1, ego_pos=ego[:2], ego_yaw=float(ego[2]))
 objs = [SimpleNamespace(cartesian=SimpleNamespace(**{k: a[i] for k, a in traj.items()})) for i in range(M)]
 for rep in range(3):
@@ -30,6 +40,7 @@ for rep in range(3):
     fo.evaluate_scenario({}, ego[:2], float(ego[2]), (0.0, 0.0), float(ego[3]), 0, None)
     t1 = time.perf_counter()
     fo.trajectory_safety_assessment_batch(objs, mode="full")
+    t_issue = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     acc = 0.0
@@ -41,6 +52,23 @@ for rep in range(3):
         res, safe = fo.trajectory_safety_assessment(o)
         res.materialize()
     t4 = time.perf_counter()
+# the packing alone: the native helper (csrc/fo_pyhost.c) and the numpy gather it replaces
+from frenetix_occlusion import _native as N
+from frenetix_occlusion.metrics.metric import trajectories_to_arrays
+H = N.pyhost()
+pack_native = pack_numpy = float("nan")
+if H is not None:
+    out = np.empty((5, M, len(objs[0].cartesian.x)))
+    H.pack_trajectories(objs, out, ("x", "y", "theta", "v", "a"))
+    t_ = time.perf_counter()
+    for _ in range(20):
+        H.pack_trajectories(objs, out, ("x", "y", "theta", "v", "a"))
+    pack_native = (time.perf_counter() - t_) / 20 * 1e3
+t_ = time.perf_counter()
+for _ in range(5):
+    trajectories_to_arrays(objs)
+pack_numpy = (time.perf_counter() - t_) / 5 * 1e3
+print(f"packing {M} trajectory objects: native helper {pack_native:.3f} ms, numpy gather {pack_numpy:.3f} ms; batch call issued in {1e3 * (t_issue - t1):.3f} ms")
 print(f"M = {M}, {len(fo.agent_manager.predictions)} predictions: evaluate_scenario {1e3 * (t1 - t0):.3f} ms, batch (pack {M} objects + "
       f"sweep + sync) {1e3 * (t2 - t1):.3f} ms, then {M} per-trajectory calls reading the flag and hr.max_obst_risk_all: "
       f"{1e6 * (t3 - t2) / M:.1f} us each ({1e3 * (t3 - t2):.2f} ms in all); with every sub-dict opened: {1e6 * (t4 - t3) / 50:.1f} us each")
