@@ -975,26 +975,17 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
 // flags of an obstacle at this step: bit0 present, bit1 occludes (not a bicycle), bit2 dynamic role, bit3 type bicycle or
 // pedestrian (never triggers the dynamic rule, :209-210)
 constexpr int RL_THREADS = 1024;   // the dynamic rule's lattice work spreads over sixteen waves (the other rules use one)
-constexpr int RL_THREADS_SMALL = 128;   // the launch of the turn rule, the records and the static rule: two waves per obstacle
-// Two launch shapes of one kernel body (round 5).  DYNK = false: block 0 = the turn rule, blocks 1 .. O = an obstacle each (its
-// record, the static rule) on two waves and 43 KB of LDS.  DYNK = true: the dynamic rule's sixteen workgroups of sixteen waves
-// (144 KB of LDS each, a CU apiece) -- for the obstacles whose HOST-known flags allow the rule at all (present, dynamic role, no
-// bicycle / pedestrian: fo_spawn_rule_params_t::n_dynamic_plus1), not for every obstacle: whether such an obstacle is visible
-// and the rule applies is device data, but how many workgroups of that shape have to be dispatched is not, and dispatching
-// 1 + 16 O of them cost 20 us of every step of scenario 1 (seven obstacles, one of them a moving truck) before the first did
-// anything -- with no candidate at all the second launch does not happen.
-template <bool DYNK>
-__global__ __launch_bounds__(DYNK ? RL_THREADS : RL_THREADS_SMALL) void fo_spawn_rules_kernel(
-    RuleView v, RuleParams pr, int O, const double *__restrict__ ocorn, const double *__restrict__ ocen, const double *__restrict__ oyaw,
-    const double *__restrict__ odims, const uint8_t *__restrict__ oflags, const uint8_t *__restrict__ ovis, double *__restrict__ recs,
-    int *__restrict__ g_lab, int *__restrict__ g_cnt) {
-  // one LDS arena, carved per rule (the dynamic rule needs the two lattice arrays: 2 x 37.6 KB; the others the front of `lab`
-  // -- four rows of RL_MAXSAMP doubles -- and a second copy of the path table in `red`)
-  __shared__ int lab[DYNK ? RL_LAT * RL_LAT : 8 * RL_MAXSAMP];
-  __shared__ int ired[DYNK ? RL_LAT * RL_LAT : 1];
-  __shared__ double red[DYNK ? 3 * RL_THREADS : 6 * RL_PATHV];
-  __shared__ unsigned char bytes[2 * RL_MAXSAMP];
-  __shared__ double polyv[DYNK ? 2 * RL_PVERT : 1];   // dynamic rule: the vertices of the candidate region's lanelet polygons
+__global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, RuleParams pr, int O, const double *__restrict__ ocorn,
+                                                             const double *__restrict__ ocen, const double *__restrict__ oyaw,
+                                                             const double *__restrict__ odims, const uint8_t *__restrict__ oflags,
+                                                             const uint8_t *__restrict__ ovis, double *__restrict__ recs,
+                                                             int *__restrict__ g_lab, int *__restrict__ g_cnt, int all_obstacles, int n_helped) {
+  // one LDS arena, carved per rule (the dynamic rule needs the two lattice arrays: 2 x 37.6 KB)
+  __shared__ int lab[RL_LAT * RL_LAT];
+  __shared__ int ired[RL_LAT * RL_LAT];
+  __shared__ double red[3 * RL_THREADS];
+  __shared__ unsigned char bytes[2048];
+  __shared__ double polyv[2 * RL_PVERT];   // dynamic rule: the vertices of the candidate region's lanelet polygons
   // the reference path table into LDS: the projections and the arc-length searches of every rule are chains of dependent
   // reads of it (a binary search in HBM costs eight round trips of ~0.6 us; in LDS, of ~30 ns)
   __shared__ double pathv[6 * RL_PATHV];
@@ -1009,7 +1000,7 @@ __global__ __launch_bounds__(DYNK ? RL_THREADS : RL_THREADS_SMALL) void fo_spawn
       v.path = dst;
     }
   };
-  if (!DYNK && blockIdx.x == 0) {   // the turn rule's record
+  if (blockIdx.x == 0) {   // the turn rule's record
     if (wave > 0) return;
     double *rec = recs;
     for (int i = lane; i < RL_REC; i += 64) rec[i] = 0.0;
@@ -1020,36 +1011,39 @@ __global__ __launch_bounds__(DYNK ? RL_THREADS : RL_THREADS_SMALL) void fo_spawn
     }
     return;
   }
-  // DYNK = false, blocks 1 .. O: an obstacle each (its record, the static rule).  DYNK = true: block b = part b % RL_PARTS of the
-  // lattice of the (b / RL_PARTS)-th obstacle whose flags allow the dynamic rule (present, dynamic role, no bicycle / pedestrian)
-  int o = (int)blockIdx.x - 1, part = 0;
-  if (DYNK) {
-    int want = (int)blockIdx.x / RL_PARTS;
-    part = (int)blockIdx.x % RL_PARTS;
-    o = -1;
-    for (int i = 0; i < O; ++i)
-      if ((oflags[i] & 13) == 5 && want-- == 0) { o = i; break; }
-    if (o < 0) return;       // (the host counted more candidates than there are: nothing to do)
+  // blocks 1 .. O: an obstacle each (its record, the static rule, part 0 of the dynamic rule's lattice); blocks beyond: the
+  // other RL_PARTS - 1 parts of the dynamic rule's lattice -- of the c-th obstacle whose HOST-known flags allow the rule at
+  // all (present, dynamic role, no bicycle / pedestrian), c = (b - 1 - O) / (RL_PARTS - 1): the caller says how many there
+  // are (fo_spawn_rule_params_t::n_dynamic_plus1), and the launch dispatches helper workgroups -- sixteen waves and 144 KB of
+  // LDS each, a CU apiece -- for those only instead of for every obstacle (scenario 1: 23 workgroups instead of 113; whether
+  // such an obstacle is visible and the rule applies stays a decision of the device).  `all_obstacles`: the caller did not say.
+  const bool helper = (int)blockIdx.x > O;
+  int o = (int)blockIdx.x - 1;
+  const int part = helper ? 1 + ((int)blockIdx.x - 1 - O) % (RL_PARTS - 1) : 0;
+  if (helper) {
+    int want = ((int)blockIdx.x - 1 - O) / (RL_PARTS - 1);
+    if (all_obstacles) o = want;
+    else {
+      o = -1;
+      for (int i = 0; i < O; ++i)
+        if ((oflags[i] & 13) == 5 && want-- == 0) { o = i; break; }
+      if (o < 0) return;      // (the caller counted more candidates than the flags hold: nothing to do)
+    }
   }
   double *rec = recs + (size_t)(1 + o) * RL_REC;
   const bool vis = (oflags[o] & 1) && ovis[o];
   // (one call site for the dynamic rule, inlined: a call would put the kernel's RuleView on a stack in scratch memory -- and a
   // kernel with a private segment is dispatched noticeably later than one without, measured ~11 us here)
-  const bool dyn_rule = vis && (oflags[o] & 4) && !(oflags[o] & 8) && pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1);
-  if (DYNK && !dyn_rule) return;
-  if (!DYNK && dyn_rule) {
-    // the obstacle's record belongs to the dynamic rule (the second launch: its parts clear the validity words, its last part
-    // writes the fits): the head -- distance to the ego, role -- is written here
-    if (wave > 0) return;
-    for (int i = lane; i < RL_REC; i += 64) rec[i] = 0.0;
-    if (lane == 0) {
-      const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
-      rec[0] = sqrt(dx * dx + dy * dy);
-      rec[1] = 2.0;
-    }
-    return;
+  bool dyn_rule = vis && (oflags[o] & 4) && !(oflags[o] & 8) && pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1);
+  if (dyn_rule && !helper && !all_obstacles) {
+    // (a caller that counted fewer candidates than its flags hold: an obstacle beyond the count has no helper workgroups --
+    // its lattice would never be handed over -- and is treated like a dynamic obstacle the rule does not apply to)
+    int rank = 0;
+    for (int i = 0; i < o; ++i) rank += (oflags[i] & 13) == 5;
+    if (rank >= n_helped) dyn_rule = false;
   }
-  if constexpr (!DYNK) {
+  if (helper && !dyn_rule) return;
+  if (!dyn_rule) {
     // the obstacle's own workgroup without the dynamic rule: wave 0 keeps the record's head and the first cross line of the
     // static rule, wave 1 the second (helper workgroups of an obstacle WITHOUT the dynamic rule have returned above; with it,
     // every part clears the two validity words rec[2] / rec[5] in rl_dynamic_rule before its hand-off ticket -- the same value
@@ -1074,17 +1068,25 @@ __global__ __launch_bounds__(DYNK ? RL_THREADS : RL_THREADS_SMALL) void fo_spawn
                      bytes + RL_MAXSAMP * wave, wave);
     }
     return;
-  } else {
-    // the dynamic rule (straight ahead or left turn, :124-126): all sixteen waves, sixteen workgroups per obstacle (the record's
-    // head and its clearing: the first launch)
-    if (v.n_path <= RL_PATHV) {
-      for (int i = threadIdx.x; i < 6 * v.n_path; i += blockDim.x) pathv[i] = v.path[i];
-      v.path = pathv;
-    }
-    __syncthreads();
-    RL_WTICK(1);
-    rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, part, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
   }
+  // the dynamic rule (straight ahead or left turn, :124-126): all sixteen waves, sixteen workgroups per obstacle
+  if (v.n_path <= RL_PATHV) {
+    for (int i = threadIdx.x; i < 6 * v.n_path; i += blockDim.x) pathv[i] = v.path[i];
+    v.path = pathv;
+  }
+  if (!helper) {
+    // (no fence behind the clear: the only other writer of the record is the rule's last part, which takes its ticket after this
+    // workgroup has released its own -- rl_dynamic_rule fences before the ticket)
+    if (threadIdx.x < RL_REC) rec[threadIdx.x] = 0.0;
+  }
+  __syncthreads();
+  RL_WTICK(1);
+  if (!helper && threadIdx.x == 0) {
+    const double dx = pr.ego_x - ocen[2 * o], dy = pr.ego_y - ocen[2 * o + 1];
+    rec[0] = sqrt(dx * dx + dy * dy);
+    rec[1] = 2.0;
+  }
+  rl_dynamic_rule(v, pr, o, ocorn, ocen, oyaw, odims, rec, lab, red, ired, bytes, polyv, part, g_lab + (size_t)o * (RL_LAT * RL_LAT), g_cnt + o);
 }
 
 // what depends on the order of the obstacles: both lists sorted by distance (stable), the maxima of the YAML compared
@@ -1318,14 +1320,13 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
     if ((rc = fo_reserve(ctx, &sc->d_rule_cnt, &sc->cap_rule_cnt, (size_t)(O > 0 ? O : 1)))) return rc;
     if (sc->cap_rule_cnt != cap0) FO_HIP_TRY(ctx, hipMemsetAsync(sc->d_rule_cnt, 0, sc->cap_rule_cnt * sizeof(int), s));
   }
-  hipLaunchKernelGGL(fo_spawn_rules_kernel<false>, dim3(1 + O), dim3(RL_THREADS_SMALL), 0, s, v, pr, O, d_ocorn, d_ocen, d_oyaw, d_odims,
-                     d_oflags, d_obst_vis, sc->d_rule_rec, sc->d_rule_lab, sc->d_rule_cnt);
-  // the dynamic rule's launch: sixteen big workgroups per obstacle that MAY take it (n_dynamic_plus1 - 1 of them by the caller's
-  // flags; 0 = not told: every obstacle) -- none when the rule is off, the ego turns right, or no obstacle qualifies
-  const int n_dyn = params->n_dynamic_plus1 > 0 ? (params->n_dynamic_plus1 - 1 < O ? params->n_dynamic_plus1 - 1 : O) : O;
-  if (n_dyn > 0 && pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1))
-    hipLaunchKernelGGL(fo_spawn_rules_kernel<true>, dim3(n_dyn * RL_PARTS), dim3(RL_THREADS), 0, s, v, pr, O, d_ocorn, d_ocen, d_oyaw,
-                       d_odims, d_oflags, d_obst_vis, sc->d_rule_rec, sc->d_rule_lab, sc->d_rule_cnt);
+  // helper workgroups of the dynamic rule for the obstacles that MAY take it (n_dynamic_plus1 - 1 of them by the caller's flags;
+  // 0 = not told: every obstacle) -- none when the rule is off or the ego turns right
+  const bool told = params->n_dynamic_plus1 > 0;
+  int n_dyn = told ? (params->n_dynamic_plus1 - 1 < O ? params->n_dynamic_plus1 - 1 : O) : O;
+  if (!(pr.behind_dynamic && (pr.intention == 0 || pr.intention == 1))) n_dyn = 0;
+  hipLaunchKernelGGL(fo_spawn_rules_kernel, dim3(1 + O + n_dyn * (RL_PARTS - 1)), dim3(RL_THREADS), 0, s, v, pr, O, d_ocorn, d_ocen,
+                     d_oyaw, d_odims, d_oflags, d_obst_vis, sc->d_rule_rec, sc->d_rule_lab, sc->d_rule_cnt, told ? 0 : 1, n_dyn);
   hipLaunchKernelGGL(fo_spawn_rules_select_kernel, dim3(1), dim3(64), 0, s, v, pr, O, d_ocorn, d_oflags, d_obst_vis,
                      sc->d_rule_rec, max_out, d_out, d_n_out);
   FO_HIP_TRY(ctx, hipGetLastError());

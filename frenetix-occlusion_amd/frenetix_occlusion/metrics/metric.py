@@ -221,6 +221,8 @@ class _LazyDict(dict):
     ``d.update(m)`` copy the raw storage only while ``tp_iter`` is dict's own -- overriding ``__iter__`` / ``keys`` sends
     them through ``keys()`` + ``__getitem__``; ``pop`` / ``popitem`` / ``setdefault`` / ``|`` are overridden one by one"""
 
+    __slots__ = ()          # (subclasses name their few fields: no per-instance __dict__ for the garbage collector to track)
+
     def _build(self, key):
         raise NotImplementedError
 
@@ -330,6 +332,7 @@ class _Column:
 
 class LazyMetrics(_LazyDict):
     """result dict of one trajectory (keys = the activated metrics in the reference's order, metric.py:125-147)"""
+    __slots__ = ("_batch", "_m", "_c")
 
     def __init__(self, batch, m):
         dict.__init__(self, batch._fast[2])          # the key template: every metric unbuilt
@@ -346,6 +349,7 @@ class LazyHR(_LazyDict):
     """the 'hr' sub-dict: one entry per prediction with a harm model + the six maxima over all of them (hr.py:87-114)"""
     ALL = ("max_ego_risk_all", "max_obst_risk_all", "max_ego_harm_all", "max_obst_harm_all",
            "max_collision_probability_all", "max_obst_harm_with_cp_all")
+    __slots__ = ("_slot", "_batch", "_lazy")
 
     def __init__(self, batch, m, cost, lazy):
         # the keys (one per prediction with a harm model, then the six maxima) come from a template made once per batch; a

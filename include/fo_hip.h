@@ -283,8 +283,9 @@ int fo_scene_set_topology(fo_ctx *ctx, int P, const double *h_left0, const int32
  * switches and maxima of the YAML (spawn_locator section), the pedestrian's width / length (agent_manager section).
  * n_dynamic_plus1 (ABI 11): 1 + the number of this step's obstacles whose flags allow the dynamic-obstacle rule at all -- present
  * (bit0), dynamic role (bit2), neither bicycle nor pedestrian (bit3 clear) -- or 0 = not told (every obstacle is assumed to).  The
- * rule's lattice workgroups (sixteen per obstacle, a CU each) are launched for that many obstacles only, and not at all for none:
- * the flags are the caller's own data, whether such an obstacle is visible stays a decision of the device. */
+ * rule's helper workgroups (fifteen per obstacle, a CU each) are launched for that many obstacles only -- the first ones in list
+ * order whose flags qualify; one beyond the count is treated as if the rule did not apply to it -- and for none at all when no
+ * obstacle qualifies: the flags are the caller's own data, whether such an obstacle is visible stays a decision of the device. */
 typedef struct {
   double ego_x, ego_y, ego_yaw, ego_s, ego_d, s_threshold;
   double ped_width, ped_length;

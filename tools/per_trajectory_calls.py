@@ -44,7 +44,10 @@ for rep in range(3):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     acc = 0.0
-    for o in objs:
+    res, safe = fo.trajectory_safety_assessment(objs[0])      # the first call of a step makes the host mirror of cost / safe
+    acc += res["hr"]["max_obst_risk_all"] + safe
+    t_first = time.perf_counter()
+    for o in objs[1:]:
         res, safe = fo.trajectory_safety_assessment(o)
         acc += res["hr"]["max_obst_risk_all"] + safe
     t3 = time.perf_counter()
@@ -71,5 +74,6 @@ pack_numpy = (time.perf_counter() - t_) / 5 * 1e3
 print(f"packing {M} trajectory objects: native helper {pack_native:.3f} ms, numpy gather {pack_numpy:.3f} ms; batch call issued in {1e3 * (t_issue - t1):.3f} ms")
 print(f"M = {M}, {len(fo.agent_manager.predictions)} predictions: evaluate_scenario {1e3 * (t1 - t0):.3f} ms, batch (pack {M} objects + "
       f"sweep + sync) {1e3 * (t2 - t1):.3f} ms, then {M} per-trajectory calls reading the flag and hr.max_obst_risk_all: "
-      f"{1e6 * (t3 - t2) / M:.1f} us each ({1e3 * (t3 - t2):.2f} ms in all); with every sub-dict opened: {1e6 * (t4 - t3) / 50:.1f} us each")
+      f"{1e6 * (t3 - t2) / M:.1f} us each ({1e3 * (t3 - t2):.2f} ms in all, of which the first call {1e3 * (t_first - t2):.2f} ms); "
+      f"with every sub-dict opened: {1e6 * (t4 - t3) / 50:.1f} us each (first one mirrors the per-pair outputs of the whole batch)")
 print("step_timing:", {k: (round(x, 3) if isinstance(x, float) else x) for k, x in fo.step_timing.items()})
