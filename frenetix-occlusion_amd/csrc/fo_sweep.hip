@@ -82,6 +82,9 @@ __global__ void fo_erf_table_kernel(double2 *tab) {
 #ifndef FO_ERF_ORDER
 #define FO_ERF_ORDER 3
 #endif
+// (Round 5, measured and dropped: the scale of y folded into the two constants of the inner fma, both parked in vector
+// registers by the caller -- one multiplication less per erf -- 0.529 ms against 0.515: four registers more across the box
+// loops of a kernel that sits at its register cap cost thirteen more spilled ones.)
 __device__ __forceinline__ double fo_erf_fast128(const double2 *__restrict__ tab, double v) {
   constexpr double S = 0x1p-14;
   const double av = fmin(fabs(v), 768.0);
@@ -91,9 +94,9 @@ __device__ __forceinline__ double fo_erf_fast128(const double2 *__restrict__ tab
   const int i = __double2loint(tm);
   const double d = av - fi;
   const double2 e = tab[i];
-  const double y = fi * (d * S);
   const double sq = d * d;
   const double a0 = fma(sq, -S / 3.0, 1.0);
+  const double y = fi * (d * S);
 #if FO_ERF_ORDER >= 4
   const double a1 = fma(sq, S / 2.0, -1.0);
   const double u = y * (2.0 - y);
@@ -649,6 +652,9 @@ __global__ __launch_bounds__(TILE *WAVES) void fo_sweep_generic_kernel(const Swe
 #ifndef FO_DYN
 #define FO_DYN 0     // 1: the waves of a workgroup draw the chunk's agents one by one from an LDS counter (tuning builds)
 #endif
+#ifndef FO_BOX_UNROLL
+#define FO_BOX_UNROLL 1   // 0: tuning builds -- the three boxes of a mean one after the other outside the horizon-split form
+#endif
 #ifndef FO_POOL
 #define FO_POOL 1    // in-gate samples pooled over the workgroup's four waves at the end of every pass 1 (0: tuning builds -- every wave evaluates its own, inline)
 #endif
@@ -910,7 +916,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         // the three boxes of a mean side by side (twelve table reads in flight; round 4 kept that to the horizon-split form,
         // whose heavy waves are bound by the latency of this loop -- with the shorter erf step the registers are there in
         // every form: 0.514 -> 0.508 ms on the headline; all nine boxes in a row: 0.520)
-#pragma unroll 3
+#pragma unroll (FO_BOX_UNROLL || (SPLIT && !PAIR) ? 3 : 1)
         for (int b = 0; b < 3; ++b) {
           const double fx = fo_erf_fast128(erf_tab, cx + ox) - fo_erf_fast128(erf_tab, cx - ox);
           const double fy = fo_erf_fast128(erf_tab, cy + oy) - fo_erf_fast128(erf_tab, cy - oy);
@@ -1565,11 +1571,12 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 if (orr > max_or) { max_or = orr; idx_or = t; }
               }
               if (cp > max_cp) { max_cp = cp; idx_cp = t; oh_at_cp = oh; }
-              if (LISTS == LST_F32) { cpf = (float)cp; erf_ = (float)er; orf = (float)orr; }
+              if (lst_is32(LISTS)) { cpf = (float)cp; erf_ = (float)er; orf = (float)orr; }
             }
-            if (LISTS == LST_F32X) {   // the float64 results, rounded at the store
-              ehf = (float)eh; ohf = (float)oh; cpf = (float)cp; erf_ = (float)er; orf = (float)orr;
-            }
+            // FO_LISTS_F32_EXACT: the float64 harm values, rounded at the store.  (The probability and the risks are converted on
+            // the rows that have them, above; on the others they are the float32 constants 0 -- converted behind the branches, the
+            // zeros cost three v_mov_b64 and three v_cvt_f32_f64 per sample on 97 % of the rows.)
+            if (LISTS == LST_F32X) { ehf = (float)eh; ohf = (float)oh; }
             if (LISTS == LST_F64) {
               __builtin_nontemporal_store(cp, (double *)(lb0 + lo1));
               __builtin_nontemporal_store(fo_d2{eh, oh}, (fo_d2 *)(lb1 + lo2));

@@ -148,9 +148,9 @@ class BatchAssessment:
             # what every per-trajectory call of the step needs, made once: the flags and the cost rows as Python lists (a
             # numpy scalar read costs more than the rest of the call), the key template of the result dict
             h = self._host_small()
-            # (tuples of floats: the garbage collector stops tracking them, 2 000 lists it would walk at every collection)
-            self._fast = (tuple(h["safe"].astype(bool).tolist()), tuple(map(tuple, h["cost"].tolist())),
-                          dict.fromkeys(self.metric_order, _UNBUILT))
+            # (ONE flat list of floats, row m at [16 m, 16 m + 16): a list per row would be 2 000 containers for the garbage
+            # collector -- allocating them triggered a full collection, 16 ms inside the first call of a step)
+            self._fast = (h["safe"].astype(bool).tolist(), h["cost"].ravel().tolist(), dict.fromkeys(self.metric_order, _UNBUILT))
         return LazyMetrics(self, m), self._fast[0][m]
 
     def _hr_template(self, lazy):
@@ -169,11 +169,11 @@ class BatchAssessment:
     def _build_metric(self, m, name, lazy):
         """sub-dict of metric `name` for trajectory m; ``lazy._column()`` = that trajectory's column (see _column), gathered
         on first need and shared by the metrics of one LazyMetrics ('wttc' and the six maxima of 'hr' do not need it)"""
-        cost = self._fast[1][m]                      # (result_dict made the lists)
+        cost, base = self._fast[1], N.NC * m        # (result_dict made the flat list of cost rows)
         if name == "wttc":
-            return cost[N.COST["wttc"]]
+            return cost[base + N.COST["wttc"]]
         if name == "hr":
-            return LazyHR(self, m, cost, lazy)
+            return LazyHR(self, base, cost, lazy)
         pf, pi, ls, n_valid, pf_l, pi_l = lazy._column()
         PF, PI, LST = N.PF, N.PI, N.LST
         slots = self.prediction_slots
@@ -351,13 +351,14 @@ class LazyHR(_LazyDict):
            "max_collision_probability_all", "max_obst_harm_with_cp_all")
     __slots__ = ("_slot", "_batch", "_lazy")
 
-    def __init__(self, batch, m, cost, lazy):
+    def __init__(self, batch, base, cost, lazy):
         # the keys (one per prediction with a harm model, then the six maxima) come from a template made once per batch; a
         # call that reads the flag and the maxima -- what a planner does per candidate -- costs a dict copy and six stores
+        # (cost: the batch's cost rows as one flat list, this trajectory's at [base, base + 16))
         tpl, self._slot, idx = batch._hr_template(lazy)
         dict.__init__(self, tpl)
         for key, i in zip(self.ALL, idx):
-            dict.__setitem__(self, key, cost[i])
+            dict.__setitem__(self, key, cost[base + i])
         self._batch, self._lazy = batch, lazy
 
     def _build(self, key):

@@ -144,3 +144,38 @@ def test_two_ranks_two_gpus_rccl(torch_cuda, tmp_path):
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device); the one-GPU form of the same worker ran above")
     z = _run_ranks(tmp_path, 2, "nccl", M=333)
     _check(z, 2, 333)
+
+
+def _multi_ego(world, extra=()):
+    """tools/multi_ego_bench.py (BASELINE configs[4]: one fo_ctx / stream per ego, egos dealt round robin to the GPUs, no
+    collective) as `world` processes, one per GPU; returns the JSON line of every rank"""
+    import json
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "multi_ego_bench.py"), "--egos", "4", "--M", "256",
+                                       "--A", "16", "--steps", "6", "--warmup", "3", *extra], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE))
+    out = []
+    for r, p in enumerate(procs):
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, f"rank {r}:\n{e.decode(errors='replace')[-2000:]}"
+        out.append(json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1]))
+    return out
+
+
+def test_multi_ego_assignment_one_gpu(torch_cuda):
+    """configs[4] on the GPU this box has: four egos, four contexts and streams, one process"""
+    (j,) = _multi_ego(1)
+    assert j["n_gpus"] == 1 and j["egos_on_this_gpu"] == 4 and len(j["phantoms_per_ego"]) == 4
+    assert sum(j["phantoms_per_ego"]) > 0 and j["ms_per_step_all_egos"] > 0.0
+    # sharing the GPU must not be slower than draining the egos one after the other
+    assert j["ms_per_step_all_egos"] <= 1.5 * j["ms_per_step_egos_one_after_the_other"]
+
+
+def test_multi_ego_assignment_two_gpus(torch_cuda):
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: egos 0, 2 on GPU 0 and 1, 3 on GPU 1")
+    a, b = _multi_ego(2)
+    assert (a["n_gpus"], b["n_gpus"]) == (2, 2) and {a["rank"], b["rank"]} == {0, 1}
+    assert a["egos_on_this_gpu"] == 2 and b["egos_on_this_gpu"] == 2

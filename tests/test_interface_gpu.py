@@ -320,3 +320,59 @@ def test_real_agent_predictions_join_the_sweep_when_enabled(torch_cuda, oracle, 
     fo2, sc2, ego2, _ = _setup(tmp_path, max_agents=4)                    # default: the predictions are not evaluated
     fo2.evaluate_scenario(dict(preds), ego2[:2], float(ego2[2]), (0.0, 0.0), float(ego2[3]), 0, None)
     assert fo2.agent_manager.n_slots() == 4 * fo2.spawn_locator.R
+
+
+def test_one_call_evaluate_scenario_equals_the_stage_calls(torch_cuda, tmp_path):
+    """``accelerator.one_call`` (default True): evaluate_scenario queues the GPU side of the step as ONE native call (fo_step_run
+    without candidates) -- visible area, cell classes, visible objects, spawn points, phantom agents and the sweep over them are
+    those of the stage calls, bit for bit, in both spawn modes"""
+    import yaml
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion import synthetic as SY
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    yaw = float(ego0[2])
+    path = ego0[None, :2] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    veh = SimpleNamespace(length=SY.VEHICLE_BMW320I[0], width=SY.VEHICLE_BMW320I[1], wb_rear_axle=SY.VEHICLE_BMW320I[2],
+                          mass=SY.VEHICLE_BMW320I[3], a_max=SY.VEHICLE_BMW320I[4])
+    for mode in ("rules", "cells", "both"):
+        got = {}
+        for one_call in (True, False):
+            with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+                cfg = yaml.safe_load(f)
+            cfg["accelerator"]["spawn"].update(mode=mode, max_agents=12)
+            cfg["accelerator"]["one_call"] = one_call
+            cfg["metrics"]["metric_thresholds"].update(harm=0.1, risk=0.05)
+            p = tmp_path / f"c_{mode}_{one_call}.yaml"
+            p.write_text(yaml.safe_dump(cfg))
+            fo = interface.FOInterface(sc, path, veh, 0.1, config_path=str(p))
+            assert fo._one_call is one_call
+            res = []
+            for step in (0, 8, 25, 60):
+                ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
+                vis = fo.evaluate_scenario({}, ego, yaw, None, float(ego0[3]), step)
+                traj = SY.make_trajectories(96, 31, 0.1, seed=step, ego_pos=ego, ego_yaw=yaw)
+                ba = fo.trajectory_safety_assessment_batch(traj, mode="pair")
+                torch_cuda.cuda.synchronize()
+                b = fo.spawn_locator.batch
+                pts = [(q.agent_type, q.source, tuple(q.position)) for q in fo.spawn_points]
+                res.append(dict(cls=fo.sensor_model.cell_class.cpu().numpy().copy(), ring=vis.exterior.copy(),
+                                vis_objs=list(fo.sensor_model.visible_objects_timestep),
+                                occl={k: v.copy() for k, v in fo.sensor_model.obstacle_occlusions.items()},
+                                pts=pts, n_agents=len(fo.agent_manager.phantom_agents),
+                                pos=b.pos.cpu().numpy().copy(), ln=b.len.cpu().numpy().copy(),
+                                cost=None if ba is None else ba.cost.cpu().numpy().copy(),
+                                pair=None if ba is None else ba.result.pair_f.cpu().numpy().copy()))
+            got[one_call] = res
+        n_pts = 0
+        for a, b in zip(got[True], got[False]):
+            assert np.array_equal(a["cls"], b["cls"]) and np.array_equal(a["ring"], b["ring"])
+            assert a["vis_objs"] == b["vis_objs"] and a["pts"] == b["pts"] and a["n_agents"] == b["n_agents"]
+            assert a["occl"].keys() == b["occl"].keys() and all(np.array_equal(a["occl"][k], b["occl"][k]) for k in a["occl"])
+            assert np.array_equal(a["ln"], b["ln"]) and np.array_equal(a["pos"][a["ln"] > 0], b["pos"][b["ln"] > 0])
+            assert (a["cost"] is None) == (b["cost"] is None)
+            if a["cost"] is not None:
+                assert np.array_equal(a["cost"], b["cost"], equal_nan=True) and np.array_equal(a["pair"], b["pair"], equal_nan=True)
+            n_pts += len(a["pts"])
+        assert n_pts > 0, mode
