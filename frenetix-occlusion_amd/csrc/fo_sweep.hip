@@ -157,6 +157,70 @@ __device__ __forceinline__ double fo_sqrt(double x) {
   return y;
 #endif
 }
+// Round 5: the same for x > 0 -- the squared relative speeds of the ring, which pass 1 writes with the smallest denormal added
+// (fo_sq_sum_pos: an inline integer constant 1 in a float64 operand IS that number, no literal, no extra instruction), so that
+// the guard of fo_sqrt is not needed where pass 2 takes the root: one instruction per list entry.
+#ifndef FO_P2_TINY
+#define FO_P2_TINY 1
+#endif
+__device__ __forceinline__ double fo_sqrt_pos(double x) {
+#if FO_P2_TINY
+  const double g = __builtin_amdgcn_rsq(x);
+  const double y = x * g;
+  const double h = 0.5 * g;
+  const double r = fma(-h, y, 0.5);
+  return fma(y, r, y);
+#else
+  return fo_sqrt(x);
+#endif
+}
+__device__ __forceinline__ double fo_sq_sum_pos(double a, double b) {   // a^2 + b^2 (+ 4.9e-324)
+#if FO_P2_TINY
+  double t;
+  asm("v_fma_f64 %0, %1, %1, 1" : "=v"(t) : "v"(b));
+  return fma(a, a, t);
+#else
+  return fma(a, a, b * b);
+#endif
+}
+// value with its three lowest mantissa bits replaced by u (0..7)
+__device__ __forceinline__ double fo_pack_low(double v, int u) {
+  const unsigned lo = ((unsigned)__double2loint(v) & ~7u) | (unsigned)u;   // (v_and_or_b32 with two inline constants)
+  return __hiloint2double(__double2hiint(v), (int)lo);
+}
+// lanes of `mask`: b, the others a -- v_cndmask_b32 with the mask in a scalar pair (not vcc)
+__device__ __forceinline__ int fo_sel_b32(unsigned long long mask, int a, int b) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+  return r;
+}
+// the same for a float64 whose LOW word may stay (b = NaN or +-inf or 1.0 over a value with a zero low word, or a NaN over
+// anything: a NaN is a NaN whatever its payload) -- one v_cndmask_b32 on the high word
+__device__ __forceinline__ double fo_sel_hi(unsigned long long mask, double a, double b) {
+  return __hiloint2double(fo_sel_b32(mask, __double2hiint(a), __double2hiint(b)), __double2loint(a));
+}
+#ifndef FO_EPI_SEL
+#define FO_EPI_SEL 1   // 0: tuning builds -- the per-pair epilogue as plain C (compare + v_cndmask chains on vcc)
+#endif
+// a * b + c with three distinct register operands (the compiler prefers v_mov_b64 + v_fmac_f64 when c outlives the result)
+#ifndef FO_P2_FMA3
+#define FO_P2_FMA3 1
+#endif
+#ifndef FO_PROBE_PACK
+#define FO_PROBE_PACK 1
+#endif
+#ifndef FO_P2_UNROLL
+#define FO_P2_UNROLL 1
+#endif
+__device__ __forceinline__ double fo_fma3(double a, double b, double c) {
+#if FO_P2_FMA3
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#else
+  return fma(a, b, c);
+#endif
+}
 
 __device__ __forceinline__ double fo_round3(double v) { return __builtin_rint(v * 1000.0) / 1000.0; }  // np.round(v,3)
 // r / 1000.0, correctly rounded, for finite r: q = r RN(1/1000), one fma for the exact remainder, one for the correction
@@ -287,7 +351,18 @@ __device__ __forceinline__ double fo_lr4s_coef(double ang, double side, double r
 // k == 0 the class of phi follows exactly from the signs of  S = d x h  and  C = d . h  (h = unit heading):
 // front  C > |S|,  rear  -C >= |S|,  side otherwise.  k != 0 <=> |rel - heading| > pi only has to be decided when phi is
 // not rear, where |rel - heading| is either < 3pi/4 or > 5pi/4 -- a float32 atan2 estimate (error < 0.01) is enough.
+#ifndef FO_ATAN2_DIAMOND
+#define FO_ATAN2_DIAMOND 1
+#endif
 __device__ __forceinline__ float fo_atan2_crude(float y, float x) {
+#if FO_ATAN2_DIAMOND
+  // Round 5: the "diamond angle" -- pi/2 (1 - x / (|x| + |y|)) with the sign of y: monotonic in the true angle, exact on the
+  // axes and the diagonals, 0.071 rad off at worst (the decision it feeds has pi/4 of room, see above).  No comparison, no
+  // select: the three v_cmp + v_cndmask pairs of the octant form each held the SIMD for ten cycles beyond their own issue.
+  // (x = y = 0 does not get here: the caller puts dx = 1 for coincident centres.)
+  const float q = x * __builtin_amdgcn_rcpf(fabsf(x) + fabsf(y));
+  return copysignf(fmaf(q, -1.57079633f, 1.57079633f), y);
+#else
   const float ax = fabsf(x), ay = fabsf(y);
   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
   const float a = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
@@ -295,7 +370,9 @@ __device__ __forceinline__ float fo_atan2_crude(float y, float x) {
   if (ay > ax) r = 1.57079633f - r;
   if (x < 0.0f) r = 3.14159265f - r;
   return copysignf(r, y);
+#endif
 }
+
 // coefficient of the class: 0 (front), side, rear.  (dx, dy): from the vehicle whose occupants are rated to the other
 // party, as seen by atan2; `turn` = what is added to rel before the heading is subtracted (0 for the ego, pi for the
 // obstacle: obs_ang = pi + rel - yaw, harm_model.py:89-90).
@@ -1107,6 +1184,55 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       // Every second sample is enough for a seed (on the bench workload the exact geometry runs as rarely as with all
       // of them; stride 4 would cost a quarter more) -- and halves the loads of this phase.
       constexpr int PS = 2;
+#if FO_PROBE_PACK
+      // Round 5: the running minimum carries its sample number in the low mantissa bits (v_bfi_b32 + v_min_f64: the earlier
+      // sample wins a tie, a repeat of the last sample never does, as with the strict comparison) -- a compare and three
+      // v_cndmask_b32 on vcc per sample before, and a v_cndmask on vcc holds the SIMD for 14 cycles where an add holds it
+      // for 4 (tools/microbench/valu_rate.hip).  The probe only SEEDS the bound: the 2^-47 it moves a squared distance by
+      // cannot change a result.
+      if constexpr (SPLIT) {
+        asm volatile("; probe operands resident" ::"s"(sp_gx[0]), "s"(sp_gy[0]), "s"(sp_gx[1]), "s"(sp_gy[1]), "s"(sp_gx[2]),
+                     "s"(sp_gy[2]), "s"(sp_gx[3]), "s"(sp_gy[3]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = seg0 + 2 * u;
+          const double rx = sp_gx[u] - sp_vx[u], ry = sp_gy[u] - sp_vy[u];
+          const double c2 = fo_pack_low(fma(rx, rx, ry * ry), u);
+          if (t < Ld) bestc = fo_vmin(bestc, c2);   // (wave-uniform)
+        }
+        tb = seg0 + 2 * (int)(__double2loint(bestc) & 7);   // (bestc = inf -- NaN positions only: sample 0 of the segment)
+      } else {
+      int slot = 0;
+#pragma unroll 1
+      for (int t8 = 0; seg0 + t8 * PS < Ld; t8 += 8) {
+        double vx[8], vy[8], gpx[8], gpy[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = min(seg0 + (t8 + u) * PS, Ld - 1);
+          const fo_d2 xy = fo_ld2(tj + (size_t)t * NEF * TILE);
+          vx[u] = xy.x;
+          vy[u] = xy.y;
+          const cdp_t g = G + (size_t)t * NAF;   // eight scalar loads in flight as well (one lgkmcnt wait for all)
+          gpx[u] = g[0];
+          gpy[u] = g[1];
+        }
+        asm volatile("; probe operands resident" ::"s"(gpx[0]), "s"(gpy[0]), "s"(gpx[1]), "s"(gpy[1]), "s"(gpx[2]),
+                     "s"(gpy[2]), "s"(gpx[3]), "s"(gpy[3]), "s"(gpx[4]), "s"(gpy[4]), "s"(gpx[5]), "s"(gpy[5]),
+                     "s"(gpx[6]), "s"(gpy[6]), "s"(gpx[7]), "s"(gpy[7]));
+        double blk = INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double rx = gpx[u] - vx[u], ry = gpy[u] - vy[u];
+          blk = fo_vmin(blk, fo_pack_low(fma(rx, rx, ry * ry), u));
+        }
+        // (block against block: one comparison per eight samples -- the mask in a scalar pair, not in vcc)
+        const unsigned long long lt = __builtin_amdgcn_fcmp(blk, bestc, 4 /* olt */);
+        bestc = fo_vmin(bestc, blk);
+        slot = fo_sel_b32(lt, slot, t8);
+      }
+      tb = min(seg0 + (slot + (int)(__double2loint(bestc) & 7)) * PS, Ld - 1);
+      }
+#else
       if constexpr (SPLIT) {
         asm volatile("; probe operands resident" ::"s"(sp_gx[0]), "s"(sp_gy[0]), "s"(sp_gx[1]), "s"(sp_gy[1]), "s"(sp_gx[2]),
                      "s"(sp_gy[2]), "s"(sp_gx[3]), "s"(sp_gy[3]));
@@ -1142,6 +1268,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           if (c2 < bestc) { bestc = c2; tb = t; }
         }
       }
+#endif
       const double *e = tj + (size_t)tb * NEF * TILE;                   // per-lane sample: gathers
       const double *g = a.atab + ((size_t)k * a.Ta + tb) * NAF;
       const fo_d2 exy = fo_ld2(e), ecs = fo_ld2(e + EF(2));
@@ -1385,13 +1512,18 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
         }
         if (geo && t < Lh && !(FO_X & 4)) {
           // squared (<= 1e8: the prep kernels cap the speeds at 5e3 m/s); pass 2 takes the root where it needs the speed
-          const double dv2_ = fma(dvx, dvx, dvy * dvy);
+          const double dv2_ = fo_sq_sum_pos(dvx, dvy);
           dvw[(t - gbase) * TILE + lane] = dv2_;
           if (LISTS == LST_NONE && dvmax_mode) nze_min = fo_vmin_neg(nze_min, dv2_);
           if (lr4s) {
             // the impact angles only enter the LR4S model, and only through their class (front / side / rear)
             double ddx = px - ex, ddy = py - ey;
+#if FO_ATAN2_DIAMOND
+            // atan2(0, 0) = 0: dx = 1 for coincident centres -- |dx| + |dy| == 0, and only the high word of dx has to change
+            ddx = __hiloint2double(fabs(ddx) + fabs(ddy) == 0.0 ? 0x3ff00000 : __double2hiint(ddx), __double2loint(ddx));
+#else
             if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;  // atan2(0, 0) = 0
+#endif
             const float relc = fo_atan2_crude((float)ddy, (float)ddx);
             bool be_, bo_;
             const unsigned ce = fo_lr4s_class(ddx, ddy, ec, es, relc, 0.0f, (float)eth, false, be_);
@@ -1480,7 +1612,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             while (todo) {
               const int row = __builtin_ctz(todo), t = gbase + row;
               todo &= todo - 1u;
-              const double dv = fo_sqrt(dvw[row * TILE + lane]);
+              const double dv = fo_sqrt_pos(dvw[row * TILE + lane]);
               double cp = 0.0;
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
               if ((hvrows >> row) & 1u) {
@@ -1494,8 +1626,8 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 max_cp = cp; idx_cp = t; oh_at_cp = NAN;
               }
             }
-          } else
-          for (int t = g0s; t < g1s; ++t) {
+          } else {
+          auto row_step = [&](const int t) {
             const int row = t - gbase;
             const double dv = dvn, ze = zen, zo = zon;
             dvn = dvw[(row + 1) * TILE + lane];
@@ -1519,9 +1651,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 // 1e-7 |nz| to the argument, the slope of the logistic is <= 1/4)
                 if (LISTS != LST_NONE) nze_min = fo_vmin_neg(nze_min, dv);
                 if (lst_exact(LISTS)) {
-                  const double dvs = fo_sqrt(dv);
-                  eh = fo_logistic_neg<false>(exp_tab, fma(ke_, dvs, ce_));
-                  oh = fo_logistic_neg<false>(exp_tab, fma(ko_, dvs, co_));
+                  const double dvs = fo_sqrt_pos(dv);
+                  eh = fo_logistic_neg<false>(exp_tab, fo_fma3(ke_, dvs, ce_));
+                  oh = fo_logistic_neg<false>(exp_tab, fo_fma3(ko_, dvs, co_));
                 } else if (LISTS == LST_F32) {
                   const float dvf = __builtin_amdgcn_sqrtf((float)dv);
                   ehf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(kef_, dvf, cef_)));
@@ -1530,8 +1662,8 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
                 return;
               }
               const bool model = LR4S || prot == 0;   // wave-uniform; otherwise harm is 1 on both sides
-              const double dvs = fo_sqrt(dv);          // (the ring holds dv^2)
-              const double nze = LR4S ? fma(ke_, dvs, ze) : fma(ke_, dvs, ce_), nzo = LR4S ? fma(ko_, dvs, zo) : fma(ko_, dvs, co_);
+              const double dvs = fo_sqrt_pos(dv);      // (the ring holds dv^2)
+              const double nze = LR4S ? fma(ke_, dvs, ze) : fo_fma3(ke_, dvs, ce_), nzo = LR4S ? fma(ko_, dvs, zo) : fo_fma3(ko_, dvs, co_);
               if (lst_exact(LISTS) || !model) {
                 eh = model ? fo_logistic_neg<false>(exp_tab, nze) : 1.0;
                 oh = model ? fo_logistic_neg<false>(exp_tab, nzo) : 1.0;
@@ -1557,7 +1689,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             } else {
               if ((gmask >> row) & 1u) cp = cpw[row * TILE + lane];
               if (!lst_exact(LISTS) && hv && !(FO_X & 8) && (LR4S || DVMAX || prot == 0)) {   // the harm values themselves, where a risk may need them
-                const double dvs = fo_sqrt(dv);
+                const double dvs = fo_sqrt_pos(dv);
                 eh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ke_, dvs, ze) : fma(ke_, dvs, ce_));
                 oh = fo_logistic_neg<false>(exp_tab, LR4S ? fma(ko_, dvs, zo) : fma(ko_, dvs, co_));
                 if (LISTS == LST_F32) { ehf = (float)eh; ohf = (float)oh; }   // so that risk = harm x cp holds in the lists too
@@ -1575,7 +1707,9 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             }
             // FO_LISTS_F32_EXACT: the float64 harm values, rounded at the store.  (The probability and the risks are converted on
             // the rows that have them, above; on the others they are the float32 constants 0 -- converted behind the branches, the
-            // zeros cost three v_mov_b64 and three v_cvt_f32_f64 per sample on 97 % of the rows.)
+            // zeros cost three v_mov_b64 and three v_cvt_f32_f64 per sample on 97 % of the rows.  Round 5: the stores moved INTO
+            // the two branches, the short one with a single v_mov_b64 for its three zeros, made the allocator rotate the six
+            // running maxima through copies in every iteration -- thirteen moves for two saved.)
             if (LISTS == LST_F32X) { ehf = (float)eh; ohf = (float)oh; }
             if (LISTS == LST_F64) {
               __builtin_nontemporal_store(cp, (double *)(lb0 + lo1));
@@ -1588,6 +1722,13 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             }
             lo1 += (unsigned)M * LE;
             lo2 += (unsigned)M * (2u * LE);
+          };
+          // Round 5: two rows per trip -- the values read ahead for row t+1 (relative speed, LR4S offsets) change registers
+          // instead of being copied into row t's at the end of every trip (one to three v_mov_b64 per list row)
+          int t = g0s;
+          if (FO_P2_UNROLL == 2)
+            for (; t + 1 < g1s; t += 2) { row_step(t); row_step(t + 1); }
+          for (; t < g1s; ++t) row_step(t);
           }
         };
         if (lr4s) pass2(std::integral_constant<int, HM_LR4S>{});
@@ -1667,6 +1808,34 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       pi[FO_PI_CP_ARGMAX * ps_] = hr_valid ? idx_cp : 0;
       pi[FO_PI_HR_VALID * ps_] = hr_valid ? 1 : 0;
     }
+#if FO_EPI_SEL
+    // Round 5: the running extrema over the wave's agents as v_min / v_max plus ONE select of the index on a scalar-pair mask
+    // (a compare followed by three v_cndmask on vcc holds the SIMD for ~25 cycles beyond the instructions' own issue --
+    // tools/microbench/valu_rate.hip, "v_cmp_f64 + v_cndmask"); fmax() with its canonicalising v_max x, x in front
+    // replaced by the bare instruction (operands are results of arithmetic, never signalling NaNs).
+    if (do_dce) {
+      const unsigned long long lt = __builtin_amdgcn_fcmp(dce_m, w_min_dce, 4 /* olt */);
+      w_min_dce = fo_vmin(w_min_dce, dce_m);
+      w_arg_dce = fo_sel_b32(lt, w_arg_dce, k);
+      if (dce_m < a.thr_dce) w_dce_flag = true;
+      if (do_ttc) {
+        const unsigned long long z = __builtin_amdgcn_ballot_w64(dce == 0.0 && tdce < w_min_tttc);
+        w_min_tttc = fo_sel_b32(z, w_min_tttc, tdce);
+        w_arg_ttc = fo_sel_b32(z, w_arg_ttc, k);
+      }
+      if (do_ttce) w_min_tttce = min(w_min_tttce, tdce);
+    }
+    if (hr_valid) {
+      w_max_er = fo_vmax(w_max_er, max_er);
+      const unsigned long long gt = __builtin_amdgcn_fcmp(max_or, w_max_or, 2 /* ogt */);
+      w_max_or = fo_vmax(w_max_or, max_or);
+      w_arg_or = fo_sel_b32(gt, w_arg_or, k);
+      w_max_eh = fo_vmax(w_max_eh, max_eh);
+      w_max_oh = fo_vmax(w_max_oh, max_oh);
+      w_max_cp = fo_vmax(w_max_cp, max_cp);
+      w_max_hwc = fo_vmax(w_max_hwc, hwc);
+    }
+#else
     if (do_dce) {
       if (dce_m < w_min_dce) { w_min_dce = dce_m; w_arg_dce = k; }
       if (dce_m < a.thr_dce) w_dce_flag = true;
@@ -1681,6 +1850,7 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
       w_max_cp = fmax(w_max_cp, max_cp);
       w_max_hwc = fmax(w_max_hwc, hwc);
     }
+#endif
   }
 
   // ---------------- combine the waves of the workgroup (ascending agent order); scratch aliases the cp buffers

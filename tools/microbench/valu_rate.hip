@@ -54,6 +54,16 @@ __global__ void k(double *out, unsigned long long *cyc, double seed) {
     if (OP == 24) { I8(asm volatile("v_cmp_lt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(i7) : "vcc")) }
     if (OP == 25) { R8(asm volatile("v_cmp_lt_f64 vcc, %0, %2\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(x), "+v"(i0) : "v"(c), "v"(i7) : "vcc")) }
     if (OP == 26) { I8(asm volatile("v_max_i32 %0, %0, %1" : "+v"(x) : "v"(i7))) }
+    // round 5: is it the encoding (VOP2, implicit vcc) or the register (vcc named in a VOP3)?
+    if (OP == 27) { I8(asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(x) : "v"(i7))) }
+    if (OP == 28) { R8(asm volatile("v_mov_b64 %0, %1" : "=v"(x) : "v"(c))) }
+    if (OP == 29) { R8(asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f0) : "v"(x))) }
+    if (OP == 30) { I8(asm volatile("v_and_or_b32 %0, %0, -8, 3" : "+v"(x))) }
+    if (OP == 31) { R8(asm volatile("v_cmp_lt_f64_e64 s[4:5], %0, %2\n v_cndmask_b32_e64 %1, %1, %3, s[4:5]" : "+v"(x), "+v"(i0) : "v"(c), "v"(i7) : "s4", "s5")) }
+    if (OP == 32) { R8(asm volatile("v_min_f64 %0, %0, %1" : "+v"(x) : "v"(c))) }
+    if (OP == 33) { I8(asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x) : "v"(i7) : "vcc")) }
+    if (OP == 34) { I8(asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[4:5]\n s_nop 0" : "+v"(x) : "v"(i7) : "s4", "s5")) }
+    if (OP == 35) { I8(asm volatile("v_cndmask_b32_e64 %0, %0, 1, s[4:5]" : "+v"(x) :: "s4", "s5")) }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
@@ -84,7 +94,7 @@ int run(const char *name, int waves_per_simd) {
 }
 
 int main() {
-  for (int w : {1, 2, 3, 4}) {
+  for (int w : {1, 3}) {
     run<16>("f64 + salu (group)", w); run<17>("f64 + f32 (group)", w); run<18>("f64 + f32 + salu (group)", w);
     run<19>("s_add_u32", w); run<20>("f64 + 3 salu (group)", w); run<21>("f32 + salu (group)", w);
     run<0>("v_fma_f64", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<3>("v_max_f64", w);
@@ -94,6 +104,9 @@ int main() {
     run<15>("v_readlane+writelane", w);
     run<22>("v_cndmask vcc, distinct src", w); run<23>("v_cndmask_e64 sgpr mask", w); run<24>("v_cmp_i32 + v_cndmask (group)", w);
     run<25>("v_cmp_f64 + v_cndmask (group)", w); run<26>("v_max_i32", w);
+    run<27>("v_cndmask_e64 vcc", w); run<28>("v_mov_b64", w); run<29>("v_cvt_f32_f64", w); run<30>("v_and_or_b32", w);
+    run<31>("v_cmp_f64_e64 + v_cndmask_e64 sgpr (group)", w); run<32>("v_min_f64", w); run<33>("v_addc_co_u32 vcc", w);
+    run<34>("v_cndmask_e64 sgpr + s_nop (group)", w); run<35>("v_cndmask_e64 sgpr, inline const", w);
   }
   return 0;
 }
