@@ -200,7 +200,7 @@ __device__ __forceinline__ double fo_sel_hi(unsigned long long mask, double a, d
   return __hiloint2double(fo_sel_b32(mask, __double2hiint(a), __double2hiint(b)), __double2loint(a));
 }
 #ifndef FO_EPI_SEL
-#define FO_EPI_SEL 1   // 0: tuning builds -- the per-pair epilogue as plain C (compare + v_cndmask chains on vcc)
+#define FO_EPI_SEL 0   // 1: tuning builds -- the wave extrema as v_min / v_max + one select on a scalar-pair mask, NaN selects on the high word alone (measured: 0.504 against 0.498 ms -- fewer instructions, a worse allocation)
 #endif
 // a * b + c with three distinct register operands (the compiler prefers v_mov_b64 + v_fmac_f64 when c outlives the result)
 #ifndef FO_P2_FMA3
@@ -1789,16 +1789,32 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
     if (PAIR) {
       const size_t ps_ = (size_t)A * M;
       double *pf = a.pair_f + (size_t)k * M + m;
-      const bool cp_ok = hr_valid && max_er == max_er;   // false: a collision probability of this pair was NaN (see pass 2)
       pf[FO_PF_DCE * ps_] = do_dce ? dce_m : NAN;
       pf[FO_PF_TTC * ps_] = do_ttc ? ttc : NAN;
       pf[FO_PF_TTCE * ps_] = do_ttce ? ttce : NAN;
+#if FO_EPI_SEL
+      if (hr_valid) {   // (wave-uniform)
+        // a collision probability of this pair was NaN (see pass 2): NaN where the probability enters -- the high word alone
+        const unsigned long long bad = __builtin_amdgcn_fcmp(max_er, max_er, 8 /* uno */);
+        pf[FO_PF_MAX_EGO_RISK * ps_] = max_er;
+        pf[FO_PF_MAX_OBST_RISK * ps_] = fo_sel_hi(bad, max_or, NAN);
+        pf[FO_PF_HARM_WITH_CP * ps_] = fo_sel_hi(bad, hwc, NAN);
+        pf[FO_PF_MAX_EGO_HARM * ps_] = max_eh;
+        pf[FO_PF_MAX_OBST_HARM * ps_] = max_oh;
+        pf[FO_PF_MAX_CP * ps_] = fo_sel_hi(bad, max_cp, NAN);
+      } else {
+        pf[FO_PF_MAX_EGO_RISK * ps_] = NAN; pf[FO_PF_MAX_OBST_RISK * ps_] = NAN; pf[FO_PF_HARM_WITH_CP * ps_] = NAN;
+        pf[FO_PF_MAX_EGO_HARM * ps_] = NAN; pf[FO_PF_MAX_OBST_HARM * ps_] = NAN; pf[FO_PF_MAX_CP * ps_] = NAN;
+      }
+#else
+      const bool cp_ok = hr_valid && max_er == max_er;   // false: a collision probability of this pair was NaN (see pass 2)
       pf[FO_PF_MAX_EGO_RISK * ps_] = hr_valid ? max_er : NAN;
       pf[FO_PF_MAX_OBST_RISK * ps_] = cp_ok ? max_or : NAN;
       pf[FO_PF_HARM_WITH_CP * ps_] = cp_ok ? hwc : NAN;
       pf[FO_PF_MAX_EGO_HARM * ps_] = hr_valid ? max_eh : NAN;
       pf[FO_PF_MAX_OBST_HARM * ps_] = hr_valid ? max_oh : NAN;
       pf[FO_PF_MAX_CP * ps_] = cp_ok ? max_cp : NAN;
+#endif
       pf[FO_PF_BE_DECEL * ps_] = NAN;
       pf[FO_PF_BE_BTN * ps_] = NAN;
       pf[FO_PF_SPARE * ps_] = NAN;
