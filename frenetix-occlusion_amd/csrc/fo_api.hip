@@ -17,6 +17,11 @@ extern "C" int fo_sweep_run_prepped_(fo_ctx *ctx, int M, int T, const double *d_
                                      const double *d_v, const double *d_a, double *d_cost, uint8_t *d_safe, double *d_pair_f,
                                      int32_t *d_pair_i, double *d_lists, void *stream);   // fo_sweep.hip
 
+static int fo_step_stage_obstacles_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream);
+static int fo_step_queue_mirror_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream);
+static int fo_step_body_(fo_ctx *ctx, const fo_step_t *p, void *stream, bool stages, bool cells, bool rules, int slots, int slot0,
+                         int cell_agents);
+
 extern "C" {
 
 int fo_abi_version(void) { return FO_ABI_VERSION; }
@@ -61,6 +66,10 @@ void fo_destroy(fo_ctx *ctx) {
   if (ctx->d_exp_tab) (void)hipFree(ctx->d_exp_tab);
   if (ctx->d_gl_tab) (void)hipFree(ctx->d_gl_tab);
   if (ctx->d_agent_int) (void)hipFree(ctx->d_agent_int);
+  if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+  for (int i = 0; i < fo_ctx::kRing; ++i)
+    if (ctx->ev_ring[i]) (void)hipEventDestroy(ctx->ev_ring[i]);
+  if (ctx->ev_mirror) (void)hipEventDestroy(ctx->ev_mirror);
   if (ctx->ev_start) {
     for (int i = 0; i < fo_ctx::kMaxTimed; ++i) { (void)hipEventDestroy(ctx->ev_start[i]); (void)hipEventDestroy(ctx->ev_stop[i]); }
     delete[] ctx->ev_start;
@@ -107,6 +116,58 @@ int fo_step_run(fo_ctx *ctx, const fo_step_t *p, void *stream) {
       (rules && (p->max_rule_points < 1 || !p->d_rule_points || !p->d_n_rule_points || !p->d_path6 || !p->d_pos0 || !p->d_yaw0)))
     return fo_fail(ctx, FO_E_ARG, "fo_step_run: bad arguments");
   if ((rc = fo_sweep_set_list_format(ctx, p->list_format))) return rc;   // the format is an argument of the run
+  if ((rc = fo_step_stage_obstacles_(ctx, p, (hipStream_t)stream))) return rc;
+  rc = fo_step_body_(ctx, p, stream, stages, cells, rules, slots, slot0, cell_agents);
+  if (rc == FO_OK) rc = fo_step_queue_mirror_(ctx, p, (hipStream_t)stream);
+  return rc;
+}
+
+int fo_step_mirror_wait(fo_ctx *ctx) {
+  if (!ctx) return FO_E_ARG;
+  if (!ctx->mirror_queued) return FO_OK;
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  FO_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_mirror));
+  return FO_OK;
+}
+
+}  // extern "C"
+
+// the obstacle rows of the step: caller's host buffer -> pinned ring slot -> HBM, queued in front of the first launch
+static int fo_step_stage_obstacles_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream) {
+  if (!p->h_obstacles || p->obstacles_bytes <= 0) return FO_OK;
+  if (!p->d_obstacles) return fo_fail(ctx, FO_E_ARG, "fo_step_run: h_obstacles without d_obstacles");
+  if ((size_t)p->obstacles_bytes > fo_ctx::kRingSlot)
+    return fo_fail(ctx, FO_E_ARG, "fo_step_run: %lld bytes of obstacle rows exceed the staging slot (%zu): copy them yourself and "
+                   "pass h_obstacles = NULL", (long long)p->obstacles_bytes, fo_ctx::kRingSlot);
+  if (!ctx->h_ring) {
+    FO_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_ring, fo_ctx::kRing * fo_ctx::kRingSlot, hipHostMallocDefault));
+    for (int i = 0; i < fo_ctx::kRing; ++i) FO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_ring[i], hipEventDisableTiming));
+  }
+  const int i = ctx->ring_next;
+  ctx->ring_next = (i + 1) % fo_ctx::kRing;
+  if (ctx->ring_used[i]) FO_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ring[i]));   // (four steps back: long done)
+  char *slot = ctx->h_ring + (size_t)i * fo_ctx::kRingSlot;
+  memcpy(slot, p->h_obstacles, (size_t)p->obstacles_bytes);
+  FO_HIP_TRY(ctx, hipMemcpyAsync(p->d_obstacles, slot, (size_t)p->obstacles_bytes, hipMemcpyHostToDevice, stream));
+  FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[i], stream));
+  ctx->ring_used[i] = true;
+  return FO_OK;
+}
+
+// the step's mirror (hit ids and visibility flags for the host views of the reference's side effects): behind the last launch
+static int fo_step_queue_mirror_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream) {
+  if (!p->h_mirror || p->mirror_bytes <= 0) return FO_OK;
+  if (!p->d_mirror) return fo_fail(ctx, FO_E_ARG, "fo_step_run: h_mirror without d_mirror");
+  if (!ctx->ev_mirror) FO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mirror, hipEventDisableTiming));
+  FO_HIP_TRY(ctx, hipMemcpyAsync(p->h_mirror, p->d_mirror, (size_t)p->mirror_bytes, hipMemcpyDeviceToHost, stream));
+  FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_mirror, stream));
+  ctx->mirror_queued = true;
+  return FO_OK;
+}
+
+static int fo_step_body_(fo_ctx *ctx, const fo_step_t *p, void *stream, bool stages, bool cells, bool rules, int slots, int slot0,
+                         int cell_agents) {
+  int rc;
   if (stages) {
     if ((rc = fo_scene_fan(ctx, p->n_rays, p->ego_yaw, p->fov_deg, p->r, p->polygon_footprint, p->d_dirs, p->d_rmax, p->d_half, stream))) return rc;
     if ((rc = fo_scene_visibility(ctx, p->ego_x, p->ego_y, p->head_x, p->head_y, p->r, p->full_circle, p->exact_cells, p->n_rays,
@@ -152,5 +213,3 @@ int fo_step_run(fo_ctx *ctx, const fo_step_t *p, void *stream) {
   return fo_sweep_run(ctx, p->M, p->T, p->d_x, p->d_y, p->d_theta, p->d_vel, p->d_acc, p->d_cost, p->d_safe, p->d_pair_f,
                       p->d_pair_i, p->d_lists, stream);
 }
-
-}  // extern "C"

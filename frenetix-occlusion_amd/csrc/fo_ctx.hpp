@@ -59,6 +59,19 @@ struct fo_ctx {
   Tuned tuned[kMaxTuned];
   int n_tuned = 0, next_tuned = 0, force_apw = 0;
 
+  // ---- the two host transfers of a planning step (fo_step_t::h_obstacles / h_mirror, ABI 12): a ring of pinned staging
+  // slots for the obstacle rows on their way to HBM (the caller's buffer is free again when fo_step_run returns; a slot is
+  // written again only after the copy queued from it four steps ago has completed) and the event behind the step's
+  // device-to-host mirror (fo_step_mirror_wait)
+  static constexpr int kRing = 4;
+  static constexpr size_t kRingSlot = 64 << 10;
+  char *h_ring = nullptr;            // [kRing][kRingSlot], hipHostMalloc
+  hipEvent_t ev_ring[kRing] = {};
+  bool ring_used[kRing] = {};
+  int ring_next = 0;
+  hipEvent_t ev_mirror = nullptr;
+  bool mirror_queued = false;
+
   // ---- scene (ray-cast / grid) state lives in fo_scene.hip
   void *scene = nullptr;
 };

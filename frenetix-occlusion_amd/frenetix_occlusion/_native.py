@@ -31,7 +31,7 @@ EXPORTS = [
     "fo_sweep_configure", "fo_sweep_reserve", "fo_sweep_set_list_format", "fo_sweep_set_agents", "fo_sweep_run", "fo_sweep_check",
     "fo_sweep_last_launch", "fo_sweep_timing", "fo_sweep_timing_read", "fo_sweep_timing_read_each",
     "fo_scene_set_map", "fo_scene_share_map", "fo_scene_set_edge_lines", "fo_scene_set_routes", "fo_scene_map_info", "fo_scene_copy_raster", "fo_scene_fan", "fo_scene_visibility", "fo_scene_future_visibility", "fo_scene_spawn",
-    "fo_scene_candidate_count", "fo_scene_set_topology", "fo_scene_spawn_rules", "fo_step_run",
+    "fo_scene_candidate_count", "fo_scene_set_topology", "fo_scene_spawn_rules", "fo_step_run", "fo_step_mirror_wait",
     "fo_scene_set_centerlines", "fo_scene_spawn_rule_agents", "fo_sweep_autotune", "fo_scene_set_shadow_length",
 ]
 
@@ -84,7 +84,10 @@ class Step(C.Structure):       # fo_step_t (include/fo_hip.h): the arguments of 
                 ("d_safe", C.c_void_p), ("d_pair_f", C.c_void_p), ("d_pair_i", C.c_void_p), ("d_lists", C.c_void_p),
                 ("list_format", C.c_int32), ("spawn_mode", C.c_int32), ("n_path6", C.c_int32), ("max_rule_points", C.c_int32),
                 ("d_path6", C.c_void_p), ("d_oyaw", C.c_void_p), ("d_odims", C.c_void_p), ("rule", SpawnRuleParams),
-                ("rule_types", RuleAgentTypes), ("d_rule_points", C.c_void_p), ("d_n_rule_points", C.c_void_p)]
+                ("rule_types", RuleAgentTypes), ("d_rule_points", C.c_void_p), ("d_n_rule_points", C.c_void_p),
+                # ABI 12: the step's own host transfers (obstacle rows in, hit ids + visibility flags out)
+                ("h_obstacles", C.c_void_p), ("d_obstacles", C.c_void_p), ("obstacles_bytes", C.c_int64),
+                ("h_mirror", C.c_void_p), ("d_mirror", C.c_void_p), ("mirror_bytes", C.c_int64)]
 
 
 class NativeError(RuntimeError):
@@ -149,6 +152,7 @@ def load():
                                    + [D] * 3 + [dp] * 12 + [vp])
     lib.fo_scene_candidate_count.argtypes = [vp, ip, vp]
     lib.fo_step_run.argtypes = [vp, C.POINTER(Step), vp]
+    lib.fo_step_mirror_wait.argtypes = [vp]
     lib.fo_scene_set_topology.argtypes = [vp, C.c_int, dp, ip, ip, C.c_int, ip, ip, dp]
     lib.fo_scene_spawn_rules.argtypes = ([vp, dp] + [C.c_int] * 5 + [dp, C.c_int] + [dp] * 6 + [C.POINTER(SpawnRuleParams), C.c_int,
                                                                                           dp, ip, vp])

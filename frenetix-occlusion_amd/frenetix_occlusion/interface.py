@@ -155,14 +155,17 @@ class FOInterface:
             if self._scene_step is None:
                 from .step import PlanningStep
                 empty = torch.empty((0, sl.T), dtype=torch.float64, device=self.device)
-                self._scene_step = PlanningStep(sm, sl, self.metrics.sweep, empty, empty, empty, empty, empty, mode="reduced")
+                self._scene_step = PlanningStep(sm, sl, self.metrics.sweep, empty, empty, empty, empty, empty, mode="reduced",
+                                                mirror=True)
             sm.timestep = self.timestep
             sl.spawn_points, sl._rule_points, sl._n_cell_points = [], [], 0   # (last step's list: only an outside holder keeps it alive)
-            sm.upload_obstacles(self.fo_obstacles)
+            # (the obstacle rows travel with the step, and so does the copy of the hit ids / visibility flags back: the
+            # reference's visible-object bookkeeping -- visible_objects_timestep, current_visible, obstacle_occlusions, the
+            # visible multipolygon -- is applied when somebody looks at it, or when the obstacles move on to the next step)
+            sm.stage_obstacles(self.fo_obstacles)
             self._scene_step.run(self.ego_pos, self.ego_orientation, ego_v, self.ego_pos_cl)
             sm.adopt_step(self.ego_pos, self.ego_orientation)
-            sm.read_visible_objects(self.timestep, self.fo_obstacles)
-            self.fo_obstacles.update_multipolygon()
+            sm.defer_visible_objects(self.timestep, self.fo_obstacles)
             t0 = self._tick("visibility_ms", t0)
             self.spawn_points = sl.lazy_spawn_points()
         else:

@@ -242,8 +242,11 @@ class SensorModel:
         # state of the last step (names of sensor_model.py:26-35)
         self.visible_area = None
         self.occluded_area = None
-        self.obstacle_occlusions = {}
-        self.visible_objects_timestep = None
+        self._obstacle_occlusions = {}
+        self._visible_objects_timestep = None
+        self._vis_pending = None          # (timestep, obstacles, pinned mirror) of a one-call step nobody has looked at yet
+        self._obst_host = None            # obstacle rows staged for the next PlanningStep.run (stage_obstacles)
+        self._obst_dev = None
         self.timestep = None
         self.ego_pos = None
         self.ego_orientation = None
@@ -253,6 +256,26 @@ class SensorModel:
             self._share_map(share_map_with)
         else:
             self._set_map(lanelet_network)
+
+    # the reference's per-step side effects (sensor_model.py:58-101, 183) -- after a one-call step they are host VIEWS of the
+    # step's mirror (hit ids + visibility flags, copied by the step itself into pinned memory): read when somebody looks
+    @property
+    def visible_objects_timestep(self):
+        self.resolve_visible_objects()
+        return self._visible_objects_timestep
+
+    @visible_objects_timestep.setter
+    def visible_objects_timestep(self, v):
+        self._visible_objects_timestep = v
+
+    @property
+    def obstacle_occlusions(self):
+        self.resolve_visible_objects()
+        return self._obstacle_occlusions
+
+    @obstacle_occlusions.setter
+    def obstacle_occlusions(self, v):
+        self._obstacle_occlusions = v
 
     def _share_map(self, other):
         """take over another SensorModel's static map: host-side geometry by reference, device-side by fo_scene_share_map"""
@@ -363,6 +386,7 @@ class SensorModel:
     def upload_obstacles(self, obstacles):
         """obstacle corner points / centres / flags of the current step -> HBM (a few hundred bytes)"""
         dev = self.device
+        self._obst_host = None
         if obstacles is not None and len(obstacles) > 0:
             yaw = dims = None
             if hasattr(obstacles, "arrays_full"):      # + what the spawn rule families read (headings, dimensions, role bits)
@@ -392,6 +416,28 @@ class SensorModel:
             self._n_dyn_candidates = 0
         return self._obst
 
+    def stage_obstacles(self, obstacles):
+        """:meth:`upload_obstacles` without the copy: the rows are packed on the host and travel with the next
+        ``PlanningStep.run`` (``fo_step_t::h_obstacles``: the native call stages them through pinned memory in front of its
+        first launch); their HBM home is allocated once per obstacle count, so the step structure's pointers stay put."""
+        if obstacles is None or len(obstacles) == 0:
+            self._obst, self._obst_rule, self._n_dyn_candidates, self._obst_host = (None, None, None, 0), None, 0, None
+            return self._obst
+        host = obstacles.packed() if hasattr(obstacles, "packed") else None
+        if host is None:
+            return self.upload_obstacles(obstacles)
+        O = host.size // 105
+        d = self._obst_dev
+        if d is None or d.numel() != host.size:
+            d = self._obst_dev = torch.empty(host.size, dtype=torch.uint8, device=self.device)
+            self._obst_views = ((d[:O * 64].view(torch.float64).view(O, 4, 2), d[O * 64:O * 80].view(torch.float64).view(O, 2),
+                                 d[O * 104:], O),
+                                (d[O * 80:O * 88].view(torch.float64), d[O * 88:O * 104].view(torch.float64).view(O, 2)))
+        self._obst, self._obst_rule = self._obst_views
+        self._n_dyn_candidates = int(((host[O * 104:] & 13) == 5).sum())
+        self._obst_host = host
+        return self._obst
+
     def _buffers(self, w, O):
         """per-step outputs, allocated once per (window size, obstacle count) and reused"""
         key = (w.nx, w.ny, O, self.n_rays)
@@ -407,7 +453,9 @@ class SensorModel:
                              cls=torch.empty((w.ny * w.nx + 3) // 4 * 4, dtype=torch.uint8,
                                              device=dev)[:w.ny * w.nx].view(w.ny, w.nx),
                              occ=torch.empty(w.nx * w.ny, dtype=torch.int32, device=dev),
-                             n_occ=torch.zeros(1, dtype=torch.int32, device=dev))
+                             n_occ=torch.zeros(1, dtype=torch.int32, device=dev),
+                             # pinned host mirror of hv, written by a one-call step (fo_step_t::h_mirror)
+                             hv_host=torch.empty(4 * n + max(O, 1), dtype=torch.uint8, pin_memory=True))
             self._buf_key = key
         return self._buf
 
@@ -536,22 +584,55 @@ class SensorModel:
         ``visible_objects_timestep``, ``current_visible`` / ``last_visible_at_ts`` per obstacle, ``obstacle_occlusions`` --
         one device-to-host copy of the step's hit ids and visibility flags (the only point of a step where the host waits
         for the device, and only when there are obstacles)"""
-        self.visible_objects_timestep = []
-        self.obstacle_occlusions.clear()
+        self._vis_pending = None
         O = getattr(self, "_obst", (None, None, None, 0))[3]
-        if O:
-            hv = self._buf["hv"].cpu().numpy()
+        self._apply_visible(self._buf["hv"].cpu().numpy() if O else None, timestep, obstacles)
+        return self.visible_area
+
+    def _apply_visible(self, hv, timestep, obstacles):
+        self._visible_objects_timestep = []
+        self._obstacle_occlusions.clear()
+        O = getattr(self, "_obst", (None, None, None, 0))[3]
+        if O and hv is not None:
             hit_h = hv[:4 * self.n_rays].view(np.int32)
             vis = hv[4 * self.n_rays:4 * self.n_rays + O].astype(bool)
             E = len(self.map_geometry.edges)
             for i, obst in enumerate(obstacles):
                 obst.current_visible = bool(vis[i])
                 if vis[i]:
-                    self.visible_objects_timestep.append(obst.obstacle_id)
+                    self._visible_objects_timestep.append(obst.obstacle_id)
                     obst.last_visible_at_ts = timestep
                     # rays stopped by this obstacle = its shadow wedge (sensor_model.py:183: obstacle_occlusions[id])
-                    self.obstacle_occlusions[obst.obstacle_id] = np.nonzero(hit_h == E + i)[0]
-        return self.visible_area
+                    self._obstacle_occlusions[obst.obstacle_id] = np.nonzero(hit_h == E + i)[0]
+
+    def defer_visible_objects(self, timestep, obstacles):
+        """after a one-call step that mirrors its hit ids and visibility flags itself (``PlanningStep(mirror=True)``): the
+        side effects of :meth:`read_visible_objects` become pending -- applied when one of them is looked at (this object's
+        ``visible_objects_timestep`` / ``obstacle_occlusions``, an obstacle's ``current_visible`` / ``last_visible_at_ts``,
+        the obstacles' ``visible_obstacle_multipolygon``) or, at the latest, when the obstacles move on to the next step"""
+        O = getattr(self, "_obst", (None, None, None, 0))[3]
+        if not O or obstacles is None:
+            self._vis_pending = None
+            self._apply_visible(None, timestep, obstacles)
+            return
+        self._vis_pending = (timestep, obstacles, self._buf["hv_host"])
+        if hasattr(obstacles, "_pending"):
+            obstacles._pending = self.resolve_visible_objects
+        else:
+            self.resolve_visible_objects()
+
+    def resolve_visible_objects(self):
+        pend = self._vis_pending
+        if pend is None:
+            return
+        self._vis_pending = None
+        timestep, obstacles, mirror = pend
+        if hasattr(obstacles, "_pending"):
+            obstacles._pending = None
+        self.ctx.call("fo_step_mirror_wait")
+        self._apply_visible(mirror.numpy(), timestep, obstacles)
+        if hasattr(obstacles, "update_multipolygon"):
+            obstacles.update_multipolygon()
 
     def occluded_cells(self):
         """ascending window indices of the occluded cells (device tensor view; synchronises to read the count)"""

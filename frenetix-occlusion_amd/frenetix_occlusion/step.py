@@ -18,19 +18,24 @@ from .sweep import SweepResult
 
 
 class PlanningStep:
-    def __init__(self, sensor_model, spawn_locator, sweep, x, y, theta, v, a=None, mode="reduced", lists="f64", shard=None):
+    def __init__(self, sensor_model, spawn_locator, sweep, x, y, theta, v, a=None, mode="reduced", lists="f64", shard=None,
+                 mirror=False):
         """``shard`` (BASELINE configs[3]: one process per GPU, every rank builds the same step): True / a process group / a
         :class:`~frenetix_occlusion.distributed.CostGather` for the batch size -- this rank's step covers its contiguous
         block of the candidates (scene stage and phantoms replicated), writes the block's cost rows into the collective's
         block and :meth:`run` ends with the ONE all-gather of the path: ``out.cost_all`` = cost [M_total, 16] on every rank,
-        ``out.rows`` = this rank's rows; every other output holds those rows only."""
+        ``out.rows`` = this rank's rows; every other output holds those rows only.
+
+        ``mirror``: the step also copies its hit ids and visibility flags into the sensor model's pinned host mirror
+        (``fo_step_t::h_mirror``) -- what ``SensorModel.defer_visible_objects`` reads the reference's visible-object side
+        effects from, without a copy call of its own."""
         if not (sensor_model.ctx is spawn_locator.ctx is sweep.ctx):
             raise ValueError("PlanningStep: the three stages must share one context (one ego, one GPU)")
         if mode not in ("reduced", "pair", "full"):
             raise ValueError(f"unknown output mode '{mode}'")
         self.sm, self.sl, self.sw = sensor_model, spawn_locator, sweep
         self.ctx = sweep.ctx
-        self.mode, self.lists = mode, lists
+        self.mode, self.lists, self.mirror = mode, lists, bool(mirror)
         dev = sweep.device
         t = lambda q: None if q is None else torch.as_tensor(q).to(device=dev, dtype=torch.float64).contiguous()
         self.traj = [t(x), t(y), t(theta), t(v), t(a)]
@@ -104,6 +109,8 @@ class PlanningStep:
             s.n_path6, s.d_path6 = int(sl._d_path6.shape[0]), p(sl._d_path6)
             s.max_rule_points, s.d_rule_points, s.d_n_rule_points = b.n_rule_points, p(b.rule_points), p(b.rule_n)
             s.rule_types = sl.rule_types
+        if self.mirror:
+            s.h_mirror, s.d_mirror, s.mirror_bytes = buf["hv_host"].data_ptr(), p(buf["hv"]), int(buf["hv"].numel())
         self._buf = buf
         return s
 
@@ -124,6 +131,11 @@ class PlanningStep:
         d_corn, d_cen, d_flags, _ = self._obst_ref[0]
         q = lambda t: None if t is None else t.data_ptr()
         s.d_ocorn, s.d_ocen, s.d_oflags = q(d_corn), q(d_cen), q(d_flags)
+        host = getattr(sm, "_obst_host", None)       # rows staged by SensorModel.stage_obstacles: the native call copies them
+        if host is not None:
+            s.h_obstacles, s.d_obstacles, s.obstacles_bytes = host.ctypes.data, sm._obst_dev.data_ptr(), host.nbytes
+        else:
+            s.h_obstacles, s.d_obstacles, s.obstacles_bytes = None, None, 0
         if sl.mode != "cells":
             rl = self._obst_ref[1]
             if O and rl is None:
@@ -138,6 +150,7 @@ class PlanningStep:
         s.win_ix0, s.win_iy0 = w.ix0, w.iy0
         s.max_dist = sl.max_distance(ego_v)
         self.ctx._check(self.ctx._lib.fo_step_run(self.ctx._h, C.byref(s), N.current_stream(sm._dev_index)))
+        sm._obst_host = None                         # (consumed: the rows are in the context's pinned ring)
         # the stage objects see the step as if they had queued it themselves
         sm.window, sm.ego_pos, sm.ego_orientation, sm.edge_skip = w, ego_pos, yaw, skip
         b = self._buf

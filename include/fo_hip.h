@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FO_ABI_VERSION 11
+#define FO_ABI_VERSION 12
 
 enum { FO_OK = 0, FO_E_ARG = -1, FO_E_UNSUPPORTED_COV = -2, FO_E_HIP = -3, FO_E_NOMEM = -4, FO_E_STATE = -5 };
 
@@ -412,9 +412,25 @@ typedef struct {
   fo_rule_agent_types_t rule_types;
   double *d_rule_points;
   int32_t *d_n_rule_points;
+  /* ABI 12 -- the step's two host transfers, queued by the step itself (NULL / 0: none; what the reference does on the host
+   * around sensor_model.py:41-101 without noticing: its obstacles and its visible-object bookkeeping live in host memory).
+   * h_obstacles: the obstacle rows of this step in host memory, any kind (d_ocorn / d_ocen / d_oflags / d_oyaw / d_odims
+   * point into d_obstacles); copied into a pinned staging slot of the context and from there to d_obstacles in front of the
+   * first launch -- the caller's buffer is free again when fo_step_run returns; at most 64 KB.
+   * h_mirror: PINNED host memory (hipHostMalloc / a pinned torch tensor) that receives mirror_bytes from d_mirror behind the
+   * last launch of the step (the interface mirrors d_hit_id and d_obst_vis, which it allocates back to back); complete when
+   * fo_step_mirror_wait returns.  The next fo_step_run on the same stream overwrites it. */
+  const void *h_obstacles;
+  void *d_obstacles;
+  int64_t obstacles_bytes;
+  void *h_mirror;
+  const void *d_mirror;
+  int64_t mirror_bytes;
 } fo_step_t;
 enum { FO_SPAWN_CELLS = 0, FO_SPAWN_RULES = 1, FO_SPAWN_BOTH = 2 };
 int fo_step_run(fo_ctx *ctx, const fo_step_t *step, void *stream);
+/* blocks until the mirror copy of the latest fo_step_run with h_mirror has landed (returns at once when there was none) */
+int fo_step_mirror_wait(fo_ctx *ctx);
 
 #ifdef __cplusplus
 }

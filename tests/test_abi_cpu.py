@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(native):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fo_hip.h but not exported"
     assert sorted(native.EXPORTS) == declared
-    assert lib.fo_abi_version() == 11
+    assert lib.fo_abi_version() == 12
     import __graft_entry__ as g
     assert native.build_id() == g.source_id()      # the library in the tree is the tree's
 
