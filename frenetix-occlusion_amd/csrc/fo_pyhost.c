@@ -16,6 +16,7 @@
  * host memory, and the Python package falls back to its numpy statement of the same loop when the module is not built. */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <math.h>
 #include <string.h>
 #define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
 #include <numpy/arrayobject.h>
@@ -83,9 +84,76 @@ static PyObject *pack_trajectories(PyObject *self, PyObject *args) {
   Py_RETURN_NONE;
 }
 
+/* obstacle_rows(P [O][Lmax][3] f64, L [O] i64, t0 [O] i64, static [O] u8, vx [O][4] f64, vy [O][4] f64, dims [O][2] f64,
+ *               flags [O] u8, timestep: int, host [O*105] u8, present [O] u8) -> None
+ * The obstacle rows of one time step in the layout SensorModel.stage_obstacles uploads (corners [O][4][2] | centres [O][2] |
+ * headings [O] | dimensions [O][2] | flags [O]) -- utils/fo_obstacle.py FOObstacles.update, whose numpy statement of the
+ * same arithmetic (fo_obstacle.py:79-116 + helper_functions.py:99-112: rel = step - initial, 0 -> initial state, >= 1 ->
+ * state_list[rel-1], else absent; rectangle vertices rotated and shifted) costs ~40 us of interpreter time whatever O is.
+ * Same operations in the same order, libm cos / sin like math.cos / math.sin (built with -ffp-contract=off): same bits. */
+static int want(PyObject *o, int type, int ndim, const char *what) {
+  if (!PyArray_Check(o) || PyArray_TYPE((PyArrayObject *)o) != type || PyArray_NDIM((PyArrayObject *)o) != ndim ||
+      !PyArray_IS_C_CONTIGUOUS((PyArrayObject *)o)) {
+    PyErr_Format(PyExc_ValueError, "obstacle_rows: %s must be a C-contiguous array of the documented type and rank", what);
+    return 0;
+  }
+  return 1;
+}
+static PyObject *obstacle_rows(PyObject *self, PyObject *args) {
+  PyObject *P_o, *L_o, *t0_o, *st_o, *vx_o, *vy_o, *dims_o, *fl_o, *host_o, *pres_o;
+  long long timestep;
+  if (!PyArg_ParseTuple(args, "OOOOOOOOLOO", &P_o, &L_o, &t0_o, &st_o, &vx_o, &vy_o, &dims_o, &fl_o, &timestep, &host_o, &pres_o))
+    return NULL;
+  if (!want(P_o, NPY_DOUBLE, 3, "P") || !want(L_o, NPY_INT64, 1, "L") || !want(t0_o, NPY_INT64, 1, "t0") ||
+      !want(st_o, NPY_UINT8, 1, "static") || !want(vx_o, NPY_DOUBLE, 2, "vx") || !want(vy_o, NPY_DOUBLE, 2, "vy") ||
+      !want(dims_o, NPY_DOUBLE, 2, "dims") || !want(fl_o, NPY_UINT8, 1, "flags") || !want(host_o, NPY_UINT8, 1, "host") ||
+      !want(pres_o, NPY_UINT8, 1, "present"))
+    return NULL;
+  PyArrayObject *Pa = (PyArrayObject *)P_o;
+  const npy_intp O = PyArray_DIM(Pa, 0), Lmax = PyArray_DIM(Pa, 1);
+  if (PyArray_DIM(Pa, 2) != 3 || PyArray_DIM((PyArrayObject *)L_o, 0) != O || PyArray_DIM((PyArrayObject *)t0_o, 0) != O ||
+      PyArray_DIM((PyArrayObject *)st_o, 0) != O || PyArray_DIM((PyArrayObject *)vx_o, 0) != O || PyArray_DIM((PyArrayObject *)vx_o, 1) != 4 ||
+      PyArray_DIM((PyArrayObject *)vy_o, 0) != O || PyArray_DIM((PyArrayObject *)vy_o, 1) != 4 || PyArray_DIM((PyArrayObject *)dims_o, 0) != O ||
+      PyArray_DIM((PyArrayObject *)dims_o, 1) != 2 || PyArray_DIM((PyArrayObject *)fl_o, 0) != O ||
+      PyArray_DIM((PyArrayObject *)host_o, 0) != O * 105 || PyArray_DIM((PyArrayObject *)pres_o, 0) != O ||
+      !PyArray_ISWRITEABLE((PyArrayObject *)host_o) || !PyArray_ISWRITEABLE((PyArrayObject *)pres_o)) {
+    PyErr_SetString(PyExc_ValueError, "obstacle_rows: array shapes do not fit together");
+    return NULL;
+  }
+  const double *P = (const double *)PyArray_DATA(Pa), *vx = (const double *)PyArray_DATA((PyArrayObject *)vx_o);
+  const double *vy = (const double *)PyArray_DATA((PyArrayObject *)vy_o), *dims = (const double *)PyArray_DATA((PyArrayObject *)dims_o);
+  const npy_int64 *L = (const npy_int64 *)PyArray_DATA((PyArrayObject *)L_o), *t0 = (const npy_int64 *)PyArray_DATA((PyArrayObject *)t0_o);
+  const npy_uint8 *st = (const npy_uint8 *)PyArray_DATA((PyArrayObject *)st_o), *fl = (const npy_uint8 *)PyArray_DATA((PyArrayObject *)fl_o);
+  char *host = (char *)PyArray_DATA((PyArrayObject *)host_o);
+  npy_uint8 *pres = (npy_uint8 *)PyArray_DATA((PyArrayObject *)pres_o);
+  double *corn = (double *)host, *cen = (double *)(host + O * 64), *yaw = (double *)(host + O * 80), *dm = (double *)(host + O * 88);
+  npy_uint8 *flags = (npy_uint8 *)(host + O * 104);
+  memset(host, 0, (size_t)O * 105);
+  for (npy_intp i = 0; i < O; ++i) {
+    const long long rel = st[i] ? 0 : timestep - t0[i];
+    pres[i] = rel >= 0 && rel < L[i];
+    if (!pres[i]) continue;
+    const double *q = P + ((size_t)i * Lmax + (size_t)rel) * 3;
+    const double c = cos(q[2]), s = sin(q[2]);
+    for (int k = 0; k < 4; ++k) {
+      const double ax = vx[i * 4 + k], ay = vy[i * 4 + k];
+      const double cx = c * ax, sy = s * ay, sx = s * ax, cy = c * ay;
+      corn[(i * 4 + k) * 2 + 0] = q[0] + (cx - sy);
+      corn[(i * 4 + k) * 2 + 1] = q[1] + (sx + cy);
+    }
+    cen[i * 2] = q[0]; cen[i * 2 + 1] = q[1];
+    yaw[i] = q[2];
+    dm[i * 2] = dims[i * 2]; dm[i * 2 + 1] = dims[i * 2 + 1];
+    flags[i] = fl[i];
+  }
+  Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
     {"pack_trajectories", pack_trajectories, METH_VARARGS,
      "pack_trajectories(objs, out[n][M][T] float64, names): out[f][m] = objs[m].cartesian.<names[f]>"},
+    {"obstacle_rows", obstacle_rows, METH_VARARGS,
+     "obstacle_rows(P, L, t0, static, vx, vy, dims, flags, timestep, host, present): the obstacle rows of one time step"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_fo_pyhost", "host-side packing helper of frenetix_occlusion", -1, methods};

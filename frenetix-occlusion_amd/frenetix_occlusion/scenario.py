@@ -36,6 +36,10 @@ class Lanelet:
         return np.concatenate((self.left, self.right[::-1]), axis=0)
 
 
+_CVX = np.array([-1.0, -1.0, 1.0, 1.0])     # Rectangle vertices in units of the half dimensions (helper_functions.py:99-112)
+_CVY = np.array([-1.0, 1.0, 1.0, -1.0])
+
+
 @dataclass
 class Obstacle:
     obstacle_id: int
@@ -60,11 +64,14 @@ class Obstacle:
 
     def corners(self, pose):
         """helper_functions.py:99-112: Rectangle vertices (-l/2,-w/2), (-l/2,w/2), (l/2,w/2), (l/2,-w/2) rotated + shifted"""
+        # (written out per coordinate -- x = px + (c vx - s vy), y = py + (s vx + c vy) -- so that FOObstacles.update, which
+        # does all obstacles of a step in one array expression, produces the same bits)
         l2, w2 = self.length / 2.0, self.width / 2.0
-        v = np.array([[-l2, -w2], [-l2, w2], [l2, w2], [l2, -w2]])
         c, s = math.cos(pose[2]), math.sin(pose[2])
-        rot = np.array([[c, -s], [s, c]])
-        return (rot @ v.T).T + pose[:2]
+        out = np.empty((4, 2))
+        out[:, 0] = pose[0] + (c * (_CVX * l2) - s * (_CVY * w2))
+        out[:, 1] = pose[1] + (s * (_CVX * l2) + c * (_CVY * w2))
+        return out
 
 
 @dataclass

@@ -431,3 +431,67 @@ def test_native_trajectory_packer_equals_the_numpy_gather():
         H.pack_trajectories(objs[:10], out, ("x", "y", "theta", "v", "a"))
     with pytest.raises(AttributeError):
         H.pack_trajectories([SimpleNamespace(cartesian=SimpleNamespace(x=np.zeros(T)))] * M, out, ("x", "y", "theta", "v", "a"))
+
+
+@pytest.mark.parametrize("helper", ["c", "numpy"])
+def test_obstacle_rows_of_a_step_equal_the_per_obstacle_statement(helper, monkeypatch):
+    """FOObstacles.update (all obstacles of a step at once: the C helper csrc/fo_pyhost.c obstacle_rows, or its numpy
+    statement) against FOObstacle.update_at_timestep per obstacle (fo_obstacle.py:79-116, helper_functions.py:99-112):
+    poses, corner points, presence and the rows a one-call step uploads, bit for bit -- present, not yet there, gone"""
+    import __graft_entry__ as g
+    g.build_pyhost()
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.utils import fo_obstacle as FO
+    if helper == "numpy":
+        monkeypatch.setattr(FO, "_pyhost", lambda: None)
+    elif FO._pyhost() is None:
+        pytest.skip("_fo_pyhost not built")
+    for n in (1, 2, 3):
+        sc = S.load_geometry_npz(os.path.join(GOLDEN, f"scenario{n}_geometry.npz"))
+        obst = list(sc.obstacles) * (5 if helper == "numpy" else 1)      # (the numpy form serves from four obstacles on)
+        a, b = FO.FOObstacles(obst), FO.FOObstacles(obst)
+        for t in (0, 1, 5, 17, 40, 200):
+            a.update(t)
+            for o in b.fo_obstacles:
+                o.update_at_timestep(t)
+            assert a._packed is not None and b._packed is None
+            assert a.packed().tobytes() == b.packed().tobytes(), (n, t)
+            for x, y in zip(a, b):
+                assert (x.current_pos is None) == (y.current_pos is None) and x.relative_time_step == y.relative_time_step
+                if x.current_pos is not None:
+                    assert np.array_equal(x.current_pos, y.current_pos) and x.current_orientation == y.current_orientation
+                    assert np.array_equal(x.current_corner_points, y.current_corner_points)
+            for u, v in zip(a.arrays_full(), b.arrays_full()):
+                assert np.array_equal(u, v)
+        # a step's views outlive the step: the next update works on fresh memory
+        a.update(0)
+        first = [o.current_corner_points for o in a if o.current_pos is not None]
+        keep = [c.copy() for c in first]
+        a.update(7)
+        assert all(np.array_equal(c, k) for c, k in zip(first, keep))
+
+
+def test_pending_visibility_is_applied_before_the_obstacles_move_on():
+    """FOObstacles / FOObstacle: a pending visibility resolver (SensorModel.defer_visible_objects after a one-call step) runs
+    when a visibility attribute is read, and at the latest when update() moves the obstacles to the next step"""
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion.utils.fo_obstacle import FOObstacles
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    fo = FOObstacles(sc.obstacles)
+    fo.update(0)
+    calls = []
+
+    def resolver():
+        fo._pending = None
+        calls.append(1)
+        for o in fo:
+            o.current_visible = True
+            o.last_visible_at_ts = 0
+        fo.update_multipolygon()
+
+    fo._pending = resolver
+    assert fo.fo_obstacles[0].current_visible is True and len(calls) == 1            # a read resolves
+    assert len(fo.visible_obstacle_multipolygon) == sum(o.current_pos is not None for o in fo)
+    fo._pending = resolver
+    fo.update(1)                                                                   # ... and so does the next step
+    assert len(calls) == 2 and all(o.last_visible_at_ts == 0 for o in fo) and not any(o._current_visible for o in fo)

@@ -376,3 +376,45 @@ def test_one_call_evaluate_scenario_equals_the_stage_calls(torch_cuda, tmp_path)
                 assert np.array_equal(a["cost"], b["cost"], equal_nan=True) and np.array_equal(a["pair"], b["pair"], equal_nan=True)
             n_pts += len(a["pts"])
         assert n_pts > 0, mode
+
+
+def test_visible_object_bookkeeping_of_a_one_call_step_is_a_late_view(torch_cuda, tmp_path):
+    """After a one-call ``evaluate_scenario`` the reference's visible-object side effects (sensor_model.py:58-101, 183) are
+    views of the step's own device-to-host mirror (``fo_step_t::h_mirror``): nothing is copied until somebody looks, and what
+    nobody looked at is applied when the obstacles move on -- ``last_visible_at_ts`` after a run in which the host never
+    read a thing equals that of the stage calls, which read every step"""
+    import yaml
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion import synthetic as SY
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    yaw = float(ego0[2])
+    path = ego0[None, :2] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    veh = SimpleNamespace(length=SY.VEHICLE_BMW320I[0], width=SY.VEHICLE_BMW320I[1], wb_rear_axle=SY.VEHICLE_BMW320I[2],
+                          mass=SY.VEHICLE_BMW320I[3], a_max=SY.VEHICLE_BMW320I[4])
+    fos = {}
+    for one_call in (True, False):
+        with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+            cfg = yaml.safe_load(f)
+        cfg["accelerator"]["one_call"] = one_call
+        p = tmp_path / f"late_{one_call}.yaml"
+        p.write_text(yaml.safe_dump(cfg))
+        fos[one_call] = interface.FOInterface(sc, path, veh, 0.1, config_path=str(p))
+    lazy, eager = fos[True], fos[False]
+    steps = (0, 3, 8, 25, 40, 60)
+    for step in steps:
+        ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
+        for fo in (lazy, eager):
+            fo.evaluate_scenario({}, ego, yaw, None, float(ego0[3]), step)
+        assert lazy.sensor_model._vis_pending is not None and lazy.fo_obstacles._pending is not None     # nobody has looked
+    # the first look, one step late for none of them: everything of the last step and the memory of the earlier ones
+    seen = [(o.obstacle_id, o.current_visible, o.last_visible_at_ts) for o in lazy.fo_obstacles]
+    assert lazy.sensor_model._vis_pending is None and lazy.fo_obstacles._pending is None
+    assert seen == [(o.obstacle_id, o.current_visible, o.last_visible_at_ts) for o in eager.fo_obstacles]
+    assert any(v for _, v, _ in seen) and any(ts not in (None, steps[-1]) for _, _, ts in seen)
+    assert lazy.sensor_model.visible_objects_timestep == eager.sensor_model.visible_objects_timestep
+    a, b = lazy.fo_obstacles.visible_obstacle_multipolygon, eager.fo_obstacles.visible_obstacle_multipolygon
+    assert len(a) == len(b) and all(np.array_equal(u, v) for u, v in zip(a, b))
+    occ_a, occ_b = lazy.sensor_model.obstacle_occlusions, eager.sensor_model.obstacle_occlusions
+    assert occ_a.keys() == occ_b.keys() and all(np.array_equal(occ_a[k], occ_b[k]) for k in occ_a)
