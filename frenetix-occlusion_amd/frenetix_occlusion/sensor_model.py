@@ -416,6 +416,8 @@ class SensorModel:
             self._n_dyn_candidates = 0
         return self._obst
 
+    STAGE_BYTES = 64 << 10      # fo_step_t::h_obstacles: one slot of the context's pinned ring (624 obstacles)
+
     def stage_obstacles(self, obstacles):
         """:meth:`upload_obstacles` without the copy: the rows are packed on the host and travel with the next
         ``PlanningStep.run`` (``fo_step_t::h_obstacles``: the native call stages them through pinned memory in front of its
@@ -424,7 +426,7 @@ class SensorModel:
             self._obst, self._obst_rule, self._n_dyn_candidates, self._obst_host = (None, None, None, 0), None, 0, None
             return self._obst
         host = obstacles.packed() if hasattr(obstacles, "packed") else None
-        if host is None:
+        if host is None or host.nbytes > self.STAGE_BYTES:      # (beyond the native call's staging slot: the plain copy)
             return self.upload_obstacles(obstacles)
         O = host.size // 105
         d = self._obst_dev

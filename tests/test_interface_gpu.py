@@ -418,3 +418,49 @@ def test_visible_object_bookkeeping_of_a_one_call_step_is_a_late_view(torch_cuda
     assert len(a) == len(b) and all(np.array_equal(u, v) for u, v in zip(a, b))
     occ_a, occ_b = lazy.sensor_model.obstacle_occlusions, eager.sensor_model.obstacle_occlusions
     assert occ_a.keys() == occ_b.keys() and all(np.array_equal(occ_a[k], occ_b[k]) for k in occ_a)
+
+
+def test_step_host_transfers_at_the_c_boundary(torch_cuda, tmp_path):
+    """``fo_step_t::h_obstacles`` / ``h_mirror`` (ABI 12): the caller's obstacle buffer is free again when ``fo_step_run`` returns
+    (the rows were staged), the mirror holds the step's hit ids and visibility flags once ``fo_step_mirror_wait`` returns, rows
+    beyond the staging slot are refused, and a sensor model staging more than the slot holds falls back to its own copy"""
+    import ctypes as C
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as S
+    from frenetix_occlusion import synthetic as SY
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    yaw = float(ego0[2])
+    path = ego0[None, :2] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    veh = SimpleNamespace(length=SY.VEHICLE_BMW320I[0], width=SY.VEHICLE_BMW320I[1], wb_rear_axle=SY.VEHICLE_BMW320I[2],
+                          mass=SY.VEHICLE_BMW320I[3], a_max=SY.VEHICLE_BMW320I[4])
+    fo = interface.FOInterface(sc, path, veh, 0.1)
+    sm = fo.sensor_model
+    fo.evaluate_scenario({}, ego0[:2], yaw, None, float(ego0[3]), 8)
+    step, s = fo._scene_step, fo._scene_step._s
+    assert s.h_mirror and s.mirror_bytes == sm._buf["hv"].numel() and sm._obst_host is None      # (consumed by the call)
+    # the same step by hand: scribble over the host rows right after the call -- the device must hold the real ones
+    fo.fo_obstacles.update(8)
+    rows = fo.fo_obstacles.packed().copy()
+    sm.stage_obstacles(fo.fo_obstacles)
+    sm._obst_host = rows
+    step.run(ego0[:2], yaw, float(ego0[3]), None)
+    rows[:] = 0xAB
+    fo.ctx.call("fo_step_mirror_wait")
+    torch_cuda.cuda.synchronize()
+    assert sm._obst_dev.cpu().numpy().tobytes() == fo.fo_obstacles.packed().tobytes()
+    assert np.array_equal(sm._buf["hv_host"].numpy(), sm._buf["hv"].cpu().numpy())
+    assert sm._buf["hv_host"].numpy()[4 * sm.n_rays:4 * sm.n_rays + len(fo.fo_obstacles)].any()       # somebody is visible
+    # rows that do not fit the staging slot: refused by the C entry ...
+    big = np.zeros(70000, dtype=np.uint8)
+    s.h_obstacles, s.obstacles_bytes = big.ctypes.data, big.nbytes
+    rc = fo.ctx._lib.fo_step_run(fo.ctx._h, C.byref(s), N.current_stream(sm._dev_index))
+    assert rc != 0 and b"staging slot" in fo.ctx._lib.fo_last_error(fo.ctx._h)
+    s.h_obstacles, s.obstacles_bytes = None, 0
+    # ... and never offered by the sensor model: a crowd beyond the slot takes the plain copy
+    crowd = type(fo.fo_obstacles)(list(sc.obstacles) * 130)
+    crowd.update(8)
+    assert crowd.packed().nbytes > sm.STAGE_BYTES
+    sm.stage_obstacles(crowd)
+    assert sm._obst_host is None and sm._obst[3] == len(crowd)
