@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "fo_hip.h"
 
@@ -75,6 +76,18 @@ struct fo_ctx {
   // ---- scene (ray-cast / grid) state lives in fo_scene.hip
   void *scene = nullptr;
 };
+
+// Tuning / test knobs come from the environment and are looked at on every call (tests switch them at run time).  One pass
+// over `environ` for the family's prefix decides whether any getenv() is worth making: none is set in production, and eight
+// look-ups per planning step were 2.5 us of the host's 45.
+extern char **environ;
+inline bool fo_env_any(const char *prefix) {
+  const size_t n = strlen(prefix);
+  for (char **e = environ; e && *e; ++e)
+    if (strncmp(*e, prefix, n) == 0) return true;
+  return false;
+}
+inline const char *fo_getenv(bool any, const char *name) { return any ? getenv(name) : nullptr; }
 
 inline int fo_fail(fo_ctx *ctx, int code, const char *fmt, ...) {
   if (ctx) {

@@ -1661,7 +1661,7 @@ static int scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head
   // one wave per ray / probe / undecided cell where the soup is a single group of chunk boxes (see fo_rays_kernel) and the
   // obstacle sides fit a wave; the tile table's spare workgroups then take horizon slices of two samples (a lane handles two
   // elements, as in the 256-thread shape)
-  const bool one_wave = (sc->map->E + 63) / 64 <= 64 && 4 * O <= 64 && !getenv("FO_SCENE_FIVE_WAVES");
+  const bool one_wave = (sc->map->E + 63) / 64 <= 64 && 4 * O <= 64 && !fo_getenv(fo_env_any("FO_SCENE_"), "FO_SCENE_FIVE_WAVES");
   if (one_wave && prep.on) { prep.tz = prep.T > 2 ? 2 : prep.T; prep.nz = (prep.T + prep.tz - 1) / prep.tz; }
   const dim3 rgrid(n_rays + (probes ? 5 * O : 0) + prep.blocks()), rblock(64 * (one_wave ? 1 : RAY_WAVES));
 #define FO_LAUNCH_RAYS(SK, NW_)                                                                                                       \

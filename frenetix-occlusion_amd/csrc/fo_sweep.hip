@@ -2374,7 +2374,8 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
                                                      FO_NL * (size_t)A * (T - 1) * M, s));
   const int Mp = round_up(M, TILE);
   const int n_tiles = Mp / TILE;
-  const char *force_generic = getenv("FO_SWEEP_GENERIC");  // debug / A-B aid
+  const bool knobs = fo_env_any("FO_SWEEP_");   // (any tuning / test knob of this family in the environment at all?)
+  const char *force_generic = fo_getenv(knobs, "FO_SWEEP_GENERIC");  // debug / A-B aid
   // (the queue kernel reads agent rows up to index T without clamping: horizons far beyond the predictions' take the generic kernel)
   // (the queue kernel addresses one agent's list rows by 32-bit byte offsets: (T-1) M pairs of float64 must stay under 4 GB)
   bool use_queue = !(force_generic && force_generic[0] == '1') && (!FO_DIET || T <= Ta + AGENT_PAD_ROWS - 1 || A == 0) &&
@@ -2382,7 +2383,7 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
   const int lst_mode = !d_lists ? LST_NONE : ctx->list_format == FO_LISTS_F32 ? LST_F32 : ctx->list_format == FO_LISTS_F32_EXACT ? LST_F32X : LST_F64;
   {  // FO_LISTS_F32_EXACT has one queue-kernel instantiation (default metric set, full grid); everything else: generic kernel
     const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
-    if (lst_mode == LST_F32X && ((ctx->mask & all5) != all5 || getenv("FO_SWEEP_ABLATE"))) use_queue = false;
+    if (lst_mode == LST_F32X && ((ctx->mask & all5) != all5 || fo_getenv(knobs, "FO_SWEEP_ABLATE"))) use_queue = false;
   }
   const int wpb = use_queue ? QWAVES : WAVES;  // waves per workgroup of the kernel that will run
   int apw = pick_apw(n_tiles, A, wpb);
@@ -2392,11 +2393,11 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
     if (tu.n_tiles == n_tiles && tu.A == A && tu.T == T && tu.lst == lst_mode && tu.pair == (d_pair_f != nullptr)) apw = tu.apw;
   }
   if (ctx->force_apw > 0) apw = ctx->force_apw;   // (fo_sweep_autotune while it measures)
-  if (const char *e = getenv("FO_SWEEP_APW")) { const int v = atoi(e); if (v >= 1 && v <= 64) apw = v; }  // tuning aid
+  if (const char *e = fo_getenv(knobs, "FO_SWEEP_APW")) { const int v = atoi(e); if (v >= 1 && v <= 64) apw = v; }  // tuning aid
   // Small batches: with one agent per wave the grid is n_tiles x A waves; below the 3 072 wave slots of the chip the
   // horizon of every agent is split over the four waves of a workgroup instead (one workgroup per tile and agent).
   bool split = use_queue && T <= QWAVES * TC && (long)n_tiles * A < 3072;
-  if (const char *e = getenv("FO_SWEEP_SPLIT")) split = use_queue && T <= QWAVES * TC && e[0] == '1';  // tests, A/B runs
+  if (const char *e = fo_getenv(knobs, "FO_SWEEP_SPLIT")) split = use_queue && T <= QWAVES * TC && e[0] == '1';  // tests, A/B runs
   if (lst_mode == LST_F32X) split = false;
   if (split) {
     // agents per workgroup of the horizon-split form, one after the other: 1.  (Measured on 2 000 x 32, 1 024 (tile, agent)
@@ -2404,7 +2405,7 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
     // against 39: the launch lasts as long as its heaviest workgroup, the agents next to the candidates' path, and those
     // come in pairs.  FO_SWEEP_SPLIT_APW: tests, A/B runs.)
     apw = 1;
-    if (const char *e = getenv("FO_SWEEP_SPLIT_APW")) { const int v = atoi(e); if (v >= 1 && v <= 16) apw = v; }
+    if (const char *e = fo_getenv(knobs, "FO_SWEEP_SPLIT_APW")) { const int v = atoi(e); if (v >= 1 && v <= 16) apw = v; }
   }
   // Tapered grid (queue kernel, grids beyond one round of the chip): agents per wave halve from phase to phase down to
   // one -- see SweepArgs::ph_n.  f[]: fraction of the agents per phase; FO_SWEEP_TAPER="f0,f1,f2" overrides them
@@ -2415,7 +2416,7 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
   if (use_queue && !split && apw >= 2 && A > 0) {
     double f[3] = {0.85, 0.10, 0.0};
     if (apw >= 8) { f[0] = 0.55; f[1] = 0.25; f[2] = 0.12; }
-    if (const char *e = getenv("FO_SWEEP_TAPER")) {
+    if (const char *e = fo_getenv(knobs, "FO_SWEEP_TAPER")) {
       f[0] = 1.0; f[1] = f[2] = 0.0;
       sscanf(e, "%lf,%lf,%lf", &f[0], &f[1], &f[2]);
       if (f[0] <= 0.0) f[0] = 1.0;
@@ -2475,7 +2476,7 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
     a.off_x = ctx->veh.length / 6.0; a.off_y = ctx->veh.width / 2.0;
     a.hc = ctx->hc; a.dt = ctx->dt; a.thr_dce = ctx->thr.dce; a.mask = ctx->mask;
     {
-      const char *ab = getenv("FO_SWEEP_ABLATE");
+      const char *ab = fo_getenv(knobs, "FO_SWEEP_ABLATE");
       a.ablate = ab ? (uint32_t)atoi(ab) : 0u;
     }
     const int grid = a.nt8 * 8 * n_chunks;
@@ -2485,7 +2486,7 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
     const dim3 g(grid), b(TILE * wpb);
 #if FO_TRACE
     static long long *d_trace = nullptr;
-    const char *trace_path = getenv("FO_SWEEP_TRACE");
+    const char *trace_path = fo_getenv(knobs, "FO_SWEEP_TRACE");
     if (trace_path && !d_trace) (void)hipMalloc((void **)&d_trace, sizeof(long long) * 4 * 65536);
     a.trace = trace_path ? d_trace : nullptr;
 #endif
@@ -2509,10 +2510,10 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
     FO_HIP_TRY(ctx, hipGetLastError());
     if (timed) FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop[ctx->n_timed++], s));
 #if FO_TRACE
-    if (a.trace && getenv("FO_SWEEP_TRACE_DUMP")) {   // (set for the one launch that is to be dumped)
+    if (a.trace && fo_getenv(knobs, "FO_SWEEP_TRACE_DUMP")) {   // (set for the one launch that is to be dumped)
       (void)hipStreamSynchronize(s);
       // (FO_SWEEP_TRACE_PHASES: the per-workgroup phase stamps as well, rows [32768, 32768 + grid) -- tools/split_trace.py)
-      const size_t rows = getenv("FO_SWEEP_TRACE_PHASES") && grid <= 32768 ? (size_t)32768 + grid : (size_t)grid;
+      const size_t rows = fo_getenv(knobs, "FO_SWEEP_TRACE_PHASES") && grid <= 32768 ? (size_t)32768 + grid : (size_t)grid;
       long long *h = (long long *)malloc(sizeof(long long) * 4 * rows);
       (void)hipMemcpy(h, d_trace, sizeof(long long) * 4 * rows, hipMemcpyDeviceToHost);
       if (FILE *f = fopen(trace_path, "wb")) { fwrite(h, sizeof(long long), 4 * rows, f); fclose(f); }

@@ -16,6 +16,7 @@ from .. import _native as N
 from ..sweep import DEFAULT_HARM_COEFF, MetricSweep, SweepResult, list_views
 
 AVAILABLE = ("dce", "cp", "ttc", "ttce", "wttc", "be", "hr")   # metric.py:109-117
+_NP_DTYPE = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32, torch.uint8: np.uint8}
 
 
 def check_required_metrics(metric_names):
@@ -72,6 +73,36 @@ def trajectories_to_arrays(trajectories):
     return out
 
 
+class HostMirrorPool:
+    """Host memory for the full mirror of a batch's per-pair outputs (what a planner that opens result sub-dicts makes
+    ``BatchAssessment._to_host`` fetch: tens of MB per step for 2 000 x 32 x 30 lists).  Fresh pageable memory costs ~35 ms
+    of page faults to fill and ~20 ms for the operating system to take back at the next step; a pinned buffer kept across
+    steps costs the copy alone.  The arrays handed out are VIEWS of the pool: a buffer is written again only when nobody
+    outside holds a view of it any more (the reference returns fresh arrays per call, and a planner may keep a step's
+    results) -- otherwise the holder keeps that buffer and the pool takes a new one."""
+
+    def __init__(self, pinned=True):
+        self.pinned = bool(pinned)
+        self.bufs = {}            # name -> (uint8 tensor, its numpy array)
+        self.allocations = 0
+
+    def fetch(self, name, src):
+        """device tensor -> host array of the same shape and dtype (a view of the pool's buffer `name`)"""
+        import sys
+        src = src.contiguous()
+        n = src.numel() * src.element_size()
+        ent = self.bufs.get(name)
+        if ent is not None and (ent[0].numel() < n or sys.getrefcount(ent[1]) > 2):    # (the tuple's reference + the call's)
+            ent = None
+        if ent is None:
+            t = torch.empty(max(n, 1), dtype=torch.uint8, pin_memory=self.pinned)
+            ent = self.bufs[name] = (t, t.numpy())
+            self.allocations += 1
+        t, base = ent
+        t[:n].view(src.dtype).view(src.shape).copy_(src)
+        return base[:n].view(_NP_DTYPE[src.dtype]).reshape(tuple(src.shape))
+
+
 class BatchAssessment:
     """result of ``evaluate_batch``: device tensors of the sweep + accessors in the reference's vocabulary"""
 
@@ -92,6 +123,7 @@ class BatchAssessment:
         self._small = None
         self._fast = None
         self._hr_tpl = None
+        self._pool = None                # HostMirrorPool of the Metric this batch belongs to (None: plain .cpu() copies)
 
     def __len__(self):
         return int(self.cost.shape[0])
@@ -116,12 +148,13 @@ class BatchAssessment:
         if self._host is None:
             r = self.result
             big = r.lists_raw is not None and r.lists_raw.numel() * r.lists_raw.element_size() > self.HOST_CACHE_BYTES
+            get = (lambda name, t: t.cpu().numpy()) if self._pool is None else self._pool.fetch
             self._host = dict(self._host_small(),
-                              pair_f=None if (r.pair_f is None or big) else r.pair_f.cpu().numpy(),
-                              pair_i=None if (r.pair_i is None or big) else r.pair_i.cpu().numpy(),
+                              pair_f=None if (r.pair_f is None or big) else get("pair_f", r.pair_f),
+                              pair_i=None if (r.pair_i is None or big) else get("pair_i", r.pair_i),
                               # one copy of the raw buffer; the five lists are strided views of it
                               lists=None if (r.lists_raw is None or big) else
-                              list_views(r.lists_raw.cpu().numpy(), *r.lists_shape))
+                              list_views(get("lists", r.lists_raw), *r.lists_shape))
         return self._host
 
     def _column(self, m):
@@ -386,6 +419,7 @@ class Metric:
         self._batch = None
         self._batch_ids = {}
         self._batch_objs = []
+        self._mirror_pool = HostMirrorPool()      # host memory of the full per-pair mirror, kept across planning steps
 
     def invalidate(self):
         """call when the phantom set changed (FOInterface.evaluate_scenario does)"""
@@ -449,6 +483,7 @@ class Metric:
         _ = self.agent_manager.predictions if mode == "full" else None
         slots = getattr(self.agent_manager, "prediction_slots", None) if mode == "full" else None
         ba = BatchAssessment(res, slots, self.metrics, mode)
+        ba._pool = self._mirror_pool
         if remember is not None:
             self._batch = ba
             # strong references: id() is only unique among live objects, and the planner may drop its list and

@@ -495,3 +495,27 @@ def test_pending_visibility_is_applied_before_the_obstacles_move_on():
     fo._pending = resolver
     fo.update(1)                                                                   # ... and so does the next step
     assert len(calls) == 2 and all(o.last_visible_at_ts == 0 for o in fo) and not any(o._current_visible for o in fo)
+
+
+def test_host_mirror_pool_never_rewrites_memory_somebody_still_reads():
+    """metrics.metric.HostMirrorPool (the host memory of a batch's full per-pair mirror, kept across planning steps): a
+    buffer is reused only when no view of it is alive outside the pool; a planner that keeps a piece of a step's results keeps
+    that step's buffer and the pool takes a new one"""
+    import gc
+    import torch
+    from frenetix_occlusion.metrics.metric import HostMirrorPool
+    pool = HostMirrorPool(pinned=False)
+    a = torch.arange(24, dtype=torch.float64).reshape(2, 3, 4)
+    v1 = pool.fetch("lists", a)
+    assert np.array_equal(v1, a.numpy()) and pool.allocations == 1
+    kept = v1[:, :, 1]                              # a column of step 1 stays with the planner
+    v2 = pool.fetch("lists", a + 100.0)             # step 2
+    assert pool.allocations == 2 and np.array_equal(kept, a.numpy()[:, :, 1]) and np.array_equal(v2, (a + 100.0).numpy())
+    del v1, kept, v2
+    gc.collect()
+    v3 = pool.fetch("lists", a * 2.0)               # nobody holds step 2's views: the same memory again
+    assert pool.allocations == 2 and np.array_equal(v3, (a * 2.0).numpy())
+    v4 = pool.fetch("lists", torch.zeros(1000, dtype=torch.float64))      # a larger batch: a larger buffer
+    assert pool.allocations == 3 and v4.shape == (1000,)
+    w = pool.fetch("pair_i", torch.arange(6, dtype=torch.int32).reshape(2, 3))
+    assert w.dtype == np.int32 and w.tolist() == [[0, 1, 2], [3, 4, 5]]
