@@ -139,6 +139,7 @@ static int fo_step_stage_obstacles_(fo_ctx *ctx, const fo_step_t *p, hipStream_t
   if ((size_t)p->obstacles_bytes > fo_ctx::kRingSlot)
     return fo_fail(ctx, FO_E_ARG, "fo_step_run: %lld bytes of obstacle rows exceed the staging slot (%zu): copy them yourself and "
                    "pass h_obstacles = NULL", (long long)p->obstacles_bytes, fo_ctx::kRingSlot);
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (!ctx->h_ring) {
     FO_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_ring, fo_ctx::kRing * fo_ctx::kRingSlot, hipHostMallocDefault));
     for (int i = 0; i < fo_ctx::kRing; ++i) FO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_ring[i], hipEventDisableTiming));
@@ -158,6 +159,7 @@ static int fo_step_stage_obstacles_(fo_ctx *ctx, const fo_step_t *p, hipStream_t
 static int fo_step_queue_mirror_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream) {
   if (!p->h_mirror || p->mirror_bytes <= 0) return FO_OK;
   if (!p->d_mirror) return fo_fail(ctx, FO_E_ARG, "fo_step_run: h_mirror without d_mirror");
+  FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (!ctx->ev_mirror) FO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mirror, hipEventDisableTiming));
   FO_HIP_TRY(ctx, hipMemcpyAsync(p->h_mirror, p->d_mirror, (size_t)p->mirror_bytes, hipMemcpyDeviceToHost, stream));
   FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_mirror, stream));

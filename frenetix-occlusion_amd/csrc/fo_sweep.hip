@@ -200,7 +200,7 @@ __device__ __forceinline__ double fo_sel_hi(unsigned long long mask, double a, d
   return __hiloint2double(fo_sel_b32(mask, __double2hiint(a), __double2hiint(b)), __double2loint(a));
 }
 #ifndef FO_EPI_SEL
-#define FO_EPI_SEL 0   // 1: tuning builds -- the wave extrema as v_min / v_max + one select on a scalar-pair mask, NaN selects on the high word alone (measured: 0.504 against 0.498 ms -- fewer instructions, a worse allocation)
+#define FO_EPI_SEL 1   // 0: tuning builds -- the per-pair epilogue as plain C (compare + v_cndmask chains on vcc): +1 % on the headline kernel (measured with the product build's flags on both sides; an earlier comparison across two flag sets had the sign wrong)
 #endif
 // a * b + c with three distinct register operands (the compiler prefers v_mov_b64 + v_fmac_f64 when c outlives the result)
 #ifndef FO_P2_FMA3

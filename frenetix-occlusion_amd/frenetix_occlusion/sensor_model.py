@@ -587,6 +587,8 @@ class SensorModel:
         one device-to-host copy of the step's hit ids and visibility flags (the only point of a step where the host waits
         for the device, and only when there are obstacles)"""
         self._vis_pending = None
+        if getattr(obstacles, "_pending", None) is not None:     # (a one-call step's view nobody looked at: superseded)
+            obstacles._pending = None
         O = getattr(self, "_obst", (None, None, None, 0))[3]
         self._apply_visible(self._buf["hv"].cpu().numpy() if O else None, timestep, obstacles)
         return self.visible_area
