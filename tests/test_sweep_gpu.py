@@ -612,6 +612,24 @@ def test_dce_ties_stationary_and_random_geometry(torch_cuda, oracle):
     td = ref["pair_i"][..., oracle.PI["time_dce"]]
     assert td[0, 0] == 0 and td[2, 0] == 15 and td[0, 4] == 0                 # ties -> earliest; symmetric -> first
     assert ref["pair_f"][0, 4, oracle.PF["dce"]] == 0.0                        # touching counts as distance 0
+    # Coincident reference points (harm_model.py:86-90: atan2(0, 0) = 0, then the UN-wrapped angle pi + 0 - yaw decides the
+    # obstacle's impact class -- "rear" for every negative yaw) and zero relative speed at every sample: vehicles parked exactly on
+    # the trajectory point of the ego at rest, headings on both sides of zero and beyond pi; one of them drives off later
+    yaws = np.array([-0.5, 1.5, 3.5, -3.5, 0.0, 2.8])        # pi - yaw: rear, side, front, rear (un-wrapped 6.64), rear, front
+    A2 = len(yaws)
+    pos2 = np.zeros((A2, T, 2))
+    pos2[2, 10:, 0] = 0.8 * (t[10:] - t[10])
+    v2 = np.zeros((A2, T))
+    v2[2, 10:] = 0.8
+    agents2 = {"pos": pos2, "yaw": np.repeat(yaws[:, None], T, 1), "v": v2, "cov": np.tile(0.1 * np.eye(2), (A2, T, 1, 1)),
+               "shape": np.tile([5.76, 2.6], (A2, 1)), "raw_dims": np.tile([4.8, 2.0], (A2, 1)),
+               "type": np.zeros(A2, dtype=np.int32), "len": np.full(A2, T, dtype=np.int32)}
+    for lists in ("f64", "f32x"):
+        ref2 = oracle.sweep(traj, agents2, S.VEHICLE_BMW320I, 0.1)
+        got2 = _hip_sweep(torch_cuda, traj, agents2, S.VEHICLE_BMW320I, 0.1, lists=lists)
+        _compare(oracle, ref2, got2, atol=ATOL if lists == "f64" else 1e-6)
+    oh = ref2["lists"][0, :, oracle.LST["obst_harm"], 0]                       # ego at rest on top of them, first sample
+    assert len({oh[0], oh[1], oh[2]}) == 3 and oh[0] == oh[3] == oh[4] and oh[2] == oh[5]      # three classes, by the un-wrapped angle
     rng = np.random.default_rng(123)
     for trial in range(3):
         M, A = 256, 24
