@@ -7,6 +7,7 @@
 #include "fo_prep_traj.hpp"
 
 extern "C" void fo_scene_destroy_(fo_ctx *ctx);  // fo_scene.hip
+extern "C" void *fo_step_direct_mirror_(fo_ctx *ctx, const fo_step_t *p);   // fo_scene.hip
 extern "C" int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, const fo_prep_args_t *prep, void *stream);  // fo_scene.hip
 extern "C" int fo_sweep_agents_begin_(fo_ctx *ctx, int A, int Ta, void *stream, fo_agent_table_t *out);   // fo_sweep.hip
 extern "C" int fo_sweep_init_(fo_ctx *ctx);      // fo_sweep.hip
@@ -18,7 +19,7 @@ extern "C" int fo_sweep_run_prepped_(fo_ctx *ctx, int M, int T, const double *d_
                                      int32_t *d_pair_i, double *d_lists, void *stream);   // fo_sweep.hip
 
 static int fo_step_stage_obstacles_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream);
-static int fo_step_queue_mirror_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream);
+static int fo_step_queue_mirror_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream, bool direct);
 static int fo_step_body_(fo_ctx *ctx, const fo_step_t *p, void *stream, bool stages, bool cells, bool rules, int slots, int slot0,
                          int cell_agents);
 
@@ -118,7 +119,7 @@ int fo_step_run(fo_ctx *ctx, const fo_step_t *p, void *stream) {
   if ((rc = fo_sweep_set_list_format(ctx, p->list_format))) return rc;   // the format is an argument of the run
   if ((rc = fo_step_stage_obstacles_(ctx, p, (hipStream_t)stream))) return rc;
   rc = fo_step_body_(ctx, p, stream, stages, cells, rules, slots, slot0, cell_agents);
-  if (rc == FO_OK) rc = fo_step_queue_mirror_(ctx, p, (hipStream_t)stream);
+  if (rc == FO_OK) rc = fo_step_queue_mirror_(ctx, p, (hipStream_t)stream, !stages && fo_step_direct_mirror_(ctx, p) != nullptr);
   return rc;
 }
 
@@ -156,12 +157,15 @@ static int fo_step_stage_obstacles_(fo_ctx *ctx, const fo_step_t *p, hipStream_t
 }
 
 // the step's mirror (hit ids and visibility flags for the host views of the reference's side effects): behind the last launch
-static int fo_step_queue_mirror_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream) {
+static int fo_step_queue_mirror_(fo_ctx *ctx, const fo_step_t *p, hipStream_t stream, bool direct) {
   if (!p->h_mirror || p->mirror_bytes <= 0) return FO_OK;
   if (!p->d_mirror) return fo_fail(ctx, FO_E_ARG, "fo_step_run: h_mirror without d_mirror");
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (!ctx->ev_mirror) FO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mirror, hipEventDisableTiming));
-  FO_HIP_TRY(ctx, hipMemcpyAsync(p->h_mirror, p->d_mirror, (size_t)p->mirror_bytes, hipMemcpyDeviceToHost, stream));
+  // (the fused step stores the mirror from the kernels that produce its contents -- fo_scene.hip, FanArgs::hit_host -- when the
+  // mirror is the interface's (hit ids | visibility flags) pair; the event behind the step is all that is left to queue)
+  if (!direct)
+    FO_HIP_TRY(ctx, hipMemcpyAsync(p->h_mirror, p->d_mirror, (size_t)p->mirror_bytes, hipMemcpyDeviceToHost, stream));
   FO_HIP_TRY(ctx, hipEventRecord(ctx->ev_mirror, stream));
   ctx->mirror_queued = true;
   return FO_OK;

@@ -72,6 +72,7 @@ struct fo_ctx {
   int ring_next = 0;
   hipEvent_t ev_mirror = nullptr;
   bool mirror_queued = false;
+  void *mirror_host = nullptr, *mirror_dev = nullptr;   // the last h_mirror and its device-side address (hipHostGetDevicePointer)
 
   // ---- scene (ray-cast / grid) state lives in fo_scene.hip
   void *scene = nullptr;

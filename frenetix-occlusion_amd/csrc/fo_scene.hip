@@ -343,6 +343,11 @@ struct FanArgs {
   int on = 0, full = 0, polygon = 0;
   double yaw = 0, fov = 0;
   double *dirs = nullptr, *rmax = nullptr, *half = nullptr;
+  // fo_step_t::h_mirror as the device sees it (pinned host memory is mapped): the hit ids and the obstacles' visibility
+  // flags are ALSO stored there by the launches that produce them -- posted writes over PCIe, no copy command behind the step
+  // (a device-to-host copy of 3 KB is a blit launch of ~5 us); null: no mirror, or one the step copies
+  int32_t *hit_host = nullptr;
+  uint8_t *vis_host = nullptr;
 };
 struct FanDirs {   // the direction of ray i by the fan's arithmetic (bit-identical to the table entry)
   int n;
@@ -451,6 +456,7 @@ __global__ __launch_bounds__(64 * NW) void fo_rays_kernel(int E, const double *_
       if (!(best <= rm)) { best = rm; id = -1; }
       range[i] = best;
       hit_id[i] = id;
+      if (fan.hit_host) fan.hit_host[i] = id;
       // a ray that stops at an obstacle has reached a lit point of its boundary: the obstacle touches the visible area
       // (sensor_model.py:59-76); the probe workgroups below add the obstacles that slip between two rays
       if (id >= E && vis32) atomicOr(&vis32[id - E], 1);
@@ -592,7 +598,7 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
                                int32_t *__restrict__ amb, int32_t *__restrict__ n_amb,
                                const double *__restrict__ half, const int32_t *__restrict__ edge_line,
                                const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags, double shadow_length,
-                               double *__restrict__ ofar, int n_obst) {
+                               double *__restrict__ ofar, int n_obst, uint8_t *__restrict__ vis_host) {
   __shared__ int wsum[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   // where the obstacles' shadows end (read by the settle kernel, the next launch): sixteen lanes per obstacle
@@ -603,6 +609,7 @@ __global__ void fo_grid_kernel(const uint8_t *__restrict__ raster, int rnx, int 
   }
   if (vis && idx < O) {  // obstacle-visibility flags of the probe workgroups (previous launch); self-cleaning
     vis[idx] = vis32[idx] ? 1 : 0;
+    if (vis_host) vis_host[idx] = vis32[idx] ? 1 : 0;
     vis32[idx] = 0;
   }
   const bool in = idx < nx * ny;
@@ -1683,7 +1690,8 @@ static int scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head
                      sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, win_ny, ego_x, ego_y, head_x, head_y, r, full_circle,
                      n_rays, d_dirs, d_range, d_cls, sc->d_flags, sc->d_blk, probes ? O : 0, sc->d_vis32,
                      probes ? d_obst_vis : nullptr, exact_cells ? 1 : 0, sc->map->E, d_hit_id, d_rmax, sc->d_amb,
-                     sc->d_namb, d_half, sc->map->d_edge_line, d_ocorn, d_oflags, sc->shadow_length, far, O);
+                     sc->d_namb, d_half, sc->map->d_edge_line, d_ocorn, d_oflags, sc->shadow_length, far, O,
+                     probes ? fan.vis_host : nullptr);
   if (exact_cells) {
     if ((uintptr_t)d_cls & 3) return fo_fail(ctx, FO_E_ARG, "fo_scene_visibility: d_cls must be 4-byte aligned");
     const dim3 sgrid(SETTLE_BLOCKS + O), sblock(64 * (one_wave ? 1 : RAY_WAVES));
@@ -1809,6 +1817,23 @@ int fo_scene_rule_agents_(fo_ctx *ctx, int max_points, const double *d_points, c
                           double *d_v, double *d_cov, double *d_shape, double *d_raw_dims, int32_t *d_type, int32_t *d_len,
                           void *stream, const fo_agent_table_t *at);   // fo_spawn_rules.hpp
 
+// h_mirror as a device pointer if the kernels can fill it themselves (see FanArgs::hit_host), else null (fo_api.hip copies)
+void *fo_step_direct_mirror_(fo_ctx *ctx, const fo_step_t *p) {
+  if (!p->h_mirror || !p->d_mirror || p->O < 1 || !p->d_obst_vis) return nullptr;
+  if (p->d_mirror != (const void *)p->d_hit_id || (const uint8_t *)p->d_obst_vis != (const uint8_t *)p->d_hit_id + sizeof(int32_t) * (size_t)p->n_rays ||
+      p->mirror_bytes != (int64_t)(sizeof(int32_t) * (size_t)p->n_rays + (size_t)p->O))
+    return nullptr;
+  static const bool off = [] { const char *e = getenv("FO_STEP_MIRROR_COPY"); return e && e[0] == '1'; }();   // (A/B runs)
+  if (off) return nullptr;
+  if (ctx->mirror_host != p->h_mirror) {
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, p->h_mirror, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+    ctx->mirror_host = p->h_mirror;
+    ctx->mirror_dev = d;
+  }
+  return ctx->mirror_dev;
+}
+
 int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, const fo_prep_args_t *prep, void *stream) {
   if (!ctx || !p) return FO_E_ARG;
   if (p->n_rays < 4 || !p->d_dirs || !(p->r > 0) || !(p->fov_deg > 0)) return fo_fail(ctx, FO_E_ARG, "fo_scene_fan: bad arguments");
@@ -1817,6 +1842,12 @@ int fo_scene_step_(fo_ctx *ctx, const fo_step_t *p, const fo_agent_table_t *at, 
   fan.on = 1; fan.full = p->fov_deg >= 359.9; fan.polygon = p->polygon_footprint; fan.yaw = p->ego_yaw;
   fan.fov = p->fov_deg * (3.14159265358979323846 / 180.0);
   fan.dirs = p->d_dirs; fan.rmax = p->d_rmax; fan.half = p->d_half;
+  // the step's mirror, when it is exactly the pair (hit ids | visibility flags) the interface allocates back to back: stored
+  // by the kernels themselves (fo_api.hip then only records the event behind the step)
+  if (void *hm = fo_step_direct_mirror_(ctx, p)) {
+    fan.hit_host = (int32_t *)hm;
+    fan.vis_host = (uint8_t *)hm + sizeof(int32_t) * (size_t)p->n_rays;
+  }
   SpawnFlagArgs sf;
   sf.all_occluded = p->all_occluded ? 1 : 0; sf.min_ahead = p->min_ahead; sf.max_dist = p->max_dist;
   int rc;

@@ -417,9 +417,11 @@ typedef struct {
    * h_obstacles: the obstacle rows of this step in host memory, any kind (d_ocorn / d_ocen / d_oflags / d_oyaw / d_odims
    * point into d_obstacles); copied into a pinned staging slot of the context and from there to d_obstacles in front of the
    * first launch -- the caller's buffer is free again when fo_step_run returns; at most 64 KB.
-   * h_mirror: PINNED host memory (hipHostMalloc / a pinned torch tensor) that receives mirror_bytes from d_mirror behind the
-   * last launch of the step (the interface mirrors d_hit_id and d_obst_vis, which it allocates back to back); complete when
-   * fo_step_mirror_wait returns.  The next fo_step_run on the same stream overwrites it. */
+   * h_mirror: PINNED, device-mapped host memory (hipHostMalloc / a pinned torch tensor) that receives mirror_bytes from
+   * d_mirror by the end of the step (the interface mirrors d_hit_id and d_obst_vis, which it allocates back to back: that
+   * pair is stored into the mirror by the kernels that produce it -- posted writes, no copy command; any other region is
+   * copied behind the last launch); complete when fo_step_mirror_wait returns.  The next fo_step_run on the same stream
+   * overwrites it. */
   const void *h_obstacles;
   void *d_obstacles;
   int64_t obstacles_bytes;
