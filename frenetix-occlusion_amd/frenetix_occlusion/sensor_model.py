@@ -445,6 +445,10 @@ class SensorModel:
         key = (w.nx, w.ny, O, self.n_rays)
         if getattr(self, "_buf_key", None) != key:
             dev, n = self.device, self.n_rays
+            if getattr(self, "_buf", None) is not None:
+                # (the window or the obstacle count changed -- rare: a step still in flight may be writing the old pinned
+                # mirror, which the allocator would hand to the next pinned request the moment it is dropped)
+                torch.cuda.current_stream(dev).synchronize()
             # hit ids and visibility flags are read back together after a step: one allocation, one copy
             hv = torch.zeros(4 * n + max(O, 1), dtype=torch.uint8, device=dev)
             self._buf = dict(rng=torch.empty(n, dtype=torch.float64, device=dev),
