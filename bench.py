@@ -469,6 +469,38 @@ def rules_step(local_rank, steps=60):
     return out
 
 
+def box_probe(local_rank):
+    """What THIS box reaches on two plain library operations, beside the step it just timed: the boxes of the pool differ (the same
+    library measured 0.487-0.553 ms on a dozen of them in round 5), and a bench line that carries a fill rate and a float64 GEMM
+    rate of its own box says which kind it met.  Context only: `roofline.peak` stays the guide's 8 TB/s."""
+    import torch
+    dev = torch.device("cuda", local_rank)
+    out = {}
+    buf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        buf.fill_(1)
+    e0.record()
+    for _ in range(8):
+        buf.fill_(2)
+    e1.record()
+    torch.cuda.synchronize()
+    out["fill_gbs"] = 8 * buf.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del buf
+    n = 4096
+    a = torch.randn((n, n), dtype=torch.float64, device=dev)
+    b = torch.randn((n, n), dtype=torch.float64, device=dev)
+    c = a @ b
+    e0.record()
+    for _ in range(4):
+        c = a @ b
+    e1.record()
+    torch.cuda.synchronize()
+    out["dgemm_f64_tflops"] = 4 * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    out["what"] = "torch fill_ of 1 GiB and a 4096^3 float64 matmul on this box, after the timed steps (context for the box-to-box spread; not used in any figure above)"
+    return out
+
+
 def shard_probe(scene, sw, tensors, local_rank, N, steps=200):
     """What ONE GPU can measure about BASELINE configs[3] (the 10k x 256 batch block-partitioned over 8 / 4 / 2 GPUs): the planning
     step of a 1/8, 1/4 and 1/2 shard -- same scene stage, same agents, the library's measured agents-per-wave for the shard's
@@ -870,6 +902,7 @@ def main():
                 return d_
             del out
             torch.cuda.empty_cache()
+            res["config"]["box"] = box_probe(local_rank)
             # the same step with the lists in the other element type, and with reduced outputs (cost vectors + flags:
             # what a planner loop consumes), beside the headline
             for other in ("f64", "f32x", "f32"):
