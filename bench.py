@@ -10,7 +10,8 @@ One "step" = one planning step of BASELINE.json configs[2] with every input alre
     CP / harm / risk over T = 31) for 10 000 candidate trajectories  ->  threshold reduction
     (+ one RCCL all-gather of the per-trajectory cost vectors when N > 1).
 `roofline.bound` names the binding unit from the committed rocprofv3 counters of the loaded library (`profiles/`): the larger
-of `valu_issue_frac` (VALU issue slots taken) and `hbm_frac_of_achievable` (counter traffic over the 6.3 TB/s the chip reaches).
+of `valu_issue_frac` (VALU issue slots taken) and `hbm_frac_of_achievable` (counter traffic over the 6.3 TB/s the chip reaches)
+when that one exceeds 0.8, else "latency/issue mix (hbm x, valu y)" -- short of both limits at once.
 
 N > 1 (BASELINE configs[3]): ONE batch of --M trajectories is block-partitioned over the ranks (`--scaling strong`, the
 default; M/N per rank, scene stage and agents replicated, `cost [M][16]` all-gathered) -- `--scaling weak` gives every
@@ -78,7 +79,7 @@ def bytes_stored(M, A, T, mode, lists):
     if mode in ("pair", "full"):
         b += M * A * (12 * 8 + 4 * 4)
     if mode == "full":
-        b += M * A * 5 * (T - 1) * (4 if lists == "f32" else 8)
+        b += M * A * 5 * (T - 1) * (4 if lists in ("f32", "f32x") else 8)     # f32x: float64 results, float32 elements
     return b
 
 
@@ -271,12 +272,31 @@ def cpu_and_parity(S, N, traj, agents, out, lists_fmt, want_parity=True):
 HBM_ACHIEVABLE_GBS = 6300.0   # what a plain fill reaches on this chip (guide; tools/microbench/write_bw.py)
 
 
+def bound_word(hbm_frac, valu_frac):
+    """the binding unit by the two counter fractions: a unit is named only when its fraction exceeds 0.8; below that the
+    kernel is short of both limits at once and the line says so instead of picking the larger of two middling numbers"""
+    if max(hbm_frac, valu_frac) > 0.8:
+        return "hbm" if hbm_frac > valu_frac else "valu-issue"
+    return f"latency/issue mix (hbm {hbm_frac:.2f}, valu {valu_frac:.2f})"
+
+
+def roofline_checks(a8d, ast, kern_s, traffic):
+    """what has to hold between the byte figures of one launch before they are printed: SURVEY 8d's bytes <= the bytes this
+    build stores <= 1.1 x the counter traffic of the committed profile (when there is one), and no figure above what the
+    chip reaches.  Returns (checks, ok)."""
+    c = {"algorithmic_le_stored": a8d <= ast,
+         "stored_le_1p1_traffic": (ast <= 1.1 * traffic) if traffic else None,
+         "achieved_stored_le_hbm_achievable": ast / kern_s / 1e9 <= HBM_ACHIEVABLE_GBS,
+         "achieved_le_hbm_achievable": a8d / kern_s / 1e9 <= HBM_ACHIEVABLE_GBS}
+    return c, all(v is not False for v in c.values())
+
+
 def committed_pmc(N, mode, lists_fmt):
     """What the committed rocprofv3 summary of THIS library says about the dominant kernel of an output mode:
     HBM traffic per launch (WRITE_SIZE + 2 x FETCH_SIZE, the guide's gfx950 correction; KB -> bytes), the VALU issue fraction
     SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs), the
-    HBM fraction = traffic / time over the 6.3 TB/s the chip reaches, and the binding unit = the LARGER of the two fractions
-    (both are printed; no threshold).  profiles/<tag>_build.json must name the fo_build_id() of the loaded library, else
+    HBM fraction = traffic / time over the 6.3 TB/s the chip reaches, and the binding unit = the larger of the two fractions
+    if it exceeds 0.8, else "latency/issue mix" with both figures (bound_word).  profiles/<tag>_build.json must name the fo_build_id() of the loaded library, else
     everything is None."""
     import csv
     base = os.environ.get("FO_PROFILE_TAG", "r05")
@@ -304,7 +324,7 @@ def committed_pmc(N, mode, lists_fmt):
                 if out["hbm_traffic_gbs"] is not None:
                     out["hbm_frac"] = out["hbm_traffic_gbs"] / HBM_ACHIEVABLE_GBS
                 if out["hbm_frac"] is not None and out["valu_issue_frac"] is not None:
-                    out["bound"] = "hbm" if out["hbm_frac"] > out["valu_issue_frac"] else "valu-issue"
+                    out["bound"] = bound_word(out["hbm_frac"], out["valu_issue_frac"])
                 break
     except Exception:
         pass
@@ -808,6 +828,11 @@ def main():
         pmc = {"traffic": None, "valu_issue_frac": None, "bound": None, "profile": None, "hbm_traffic_gbs": None, "hbm_frac": None}
         if default_workload and world == 1:
             pmc = committed_pmc(N, args.mode, args.lists)
+        checks, checks_ok = roofline_checks(a8d, ast, kern_s, pmc["traffic"])
+        if not checks_ok:     # a bug of this script, not of the box: say so loudly and print no impossible bandwidth
+            print(f"bench.py: inconsistent byte figures {checks}", file=sys.stderr, flush=True)
+            if os.environ.get("FO_BENCH_STRICT") == "1":
+                raise AssertionError(f"roofline byte figures are inconsistent: {checks}")
         dtype = "f64" if (args.mode != "full" or args.lists == "f64") else ("f64+f32lists" if args.lists == "f32" else "f64 (lists stored f32)")
         res = {
             "metric": "trajectory_x_agent_metric_evals_per_sec", "value": pairs / elapsed, "unit": "pair-evals/s",
@@ -844,8 +869,8 @@ def main():
                        "allgathers_issued": cg.calls if cg is not None else 0,
                        "allgather_ms": ag_ms, "allgather_bytes_per_rank": per * N.NC * 8 if use_dist else None,
                        "build_id": N.build_id()},
-            # bound: the larger of the two fractions the committed PMC summary of this library gives -- VALU issue slots taken,
-            # HBM traffic over what the chip reaches -- both printed; achieved / peak / frac stay SURVEY 8d's byte figure on the HBM peak
+            # bound: from the two fractions the committed PMC summary of this library gives -- VALU issue slots taken, HBM traffic
+            # over what the chip reaches -- both printed, a unit named only above 0.8 (bound_word); achieved / peak / frac stay SURVEY 8d's byte figure on the HBM peak
             "roofline": {"bound": pmc["bound"] or "unknown (no PMC summary of this library under profiles/)",
                          "kernel": "fo_sweep_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"], "traffic_profile": pmc["profile"],
@@ -855,7 +880,9 @@ def main():
                          "bytes_definition": "SURVEY 8d, fp32 storage: 620 B/trajectory + 636 B/agent + per pair 48 B "
                                              "scalars (+ 600 B lists in full mode); 64 B/trajectory in reduced mode",
                          "algorithmic_bytes_per_launch": a8d, "stored_bytes_per_launch": ast,
-                         "achieved_stored": ast / kern_s / 1e9, "frac_stored_bytes": ast / kern_s / 1e9 / HBM_PEAK_GBS,
+                         "achieved_stored": ast / kern_s / 1e9 if checks_ok else None,
+                         "frac_stored_bytes": ast / kern_s / 1e9 / HBM_PEAK_GBS if checks_ok else None,
+                         "byte_checks": checks,
                          "kernel_ms": kern_s * 1e3, "launches_timed": kern_n, "timed_every": time_every,
                          "kernel_ms_p50": float(np.percentile(kern_each, 50)) if kern_each else None,
                          "kernel_ms_p95": float(np.percentile(kern_each, 95)) if kern_each else None,
@@ -890,7 +917,7 @@ def main():
                 kms_r, kn_r = sw.ctx.timing_read()
                 sw.ctx.timing(False)
                 ks = kms_r / max(kn_r, 1) / 1e3
-                b8, bs = bytes_8d(M, n_active, T, mode), bytes_stored(M, n_active, T, mode, "f32" if lists != "f64" else "f64")
+                b8, bs = bytes_8d(M, n_active, T, mode), bytes_stored(M, n_active, T, mode, lists)
                 del r
                 pm = committed_pmc(N, mode, lists)
                 d_ = {"ms_per_step": dt_r * 1e3, "pair_evals_per_sec": M * n_active / dt_r, "sweep_kernel_ms": ks * 1e3,

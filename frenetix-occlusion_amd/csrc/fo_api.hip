@@ -105,7 +105,8 @@ int fo_sweep_check(fo_ctx *ctx, void *stream) {
 int fo_step_run(fo_ctx *ctx, const fo_step_t *p, void *stream) {
   if (!ctx || !p) return fo_fail(ctx, FO_E_ARG, "fo_step_run: null argument");
   int rc;
-  static const bool stages = [] { const char *e = getenv("FO_STEP_STAGES"); return e && e[0] == '1'; }();
+  const char *e_stages = fo_getenv(fo_env_any("FO_STEP_"), "FO_STEP_STAGES");   // (every call: tests switch it at run time)
+  const bool stages = e_stages && e_stages[0] == '1';
   if (p->spawn_mode != FO_SPAWN_CELLS && p->spawn_mode != FO_SPAWN_RULES && p->spawn_mode != FO_SPAWN_BOTH)
     return fo_fail(ctx, FO_E_ARG, "fo_step_run: unknown spawn_mode %d", p->spawn_mode);
   const bool cells = p->spawn_mode != FO_SPAWN_RULES, rules = p->spawn_mode != FO_SPAWN_CELLS;
@@ -161,7 +162,9 @@ static int fo_step_queue_mirror_(fo_ctx *ctx, const fo_step_t *p, hipStream_t st
   if (!p->h_mirror || p->mirror_bytes <= 0) return FO_OK;
   if (!p->d_mirror) return fo_fail(ctx, FO_E_ARG, "fo_step_run: h_mirror without d_mirror");
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (!ctx->ev_mirror) FO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mirror, hipEventDisableTiming));
+  // (release to SYSTEM scope: the direct mirror is written by kernel stores into mapped host memory, and the host reads it
+  // after hipEventSynchronize on this event -- the default release scope of an event is the runtime's choice)
+  if (!ctx->ev_mirror) FO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mirror, hipEventDisableTiming | hipEventReleaseToSystem));
   // (the fused step stores the mirror from the kernels that produce its contents -- fo_scene.hip, FanArgs::hit_host -- when the
   // mirror is the interface's (hit ids | visibility flags) pair; the event behind the step is all that is left to queue)
   if (!direct)

@@ -73,6 +73,7 @@ struct fo_ctx {
   hipEvent_t ev_mirror = nullptr;
   bool mirror_queued = false;
   void *mirror_host = nullptr, *mirror_dev = nullptr;   // the last h_mirror and its device-side address (hipHostGetDevicePointer)
+  int64_t mirror_bytes = 0;                              // ... and its size (the cache is keyed on both)
 
   // ---- scene (ray-cast / grid) state lives in fo_scene.hip
   void *scene = nullptr;

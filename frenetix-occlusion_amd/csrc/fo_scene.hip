@@ -1823,12 +1823,17 @@ void *fo_step_direct_mirror_(fo_ctx *ctx, const fo_step_t *p) {
   if (p->d_mirror != (const void *)p->d_hit_id || (const uint8_t *)p->d_obst_vis != (const uint8_t *)p->d_hit_id + sizeof(int32_t) * (size_t)p->n_rays ||
       p->mirror_bytes != (int64_t)(sizeof(int32_t) * (size_t)p->n_rays + (size_t)p->O))
     return nullptr;
-  static const bool off = [] { const char *e = getenv("FO_STEP_MIRROR_COPY"); return e && e[0] == '1'; }();   // (A/B runs)
-  if (off) return nullptr;
-  if (ctx->mirror_host != p->h_mirror) {
+  // (FO_STEP_MIRROR_COPY=1: the copy command instead, for A/B runs and the test that compares the two paths -- looked at on
+  // every call like the other knobs, fo_ctx.hpp)
+  const char *e = fo_getenv(fo_env_any("FO_STEP_"), "FO_STEP_MIRROR_COPY");
+  if (e && e[0] == '1') return nullptr;
+  // the device-side address of the pinned block, cached by (address, size): a block freed and registered again at the same
+  // address with another size is another mapping
+  if (ctx->mirror_host != p->h_mirror || ctx->mirror_bytes != p->mirror_bytes) {
     void *d = nullptr;
     if (hipHostGetDevicePointer(&d, p->h_mirror, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
     ctx->mirror_host = p->h_mirror;
+    ctx->mirror_bytes = p->mirror_bytes;
     ctx->mirror_dev = d;
   }
   return ctx->mirror_dev;

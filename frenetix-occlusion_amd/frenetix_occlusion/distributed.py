@@ -72,7 +72,9 @@ class CostGather:
         return self.mine[: self.n_local]
 
     def gather(self, cost: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``cost``: this rank's cost rows if they were not written into ``block()`` directly.  Returns cost [M, 16]."""
+        """``cost``: this rank's cost rows if they were not written into ``block()`` directly.  Returns cost [M, 16] -- a VIEW
+        of this object's gathered matrix, which the next ``gather()`` overwrites: valid until the next step of whoever
+        reuses this CostGather (``PlanningStep.out.cost_all``, ``BatchAssessment.cost``); ``.clone()`` what must outlive it."""
         if cost is not None and self.n_local and cost.data_ptr() != self.mine.data_ptr():
             self.mine[: self.n_local].copy_(cost)
         if self.collective:

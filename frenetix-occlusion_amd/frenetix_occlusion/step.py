@@ -122,7 +122,11 @@ class PlanningStep:
         w = sm._window_for(ego_pos)
         O = getattr(sm, "_obst", (None, None, None, 0))[3]
         key = (w.nx, w.ny, O)
-        if self._s is None or key != self._key:
+        # the sensor model owns ONE buffer set, keyed by (window size, obstacle count): another caller between two runs of
+        # this step (a direct calc_visible_and_occluded_area, a second PlanningStep, an upload with another obstacle count)
+        # may have re-keyed it.  _buffers() re-keys it back for this step; a set that is not the one the structure points
+        # at means the structure is stale -- adopt_step / defer_visible_objects read sm._buf, so both must be the same set
+        if self._s is None or key != self._key or sm._buffers(w, O) is not self._buf:
             self._s, self._key = self._fill(w, O), key
         s = self._s
         # the obstacle tensors are re-allocated by every upload_obstacles: their pointers are per-step members (and the

@@ -68,6 +68,10 @@ class FOObstacle:
     def update_at_timestep(self, timestep):
         """fo_obstacle.py:79-116: rel = step - initial; 0 -> initial state, >= 1 -> state_list[rel-1], else absent"""
         if self._owner is not None:
+            # the last step's visibility first (as FOObstacles.update does): a deferred one-call step must stamp
+            # last_visible_at_ts with ITS time step before this obstacle moves on, not overwrite the moved state later
+            if self._owner._pending is not None:
+                self._owner._pending()
             self._owner._packed = None       # (a single obstacle moved by hand: the owner's packed rows are stale)
         self.global_timestep = timestep
         self.relative_time_step = timestep - self.initial_timestep

@@ -421,7 +421,10 @@ typedef struct {
    * d_mirror by the end of the step (the interface mirrors d_hit_id and d_obst_vis, which it allocates back to back: that
    * pair is stored into the mirror by the kernels that produce it -- posted writes, no copy command; any other region is
    * copied behind the last launch); complete when fo_step_mirror_wait returns.  The next fo_step_run on the same stream
-   * overwrites it. */
+   * overwrites it.  COHERENCE: the direct stores need host-coherent pinned memory -- hipHostMalloc with the default flags
+   * (or hipHostMallocCoherent / a pinned torch tensor); the event the wait synchronises on releases to system scope
+   * (hipEventReleaseToSystem).  Memory from hipHostMallocNonCoherent or hipHostRegister carries no such guarantee: pass it
+   * with FO_STEP_MIRROR_COPY=1 in the environment (the copy command instead of the direct stores) or not at all. */
   const void *h_obstacles;
   void *d_obstacles;
   int64_t obstacles_bytes;

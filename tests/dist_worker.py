@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--M", type=int, default=333)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE configs[3] itself: the urban grid, 256 phantom slots, --M candidates (10 000), reduced outputs, "
+                         "split through PlanningStep(shard=...) -- instead of the scenario-1 scene")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", "0")) if args.backend == "nccl" else 0
@@ -43,6 +46,8 @@ def main():
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     assert dist.get_world_size() == world
+    if args.config3:
+        return config3(args, rank, world, local)
 
     with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
         cfg = yaml.safe_load(f)
@@ -106,6 +111,69 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     os.remove(cfg_path)
+
+
+def config3(args, rank, world, local):
+    """The partition BASELINE configs[3] names -- the synthetic 10k x 256 batch of the bench line, block-partitioned over
+    `world` ranks (8: 1 250 trajectories per rank), scene stage and phantoms replicated, ONE all-gather of the cost rows --
+    through the product's one-call step.  Rank 0 also runs the unsharded step and writes both."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import yaml
+    from frenetix_occlusion import _native as N
+    from frenetix_occlusion import distributed as D
+    from frenetix_occlusion import interface
+    from frenetix_occlusion import scenario as SC
+    from frenetix_occlusion import synthetic as S
+    from frenetix_occlusion.sensor_model import SensorModel
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    from frenetix_occlusion.step import PlanningStep
+    from frenetix_occlusion.sweep import MetricSweep
+    M, A, T = args.M, 256, 31
+    thr = {"harm": 0.1, "risk": 1}
+    ctx = N.Context(local)
+    sc = SC.synthetic_urban_grid()
+    ego = sc.ego_initial
+    with open(os.path.join(os.path.dirname(interface.__file__), "config", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["accelerator"]["spawn"]["mode"] = "cells"
+    cfg["accelerator"]["spawn"].update(max_agents=A, all_occluded=True, max_dist=45.0)
+    ref_path = ego[None, :2] + np.linspace(0.0, 80.0, 81)[:, None] * np.array([[math.cos(ego[2]), math.sin(ego[2])]])
+    sm = SensorModel(sc.lanelets, ref_path, sensor_radius=50.0, sensor_angle=360.0, n_rays=720, cell_size=0.5, ctx=ctx, device=local)
+    sm.upload_obstacles(sc.obstacle_arrays(0)[:3])
+    sl = SpawnLocator(None, ref_path, cfg, sm, dt=0.1, horizon=(T - 1) * 0.1)
+    sw = MetricSweep(S.VEHICLE_BMW320I, 0.1, thresholds=thr, device=local, ctx=ctx)
+    traj = S.make_trajectories(M, T, 0.1, seed=20240131 + 3, ego_pos=ego[:2], ego_yaw=float(ego[2]))   # bench.py's batch, on every rank
+    dev = torch.device("cuda", local)
+    t = lambda k: torch.as_tensor(traj[k]).to(dev)
+    dev_coll = dev if args.backend == "nccl" else torch.device("cpu")
+    cg = D.CostGather(M, device=dev_coll)
+    assert (cg.world, cg.rank) == (world, rank) and (cg.lo, cg.hi) == D.shard_bounds(M, world, rank)
+    ps = PlanningStep(sm, sl, sw, t("x"), t("y"), t("theta"), t("v"), t("a"), mode="reduced", shard=cg)
+    for _ in range(3):
+        o = ps.run(ego[:2], float(ego[2]), float(ego[3]))
+    torch.cuda.synchronize()
+    per = -(-M // world)
+    assert o.rows == (min(rank * per, M), min(rank * per + per, M)) and tuple(o.cost.shape) == (o.rows[1] - o.rows[0], 16)
+    assert tuple(o.cost_all.shape) == (M, 16) and cg.calls == 3
+    cost_all = o.cost_all.cpu().numpy().copy()
+    pick = D.select_trajectory(o.cost_all)
+    n_agents = int(sl.batch.n.item())
+    # what the padding of the last block looks like before it is cut off: NaN rows behind row M of the gathered blocks
+    pad = cg.gathered[M:].cpu().numpy() if cg.collective else np.zeros((0, 16))
+    got = [None] * world
+    dist.all_gather_object(got, (pick, o.rows, n_agents, float(np.nansum(cost_all))))
+    assert len({(g[0], g[2], g[3]) for g in got}) == 1, got          # every rank: the same pick, agent count and matrix
+    if rank == 0:
+        ps1 = PlanningStep(sm, sl, sw, t("x"), t("y"), t("theta"), t("v"), t("a"), mode="reduced")
+        o1 = ps1.run(ego[:2], float(ego[2]), float(ego[3]))
+        torch.cuda.synchronize()
+        np.savez(args.out, cost_all=cost_all, ref_cost=o1.cost.cpu().numpy(), ref_safe=o1.safe.cpu().numpy(), pick=pick,
+                 ref_pick=D.select_trajectory(o1.cost), rows=np.array([g[1] for g in got]), world=world, n_agents=n_agents,
+                 pad_is_nan=bool(np.isnan(pad).all()), pad_rows=pad.shape[0], safe_col=N.COST["safe"])
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: two processes, gloo, each evaluates its trajectory shard (with the oracle standing in for the
+"""The N > 1 path on CPU: two and eight processes, gloo, each evaluates its trajectory shard (with the oracle standing in for the
 HIP sweep), one all-gather of the cost vectors -- the result must be bit-identical to the single-process evaluation."""
 import os
 import socket
@@ -43,30 +43,37 @@ def _worker(rank, world, port, M, A, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("M,A", [(101, 5), (64, 3), (1, 2)])
-def test_two_rank_shard_and_all_gather_matches_single_process(oracle, M, A):
+@pytest.mark.parametrize("M,A,world", [(101, 5, 2), (64, 3, 2), (1, 2, 2),
+                                       # BASELINE configs[3]'s rank count: an even split (8 x 10), the uneven one (the last
+                                       # block padded with NaN, ceil(81 / 8) = 11 rows per rank, rank 7 holds 4) and more
+                                       # ranks than rows (ranks 5..7 contribute padding only)
+                                       (80, 3, 8), (81, 3, 8), (5, 2, 8)])
+def test_shard_and_all_gather_matches_single_process(oracle, M, A, world):
     import torch.multiprocessing as mp
     from frenetix_occlusion import distributed as D
     from frenetix_occlusion import synthetic as S
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, M, A, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, A, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=180) for _ in range(2)]
+    got = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     traj, agents = S.make_batch(M, A, config_id=21)
     ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.3, "risk": 0.2}, want_lists=False)["cost"]
-    bounds = sorted(g[3] for g in got)
-    assert bounds[0][0] == 0 and bounds[-1][1] == M and bounds[0][1] == bounds[1][0]      # contiguous cover
+    bounds = [b for _, b in sorted((g[0], g[3]) for g in got)]                            # by rank
+    assert bounds[0][0] == 0 and bounds[-1][1] == M
+    assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))                # contiguous cover, in rank order
+    per = -(-M // world)
+    assert bounds == [(min(r * per, M), min(r * per + per, M)) for r in range(world)]
     for rank, cost, pick, _ in got:
         assert cost.shape == (M, 16)
         assert np.array_equal(cost, ref, equal_nan=True), f"rank {rank}"
     import torch
-    assert got[0][2] == got[1][2] == D.select_trajectory(torch.from_numpy(ref))
+    assert {g[2] for g in got} == {D.select_trajectory(torch.from_numpy(ref))}
 
 
 def test_shard_bounds_cover_every_row_once():

@@ -97,20 +97,20 @@ def test_world_size_one_nccl_sharded_sweep_is_bit_identical(torch_cuda, nccl_wor
         me.evaluate_batch(traj, mode="reduced", shard=D.CostGather(M + 1))
 
 
-def _run_ranks(tmp_path, world, backend, M=333):
+def _run_ranks(tmp_path, world, backend, M=333, extra=()):
     port = _free_port()
-    out = str(tmp_path / f"dist_{backend}_{world}.npz")
+    out = str(tmp_path / f"dist_{backend}_{world}_{M}.npz")
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--backend", backend,
-                                       "--M", str(M), "--out", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                                       "--M", str(M), "--out", out, *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=600)
+            o, _ = p.communicate(timeout=900)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -137,6 +137,30 @@ def _check(z, world, M):
 def test_two_ranks_on_one_gpu_shard_the_planning_step(torch_cuda, tmp_path):
     z = _run_ranks(tmp_path, 2, "gloo", M=333)
     _check(z, 2, 333)
+
+
+@pytest.mark.parametrize("M", [10000, 10001])
+def test_config3_partition_eight_ranks_on_one_gpu(torch_cuda, tmp_path, M):
+    """BASELINE configs[3]'s exact partition on the GPU this box has: the bench line's 10 000 x 256 batch on the urban grid,
+    EIGHT ranks (eight processes on the one GPU, each with its own context and HIP sweep; the collective over gloo -- RCCL
+    refuses two ranks on one device), reduced outputs, the split inside ``PlanningStep(shard=...)``: the gathered cost
+    [M, 16], the safe flags in it and the selected trajectory are bit-identical to the unsharded ``fo_step_run`` of rank 0;
+    rank 7 holds rows 8 750 - 9 999.  M = 10 001: ceil(M / 8) = 1 251 rows per block, rank 7 holds 1 244 and its block is
+    padded with NaN behind them; ``cost_all[:M]`` is clean.  What stays untested on one GPU: RCCL over xGMI with N > 1."""
+    world = 8
+    z = _run_ranks(tmp_path, world, "gloo", M=M, extra=("--config3",))
+    assert int(z["world"]) == world and int(z["n_agents"]) == 256
+    per = -(-M // world)
+    assert [tuple(r) for r in z["rows"]] == [(min(r * per, M), min(r * per + per, M)) for r in range(world)]
+    if M == 10000:
+        assert tuple(z["rows"][7]) == (8750, 10000) and int(z["pad_rows"]) == 0
+    else:
+        assert tuple(z["rows"][7]) == (8757, 10001) and int(z["pad_rows"]) == 8 * 1251 - 10001 and bool(z["pad_is_nan"])
+    assert z["cost_all"].shape == (M, 16)
+    assert np.array_equal(z["cost_all"], z["ref_cost"], equal_nan=True)                     # gathered == unsharded, bit for bit
+    assert np.array_equal(z["cost_all"][:, int(z["safe_col"])] > 0.5, z["ref_safe"].astype(bool))
+    assert 0 < int(z["ref_safe"].sum()) < M
+    assert int(z["pick"]) == int(z["ref_pick"]) >= 0
 
 
 def test_two_ranks_two_gpus_rccl(torch_cuda, tmp_path):

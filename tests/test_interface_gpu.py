@@ -452,6 +452,23 @@ def test_step_host_transfers_at_the_c_boundary(torch_cuda, tmp_path):
     assert sm._obst_dev.cpu().numpy().tobytes() == fo.fo_obstacles.packed().tobytes()
     assert np.array_equal(sm._buf["hv_host"].numpy(), sm._buf["hv"].cpu().numpy())
     assert sm._buf["hv_host"].numpy()[4 * sm.n_rays:4 * sm.n_rays + len(fo.fo_obstacles)].any()       # somebody is visible
+    # both mirror paths in one process (the knob is looked at on every call): the kernels' own posted stores (default) and the
+    # copy command behind the step (FO_STEP_MIRROR_COPY=1) leave the same bytes
+    direct = sm._buf["hv_host"].numpy().copy()
+    sm._buf["hv_host"].zero_()
+    os.environ["FO_STEP_MIRROR_COPY"] = "1"
+    try:
+        sm.stage_obstacles(fo.fo_obstacles)
+        step.run(ego0[:2], yaw, float(ego0[3]), None)
+        fo.ctx.call("fo_step_mirror_wait")
+    finally:
+        del os.environ["FO_STEP_MIRROR_COPY"]
+    assert np.array_equal(sm._buf["hv_host"].numpy(), direct) and direct[:4 * sm.n_rays].view(np.int32).max() >= 0
+    sm._buf["hv_host"].zero_()
+    sm.stage_obstacles(fo.fo_obstacles)
+    step.run(ego0[:2], yaw, float(ego0[3]), None)          # and back to the direct stores
+    fo.ctx.call("fo_step_mirror_wait")
+    assert np.array_equal(sm._buf["hv_host"].numpy(), direct)
     # rows that do not fit the staging slot: refused by the C entry ...
     big = np.zeros(70000, dtype=np.uint8)
     s.h_obstacles, s.obstacles_bytes = big.ctypes.data, big.nbytes
