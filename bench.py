@@ -402,7 +402,35 @@ def small_batch_step(local_rank, steps=300):
     kms, kn = sw.ctx.timing_read()
     sw.ctx.timing(False)
     dt, t_issue = sorted(runs)[1]
+
+    # the same step with FULL outputs in the headline list format (float64 results stored as float32): the queue kernel's
+    # horizon-split instantiation of that format (round 6) beside the generic kernel the format used to drop to at this size
+    def full_f32x(generic):
+        if generic:
+            os.environ["FO_SWEEP_GENERIC"] = "1"
+        try:
+            psf = PlanningStep(sm, sl, sw, *tr, mode="full", lists="f32x")
+            for _ in range(50):
+                psf.run(ego[:2], yaw, float(ego[3]))
+            torch.cuda.synchronize()
+            sw.ctx.timing(True, every=16)
+            t0_ = time.perf_counter()
+            for _ in range(steps):
+                psf.run(ego[:2], yaw, float(ego[3]))
+            torch.cuda.synchronize()
+            d_ = (time.perf_counter() - t0_) / steps
+            k_, n_ = sw.ctx.timing_read()
+            sw.ctx.timing(False)
+            return {"ms_per_step": d_ * 1e3, "sweep_kernel_ms": k_ / max(n_, 1), "sweep_grid": sw.ctx.last_launch()["grid"],
+                    "sweep_block": sw.ctx.last_launch()["block"]}
+        finally:
+            os.environ.pop("FO_SWEEP_GENERIC", None)
+
+    full_q, full_g = full_f32x(False), full_f32x(True)
     return {"workload": "BASELINE configs[1]: scenario1 geometry, 2000 trajectories x 32 phantom slots, T=31, reduced outputs",
+            "full_f32x": dict(full_q, what="the same step with full outputs, lists = float64 results stored as float32 (the headline "
+                                           "format): fo_sweep_queue_kernel<true, 3, true, true>, the horizon-split form",
+                              generic_kernel=full_g),
             "ms_per_step": dt * 1e3, "host_issue_ms_per_step": t_issue * 1e3, "ms_per_step_stage_calls": dt_stages * 1e3,
             "entry": "fo_step_run (one native call per planning step); ms_per_step_stage_calls = the same step as five "
                      "stage calls from Python",
@@ -942,6 +970,7 @@ def main():
             planning_steps.clear()
             torch.cuda.empty_cache()
             res["config"]["small_batch"] = small_batch_step(local_rank)
+            res["config"]["small_batch_full_f32x"] = res["config"]["small_batch"].pop("full_f32x")
             res["config"]["rules_step"] = rules_step(local_rank)
         if use_dist:   # RCCL's start-up banner sits in the C library's stdout buffer: let it out first, the JSON line last
             import ctypes

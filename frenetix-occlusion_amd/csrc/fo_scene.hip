@@ -806,16 +806,18 @@ __global__ __launch_bounds__(64 * NW) void fo_settle_kernel(
 // per-ray box culling, and a wave whose rays all miss a chunk skips it -- keeping the first hit; (3) shoelace area of
 // the polygon of hit points; (4) the cells of the current occluded set are tested against the fan (chord rule of the
 // cell-grid kernel) and counted.  Ranges never leave LDS.
-constexpr int FV_THREADS = 256;   // = maximum number of rays
+constexpr int FV_THREADS = 256;   // threads per pose; a thread walks RPT rays (tid, tid + 256, ...): RPT = ceil(n_rays / 256)
+constexpr int FV_MAX_RPT = 3;     // <= 768 rays: the 720-ray fan of BASELINE configs[2] (0.5 deg) fits (round 6; 256 before)
 constexpr int FV_BATCH = 48;      // 16-piece quarters staged in LDS at a time (24 KB)
+template <int RPT>
 __global__ __launch_bounds__(FV_THREADS) void fo_future_visibility_kernel(
     int T, const double *__restrict__ x, const double *__restrict__ y, int t_stride, int K, int n_rays,
     const double *__restrict__ dirs, double r, int E, const double *__restrict__ edges,
     const double *__restrict__ sub_box, int O, const double *__restrict__ ocorn, const uint8_t *__restrict__ oflags,
     const int32_t *__restrict__ occ_idx, const int32_t *__restrict__ n_occ_ptr, double rx0, double ry0, double cs,
     int ix0, int iy0, int nx, int32_t *__restrict__ revealed, double *__restrict__ area) {
-  __shared__ double s_dir[2 * FV_THREADS];
-  __shared__ double s_rng[FV_THREADS];
+  __shared__ double s_dir[2 * FV_THREADS * RPT];
+  __shared__ double s_rng[FV_THREADS * RPT];
   __shared__ double s_seg[FV_BATCH][64];    // 16 pieces x (ax, ay, bx, by) per staged quarter
   __shared__ float s_box[FV_BATCH][4];      // their boxes relative to the pose (float, grown by 1 mm)
   __shared__ int s_ch[FV_BATCH];
@@ -826,11 +828,19 @@ __global__ __launch_bounds__(FV_THREADS) void fo_future_visibility_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = blockIdx.x / K, k = blockIdx.x % K;
   const double px = x[(size_t)m * T + (size_t)k * t_stride], py = y[(size_t)m * T + (size_t)k * t_stride];
-  if (tid < n_rays) { s_dir[2 * tid] = dirs[2 * tid]; s_dir[2 * tid + 1] = dirs[2 * tid + 1]; }
+  for (int i = tid; i < n_rays; i += FV_THREADS) { s_dir[2 * i] = dirs[2 * i]; s_dir[2 * i + 1] = dirs[2 * i + 1]; }
   __syncthreads();
-  const bool ray = tid < n_rays;
-  const double dx = ray ? s_dir[2 * tid] : 1.0, dy = ray ? s_dir[2 * tid + 1] : 0.0;
-  double best = INFINITY;
+  // ray u of this thread: index tid + 256 u
+  bool ray[RPT];
+  double dx[RPT], dy[RPT], best[RPT];
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    const int i = tid + u * FV_THREADS;
+    ray[u] = i < n_rays;
+    dx[u] = ray[u] ? s_dir[2 * i] : 1.0;
+    dy[u] = ray[u] ? s_dir[2 * i + 1] : 0.0;
+    best[u] = INFINITY;
+  }
   // (1) + (2): the 16-piece quarters whose box lies within r of the pose are listed FV_BATCH at a time, staged in LDS
   // by the whole workgroup (one exposed round trip per batch), and every ray walks the staged list: box culling per
   // ray, 16 segment tests per surviving quarter, all operands LDS broadcasts
@@ -882,10 +892,12 @@ __global__ __launch_bounds__(FV_THREADS) void fo_future_visibility_kernel(
       }
     }
     __syncthreads();
-    if (ray) {
+#pragma unroll
+    for (int u = 0; u < RPT; ++u)
+    if (ray[u]) {
       // the ray segment [0, r d] against the staged boxes, all in pose-relative float: bounding boxes, then "all four
       // corners on one side of the ray's line" (1 mm margins; culling is conservative, it never changes a result)
-      const float fdx = (float)dx, fdy = (float)dy, fr = (float)r * 1.000001f;
+      const float fdx = (float)dx[u], fdy = (float)dy[u], fr = (float)r * 1.000001f;
       const float ex_ = fr * fdx, ey_ = fr * fdy;
       const float sx0 = fminf(0.0f, ex_) - 1e-3f, sx1 = fmaxf(0.0f, ex_) + 1e-3f;
       const float sy0 = fminf(0.0f, ey_) - 1e-3f, sy1 = fmaxf(0.0f, ey_) + 1e-3f;
@@ -900,8 +912,8 @@ __global__ __launch_bounds__(FV_THREADS) void fo_future_visibility_kernel(
         const int cnt = E - e_first < 16 ? E - e_first : 16;
         const double *buf = s_seg[q];
         for (int e = 0; e < cnt; ++e) {
-          const double t = ray_segment(px, py, dx, dy, buf[4 * e], buf[4 * e + 1], buf[4 * e + 2], buf[4 * e + 3]);
-          best = t < best ? t : best;
+          const double t = ray_segment(px, py, dx[u], dy[u], buf[4 * e], buf[4 * e + 1], buf[4 * e + 2], buf[4 * e + 3]);
+          best[u] = t < best[u] ? t : best[u];
         }
       }
     }
@@ -926,36 +938,43 @@ __global__ __launch_bounds__(FV_THREADS) void fo_future_visibility_kernel(
       }
     }
     __syncthreads();
-    if (ray) {
+#pragma unroll
+    for (int u = 0; u < RPT; ++u)
+    if (ray[u]) {
       for (int q = 0; q < s_nob; ++q) {
         const double *c = s_ob[q];
         {  // per-ray early-out: the obstacle's circumscribed circle misses the ray segment (margin as for the boxes)
           const double mx = 0.5 * (c[0] + c[4]) - px, my = 0.5 * (c[1] + c[5]) - py;
           const double hd2 = (c[0] - px - mx) * (c[0] - px - mx) + (c[1] - py - my) * (c[1] - py - my);
-          const double cr = dx * my - dy * mx, al = dx * mx + dy * my;      // offset from the line, position along it
+          const double cr = dx[u] * my - dy[u] * mx, al = dx[u] * mx + dy[u] * my;      // offset from the line, position along it
           const double lim = hd2 + 1e-6 * (1.0 + hd2);
           if (cr * cr > lim || (al < 0.0 && al * al > lim) || (al > r && (al - r) * (al - r) > lim)) continue;
         }
 #pragma unroll
         for (int sd = 0; sd < 4; ++sd) {
           const int s2 = (sd + 1) & 3;
-          const double t = ray_segment(px, py, dx, dy, c[2 * sd], c[2 * sd + 1], c[2 * s2], c[2 * s2 + 1]);
-          best = t < best ? t : best;
+          const double t = ray_segment(px, py, dx[u], dy[u], c[2 * sd], c[2 * sd + 1], c[2 * s2], c[2 * s2 + 1]);
+          best[u] = t < best[u] ? t : best[u];
         }
       }
     }
   }
-  if (!(best <= r)) best = r;
-  if (ray) s_rng[tid] = best;
-  __syncthreads();
-  // (3) shoelace area of the polygon of hit points: per-thread term, fixed-order tree sum
-  double term = 0.0;
-  if (ray) {
-    const int j = (tid + 1 == n_rays) ? 0 : tid + 1;
-    const double hix = s_rng[tid] * s_dir[2 * tid], hiy = s_rng[tid] * s_dir[2 * tid + 1];
-    const double hjx = s_rng[j] * s_dir[2 * j], hjy = s_rng[j] * s_dir[2 * j + 1];
-    term = hix * hjy - hjx * hiy;
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    if (!(best[u] <= r)) best[u] = r;
+    if (ray[u]) s_rng[tid + u * FV_THREADS] = best[u];
   }
+  __syncthreads();
+  // (3) shoelace area of the polygon of hit points: per-thread terms (its rays in ascending order), fixed-order tree sum
+  double term = 0.0;
+#pragma unroll
+  for (int u = 0; u < RPT; ++u)
+    if (ray[u]) {
+      const int i = tid + u * FV_THREADS, j = (i + 1 == n_rays) ? 0 : i + 1;
+      const double hix = s_rng[i] * s_dir[2 * i], hiy = s_rng[i] * s_dir[2 * i + 1];
+      const double hjx = s_rng[j] * s_dir[2 * j], hjy = s_rng[j] * s_dir[2 * j + 1];
+      term += hix * hjy - hjx * hiy;
+    }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) term += __shfl_xor(term, off);
   if (lane == 0) s_red[wave] = term;
@@ -1733,15 +1752,20 @@ int fo_scene_future_visibility(fo_ctx *ctx, int M, int T, const double *d_x, con
                                int32_t *d_revealed, double *d_area, void *stream) {
   if (!ctx || !ctx->scene) return fo_fail(ctx, FO_E_STATE, "fo_scene_future_visibility: call fo_scene_set_map first");
   Scene *sc = (Scene *)ctx->scene;
-  if (M < 0 || T < 1 || !d_x || !d_y || t_stride < 1 || n_rays < 4 || n_rays > FV_THREADS || !d_dirs || !(r > 0) || O < 0 ||
+  if (M < 0 || T < 1 || !d_x || !d_y || t_stride < 1 || n_rays < 4 || n_rays > FV_THREADS * FV_MAX_RPT || !d_dirs || !(r > 0) || O < 0 ||
       (O > 0 && (!d_ocorn || !d_oflags)) || !d_occ_idx || !d_n_occ || win_nx < 1 || !d_revealed || !d_area)
-    return fo_fail(ctx, FO_E_ARG, "fo_scene_future_visibility: bad arguments (4 <= n_rays <= %d)", FV_THREADS);
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_future_visibility: bad arguments (4 <= n_rays <= %d)", FV_THREADS * FV_MAX_RPT);
   if (M == 0) return FO_OK;
   FO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int K = (T + t_stride - 1) / t_stride;
-  hipLaunchKernelGGL(fo_future_visibility_kernel, dim3((unsigned)((size_t)M * K)), dim3(FV_THREADS), 0, (hipStream_t)stream,
-                     T, d_x, d_y, t_stride, K, n_rays, d_dirs, r, sc->map->E, sc->map->d_edges, sc->map->d_sub_box, O, d_ocorn,
-                     d_oflags, d_occ_idx, d_n_occ, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, d_revealed, d_area);
+  // a thread per ray up to 256 rays (the form of rounds 1-5, unchanged), two or three rays per thread beyond
+#define FO_LAUNCH_FV(RPT_)                                                                                                          \
+  hipLaunchKernelGGL(fo_future_visibility_kernel<RPT_>, dim3((unsigned)((size_t)M * K)), dim3(FV_THREADS), 0, (hipStream_t)stream, \
+                     T, d_x, d_y, t_stride, K, n_rays, d_dirs, r, sc->map->E, sc->map->d_edges, sc->map->d_sub_box, O, d_ocorn,        \
+                     d_oflags, d_occ_idx, d_n_occ, sc->map->x0, sc->map->y0, sc->map->cs, win_ix0, win_iy0, win_nx, d_revealed, d_area)
+  const int rpt = (n_rays + FV_THREADS - 1) / FV_THREADS;
+  if (rpt == 1) FO_LAUNCH_FV(1); else if (rpt == 2) FO_LAUNCH_FV(2); else FO_LAUNCH_FV(3);
+#undef FO_LAUNCH_FV
   FO_HIP_TRY(ctx, hipGetLastError());
   return FO_OK;
 }

@@ -2216,12 +2216,9 @@ template <bool ALLM, bool SPLIT>
 bool launch_queue(int lst, bool pair, dim3 g, dim3 b, hipStream_t s, const SweepArgs &a) {
   if (lst == LST_F64) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F64, ALLM, SPLIT>), g, b, 0, s, a);
   else if (lst == LST_F32) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F32, ALLM, SPLIT>), g, b, 0, s, a);
-  else if (lst == LST_F32X) {
-    // one instantiation only (the default metric set on a full grid); fo_sweep_run sends every other case to the generic
-    // kernel, which has this arithmetic anyway (float64 throughout, converted at the store)
-    if constexpr (ALLM && !SPLIT) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F32X, true, false>), g, b, 0, s, a);
-    else return false;
-  }
+  // (round 6: the headline format has every instantiation the other list formats have -- horizon-split for small batches,
+  // metric subsets -- instead of dropping to the generic kernel at the reference's own batch sizes, metric.py:125-147)
+  else if (lst == LST_F32X) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_F32X, ALLM, SPLIT>), g, b, 0, s, a);
   else if (pair) hipLaunchKernelGGL((fo_sweep_queue_kernel<true, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
   else hipLaunchKernelGGL((fo_sweep_queue_kernel<false, LST_NONE, ALLM, SPLIT>), g, b, 0, s, a);
   return true;
@@ -2407,10 +2404,6 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
   bool use_queue = !(force_generic && force_generic[0] == '1') && (!FO_DIET || T <= Ta + AGENT_PAD_ROWS - 1 || A == 0) &&
                          (size_t)(T > 1 ? T - 1 : 1) * (size_t)M * 16u < ((size_t)1 << 32);
   const int lst_mode = !d_lists ? LST_NONE : ctx->list_format == FO_LISTS_F32 ? LST_F32 : ctx->list_format == FO_LISTS_F32_EXACT ? LST_F32X : LST_F64;
-  {  // FO_LISTS_F32_EXACT has one queue-kernel instantiation (default metric set, full grid); everything else: generic kernel
-    const uint32_t all5 = FO_M_DCE | FO_M_CP | FO_M_TTC | FO_M_TTCE | FO_M_HR;
-    if (lst_mode == LST_F32X && ((ctx->mask & all5) != all5 || fo_getenv(knobs, "FO_SWEEP_ABLATE"))) use_queue = false;
-  }
   const int wpb = use_queue ? QWAVES : WAVES;  // waves per workgroup of the kernel that will run
   int apw = pick_apw(n_tiles, A, wpb);
   // a setting fo_sweep_autotune measured for this shape on this context wins over the static choice
@@ -2424,7 +2417,6 @@ int sweep_run(fo_ctx *ctx, int M, int T, const double *d_x, const double *d_y, c
   // horizon of every agent is split over the four waves of a workgroup instead (one workgroup per tile and agent).
   bool split = use_queue && T <= QWAVES * TC && (long)n_tiles * A < 3072;
   if (const char *e = fo_getenv(knobs, "FO_SWEEP_SPLIT")) split = use_queue && T <= QWAVES * TC && e[0] == '1';  // tests, A/B runs
-  if (lst_mode == LST_F32X) split = false;
   if (split) {
     // agents per workgroup of the horizon-split form, one after the other: 1.  (Measured on 2 000 x 32, 1 024 (tile, agent)
     // pairs on 768 resident workgroups: 2 / 3 / 4 agents per workgroup -- one round instead of two -- take 64 / 56 / 81 us

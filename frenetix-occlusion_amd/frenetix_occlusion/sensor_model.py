@@ -533,7 +533,7 @@ class SensorModel:
         """How much of the currently occluded area each candidate trajectory will come to see.
 
         x, y: [M, T] trajectory samples (numpy or device tensors).  From every ``t_stride``-th sample a world-aligned
-        full fan of ``n_rays`` rays (<= 256) of length ``radius`` (default: the sensor radius) is cast against the
+        full fan of ``n_rays`` rays (<= 768) of length ``radius`` (default: the sensor radius) is cast against the
         static map and the obstacles of the last ``upload_obstacles``; returns device tensors
         ``revealed [M, K]`` (int32: cells of the occluded set of the last ``launch`` that lie inside that fan) and
         ``area [M, K]`` (float64: area of the polygon of hit points), K = ceil(T / t_stride).  Queued on the current

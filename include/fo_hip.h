@@ -233,7 +233,7 @@ int fo_scene_visibility(fo_ctx *ctx, double ego_x, double ego_y, double head_x, 
 
 /* EXTENSION, not part of the reference: how much of the currently occluded area each candidate trajectory
  * will come to see.  d_x / d_y [M][T] as for fo_sweep_run; pose (m, k) = sample k * t_stride, K = ceil(T / t_stride).
- * From every pose a full fan of n_rays (<= 256) rays of length r along d_dirs [n_rays][2] (world-aligned, counter-
+ * From every pose a full fan of n_rays (<= 768: the 720-ray fan of the visibility stage fits) rays of length r along d_dirs [n_rays][2] (world-aligned, counter-
  * clockwise, e.g. fo_scene_fan with yaw 0) is cast against the static map and the obstacles where they stand now
  * (d_ocorn / d_oflags as for fo_scene_visibility).  d_revealed [M][K] = number of cells of the current occluded set
  * (d_occ_idx / d_n_occ and the window of the fo_scene_visibility call that produced them) whose centre lies within r

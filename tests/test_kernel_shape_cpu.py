@@ -29,9 +29,9 @@ def test_sweep_kernel_register_and_lds_budgets(tmp_path):
             f = re.search(r"queue_kernelILb(\d)ELi(\d)ELb(\d)ELb(\d)E", m.group(2))
             pair, lists, allm, split = f.group(1) == "1", int(f.group(2)), f.group(3) == "1", f.group(4) == "1"
             seen[(pair, lists, allm, split)] = (int(m.group(1)), int(m.group(3)))
-    # (float64 lists, float32 lists, pair scalars, reduced) x (all metrics, subset) x (split, not) + the one instantiation
-    # with float32 storage of float64 list entries (FO_LISTS_F32_EXACT: default metric set, full grid)
-    assert len(seen) == 17 and (True, 3, True, False) in seen
+    # (float64 lists, float32 lists, float32 storage of float64 list entries -- FO_LISTS_F32_EXACT, the headline format, which
+    # has every form the others have since round 6 --, pair scalars, reduced) x (all metrics, subset) x (split, not)
+    assert len(seen) == 20 and all((True, 3, allm, split) in seen for allm in (False, True) for split in (False, True))
     for (pair, lists, allm, split), (lds, vgpr) in seen.items():
         assert vgpr <= 168 and 3 * lds <= 160 * 1024, (pair, lists, allm, split, lds, vgpr)
 

@@ -38,7 +38,7 @@ def _hip_sweep(torch, traj, agents, veh, dt, metrics=None, thr=None, mode="full"
                   agents["type"], agents["len"])
     out = sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], traj.get("a"), mode=mode, lists=lists)
     torch.cuda.synchronize()
-    res = {"cost": out.cost.cpu().numpy(), "safe": out.safe.cpu().numpy()}
+    res = {"cost": out.cost.cpu().numpy(), "safe": out.safe.cpu().numpy(), "launch": sw.ctx.last_launch()}
     if out.pair_f is not None:
         res["pair_f"] = out.pair_f.permute(2, 1, 0).cpu().numpy()   # -> [M,A,NPF] (oracle layout)
         res["pair_i"] = out.pair_i.permute(2, 1, 0).cpu().numpy()
@@ -260,33 +260,54 @@ def _assert_rounded_float64(got32, want64, tol=1e-9):
     return float(np.mean(got32[f] != want64[f].astype(np.float32)))
 
 
-@pytest.mark.parametrize("M,A,cfg", [(300, 16, 1), (2000, 32, 2), (70, 9, 8)])
+@pytest.mark.parametrize("M,A,cfg", [(300, 16, 1), (2000, 32, 2), (70, 9, 8), (3300, 64, 3)])
 def test_float32_exact_lists_are_the_float64_lists_rounded(torch_cuda, oracle, monkeypatch, M, A, cfg):
-    """fo_sweep_set_list_format(FO_LISTS_F32_EXACT) / lists='f32x': float32 storage of the float64 results -- every list entry
-    equals the float64-list mode's entry rounded to float32 (the queue kernel's instantiation for the default metric set; a
-    metric subset goes through the generic kernel, which converts at the store as well), everything else bit-identical; and
-    against the oracle every entry is a float64 value within 1e-9 of the oracle's, rounded to float32"""
+    """fo_sweep_set_list_format(FO_LISTS_F32_EXACT) / lists='f32x' -- the format bench.py's headline runs: float32 storage of
+    the float64 results.  Every list entry equals the float64-list mode's entry rounded to float32, everything else is
+    bit-identical, and against the oracle every entry is a float64 value within 1e-9 of the oracle's, rounded to float32 --
+    in EVERY form of the queue kernel (round 6: the format has all the instantiations of the other formats): the full grid
+    (3 300 x 64 and, forced, the small ones), the horizon-split form small batches take by themselves (2 000 x 32 = BASELINE
+    configs[1]'s shape), a metric subset such as the reference's configs[0] (['hr', 'ttc'], metric.py:125-147), and both at
+    once; the generic kernel (FO_SWEEP_GENERIC=1) stays the same arithmetic converted at the store."""
     from frenetix_occlusion import synthetic as S
     traj, agents = S.make_batch(M, A, config_id=cfg)
     if cfg == 8:
         agents["len"] = np.array([31, 1, 2, 30, 17, 31, 5, 29, 0], dtype=np.int32)
     thr = {"harm": 0.3, "risk": 0.2, "ttc": 1.0, "dce": 0.05, "cp": 0.8}
-    g64 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr)
-    gx = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, lists="f32x")
-    assert gx["lists"].dtype == np.float32
-    for k in ("cost", "safe", "pair_i"):
-        assert np.array_equal(gx[k], g64[k]), k
-    assert np.array_equal(gx["pair_f"], g64["pair_f"], equal_nan=True)
-    assert np.array_equal(gx["lists"], g64["lists"].astype(np.float32), equal_nan=True)
     ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, nthreads=8)
-    _assert_rounded_float64(gx["lists"], ref["lists"], tol=1e-9)
-    # metric subset -> generic kernel: against the oracle
-    ref = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
-    gxs = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32x")
-    monkeypatch.setenv("FO_SWEEP_GENERIC", "1")    # (its float64 twin: the generic kernel with float64 lists)
-    g64s = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
-    _compare_f32_lists(ref["lists"], gxs, g64s)
-    assert np.array_equal(gxs["lists"], g64s["lists"].astype(np.float32), equal_nan=True)
+    ref_sub = oracle.sweep(traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), nthreads=8)
+    seen = set()
+    for split in (None, "1", "0"):            # the library's own choice, then both forms forced
+        if split is None:
+            monkeypatch.delenv("FO_SWEEP_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("FO_SWEEP_SPLIT", split)
+        g64 = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr)
+        gx = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr=thr, lists="f32x")
+        assert gx["lists"].dtype == np.float32
+        for k in ("cost", "safe", "pair_i"):
+            assert np.array_equal(gx[k], g64[k]), (split, k)
+        assert np.array_equal(gx["pair_f"], g64["pair_f"], equal_nan=True)
+        assert np.array_equal(gx["lists"], g64["lists"].astype(np.float32), equal_nan=True), split
+        _assert_rounded_float64(gx["lists"], ref["lists"], tol=1e-9)
+        # metric subset: the queue kernel's instantiation without the compile-time metric set, float64 twin of the same form
+        g64s = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
+        gxs = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32x")
+        for k in ("cost", "safe", "pair_i"):
+            assert np.array_equal(gxs[k], g64s[k]), (split, k)
+        assert np.array_equal(gxs["pair_f"], g64s["pair_f"], equal_nan=True)
+        assert np.array_equal(gxs["lists"], g64s["lists"].astype(np.float32), equal_nan=True), split
+        _assert_rounded_float64(gxs["lists"], ref_sub["lists"], tol=1e-9)
+        seen.add((gx["launch"]["grid"], gxs["launch"]["grid"]))
+        assert gx["launch"] == g64["launch"] and gxs["launch"] == g64s["launch"]      # the same form for both formats
+    assert len(seen) == 2       # the two forms really are two launches (split: one workgroup per (tile, agent))
+    # the generic kernel: the same arithmetic from libm, converted at the store
+    monkeypatch.delenv("FO_SWEEP_SPLIT", raising=False)
+    monkeypatch.setenv("FO_SWEEP_GENERIC", "1")
+    g64g = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"))
+    gxg = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, metrics=("hr", "ttc"), lists="f32x")
+    _compare_f32_lists(ref_sub["lists"], gxg, g64g)
+    assert np.array_equal(gxg["lists"], g64g["lists"].astype(np.float32), equal_nan=True)
 
 
 def test_autotune_measures_and_keeps_a_setting_without_changing_results(torch_cuda):
@@ -768,6 +789,11 @@ def test_horizon_split_variant_is_bit_identical(torch_cuda, monkeypatch):
             red = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.2, "risk": 0.1, "ttc": 1.0},
                              mode="reduced")
             assert np.array_equal(red["cost"], outs[-1]["cost"], equal_nan=True) and np.array_equal(red["safe"], outs[-1]["safe"])
+            if per_wg == "1":      # the headline list format (float64 results stored as float32) in both forms: the float64 lists, rounded
+                gx = _hip_sweep(torch_cuda, traj, agents, S.VEHICLE_BMW320I, 0.1, thr={"harm": 0.2, "risk": 0.1, "ttc": 1.0}, lists="f32x")
+                for k in ("cost", "safe", "pair_f", "pair_i"):
+                    assert np.array_equal(gx[k], outs[-1][k], equal_nan=True), (M, A, T, flag, k)
+                assert np.array_equal(gx["lists"], outs[-1]["lists"].astype(np.float32), equal_nan=True), (M, A, T, flag)
         for o in outs[1:]:
             for k in ("cost", "safe", "pair_f", "pair_i", "lists"):
                 assert np.array_equal(outs[0][k], o[k], equal_nan=True), (M, A, T, k)
