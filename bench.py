@@ -439,6 +439,32 @@ def small_batch_step(local_rank, steps=300):
             "sweep_grid": sw.ctx.last_launch()["grid"]}
 
 
+def future_visibility_leg(scene, tx, ty, n=5):
+    """SURVEY 8f-2 (an extension: the reference never fills its `occ_*` cost terms): for the headline batch on the urban grid,
+    every 5th sample of every candidate (10 000 x 7 poses) casts the visibility stage's own 720-ray fan against the static
+    map + obstacles and counts the cells of the CURRENT occluded set it would reveal; HIP events around n calls."""
+    import torch
+    sm = scene["sm"]
+    out = {}
+    for rays in (720, 192):
+        sm.future_visibility(tx, ty, t_stride=5, n_rays=rays)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            rev, area = sm.future_visibility(tx, ty, t_stride=5, n_rays=rays)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        M, K = int(tx.shape[0]), int(rev.shape[1])
+        out[f"rays{rays}"] = {"ms": ms, "poses": M * K, "poses_per_sec": M * K / ms * 1e3, "rays_per_sec": M * K * rays / ms * 1e3,
+                              "mean_revealed_last_pose": float(rev[:, -1].double().mean())}
+    out["what"] = ("fo_scene_future_visibility (extension, SURVEY 8f-2): 10 000 trajectories x 7 poses (t_stride 5), a world-aligned full "
+                   "fan per pose against 9 360 boundary pieces + 64 obstacles, revealed cells of the current occluded set "
+                   f"({int(sm.n_occluded.item())} cells) by the chord rule; 720 rays = the visibility stage's fan, 192 = the round-1 figure")
+    return out
+
+
 def rules_step(local_rank, steps=60):
     """The reference's own spawn semantics as a device-resident planning step (fo_step_run, spawn_mode FO_SPAWN_RULES): scenario1
     geometry, 2 000 candidates, the three rule families of spawn_locator.py:145-578 on the cell classes -> their spawn points
@@ -966,6 +992,7 @@ def main():
             res["config"]["f32_lists"]["what"] = ("the harm list entries away from the 5 m gate in float32 ARITHMETIC (FO_LISTS_F32: narrower than the "
                                                   "reference's float64, |error| < 4e-7): what that shortcut would buy against the headline")
             res["config"]["reduced_outputs"] = side("reduced", args.lists)
+            res["config"]["future_visibility"] = future_visibility_leg(scene, tx, ty)
             res["config"]["shard_probe"] = shard_probe(scene, sw, (tx, ty, tth, tv, ta), local_rank, N)
             planning_steps.clear()
             torch.cuda.empty_cache()

@@ -65,8 +65,28 @@ def test_city_grid_and_odd_sizes(torch_cuda, oracle):
     from frenetix_occlusion import scenario as S
     sc = S.synthetic_urban_grid()
     _check(torch_cuda, oracle, sc, sc.ego_initial, 24, 7, 97, seed=11)      # K = 5, odd ray count
-    rev, area, sm, traj = _check(torch_cuda, oracle, sc, sc.ego_initial, 16, 31, 256, seed=12)   # K = 1, max rays
+    rev, area, sm, traj = _check(torch_cuda, oracle, sc, sc.ego_initial, 16, 31, 256, seed=12)   # K = 1, a thread per ray
     assert rev.shape[1] == 1
+
+
+@pytest.mark.parametrize("n_rays", [720, 257, 512, 513, 768])
+def test_the_720_ray_fan_of_the_visibility_stage(torch_cuda, oracle, n_rays):
+    """SURVEY 8f-2 speaks of the 720-ray fan (0.5 deg, BASELINE configs[2]): two or three rays per thread beyond 256 -- counts
+    bit-exact against the brute-force restatement at 720 rays on the city grid and scenario 1, the edges of the two- and
+    three-ray forms (257, 512, 513, 768), and one ray more is refused"""
+    from frenetix_occlusion import scenario as S
+    sc = S.synthetic_urban_grid()
+    rev, area, sm, traj = _check(torch_cuda, oracle, sc, sc.ego_initial, 20, 6, n_rays, seed=13)
+    assert rev.max() > 0
+    if n_rays == 720:
+        sc1 = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+        rev1, _, sm1, _ = _check(torch_cuda, oracle, sc1, sc1.ego_initial, 40, 5, 720, seed=7)
+        # from the ego pose with the stage's own 720 rays next to nothing of the occluded set is seen (chord rule, no
+        # settlement: a handful of cells at shadow edges)
+        assert rev1[0, 0] <= 0.02 * len(sm1.occluded_cells())
+    if n_rays == 768:
+        with pytest.raises(RuntimeError):
+            sm.future_visibility(traj["x"], traj["y"], t_stride=6, n_rays=769)
 
 
 def test_interface_entry_and_empty_batch(torch_cuda, tmp_path):

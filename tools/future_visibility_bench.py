@@ -22,7 +22,7 @@ def main():
     dev = sm.device
     tx, ty = torch.as_tensor(traj["x"]).to(dev), torch.as_tensor(traj["y"]).to(dev)
     n_occ = int(sm.n_occluded.item())
-    for stride, rays in ((5, 192), (10, 192), (5, 96), (1, 192)):
+    for stride, rays in ((5, 192), (5, 720), (10, 192), (5, 96), (5, 256), (5, 384), (1, 192)):
         sm.future_visibility(tx, ty, t_stride=stride, n_rays=rays)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

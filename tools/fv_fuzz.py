@@ -41,7 +41,7 @@ def main():
         M = int(rng.choice([1, 3, 17, 64]))
         T = int(rng.choice([2, 11, 31]))
         stride = int(rng.choice([1, 3, 5, 40]))
-        n_rays = int(rng.choice([4, 5, 64, 97, 192, 255, 256]))
+        n_rays = int(rng.choice([4, 5, 64, 97, 192, 255, 256, 257, 360, 511, 720, 768]))
         traj = SY.make_trajectories(M, T, 0.1, seed=int(rng.integers(1 << 30)), ego_pos=pos, ego_yaw=yaw)
         rev, area = sm.future_visibility(traj["x"], traj["y"], t_stride=stride, n_rays=n_rays)
         torch.cuda.synchronize()
