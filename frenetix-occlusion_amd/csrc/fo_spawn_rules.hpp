@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifndef FO_RULE_RUNS
+#define FO_RULE_RUNS 1    // 0: tuning / test builds -- the dynamic rule's connected parts on the lattice nodes (rounds 4-5) instead of on the row runs
+#endif
 #ifndef FO_RULE_TRACE
 #define FO_RULE_TRACE 0
 #endif
@@ -112,20 +115,38 @@ __device__ inline bool rl_lane_yaw_at(const RuleView &v, double x, double y, dou
   return yaw == yaw;
 }
 
-// crossing-number test, the rule of the road raster (half-open in y)
+// crossing-number test, the rule of the road raster (half-open in y).
+// rl_crossing_parity: vertices b .. e-1 of one ring through `get(k)`; the edge arithmetic of the plain loop (xc = xi + (y - yi)
+// (xj - xi) / (yj - yi) on the edges that straddle y), with the vertices fetched EIGHT at a time in front of their tests: the
+// loop used to be a chain of dependent round trips -- a load, a test, a branch per vertex, ~30 of them per lanelet polygon at
+// 0.2-0.5 us each from the L2 -- and every "which lanelet holds this point" of the rule families waited for it (round 6)
+template <class GET>
+__device__ __forceinline__ int rl_crossing_parity(int b, int e, double x, double y, GET get) {
+  int c = 0;
+  double2 pj = get(e - 1);
+  for (int i0 = b; i0 < e; i0 += 8) {
+    double2 pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pv[u] = get(i0 + u < e ? i0 + u : e - 1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < e) {
+        const double xi = pv[u].x, yi = pv[u].y, xj = pj.x, yj = pj.y;
+        if ((yi > y) != (yj > y)) {
+          const double xc = xi + (y - yi) * (xj - xi) / (yj - yi);
+          if (x < xc) c ^= 1;
+        }
+        pj = pv[u];
+      }
+  }
+  return c;
+}
 __device__ inline bool rl_in_polygon(const RuleView &v, int p, double x, double y) {
   const double *bb = v.poly_box + 4 * (size_t)p;
   if (x < bb[0] || x > bb[2] || y < bb[1] || y > bb[3]) return false;
   const int b = v.poly_off[p], e = v.poly_off[p + 1];
-  int c = 0;
-  for (int i = b, j = e - 1; i < e; j = i++) {
-    const double xi = v.poly_xy[2 * i], yi = v.poly_xy[2 * i + 1], xj = v.poly_xy[2 * j], yj = v.poly_xy[2 * j + 1];
-    if ((yi > y) != (yj > y)) {
-      const double xc = xi + (y - yi) * (xj - xi) / (yj - yi);
-      if (x < xc) c ^= 1;
-    }
-  }
-  return c != 0;
+  const double2 *xy = (const double2 *)v.poly_xy;
+  return rl_crossing_parity(b, e, x, y, [&](int k) { return xy[k]; }) != 0;
 }
 __device__ inline int rl_lanelet_of(const RuleView &v, double x, double y) {   // first lanelet (list order) holding the point
   for (int p = 0; p < v.P; ++p)
@@ -498,6 +519,7 @@ __device__ __forceinline__ void rl_static_rule(const RuleView &v, const RulePara
 
 // ---------------------------------------------------------------- Car / Bicycle behind a dynamic obstacle (a workgroup)
 struct RlFit { double area, cx, cy, jac; bool any; };
+constexpr int RL_THREADS_DYN = 1024;   // threads of the workgroup that runs the rule (= RL_THREADS below)
 
 // rec: [0] distance, [1] role = 2, [2] car valid, [3] car x, [4] car y, [5] bicycle valid, [6] x, [7] y
 __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RuleParams &pr, int o, const double *ocorn, const double *ocen,
@@ -507,7 +529,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   const double cx = ocen[2 * o], cy = ocen[2 * o + 1], oy = oyaw[o], olen = odims[2 * o], owid = odims[2 * o + 1];
   const double *oc = ocorn + 8 * (size_t)o;
   __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn, s_ego_ll, s_inter, s_nin, s_in[16], s_vll[64], s_relc, s_curv_ok;
-  __shared__ int s_poff[9], s_plds;
+  __shared__ int s_poff[9], s_plds, s_inter_first;
   __shared__ double s_c[2], s_yaw, s_pbox[32], s_obsd[2];
   // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
   // oncoming neighbours (adj_left) of the lanelets under every fifth vertex of the reference window.  Flags per lanelet
@@ -518,10 +540,13 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   for (int p = tid; p < v.P; p += nth) ired[p] = 0;
   if (tid == 0) {
     rec[2] = 0.0; rec[5] = 0.0;
-    s_go = 0; s_npol = 0; s_inter = -1; s_ego_ll = 0x7fffffff; s_nin = 0; s_relc = 0; s_curv_ok = 0;
+    s_go = 0; s_npol = 0; s_inter = -1; s_inter_first = 0x7fffffff; s_ego_ll = 0x7fffffff; s_nin = 0; s_relc = 0; s_curv_ok = 0;
   }
   if (tid < 64) s_vll[tid] = 0x7fffffff;
   __syncthreads();
+  // (measured and dropped, round 6: the lanelets under every fifth vertex of the reference window -- needed when the ego turns
+  // out to be in no intersection, two barriers further down -- asked in this same pass: +4 us in front of the lattice where
+  // there IS an intersection, the usual case of the rule)
   for (int p = tid; p < v.P; p += nth) {
     if (rl_in_polygon(v, p, pr.ego_x, pr.ego_y)) atomicMin(&s_ego_ll, p);
     if (rl_in_polygon(v, p, cx, cy)) {   // the obstacle's lanelets (also flagged: more than sixteen are re-collected in list order below)
@@ -537,10 +562,19 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   }
   __syncthreads();
   if (s_ego_ll == 0x7fffffff) return;
-  if (tid == 0)
-    for (int it = 0; it < v.n_inter && s_inter < 0; ++it)
-      for (int e = v.inter_off[it]; e < v.inter_off[it + 1]; ++e)
-        if (v.inter_lanelet[e] == s_ego_ll) { s_inter = it; break; }
+  // the first intersection (list order) that lists the ego's lanelet: a thread per table entry and an atomicMin on the
+  // intersection's index (one thread walking the table was a chain of dependent loads)
+  {
+    const int n_ent = v.n_inter > 0 ? v.inter_off[v.n_inter] : 0;
+    for (int e = tid; e < n_ent; e += nth)
+      if (v.inter_lanelet[e] == s_ego_ll) {
+        int it = 0;
+        while (it + 1 < v.n_inter && v.inter_off[it + 1] <= e) ++it;
+        atomicMin(&s_inter_first, it);
+      }
+  }
+  __syncthreads();
+  if (tid == 0) s_inter = s_inter_first == 0x7fffffff ? -1 : s_inter_first;
   __syncthreads();
   if (s_inter >= 0) {
     for (int e = v.inter_off[s_inter] + tid; e < v.inter_off[s_inter + 1]; e += nth) {
@@ -549,8 +583,8 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     }
   } else if (v.adj_left) {
     const int nv = min((pr.win_i1 - pr.win_i0 + 4) / 5, 64);   // every fifth vertex of the reference window (40 m: a dozen)
-    for (long long w = tid; w < (long long)nv * v.P; w += nth) {
-      const int vi = (int)(w / v.P), p = (int)(w % v.P);
+    for (unsigned w = tid; w < (unsigned)nv * (unsigned)v.P; w += nth) {   // (<= 64 x 9 409 pairs: 32-bit index arithmetic)
+      const int vi = (int)(w / (unsigned)v.P), p = (int)(w - (unsigned)vi * (unsigned)v.P);
       const double *q = v.path + 6 * (size_t)(pr.win_i0 + 5 * vi);
       if (rl_in_polygon(v, p, q[0], q[1])) atomicMin(&s_vll[vi], p);
     }
@@ -626,10 +660,14 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   // returns 0 (not a member) or 1 + the slot of a candidate polygon that holds the point; `hint`: the slot asked first
   auto member_idx = [&](double x, double y, int hint) -> int {
     const double rx = x - cx, ry = y - cy;
-    if (!(sqrt(rx * rx + ry * ry) <= RL_BUFFER_SIDE)) return 0;
+    // sqrt(d2) <= 12 exactly when d2 <= 144: the midpoint between 12 and the next double squares to 144 + 2.1e-14, below the
+    // double that follows 144 (144 + 2.8e-14) -- no square root needed
+    static_assert(RL_BUFFER_SIDE == 12.0, "the squared form of the distance test is derived for 12 m");
+    if (!(rx * rx + ry * ry <= 144.0)) return 0;
     const double lx_ = oc_c * rx + oc_s * ry, ly_ = -oc_s * rx + oc_c * ry;
     const double ex_ = fmax(fabs(lx_) - olen / 2.0, 0.0), ey_ = fmax(fabs(ly_) - owid / 2.0, 0.0);
-    if (!(sqrt(ex_ * ex_ + ey_ * ey_) > 1.0)) return 0;                           // minus the obstacle grown by 1 m
+    // minus the obstacle grown by 1 m: sqrt(e2) > 1 exactly when e2 > 1 + 2^-52 (sqrt(1 + 2^-52) = 1 + 2^-53 - ... rounds to 1)
+    if (!(ex_ * ex_ + ey_ * ey_ > 1.0000000000000002)) return 0;
     if (wedge) {   // the obstacle's own shadow: the sight line ego -> point crosses the rectangle (:264)
       bool hit = false;
       const double dx = x - pr.ego_x, dy = y - pr.ego_y;
@@ -658,16 +696,8 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       }
       const double *bb = s_pbox + 4 * i;            // rl_in_polygon on the copy in LDS (the same arithmetic)
       if (x < bb[0] || x > bb[2] || y < bb[1] || y > bb[3]) continue;
-      const int b0 = s_poff[i], e0 = s_poff[i + 1];
-      int c = 0;
-      for (int k = b0, j = e0 - 1; k < e0; j = k++) {
-        const double xi = polyv[2 * k], yi = polyv[2 * k + 1], xj = polyv[2 * j], yj = polyv[2 * j + 1];
-        if ((yi > y) != (yj > y)) {
-          const double xc = xi + (y - yi) * (xj - xi) / (yj - yi);
-          if (x < xc) c ^= 1;
-        }
-      }
-      if (c != 0) return i + 1;
+      const double2 *pv2 = (const double2 *)polyv;
+      if (rl_crossing_parity(s_poff[i], s_poff[i + 1], x, y, [&](int k) { return pv2[k]; }) != 0) return i + 1;
     }
     return 0;
   };
@@ -698,6 +728,141 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   }
   __syncthreads();
   RL_TICK(1);
+  // connected parts (4-neighbourhood, scipy.ndimage.label's default), their sizes and the largest one (first maximum in label
+  // order, :279-281).  Round 6: on the RUNS of the lattice rows (maximal stretches of member nodes in a row: a few per row, a
+  // couple of hundred in all) instead of on its 9 409 nodes -- the sixteen waves cut the rows into runs with two ballots per
+  // row, ONE wave then labels the runs by the same label equivalence as before (a run's label = its index, runs are numbered
+  // row-major, so the smallest index of a part is the run that holds the part's smallest linear node index = scipy's numbering
+  // order; runs of neighbouring rows touch where their column intervals overlap), adds up the run lengths per root and picks
+  // the largest part; the nodes of that part are then stamped with its label.  A wave's LDS traffic is ordered: its rounds need
+  // no workgroup barrier, where the node form paid three barriers of sixteen waves per round and two more passes over the
+  // lattice for the sizes (7.8 + 8.5 us -> see DESIGN section 5).  More runs than the arrays hold: the node form below.
+  constexpr int RL_MAXRUN = 3072;
+  int *run_rec = ired, *run_lab = ired + RL_MAXRUN, *run_size = ired + 2 * RL_MAXRUN;   // (ired: 9 409 ints)
+  __shared__ int s_rowoff[RL_LAT + 1], s_nrun;
+  __shared__ unsigned long long s_rowbits[RL_LAT][2];
+  bool by_runs = FO_RULE_RUNS != 0;
+  if (by_runs) {
+    const int wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
+    for (int r = wave; r < RL_LAT; r += nw) {
+      const unsigned long long b0 = __ballot(lab[r * RL_LAT + lane] != 0x7fffffff);
+      const unsigned long long b1 = __ballot(lane < RL_LAT - 64 && lab[r * RL_LAT + 64 + (lane < RL_LAT - 64 ? lane : 0)] != 0x7fffffff);
+      if (lane == 0) {
+        const unsigned long long s0 = b0 & ~(b0 << 1), s1 = b1 & ~((b1 << 1) | (b0 >> 63));
+        s_rowbits[r][0] = b0; s_rowbits[r][1] = b1;
+        s_rowoff[r + 1] = __popcll(s0) + __popcll(s1);
+      }
+    }
+    if (tid == 0) s_rowoff[0] = 0;
+    __syncthreads();
+    if (tid < 64) {   // inclusive prefix of the row counts (97 rows: two per lane)
+      const int r0 = 2 * tid + 1, r1 = 2 * tid + 2;
+      const int c0 = r0 <= RL_LAT ? s_rowoff[r0] : 0, c1 = r1 <= RL_LAT ? s_rowoff[r1] : 0;
+      int incl = c0 + c1;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (tid >= off) incl += t; }
+      if (r0 <= RL_LAT) s_rowoff[r0] = incl - c1;
+      if (r1 <= RL_LAT) s_rowoff[r1] = incl;
+      if (tid == 63) s_nrun = incl;
+    }
+    __syncthreads();
+    by_runs = s_nrun <= RL_MAXRUN;   // (uniform)
+  }
+  if (by_runs) {
+    const int wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
+    const int NR = s_nrun;
+    for (int r = wave; r < RL_LAT; r += nw) {   // the runs of row r: a lane per start column
+      const unsigned long long b0 = s_rowbits[r][0], b1 = s_rowbits[r][1];
+      const unsigned long long s0 = b0 & ~(b0 << 1), s1 = b1 & ~((b1 << 1) | (b0 >> 63));
+      const int base = s_rowoff[r];
+      if ((s0 >> lane) & 1ull) {
+        const unsigned long long z = ~(b0 >> lane);          // first column past the run, relative to `lane`
+        int len = z ? __builtin_ctzll(z) : 64;
+        if (lane + len == 64) len += b1 == ~0ull ? 64 : __builtin_ctzll(~b1);   // (the run goes on in the second word)
+        const int idx = base + __popcll(s0 & ((1ull << lane) - 1ull));
+        run_rec[idx] = (r << 16) | (lane << 8) | (lane + len - 1);
+        run_lab[idx] = idx;
+        run_size[idx] = 0;
+      }
+      if ((s1 >> lane) & 1ull) {
+        const int len = __builtin_ctzll(~(b1 >> lane));
+        const int idx = base + __popcll(s0) + __popcll(s1 & ((1ull << lane) - 1ull));
+        run_rec[idx] = (r << 16) | ((64 + lane) << 8) | (64 + lane + len - 1);
+        run_lab[idx] = idx;
+        run_size[idx] = 0;
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {   // wave 0 alone: label equivalence on the runs, sizes, the largest part
+      for (int round = 0; round < 4096; ++round) {
+        bool ch = false;
+        for (int i = lane; i < NR; i += 64) {
+          const int rec_ = run_rec[i], r = rec_ >> 16, c0 = (rec_ >> 8) & 255, c1 = rec_ & 255;
+          const int l = run_lab[i];
+          int m = l;
+          if (r > 0)
+            for (int j = s_rowoff[r - 1]; j < s_rowoff[r]; ++j) {
+              const int q = run_rec[j];
+              if (((q >> 8) & 255) <= c1 && (q & 255) >= c0) m = min(m, run_lab[j]);
+            }
+          if (r + 1 < RL_LAT)
+            for (int j = s_rowoff[r + 1]; j < s_rowoff[r + 2]; ++j) {
+              const int q = run_rec[j];
+              if (((q >> 8) & 255) <= c1 && (q & 255) >= c0) m = min(m, run_lab[j]);
+            }
+          if (m < l) { atomicMin(&run_lab[l], m); ch = true; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int i = lane; i < NR; i += 64) {
+          int r0 = run_lab[i];
+          while (true) {
+            const int q = run_lab[r0];
+            if (q == r0) break;
+            r0 = q;
+          }
+          run_lab[i] = r0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (!__ballot(ch)) break;
+      }
+      for (int i = lane; i < NR; i += 64) {
+        const int rec_ = run_rec[i];
+        atomicAdd(&run_size[run_lab[i]], (rec_ & 255) - ((rec_ >> 8) & 255) + 1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // the largest part, the smallest label among equals: (size, -index) as one 64-bit key
+      unsigned long long key = 0ull;
+      for (int i = lane; i < NR; i += 64)
+        if (run_lab[i] == i) {
+          const unsigned long long k_ = ((unsigned long long)(unsigned)run_size[i] << 32) | (unsigned)(0x7fffffff - i);
+          key = k_ > key ? k_ : key;
+        }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o_ = __shfl_xor(key, off);
+        key = o_ > key ? o_ : key;
+      }
+      if (tid == 0) {
+        if (key >> 32) {
+          const int bi = 0x7fffffff - (int)(unsigned)(key & 0xffffffffull), rec_ = run_rec[bi];
+          s_bestn = (int)(key >> 32);
+          s_best = (rec_ >> 16) * RL_LAT + ((rec_ >> 8) & 255);   // the part's smallest linear node index = its label
+          s_changed = bi;                                          // (the root run, for the stamping below)
+        } else { s_bestn = 0; s_best = -1; s_changed = -1; }
+      }
+    }
+    __syncthreads();
+    RL_TICK(2);
+    {   // stamp the nodes of the largest part (every other member node keeps its own index, which is not the part's label)
+      const int root = s_changed, bl = s_best;
+      for (int i = tid; i < NR; i += nth)
+        if (run_lab[i] == root) {
+          const int rec_ = run_rec[i], r = rec_ >> 16;
+          for (int c = (rec_ >> 8) & 255; c <= (rec_ & 255); ++c) lab[r * RL_LAT + c] = bl;
+        }
+    }
+    __syncthreads();
+  } else {
   // connected parts (4-neighbourhood, scipy.ndimage.label's default) by label equivalence (Hawick et al.): every member node
   // starts as its own root (label = linear index); a round links the root of every node whose neighbourhood holds a smaller
   // label to that label (atomicMin), then flattens every node to its root by pointer jumping; labels only ever decrease
@@ -776,9 +941,21 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       }
     __syncthreads();
   }
+  }
   const int best = s_best;
   if (best < 0 || (double)s_bestn * h * h < RL_MIN_AREA) return;                  // :282-284
   RL_TICK(3);
+  // (the polygon slot that held each lattice node -- the hint of member_idx, for the fits -- is asked for here, under the
+  // centroid's arithmetic, and parked in `ired`, which is free from here on)
+  int hint_w[(RL_LAT * RL_LAT + RL_THREADS_DYN - 1) / RL_THREADS_DYN];
+  {
+    const volatile int *gl = g_lab;
+#pragma unroll
+    for (int u = 0; u < (RL_LAT * RL_LAT + RL_THREADS_DYN - 1) / RL_THREADS_DYN; ++u) {
+      const int i = tid + u * RL_THREADS_DYN;
+      hint_w[u] = i < NL ? gl[i] : 0x7fffffff;
+    }
+  }
   // centroid of the part (mean of its nodes; fixed summation order: per-thread partials, then thread 0)
   double ax = 0.0, ay = 0.0;
   for (int i = tid; i < NL; i += nth)
@@ -787,6 +964,11 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { ax += __shfl_xor(ax, off); ay += __shfl_xor(ay, off); }
   if ((tid & 63) == 0) { red[2 * (tid >> 6)] = ax; red[2 * (tid >> 6) + 1] = ay; }
+#pragma unroll
+  for (int u = 0; u < (RL_LAT * RL_LAT + RL_THREADS_DYN - 1) / RL_THREADS_DYN; ++u) {
+    const int i = tid + u * RL_THREADS_DYN;
+    if (i < NL) ired[i] = hint_w[u] == 0x7fffffff ? 0 : (hint_w[u] >> 16);
+  }
   __syncthreads();
   if (tid == 0) {
     double sx_ = 0.0, sy_ = 0.0;
@@ -794,22 +976,27 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     s_c[0] = sx_ / (double)s_bestn; s_c[1] = sy_ / (double)s_bestn;
   }
   __syncthreads();
-  // (ired is free from here on: it takes the polygon slot that held each lattice node, the hint of member_idx)
-  {
-    const volatile int *gl = g_lab;
-    for (int i = tid; i < NL; i += nth) { const int w = gl[i]; ired[i] = w == 0x7fffffff ? 0 : (w >> 16); }
-  }
-  __syncthreads();
   auto in_region = [&](double x, double y) {
     const int ix = (int)rint((x - (cx - RL_BUFFER_SIDE)) / h), iy = (int)rint((y - (cy - RL_BUFFER_SIDE)) / h);
     if (ix < 0 || ix >= RL_LAT || iy < 0 || iy >= RL_LAT) return false;
     return lab[iy * RL_LAT + ix] == best && member_idx(x, y, ired[iy * RL_LAT + ix]) != 0;
   };
+  // three conditions, independent of each other (:287-300): the centroid on a relevant lanelet -- every lanelet asked at once
+  // --, no region in front of the obstacle, a lane heading at the centroid.  Round 6: the last two are taken by the LAST thread
+  // of the workgroup (another wave) while the others ask the lanelets, instead of by thread 0 behind them (a membership test
+  // and a raster look-up by one thread: ~3 us of the chain)
+  __shared__ int s_front, s_yawok;
+  if (tid == nth - 1) {
+    s_front = in_region(cx + 4.0 * oc_c, cy + 4.0 * oc_s) ? 1 : 0;                  // the region in front of the obstacle (:297)
+    double yw = 0.0;
+    s_yawok = rl_lane_yaw_at(v, s_c[0], s_c[1], yw) ? 1 : 0;
+    s_yaw = yw;
+  }
   if (rel_fits) {   // the centroid must lie on a relevant lanelet (:287-291): every lanelet asked at once
     for (int p = tid; p < v.P; p += nth)
       if ((relflag[p] & 1) && rl_in_polygon(v, p, s_c[0], s_c[1])) s_relc = 1;
-    __syncthreads();
   }
+  __syncthreads();
   if (tid == 0) {
     s_go = 0;
     do {
@@ -817,9 +1004,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       bool rel_c = rel_fits && s_relc;
       for (int p = 0; !rel_fits && p < v.P && !rel_c; ++p)
         if (rl_in_polygon(v, p, s_c[0], s_c[1])) {
-          if (rel_fits) {
-            rel_c = relflag[p] & 1;
-          } else if (s_inter >= 0) {
+          if (s_inter >= 0) {
             if (p != s_ego_ll)
               for (int e = v.inter_off[s_inter]; e < v.inter_off[s_inter + 1]; ++e)
                 if (v.inter_lanelet[e] == p) rel_c = true;
@@ -832,10 +1017,8 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
           }
         }
       if (!rel_c) break;
-      if (in_region(cx + 4.0 * oc_c, cy + 4.0 * oc_s)) break;                      // the region in front of the obstacle (:297)
-      double yw;
-      if (!rl_lane_yaw_at(v, s_c[0], s_c[1], yw)) break;
-      s_yaw = yw;
+      if (s_front) break;
+      if (!s_yawok) break;
       s_go = 1;
     } while (false);
   }
@@ -975,6 +1158,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
 // flags of an obstacle at this step: bit0 present, bit1 occludes (not a bicycle), bit2 dynamic role, bit3 type bicycle or
 // pedestrian (never triggers the dynamic rule, :209-210)
 constexpr int RL_THREADS = 1024;   // the dynamic rule's lattice work spreads over sixteen waves (the other rules use one)
+static_assert(RL_THREADS == RL_THREADS_DYN, "rl_dynamic_rule sizes its per-thread lattice slices for the kernel's block");
 __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, RuleParams pr, int O, const double *__restrict__ ocorn,
                                                              const double *__restrict__ ocen, const double *__restrict__ oyaw,
                                                              const double *__restrict__ odims, const uint8_t *__restrict__ oflags,
@@ -985,7 +1169,7 @@ __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, 
   __shared__ int ired[RL_LAT * RL_LAT];
   __shared__ double red[3 * RL_THREADS];
   __shared__ unsigned char bytes[2048];
-  __shared__ double polyv[2 * RL_PVERT];   // dynamic rule: the vertices of the candidate region's lanelet polygons
+  __shared__ __align__(16) double polyv[2 * RL_PVERT];   // dynamic rule: the vertices of the candidate region's lanelet polygons (read as double2)
   // the reference path table into LDS: the projections and the arc-length searches of every rule are chains of dependent
   // reads of it (a binary search in HBM costs eight round trips of ~0.6 us; in LDS, of ~30 ns)
   __shared__ double pathv[6 * RL_PATHV];

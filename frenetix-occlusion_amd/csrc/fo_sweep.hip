@@ -357,12 +357,17 @@ __device__ __forceinline__ double fo_lr4s_coef(double ang, double side, double r
 #ifndef FO_ATAN2_DIAMOND
 #define FO_ATAN2_DIAMOND 1
 #endif
+#ifndef FO_ATAN2_GUARD
+#define FO_ATAN2_GUARD 1   // round 6: a NaN of the float32 estimate (offsets of ~1e-40 m: both casts flush to zero) sends the sample to the float64 route
+#endif
 __device__ __forceinline__ float fo_atan2_crude(float y, float x) {
 #if FO_ATAN2_DIAMOND
   // Round 5: the "diamond angle" -- pi/2 (1 - x / (|x| + |y|)) with the sign of y: monotonic in the true angle, exact on the
   // axes and the diagonals, 0.071 rad off at worst (the decision it feeds has pi/4 of room, see above).  No comparison, no
   // select: the three v_cmp + v_cndmask pairs of the octant form each held the SIMD for ten cycles beyond their own issue.
-  // (x = y = 0 does not get here: the caller puts dx = 1 for coincident centres.)
+  // (x = y = 0 does not get here: the caller puts dx = 1 for coincident centres.  Offsets that are nonzero in float64 but vanish
+  // -- or overflow, or are denormal -- as float32 give 0 * inf = NaN or +-inf here, never a value in [-pi, pi]: the callers hand
+  // such a sample to the reference's own float64 route, FO_ATAN2_GUARD.)
   const float q = x * __builtin_amdgcn_rcpf(fabsf(x) + fabsf(y));
   return copysignf(fmaf(q, -1.57079633f, 1.57079633f), y);
 #else
@@ -1531,7 +1536,11 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
             bool be_, bo_;
             const unsigned ce = fo_lr4s_class(ddx, ddy, ec, es, relc, 0.0f, (float)eth, false, be_);
             const unsigned co = fo_lr4s_class(ddx, ddy, pc, ps, relc, 3.14159265f, (float)pyaw, true, bo_);
+#if FO_ATAN2_GUARD
+            if (__ballot(be_ || bo_ || !(fabsf(relc) <= 4.0f))) wgate |= 0x10000u << (t & 15);   // re-rated after the loop (rare; see there)
+#else
             if (__ballot(be_ || bo_)) wgate |= 0x10000u << (t & 15);   // re-rated after the loop (rare; see there)
+#endif
             const int sh = (t & 15) * 2;
             cls_e = (cls_e & ~(3u << sh)) | (ce << sh);
             cls_o = (cls_o & ~(3u << sh)) | (co << sh);
@@ -1567,7 +1576,15 @@ __device__ __forceinline__ void fo_sweep_queue_body(const SweepArgs a, const dou
           const cdp_t g0 = G + (size_t)min(t, L - 1) * NAF;
           double ddx = g0[0] - xy.x, ddy = g0[1] - xy.y;
           if (ddx == 0.0 && ddy == 0.0) ddx = 1.0;
+#if FO_ATAN2_GUARD
+          // (an offset whose float32 casts under- or overflow -- the estimate above was NaN and "far" read false: both classes
+          // by the float64 route)
+          const float crude_ = fo_atan2_crude((float)ddy, (float)ddx);
+          const bool nf_ = !(fabsf(crude_) <= 4.0f);   // NaN (0 * inf) or +-inf (a float32 denormal times the reciprocal of one)
+          const bool be_ = nf_ || fo_lr4s_on_boundary(ddx, ddy, cs.x, cs.y), bo_ = nf_ || fo_lr4s_on_boundary(ddx, ddy, g0[2], g0[3]);
+#else
           const bool be_ = fo_lr4s_on_boundary(ddx, ddy, cs.x, cs.y), bo_ = fo_lr4s_on_boundary(ddx, ddy, g0[2], g0[3]);
+#endif
           if (be_ || bo_) {
             const unsigned both = fo_lr4s_classes_ref(ddx, ddy, th0, g0[4]);
             const int sh = slot * 2;

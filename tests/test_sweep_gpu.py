@@ -651,6 +651,27 @@ def test_dce_ties_stationary_and_random_geometry(torch_cuda, oracle):
         _compare(oracle, ref2, got2, atol=ATOL if lists == "f64" else 1e-6)
     oh = ref2["lists"][0, :, oracle.LST["obst_harm"], 0]                       # ego at rest on top of them, first sample
     assert len({oh[0], oh[1], oh[2]}) == 3 and oh[0] == oh[3] == oh[4] and oh[2] == oh[5]      # three classes, by the un-wrapped angle
+    # Centres that coincide to within ~1e-40 m (advisor, round 5): the offsets are nonzero in float64 -- atan2 sees their
+    # direction -- but denormal (1e-40) or zero (1e-60) as float32, where the kernel's cheap angle estimate is 0 * inf; such
+    # samples must take the float64 route.  Eight directions x two magnitudes around the ego at rest at the origin, LR4S cars,
+    # headings chosen so that the three classes all occur on both sides.
+    dirs8 = np.array([[1, 2], [-2, 1], [-1, -2], [2, -1], [1, 0], [0, 1], [-1, 0], [0, -1]], dtype=np.float64)
+    pos3 = np.concatenate([dirs8 * 1e-40, dirs8 * 1e-60])[:, None, :].repeat(T, 1)
+    A3 = pos3.shape[0]
+    yaw3 = np.tile(np.array([0.3, -2.9, 2.0, -1.2, 3.3, -0.4, 1.1, -3.4]), 2)
+    agents3 = {"pos": pos3, "yaw": np.repeat(yaw3[:, None], T, 1), "v": np.zeros((A3, T)), "cov": np.tile(0.1 * np.eye(2), (A3, T, 1, 1)),
+               "shape": np.tile([5.76, 2.6], (A3, 1)), "raw_dims": np.tile([4.8, 2.0], (A3, 1)),
+               "type": np.zeros(A3, dtype=np.int32), "len": np.full(A3, T, dtype=np.int32)}
+    traj3 = {k: v.copy() for k, v in traj.items()}
+    traj3["theta"][0, :] = 0.4                      # (ego at rest at the origin, heading 0.4: its own classes vary with the direction)
+    ref3 = oracle.sweep(traj3, agents3, S.VEHICLE_BMW320I, 0.1)
+    eh = ref3["lists"][0, :, oracle.LST["ego_harm"], 0]
+    assert len(set(np.round(eh[:8], 12))) == 3 and np.array_equal(eh[:8], eh[8:])         # all three classes; magnitude is irrelevant
+    for lists in ("f64", "f32x"):
+        got3 = _hip_sweep(torch_cuda, traj3, agents3, S.VEHICLE_BMW320I, 0.1, lists=lists)
+        _compare(oracle, ref3, got3, atol=ATOL if lists == "f64" else 1e-6)
+    red3 = _hip_sweep(torch_cuda, traj3, agents3, S.VEHICLE_BMW320I, 0.1, mode="reduced")
+    assert np.array_equal(red3["cost"], got3["cost"], equal_nan=True)
     rng = np.random.default_rng(123)
     for trial in range(3):
         M, A = 256, 24

@@ -60,3 +60,13 @@ for step in (0, 8, 25, 60):
             print("   dynamic-rule phases (us): ", np.round(d, 1).tolist(),
                   "(membership, labelling, sizes, centroid+checks | car fit: clip, sums + rows, hull + rectangle)" if two else
                   "(membership, labelling, sizes, centroid+checks, car fit, bicycle fit)")
+            # where the chain sits in the launch: the first wave of any workgroup (RL_WTICK(0)) to the phase stamps
+            import ctypes
+            from frenetix_occlusion import _native as N
+            t = (ctypes.c_longlong * (8 * 1024))()
+            if N.load().fo_debug_rule_wticks(t) == 0:
+                w = np.array(list(t), dtype=np.int64).reshape(1024, 8)
+                ok = w[:, 0] > 0
+                k0 = w[ok, 0].min()
+                print("   from the launch's first wave (us): last workgroup started %.1f, path tables in LDS (latest) %.1f, phase stamps %s"
+                      % ((w[ok, 0].max() - k0) * 0.01, (w[ok, 1].max() - k0) * 0.01, np.round((h[:7] - k0) * 0.01, 1).tolist()))
