@@ -331,6 +331,53 @@ def committed_pmc(N, mode, lists_fmt):
     return out
 
 
+def live_pmc(lists_fmt, mode="full"):
+    """HBM traffic and VALU issue counters of the dominant kernel measured IN THIS RUN: two short `rocprofv3 --pmc` passes of
+    this script as child processes (the guide's recipe: counters in passes of their own, --pmc with --kernel-trace only; FETCH_SIZE
+    x 2 on gfx950, KB -> bytes), started before this process has touched the GPU.  Returns the same keys as committed_pmc(), or
+    None when rocprofv3 is not there or a pass fails (the line then falls back to the committed summary of this library)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    want = {"full/f32": "fo_sweep_queue_kernel<true, 2", "full/f64": "fo_sweep_queue_kernel<true, 1",
+            "full/f32x": "fo_sweep_queue_kernel<true, 3", "reduced": "fo_sweep_queue_kernel<false, 0",
+            "pair": "fo_sweep_queue_kernel<true, 0"}[mode + ("/" + lists_fmt if mode == "full" else "")]
+    vals, t0 = {}, time.time()
+    top = tempfile.mkdtemp(prefix="fo_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for i, grp in enumerate((("FETCH_SIZE", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"), ("WRITE_SIZE",))):
+            d = os.path.join(top, f"p{i}")
+            cmd = [exe, "--pmc", *grp, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-autotune",
+                   "--no-extras", "--no-live-pmc", "--mode", mode, "--lists", lists_fmt]
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240,
+                               env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")), cwd=top)
+            if r.returncode != 0:
+                return None
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                    if k.startswith(want) and ", false>" in k:
+                        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c in grp:
+                if not acc.get(c):
+                    return None
+                vals[c] = sum(acc[c]) / len(acc[c])
+                vals["launches"] = len(acc[c])
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(top, ignore_errors=True)
+    return {"traffic": (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"]) * 1024.0,
+            "valu_issue_frac": vals["SQ_INSTS_VALU"] * 4.0 / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0),
+            "launches": vals["launches"], "seconds": time.time() - t0}
+
+
 def small_batch_step(local_rank, steps=300):
     """BASELINE configs[1] beside the headline: scenario1 geometry, 2 000 candidates x 32 phantom slots, the same planning
     step (scene stage + sampling + sweep + reduction, reduced outputs as a planner consumes them), own context; a few
@@ -676,6 +723,9 @@ def main():
     ap.add_argument("--order", default="sampler", choices=["sampler", "random"],
                     help="row order of the synthetic trajectories (synthetic.make_trajectories)")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic in this run (the default N = 1 run of the "
+                         "headline workload does; the committed summary of the loaded library is the fallback)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -683,6 +733,11 @@ def main():
         sys.exit(launch_workers(args.gpus, sys.argv[1:]))
     if args.launcher_selftest:
         sys.exit(launcher_selftest(args))
+    # roofline.traffic measured in THIS run: counter passes as child processes, before this process touches the GPU
+    live = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_live_pmc and not args.no_extras and args.scene == "urban"
+            and (args.M, args.A, args.T, args.mode) == (10000, 256, 31, "full")):
+        live = live_pmc(args.lists, args.mode)
 
     import numpy as np
     import torch
@@ -882,6 +937,14 @@ def main():
         pmc = {"traffic": None, "valu_issue_frac": None, "bound": None, "profile": None, "hbm_traffic_gbs": None, "hbm_frac": None}
         if default_workload and world == 1:
             pmc = committed_pmc(N, args.mode, args.lists)
+        traffic_source = ("committed rocprofv3 summary of this library: profiles/" + pmc["profile"] + "_summary.csv") if pmc["traffic"] else None
+        if live is not None:      # measured in this run: per launch, over this run's own kernel time
+            pmc = dict(pmc, traffic=live["traffic"], valu_issue_frac=live["valu_issue_frac"],
+                       hbm_traffic_gbs=live["traffic"] / kern_s / 1e9, hbm_frac=live["traffic"] / kern_s / 1e9 / HBM_ACHIEVABLE_GBS,
+                       committed_traffic=pmc["traffic"])
+            pmc["bound"] = bound_word(pmc["hbm_frac"], pmc["valu_issue_frac"])
+            traffic_source = (f"this run: two rocprofv3 --pmc passes of bench.py as child processes ({live['launches']} launches of the "
+                              f"kernel each, {live['seconds']:.0f} s), WRITE_SIZE + 2 x FETCH_SIZE")
         checks, checks_ok = roofline_checks(a8d, ast, kern_s, pmc["traffic"])
         if not checks_ok:     # a bug of this script, not of the box: say so loudly and print no impossible bandwidth
             print(f"bench.py: inconsistent byte figures {checks}", file=sys.stderr, flush=True)
@@ -928,9 +991,10 @@ def main():
             "roofline": {"bound": pmc["bound"] or "unknown (no PMC summary of this library under profiles/)",
                          "kernel": "fo_sweep_queue_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"], "traffic_profile": pmc["profile"],
+                         "traffic_source": traffic_source, "traffic_committed_profile": pmc.get("committed_traffic"),
                          "hbm_traffic_gbs": pmc["hbm_traffic_gbs"], "hbm_achievable_gbs": HBM_ACHIEVABLE_GBS, "hbm_frac_of_achievable": pmc["hbm_frac"],
                          "valu_issue_frac": pmc["valu_issue_frac"],
-                         "valu_issue_frac_definition": "SQ_INSTS_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed PMC summary",
+                         "valu_issue_frac_definition": "SQ_INSTS_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), same source as traffic",
                          "bytes_definition": "SURVEY 8d, fp32 storage: 620 B/trajectory + 636 B/agent + per pair 48 B "
                                              "scalars (+ 600 B lists in full mode); 64 B/trajectory in reduced mode",
                          "algorithmic_bytes_per_launch": a8d, "stored_bytes_per_launch": ast,
