@@ -299,7 +299,7 @@ def committed_pmc(N, mode, lists_fmt):
     if it exceeds 0.8, else "latency/issue mix" with both figures (bound_word).  profiles/<tag>_build.json must name the fo_build_id() of the loaded library, else
     everything is None."""
     import csv
-    base = os.environ.get("FO_PROFILE_TAG", "r05")
+    base = os.environ.get("FO_PROFILE_TAG", "r06")
     tag = base + {"full/f32x": "_final", "full/f64": "_f64lists", "full/f32": "_f32", "reduced": "_reduced",
                   "pair": "_pair"}.get(mode + ("/" + lists_fmt if mode == "full" else ""), "_final")
     want = {"full/f32": "fo_sweep_queue_kernel<true, 2", "full/f64": "fo_sweep_queue_kernel<true, 1",

@@ -1,14 +1,16 @@
 #!/bin/bash
 # tools/copy_profiles.sh <rNN>: after tools/collect_round.sh <rNN> ran on the GPU box: gpurun_out -> profiles/
 set -e
-R=${1:-r05}
+R=${1:-r06}
 cd $(dirname $0)/..
 for t in ${R}_final ${R}_f64lists ${R}_f32 ${R}_reduced; do
   cp gpurun_out/${t}_stats/run_kernel_stats.csv profiles/${t}_kernel_stats.csv
   cp gpurun_out/summ/${t}_summary.csv profiles/${t}_summary.csv
   cp gpurun_out/summ/${t}_build.json profiles/
 done
-for t in small_batch spawn_rules rules_step; do cp gpurun_out/${R}_${t}_stats/run_kernel_stats.csv profiles/${R}_${t}_kernel_stats.csv; done
+for t in small_batch spawn_rules rules_step fv; do cp gpurun_out/${R}_${t}_stats/run_kernel_stats.csv profiles/${R}_${t}_kernel_stats.csv; done
+cp gpurun_out/summ/${R}_fv_summary.csv profiles/${R}_fv_summary.csv
+cp gpurun_out/${R}_fv.log profiles/${R}_fv_bench.txt
 cp gpurun_out/${R}_final_bench.json profiles/
 python3 - <<PY
 import json, csv
