@@ -123,6 +123,7 @@ __device__ inline bool rl_lane_yaw_at(const RuleView &v, double x, double y, dou
 template <class GET>
 __device__ __forceinline__ int rl_crossing_parity(int b, int e, double x, double y, GET get) {
   int c = 0;
+  if (e <= b) return 0;   // (an empty ring holds nothing -- and has no last vertex to start from)
   double2 pj = get(e - 1);
   for (int i0 = b; i0 < e; i0 += 8) {
     double2 pv[8];
@@ -323,6 +324,7 @@ struct RuleParams {
   int intention;                 // 0 straight ahead, 1 left turn, 2 right turn
   int win_i0, win_i1;            // reference window = path vertices [i0, i1)
   int behind_static, behind_turn, behind_dynamic, max_static, max_dynamic;
+  int label_nodes;               // tests (FO_SCENE_RULE_NODES=1): the dynamic rule's connected parts on the lattice nodes, not on the row runs
 };
 
 // sample i of a polyline with cumulative lengths cum[] (np.interp on both coordinates); n_s samples, step apart, the
@@ -741,7 +743,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   int *run_rec = ired, *run_lab = ired + RL_MAXRUN, *run_size = ired + 2 * RL_MAXRUN;   // (ired: 9 409 ints)
   __shared__ int s_rowoff[RL_LAT + 1], s_nrun;
   __shared__ unsigned long long s_rowbits[RL_LAT][2];
-  bool by_runs = FO_RULE_RUNS != 0;
+  bool by_runs = FO_RULE_RUNS != 0 && !pr.label_nodes;
   if (by_runs) {
     const int wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
     for (int r = wave; r < RL_LAT; r += nw) {
@@ -1500,6 +1502,10 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
   pr.intention = params->intention; pr.win_i0 = params->win_i0; pr.win_i1 = params->win_i1;
   pr.behind_static = params->behind_static; pr.behind_turn = params->behind_turn; pr.behind_dynamic = params->behind_dynamic;
   pr.max_static = params->max_static; pr.max_dynamic = params->max_dynamic;
+  {  // (looked at on every call, like the other knobs: a test runs both labelling forms in one process)
+    const char *e = fo_getenv(fo_env_any("FO_SCENE_"), "FO_SCENE_RULE_NODES");
+    pr.label_nodes = e && e[0] == '1';
+  }
   {  // lattice hand-off of the dynamic rule: [O][97 x 97] labels + a counter per obstacle (zero between launches)
     const size_t cap0 = sc->cap_rule_cnt;
     if ((rc = fo_reserve(ctx, &sc->d_rule_lab, &sc->cap_rule_lab, (size_t)(O > 0 ? O : 1) * RL_LAT * RL_LAT))) return rc;

@@ -3,6 +3,11 @@
  *
  * Loop structure follows the reference: per trajectory -> per metric -> per agent prediction -> per timestep
  * (interface.py:216-219 -> metrics/metric.py:35-100).
+ *
+ * Pinned to outputs of the reference's own code (tests/golden/*.npz, written by tests/golden/gen_golden.py with the reference
+ * imported from /root/reference): CP, harm, risk, HR, TTC, TTCE, WTTC, the safety decision -- and, since round 6, the DCE walk
+ * over the time steps (dce_loop.npz) and BE's bisection (be_bisection.npz), whose reference classes run unmodified over this
+ * file's rectangle primitives.  Restated from the published algorithm, not pinned: the polygon distance itself (GEOS, below).
  */
 #define _GNU_SOURCE
 #include "fo_oracle.h"

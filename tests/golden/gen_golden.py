@@ -17,8 +17,13 @@ Three third-party names those files import are absent from this image and are al
                                                   (collision_probability.py:149-156 uses only these)
   * scipy.stats.mvn                            -> scipy.stats._mvn (the same Fortran MVNDST wrapper; the public
                                                   alias was dropped in scipy 1.15)
-DCE, BE, SensorModel, SpawnLocator need shapely/commonroad proper and are NOT run here; for those the
-oracle is pinned by analytic known-answer tests only ("parity unpinned").
+SensorModel and SpawnLocator need shapely/commonroad proper and are NOT run here; for those the oracle is pinned by
+analytic known-answer tests only ("parity unpinned").  DCE and BE (round 6; `gen_golden.py dce`, `gen_golden.py be`,
+each in a process of its own): metrics/dce.py and metrics/be.py ARE executed unmodified -- the walk over the time steps with its
+rounding, tie and stop rules; the deceleration profiles, scipy re-sampling and bisection -- with the ONE module they import
+besides numpy / scipy, metrics/utils/convert_dynamic_obstacle.py (commonroad proper), replaced by duck-typed obstacles over this
+repository's rectangle primitives (_install_rectangle_stub): the polygon `distance` / `intersects` under those loops is the
+oracle's restatement of GEOS' (pinned to exact arithmetic by tests/test_dce_sympy.py), everything above it is the reference's.
 
 Only arrays (inputs and the reference's outputs) are written, to tests/golden/*.npz.  No reference source
 or bytecode is copied.
@@ -795,9 +800,243 @@ def gen_shadow_geometry():
     print("shadow_geometry.npz quads", quads.shape, "wedges", wedges.shape, "sectors", np.array([c[5] for c in cases]).shape)
 
 
+def _install_rectangle_stub(O):
+    """frenetix_occlusion.metrics.utils.convert_dynamic_obstacle (commonroad proper: not installable here) as a module whose two
+    converters build duck-typed obstacles -- `.prediction.trajectory.state_list`, `.occupancy_at_time(i)` (None beyond the last
+    state, as commonroad's) with `.shape.shapely_object` -- over this repository's rectangle primitives: vertices by
+    oracle.rect_vertices (rear axle -> centre as convert_dynamic_obstacle.py:73), `distance` = oracle.quad_distance (the
+    restatement of GEOS' polygon distance), `intersects` = that distance == 0.  Everything the reference's metric classes do ON
+    TOP of those two predicates then runs unmodified."""
+    class _Poly:
+        def __init__(self, q):
+            self.q = q
+
+        def distance(self, other):
+            return O.quad_distance(self.q, other.q)
+
+        def intersects(self, other):
+            return O.quad_distance(self.q, other.q) == 0.0
+
+    class _NS:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class _Dyn:
+        def __init__(self, quads):
+            self._q = quads
+            self.prediction = _NS(trajectory=_NS(state_list=[None] * len(quads)))
+
+        def occupancy_at_time(self, i):
+            return None if i >= len(self._q) else _NS(shape=_NS(shapely_object=_Poly(self._q[i])))
+
+    def convert_traj_to_dyn_obstacle(trajectory, vehicle_params, obstacle_id=42):
+        c = trajectory.cartesian
+        wb = vehicle_params.wb_rear_axle
+        return _Dyn([O.rect_vertices(x + wb * np.cos(t), y + wb * np.sin(t), t, vehicle_params.length, vehicle_params.width)
+                     for x, y, t in zip(c.x, c.y, c.theta)])
+
+    def convert_prediction_to_dyn_obstacle(agent, key, prediction):
+        return _Dyn([O.rect_vertices(p[0], p[1], yaw, agent.shape.length, agent.shape.width)
+                     for p, yaw in zip(prediction["pos_list"], prediction["orientation_list"])])
+
+    mod = types.ModuleType("frenetix_occlusion.metrics.utils.convert_dynamic_obstacle")
+    mod.convert_traj_to_dyn_obstacle = convert_traj_to_dyn_obstacle
+    mod.convert_prediction_to_dyn_obstacle = convert_prediction_to_dyn_obstacle
+    sys.modules["frenetix_occlusion.metrics.utils.convert_dynamic_obstacle"] = mod
+    return _NS
+
+
+def gen_dce():
+    """tests/golden/dce_loop.npz: the reference's own, unmodified metrics/dce.py (DCE.evaluate / _calc_dce, dce.py:31-99: the
+    walk over the time steps, np.round(distance, 3), 'first strict minimum', the stop at the first zero and at the end of a
+    prediction) with metrics/ttc.py, ttce.py and wttc.py on top of ITS results -- over the stubbed rectangles of
+    _install_rectangle_stub: the polygon distance under the loop is this repository's restatement of GEOS', the loop is the
+    reference's.  Ragged predictions, overlaps at t = 0 and later, touching rectangles, stationary pairs (every step ties),
+    symmetric pass-bys (two equal minima), pairs that never come near."""
+    _install_aliases()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import fo_oracle as O
+    O.build()
+    _NS = _install_rectangle_stub(O)
+    from frenetix_occlusion.metrics.dce import DCE         # the reference's own classes, unmodified
+    from frenetix_occlusion.metrics.ttc import TTC
+    from frenetix_occlusion.metrics.ttce import TTCE
+    from frenetix_occlusion.metrics.wttc import WTTC
+    dt, T = 0.1, 31
+    t = np.arange(T) * dt
+    rng = np.random.default_rng(20240207)
+    vp = VehicleParams()
+    trajs = [Traj(*make_traj(rng, T, dt, psi0=rng.uniform(-0.4, 0.4))) for _ in range(28)]
+    trajs.append(Traj(np.full(T, -40.0), np.full(T, 10.0), np.zeros(T), np.zeros(T), np.zeros(T)))           # ego at rest, away from the others' start
+    xs = np.concatenate((np.linspace(0, 9, 16), np.linspace(9, 0, 16)[1:]))                                # out and back: symmetric
+    trajs.append(Traj(xs, np.zeros(T), np.zeros(T), np.full(T, 6.0), np.zeros(T)))
+    trajs.append(Traj(6.0 * t, np.zeros(T), np.zeros(T), np.full(T, 6.0), np.zeros(T)))                     # straight
+    mid = np.array([trajs[0].cartesian.x[15], trajs[0].cartesian.y[15]])
+    kinds = [AGENT_TYPES[i % 4] for i in range(12)] + ["Car", "Car", "Car", "Pedestrian"]
+    lens = [31, 31, 20, 31, 9, 31, 1, 40, 31, 15, 31, 2, 31, 31, 31, 31]
+    preds = [make_prediction(rng, k, L, dt, mid, curved=(i % 3 == 0)) for i, (k, L) in enumerate(zip(kinds[:12], lens[:12]))]
+    touch_x = vp.wb_rear_axle + vp.length / 2 + RAW_DIMS["Car"][0] / 2          # faces touch the ego at rest: distance 0
+    for p0, L in (((30.0, 0.0), 31), ((15.0, 0.0), 31), ((-40.0 + touch_x, 10.0), 31), ((20.0, 6.0), 31)):
+        kind = kinds[len(preds)]
+        spd = 0.0 if kind == "Car" else 4.0
+        psi = 0.0 if kind == "Car" else -np.pi / 2
+        tt = np.arange(L) * dt
+        pos = np.asarray(p0) + tt[:, None] * spd * np.array([np.cos(psi), np.sin(psi)])
+        preds.append({"pos_list": pos, "v_list": np.full(L, spd), "orientation_list": np.full(L, psi),
+                      "cov_list": np.tile(0.1 * np.eye(2), (L, 1, 1)),
+                      "shape": {"length": RAW_DIMS[kind][0] * 1.2, "width": RAW_DIMS[kind][1] * 1.3}})
+    am = AgentManager(dt)
+    keys = []
+    for i, (kind, pred) in enumerate(zip(kinds, preds)):
+        ag = Agent(10000 + i, kind)
+        ag.shape = _NS(length=RAW_DIMS[kind][0], width=RAW_DIMS[kind][1])      # agent.py:216: the RAW dimensions
+        ag.obstacle_type = kind
+        am.phantom_agents.append(ag)
+        key = int(str(10000 + i) + "0")
+        am.predictions[key] = pred
+        keys.append(key)
+    dce_m, ttc_m, ttce_m, wttc_m = DCE(vp, am), TTC(am), TTCE(am), WTTC()
+    M, A = len(trajs), len(keys)
+    out_d, out_t, out_ttc, out_ttce, out_w = (np.zeros((M, A)), np.zeros((M, A), dtype=np.int64), np.zeros((M, A)),
+                                              np.zeros((M, A)), np.zeros(M))
+    for m, tr in enumerate(trajs):
+        res = {"dce": dce_m.evaluate(tr, {})}
+        res["ttc"] = ttc_m.evaluate(tr, res)
+        res["ttce"] = ttce_m.evaluate(tr, res)
+        res["wttc"] = wttc_m.evaluate(tr, res)
+        for j, k in enumerate(keys):
+            out_d[m, j], out_t[m, j] = res["dce"][k]["dce"], res["dce"][k]["time_dce"]
+            out_ttc[m, j], out_ttce[m, j] = res["ttc"][k], res["ttce"][k]
+        out_w[m] = res["wttc"]
+    Lmax = max(lens)
+    codes = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4}
+    agents = {
+        "pos": np.stack([np.pad(p["pos_list"], ((0, Lmax - len(p["pos_list"])), (0, 0))) for p in preds]),
+        "yaw": pad([p["orientation_list"] for p in preds], Lmax, 0.0), "v": pad([p["v_list"] for p in preds], Lmax, 0.0),
+        "cov": np.stack([np.pad(p["cov_list"], ((0, Lmax - len(p["cov_list"])), (0, 0), (0, 0))) for p in preds]),
+        "shape": np.array([[p["shape"]["length"], p["shape"]["width"]] for p in preds]),
+        "raw_dims": np.array([RAW_DIMS[k] for k in kinds]), "type": np.array([codes[k.lower()] for k in kinds], dtype=np.int32),
+        "len": np.array(lens, dtype=np.int32)}
+    outd = {"dt": dt, "vehicle": np.array([vp.length, vp.width, vp.wb_rear_axle, vp.mass, vp.a_max]),
+            **{"traj_" + k: np.stack([getattr(tr.cartesian, k) for tr in trajs]) for k in ("x", "y", "theta", "v", "a")},
+            "agent_type": np.array(kinds), **{"agent_" + k: v for k, v in agents.items() if k != "type"},
+            "agent_type_code": agents["type"], "ref_dce": out_d, "ref_time_dce": out_t, "ref_ttc": out_ttc, "ref_ttce": out_ttce,
+            "ref_wttc": out_w}
+    path = os.path.join(OUT, "dce_loop.npz")
+    np.savez_compressed(path, **outd)
+    print("wrote", path, "pairs", M * A, "zero distances", int((out_d == 0).sum()), "time_dce > 0", int((out_t > 0).sum()),
+          "finite ttc", int(np.isfinite(out_ttc).sum()), "distinct time_dce", len(np.unique(out_t)))
+
+
+def gen_be():
+    """tests/golden/be_bisection.npz: the reference's own, unmodified metrics/be.py (BE.evaluate -> find_minimum_deceleration ->
+    _calc_deceleration_trajectory -> _collision_check, be.py:31-193) and metrics/ttc.py on top of it.  be.py's one import
+    besides numpy / scipy, metrics/utils/convert_dynamic_obstacle.py, needs commonroad proper and is replaced by a module
+    whose two converters build duck-typed obstacles: `.prediction.trajectory.state_list`, `.occupancy_at_time(i)` (None
+    beyond the last state) with `.shape.shapely_object.intersects(other)`.  Only that predicate is NOT the reference's: it is
+    this repository's rectangle predicate (oracle quad_distance == 0, the restatement of GEOS' distance; rear axle -> centre as
+    convert_dynamic_obstacle.py:73).  Everything BE adds on top -- the speed profile of a constant deceleration, the
+    re-sampling of the path by scipy's interp1d, the bisection with its bracket, rounding, iteration count and stop rule, the
+    brake threat number, which pairs get a value at all (`ttc is not np.inf`, `ttc > 0`) -- is the reference's code."""
+    _install_aliases()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import fo_oracle as O
+    O.build()
+
+    _NS = _install_rectangle_stub(O)
+    from frenetix_occlusion.metrics.be import BE          # the reference's own class, unmodified
+    from frenetix_occlusion.metrics.ttc import TTC
+
+    dt, T = 0.1, 31
+    t = np.arange(T) * dt
+    rng = np.random.default_rng(20240206)
+    vp = VehicleParams()
+
+    def ego(v0, a_prof, psi0, kappa):
+        """a path integrated sample by sample (chord = v dt along the heading), so that the travelled length is the sum of
+        the speeds: a constant deceleration from v[1] on never runs ahead of a profile that brakes less hard than it"""
+        v = np.maximum(v0 + np.concatenate(([0.0], np.cumsum(a_prof[:-1] * dt))), 0.5)
+        th = psi0 + kappa * np.concatenate(([0.0], np.cumsum(v[:-1] * dt)))
+        x = np.concatenate(([0.0], np.cumsum(v[:-1] * np.cos(th[:-1]) * dt)))
+        y = np.concatenate(([0.0], np.cumsum(v[:-1] * np.sin(th[:-1]) * dt)))
+        return Traj(x, y, th, v, np.gradient(v, dt))
+
+    trajs = []
+    for i in range(40):
+        v0 = rng.uniform(4.0, 14.0)
+        kind = i % 4
+        a_prof = (np.zeros(T) if kind == 0 else np.full(T, -rng.uniform(0.2, 2.5)) if kind == 1 else
+                  rng.uniform(0.2, 1.5) * np.ones(T) if kind == 2 else -rng.uniform(0.5, 3.0) * (t > rng.uniform(0.3, 2.0)))
+        trajs.append(ego(v0, a_prof, rng.uniform(-0.2, 0.2), rng.uniform(-0.03, 0.03)))
+    # agents: standing and slow vehicles ahead on the candidates' way (the bisection has something to find), crossing
+    # pedestrians and a bicycle, an oncoming car, one far away (no collision: no value), one on top of the ego at t = 0
+    # (ttc = 0: no value), short predictions
+    kinds = ["Car", "Car", "Truck", "Pedestrian", "Pedestrian", "Bicycle", "Car", "Car", "Car", "Truck"]
+    specs = [((14.0, 0.3), 0.0, 0.0, 31), ((22.0, -0.5), 0.1, 2.0, 31), ((30.0, 1.0), -0.1, 1.0, 31),
+             ((12.0, -4.0), np.pi / 2, 1.4, 31), ((18.0, 5.0), -np.pi / 2, 1.6, 25), ((16.0, -6.0), np.pi / 2 - 0.2, 4.0, 31),
+             ((45.0, 0.5), np.pi, 8.0, 31), ((200.0, 50.0), 0.3, 5.0, 31), ((1.0, 0.0), 0.0, 0.0, 31), ((10.0, 0.0), 0.05, 0.5, 12)]
+    am = AgentManager(dt)
+    preds, keys = [], []
+    for i, (kind, (p0, psi, spd, L)) in enumerate(zip(kinds, specs)):
+        ag = Agent(10000 + i, kind)
+        ag.shape = _NS(length=RAW_DIMS[kind][0], width=RAW_DIMS[kind][1])      # agent.py:216: the RAW dimensions
+        ag.obstacle_type = kind
+        am.phantom_agents.append(ag)
+        tt = np.arange(L) * dt
+        pos = np.asarray(p0) + tt[:, None] * spd * np.array([np.cos(psi), np.sin(psi)])
+        pred = {"pos_list": pos, "v_list": np.full(L, spd), "orientation_list": np.full(L, psi),
+                "cov_list": np.tile(0.1 * np.eye(2), (L, 1, 1)), "shape": {"length": RAW_DIMS[kind][0] * 1.2, "width": RAW_DIMS[kind][1] * 1.3}}
+        key = int(str(10000 + i) + "0")
+        am.predictions[key] = pred
+        preds.append(pred)
+        keys.append(key)
+    Lmax = T
+    codes = {"car": 0, "truck": 1, "bus": 2, "bicycle": 3, "pedestrian": 4}
+    keep, decel, btn, ttc_out = [], [], [], []
+    be, ttc_m = BE(vp, am), TTC(am)
+    for m, tr in enumerate(trajs):
+        traj1 = {k: getattr(tr.cartesian, k)[None] for k in ("x", "y", "theta", "v", "a")}
+        agents = {
+            "pos": np.stack([np.pad(p["pos_list"], ((0, Lmax - len(p["pos_list"])), (0, 0))) for p in preds]),
+            "yaw": pad([p["orientation_list"] for p in preds], Lmax, 0.0), "v": pad([p["v_list"] for p in preds], Lmax, 0.0),
+            "cov": np.stack([np.pad(p["cov_list"], ((0, Lmax - len(p["cov_list"])), (0, 0), (0, 0))) for p in preds]),
+            "shape": np.array([[p["shape"]["length"], p["shape"]["width"]] for p in preds]),
+            "raw_dims": np.array([RAW_DIMS[k] for k in kinds]), "type": np.array([codes[k.lower()] for k in kinds], dtype=np.int32),
+            "len": np.array([len(p["pos_list"]) for p in preds], dtype=np.int32)}
+        orc = O.sweep(traj1, agents, (vp.length, vp.width, vp.wb_rear_axle, vp.mass, vp.a_max), dt, metrics=("dce", "ttc"))
+        res = {"dce": {key: {"dce": float(orc["pair_f"][0, j, O.PF["dce"]]), "time_dce": int(orc["pair_i"][0, j, O.PI["time_dce"]])}
+                       for j, key in enumerate(keys)}}
+        res["ttc"] = ttc_m.evaluate(tr, res)                  # the reference's own TTC (np.inf by identity where no collision)
+        try:
+            out = be.evaluate(tr, res)
+        except ValueError:      # scipy's interp1d refuses a re-sampled arc length beyond the path: the reference raises; not a case
+            continue
+        keep.append(m)
+        decel.append([out[k]["required_constant_deceleration"] for k in keys])
+        btn.append([out[k]["break_threat_number"] for k in keys])
+        ttc_out.append([float(res["ttc"][k]) for k in keys])
+    keep = np.array(keep)
+    outd = {"dt": dt, "vehicle": np.array([vp.length, vp.width, vp.wb_rear_axle, vp.mass, vp.a_max]),
+            **{"traj_" + k: np.stack([getattr(trajs[m].cartesian, k) for m in keep]) for k in ("x", "y", "theta", "v", "a")},
+            "agent_type": np.array(kinds), **{"agent_" + k: v for k, v in agents.items() if k != "type"},
+            "agent_type_code": agents["type"], "be_decel": np.array(decel), "be_btn": np.array(btn), "ttc": np.array(ttc_out),
+            "dropped_by_the_reference": len(trajs) - len(keep)}
+    path = os.path.join(OUT, "be_bisection.npz")
+    np.savez_compressed(path, **outd)
+    d = outd["be_decel"]
+    print("wrote", path, "trajectories", len(keep), "of", len(trajs), "pairs with a value", int((d > 0).sum()), "of", d.size,
+          "distinct decelerations", len(np.unique(np.round(d[d > 0], 6))), "range", float(d[d > 0].min()), float(d.max()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sampling":     # only the sampling-matrix fixture
         gen_sampling_matrix()
+    elif len(sys.argv) > 1 and sys.argv[1] == "be":         # only the brake-evaluation fixture (own process: it replaces a module)
+        gen_be()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dce":        # only the DCE-loop fixture (own process as well)
+        gen_dce()
     elif len(sys.argv) > 1 and sys.argv[1] == "shadow":     # only the shadow-geometry fixture
         gen_shadow_geometry()
     else:

@@ -35,3 +35,25 @@ def load_threshold_case():
         configs.append(([str(m) for m in g[f"cfg{c}_activated"]], thr, sorted(str(m) for m in g[f"cfg{c}_evaluated"]),
                         g[f"cfg{c}_safe"].astype(bool)))
     return traj, agents, tuple(g["vehicle"]), float(g["dt"]), configs
+
+
+def load_be_case():
+    """tests/golden/be_bisection.npz (gen_golden.py be): what the reference's own BE class returned -- required constant
+    deceleration and brake threat number per (trajectory, prediction) -- for 40 candidates x 10 predictions; returns
+    (golden dict, traj, agents, vehicle tuple, dt) in the oracle's input layout"""
+    g = dict(np.load(os.path.join(GOLDEN, "be_bisection.npz"), allow_pickle=False))
+    traj = {k: g["traj_" + k] for k in ("x", "y", "theta", "v", "a")}
+    agents = {k: g["agent_" + k] for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "len")}
+    agents["type"] = g["agent_type_code"]
+    return g, traj, agents, tuple(float(q) for q in g["vehicle"]), float(g["dt"])
+
+
+def load_dce_case():
+    """tests/golden/dce_loop.npz (gen_golden.py dce): what the reference's own DCE class -- its walk over the time steps -- and
+    its TTC / TTCE / WTTC on top returned for 31 candidates x 16 predictions (ragged, overlapping, touching, stationary,
+    symmetric); the polygon distance under the loop is this repository's rectangle distance"""
+    g = dict(np.load(os.path.join(GOLDEN, "dce_loop.npz"), allow_pickle=False))
+    traj = {k: g["traj_" + k] for k in ("x", "y", "theta", "v", "a")}
+    agents = {k: g["agent_" + k] for k in ("pos", "yaw", "v", "cov", "shape", "raw_dims", "len")}
+    agents["type"] = g["agent_type_code"]
+    return g, traj, agents, tuple(float(q) for q in g["vehicle"]), float(g["dt"])

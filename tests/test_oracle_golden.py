@@ -169,3 +169,43 @@ def test_route_enumeration_matches_the_references_route_planner():
             assert mine[lid] == ref[lid], (q, lid)
             total += len(ref[lid])
     assert total > 300
+
+
+def test_brake_evaluation_matches_the_references_own_bisection(oracle):
+    """metrics/be.py of the reference, imported unmodified (gen_golden.py be), ran its bisection -- bracket from the candidate's
+    own strongest deceleration rounded to two decimals, <= 10 halvings, stop below 0.1, a constant deceleration from the second
+    sample on, the path re-sampled by scipy's interp1d over the travelled chord length -- on 40 candidates x 10 predictions;
+    only `intersects` of two rectangles came from this repository (shapely is not installable here).  The oracle reproduces
+    every required deceleration and brake threat number EXACTLY (they are dyadic midpoints of the bracket: a single different
+    collision verdict anywhere in a bisection would move the result by >= 0.07), and which pairs have a value at all."""
+    from golden_util import load_be_case
+    g, traj, agents, veh, dt = load_be_case()
+    ref = oracle.sweep(traj, agents, veh, dt, metrics=("dce", "ttc", "be"))
+    d, b = ref["pair_f"][..., oracle.PF["be_decel"]], ref["pair_f"][..., oracle.PF["be_btn"]]
+    assert d.shape == g["be_decel"].shape == (40, 10)
+    assert np.array_equal(d, g["be_decel"]) and np.array_equal(b, g["be_btn"])
+    has = g["be_decel"] > 0
+    assert has.sum() > 100 and len(np.unique(g["be_decel"][has])) > 40 and (~has).sum() > 100      # both kinds of pairs
+    # a value exactly where the reference's own TTC saw a collision after t = 0
+    assert np.array_equal(has, np.isfinite(g["ttc"]) & (g["ttc"] > 0))
+    np.testing.assert_array_equal(np.nan_to_num(ref["pair_f"][..., oracle.PF["ttc"]], posinf=np.inf), g["ttc"])
+    assert np.array_equal(ref["cost"][:, oracle.COST["max_btn"]], g["be_btn"].max(axis=1))
+
+
+def test_dce_loop_matches_the_references_own_walk_over_the_time_steps(oracle):
+    """metrics/dce.py of the reference, imported unmodified (gen_golden.py dce), walked the time steps of 31 candidates x 16
+    predictions -- np.round(distance, 3), first strict minimum, the stop at the first zero and where a prediction ends -- and its
+    TTC / TTCE / WTTC read the results; only the distance between two rectangles under the loop came from this repository
+    (shapely is not installable here; that primitive is pinned to exact arithmetic by tests/test_dce_sympy.py).  The oracle
+    reproduces dce, time_dce, ttc, ttce and wttc exactly: ties on stationary pairs (every step), two equal minima of a
+    symmetric pass-by, touching faces (distance 0), predictions of 1 ... 40 samples against 31 of the candidate."""
+    from golden_util import load_dce_case
+    g, traj, agents, veh, dt = load_dce_case()
+    ref = oracle.sweep(traj, agents, veh, dt, metrics=("dce", "ttc", "ttce", "wttc"))
+    assert np.array_equal(ref["pair_f"][..., oracle.PF["dce"]], g["ref_dce"])
+    assert np.array_equal(ref["pair_i"][..., oracle.PI["time_dce"]], g["ref_time_dce"])
+    assert np.array_equal(ref["pair_f"][..., oracle.PF["ttc"]], g["ref_ttc"])            # inf where the reference says np.inf
+    assert np.array_equal(ref["pair_f"][..., oracle.PF["ttce"]], g["ref_ttce"])
+    assert np.array_equal(ref["cost"][:, oracle.COST["wttc"]], g["ref_wttc"])
+    td = g["ref_time_dce"]
+    assert (g["ref_dce"] == 0).sum() > 50 and len(np.unique(td)) == 31 and (td > 0).sum() > 300

@@ -145,6 +145,42 @@ def test_car_and_bicycle_behind_an_oncoming_truck(torch_cuda):
         _same(dev, ref, view)
 
 
+def test_both_labelling_forms_of_the_dynamic_rule(torch_cuda, monkeypatch):
+    """The candidate region's connected parts are labelled on the runs of the lattice rows (round 6); the node form of rounds
+    4-5 stays as the fallback for more runs than the arrays hold.  FO_SCENE_RULE_NODES=1 sends every case through it: both forms
+    against the checker -- and therefore against each other -- on the oncoming-truck scenes and on the scenario-1 steps at which
+    the rule fires (20, 25, 33: one and three phantom vehicles)."""
+    from frenetix_occlusion import scenario as S
+    xs = np.linspace(-10, 70, 41)
+    lane1 = S.Lanelet(1, np.stack((xs, np.zeros(41)), -1), np.stack((xs, np.full(41, -3.5)), -1))
+    lane2 = S.Lanelet(2, np.stack((xs[::-1], np.zeros(41)), -1), np.stack((xs[::-1], np.full(41, 3.5)), -1))
+    lane1.adj_left, lane1.adj_left_same_direction = 2, False
+    lane2.adj_left, lane2.adj_left_same_direction = 1, False
+    path = np.stack((np.linspace(-5, 65, 141), np.full(141, -1.75)), -1)
+    sc = S.load_geometry_npz(os.path.join(GOLDEN, "scenario1_geometry.npz"))
+    ego0 = sc.ego_initial
+    yaw = float(ego0[2])
+    path1 = ego0[None, :2] + np.linspace(-5.0, 80.0, 171)[:, None] * np.array([[math.cos(yaw), math.sin(yaw)]])
+    n_vehicles = {}
+    for form in ("runs", "nodes"):
+        if form == "nodes":
+            monkeypatch.setenv("FO_SCENE_RULE_NODES", "1")
+        n = 0
+        ob = S.Obstacle(31, "dynamic", "truck", 9.0, 3.2, 0, np.array([20.0, 1.75, math.pi, 8.0]), np.zeros((0, 4)))
+        dev, ref, view = _both(torch_cuda, [lane1, lane2], [ob], path, np.array([0.0, -1.75]), 0.0, 8.0)
+        assert [p.agent_type for p in ref] == ["Car", "Bicycle"]
+        _same(dev, ref, view)
+        n += len(dev)
+        for step in (20, 25, 33):
+            ego = ego0[:2] + 0.7634 * step * np.array([math.cos(yaw), math.sin(yaw)])
+            dev, ref, view = _both(torch_cuda, sc.lanelets, sc.obstacles, path1, ego, yaw, float(ego0[3]),
+                                   intersections=sc.intersections, timestep=step)
+            _same(dev, ref, view)
+            n += sum(p.agent_type in ("Car", "Bicycle") for p in dev)
+        n_vehicles[form] = n
+    assert n_vehicles["runs"] == n_vehicles["nodes"] >= 5
+
+
 def test_scenario1_steps(torch_cuda):
     """the scenario-1 fixture (12 lanelets, an intersection, parked and moving obstacles) at time steps 0 / 8 / 25 / 60"""
     from frenetix_occlusion import scenario as S

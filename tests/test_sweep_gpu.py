@@ -492,6 +492,41 @@ def test_be_metric_matches_oracle(torch_cuda, oracle):
         sw.run(traj["x"], traj["y"], traj["theta"], traj["v"], None)
 
 
+def test_dce_matches_the_references_own_walk_over_the_time_steps(torch_cuda):
+    """the device's DCE / TTC / TTCE / WTTC against tests/golden/dce_loop.npz -- what the reference's own, unmodified DCE class
+    and the three metrics on top of it returned (gen_golden.py dce; only the rectangle distance under the loop is this
+    repository's): distances to 1e-9 (they are whole millimetres), time_dce, ttc, ttce, wttc exact"""
+    from golden_util import load_dce_case
+    from oracle import fo_oracle as O
+    g, traj, agents, veh, dt = load_dce_case()
+    for mode in ("full", "reduced"):
+        got = _hip_sweep(torch_cuda, traj, agents, veh, dt, metrics=("dce", "ttc", "ttce", "wttc"), mode=mode)
+        assert np.array_equal(got["cost"][:, O.COST["wttc"]], g["ref_wttc"])
+        np.testing.assert_allclose(got["cost"][:, O.COST["min_dce"]], g["ref_dce"].min(axis=1), rtol=0, atol=1e-9)
+        if mode == "full":
+            np.testing.assert_allclose(got["pair_f"][..., O.PF["dce"]], g["ref_dce"], rtol=0, atol=1e-9)
+            assert np.array_equal(got["pair_i"][..., O.PI["time_dce"]], g["ref_time_dce"])
+            assert np.array_equal(got["pair_f"][..., O.PF["ttc"]], g["ref_ttc"])
+            assert np.array_equal(got["pair_f"][..., O.PF["ttce"]], g["ref_ttce"])
+
+
+def test_be_metric_matches_the_references_own_bisection(torch_cuda):
+    """the device's BE against tests/golden/be_bisection.npz -- what the reference's own, unmodified BE class returned
+    (gen_golden.py be; only the rectangle `intersects` predicate under it is this repository's): every required deceleration
+    and brake threat number, in full and in reduced mode (max_btn)"""
+    from golden_util import load_be_case
+    g, traj, agents, veh, dt = load_be_case()
+    metrics = ("dce", "ttc", "be")
+    got = _hip_sweep(torch_cuda, traj, agents, veh, dt, metrics=metrics, thr={"be": 0.2})
+    from oracle import fo_oracle as O
+    np.testing.assert_allclose(got["pair_f"][..., O.PF["be_decel"]], g["be_decel"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got["pair_f"][..., O.PF["be_btn"]], g["be_btn"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got["cost"][:, O.COST["max_btn"]], g["be_btn"].max(axis=1), rtol=0, atol=1e-12)
+    assert np.array_equal(got["safe"].astype(bool), ~(g["be_btn"].max(axis=1) > 0.2))       # metric.py:54-61
+    red = _hip_sweep(torch_cuda, traj, agents, veh, dt, metrics=metrics, thr={"be": 0.2}, mode="reduced")
+    assert np.array_equal(red["cost"], got["cost"]) and np.array_equal(red["safe"], got["safe"])
+
+
 def test_empty_trajectory_batch_and_single_lane(torch_cuda, oracle):
     from frenetix_occlusion import synthetic as S
     traj, agents = S.make_batch(65, 3, config_id=12)
