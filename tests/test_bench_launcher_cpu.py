@@ -51,3 +51,25 @@ def test_a_failing_worker_fails_the_launcher():
     p, _ = _run({"FO_BENCH_LAUNCH_TIMEOUT": "120"}, ["--gpus", "2", "--launcher-selftest", "--M", "8", "--steps", "1",
                                                      "--mode", "nonsense"])
     assert p.returncode != 0
+
+
+def test_byte_figures_of_the_bench_line():
+    """the bench line's own arithmetic (no GPU): SURVEY 8d's bytes of the headline batch, what the build stores per list
+    format -- `f32x` is float32 ELEMENTS, priced at 4 bytes (round 5 priced it at 8 and printed 6.9 TB/s "stored") --, the
+    consistency checks between them, and the word for the binding unit"""
+    sys.path.insert(0, ROOT)
+    import bench
+    M, A, T = 10000, 256, 31
+    assert bench.bytes_8d(M, A, T, "full") == 10000 * 620 + 256 * 636 + 2560000 * 648 == 1665242816
+    s64, s32, s32x = (bench.bytes_stored(M, A, T, "full", f) for f in ("f64", "f32", "f32x"))
+    assert s32 == s32x == 1843338240 and s64 - s32 == M * A * 5 * 30 * 4
+    # the figures of round 5's line: algorithmic <= stored <= 1.1 x counter traffic, nothing above what a fill reaches
+    checks, ok = bench.roofline_checks(1665242816, s32x, 0.488e-3, 1993311232.0)
+    assert ok and all(v is True for v in checks.values())
+    # ... and what round 5 printed: float64-list bytes for the f32x run -- 6.9 TB/s, and 1.7 x the counter traffic
+    checks, ok = bench.roofline_checks(1665242816, s64, 0.488e-3, 1993311232.0)
+    assert not ok and checks["achieved_stored_le_hbm_achievable"] is False and checks["stored_le_1p1_traffic"] is False
+    checks, ok = bench.roofline_checks(1665242816, s32x, 0.488e-3, None)          # no counters: that check is skipped, not failed
+    assert ok and checks["stored_le_1p1_traffic"] is None
+    assert bench.bound_word(0.95, 0.52) == "hbm" and bench.bound_word(0.03, 0.85) == "valu-issue"
+    assert bench.bound_word(0.62, 0.58) == "latency/issue mix (hbm 0.62, valu 0.58)"
