@@ -354,7 +354,7 @@ def live_pmc(lists_fmt, mode="full"):
             cmd = [exe, "--pmc", *grp, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-autotune",
                    "--no-extras", "--no-live-pmc", "--mode", mode, "--lists", lists_fmt]
-            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240,
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150,
                                env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")), cwd=top)
             if r.returncode != 0:
                 return None
