@@ -354,9 +354,21 @@ def live_pmc(lists_fmt, mode="full"):
             cmd = [exe, "--pmc", *grp, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-autotune",
                    "--no-extras", "--no-live-pmc", "--mode", mode, "--lists", lists_fmt]
-            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150,
-                               env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")), cwd=top)
-            if r.returncode != 0:
+            # (a session of its own: should a pass hang, the profiler AND the bench child under it are ended -- exactly the
+            # process group started here, nothing matched by name)
+            pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True,
+                                  env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")), cwd=top)
+            try:
+                rc = pr.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return None
+            if rc != 0:
                 return None
             acc = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
