@@ -32,6 +32,11 @@ struct Sync {
   unsigned int xcd_n[8];     // workgroups per XCD (written by a census pass)
 };
 
+// phase stamps of ONE barrier (round g_trace_round, -1 = off): per workgroup its XCD, the wall clock (100 MHz) when thread 0 has
+// released its stores and is about to arrive, when it has seen the count complete, and when its acquire is done
+__device__ long long *g_trace = nullptr;
+__device__ int g_trace_round = -1;
+
 __device__ __forceinline__ int xcc_id() {
   int v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -48,7 +53,9 @@ __device__ __forceinline__ void grid_barrier(Sync *s, unsigned int round, unsign
   if (is_xcd0(KIND)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every wave: its stores have completed in the L2
   __syncthreads();
   if (threadIdx.x == 0) {
+    const bool tr = g_trace && (int)round == g_trace_round;
     if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (tr) { g_trace[4 * blockIdx.x] = xcc_id(); g_trace[4 * blockIdx.x + 1] = wall_clock64(); }
     if (is_xcd0(KIND)) {
       __hip_atomic_fetch_add(&s->xcd[0][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (hier) {
@@ -85,7 +92,9 @@ __device__ __forceinline__ void grid_barrier(Sync *s, unsigned int round, unsign
         if (waited > 50000000ll) { __hip_atomic_store(&s->pad0[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         if (waited > 10000ll && __hip_atomic_load(&s->pad0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
+      if (tr) g_trace[4 * blockIdx.x + 2] = wall_clock64();
       if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (tr) g_trace[4 * blockIdx.x + 3] = wall_clock64();
     }
   }
   __syncthreads();
@@ -222,6 +231,41 @@ int main(int argc, char **argv) {
   CHECK(hipMemset(d_buf, 0, sizeof(double) * max_elems));
   const int Gs[] = {64, 256, 512, 1024, 2048};
   const int Ws[] = {64, 8192};   // 512 B and 64 KB per workgroup and round
+  if (!strcmp(only, "trace")) {
+    // one barrier of the best cross-XCD variant (counter per XCD, one fence pair per workgroup) under the stamps: who arrives
+    // when, who is let go when, per XCD
+    for (int G : {64, 256}) {
+      long long *d_tr;
+      CHECK(hipMalloc((void **)&d_tr, sizeof(long long) * 4 * G));
+      CHECK(hipMemset(d_tr, 0, sizeof(long long) * 4 * G));
+      const int round = N;   // (the first barrier of round N / 2 of the kernel's loop: warm)
+      CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &d_tr, sizeof(d_tr)));
+      CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_round), &round, sizeof(round)));
+      if (run_persistent<HLEAN>("hlean", G, 256, 64, N, d_s, d_buf, d_err, d_ticks)) return 1;
+      std::vector<long long> h(4 * G);
+      CHECK(hipMemcpy(h.data(), d_tr, sizeof(long long) * 4 * G, hipMemcpyDeviceToHost));
+      long long t0 = h[1], last_arr = h[1];
+      for (int b = 0; b < G; ++b) { if (h[4 * b + 1] < t0) t0 = h[4 * b + 1]; if (h[4 * b + 1] > last_arr) last_arr = h[4 * b + 1]; }
+      printf("trace    G=%4d: one barrier, us from the first arrival; the last workgroup arrives at %.2f\n", G, (last_arr - t0) * 0.01);
+      for (int x = 0; x < 8; ++x) {
+        long long a0 = 1ll << 62, a1 = 0, r0 = 1ll << 62, r1 = 0, q1 = 0;
+        int n = 0;
+        for (int b = 0; b < G; ++b)
+          if (h[4 * b] == x) {
+            ++n;
+            a0 = h[4 * b + 1] < a0 ? h[4 * b + 1] : a0; a1 = h[4 * b + 1] > a1 ? h[4 * b + 1] : a1;
+            r0 = h[4 * b + 2] < r0 ? h[4 * b + 2] : r0; r1 = h[4 * b + 2] > r1 ? h[4 * b + 2] : r1;
+            q1 = h[4 * b + 3] > q1 ? h[4 * b + 3] : q1;
+          }
+        if (n) printf("   XCD %d (%3d workgroups): arrivals %.2f .. %.2f, count seen complete %.2f .. %.2f, acquire done by %.2f\n", x, n,
+                      (a0 - t0) * 0.01, (a1 - t0) * 0.01, (r0 - t0) * 0.01, (r1 - t0) * 0.01, (q1 - t0) * 0.01);
+      }
+      const int off = -1;
+      CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_round), &off, sizeof(off)));
+      CHECK(hipFree(d_tr));
+    }
+    return 0;
+  }
   if (!strcmp(only, "chain")) {
     for (int G : {64, 256, 1024}) if (run_chain(G, 256, 64, N, d_buf, d_err)) return 1;
     return 0;
