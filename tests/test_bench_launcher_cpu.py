@@ -73,3 +73,47 @@ def test_byte_figures_of_the_bench_line():
     assert ok and checks["stored_le_1p1_traffic"] is None
     assert bench.bound_word(0.95, 0.52) == "hbm" and bench.bound_word(0.03, 0.85) == "valu-issue"
     assert bench.bound_word(0.62, 0.58) == "latency/issue mix (hbm 0.62, valu 0.58)"
+
+
+def test_live_counter_passes_are_parsed_and_failures_fall_back(tmp_path, monkeypatch):
+    """bench.live_pmc without a GPU: a stand-in `rocprofv3` on PATH that writes what the real one does for `--pmc ... --output-format
+    csv -d DIR` (one row per dispatch and counter).  Parsed: the mean per launch of the headline instantiation only (not the
+    correlated-covariance body's name, not other kernels), KB -> bytes, FETCH_SIZE x 2, the issue fraction; a pass that fails,
+    or one that lacks a counter, yields None (the bench line then falls back to the committed summary)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text('''#!%s
+import os, sys
+a = sys.argv[1:]
+if os.environ.get("FAKE_FAIL") == "1":
+    sys.exit(3)
+ctrs = a[a.index("--pmc") + 1:a.index("--kernel-trace")]
+d = a[a.index("-d") + 1]
+os.makedirs(os.path.join(d, "host", "123"), exist_ok=True)
+vals = {"FETCH_SIZE": 70000.0, "WRITE_SIZE": 1800000.0, "GRBM_GUI_ACTIVE": 8.0e6, "SQ_INSTS_VALU": 1.5e8}
+names = ["void (anonymous namespace)::fo_sweep_queue_kernel<true, 3, true, false>((anonymous namespace)::SweepArgs)",
+         "void (anonymous namespace)::fo_sweep_queue_kernel<true, 3, true, true>((anonymous namespace)::SweepArgs)",
+         "(anonymous namespace)::fo_reduce_kernel(int)"]
+with open(os.path.join(d, "host", "123", "run_counter_collection.csv"), "w") as f:
+    f.write("Kernel_Name,Counter_Name,Counter_Value\\n")
+    for rep in range(4):
+        for k, n in enumerate(names):
+            for c in ctrs:
+                if os.environ.get("FAKE_DROP") == c:
+                    continue
+                f.write('"%%s",%%s,%%r\\n' %% (n, c, vals[c] * (1 if k == 0 else 7)))
+''' % sys.executable)
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    got = bench.live_pmc("f32x")
+    assert got is not None and got["launches"] == 4
+    assert got["traffic"] == (1800000.0 + 2 * 70000.0) * 1024.0
+    assert abs(got["valu_issue_frac"] - 1.5e8 * 4 / (1024 * 8.0e6 / 8)) < 1e-12
+    assert not [p for p in os.listdir(tmp_path) if p.startswith("fo_pmc_")]        # its scratch directory is gone
+    monkeypatch.setenv("FAKE_DROP", "WRITE_SIZE")
+    assert bench.live_pmc("f32x") is None
+    monkeypatch.delenv("FAKE_DROP")
+    monkeypatch.setenv("FAKE_FAIL", "1")
+    assert bench.live_pmc("f32x") is None
