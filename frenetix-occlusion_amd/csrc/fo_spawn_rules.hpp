@@ -628,24 +628,39 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       if (s_obsd[0] < pr.ego_s + 3.0 || fabs(s_obsd[1]) > 15.0) break;            // :234
       if (s_inter >= 0 && n_ob > 0 && all_inner && v.pred0 && v.pred0[first_rel] >= 0 && s_npol < 8) s_pol[s_npol++] = v.pred0[first_rel];   // :249-252
       s_go = 1;
-      // where the candidate polygons' vertices go in LDS (member() below); too many vertices: read from HBM as before
-      int tot = 0;
-      for (int i = 0; i < s_npol; ++i) { s_poff[i] = tot; tot += v.poly_off[s_pol[i] + 1] - v.poly_off[s_pol[i]]; }
-      s_poff[s_npol] = tot;
-      s_plds = tot <= RL_PVERT;
     } while (false);
   }
   __syncthreads();
   if (!s_go) return;
   RL_TICK(0);
   const int npol = s_npol;
+  // where the candidate polygons' vertices go in LDS (member() below); too many vertices: read from HBM as before.  (Round 6:
+  // a thread per polygon asks for its offsets, then ONE flat copy of all vertices -- thread 0 used to walk the offset table,
+  // sixteen loads one after the other, and the copy ran polygon by polygon behind a load of its own each)
+  __shared__ int s_pb0[8], s_plen[8];
+  if (tid < npol) {
+    const int p = s_pol[tid], b0 = v.poly_off[p];
+    s_pb0[tid] = b0;
+    s_plen[tid] = v.poly_off[p + 1] - b0;
+  }
+  if (tid < 4 * npol) s_pbox[tid] = v.poly_box[4 * (size_t)s_pol[tid >> 2] + (tid & 3)];
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int i = 0; i < npol; ++i) { s_poff[i] = tot; tot += s_plen[i]; }
+    s_poff[npol] = tot;
+    s_plds = tot <= RL_PVERT;
+  }
+  __syncthreads();
   const bool plds = s_plds != 0;
+  RL_WTICK(2);
   if (plds) {
-    for (int i = 0; i < npol; ++i) {
-      const int b0 = v.poly_off[s_pol[i]], n_ = s_poff[i + 1] - s_poff[i];
-      for (int k = tid; k < 2 * n_; k += nth) polyv[2 * s_poff[i] + k] = v.poly_xy[2 * (size_t)b0 + k];
+    const int n2 = 2 * s_poff[npol];
+    for (int k = tid; k < n2; k += nth) {
+      int i = 0;
+      while (i + 1 < npol && k >= 2 * s_poff[i + 1]) ++i;
+      polyv[k] = v.poly_xy[2 * (size_t)s_pb0[i] + (k - 2 * s_poff[i])];
     }
-    if (tid < 4 * npol) s_pbox[tid] = v.poly_box[4 * (size_t)s_pol[tid >> 2] + (tid & 3)];
   }
   // (the relevance flags move to the end of `lab`'s companion array later; keep a compact copy for the centroid test)
   unsigned char *relflag = fitok + 1536;   // [P] bit0: relevant -- only consulted for the few lanelets holding the centroid
@@ -653,6 +668,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   if (rel_fits)
     for (int p = tid; p < v.P; p += nth) relflag[p] = (unsigned char)(ired[p] & 1);
   __syncthreads();
+  RL_WTICK(3);
   // membership of a point in the candidate region's defining sets (:254-277)
   const double diff = fmod(fabs(oy - pr.ego_yaw), 6.283185307179586);
   const bool wedge = 3.141592653589793 - RL_TOL_SAME_DIR <= diff && diff <= 3.141592653589793 + RL_TOL_SAME_DIR;
@@ -718,13 +734,26 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       g_lab[i] = mi ? (i | ((mi - 1) << 16)) : 0x7fffffff;      // (+ which polygon held the node: the fits' hint)
     }
     __shared__ int s_ticket;
-    __threadfence();
+    RL_WTICK(4);
+    // Hand-off with ONE release and ONE acquire per workgroup (round 6).  The fences are whole-cache operations -- the release
+    // writes the XCD's L2 back, the acquire invalidates the CU's L1 and the L2's non-local lines -- and sixteen waves issuing
+    // them one after the other cost 5 us on the releasing and 3 us on the acquiring side (stamps of the trace build;
+    // tools/microbench/grid_barrier.hip: the same finding for a grid barrier).  The workgroup barrier in front orders every
+    // wave's stores before thread 0's release (its cumulativity carries them to agent scope), the one behind holds the
+    // other waves' loads back until thread 0's acquire has been executed for the CU they share.
     __syncthreads();
-    if (tid == 0) s_ticket = atomicAdd(g_cnt, 1);
+    if (tid == 0) {
+      __threadfence();
+      s_ticket = atomicAdd(g_cnt, 1);
+    }
     __syncthreads();
+    RL_WTICK(5);
     if (s_ticket != RL_PARTS - 1) return;
-    if (tid == 0) *g_cnt = 0;   // for the next planning step (launches on a stream are ordered)
-    __threadfence();
+    if (tid == 0) {
+      *g_cnt = 0;   // for the next planning step (launches on a stream are ordered)
+      __threadfence();
+    }
+    __syncthreads();
     const volatile int *gl = g_lab;
     for (int i = tid; i < NL; i += nth) { const int w = gl[i]; lab[i] = w == 0x7fffffff ? w : (w & 0xffff); }
   }

@@ -68,5 +68,9 @@ for step in (0, 8, 25, 60):
                 w = np.array(list(t), dtype=np.int64).reshape(1024, 8)
                 ok = w[:, 0] > 0
                 k0 = w[ok, 0].min()
+                dyn = w[:, 5] > 0          # workgroups of the dynamic rule's lattice: tables staged | set-up barrier | nodes done | ticket taken
+                if dyn.any():
+                    for col, name in ((2, "decisions + offsets"), (3, "polygons staged"), (4, "nodes decided"), (5, "ticket taken")):
+                        print("      lattice workgroups, %-20s %.1f .. %.1f" % (name + ":", (w[dyn, col].min() - k0) * 0.01, (w[dyn, col].max() - k0) * 0.01))
                 print("   from the launch's first wave (us): last workgroup started %.1f, path tables in LDS (latest) %.1f, phase stamps %s"
                       % ((w[ok, 0].max() - k0) * 0.01, (w[ok, 1].max() - k0) * 0.01, np.round((h[:7] - k0) * 0.01, 1).tolist()))
