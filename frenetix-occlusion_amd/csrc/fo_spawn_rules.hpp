@@ -40,6 +40,11 @@ __device__ long long g_rule_wticks[8 * 1024];
 #else
 #define RL_WTICK(i) do { } while (0)
 #endif
+#if FO_RULE_TRACE == 3   // tuning: stamps inside the dynamic rule's SET-UP (slots 2..7 of the workgroup's row)
+#define RL_STICK(i) RL_WTICK(i)
+#else
+#define RL_STICK(i) do { } while (0)
+#endif
 #if FO_RULE_TRACE == 2   // tuning: stamps INSIDE the first rectangle fit instead of after the two fits (slots 5, 6, 7)
 #define RL_TICKF(i) do { __syncthreads(); if (threadIdx.x == 0 && rec[16 + (i)] == 0.0) rec[16 + (i)] = (double)wall_clock64(); } while (0)
 #else
@@ -149,6 +154,73 @@ __device__ inline bool rl_in_polygon(const RuleView &v, int p, double x, double 
   const double2 *xy = (const double2 *)v.poly_xy;
   return rl_crossing_parity(b, e, x, y, [&](int k) { return xy[k]; }) != 0;
 }
+// the same test by a whole wave (uniform arguments): a lane per edge -- bounding box, offsets and vertices are one round trip each,
+// where a thread on its own walks the ring in chunks (1 + 1 + 1 + ceil(n / 8) trips); the edge arithmetic is that of
+// rl_crossing_parity, the parity comes from a ballot
+__device__ inline bool rl_in_polygon_wave(const RuleView &v, int p, double x, double y) {
+  const int lane = threadIdx.x & 63;
+  const int b = v.poly_off[p], e = v.poly_off[p + 1];
+  const double2 *xy = (const double2 *)v.poly_xy;
+  int c = 0;
+  for (int i0 = b; i0 < e; i0 += 64) {
+    const int i = i0 + lane;
+    bool cross = false;
+    if (i < e) {
+      const double2 pi = xy[i], pj = xy[i == b ? e - 1 : i - 1];
+      if ((pi.y > y) != (pj.y > y)) {
+        const double xc = pi.x + (y - pi.y) * (pj.x - pi.x) / (pj.y - pi.y);
+        cross = x < xc;
+      }
+    }
+    c ^= (int)(__popcll(__ballot(cross)) & 1);
+  }
+  return c != 0;
+}
+
+// "Which lanelets hold these points?" for a workgroup (round 6): nq query points x P lanelets.  Pass A, a thread per (point,
+// lanelet): the bounding box -- one round trip -- and the survivors (a handful: a point lies in two or three boxes) go to a list
+// in LDS; pass B, a WAVE per survivor: the crossing-number test a lane per edge.  Three round trips and a barrier, where the
+// thread-per-pair form took seven trips per test and ran the tests of one thread one after the other (the dynamic rule's set-up
+// spent 7 of its 9 us there, stamps of the trace build -DFO_RULE_TRACE=3).  `keep(q, p)`: pairs worth asking at all;
+// `act(q, p)`: called by lane 0 of the wave that found point q inside lanelet p -- the callers combine with atomics, so the
+// order of the list does not matter.  *n_hits must be 0 on entry (and a barrier passed since); more survivors than the list
+// holds: the thread-per-pair form.  Every thread of the workgroup must call; ends with a barrier.
+template <class PT, class KEEP, class ACT>
+__device__ __forceinline__ void rl_which_lanelets(const RuleView &v, int nq, PT point, KEEP keep, ACT act, int *hits, int cap, int *n_hits) {
+  const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
+  const unsigned total = (unsigned)nq * (unsigned)v.P;
+  for (unsigned w = tid; w < total; w += nth) {
+    const int q = (int)(w / (unsigned)v.P), p = (int)(w - (unsigned)q * (unsigned)v.P);
+    if (!keep(q, p)) continue;
+    double x, y;
+    point(q, x, y);
+    const double *bb = v.poly_box + 4 * (size_t)p;
+    if (x < bb[0] || x > bb[2] || y < bb[1] || y > bb[3]) continue;
+    const int h = atomicAdd(n_hits, 1);
+    if (h < cap) hits[h] = (q << 16) | p;
+  }
+  __syncthreads();
+  const int nh = *n_hits;
+  if (nh <= cap && v.P < 65536) {
+    for (int h = wave; h < nh; h += nw) {
+      const int q = hits[h] >> 16, p = hits[h] & 0xffff;
+      double x, y;
+      point(q, x, y);
+      const bool in = rl_in_polygon_wave(v, p, x, y);
+      if (in && lane == 0) act(q, p);
+    }
+  } else {
+    for (unsigned w = tid; w < total; w += nth) {
+      const int q = (int)(w / (unsigned)v.P), p = (int)(w - (unsigned)q * (unsigned)v.P);
+      if (!keep(q, p)) continue;
+      double x, y;
+      point(q, x, y);
+      if (rl_in_polygon(v, p, x, y)) act(q, p);
+    }
+  }
+  __syncthreads();
+}
+
 __device__ inline int rl_lanelet_of(const RuleView &v, double x, double y) {   // first lanelet (list order) holding the point
   for (int p = 0; p < v.P; ++p)
     if (rl_in_polygon(v, p, x, y)) return p;
@@ -531,7 +603,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   const double cx = ocen[2 * o], cy = ocen[2 * o + 1], oy = oyaw[o], olen = odims[2 * o], owid = odims[2 * o + 1];
   const double *oc = ocorn + 8 * (size_t)o;
   __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn, s_ego_ll, s_inter, s_nin, s_in[16], s_vll[64], s_relc, s_curv_ok;
-  __shared__ int s_poff[9], s_plds, s_inter_first;
+  __shared__ int s_poff[9], s_plds, s_inter_first, s_nhit;
   __shared__ double s_c[2], s_yaw, s_pbox[32], s_obsd[2];
   // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
   // oncoming neighbours (adj_left) of the lanelets under every fifth vertex of the reference window.  Flags per lanelet
@@ -542,26 +614,31 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   for (int p = tid; p < v.P; p += nth) ired[p] = 0;
   if (tid == 0) {
     rec[2] = 0.0; rec[5] = 0.0;
-    s_go = 0; s_npol = 0; s_inter = -1; s_inter_first = 0x7fffffff; s_ego_ll = 0x7fffffff; s_nin = 0; s_relc = 0; s_curv_ok = 0;
+    s_go = 0; s_npol = 0; s_inter = -1; s_inter_first = 0x7fffffff; s_ego_ll = 0x7fffffff; s_nin = 0; s_relc = 0; s_curv_ok = 0; s_nhit = 0;
   }
   if (tid < 64) s_vll[tid] = 0x7fffffff;
   __syncthreads();
+  RL_STICK(2);
   // (measured and dropped, round 6: the lanelets under every fifth vertex of the reference window -- needed when the ego turns
   // out to be in no intersection, two barriers further down -- asked in this same pass: +4 us in front of the lattice where
   // there IS an intersection, the usual case of the rule)
-  for (int p = tid; p < v.P; p += nth) {
-    if (rl_in_polygon(v, p, pr.ego_x, pr.ego_y)) atomicMin(&s_ego_ll, p);
-    if (rl_in_polygon(v, p, cx, cy)) {   // the obstacle's lanelets (also flagged: more than sixteen are re-collected in list order below)
-      atomicOr(&ired[p], 4);
-      const int q = atomicAdd(&s_nin, 1);
-      if (q < 16) s_in[q] = p;
-    }
-  }
+  // the lanelets under the ego (the first in list order) and under the obstacle's centre (all of them; also flagged: more than
+  // sixteen are re-collected in list order below); the hit list borrows the lattice array, which is idle until the hand-off
+  rl_which_lanelets(v, 2, [&](int q, double &x, double &y) { x = q == 0 ? pr.ego_x : cx; y = q == 0 ? pr.ego_y : cy; },
+                    [](int, int) { return true; },
+                    [&](int q, int p) {
+                      if (q == 0) { atomicMin(&s_ego_ll, p); return; }
+                      atomicOr(&ired[p], 4);
+                      const int k = atomicAdd(&s_nin, 1);
+                      if (k < 16) s_in[k] = p;
+                    }, lab, 2048, &s_nhit);
+  RL_STICK(3);
   if (tid < 64) {   // the obstacle's curvilinear position (wave 0)
     double ob_s, ob_d;
     const bool okc = rl_to_curv_wave(v, cx, cy, ob_s, ob_d);
-    if (tid == 0) { s_curv_ok = okc ? 1 : 0; s_obsd[0] = ob_s; s_obsd[1] = ob_d; }
+    if (tid == 0) { s_curv_ok = okc ? 1 : 0; s_obsd[0] = ob_s; s_obsd[1] = ob_d; s_nhit = 0; }
   }
+  RL_STICK(4);
   __syncthreads();
   if (s_ego_ll == 0x7fffffff) return;
   // the first intersection (list order) that lists the ego's lanelet: a thread per table entry and an atomicMin on the
@@ -578,6 +655,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   __syncthreads();
   if (tid == 0) s_inter = s_inter_first == 0x7fffffff ? -1 : s_inter_first;
   __syncthreads();
+  RL_STICK(5);
   if (s_inter >= 0) {
     for (int e = v.inter_off[s_inter] + tid; e < v.inter_off[s_inter + 1]; e += nth) {
       const int p = v.inter_lanelet[e];
@@ -585,19 +663,17 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     }
   } else if (v.adj_left) {
     const int nv = min((pr.win_i1 - pr.win_i0 + 4) / 5, 64);   // every fifth vertex of the reference window (40 m: a dozen)
-    for (unsigned w = tid; w < (unsigned)nv * (unsigned)v.P; w += nth) {   // (<= 64 x 9 409 pairs: 32-bit index arithmetic)
-      const int vi = (int)(w / (unsigned)v.P), p = (int)(w - (unsigned)vi * (unsigned)v.P);
-      const double *q = v.path + 6 * (size_t)(pr.win_i0 + 5 * vi);
-      if (rl_in_polygon(v, p, q[0], q[1])) atomicMin(&s_vll[vi], p);
-    }
-    __syncthreads();
+    rl_which_lanelets(v, nv, [&](int q, double &x, double &y) { const double *w_ = v.path + 6 * (size_t)(pr.win_i0 + 5 * q); x = w_[0]; y = w_[1]; },
+                      [](int, int) { return true; }, [&](int q, int p) { atomicMin(&s_vll[q], p); }, lab, 2048, &s_nhit);
     if (tid < nv) {
       const int ll = s_vll[tid];
       if (ll != 0x7fffffff && v.adj_left[ll] >= 0) atomicOr(&ired[v.adj_left[ll]], 1);
     }
   }
   __syncthreads();
+  RL_STICK(6);
   if (tid == 0) {
+    s_nhit = 0;   // (the next lanelet query -- the centroid's -- finds its list empty)
     do {
       if (sqrt((pr.ego_x - cx) * (pr.ego_x - cx) + (pr.ego_y - cy) * (pr.ego_y - cy)) > RL_MAX_DIST_OBST) break;   // :215
       // the obstacle's lanelets (all that hold its centre) in list order.  Up to sixteen arrived through the atomic counter
@@ -631,6 +707,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     } while (false);
   }
   __syncthreads();
+  RL_STICK(7);
   if (!s_go) return;
   RL_TICK(0);
   const int npol = s_npol;
@@ -653,7 +730,9 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   }
   __syncthreads();
   const bool plds = s_plds != 0;
+#if FO_RULE_TRACE != 3
   RL_WTICK(2);
+#endif
   if (plds) {
     const int n2 = 2 * s_poff[npol];
     for (int k = tid; k < n2; k += nth) {
@@ -668,7 +747,9 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   if (rel_fits)
     for (int p = tid; p < v.P; p += nth) relflag[p] = (unsigned char)(ired[p] & 1);
   __syncthreads();
+#if FO_RULE_TRACE != 3
   RL_WTICK(3);
+#endif
   // membership of a point in the candidate region's defining sets (:254-277)
   const double diff = fmod(fabs(oy - pr.ego_yaw), 6.283185307179586);
   const bool wedge = 3.141592653589793 - RL_TOL_SAME_DIR <= diff && diff <= 3.141592653589793 + RL_TOL_SAME_DIR;
@@ -734,7 +815,9 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       g_lab[i] = mi ? (i | ((mi - 1) << 16)) : 0x7fffffff;      // (+ which polygon held the node: the fits' hint)
     }
     __shared__ int s_ticket;
+#if FO_RULE_TRACE != 3
     RL_WTICK(4);
+#endif
     // Hand-off with ONE release and ONE acquire per workgroup (round 6).  The fences are whole-cache operations -- the release
     // writes the XCD's L2 back, the acquire invalidates the CU's L1 and the L2's non-local lines -- and sixteen waves issuing
     // them one after the other cost 5 us on the releasing and 3 us on the acquiring side (stamps of the trace build;
@@ -747,7 +830,9 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       s_ticket = atomicAdd(g_cnt, 1);
     }
     __syncthreads();
+#if FO_RULE_TRACE != 3
     RL_WTICK(5);
+#endif
     if (s_ticket != RL_PARTS - 1) return;
     if (tid == 0) {
       *g_cnt = 0;   // for the next planning step (launches on a stream are ordered)
@@ -1023,11 +1108,13 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     s_yawok = rl_lane_yaw_at(v, s_c[0], s_c[1], yw) ? 1 : 0;
     s_yaw = yw;
   }
-  if (rel_fits) {   // the centroid must lie on a relevant lanelet (:287-291): every lanelet asked at once
-    for (int p = tid; p < v.P; p += nth)
-      if ((relflag[p] & 1) && rl_in_polygon(v, p, s_c[0], s_c[1])) s_relc = 1;
+  if (rel_fits) {   // the centroid must lie on a relevant lanelet (:287-291): every relevant lanelet asked at once
+    // (s_nhit: zero since the set-up's last query -- the hand-off and four barriers lie between; the list borrows the tail of `red`)
+    rl_which_lanelets(v, 1, [&](int, double &x, double &y) { x = s_c[0]; y = s_c[1]; }, [&](int, int p) { return (relflag[p] & 1) != 0; },
+                      [&](int, int) { s_relc = 1; }, (int *)(red + 64), 2048, &s_nhit);
+  } else {
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) {
     s_go = 0;
     do {

@@ -56,6 +56,8 @@ for step in (0, 8, 25, 60):
         h = sl.batch.rule_points.cpu().numpy()[-1]
         if h[0] != 0:
             two = os.environ["FO_RULE_TRACE"] == "2"
+            if os.environ["FO_RULE_TRACE"] == "3":
+                h = h.copy(); h[:7] = h[:7]
             d = np.diff(h[:8] if two else h[:7]) * 0.01
             print("   dynamic-rule phases (us): ", np.round(d, 1).tolist(),
                   "(membership, labelling, sizes, centroid+checks | car fit: clip, sums + rows, hull + rectangle)" if two else
@@ -68,7 +70,13 @@ for step in (0, 8, 25, 60):
                 w = np.array(list(t), dtype=np.int64).reshape(1024, 8)
                 ok = w[:, 0] > 0
                 k0 = w[ok, 0].min()
-                dyn = w[:, 5] > 0          # workgroups of the dynamic rule's lattice: tables staged | set-up barrier | nodes done | ticket taken
+                if os.environ["FO_RULE_TRACE"] == "3":      # stamps inside the dynamic rule's set-up (trace build -DFO_RULE_TRACE=3)
+                    dyn3 = w[:, 7] > 0
+                    for col, name in ((1, "path table in LDS"), (2, "cleared, first barrier"), (3, "lanelets of ego / obstacle asked"), (4, "obstacle projected (wave 0)"),
+                                      (5, "intersection found"), (6, "relevance flags set"), (7, "decisions taken")):
+                        if dyn3.any():
+                            print("      set-up, %-34s %.1f .. %.1f" % (name + ":", (w[dyn3, col].min() - k0) * 0.01, (w[dyn3, col].max() - k0) * 0.01))
+                dyn = (w[:, 5] > 0) & (os.environ["FO_RULE_TRACE"] != "3")         # workgroups of the dynamic rule's lattice: tables staged | set-up barrier | nodes done | ticket taken
                 if dyn.any():
                     for col, name in ((2, "decisions + offsets"), (3, "polygons staged"), (4, "nodes decided"), (5, "ticket taken")):
                         print("      lattice workgroups, %-20s %.1f .. %.1f" % (name + ":", (w[dyn, col].min() - k0) * 0.01, (w[dyn, col].max() - k0) * 0.01))
