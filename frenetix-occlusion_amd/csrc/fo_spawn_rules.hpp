@@ -45,6 +45,12 @@ __device__ long long g_rule_wticks[8 * 1024];
 #else
 #define RL_STICK(i) do { } while (0)
 #endif
+// (thread 0's own clock inside the first rectangle fit, no barrier: trace build -DFO_RULE_TRACE=4)
+#if FO_RULE_TRACE == 4
+#define RL_FTICK(i) do { if (ftr && blockIdx.x < 1024) g_rule_wticks[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define RL_FTICK(i) do { } while (0)
+#endif
 #if FO_RULE_TRACE == 2   // tuning: stamps INSIDE the first rectangle fit instead of after the two fits (slots 5, 6, 7)
 #define RL_TICKF(i) do { __syncthreads(); if (threadIdx.x == 0 && rec[16 + (i)] == 0.0) rec[16 + (i)] = (double)wall_clock64(); } while (0)
 #else
@@ -62,6 +68,9 @@ constexpr int RL_MAXSAMP = 1024;                   // samples of a rule polyline
 constexpr int RL_REC = 24;                         // doubles per per-workgroup record
 constexpr int RL_PATHV = 512;                      // vertices of the reference path table held in LDS (longer paths: read from HBM)
 constexpr int RL_PARTS = 16;                       // workgroups that share a dynamic obstacle's candidate lattice
+#ifndef FO_EXP
+#define FO_EXP 0
+#endif
 constexpr int RL_PVERT = 1024;                     // vertices of a dynamic obstacle's <= 8 candidate lanelet polygons held in LDS
 
 enum { RL_TYPE_CAR = 0, RL_TYPE_BICYCLE = 3, RL_TYPE_PED = 4 };
@@ -125,6 +134,18 @@ __device__ inline bool rl_lane_yaw_at(const RuleView &v, double x, double y, dou
 // (xj - xi) / (yj - yi) on the edges that straddle y), with the vertices fetched EIGHT at a time in front of their tests: the
 // loop used to be a chain of dependent round trips -- a load, a test, a branch per vertex, ~30 of them per lanelet polygon at
 // 0.2-0.5 us each from the L2 -- and every "which lanelet holds this point" of the rule families waited for it (round 6)
+// x < xi + (y - yi) (xj - xi) / (yj - yi) for an edge that straddles y (yi != yj) -- the quotient form is the checker's and
+// decides whenever it is close; everywhere else the sign of s = (x - xi) d - (y - yi)(xj - xi) against the sign of d = yj - yi
+// says the same without the ~40 instructions of a float64 quotient (the listed edges of a band are nearly all straddled by
+// some lane of a wave).  The bound: the computed crossing differs from the real one of the rounded differences by
+// < 2.01 u |m / d| + u |xc| (u = 2^-53; product, quotient and sum round once each), i.e. |s_real| > 3.01 u |m| + u |d xi|
+// decides, and the computed s is within 3.02 u (|t2| + |m|) of s_real; 2^-48 (|t2| + |m| + |d xi|) = 32 u (...) covers both
+// with room.  NaNs fail the comparison and take the quotient.
+__device__ __forceinline__ bool rl_left_of_crossing(double x, double y, double xi, double yi, double xj, double yj) {
+  const double d = yj - yi, m = (y - yi) * (xj - xi), t2 = (x - xi) * d, s = t2 - m;
+  if (fabs(s) > 0x1p-48 * (fabs(t2) + fabs(m) + fabs(d * xi))) return (s < 0.0) != (d < 0.0);
+  return x < xi + m / d;
+}
 template <class GET>
 __device__ __forceinline__ int rl_crossing_parity(int b, int e, double x, double y, GET get) {
   int c = 0;
@@ -603,8 +624,8 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   const double cx = ocen[2 * o], cy = ocen[2 * o + 1], oy = oyaw[o], olen = odims[2 * o], owid = odims[2 * o + 1];
   const double *oc = ocorn + 8 * (size_t)o;
   __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn, s_ego_ll, s_inter, s_nin, s_in[16], s_vll[64], s_relc, s_curv_ok;
-  __shared__ int s_poff[9], s_plds, s_inter_first, s_nhit;
-  __shared__ double s_c[2], s_yaw, s_pbox[32], s_obsd[2];
+  __shared__ int s_poff[9], s_plds, s_inter_first, s_nhit, s_ecnt[1];
+  __shared__ double s_c[2], s_yaw, s_pbox[32], s_obsd[2], s_oc[8];
   // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
   // oncoming neighbours (adj_left) of the lanelets under every fifth vertex of the reference window.  Flags per lanelet
   // in ired[0, P): bit0 relevant, bit1 inner, bit2 holds the obstacle's centre.  Every "which lanelet holds this point" below is asked of all lanelets at
@@ -616,6 +637,8 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     rec[2] = 0.0; rec[5] = 0.0;
     s_go = 0; s_npol = 0; s_inter = -1; s_inter_first = 0x7fffffff; s_ego_ll = 0x7fffffff; s_nin = 0; s_relc = 0; s_curv_ok = 0; s_nhit = 0;
   }
+  if (tid == 0) s_ecnt[0] = 0;   // (edge_band's count, far below)
+  if (tid >= 64 && tid < 72) s_oc[tid - 64] = oc[tid - 64];   // (the obstacle's corners for the shadow test: LDS instead of a load from HBM's caches per edge and point)
   if (tid < 64) s_vll[tid] = 0x7fffffff;
   __syncthreads();
   RL_STICK(2);
@@ -730,7 +753,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   }
   __syncthreads();
   const bool plds = s_plds != 0;
-#if FO_RULE_TRACE != 3
+#if FO_RULE_TRACE < 3
   RL_WTICK(2);
 #endif
   if (plds) {
@@ -747,7 +770,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   if (rel_fits)
     for (int p = tid; p < v.P; p += nth) relflag[p] = (unsigned char)(ired[p] & 1);
   __syncthreads();
-#if FO_RULE_TRACE != 3
+#if FO_RULE_TRACE < 3
   RL_WTICK(3);
 #endif
   // membership of a point in the candidate region's defining sets (:254-277)
@@ -757,6 +780,10 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   // (the tests are a conjunction: cheapest first -- distance, the obstacle grown by 1 m, shadow / occluded class -- and
   // the lanelet polygons, the dear ones, last)
   // returns 0 (not a member) or 1 + the slot of a candidate polygon that holds the point; `hint`: the slot asked first
+  int *const el = (int *)(red + 64);   // [<= RL_PVERT] edge_band's list
+  bool el_on = false;
+  int ftr = 0;   // (trace build 4: thread 0's first point of the first fit)
+  (void)ftr;
   auto member_idx = [&](double x, double y, int hint) -> int {
     const double rx = x - cx, ry = y - cy;
     // sqrt(d2) <= 12 exactly when d2 <= 144: the midpoint between 12 and the next double squares to 144 + 2.1e-14, below the
@@ -767,13 +794,18 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     const double ex_ = fmax(fabs(lx_) - olen / 2.0, 0.0), ey_ = fmax(fabs(ly_) - owid / 2.0, 0.0);
     // minus the obstacle grown by 1 m: sqrt(e2) > 1 exactly when e2 > 1 + 2^-52 (sqrt(1 + 2^-52) = 1 + 2^-53 - ... rounds to 1)
     if (!(ex_ * ex_ + ey_ * ey_ > 1.0000000000000002)) return 0;
+    RL_FTICK(4);
+#if FO_EXP == 2
+    if (false) {
+#else
     if (wedge) {   // the obstacle's own shadow: the sight line ego -> point crosses the rectangle (:264)
+#endif
       bool hit = false;
       const double dx = x - pr.ego_x, dy = y - pr.ego_y;
       for (int i = 0; i < 4 && !hit; ++i) {
         const int j = (i + 1) & 3;
-        const double ex = oc[2 * j] - oc[2 * i], ey = oc[2 * j + 1] - oc[2 * i + 1];
-        const double den = dx * ey - dy * ex, wx = oc[2 * i] - pr.ego_x, wy = oc[2 * i + 1] - pr.ego_y;
+        const double ex = s_oc[2 * j] - s_oc[2 * i], ey = s_oc[2 * j + 1] - s_oc[2 * i + 1];
+        const double den = dx * ey - dy * ex, wx = s_oc[2 * i] - pr.ego_x, wy = s_oc[2 * i + 1] - pr.ego_y;
         if (fabs(den) > 1e-14) {
           // t = tn / den and u = un / den in [0, 1] without the divisions: a correctly rounded quotient is <= 1 exactly
           // when |tn| <= |den| and >= 0 exactly when the signs agree (or tn = 0)
@@ -782,11 +814,46 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
         }
       }
       if (!hit) return 0;
-    } else if (!(rl_class_at(v, x, y) & 4)) {   // the global occluded area (:272)
+    }
+#if FO_EXP != 2
+    else if (!(rl_class_at(v, x, y) & 4)) {   // the global occluded area (:272)
       return 0;
     }
+#endif
+#if FO_EXP == 1
+    return hint + 1;
+#endif
+    RL_FTICK(5);
     // possible_polygon (:255): the union of the candidate lanelet polygons -- any order of asking gives the same answer;
     // the polygon that held the nearest lattice node goes first (it holds most points around that node as well)
+    if (el_on) {
+      // ONE pass over the edges listed for the band the point lies in (edge_band below: only those can straddle its y), all
+      // polygons at once: a crossing flips the bit of the edge's polygon -- the crossing number is a parity, the order of the
+      // edges does not matter, each edge is tested by the arithmetic of the ring walk -- and a polygon with an odd count
+      // holds the point if its bounding box does (rl_in_polygon asks the box first; kept, so that the answer is the ring
+      // walk's in every rounding case).  The walk polygon by polygon was a chain of four dependent LDS round trips per
+      // polygon, and a wave walks every polygon one of its lanes needs: 1.3 of the 2.2 us a wave spent per point.
+      const double2 *pv2 = (const double2 *)polyv;
+      const int n = s_ecnt[0];
+      int par = 0;
+      for (int h0 = 0; h0 < n; h0 += 4) {
+        int en[4];
+        double2 pi[4], pj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en[u] = el[h0 + u < n ? h0 + u : n - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { pi[u] = pv2[en[u] & 1023]; pj[u] = pv2[(en[u] >> 10) & 1023]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (h0 + u < n && (pi[u].y > y) != (pj[u].y > y) && rl_left_of_crossing(x, y, pi[u].x, pi[u].y, pj[u].x, pj[u].y)) par ^= 1 << (en[u] >> 20);
+      }
+      for (int i = 0; par != 0 && i < npol; ++i)
+        if ((par >> i) & 1) {
+          const double *bb = s_pbox + 4 * i;
+          if (!(x < bb[0] || x > bb[2] || y < bb[1] || y > bb[3])) return i + 1;
+        }
+      return 0;
+    }
     for (int q = 0; q < npol; ++q) {
       const int i = q == 0 ? hint : (q <= hint ? q - 1 : q);
       if (!plds) {
@@ -800,6 +867,25 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     }
     return 0;
   };
+  // edge_band(ylo, yhi): the edges of the candidate polygons that some y in [ylo, yhi] can straddle (min(yi, yj) <= yhi and
+  // max(yi, yj) > ylo: a straddled edge has min <= y < max) -- round 6.  A lanelet polygon has 50-100 vertices; a band of lattice
+  // rows or a fit's rectangle is crossed by a handful of its edges.  An entry: the edge's vertex | its predecessor in the ring
+  // << 10 | the polygon's slot << 20 (RL_PVERT = 1024 vertices in LDS).  The list borrows the tail of `red` (the lanelet
+  // queries' hit list, idle here) and holds every edge if it must.  The count is zero on entry (cleared behind a barrier
+  // after its last reader); ends with a barrier.
+  static_assert(RL_PVERT <= 1024, "edge_band packs two vertex indices of ten bits");
+  auto edge_band = [&](double ylo, double yhi) {
+    const double2 *pv2 = (const double2 *)polyv;
+    const int tot = s_poff[npol];
+    for (int k = tid; k < tot; k += nth) {
+      int i = 0;
+      while (i + 1 < npol && k >= s_poff[i + 1]) ++i;
+      const int kj = k == s_poff[i] ? s_poff[i + 1] - 1 : k - 1;
+      const double yi = pv2[k].y, yj = pv2[kj].y;
+      if (fmin(yi, yj) <= yhi && fmax(yi, yj) > ylo) el[atomicAdd(&s_ecnt[0], 1)] = k | (kj << 10) | (i << 20);
+    }
+    __syncthreads();
+  };
   // the 0.25 m lattice around the obstacle; label = linear index where the node is a member, INT_MAX elsewhere
   const double h = 0.25;
   constexpr int NL = RL_LAT * RL_LAT;
@@ -809,13 +895,18 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   // are done.  (Every workgroup took the same decisions up to here: they read the same inputs.)
   {
     const int chunk = (NL + RL_PARTS - 1) / RL_PARTS, i1 = min((part + 1) * chunk, NL);
+    if (plds && part * chunk < i1) {   // the rows of this workgroup's slice (the nodes' y by the expression of the loop below: monotone in the row)
+      edge_band(cy + (-RL_BUFFER_SIDE + (double)((part * chunk) / RL_LAT) * h), cy + (-RL_BUFFER_SIDE + (double)((i1 - 1) / RL_LAT) * h));
+      el_on = true;
+    }
     for (int i = part * chunk + tid; i < i1; i += nth) {
       const int ix = i % RL_LAT, iy = i / RL_LAT;
       const int mi = member_idx(cx + (-RL_BUFFER_SIDE + (double)ix * h), cy + (-RL_BUFFER_SIDE + (double)iy * h), 0);
       g_lab[i] = mi ? (i | ((mi - 1) << 16)) : 0x7fffffff;      // (+ which polygon held the node: the fits' hint)
     }
+    el_on = false;
     __shared__ int s_ticket;
-#if FO_RULE_TRACE != 3
+#if FO_RULE_TRACE < 3
     RL_WTICK(4);
 #endif
     // Hand-off with ONE release and ONE acquire per workgroup (round 6).  The fences are whole-cache operations -- the release
@@ -830,7 +921,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       s_ticket = atomicAdd(g_cnt, 1);
     }
     __syncthreads();
-#if FO_RULE_TRACE != 3
+#if FO_RULE_TRACE < 3
     RL_WTICK(5);
 #endif
     if (s_ticket != RL_PARTS - 1) return;
@@ -838,6 +929,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       *g_cnt = 0;   // for the next planning step (launches on a stream are ordered)
       __threadfence();
     }
+    if (tid == 64) s_ecnt[0] = 0;   // (edge_band's count: every reader is past the barriers above)
     __syncthreads();
     const volatile int *gl = g_lab;
     for (int i = tid; i < NL; i += nth) { const int w = gl[i]; lab[i] = w == 0x7fffffff ? w : (w & 0xffff); }
@@ -1095,7 +1187,9 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   auto in_region = [&](double x, double y) {
     const int ix = (int)rint((x - (cx - RL_BUFFER_SIDE)) / h), iy = (int)rint((y - (cy - RL_BUFFER_SIDE)) / h);
     if (ix < 0 || ix >= RL_LAT || iy < 0 || iy >= RL_LAT) return false;
-    return lab[iy * RL_LAT + ix] == best && member_idx(x, y, ired[iy * RL_LAT + ix]) != 0;
+    const int l_ = lab[iy * RL_LAT + ix], hn_ = ired[iy * RL_LAT + ix];
+    RL_FTICK(3);
+    return l_ == best && member_idx(x, y, hn_) != 0;
   };
   // three conditions, independent of each other (:287-300): the centroid on a relevant lanelet -- every lanelet asked at once
   // --, no region in front of the obstacle, a lane heading at the centroid.  Round 6: the last two are taken by the LAST thread
@@ -1145,29 +1239,52 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   RL_TICK(4);
   // rectangle fits on a 0.1 m lattice (:695-726): lane-aligned rectangle clipped to the region -> area, centroid, Jaccard
   // similarity with the minimum rotated rectangle of the clipped part
+  int fitno = 0;
+  (void)fitno;
   const double fc = cos(s_yaw), fs = sin(s_yaw);
   __shared__ double s_fit[4];   // area, cx, cy, jaccard
   __shared__ int s_fitany;
   __shared__ int s_a0[32], s_a1[32], s_nv, s_np2, s_pr[64], s_pc[64];
   __shared__ unsigned long long s_bestA;
-  auto fit = [&](double ccx, double ccy, double length, double width) {
+  auto fit = [&](auto nx_c, auto ny_c, double ccx, double ccy, double length, double width) {
     const double fh = 0.1;
-    const int nx_ = (int)rint(length / fh), ny_ = (int)rint(width / fh), np_ = nx_ * ny_;   // (ny_ <= 32)
+    // (rint(length / fh), rint(width / fh) as constants: the index split below is a multiplication instead of two divisions per point)
+    constexpr int nx_ = decltype(nx_c)::value, ny_ = decltype(ny_c)::value, np_ = nx_ * ny_;   // (ny_ <= 32)
     int cnt = 0;
     double fx = 0.0, fy = 0.0;
+    if (plds) {   // the rectangle's extent in y (+ a micrometre for the roundings of the points' expression below)
+      const double ext = fabs(fs) * (length / 2.0) + fabs(fc) * (width / 2.0) + 1e-6;
+      edge_band(ccy - ext, ccy + ext);
+      el_on = true;
+    }
     for (int i = tid; i < np_; i += nth) {
       const double u = ((double)(i % nx_) + 0.5) * fh - length / 2.0, w_ = ((double)(i / nx_) + 0.5) * fh - width / 2.0;
       const double x = ccx + fc * u - fs * w_, y = ccy + fs * u + fc * w_;
+#if FO_RULE_TRACE == 4
+      ftr = tid < 64 && fitno == 0 && i < 64;
+#endif
+      RL_FTICK(2);
+#if FO_EXP == 3
+      const bool ok = true;
+#else
       const bool ok = in_region(x, y);
+#endif
       fitok[i] = ok ? 1 : 0;
+      RL_FTICK(6);
       if (ok) { ++cnt; fx += x; fy += y; }
+      RL_FTICK(7);
+#if FO_RULE_TRACE == 4
+      ftr = 0;
+#endif
     }
+    el_on = false;
     double fn = (double)cnt;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { fx += __shfl_xor(fx, off); fy += __shfl_xor(fy, off); fn += __shfl_xor(fn, off); }
     if ((tid & 63) == 0) { red[3 * (tid >> 6)] = fx; red[3 * (tid >> 6) + 1] = fy; red[3 * (tid >> 6) + 2] = fn; }
     __syncthreads();
     RL_TICKF(5);
+    if (tid == 128) s_ecnt[0] = 0;   // (edge_band's count, read by the clipping above; barriers follow)
     // the clipped part's convex hull needs only the first and last clipped point of every lattice row (the rest of a row
     // lies between them): a thread per row finds them while thread 0 adds up the partial sums
     if (tid >= 64 && tid < 64 + ny_) {
@@ -1256,14 +1373,15 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     if (tid == 0) s_fit[3] = fmin(1.0, s_fit[0] / __longlong_as_double((long long)s_bestA));
     __syncthreads();
   };
-  fit(s_c[0], s_c[1], 5.5, 2.5);
+  fit(std::integral_constant<int, 55>{}, std::integral_constant<int, 25>{}, s_c[0], s_c[1], 5.5, 2.5);
+  ++fitno;
 #if FO_RULE_TRACE != 2
   RL_TICK(5);
 #endif
   if (!s_fitany) return;
   const double car_a = s_fit[0], car_x = s_fit[1], car_y = s_fit[2], car_j = s_fit[3];
   __syncthreads();
-  fit(car_x, car_y, 2.0, 1.0);
+  fit(std::integral_constant<int, 20>{}, std::integral_constant<int, 10>{}, car_x, car_y, 2.0, 1.0);
 #if FO_RULE_TRACE != 2
   RL_TICK(6);
 #endif

@@ -76,7 +76,11 @@ for step in (0, 8, 25, 60):
                                       (5, "intersection found"), (6, "relevance flags set"), (7, "decisions taken")):
                         if dyn3.any():
                             print("      set-up, %-34s %.1f .. %.1f" % (name + ":", (w[dyn3, col].min() - k0) * 0.01, (w[dyn3, col].max() - k0) * 0.01))
-                dyn = (w[:, 5] > 0) & (os.environ["FO_RULE_TRACE"] != "3")         # workgroups of the dynamic rule's lattice: tables staged | set-up barrier | nodes done | ticket taken
+                if os.environ["FO_RULE_TRACE"] == "4":      # thread 0 inside the first fit (trace build -DFO_RULE_TRACE=4), from the phase stamp in front of the fits
+                    r = int(np.argmax(w[:, 7]))
+                    print("      first fit, thread 0's first point (us from the centroid phase's end): point computed %.2f, lattice label + hint read %.2f, distances passed %.2f, "
+                          "shadow / class passed %.2f, polygons asked + flag stored %.2f, summed %.2f" % tuple((w[r, 2:8] - h[4]) * 0.01))
+                dyn = (w[:, 5] > 0) & (os.environ["FO_RULE_TRACE"] not in ("3", "4"))         # workgroups of the dynamic rule's lattice: tables staged | set-up barrier | nodes done | ticket taken
                 if dyn.any():
                     for col, name in ((2, "decisions + offsets"), (3, "polygons staged"), (4, "nodes decided"), (5, "ticket taken")):
                         print("      lattice workgroups, %-20s %.1f .. %.1f" % (name + ":", (w[dyn, col].min() - k0) * 0.01, (w[dyn, col].max() - k0) * 0.01))
