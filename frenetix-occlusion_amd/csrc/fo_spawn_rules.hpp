@@ -68,9 +68,6 @@ constexpr int RL_MAXSAMP = 1024;                   // samples of a rule polyline
 constexpr int RL_REC = 24;                         // doubles per per-workgroup record
 constexpr int RL_PATHV = 512;                      // vertices of the reference path table held in LDS (longer paths: read from HBM)
 constexpr int RL_PARTS = 16;                       // workgroups that share a dynamic obstacle's candidate lattice
-#ifndef FO_EXP
-#define FO_EXP 0
-#endif
 constexpr int RL_PVERT = 1024;                     // vertices of a dynamic obstacle's <= 8 candidate lanelet polygons held in LDS
 
 enum { RL_TYPE_CAR = 0, RL_TYPE_BICYCLE = 3, RL_TYPE_PED = 4 };
@@ -795,11 +792,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
     // minus the obstacle grown by 1 m: sqrt(e2) > 1 exactly when e2 > 1 + 2^-52 (sqrt(1 + 2^-52) = 1 + 2^-53 - ... rounds to 1)
     if (!(ex_ * ex_ + ey_ * ey_ > 1.0000000000000002)) return 0;
     RL_FTICK(4);
-#if FO_EXP == 2
-    if (false) {
-#else
     if (wedge) {   // the obstacle's own shadow: the sight line ego -> point crosses the rectangle (:264)
-#endif
       bool hit = false;
       const double dx = x - pr.ego_x, dy = y - pr.ego_y;
       for (int i = 0; i < 4 && !hit; ++i) {
@@ -814,15 +807,9 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
         }
       }
       if (!hit) return 0;
-    }
-#if FO_EXP != 2
-    else if (!(rl_class_at(v, x, y) & 4)) {   // the global occluded area (:272)
+    } else if (!(rl_class_at(v, x, y) & 4)) {   // the global occluded area (:272)
       return 0;
     }
-#endif
-#if FO_EXP == 1
-    return hint + 1;
-#endif
     RL_FTICK(5);
     // possible_polygon (:255): the union of the candidate lanelet polygons -- any order of asking gives the same answer;
     // the polygon that held the nearest lattice node goes first (it holds most points around that node as well)
@@ -1264,11 +1251,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       ftr = tid < 64 && fitno == 0 && i < 64;
 #endif
       RL_FTICK(2);
-#if FO_EXP == 3
-      const bool ok = true;
-#else
       const bool ok = in_region(x, y);
-#endif
       fitok[i] = ok ? 1 : 0;
       RL_FTICK(6);
       if (ok) { ++cnt; fx += x; fy += y; }
