@@ -1,6 +1,9 @@
 """One-off robustness run on the GPU box: the spawn rule families on the device (fo_scene_spawn_rules) against their NumPy
 checker (oracle/fo_spawn_rules_ref.py) on random ego poses, reference paths (straight ahead / along the lanelet's centre
-line and its successors) and time steps of the three scenario fixtures.  usage: python tools/spawn_rules_fuzz.py [n] [seed]"""
+line and its successors) and time steps of the three scenario fixtures.  usage: python tools/spawn_rules_fuzz.py [n] [seed] [densify]
+densify = k > 1: every lanelet bound is subdivided into k pieces per segment (polygons of k times the vertices: at 4 the dynamic
+rule's candidate polygons hold hundreds of edges, its per-band edge lists run over many chunks; at 12 they no longer fit its
+1 024-vertex table in LDS and the rule reads them from HBM)."""
 import math
 import os
 import sys
@@ -20,6 +23,14 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
     scs = [S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", f"scenario{i}_geometry.npz")) for i in (1, 2, 3)]
+    dens = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    if dens > 1:
+        def sub(b):
+            t = np.arange(dens)[None, :, None] / dens
+            return np.concatenate(((b[:-1, None, :] + t * (b[1:, None, :] - b[:-1, None, :])).reshape(-1, 2), b[-1:]))
+        for sc in scs:
+            for l in sc.lanelets:
+                l.left, l.right = sub(l.left), sub(l.right)
     kinds, n_pts = {}, 0
     for it in range(n):
         si = int(rng.integers(3))
