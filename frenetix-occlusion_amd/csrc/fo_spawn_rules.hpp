@@ -64,6 +64,8 @@ constexpr double RL_BUFFER_SIDE = 12.0;            // :70
 constexpr double RL_MIN_AREA = 10.0;               // :71
 constexpr double RL_AREA_CAR = 9.0, RL_AREA_BIKE = 1.7;   // :72
 constexpr int RL_LAT = 97;                         // nodes per side of the 0.25 m candidate lattice (2 x 12 m + 1)
+constexpr int RL_TURNW = 1536;                      // vertices of the reference window the turn rule holds (40 m of path; fo_scene_spawn_rules refuses more)
+constexpr int RL_FIFTHV = 512;                     // every-fifth-vertex queries of the window (dynamic rule outside an intersection)
 constexpr int RL_MAXSAMP = 1024;                   // samples of a rule polyline (cs/8 steps; 40 m at cs = 0.5 -> 641)
 constexpr int RL_REC = 24;                         // doubles per per-workgroup record
 constexpr int RL_PATHV = 512;                      // vertices of the reference path table held in LDS (longer paths: read from HBM)
@@ -438,7 +440,8 @@ __device__ __forceinline__ void rl_turn_rule(const RuleView &v, const RuleParams
   const int lane = threadIdx.x & 63;
   if (lane == 0) rec[0] = 0.0;
   const int nw = pr.win_i1 - pr.win_i0;
-  if (nw < 2 || nw > 256) return;
+  if (nw < 2) return;
+  if (nw > RL_TURNW) { if (lane == 0) rec[0] = -1.0; return; }   // (refused by the host entry already; -1: out of table space, see the selection kernel)
   const bool left = pr.intention == 1;
   // the line: the reference window, for a left turn shifted 3 m to the left (spawn_locator.py:510-518)
   bool ok = true;
@@ -458,8 +461,8 @@ __device__ __forceinline__ void rl_turn_rule(const RuleView &v, const RuleParams
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const double total = cum[nw - 1], step = v.cs / 8.0;
   if (!(total > 0.0)) return;
-  int ns = (int)ceil((total + 0.5 * step) / step);
-  if (ns > RL_MAXSAMP) ns = RL_MAXSAMP;
+  const int ns = (int)ceil((total + 0.5 * step) / step);
+  if (ns > RL_MAXSAMP) { if (lane == 0) rec[0] = -1.0; return; }   // a line longer than the sample table (cells below 0.32 m at a 40 m window)
   for (int i = lane; i < ns; i += 64) {
     double x, y;
     rl_sample(lx, ly, cum, nw, fmin((double)i * step, total), x, y);
@@ -530,8 +533,8 @@ __device__ __forceinline__ void rl_static_rule(const RuleView &v, const RulePara
     if (!rl_to_cart(v, s_line, d_min, ax, ay) || !rl_to_cart(v, s_line, d_max, bx, by)) continue;
     const double total = sqrt((bx - ax) * (bx - ax) + (by - ay) * (by - ay)), step = v.cs / 8.0;
     if (!(total > 0.0)) continue;
-    int ns = (int)ceil((total + 0.5 * step) / step);
-    if (ns > RL_MAXSAMP) ns = RL_MAXSAMP;
+    const int ns = (int)ceil((total + 0.5 * step) / step);
+    if (ns > RL_MAXSAMP) { if (lane == 0) rec[2 + 6 * li] = -1.0; continue; }       // (a cross line of > 64 m at 0.5 m cells: out of table space)
     const double b = pr.ped_length / 2.0 * 1.3;                                    // :414
     bool t_occ = false, t_vis = false;
     for (int i = lane; i < ns; i += 64) {
@@ -620,7 +623,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   const int tid = threadIdx.x, nth = blockDim.x;
   const double cx = ocen[2 * o], cy = ocen[2 * o + 1], oy = oyaw[o], olen = odims[2 * o], owid = odims[2 * o + 1];
   const double *oc = ocorn + 8 * (size_t)o;
-  __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn, s_ego_ll, s_inter, s_nin, s_in[16], s_vll[64], s_relc, s_curv_ok;
+  __shared__ int s_pol[8], s_npol, s_go, s_changed, s_best, s_bestn, s_ego_ll, s_inter, s_nin, s_in[16], s_vll[RL_FIFTHV], s_relc, s_curv_ok;
   __shared__ int s_poff[9], s_plds, s_inter_first, s_nhit, s_ecnt[1];
   __shared__ double s_c[2], s_yaw, s_pbox[32], s_obsd[2], s_oc[8];
   // relevant lanelets (:171-202): the other incomings / inner lanelets of the intersection the ego is in, else the
@@ -628,7 +631,12 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   // in ired[0, P): bit0 relevant, bit1 inner, bit2 holds the obstacle's centre.  Every "which lanelet holds this point" below is asked of all lanelets at
   // once, a thread per (point, lanelet) -- the first lanelet in list order by atomicMin -- instead of one thread walking
   // the polygon table in HBM
-  if (v.P > RL_LAT * RL_LAT) return;
+  // out of table space (-1 in the Car slot's validity word; every part of the obstacle decides the same and leaves before the
+  // hand-off): more lanelets than the flag array holds (refused by the host entry already), or more fifth vertices of the window
+  if (v.P > RL_LAT * RL_LAT || (pr.win_i1 - pr.win_i0 + 4) / 5 > RL_FIFTHV) {
+    if (part == 0 && tid == 0) { rec[2] = -1.0; rec[5] = 0.0; }
+    return;
+  }
   for (int p = tid; p < v.P; p += nth) ired[p] = 0;
   if (tid == 0) {
     rec[2] = 0.0; rec[5] = 0.0;
@@ -636,7 +644,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
   }
   if (tid == 0) s_ecnt[0] = 0;   // (edge_band's count, far below)
   if (tid >= 64 && tid < 72) s_oc[tid - 64] = oc[tid - 64];   // (the obstacle's corners for the shadow test: LDS instead of a load from HBM's caches per edge and point)
-  if (tid < 64) s_vll[tid] = 0x7fffffff;
+  if (tid < RL_FIFTHV) s_vll[tid] = 0x7fffffff;
   __syncthreads();
   RL_STICK(2);
   // (measured and dropped, round 6: the lanelets under every fifth vertex of the reference window -- needed when the ego turns
@@ -682,7 +690,7 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       atomicOr(&ired[p], (p != s_ego_ll ? 1 : 0) | (v.inter_kind[e] == 1 ? 2 : 0));
     }
   } else if (v.adj_left) {
-    const int nv = min((pr.win_i1 - pr.win_i0 + 4) / 5, 64);   // every fifth vertex of the reference window (40 m: a dozen)
+    const int nv = (pr.win_i1 - pr.win_i0 + 4) / 5;   // every fifth vertex of the reference window (40 m: a dozen; <= RL_FIFTHV, above)
     rl_which_lanelets(v, nv, [&](int q, double &x, double &y) { const double *w_ = v.path + 6 * (size_t)(pr.win_i0 + 5 * q); x = w_[0]; y = w_[1]; },
                       [](int, int) { return true; }, [&](int q, int p) { atomicMin(&s_vll[q], p); }, lab, 2048, &s_nhit);
     if (tid < nv) {
@@ -1409,7 +1417,8 @@ __global__ __launch_bounds__(RL_THREADS) void fo_spawn_rules_kernel(RuleView v, 
     for (int i = lane; i < RL_REC; i += 64) rec[i] = 0.0;
     if (pr.behind_turn && pr.intention != 0) {
       own_path(pathv);
-      double *lx = (double *)lab, *ly = lx + 256, *cum = ly + 256;
+      static_assert(3 * RL_TURNW * sizeof(double) <= sizeof(lab), "the turn rule's three window arrays borrow the lattice array");
+      double *lx = (double *)lab, *ly = lx + RL_TURNW, *cum = ly + RL_TURNW;
       rl_turn_rule(v, pr, rec, lx, ly, cum, bytes);
     }
     return;
@@ -1502,6 +1511,15 @@ __global__ void fo_spawn_rules_select_kernel(RuleView v, RuleParams pr, int O, c
   // (round 6, measured and dropped: the records and flags copied into LDS by the wave, the deciding thread reading them there
   // instead of in HBM -- the rules step does not move, same box, two passes: 0.0845 / 0.0831 against 0.0830 / 0.0850 ms)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // a rule that ran out of table space left -1 in its validity word: the step's list would be short of a point the reference
+  // finds, so there is NO list -- the count says -1 and the callers refuse it (fo_hip.h)
+  bool over = pr.behind_turn && pr.intention != 0 && recs[0] < 0.0;
+  for (int o = 0; o < O; ++o) {   // (no short cuts: the loads of all records go out together)
+    const double *r = recs + (size_t)(1 + o) * RL_REC;
+    const double role = r[1], v0 = r[2], v1 = r[8];
+    over = over | ((role == 2.0) & (v0 < 0.0)) | ((role == 1.0) & ((v0 < 0.0) | (v1 < 0.0)));
+  }
+  if (over) { *n_out = -1; return; }
   int n = 0;
   auto put = [&](double type, double x, double y, double yaw, double s, double d, double src, double ob) {
     if (n < max_out) {
@@ -1692,6 +1710,18 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
   if (!m->d_poly_off) return fo_fail(ctx, FO_E_STATE, "fo_scene_spawn_rules: the map holds no lanelet polygons");
   if (params->win_i0 < 0 || params->win_i1 > n_path || params->win_i1 < params->win_i0)
     return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: reference window [%d, %d) outside the path", params->win_i0, params->win_i1);
+  // table space the host can see (what only the device can -- a sampled line longer than RL_MAXSAMP cells / 8 -- comes back as
+  // *d_n_out = -1): a rule that ran short would leave out a point the reference finds, unnoticed
+  if (params->behind_turn && params->intention != 0 && params->win_i1 - params->win_i0 > RL_TURNW)
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: the reference window holds %d path vertices, the turn rule %d "
+                   "(thin the path out: the window is 40 m)", params->win_i1 - params->win_i0, RL_TURNW);
+  if (params->behind_dynamic && (params->intention == 0 || params->intention == 1)) {
+    if (m->P > RL_LAT * RL_LAT)
+      return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: %d lanelets, the dynamic-obstacle rule holds flags for %d", m->P, RL_LAT * RL_LAT);
+    if ((params->win_i1 - params->win_i0 + 4) / 5 > RL_FIFTHV)
+      return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: the reference window holds %d path vertices, the dynamic-obstacle rule "
+                     "asks every fifth of at most %d", params->win_i1 - params->win_i0, 5 * RL_FIFTHV);
+  }
   {
     // the select kernel compares the maxima BEFORE appending and a dynamic obstacle can yield two points (Q11): what the three
     // families can emit.  A smaller buffer would silently lose the last points in the reference's order (the turn rule's

@@ -113,6 +113,9 @@ class PhantomBatch:
             o3 = o2 + Rp * 64
             o4 = o3 + 8
             cnt = h[o3:o4].view(np.int32)
+            if Rp and int(cnt[1]) < 0:
+                raise RuntimeError("fo_scene_spawn_rules: a rule family ran out of table space at this step (a sampled line of more "
+                                   "than 1 024 cells / 8: include/fo_hip.h) -- there is no spawn-point list; use cells of >= 0.32 m")
             self._host = dict(n=int(cnt[0]) if self.n_cell_agents else 0, rule_n=min(int(cnt[1]), Rp) if Rp else 0,
                               pos0=h[:o1].view(np.float64).reshape(A, 2), yaw0=h[o1:o2].view(np.float64),
                               rule_points=h[o2:o3].view(np.float64).reshape(Rp, 8), type=h[o4:o4 + 4 * S_].view(np.int32))

@@ -29,7 +29,7 @@ def torch_cuda():
     return torch
 
 
-def _both(torch, lanelets, obstacles, path, ego, yaw, v, intersections=None, timestep=0, n_rays=720):
+def _both(torch, lanelets, obstacles, path, ego, yaw, v, intersections=None, timestep=0, n_rays=720, cell_size=0.5):
     """device rule points and checker rule points for one scene"""
     from frenetix_occlusion import scenario as S
     from frenetix_occlusion.sensor_model import SensorModel
@@ -39,7 +39,8 @@ def _both(torch, lanelets, obstacles, path, ego, yaw, v, intersections=None, tim
     from oracle.fo_spawn_rules_ref import CellView, SpawnRules
     obs = FOObstacles(obstacles)
     obs.update(timestep)
-    sm = SensorModel(lanelets, path, sensor_radius=50.0, sensor_angle=360.0, n_rays=n_rays, intersections=intersections)
+    sm = SensorModel(lanelets, path, sensor_radius=50.0, sensor_angle=360.0, n_rays=n_rays, intersections=intersections,
+                     cell_size=cell_size)
     sm.calc_visible_and_occluded_area(timestep, ego, yaw, obs)
     am = SimpleNamespace(scenario=SimpleNamespace(intersections=intersections or []))
     sl = SpawnLocator(am, path, CFG, sm, fo_obstacles=obs)
@@ -126,6 +127,34 @@ def test_pedestrian_behind_a_right_and_a_left_turn(torch_cuda):
     straight = np.stack((np.linspace(-30, 40, 141), np.full(141, -1.75)), -1)
     dev, ref, view = _both(torch_cuda, main + side, [], straight, ego, 0.0, 6.0)
     assert dev == [] and ref == []
+
+
+def test_table_space_of_the_rules_is_enough_or_refused(torch_cuda):
+    """A reference path sampled every 6 cm puts 640 vertices into the 40 m window (the turn rule held 256 until round 6 and left
+    silently: tools/spawn_rules_fuzz.py with subdivided lanelets found it); 1 900 vertices are refused by the entry point, and a
+    line of more samples than the rule's table (cells of 0.25 m: 1 281 over 40 m) comes back as a refused count, not as a
+    shorter list."""
+    from frenetix_occlusion import scenario as S
+    main = [_straight(S, 1, -40, 40, -3.5, 0.0), _straight(S, 2, -40, 40, 0.0, 3.5)]
+    ys = np.linspace(-3.5, -43.5, 41)
+    side = [S.Lanelet(3, np.stack((np.full(41, 13.5), ys), -1), np.stack((np.full(41, 10.0), ys), -1)),
+            S.Lanelet(4, np.stack((np.full(41, 17.0), ys), -1), np.stack((np.full(41, 13.5), ys), -1))]
+    ego = np.array([-5.0, -1.75])
+    ang = np.linspace(0, math.pi / 2, 30)
+    path = np.concatenate((np.stack((np.linspace(-30, 7.75, 76), np.full(76, -1.75)), -1),
+                           np.stack((7.75 + 4.0 * np.sin(ang), -5.75 + 4.0 * np.cos(ang)), -1)[1:],
+                           np.stack((np.full(60, 11.75), np.linspace(-6.25, -36.0, 60)), -1)))
+
+    def subdivided(k):
+        t = np.arange(k)[None, :, None] / k
+        return np.concatenate(((path[:-1, None, :] + t * (path[1:, None, :] - path[:-1, None, :])).reshape(-1, 2), path[-1:]))
+    dev, ref, view = _both(torch_cuda, main + side, [], subdivided(8), ego, 0.0, 6.0)
+    assert len(ref) == 1 and ref[0].source == "right turn"
+    _same(dev, ref, view)
+    with pytest.raises(RuntimeError, match="turn rule"):
+        _both(torch_cuda, main + side, [], subdivided(24), ego, 0.0, 6.0)
+    with pytest.raises(RuntimeError, match="table space"):
+        _both(torch_cuda, main + side, [], path, ego, 0.0, 6.0, cell_size=0.25)
 
 
 def test_car_and_bicycle_behind_an_oncoming_truck(torch_cuda):

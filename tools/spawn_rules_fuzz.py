@@ -64,7 +64,13 @@ def main():
                                       timestep=step, n_rays=360)
         except ValueError:          # ego outside the path's projection domain: nothing to compare
             continue
-        TG._same(dev, ref, view)
+        try:
+            TG._same(dev, ref, view)
+        except AssertionError:
+            print("MISMATCH at case", it, "scenario", si + 1, "step", step, "ego", ego.tolist(), "yaw", yaw, "v", v, flush=True)
+            print("  device :", [(p.agent_type, p.source, np.round(p.position, 6).tolist()) for p in dev])
+            print("  checker:", [(p.agent_type, p.source, np.round(p.position, 6).tolist()) for p in ref], flush=True)
+            raise
         n_pts += len(ref)
         for p in ref:
             kinds[p.source.split(" ")[0] + ":" + p.agent_type] = kinds.get(p.source.split(" ")[0] + ":" + p.agent_type, 0) + 1
