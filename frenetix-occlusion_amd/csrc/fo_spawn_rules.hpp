@@ -708,7 +708,9 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       // in any order and are sorted; MORE than sixteen (a centre on a pile of overlapping lanelets) would leave a subset that
       // depends on the arrival order -- and the sixteen workgroups of an obstacle must take identical decisions before their
       // hand-off ticket below -- so the first sixteen in list order are collected from the flags instead
+      // (and more than sixteen is more than the rule holds: the step's list is refused, below)
       int n_ob = min(s_nin, 16);
+      bool short_of_space = s_nin > 16;
       if (s_nin > 16) {
         n_ob = 0;
         for (int p = 0; p < v.P && n_ob < 16; ++p)
@@ -724,9 +726,17 @@ __device__ __forceinline__ void rl_dynamic_rule(const RuleView &v, const RulePar
       bool any_rel = false, all_inner = true;
       for (int i = 0; i < n_ob; ++i) {
         const int p = s_in[i];
-        if (ired[p] & 1) { any_rel = true; if (first_rel < 0) first_rel = p; if (s_npol < 7) s_pol[s_npol++] = p; }
+        if (ired[p] & 1) {
+          any_rel = true;
+          if (first_rel < 0) first_rel = p;
+          if (s_npol < 7) s_pol[s_npol++] = p; else short_of_space = true;
+        }
         if (!(ired[p] & 2)) all_inner = false;
       }
+      // more relevant lanelets under the obstacle's centre than candidate polygons are held (seven + the predecessor): out of
+      // table space, -1 in the Car slot's validity word (the selection kernel refuses the step's list).  Every part of the
+      // obstacle decides the same and writes the same -- whichever clears the word last at its own start writes it again here.
+      if (short_of_space) { rec[2] = -1.0; break; }
       if (!any_rel) break;                                                        // :222
       if (!s_curv_ok) break;
       if (s_obsd[0] < pr.ego_s + 3.0 || fabs(s_obsd[1]) > 15.0) break;            // :234
@@ -1715,6 +1725,8 @@ int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win
   if (params->behind_turn && params->intention != 0 && params->win_i1 - params->win_i0 > RL_TURNW)
     return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: the reference window holds %d path vertices, the turn rule %d "
                    "(thin the path out: the window is 40 m)", params->win_i1 - params->win_i0, RL_TURNW);
+  if (params->behind_static && params->max_static > 15)
+    return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: max_static = %d, the selection compares the pedestrians of at most 16 obstacles", params->max_static);
   if (params->behind_dynamic && (params->intention == 0 || params->intention == 1)) {
     if (m->P > RL_LAT * RL_LAT)
       return fo_fail(ctx, FO_E_ARG, "fo_scene_spawn_rules: %d lanelets, the dynamic-obstacle rule holds flags for %d", m->P, RL_LAT * RL_LAT);

@@ -305,9 +305,10 @@ typedef struct {
  * switched on: the reference compares its maxima before it appends, and one dynamic obstacle can yield a Car and a Bicycle
  * (spawn_locator.py:212,304-309,365) -- else FO_E_ARG (a short buffer would drop the last points unnoticed).
  * Table space: the turn rule holds a reference window of <= 1 536 path vertices, the dynamic-obstacle rule flags for <= 9 409
- * lanelets and every fifth of <= 2 560 window vertices -- beyond: FO_E_ARG; a line a rule samples (cell size / 8 apart: the
- * 40 m window, an obstacle's cross line) holds <= 1 024 samples, which only the device can tell -- beyond: *d_n_out = -1 and
- * no list (fo_scene_spawn_rule_agents and fo_step_run then add no rule agents; whoever reads the count must refuse it). */
+ * lanelets and every fifth of <= 2 560 window vertices, max_static <= 15 -- beyond: FO_E_ARG.  What only the device can tell: an
+ * obstacle's centre on more than sixteen lanelets or on more than seven relevant ones, a line a rule samples (cell size / 8
+ * apart: the 40 m window, an obstacle's cross line) of more than 1 024 samples -- then *d_n_out = -1 and there is no list
+ * (fo_scene_spawn_rule_agents and fo_step_run add no rule agents; whoever reads the count must refuse it). */
 int fo_scene_spawn_rules(fo_ctx *ctx, const uint8_t *d_cls, int win_ix0, int win_iy0, int win_nx, int win_ny, int n_path,
                          const double *d_path6, int O, const double *d_ocorn, const double *d_ocen, const double *d_oyaw,
                          const double *d_odims, const uint8_t *d_oflags, const uint8_t *d_obst_vis,
