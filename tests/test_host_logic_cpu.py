@@ -359,6 +359,29 @@ def test_lazy_spawn_points_behave_like_the_references_list():
         len(z)
 
 
+def test_a_refused_rule_point_count_raises_when_the_list_is_read():
+    """fo_scene_spawn_rules answers a rule family that ran out of table space with a count of -1 (include/fo_hip.h): the
+    host view of the step's head refuses it instead of handing out a shorter list"""
+    torch = pytest.importorskip("torch")
+    from frenetix_occlusion.spawn_locator import PhantomBatch
+    A, S_, Rp = 8, 24, 8
+    o1, o2 = A * 16, A * 24
+    o3 = o2 + Rp * 64
+    head = np.zeros(o3 + 8 + 4 * S_, np.uint8)
+
+    def batch(rule_n):
+        head[o3:o3 + 8].view(np.int32)[:] = (0, rule_n)
+        h = torch.from_numpy(head.copy())
+        return PhantomBatch(None, None, torch.zeros(A, 2, dtype=torch.float64), None, None, None, None, None, None, None,
+                            torch.zeros(S_, dtype=torch.int32), None, R=3, head=h, n_cell_agents=0, n_rule_points=Rp)
+    assert batch(3).host_head()["rule_n"] == 3 and batch(3).live_agents() == [0, 1, 2]
+    assert batch(99).host_head()["rule_n"] == Rp            # (a count beyond the buffer: what fits)
+    with pytest.raises(RuntimeError, match="table space"):
+        batch(-1).host_head()
+    with pytest.raises(RuntimeError, match="table space"):
+        batch(-1).live_agents()
+
+
 def test_lazy_result_dicts_never_leak_placeholders_through_dict_fast_paths():
     """The per-trajectory result is a dict SUBCLASS with lazily built values (metrics/metric.py); CPython copies a dict
     subclass through C shortcuts that bypass ``__getitem__`` unless ``__iter__`` is overridden.  Every way a planner may
