@@ -281,6 +281,41 @@ def test_fifty_seeded_random_cases_on_the_three_scenarios(torch_cuda):
     assert any(k.startswith(("left", "right")) for k in kinds), kinds
 
 
+@pytest.mark.parametrize("k", [4, 12])
+def test_seeded_random_cases_with_subdivided_lanelet_bounds(torch_cuda, k):
+    """the same kind of cases on maps whose lanelet bounds are subdivided k-fold (tools/spawn_rules_fuzz.py's third argument):
+    polygons of up to 550 vertices -- the dynamic rule's per-band edge lists run over many chunks at 4; at 12 the candidate
+    polygons no longer fit its LDS table (read from HBM), a centre-line reference path puts > 256 vertices into the 40 m window
+    (the turn rule's capacity until round 6) and the window's every-fifth-vertex query asks > 64 points"""
+    from frenetix_occlusion import scenario as S
+    scs = [S.load_geometry_npz(os.path.join(GOLDEN, f"scenario{i}_geometry.npz")) for i in (1, 2, 3)]
+    t = np.arange(k)[None, :, None] / k
+    sub = lambda b: np.concatenate(((b[:-1, None, :] + t * (b[1:, None, :] - b[:-1, None, :])).reshape(-1, 2), b[-1:]))
+    for sc in scs:
+        for ll in sc.lanelets:
+            ll.left, ll.right = sub(ll.left), sub(ll.right)
+    rng = np.random.default_rng(106)
+    done, n_pts, long_windows = 0, 0, 0
+    while done < 24:
+        si, sc, path, ego, yaw, step, v = _random_case(rng, scs)
+        if len(path) < 4:
+            continue
+        try:
+            dev, ref, view = _both(torch_cuda, sc.lanelets, sc.obstacles, path, ego, yaw, v, intersections=sc.intersections,
+                                   timestep=step, n_rays=360)
+        except ValueError:          # ego outside the path's projection domain: nothing to compare
+            continue
+        _same(dev, ref, view)
+        done += 1
+        n_pts += len(ref)
+        arc = np.concatenate(([0.0], np.cumsum(np.hypot(np.diff(path[:, 0]), np.diff(path[:, 1])))))
+        i0 = int(np.argmin(np.hypot(path[:, 0] - ego[0], path[:, 1] - ego[1])))
+        long_windows += int(np.searchsorted(arc, arc[i0] + 40.0) - i0 > 256)
+    assert n_pts > 0
+    if k == 12:
+        assert long_windows > 0      # (a path along subdivided centre lines: more window vertices than the turn rule used to hold)
+
+
 def test_urban_grid_rule_cases(torch_cuda):
     """the BASELINE configs[2] city grid (9 360 boundary pieces, 64 parked cars, ~600 lanelets): the rule families at the
     bench's ego pose and at poses along two streets -- pedestrians behind parked cars, device == checker"""
