@@ -1,6 +1,8 @@
 """One-off robustness run on the GPU box: the scene stage against the oracle (bit-exact ranges, hit ids, cell classes,
 occluded indices, visibility flags, spawn cells) at many random poses / fans / radii on the three scenario maps and
-the city grid.  Reuses the checker of tests/test_scene_gpu.py.  usage: python tools/scene_fuzz.py [n] [seed] [near]
+the city grid.  Reuses the checker of tests/test_scene_gpu.py.  usage: python tools/scene_fuzz.py [n] [seed] [near|far] [k]
+k > 1: the lanelet bounds of the three scenario maps subdivided k-fold (k times the boundary pieces: at 12 the maps no longer fit
+the one-wave shape of the ray / settle kernels).
 near: one to three extra obstacles of random size and heading 0.2-4 m from the ego (so close that the end of their occlusion
 polygons falls inside the sensor range) and a random shadow length -- the far-chord half-planes (16 arccos per obstacle, device
 libm against the host's) under the bit-exact comparison of the cell classes."""
@@ -26,6 +28,13 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     oracle.build()
     maps = [S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", f"scenario{k}_geometry.npz")) for k in (1, 2, 3)]
+    dens = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    if dens > 1:
+        t = np.arange(dens)[None, :, None] / dens
+        sub = lambda b: np.concatenate(((b[:-1, None, :] + t * (b[1:, None, :] - b[:-1, None, :])).reshape(-1, 2), b[-1:]))
+        for sc in maps:
+            for l in sc.lanelets:
+                l.left, l.right = sub(l.left), sub(l.right)
     maps.append(S.synthetic_urban_grid())
     tot = dict(n_exact=0, skipped=0, n_occ=0)
     for it in range(n):
