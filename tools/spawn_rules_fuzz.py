@@ -1,6 +1,6 @@
 """One-off robustness run on the GPU box: the spawn rule families on the device (fo_scene_spawn_rules) against their NumPy
 checker (oracle/fo_spawn_rules_ref.py) on random ego poses, reference paths (straight ahead / along the lanelet's centre
-line and its successors) and time steps of the three scenario fixtures.  usage: python tools/spawn_rules_fuzz.py [n] [seed] [densify]
+line and its successors) and time steps of the three scenario fixtures.  usage: python tools/spawn_rules_fuzz.py [n] [seed] [densify] [cell size]
 densify = k > 1: every lanelet bound is subdivided into k pieces per segment (polygons of k times the vertices: at 4 the dynamic
 rule's candidate polygons hold hundreds of edges, its per-band edge lists run over many chunks; at 12 they no longer fit its
 1 024-vertex table in LDS and the rule reads them from HBM)."""
@@ -24,6 +24,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
     scs = [S.load_geometry_npz(os.path.join(ROOT, "tests", "golden", f"scenario{i}_geometry.npz")) for i in (1, 2, 3)]
     dens = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    cell = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5    # (>= 0.32: the turn rule samples its 40 m window every cell / 8)
     if dens > 1:
         def sub(b):
             t = np.arange(dens)[None, :, None] / dens
@@ -61,7 +62,7 @@ def main():
         v = float(rng.uniform(2.0, 12.0))
         try:
             dev, ref, view = TG._both(torch, sc.lanelets, sc.obstacles, path, ego, yaw, v, intersections=sc.intersections,
-                                      timestep=step, n_rays=360)
+                                      timestep=step, n_rays=360, cell_size=cell)
         except ValueError:          # ego outside the path's projection domain: nothing to compare
             continue
         try:
