@@ -39,6 +39,13 @@ class SpawnPoint:
     orientation: Optional[float] = None
 
 
+def intention_from_curvature(k) -> int:
+    """``SpawnLocator._find_ego_intention`` (spawn_locator.py:729-741) behind its curvature call: 1 left turn if the largest
+    curvature of the window exceeds 0.10 1/m, else 2 right turn if the smallest is below -0.10, else 0 straight ahead
+    (pinned to the reference's own method: tests/golden/relevant_lanelets.npz)"""
+    return 1 if k.max() > 0.10 else 2 if k.min() < -0.10 else 0
+
+
 @dataclass
 class PhantomBatch:
     """device-resident phantom predictions, exactly the argument list of ``MetricSweep.set_agents``.
@@ -408,7 +415,7 @@ class SpawnLocator:
             key = (i0, i1)
             if getattr(self, "_intent_key", None) != key:
                 k = curvature(self.ref_path[i0:i1])
-                self._intent = 1 if k.max() > 0.10 else 2 if k.min() < -0.10 else 0
+                self._intent = intention_from_curvature(k)
                 self._intent_key = key
             intention = self._intent
         self.last_intention = ("straight ahead", "left turn", "right turn")[intention]

@@ -178,7 +178,11 @@ class SpawnRules:
     def ego_intention(reference):
         if len(reference) < 3:
             return "straight ahead"
-        k = curvature(reference)
+        return SpawnRules.intention_of(curvature(reference))
+
+    @staticmethod
+    def intention_of(k):
+        """the thresholds of spawn_locator.py:735-741 on a curvature array (pinned: tests/golden/relevant_lanelets.npz)"""
         if k.max() > 0.10:
             return "left turn"
         if k.min() < -0.10:

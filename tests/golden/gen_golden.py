@@ -1030,8 +1030,122 @@ def gen_be():
           "distinct decelerations", len(np.unique(np.round(d[d > 0], 6))), "range", float(d[d > 0].min()), float(d.max()))
 
 
+def gen_relevant_lanelets():
+    """The topology side of the dynamic-obstacle rule, from the reference's OWN SpawnLocator methods (spawn_locator.py, imported
+    unmodified; commonroad_dc / shapely / commonroad_route_planner as inert stubs -- none of them is touched on this path):
+    ``_find_relevant_intersection`` + ``_find_intersection_lanelets`` (:584-622: the first intersection in list order whose
+    incoming or successor lanelets hold the ego's lanelet), ``_find_lanelets_along_reference`` (:624-635: every fifth vertex of
+    the reference window, the first lanelet at each, no repeats) with ``_find_lanelet_by_position`` (:666-676) underneath,
+    composed as lines :186-202 compose them, and ``_find_nearest_index`` / ``_find_ego_intention`` (:729-750; the curvature
+    itself is commonroad_dc's and is an INPUT here).  The scenario side is duck-typed: random lanelet networks and
+    intersections, 'which lanelets hold this point' from a table.  Inputs and outputs only go to relevant_lanelets.npz."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class Dummy:
+        def __init__(self, *a, **kw):
+            pass
+    curv_box = {}
+    mod("commonroad_dc", geometry=mod("commonroad_dc.geometry", util=mod(
+        "commonroad_dc.geometry.util", compute_pathlength_from_polyline=lambda p: None,
+        compute_curvature_from_polyline=lambda ref: curv_box["k"])))
+    mp = mod("shapely.geometry.multipolygon", MultiPolygon=Dummy)
+    mod("shapely", geometry=mod("shapely.geometry", Polygon=Dummy, Point=Dummy, MultiPolygon=Dummy, LineString=Dummy, multipolygon=mp),
+        affinity=mod("shapely.affinity", rotate=Dummy, translate=Dummy), ops=mod("shapely.ops", unary_union=Dummy))
+    mod("commonroad_route_planner", utility=mod("commonroad_route_planner.utility", route=mod(
+        "commonroad_route_planner.utility.route", lanelet_orientation_at_position=Dummy)))
+    sys.path.insert(0, REF)
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    NS = types.SimpleNamespace
+    rng = np.random.default_rng(20240606)
+    cases = []
+    for c in range(80):
+        n = int(rng.integers(6, 40))
+        ids = [int(x) for x in rng.choice(np.arange(100, 400), size=n, replace=False)]
+        adj = {i: (int(rng.choice(ids)) if rng.random() < 0.6 else None) for i in ids}
+        lanelets = {i: NS(lanelet_id=i, adj_left=adj[i]) for i in ids}
+        inters = []
+        for _ in range(int(rng.integers(0, 4))):
+            incs = []
+            for _ in range(int(rng.integers(1, 5))):
+                pick = lambda hi: set(int(x) for x in rng.choice(ids, size=int(rng.integers(0, hi)), replace=False))
+                incs.append(NS(incoming_lanelets=pick(3) | {int(rng.choice(ids))}, successors_left=pick(3), successors_right=pick(3),
+                               successors_straight=pick(3)))
+            inters.append(NS(incomings=incs))
+        # the reference window: points with a table of the lanelets that hold each (none, one or two; the first one counts)
+        npts = int(rng.integers(3, 60))
+        pts = [np.array([float(k), float(c)]) for k in range(npts)]
+        at = {tuple(q): [int(x) for x in rng.choice(ids, size=int(rng.integers(0, 3)), replace=False)] for q in pts}
+        ego = np.array([-1.0, float(c)])
+        at[tuple(ego)] = [int(rng.choice(ids))] if rng.random() < 0.9 else []
+        if c % 4 == 0 and inters:   # the ego on an intersection's lanelet for sure
+            e0 = inters[int(rng.integers(len(inters)))].incomings[0]
+            at[tuple(ego)] = [sorted(e0.incoming_lanelets)[0]]
+        net = NS(intersections=inters, find_lanelet_by_id=lambda i: lanelets[i],
+                 find_lanelet_by_position=lambda plist: [list(at[tuple(np.asarray(plist[0], dtype=np.float64))])])
+        sl = object.__new__(SpawnLocator)
+        sl.scenario = NS(lanelet_network=net)
+        sl.ego_pos = ego
+        sl.reference = pts
+        ego_ll = sl._find_lanelet_by_position(sl.ego_pos)
+        if ego_ll is None:
+            found, rel, inner_ids = -1, [], []      # (the reference goes on to ego_lanelet.lanelet_id and raises: not a case)
+        else:
+            inter, inc, inner = sl._find_relevant_intersection(net.intersections, ego_ll)
+            if inter:                                # lines :186-198 of the rule, verbatim
+                import copy
+                relevant = copy.deepcopy(inc)
+                relevant.update(inner)
+                relevant.remove(ego_ll.lanelet_id)
+                found, rel, inner_ids = inters.index(inter), sorted(relevant), sorted(inner)
+            else:                                    # :199-202
+                along = sl._find_lanelets_along_reference(sl.reference, step=5)
+                found, rel, inner_ids = -1, [(-1 if l.adj_left is None else l.adj_left) for l in along], []
+        cases.append(dict(ids=ids, adj=[-1 if adj[i] is None else adj[i] for i in ids],
+                          inters=[[[sorted(e.incoming_lanelets), sorted(e.successors_left), sorted(e.successors_right),
+                                    sorted(e.successors_straight)] for e in it.incomings] for it in inters],
+                          at_pts=[at[tuple(q)] for q in pts], at_ego=at[tuple(ego)], found=found, rel=rel, inner=inner_ids))
+    # flat arrays (no pickles): every list of lists as values + offsets
+    out = {"n_cases": len(cases)}
+    for k, cs in enumerate(cases):
+        out[f"c{k}_ids"] = np.array(cs["ids"]); out[f"c{k}_adj"] = np.array(cs["adj"])
+        flat, meta = [], []          # meta rows: intersection, incoming element, kind (0 incoming 1 left 2 right 3 straight), count
+        for a, it in enumerate(cs["inters"]):
+            for b, el in enumerate(it):
+                for kind, lst in enumerate(el):
+                    meta.append((a, b, kind, len(lst))); flat.extend(lst)
+        out[f"c{k}_inter_meta"] = np.array(meta, dtype=np.int64).reshape(-1, 4); out[f"c{k}_inter_flat"] = np.array(flat, dtype=np.int64)
+        out[f"c{k}_n_inter"] = len(cs["inters"])
+        out[f"c{k}_at_off"] = np.cumsum([0] + [len(a) for a in cs["at_pts"]]); out[f"c{k}_at_flat"] = np.array([x for a in cs["at_pts"] for x in a], dtype=np.int64)
+        out[f"c{k}_at_ego"] = np.array(cs["at_ego"], dtype=np.int64)
+        out[f"c{k}_found"] = cs["found"]; out[f"c{k}_rel"] = np.array(cs["rel"], dtype=np.int64); out[f"c{k}_inner"] = np.array(cs["inner"], dtype=np.int64)
+    # nearest index and the intention thresholds
+    path_s = np.cumsum(np.concatenate(([0.0], rng.uniform(0.05, 1.5, 300))))
+    q_s = np.concatenate((rng.uniform(-5.0, path_s[-1] + 5.0, 200), 0.5 * (path_s[3:40] + path_s[4:41]), path_s[50:60]))   # incl. exact midpoints (ties) and vertices
+    out["path_s"] = path_s; out["query_s"] = q_s
+    out["nearest"] = np.array([int(SpawnLocator._find_nearest_index(path_s, q)) for q in q_s])
+    curvs, names = [], []
+    for _ in range(60):
+        k = rng.normal(0.0, float(rng.choice([0.02, 0.04, 0.08])), int(rng.integers(3, 30)))
+        if rng.random() < 0.3:
+            k[int(rng.integers(len(k)))] = float(rng.choice([0.10, -0.10, 0.1000001, -0.1000001]))   # on and next to the thresholds
+        curv_box["k"] = k
+        curvs.append(k); names.append(("straight ahead", "left turn", "right turn").index(SpawnLocator._find_ego_intention(None)))
+    out["curv_off"] = np.cumsum([0] + [len(k) for k in curvs]); out["curv_flat"] = np.concatenate(curvs); out["intention"] = np.array(names)
+    path = os.path.join(OUT, "relevant_lanelets.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "cases", len(cases), "with an intersection", sum(c["found"] >= 0 for c in cases),
+          "ego on no lanelet", sum(not c["at_ego"] for c in cases), "intentions", np.bincount(out["intention"]).tolist())
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "sampling":     # only the sampling-matrix fixture
+    if len(sys.argv) > 1 and sys.argv[1] == "relevant":     # only the relevant-lanelets fixture (own process: stub modules)
+        gen_relevant_lanelets()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sampling":     # only the sampling-matrix fixture
         gen_sampling_matrix()
     elif len(sys.argv) > 1 and sys.argv[1] == "be":         # only the brake-evaluation fixture (own process: it replaces a module)
         gen_be()

@@ -209,3 +209,59 @@ def test_dce_loop_matches_the_references_own_walk_over_the_time_steps(oracle):
     assert np.array_equal(ref["cost"][:, oracle.COST["wttc"]], g["ref_wttc"])
     td = g["ref_time_dce"]
     assert (g["ref_dce"] == 0).sum() > 50 and len(np.unique(td)) == 31 and (td > 0).sum() > 300
+
+
+def test_relevant_lanelets_nearest_index_and_intention_match_the_references_spawn_locator():
+    """tests/golden/relevant_lanelets.npz (gen_golden.py relevant): the reference's OWN ``SpawnLocator`` helpers under the
+    dynamic-obstacle rule -- first intersection in list order that holds the ego's lanelet, incoming + successor lanelets
+    without the ego's; without one: the left neighbours of the first lanelets under every fifth vertex of the window
+    (spawn_locator.py:186-202, 584-635, 666-676) --, ``_find_nearest_index`` (:744-750, ties included) and the thresholds of
+    ``_find_ego_intention`` (:729-741).  The rule checker (oracle/fo_spawn_rules_ref.py, what the device is compared with) and
+    the host's window / intention code reproduce all of it."""
+    import os
+    from types import SimpleNamespace as NS
+    from golden_util import GOLDEN
+    from frenetix_occlusion.spawn_locator import SpawnLocator, intention_from_curvature
+    from oracle.fo_spawn_rules_ref import SpawnRules
+    g = np.load(os.path.join(GOLDEN, "relevant_lanelets.npz"), allow_pickle=False)
+    n_inter_cases = 0
+    for c in range(int(g["n_cases"])):
+        ids, adj = g[f"c{c}_ids"].tolist(), g[f"c{c}_adj"].tolist()
+        lanelets = {i: NS(lanelet_id=i, adj_left=(None if a < 0 else a)) for i, a in zip(ids, adj)}
+        inters = [dict(incomings=[]) for _ in range(int(g[f"c{c}_n_inter"]))]
+        flat, pos = g[f"c{c}_inter_flat"].tolist(), 0
+        for a, b, kind, cnt in g[f"c{c}_inter_meta"].tolist():
+            inc = inters[a]["incomings"]
+            while len(inc) <= b:
+                inc.append(dict(incoming=[], left=[], right=[], straight=[]))
+            inc[b][("incoming", "left", "right", "straight")[kind]] = flat[pos:pos + cnt]
+            pos += cnt
+        off, at_flat = g[f"c{c}_at_off"].tolist(), g[f"c{c}_at_flat"].tolist()
+        pts = [np.array([float(k), float(c)]) for k in range(len(off) - 1)]
+        table = {tuple(q): at_flat[off[k]:off[k + 1]] for k, q in enumerate(pts)}
+        ego = np.array([-1.0, float(c)])
+        table[tuple(ego)] = g[f"c{c}_at_ego"].tolist()
+        r = object.__new__(SpawnRules)
+        r.intersections, r.reference, r.ego_pos = inters, pts, ego
+        r.lanelet_of = lambda xy: (lanelets[table[tuple(np.asarray(xy, dtype=np.float64))][0]]
+                                   if table[tuple(np.asarray(xy, dtype=np.float64))] else None)
+        it, rel, inner = r._relevant_lanelet_ids()
+        found, want_rel, want_inner = int(g[f"c{c}_found"]), g[f"c{c}_rel"].tolist(), g[f"c{c}_inner"].tolist()
+        assert (-1 if it is None else [id(x) for x in inters].index(id(it))) == found, c
+        if found >= 0:
+            n_inter_cases += 1
+            assert sorted(rel) == want_rel and sorted(inner) == want_inner, c
+        else:                                  # (the reference's list may name a neighbour twice and holds None for "no neighbour")
+            assert rel == set(want_rel) - {-1} and inner == set(), c
+    assert n_inter_cases >= 20
+    # the window's end points: np.argmin(|s - q|), the first of equally near vertices
+    sl = object.__new__(SpawnLocator)
+    sl._s_list = g["path_s"].tolist()
+    assert [sl._nearest_vertex(float(q)) for q in g["query_s"]] == g["nearest"].tolist()
+    # the intention thresholds
+    off, flat = g["curv_off"].tolist(), g["curv_flat"]
+    names = ("straight ahead", "left turn", "right turn")
+    for k in range(len(off) - 1):
+        kk = flat[off[k]:off[k + 1]]
+        assert intention_from_curvature(kk) == int(g["intention"][k]) and SpawnRules.intention_of(kk) == names[int(g["intention"][k])]
+    assert set(g["intention"].tolist()) == {0, 1, 2}
