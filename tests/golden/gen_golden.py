@@ -1136,8 +1136,41 @@ def gen_relevant_lanelets():
         curv_box["k"] = k
         curvs.append(k); names.append(("straight ahead", "left turn", "right turn").index(SpawnLocator._find_ego_intention(None)))
     out["curv_off"] = np.cumsum([0] + [len(k) for k in curvs]); out["curv_flat"] = np.concatenate(curvs); out["intention"] = np.array(names)
+    # find_spawn_points itself (:80-143) with the three rule methods replaced by recorders: s_threshold (:113), the reference
+    # window (:678-693), which rule runs under which intention and switch (:124-138), how their results are appended (:637-645)
+    len_box = {}
+    sys.modules["frenetix_occlusion.spawn_locator"].compute_pathlength_from_polyline = lambda p: len_box["s"]
+    rows, toks, tok_off = [], [], [0]
+    for c in range(80):
+        n = int(rng.integers(20, 240))
+        s_arr = np.cumsum(np.concatenate(([0.0], rng.uniform(0.2, 1.2, n - 1))))
+        len_box["s"] = s_arr
+        ego_s = float(rng.uniform(-2.0, s_arr[-1] + 2.0))
+        ego_v = float(rng.choice([rng.uniform(0.0, 15.0), 6.25, 6.2500001, 0.0]))
+        curv_box["k"] = rng.normal(0.0, float(rng.choice([0.02, 0.05, 0.09])), 12)
+        sw = [bool(x) for x in rng.random(3) < 0.75]
+        kind = [int(rng.integers(4)), int(rng.integers(4)), int(rng.integers(2))]
+        ret = lambda base, k_: None if k_ == 0 else [] if k_ == 1 else [base] if k_ == 2 else [base, None, base + 1]
+        calls = []
+        sl = object.__new__(SpawnLocator)
+        sl.spawn_points, sl.ref_path, sl.debug = [], np.stack((np.arange(n, dtype=np.float64), np.zeros(n)), -1), False
+        sl.s_threshold_time, sl.min_s_threshold = 4, 25
+        sl.spawn_point_behind_dynamic_obstacle, sl.spawn_point_behind_static_obstacle, sl.spawn_point_behind_turn = sw
+        sl._find_spawn_point_behind_dynamic_obstacle = lambda: (calls.append(0), ret(100, kind[0]))[1]
+        sl._find_spawn_point_behind_static_obstacle = lambda: (calls.append(1), ret(200, kind[1]))[1]
+        sl._find_spawn_point_behind_turn = lambda intention: (calls.append(2), None if kind[2] == 0 else 300)[1]
+        got = sl.find_spawn_points(np.array([0.0, 0.0]), 0.0, np.array([ego_s, 0.3]), ego_v)
+        i0 = int(sl.reference[0][0]) if len(sl.reference) else -1
+        inten = ("straight ahead", "left turn", "right turn").index(SpawnLocator._find_ego_intention(None))
+        rows.append([n, ego_s, ego_v, *[float(x) for x in sw], *[float(x) for x in kind], sl.s_threshold, i0, len(sl.reference), inten,
+                     float(0 in calls), float(1 in calls), float(2 in calls)])
+        out[f"o{c}_s"] = s_arr; out[f"o{c}_k"] = curv_box["k"]
+        toks.extend(int(t) for t in got); tok_off.append(len(toks))
+    out["orch"] = np.array(rows); out["orch_tokens"] = np.array(toks, dtype=np.int64); out["orch_tok_off"] = np.array(tok_off)
     path = os.path.join(OUT, "relevant_lanelets.npz")
     np.savez_compressed(path, **out)
+    print("orchestration cases", len(rows), "calls dyn / static / turn", [int(sum(r[-3 + q] for r in rows)) for q in range(3)],
+          "windows of fewer than three vertices", sum(r[11] < 3 for r in rows))
     print("wrote", path, "cases", len(cases), "with an intersection", sum(c["found"] >= 0 for c in cases),
           "ego on no lanelet", sum(not c["at_ego"] for c in cases), "intentions", np.bincount(out["intention"]).tolist())
 

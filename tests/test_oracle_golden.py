@@ -265,3 +265,61 @@ def test_relevant_lanelets_nearest_index_and_intention_match_the_references_spaw
         kk = flat[off[k]:off[k + 1]]
         assert intention_from_curvature(kk) == int(g["intention"][k]) and SpawnRules.intention_of(kk) == names[int(g["intention"][k])]
     assert set(g["intention"].tolist()) == {0, 1, 2}
+
+
+def test_find_spawn_points_orchestration_matches_the_references():
+    """the same fixture's second half: the reference's own ``find_spawn_points`` (spawn_locator.py:80-143) with its three rule
+    methods replaced by recorders -- ``s_threshold`` (:113, incl. 4 v = 25 exactly), the 40 m window's vertex range (:678-693),
+    which family runs under which intention and switch (:124-138) and in which order their points are appended (None results
+    and None entries dropped, :637-645).  The host's ``rule_params`` gives the same threshold, window and intention; the rule
+    checker's ``find`` calls the same families and returns the points in the same order."""
+    import os
+    from types import SimpleNamespace as NS
+    from golden_util import GOLDEN
+    import frenetix_occlusion.utils.curvilinear as CV
+    from frenetix_occlusion.spawn_locator import SpawnLocator
+    import oracle.fo_spawn_rules_ref as R
+    g = np.load(os.path.join(GOLDEN, "relevant_lanelets.npz"), allow_pickle=False)
+    rows, toks, off = g["orch"], g["orch_tokens"].tolist(), g["orch_tok_off"].tolist()
+    names = ("straight ahead", "left turn", "right turn")
+    n_turn = 0
+    keep_cv, keep_r = CV.curvature, R.curvature
+    try:
+        for c, row in enumerate(rows):
+            n, ego_s, ego_v = int(row[0]), float(row[1]), float(row[2])
+            sw, kind = [bool(x) for x in row[3:6]], [int(x) for x in row[6:9]]
+            s_thr, i0, n_ref, inten = float(row[9]), int(row[10]), int(row[11]), int(row[12])
+            called, want = [bool(x) for x in row[13:16]], toks[off[c]:off[c + 1]]
+            s_arr, k = g[f"o{c}_s"], g[f"o{c}_k"]
+            CV.curvature = R.curvature = lambda ref, k=k: k          # (commonroad_dc's curvature is an input of the fixture)
+            # host: threshold, window, intention
+            sl = object.__new__(SpawnLocator)
+            sl._rules_ready, sl._s_list, sl.ref_path = True, s_arr.tolist(), np.stack((np.arange(n, dtype=np.float64), np.zeros(n)), -1)
+            sl._rule_cfg = dict(ped_width=0.5, ped_length=0.3, behind_static=int(sw[1]), behind_turn=int(sw[2]), behind_dynamic=int(sw[0]),
+                                max_static=1, max_dynamic=1)
+            sl.sensor_model = NS()
+            p = sl.rule_params(np.zeros(2), 0.0, np.array([ego_s, 0.3]), ego_v)
+            assert p.s_threshold == s_thr, c
+            if n_ref > 0:
+                assert (p.win_i0, p.win_i1) == (i0, i0 + n_ref), c
+            else:
+                assert p.win_i1 <= p.win_i0, c
+            if n_ref >= 3:       # (fewer vertices: commonroad_dc's curvature raises in the reference; the host says straight ahead)
+                assert p.intention == inten and sl.last_intention == names[inten], c
+            # checker: which families run, what comes back in which order
+            r = object.__new__(R.SpawnRules)
+            r.behind_dynamic, r.behind_static, r.behind_turn = sw
+            r.ref_path, r.ref_s = sl.ref_path, s_arr
+            calls = []
+            ret = lambda base, k_: [] if k_ < 2 else [base] if k_ == 2 else [base, base + 1]
+            r.behind_dynamic_obstacle = lambda view: (calls.append(0), ret(100, kind[0]))[1]
+            r.behind_static_obstacle = lambda view: (calls.append(1), ret(200, kind[1]))[1]
+            r.behind_turn_point = lambda view, intention: (calls.append(2), None if kind[2] == 0 else 300)[1]
+            if n_ref >= 3:
+                got = r.find(None, np.zeros(2), np.array([ego_s, 0.3]), ego_v)
+                assert r.s_threshold == s_thr and r.last_intention == names[inten], c
+                assert [q in calls for q in range(3)] == called and got == want, c
+                n_turn += called[2]
+    finally:
+        CV.curvature, R.curvature = keep_cv, keep_r
+    assert n_turn >= 5
