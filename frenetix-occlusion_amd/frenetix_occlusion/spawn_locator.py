@@ -386,6 +386,14 @@ class SpawnLocator:
                               max_static=int(sl.get("max_static_spawn_points", 1)),
                               max_dynamic=int(sl.get("max_dynamic_spawn_points", 1)),
                               ped_width=float(ped["width"]), ped_length=float(ped["length"]))
+        # the turn rule samples its 40 m window every cell / 8 and holds 1 024 samples (include/fo_hip.h: a longer line comes back
+        # as a refused point count, which only whoever READS the step's list gets to see): say so once, up front
+        cs = float(getattr(sm, "cell_size", 0.5))
+        if self._rule_cfg["behind_turn"] and 40.0 / (cs / 8.0) + 2.0 > 1024.0:
+            import warnings
+            warnings.warn(f"SpawnLocator: cells of {cs} m -- the turn rule of the spawn locator samples the 40 m reference window "
+                          "every cell / 8 and holds 1 024 samples (cells >= 0.32 m); at a turn the step's spawn-point list will be "
+                          "refused (RuntimeError when it is read).  Use larger cells or spawn_points_behind_turn: False.")
         self._rules_ready = True
 
     def _nearest_vertex(self, s):

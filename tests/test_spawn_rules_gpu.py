@@ -153,8 +153,12 @@ def test_table_space_of_the_rules_is_enough_or_refused(torch_cuda):
     _same(dev, ref, view)
     with pytest.raises(RuntimeError, match="turn rule"):
         _both(torch_cuda, main + side, [], subdivided(24), ego, 0.0, 6.0)
-    with pytest.raises(RuntimeError, match="table space"):
-        _both(torch_cuda, main + side, [], path, ego, 0.0, 6.0, cell_size=0.25)
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        with pytest.raises(RuntimeError, match="table space"):
+            _both(torch_cuda, main + side, [], path, ego, 0.0, 6.0, cell_size=0.25)
+    assert any("0.32" in str(w.message) for w in rec)       # (and the locator said so when it was set up)
 
 
 def test_car_and_bicycle_behind_an_oncoming_truck(torch_cuda):
