@@ -1,0 +1,79 @@
+"""The division-free crossing test of the rule kernels (csrc/fo_spawn_rules.hpp, rl_left_of_crossing) against the quotient form it
+replaces, in NumPy float64 with the device's operation order (the translation unit is built with -ffp-contract=off: no fused
+multiply-adds).  The kernel decides ``x < xi + (y - yi) (xj - xi) / (yj - yi)`` by the sign of s = (x - xi) d - (y - yi)(xj - xi)
+against the sign of d = yj - yi whenever |s| > 2^-48 (|t2| + |m| + |d xi|), and by the quotient itself otherwise.  Claim (DESIGN
+section 5, the comment in the header): whenever the sign form decides, it decides like the quotient form -- checked here where
+it matters, on points a few units in the last place either side of the computed crossing.  CPU only."""
+import numpy as np
+
+
+def _quotient_form(x, y, xi, yi, xj, yj):
+    with np.errstate(all="ignore"):
+        return x < xi + ((y - yi) * (xj - xi)) / (yj - yi)
+
+
+def _sign_form(x, y, xi, yi, xj, yj):
+    """(decided, answer) per element -- the arithmetic of rl_left_of_crossing"""
+    d = yj - yi
+    m = (y - yi) * (xj - xi)
+    t2 = (x - xi) * d
+    s = t2 - m
+    decided = np.abs(s) > 2.0 ** -48 * (np.abs(t2) + np.abs(m) + np.abs(d * xi))
+    return decided, (s < 0.0) != (d < 0.0)
+
+
+def _edges(rng, n, scale):
+    xi, xj = rng.uniform(-scale, scale, n), rng.uniform(-scale, scale, n)
+    yi = rng.uniform(-scale, scale, n)
+    yj = yi + rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-6, np.log10(scale), n)      # short and long, steep and flat edges
+    lo, hi = np.minimum(yi, yj), np.maximum(yi, yj)
+    y = lo + rng.uniform(0.0, 1.0, n) * (hi - lo)
+    ok = (yi > y) != (yj > y)                                                               # the straddle condition of the caller
+    return tuple(a[ok] for a in (xi, yi, xj, yj, y))
+
+
+def test_sign_form_agrees_with_the_quotient_form_wherever_it_decides():
+    rng = np.random.default_rng(20240607)
+    undecided_near, n_near, n_far, undecided_far = 0, 0, 0, 0
+    for scale in (1.0, 50.0, 1e3, 1e5):
+        xi, yi, xj, yj, y = _edges(rng, 200_000, scale)
+        with np.errstate(all="ignore"):
+            xc = xi + ((y - yi) * (xj - xi)) / (yj - yi)
+        # (a) points within a few ulps of the computed crossing, both sides and on it
+        for k in range(-6, 7):
+            x = xc.copy()
+            for _ in range(abs(k)):
+                x = np.nextafter(x, np.inf if k > 0 else -np.inf)
+            want = _quotient_form(x, y, xi, yi, xj, yj)
+            dec, got = _sign_form(x, y, xi, yi, xj, yj)
+            assert np.array_equal(got[dec], want[dec]), (scale, k)
+            undecided_near += int((~dec).sum())
+            n_near += len(x)
+        # (b) points at a relative distance of 1e-15 ... 1e-9 from the crossing (where the sign form starts to decide)
+        for rel in (1e-15, 3e-15, 1e-14, 1e-13, 1e-12, 1e-9):
+            x = xc + rng.choice([-1.0, 1.0], len(xc)) * rel * (np.abs(xc) + np.abs(xi) + np.abs(xj - xi))
+            want = _quotient_form(x, y, xi, yi, xj, yj)
+            dec, got = _sign_form(x, y, xi, yi, xj, yj)
+            assert np.array_equal(got[dec], want[dec]), (scale, rel)
+        # (c) points anywhere: the sign form decides practically always (the quotient is the rare way)
+        x = rng.uniform(-scale, scale, len(xc))
+        want = _quotient_form(x, y, xi, yi, xj, yj)
+        dec, got = _sign_form(x, y, xi, yi, xj, yj)
+        assert np.array_equal(got[dec], want[dec]), scale
+        undecided_far += int((~dec).sum())
+        n_far += len(x)
+    assert undecided_near > 0.5 * n_near          # next to the crossing the quotient decides (the bound is not vacuous)
+    assert undecided_far < 1e-6 * n_far + 5       # elsewhere it is not needed
+
+
+def test_degenerate_inputs_take_the_quotient():
+    """NaN and infinite coordinates fail the comparison of the sign form (the kernel then evaluates the quotient as before); a
+    point ON a vertex row (y = yi: the product is an exact zero) is decided like the quotient form"""
+    nan, inf = np.nan, np.inf
+    for args in ((nan, 0.5, 0.0, 0.0, 1.0, 1.0), (0.2, 0.5, nan, 0.0, 1.0, 1.0), (inf, 0.5, 0.0, 0.0, 1.0, 1.0), (0.2, 0.5, 0.0, 0.0, inf, 1.0)):
+        dec, _ = _sign_form(*(np.array([a]) for a in args))
+        assert not dec[0], args
+    x = np.array([-1.0, 0.0, np.nextafter(0.0, 1.0), 1.0])
+    y, xi, yi, xj, yj = (np.full(4, v) for v in (0.0, 0.0, 0.0, 3.0, 2.0))      # y == yi, straddled since yj > y
+    dec, got = _sign_form(x, y, xi, yi, xj, yj)
+    assert np.array_equal(got[dec], _quotient_form(x, y, xi, yi, xj, yj)[dec]) and dec[0] and dec[3]
