@@ -77,3 +77,17 @@ def test_degenerate_inputs_take_the_quotient():
     y, xi, yi, xj, yj = (np.full(4, v) for v in (0.0, 0.0, 0.0, 3.0, 2.0))      # y == yi, straddled since yj > y
     dec, got = _sign_form(x, y, xi, yi, xj, yj)
     assert np.array_equal(got[dec], _quotient_form(x, y, xi, yi, xj, yj)[dec]) and dec[0] and dec[3]
+
+
+def test_square_root_free_distance_tests_are_exact():
+    """member_idx of the dynamic rule compares squared distances: ``sqrt(d2) <= 12`` as ``d2 <= 144`` and ``sqrt(e2) > 1`` as
+    ``e2 > 1 + 2^-52`` (correctly rounded square roots; the reference's comparisons are on the roots, spawn_locator.py:256-262)
+    -- exact for every double, checked on the two thousand neighbours of either threshold"""
+    d2 = np.full(2001, 144.0)
+    e2 = np.full(2001, 1.0)
+    for k in range(1, 1001):
+        d2[1000 + k], d2[1000 - k] = np.nextafter(d2[1000 + k - 1], np.inf), np.nextafter(d2[1000 - k + 1], -np.inf)
+        e2[1000 + k], e2[1000 - k] = np.nextafter(e2[1000 + k - 1], np.inf), np.nextafter(e2[1000 - k + 1], -np.inf)
+    assert np.array_equal(np.sqrt(d2) <= 12.0, d2 <= 144.0)
+    assert np.array_equal(np.sqrt(e2) > 1.0, e2 > 1.0000000000000002)
+    assert (np.sqrt(d2) <= 12.0).sum() == 1001 and (np.sqrt(e2) > 1.0).sum() == 999      # (1 + 2^-52 itself roots to 1)
