@@ -91,3 +91,23 @@ def test_square_root_free_distance_tests_are_exact():
     assert np.array_equal(np.sqrt(d2) <= 12.0, d2 <= 144.0)
     assert np.array_equal(np.sqrt(e2) > 1.0, e2 > 1.0000000000000002)
     assert (np.sqrt(d2) <= 12.0).sum() == 1001 and (np.sqrt(e2) > 1.0).sum() == 999      # (1 + 2^-52 itself roots to 1)
+
+
+def test_quotient_free_unit_interval_test_of_the_shadow_wedge():
+    """the dynamic rule's shadow test (sight line ego -> point against the obstacle's four sides, spawn_locator.py:264) asks
+    ``0 <= tn / den <= 1`` as sign agreement and |tn| <= |den|: a correctly rounded quotient is <= 1 exactly when |tn| <= |den|
+    and >= 0 exactly when the signs agree or tn = 0.  Checked on random pairs and on the neighbours of |tn| = |den| and of
+    tn = 0 (outside the underflow range: a quotient below 2^-1075 in magnitude rounds to a signed zero, which compares >= 0 --
+    the cross products of metre-scale coordinates are exact zeros or many orders above it)"""
+    rng = np.random.default_rng(5)
+    den = rng.normal(0.0, 1.0, 200_000) * 10.0 ** rng.uniform(-8, 8, 200_000)
+    den = den[np.abs(den) > 1e-14]                       # (the kernel's own guard, as in the reference)
+    n = len(den)
+    tn = np.concatenate((den * rng.uniform(-0.5, 1.5, n), den, -den, np.zeros(n), np.nextafter(den, np.inf), np.nextafter(den, -np.inf),
+                         np.copysign(5e-324 * 2.0 ** 60, den), -np.copysign(5e-324 * 2.0 ** 60, den) * (np.abs(den) < 1e3)))
+    dd = np.tile(den, 8)
+    with np.errstate(all="ignore"):
+        q = tn / dd
+    want = (q >= 0.0) & (q <= 1.0)
+    got = np.where(dd > 0.0, (tn >= 0.0) & (tn <= dd), (tn <= 0.0) & (tn >= dd))
+    assert np.array_equal(got, want)
