@@ -16,7 +16,11 @@ Rules restated: ego intention from the curvature of the next 40 m of the referen
 visible static obstacle (:323-476), pedestrian behind a turn (:481-578), Car / Bicycle behind a visible dynamic
 obstacle (:145-317; the candidate region is sampled on a 0.25 m lattice with exact lanelet / wedge / distance tests
 and the cell classes for "occluded", the rectangle fit on a 0.1 m lattice).
-PARITY UNPINNED (no GEOS here, no reference test): pinned by tests/test_spawn_rules.py.
+PARITY: the GEOMETRY is unpinned (no GEOS here, no reference test; known-answer scenes in tests/test_spawn_rules.py).  Pinned
+to the reference's own, unmodified SpawnLocator code (tests/golden/relevant_lanelets.npz, gen_golden.py relevant): find_spawn_points'
+orchestration -- s_threshold, the 40 m window, which family runs under which intention and switch, the order of the list -- the
+intention thresholds, the nearest-vertex rule with ties, and the dynamic rule's topology side (which intersection is the ego's,
+which lanelets are relevant with and without one).
 """
 import math
 from typing import List, Optional
